@@ -1,0 +1,210 @@
+"""bench.py -- canonicalize+invert throughput on BASELINE.json's headline config (224x224x3, C8).
+
+One "step" = one pass of the hot path over one batch that is already resident in HBM:
+    y   = canonicalizer(x)                      # crop+resize -> canonicalization network -> group pool/argmax
+                                                #   -> fused pad/rotate/crop (eqa_canon_transform_fwd)
+    out = canonicalizer.invert_canonicalization(f, induced_rep_type="scalar")     # eqa_invert_action_fwd
+with x, f : (B, 3, 224, 224) fp32 synthetic, and the canonicalization network = ESCNNEquivariantNetwork
+(out_channels=32, kernel_size=5, num_layers=3, C8) on a 96x96 crop+resize -- the reference's default
+(examples/images/classification/configs/canonicalization/group_equivariant.yaml).  The wrapped prediction
+network (ResNet-50) is NOT part of the measured path.  Ranks shard the batch; the forward path has no
+collective, so scaling is weak (per-GPU batch fixed).
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
+  roofline      HBM roofline of the dominant hand-written kernel (the canonicalizing transform),
+                from HIP events recorded inside the timed region;
+  group_action  transform+invert only (random group index), the figure the "% HBM roofline" target is about;
+  cpu_baseline  the CPU oracle (reference op order) on this host, bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
+H = W = 224
+C = 3
+BYTES_TRANSFORM = 2 * C * H * W * 4  # read + write per image, fp32: 1,204,224 B
+
+
+def build_canonicalizer(device):
+    import equiadapt_amd as ea
+
+    torch.manual_seed(2)
+    net = ea.ESCNNEquivariantNetwork((3, 96, 96), out_channels=32, kernel_size=5, group_type="rotation",
+                                     num_rotations=8, num_layers=3)
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=96)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (C, H, W))
+    return can.to(device).eval()
+
+
+def cpu_baseline(sample: int, reps: int):
+    """The oracle (reference op order, torch CPU ops) on the host cores: same workload, bounded sample."""
+    from oracle import image_ops as io
+    from oracle import nets as onets
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    can = build_canonicalizer("cpu")
+    sd = {k: v for k, v in can.canonicalization_network.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(sample, C, H, W, generator=g)
+    f = torch.randn(sample, C, H, W, generator=torch.Generator().manual_seed(3))
+
+    def step():
+        xin = io.pre_canonicalization_transform(x, (C, H, W), 0.8, 96)
+        acts = onets.escnn_like_network(xin, sd, "rotation", 8, 3, 32)
+        el = io.group_element_from_activations(acts, 8, "rotation", 1.0, training=False)
+        y = io.canonicalize_images(x, el["rotation"], None, (C, H, W))
+        out = io.invert_action(f, el["rotation"], None, 8, 8, "scalar")
+        return y, out
+
+    with torch.no_grad():
+        step()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            step()
+            ts.append(time.perf_counter() - t0)
+        # transform+invert alone (the part the GPU kernels replace one-for-one)
+        rot = io.group_angles(8)[torch.randint(0, 8, (sample,), generator=torch.Generator().manual_seed(1))]
+        io.canonicalize_images(x, rot, None, (C, H, W))
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            io.canonicalize_images(x, rot, None, (C, H, W))
+            io.invert_action(f, rot, None, 8, 8, "scalar")
+        ga = (time.perf_counter() - t0) / reps
+    med = statistics.median(ts)
+    return {"value": sample / med, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{sample} images x {reps} reps of the same step (oracle/: pre-transform, conv stack, "
+                      f"argmax, pad+rotate+crop, invert) on torch-CPU, {torch.get_num_threads()} threads",
+            "group_action_only_images_s": sample / ga}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=32)
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    can = build_canonicalizer(dev)
+    B = args.batch
+    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)
+    f = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+
+    def step():
+        y = can(x)
+        out = can.invert_canonicalization(f, induced_rep_type="scalar")
+        return y, out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        with ops.KernelTimer() as kt:
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            elapsed = time.perf_counter() - t0
+        ktimes = kt.summary()
+
+        # group-action-only leg: the two resampling kernels back to back with a seeded random index
+        gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
+        th_c, fl_c = device_tables("canonicalize", 8, False, (2 * H, 2 * W), dev)
+        th_i, fl_i, _ = device_tables("invert", 8, False, (H, W), dev)
+        for _ in range(3):
+            ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
+            ops.invert_action(f, gidx, th_i, fl_i, None)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
+            ops.invert_action(f, gidx, th_i, fl_i, None)
+        e1.record()
+        torch.cuda.synchronize()
+        ga_ms = e0.elapsed_time(e1) / reps
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+
+    if rank == 0:
+        total_images = B * world * args.steps
+        n_ct, ms_ct = ktimes.get("canon_transform", (0, float("nan")))
+        n_iv, ms_iv = ktimes.get("invert_action", (0, float("nan")))
+        n_gp, ms_gp = ktimes.get("group_pool", (0, float("nan")))
+        ach = B * BYTES_TRANSFORM / (ms_ct * 1e-3) / 1e9
+        ga_bytes = 2 * B * BYTES_TRANSFORM
+        line = {
+            "metric": "canonicalize+invert images/sec (224x224 C8)",
+            "value": total_images / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 224x224x3 synthetic, C8, GroupEquivariantImageCanonicalization + "
+                                   "ESCNNEquivariantNetwork(32ch,k5,3 layers, crop 0.8, resize 96) forward, "
+                                   "then invert_canonicalization(scalar, 3ch); prediction network excluded",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective)"},
+            "roofline": {"bound": "hbm", "kernel": "group_action_kernel<3,true> via eqa_canon_transform_fwd",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None, "launches_timed": n_ct, "avg_launch_ms": ms_ct,
+                         "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
+            "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv, "group_pool": ms_gp},
+            "group_action": {"images_s_per_gpu": B / (ga_ms * 1e-3), "ms": ga_ms,
+                             "achieved_GBs": ga_bytes / (ga_ms * 1e-3) / 1e9,
+                             "frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "eqa_canon_transform_fwd + eqa_invert_action_fwd only, seeded random index"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,94 @@
+"""ctypes binding of libeqa_hip.so (C ABI: include/eqa_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or does not export a symbol,
+importing an op raises.  ``build()`` compiles it in-tree with hipcc for gfx950 (cross-compiles
+without a GPU); ``__graft_entry__.build()`` calls it.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libeqa_hip.so")
+SOURCES = [os.path.join(CSRC, "eqa_hip.hip")]
+INCLUDE = os.path.join(ROOT, "include")
+
+_c_f = ctypes.POINTER(ctypes.c_float)
+_c_i = ctypes.POINTER(ctypes.c_int32)
+_vp = ctypes.c_void_p
+_int = ctypes.c_int
+
+# name -> (restype, argtypes); must list every symbol include/eqa_hip.h declares (tests check this).
+SIGNATURES = {
+    "eqa_abi_version": (_int, []),
+    "eqa_set_option": (_int, [_int, _int]),
+    "eqa_canon_transform_fwd": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
+    "eqa_invert_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
+    "eqa_orbit_expand_fwd": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
+    "eqa_group_pool_workspace_bytes": (ctypes.c_int64, [_int] * 4),
+    "eqa_group_pool_argmax": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
+    "eqa_group_argmax": (_int, [_vp, _vp, _int, _int, _vp]),
+    "eqa_so3_rotate": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
+    "eqa_gram_schmidt": (_int, [_vp, _vp, _int, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class EqaLibraryError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/*.hip -> csrc/libeqa_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    newest_src = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "eqa_hip.h")])
+    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest_src:
+        return SO_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, *SOURCES, "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise EqaLibraryError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    return SO_PATH
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the library (once) and type every entry point.  Raises if it is absent: no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(SO_PATH):
+            raise EqaLibraryError(
+                f"{SO_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). equiadapt_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(SO_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            try:
+                fn = getattr(lib, name)
+            except AttributeError as exc:
+                raise EqaLibraryError(f"{SO_PATH} does not export {name}; rebuild it") from exc
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.eqa_abi_version() != 1:
+            raise EqaLibraryError("libeqa_hip.so ABI version mismatch; rebuild it")
+        _lib = lib
+    return _lib
+
+
+_ERRORS = {-1: "invalid argument", -2: "kernel launch failed", -3: "unsupported size/shape"}
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise EqaLibraryError(f"{what} failed: {_ERRORS.get(status, status)}")

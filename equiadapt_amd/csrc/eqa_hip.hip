@@ -1,0 +1,543 @@
+// libeqa_hip.so -- hand-written CDNA4 (gfx950, wave64) kernels for equiadapt's canonicalization hot path.
+// C ABI: include/eqa_hip.h.  Design notes: DESIGN.md.
+//
+// All kernels here are HBM-bound gathers / reductions / streams: the engineering is in coalesced
+// global access, LDS-staged source tiles for the rotated resampling, XCD-aware block->image mapping
+// (each XCD's private L2 sees whole images), and wave-level shuffles for the orientation reduction.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "eqa_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTile = 32;      // output tile edge (px): 256 threads x 4 px
+constexpr int kBox = 50;       // staged source window edge: 31*sqrt(2) + neighbour + guard < 50
+constexpr int kLdsStride = 51; // odd dword stride: the 8x4-lane gather pattern is bank-conflict-free at 0/90/180/270 deg
+constexpr int kXcd = 8;
+
+int g_force_direct = 0;
+
+struct ActionArgs {
+  const float* src;
+  float* dst;
+  const int32_t* gidx;
+  const float* theta;
+  const int32_t* flags;
+  const int32_t* chan_map;
+  int E, G, n_out, B, C;
+  int H, W, pad, Hp, Wp;
+  int OH, OW, top, left;
+  int tiles_x, tiles;
+  float half_w, half_h, step_x, step_y;
+  int force_direct;
+};
+
+// torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
+__device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
+  return idx < (steps >> 1) ? (-1.0f + step * (float)idx) : (1.0f - step * (float)(steps - 1 - idx));
+}
+
+struct Sampler {
+  float t0, t1, t2, t3, t4, t5;
+  float half_w, half_h, step_x, step_y;
+  int Hp, Wp, OW, top, left;
+  bool flip_dst;
+  // frame-pixel source location of output pixel (i, j): affine_grid + grid_sample(align_corners=True) unnormalise
+  __device__ __forceinline__ void operator()(int i, int j, float& ix, float& iy) const {
+    const int fj = left + j;
+    const int fx = flip_dst ? (Wp - 1 - fj) : fj;
+    const int fy = top + i;
+    const float xn = lin_m1_p1(fx, Wp, step_x);
+    const float yn = lin_m1_p1(fy, Hp, step_y);
+    const float gx = t0 * xn + t1 * yn + t2;
+    const float gy = t3 * xn + t4 * yn + t5;
+    ix = (gx + 1.0f) * half_w;
+    iy = (gy + 1.0f) * half_h;
+  }
+};
+
+// One block = one 32x32 output tile of one output image, all channels (CH at a time through LDS).
+// Thread t owns 4 consecutive pixels of row t/8 -> float4 stores, 128 B per 8 lanes.
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kThreads) void group_action_kernel(const ActionArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  // XCD-aware decode: blocks are dealt round-robin to the 8 XCDs, so give every XCD whole images --
+  // overlapping source windows of neighbouring tiles then hit in that XCD's L2 instead of re-reading HBM.
+  const int bid = blockIdx.x;
+  const int xcd = bid & (kXcd - 1);
+  const int slot = bid >> 3;
+  const int img_local = slot / a.tiles;
+  const int tile = slot - img_local * a.tiles;
+  const int n = img_local * kXcd + xcd;
+  if (n >= a.n_out) return;
+
+  int e, b;
+  if (a.gidx) {
+    e = a.gidx[n];
+    b = n;
+  } else {
+    e = n / a.B;
+    b = n - e * a.B;
+  }
+  e = min(max(e, 0), a.E - 1);
+  const int fl = a.flags ? a.flags[e] : 0;
+  const float* th = a.theta + e * 6;
+  Sampler S{th[0], th[1], th[2], th[3], th[4], th[5], a.half_w, a.half_h, a.step_x, a.step_y,
+            a.Hp,  a.Wp,  a.OW,  a.top, a.left, (fl & EQA_FLIP_DST) != 0};
+  const bool flip_src = (fl & EQA_FLIP_SRC) != 0;
+
+  const int ty = tile / a.tiles_x;
+  const int tx = tile - ty * a.tiles_x;
+  const int i0 = ty * kTile, j0 = tx * kTile;
+  const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
+
+  // source window of the tile: the map is affine, so its extremes are at the 4 corners.
+  float cx[4], cy[4];
+  S(i0, j0, cx[0], cy[0]);
+  S(i0, j1, cx[1], cy[1]);
+  S(i1, j0, cx[2], cy[2]);
+  S(i1, j1, cx[3], cy[3]);
+  float minx = fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3]));
+  float maxx = fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3]));
+  float miny = fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3]));
+  float maxy = fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3]));
+  // keep one ring of out-of-frame (zero) pixels at most; guard the floor against 1-ulp wobble
+  minx = fmaxf(minx - 1e-3f, -1.0f);
+  miny = fmaxf(miny - 1e-3f, -1.0f);
+  maxx = fminf(maxx + 1e-3f, (float)(a.Wp - 1));
+  maxy = fminf(maxy + 1e-3f, (float)(a.Hp - 1));
+  const int x_lo = (int)floorf(minx), y_lo = (int)floorf(miny);
+  // at least 2x2 so that the (clamped) neighbour reads of fully off-frame pixels stay inside staged data
+  const int x_hi = max((int)floorf(maxx) + 1, x_lo + 1), y_hi = max((int)floorf(maxy) + 1, y_lo + 1);
+  const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+  const bool use_lds = (bw <= kBox) && (bh <= kBox) && !a.force_direct;
+
+  // per-thread pixels
+  const int tid = threadIdx.x;
+  const int r = tid >> 3, q = tid & 7;
+  const int i = i0 + r, jb = j0 + 4 * q;
+  const bool row_ok = i < a.OH;
+
+  int lidx[4];         // LDS path: index of the north-west neighbour inside the staged window
+  int gx0[4], gy0[4];  // direct path: frame coords of the north-west neighbour
+  bool live[4];        // false: all four neighbours are off the frame -> exact zero (never multiply garbage)
+  float w00[4], w01[4], w10[4], w11[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float ix, iy;
+    S(i, jb + k, ix, iy);
+    const float xf = floorf(ix), yf = floorf(iy);
+    const float wx1 = ix - xf, wy1 = iy - yf;
+    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+    // neighbours entirely off the frame contribute zero (grid_sample padding_mode="zeros")
+    const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+    const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+    live[k] = xin && yin;
+    const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
+    gx0[k] = xi;
+    gy0[k] = yi;
+    const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
+    lidx[k] = ly * kLdsStride + lx;
+    w00[k] = wy0 * wx0;  // nw
+    w01[k] = wy0 * wx1;  // ne
+    w10[k] = wy1 * wx0;  // sw
+    w11[k] = wy1 * wx1;  // se
+  }
+
+  const size_t src_plane = (size_t)a.H * a.W;
+  const size_t dst_plane = (size_t)a.OH * a.OW;
+  const int32_t* cmap = a.chan_map ? a.chan_map + e * a.G : nullptr;
+  const float inv_bw = 1.0f / (float)bw;
+  const int box_elems = bh * bw;
+
+  // frame pixel -> source value (edge-replicated pad, optional pre-flip, zero outside the frame)
+  auto src_offset = [&](int fy, int fx, bool& inside) -> int {
+    inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
+    int sx = flip_src ? (a.Wp - 1 - fx) : fx;
+    sx = min(max(sx - a.pad, 0), a.W - 1);
+    const int sy = min(max(fy - a.pad, 0), a.H - 1);
+    return sy * a.W + sx;
+  };
+
+  for (int c0 = 0; c0 < a.C; c0 += CH) {
+    const float* planes[CH];
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      const int c = min(c0 + cc, a.C - 1);
+      const int cs = cmap ? (c / a.G) * a.G + cmap[c % a.G] : c;
+      planes[cc] = a.src + ((size_t)b * a.C + cs) * src_plane;
+    }
+    float acc[CH][4];
+    if (use_lds) {
+      __syncthreads();  // previous stage's gathers are done with the window
+      for (int idx = tid; idx < box_elems; idx += kThreads) {
+        const int y = (int)(((float)idx + 0.5f) * inv_bw);
+        const int x = idx - y * bw;
+        bool inside;
+        const int off = src_offset(y_lo + y, x_lo + x, inside);
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+          const float v = inside ? planes[cc][off] : 0.0f;
+          smem[cc * (kBox * kLdsStride) + y * kLdsStride + x] = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const float* s = smem + cc * (kBox * kLdsStride);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
+          const float sw = s[lidx[k] + kLdsStride], se = s[lidx[k] + kLdsStride + 1];
+          const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
+          acc[cc][k] = live[k] ? v : 0.0f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          bool in00, in01, in10, in11;
+          const int o00 = src_offset(gy0[k], gx0[k], in00), o01 = src_offset(gy0[k], gx0[k] + 1, in01);
+          const int o10 = src_offset(gy0[k] + 1, gx0[k], in10), o11 = src_offset(gy0[k] + 1, gx0[k] + 1, in11);
+          const float nw = in00 ? planes[cc][o00] : 0.0f, ne = in01 ? planes[cc][o01] : 0.0f;
+          const float sw = in10 ? planes[cc][o10] : 0.0f, se = in11 ? planes[cc][o11] : 0.0f;
+          const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
+          acc[cc][k] = live[k] ? v : 0.0f;
+        }
+      }
+    }
+    if (row_ok) {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        if (c0 + cc < a.C) {
+          float* o = a.dst + ((size_t)n * a.C + (c0 + cc)) * dst_plane + (size_t)i * a.OW + jb;
+          if (VEC && jb + 3 < a.OW) {
+            *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (jb + k < a.OW) o[k] = acc[cc][k];
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int CH>
+int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
+  const int imgs_per_xcd = (a.n_out + kXcd - 1) / kXcd;
+  const long long nblocks = (long long)kXcd * imgs_per_xcd * a.tiles;
+  if (nblocks <= 0 || nblocks > 0x7fffffffLL) return EQA_ERR_INVALID_ARG;
+  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float);
+  if (vec)
+    hipLaunchKernelGGL((group_action_kernel<CH, true>), dim3((unsigned)nblocks), dim3(kThreads), lds, st, a);
+  else
+    hipLaunchKernelGGL((group_action_kernel<CH, false>), dim3((unsigned)nblocks), dim3(kThreads), lds, st, a);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                  const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
+                  int OW, int top, int left, void* stream) {
+  if (!src || !dst || !theta || E <= 0 || n_out < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 ||
+      OH <= 0 || OW <= 0 || top < 0 || left < 0)
+    return EQA_ERR_INVALID_ARG;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  if (Hp < 2 || Wp < 2 || top + OH > Hp || left + OW > Wp) return EQA_ERR_INVALID_ARG;
+  if (chan_map && (G <= 0 || C % G != 0)) return EQA_ERR_INVALID_ARG;
+  if ((long long)H * W > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
+  if (n_out == 0) return EQA_OK;
+  ActionArgs a;
+  a.src = src; a.dst = dst; a.gidx = gidx; a.theta = theta; a.flags = flags; a.chan_map = chan_map;
+  a.E = E; a.G = chan_map ? G : 1; a.n_out = n_out; a.B = B; a.C = C;
+  a.H = H; a.W = W; a.pad = pad; a.Hp = Hp; a.Wp = Wp;
+  a.OH = OH; a.OW = OW; a.top = top; a.left = left;
+  a.tiles_x = (OW + kTile - 1) / kTile;
+  a.tiles = a.tiles_x * ((OH + kTile - 1) / kTile);
+  a.half_w = (float)(Wp - 1) / 2.0f;
+  a.half_h = (float)(Hp - 1) / 2.0f;
+  a.step_x = 2.0f / (float)(Wp - 1);
+  a.step_y = 2.0f / (float)(Hp - 1);
+  a.force_direct = g_force_direct;
+  const bool vec = (OW % 4 == 0) && (((uintptr_t)dst & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 3 == 0) return launch_action_ch<3>(a, vec, st);
+  if (C % 2 == 0) return launch_action_ch<2>(a, vec, st);
+  return launch_action_ch<1>(a, vec, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// I3 + I4: group pooling (mean over channels and space per group slot) and orientation argmax
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kPoolSplitTarget = 2048;  // blocks wanted in flight for the streaming pass
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// grid (splits, B).  Block (b, s) streams channels [s*cps, (s+1)*cps) of image b: each wave takes whole
+// (channel, group) planes of HW contiguous floats with float4 loads, reduces them with shuffles and
+// adds the plane sum to its own per-group accumulator in LDS (fp64: the cross-plane sum is the long one).
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void group_pool_partial_kernel(const float* __restrict__ feat,
+                                                                     double* __restrict__ partial, int Cf, int G,
+                                                                     int HW, int cps, int splits) {
+  extern __shared__ __attribute__((aligned(16))) double acc[];  // [4 waves][G]
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 4 * G; k += kThreads) acc[k] = 0.0;
+  __syncthreads();
+  const int c_lo = s * cps, c_hi = min(c_lo + cps, Cf);
+  const int planes = (c_hi - c_lo) * G;
+  const float* base = feat + ((size_t)b * Cf + c_lo) * G * HW;
+  for (int p = wave; p < planes; p += 4) {
+    const float* pl = base + (size_t)p * HW;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (VEC) {
+      const float4* p4 = reinterpret_cast<const float4*>(pl);
+      const int n4 = HW >> 2;
+      for (int k = lane; k < n4; k += 64) {
+        const float4 t = p4[k];
+        v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
+      }
+    } else {
+      for (int k = lane; k < HW; k += 64) v0 += pl[k];
+    }
+    const float tot = wave_sum((v0 + v1) + (v2 + v3));
+    if (lane == 0) acc[wave * G + (p % G)] += (double)tot;
+  }
+  __syncthreads();
+  if (tid < G) partial[((size_t)b * splits + s) * G + tid] = (acc[tid] + acc[G + tid]) + (acc[2 * G + tid] + acc[3 * G + tid]);
+}
+
+// one wave per image: lanes g < G own one orientation each; argmax by butterfly shuffles with
+// (value, index) pairs, smaller index winning ties == torch.argmax's first-maximum rule.
+__device__ __forceinline__ void wave_argmax_store(float v, int g, int G, int32_t* out) {
+  int idx = (g < G) ? g : 0x7fffffff;
+  float val = (g < G) ? v : -INFINITY;
+  // NaN handling as torch: a NaN is "greater" than everything; first NaN wins.
+  bool isn = (g < G) && (v != v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(val, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    const bool on = __shfl_xor((int)isn, o, 64) != 0;
+    bool take;
+    if (on != isn) take = on;
+    else if (on) take = oi < idx;
+    else take = (ov > val) || (ov == val && oi < idx);
+    if (take) { val = ov; idx = oi; isn = on; }
+  }
+  if (g == 0) *out = idx;
+}
+
+__global__ __launch_bounds__(kThreads) void group_pool_finalize_kernel(const double* __restrict__ partial,
+                                                                      float* __restrict__ act,
+                                                                      int32_t* __restrict__ gidx, int B, int G,
+                                                                      int splits, double inv_count) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  for (int g0 = 0; g0 < G; g0 += 64) {  // G <= 64 in every supported group; loop keeps it general for act
+    const int g = g0 + lane;
+    float a = 0.f;
+    if (g < G) {
+      double sum = 0.0;
+      for (int s = 0; s < splits; ++s) sum += partial[((size_t)b * splits + s) * G + g];
+      a = (float)(sum * inv_count);
+      act[(size_t)b * G + g] = a;
+    }
+    if (G <= 64 && gidx) wave_argmax_store(a, g, G, gidx + b);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void group_argmax_kernel(const float* __restrict__ act, int32_t* __restrict__ gidx,
+                                                               int B, int G) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float a = lane < G ? act[(size_t)b * G + lane] : 0.f;
+  wave_argmax_store(a, lane, G, gidx + b);
+}
+
+int pool_splits(int B, int Cf) {
+  int s = (kPoolSplitTarget + B - 1) / B;
+  if (s > Cf) s = Cf;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P4 / P3: SO(3) action on point clouds, batched Gram-Schmidt
+// ------------------------------------------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void so3_rotate_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                             float* __restrict__ y, int N, int transpose) {
+  const int b = blockIdx.y;
+  const float* Rb = R + (size_t)b * 9;
+  float m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = transpose ? Rb[(k % 3) * 3 + k / 3] : Rb[k];
+  const float* xb = x + (size_t)b * 3 * N;
+  float* yb = y + (size_t)b * 3 * N;
+  if (VEC) {
+    const int n4 = N >> 2;
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= n4) return;
+    const float4 p0 = reinterpret_cast<const float4*>(xb)[k];
+    const float4 p1 = reinterpret_cast<const float4*>(xb + N)[k];
+    const float4 p2 = reinterpret_cast<const float4*>(xb + 2 * (size_t)N)[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      // same accumulation order as a k-ordered dot product: (m0*x0 + m1*x1) + m2*x2
+      float4 o;
+      o.x = m[r * 3] * p0.x + m[r * 3 + 1] * p1.x + m[r * 3 + 2] * p2.x;
+      o.y = m[r * 3] * p0.y + m[r * 3 + 1] * p1.y + m[r * 3 + 2] * p2.y;
+      o.z = m[r * 3] * p0.z + m[r * 3 + 1] * p1.z + m[r * 3 + 2] * p2.z;
+      o.w = m[r * 3] * p0.w + m[r * 3 + 1] * p1.w + m[r * 3 + 2] * p2.w;
+      reinterpret_cast<float4*>(yb + (size_t)r * N)[k] = o;
+    }
+  } else {
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= N) return;
+    const float p0 = xb[k], p1 = xb[N + k], p2 = xb[2 * (size_t)N + k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) yb[(size_t)r * N + k] = m[r * 3] * p0 + m[r * 3 + 1] * p1 + m[r * 3 + 2] * p2;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* p = v + (size_t)b * 9;
+  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  // e1 = a / |a|   (torch.norm: sqrt of the sum of squares; division, not rsqrt, to stay on the reference's rounding)
+  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  a0 /= n; a1 /= n; a2 /= n;
+  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
+  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  b0 /= n; b1 /= n; b2 /= n;
+  const float d1 = c0 * a0 + c1 * a1 + c2 * a2;
+  const float d2 = c0 * b0 + c1 * b1 + c2 * b2;  // classical GS: both projections use the ORIGINAL c
+  c0 = c0 - d1 * a0 - d2 * b0;
+  c1 = c1 - d1 * a1 - d2 * b1;
+  c2 = c2 - d1 * a2 - d2 * b2;
+  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  c0 /= n; c1 /= n; c2 /= n;
+  float* o = out + (size_t)b * 9;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+}
+
+inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int eqa_abi_version(void) { return 1; }
+
+int eqa_set_option(int key, int value) {
+  if (key == 0) {
+    g_force_direct = value ? 1 : 0;
+    return EQA_OK;
+  }
+  return EQA_ERR_INVALID_ARG;
+}
+
+int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                         const int32_t* chan_map, int num_elements, int G, int n_out, int B, int C, int H, int W,
+                         int pad, int OH, int OW, int top, int left, void* stream) {
+  return launch_action(src, dst, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad, OH, OW, top,
+                       left, stream);
+}
+
+int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const float* theta, const int32_t* flags,
+                            int num_elements, int B, int C, int H, int W, int pad, void* stream) {
+  if (!gidx) return EQA_ERR_INVALID_ARG;
+  // CenterCrop offset of torchvision: int(round((Hp - H) / 2)) == pad exactly, since Hp - H = 2*pad
+  return launch_action(x, y, gidx, theta, flags, nullptr, num_elements, 1, B, B, C, H, W, pad, H, W, pad, pad, stream);
+}
+
+int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const float* theta, const int32_t* flags,
+                          const int32_t* chan_map, int num_elements, int G, int B, int C, int H, int W, void* stream) {
+  if (!gidx) return EQA_ERR_INVALID_ARG;
+  return launch_action(f, out, gidx, theta, flags, chan_map, num_elements, G, B, B, C, H, W, 0, H, W, 0, 0, stream);
+}
+
+int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int32_t* flags, int num_elements, int B,
+                         int C, int S, int pad, void* stream) {
+  if (num_elements <= 0 || B <= 0) return EQA_ERR_INVALID_ARG;
+  if ((long long)num_elements * B > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
+  return launch_action(x, y, nullptr, theta, flags, nullptr, num_elements, 1, num_elements * B, B, C, S, S, pad, S, S,
+                       pad, pad, stream);
+}
+
+int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {
+  (void)HW;
+  if (B <= 0 || Cf <= 0 || G <= 0) return 0;
+  return (int64_t)B * pool_splits(B, Cf) * G * (int64_t)sizeof(double);
+}
+
+int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* workspace, int B, int Cf, int G, int HW,
+                          void* stream) {
+  if (!feat || !act || !workspace || B < 0 || Cf <= 0 || G <= 0 || HW <= 0) return EQA_ERR_INVALID_ARG;
+  if (gidx && G > 64) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = pool_splits(B, Cf);
+  const int cps = (Cf + splits - 1) / splits;
+  const int used = (Cf + cps - 1) / cps;  // splits that own at least one channel
+  double* partial = (double*)workspace;
+  const bool vec = (HW % 4 == 0) && (((uintptr_t)feat & 15) == 0);
+  const size_t lds = (size_t)4 * G * sizeof(double);
+  if (vec)
+    hipLaunchKernelGGL((group_pool_partial_kernel<true>), dim3(used, B), dim3(kThreads), lds, st, feat, partial, Cf, G, HW, cps, used);
+  else
+    hipLaunchKernelGGL((group_pool_partial_kernel<false>), dim3(used, B), dim3(kThreads), lds, st, feat, partial, Cf, G, HW, cps, used);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  const double inv_count = 1.0 / ((double)Cf * (double)HW);
+  hipLaunchKernelGGL(group_pool_finalize_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, st, partial, act, gidx, B, G, used, inv_count);
+  return launch_status();
+}
+
+int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream) {
+  if (!act || !gidx || B < 0 || G <= 0) return EQA_ERR_INVALID_ARG;
+  if (G > 64) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipLaunchKernelGGL(group_argmax_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, act, gidx, B, G);
+  return launch_status();
+}
+
+int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream) {
+  if (!x || !R || !y || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (N % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL((so3_rotate_kernel<true>), dim3(((N >> 2) + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  else
+    hipLaunchKernelGGL((so3_rotate_kernel<false>), dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  return launch_status();
+}
+
+int eqa_gram_schmidt(const float* v, float* out, int B, void* stream) {
+  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  hipLaunchKernelGGL(gram_schmidt_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, out, B);
+  return launch_status();
+}
+
+}  // extern "C"

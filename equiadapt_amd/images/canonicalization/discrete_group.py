@@ -1,0 +1,263 @@
+"""Discrete-group (C_n / D_n) image canonicalizers on MI355X.
+
+API mirror of ``equiadapt/images/canonicalization/discrete_group.py``: same class
+names, constructor arguments (network, hyperparams read BY ATTRIBUTE, in_shape), attributes and state.
+What differs is underneath:
+
+* ``canonicalize``: the reference pads to (2H x 2W), blends with an h-flipped copy, resamples the whole
+  padded frame and crops (about 8 MB of traffic per 224x224x3 image).  Here ONE kernel
+  (``eqa_canon_transform_fwd``) computes only the H x W pixels that are kept, reading the source through
+  an edge-clamp (== the replicate pad) with the flip folded into the addressing: 1.2 MB per image.
+* the orientation index never leaves the device (no ``.item()``), so a whole step is graph-capturable.
+* ``invert_canonicalization`` is one kernel as well (rotate + flip + regular-representation roll).
+"""
+import math
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+
+from equiadapt_amd import ops
+from equiadapt_amd.common.basecanonicalization import DiscreteGroupCanonicalization
+from equiadapt_amd.images import geometry
+from equiadapt_amd.images.transforms import CenterCrop, EdgePad, Resize
+from equiadapt_amd.images.utils import (
+    device_tables,
+    flip_boxes,
+    flip_masks,
+    get_action_on_image_features,
+    rotate_boxes,
+    rotate_masks,
+)
+
+
+class _CanonTransformFn(torch.autograd.Function):
+    """y = crop(rotate(flip?(pad(x)), -rotation)).  Forward: fused HIP kernel driven by the int index."""
+
+    @staticmethod
+    def forward(ctx, x, rotation, reflection, gidx, theta, flags, pad):
+        return ops.canon_transform(x, gidx, theta, flags, pad)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        raise NotImplementedError(
+            "backward through the canonicalizing transform (d/d-angle and d/d-input kernels) is not built "
+            "yet; train the canonicalizer with the prior loss or run under torch.no_grad()")
+
+
+class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
+    """Base of the discrete-group image canonicalizers (reference: discrete_group.py:20-259)."""
+
+    def __init__(self, canonicalization_network: torch.nn.Module, canonicalization_hyperparams: Any, in_shape: tuple):
+        super().__init__(canonicalization_network)
+        self.beta = canonicalization_hyperparams.beta
+        assert len(in_shape) == 3, "Input shape should be in the format (channels, height, width)"
+        self.in_shape = tuple(int(s) for s in in_shape)
+        is_grayscale = self.in_shape[0] == 1
+        # kept as attributes for API parity; canonicalize() fuses pad+rotate+crop instead of calling them
+        self.pad_size = 0 if is_grayscale else math.ceil(self.in_shape[-1] * 0.5)
+        self.pad = torch.nn.Identity() if is_grayscale else EdgePad(self.pad_size)
+        self.crop = torch.nn.Identity() if is_grayscale else CenterCrop((self.in_shape[-2], self.in_shape[-1]))
+        self.crop_canonization = (
+            torch.nn.Identity() if is_grayscale else CenterCrop((
+                math.ceil(self.in_shape[-2] * canonicalization_hyperparams.input_crop_ratio),
+                math.ceil(self.in_shape[-1] * canonicalization_hyperparams.input_crop_ratio)))
+        )
+        self.resize_canonization = (
+            torch.nn.Identity() if is_grayscale else Resize(size=_as_size(canonicalization_hyperparams.resize_shape))
+        )
+        self._consts: Dict[str, torch.Tensor] = {}
+
+    # -- group bookkeeping -------------------------------------------------------------------------
+
+    def _group_constants(self, device: torch.device) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """Per-element rotation angles (deg) and reflection indicators, cached on the device."""
+        key = f"{device}:{self.num_rotations}:{self.group_type}"
+        hit = self._consts.get(key)
+        if hit is None:
+            angles = geometry.group_angles(self.num_rotations)
+            if self.group_type == "roto-reflection":
+                rot = torch.cat([angles, angles], dim=0)
+                ref = torch.cat([torch.zeros(self.num_rotations), torch.ones(self.num_rotations)], dim=0)
+                hit = (rot.to(device), ref.to(device))
+            else:
+                hit = (angles.to(device), None)
+            self._consts = {key: hit}
+        return hit
+
+    def groupactivations_to_groupelement(self, group_activations: torch.Tensor,
+                                         group_index: Optional[torch.Tensor] = None) -> dict:
+        """(B, G) activations -> {"rotation" (deg)[, "reflection"], "group_index"} (reference :94-135).
+
+        ``rotation`` / ``reflection`` carry the straight-through gradient in training mode exactly like the
+        reference; ``group_index`` (int32, device) is what the kernels consume.
+        """
+        if group_index is None:
+            group_index = self.group_index(group_activations)
+        onehot = self.groupactivations_to_groupelementonehot(group_activations, group_index)
+        rot_comp, ref_comp = self._group_constants(group_activations.device)
+        element = {"rotation": torch.sum(onehot * rot_comp, dim=-1)}
+        if ref_comp is not None:
+            element["reflection"] = torch.sum(onehot * ref_comp, dim=-1)
+        element["group_index"] = group_index
+        return element
+
+    def get_group_activations(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(
+            "get_group_activations is not implemented for the DiscreteGroupImageCanonicalization class")
+
+    def get_groupelement(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Image batch -> group element per image; records activations/element in the info dict (:152-172)."""
+        group_activations = self.get_group_activations(x)
+        group_index = self.group_index(group_activations)
+        element = self.groupactivations_to_groupelement(group_activations, group_index)
+        if not hasattr(self, "canonicalization_info_dict"):
+            self.canonicalization_info_dict = {}
+        # "group_index" stays out of the element dict callers iterate over (they test `"reflection" in ...`)
+        self.canonicalization_info_dict["group_index"] = element.pop("group_index")
+        self.canonicalization_info_dict["group_element"] = element
+        self.canonicalization_info_dict["group_activations"] = group_activations
+        return element
+
+    def transformations_before_canonicalization_network_forward(self, x: torch.Tensor) -> torch.Tensor:
+        """Centre crop by ``input_crop_ratio`` then resize to ``resize_shape`` (reference :174-188)."""
+        return self.resize_canonization(self.crop_canonization(x))
+
+    # -- the hot path ------------------------------------------------------------------------------
+
+    def canonicalize(self, x: torch.Tensor, targets: Optional[List] = None, **kwargs: Any
+                     ) -> Union[torch.Tensor, Tuple[torch.Tensor, List]]:
+        """Rotate (and reflect) every image into its canonical orientation (reference :190-238)."""
+        self.device = x.device
+        element = self.get_groupelement(x)
+        gidx = self.canonicalization_info_dict["group_index"]
+        reflections = "reflection" in element
+        H, W = x.shape[-2:]
+        pad = self.pad_size
+        theta, flags = device_tables("canonicalize", self.num_rotations, reflections, (H + 2 * pad, W + 2 * pad), x.device)
+        x = _CanonTransformFn.apply(x, element["rotation"], element.get("reflection"), gidx, theta, flags, pad)
+
+        if targets:
+            # boxes and masks follow the image (reference :217-236).  NOTE (reference behaviour kept): when the
+            # group has reflections every target is flipped, whatever its own reflection indicator says.
+            image_width = x.shape[-1]
+            if reflections:
+                for t in range(len(targets)):
+                    targets[t]["boxes"] = flip_boxes(targets[t]["boxes"], image_width)
+                    targets[t]["masks"] = flip_masks(targets[t]["masks"])
+            # one device->host copy for the whole batch instead of a sync per sample
+            rot_host = element["rotation"].detach().cpu()
+            for t in range(len(targets)):
+                targets[t]["boxes"] = rotate_boxes(targets[t]["boxes"], element["rotation"][t], image_width)
+                targets[t]["masks"] = rotate_masks(targets[t]["masks"], -rot_host[t].item())
+            return x, targets
+        return x
+
+    def invert_canonicalization(self, x_canonicalized_out: torch.Tensor, **kwargs: Any) -> torch.Tensor:
+        """Map an image-shaped output back to the input's orientation (reference :240-259)."""
+        induced_rep_type = kwargs.get("induced_rep_type", "regular")
+        element = dict(self.canonicalization_info_dict["group_element"])
+        element["group_index"] = self.canonicalization_info_dict["group_index"]
+        return get_action_on_image_features(
+            feature_map=x_canonicalized_out,
+            group_info_dict=self.group_info_dict,
+            group_element_dict=element,
+            induced_rep_type=induced_rep_type,
+        )
+
+
+def _as_size(resize_shape: Any):
+    if isinstance(resize_shape, int):
+        return resize_shape
+    return tuple(int(s) for s in resize_shape)
+
+
+def _num_group(group_type: str, num_rotations: int) -> int:
+    return num_rotations if group_type == "rotation" else 2 * num_rotations
+
+
+class GroupEquivariantImageCanonicalization(DiscreteGroupImageCanonicalization):
+    """Canonicalizer driven by a group-EQUIVARIANT network that outputs (B, G) activations.
+
+    Reference: discrete_group.py:262-317.  ``group_type`` / ``num_rotations`` are read from the network.
+    """
+
+    def __init__(self, canonicalization_network: torch.nn.Module, canonicalization_hyperparams: Any, in_shape: tuple):
+        super().__init__(canonicalization_network, canonicalization_hyperparams, in_shape)
+        self.group_type = canonicalization_network.group_type
+        self.num_rotations = canonicalization_network.num_rotations
+        self.num_group = _num_group(self.group_type, self.num_rotations)
+        self.group_info_dict = {"num_rotations": self.num_rotations, "num_group": self.num_group}
+
+    def get_group_activations(self, x: torch.Tensor) -> torch.Tensor:
+        x = self.transformations_before_canonicalization_network_forward(x)
+        return self.canonicalization_network(x)
+
+
+class OptimizedGroupEquivariantImageCanonicalization(DiscreteGroupImageCanonicalization):
+    """Canonicalizer for a NON-equivariant network: score every group view against a reference vector.
+
+    Reference: discrete_group.py:320-512.  The orbit (all G views of the resized batch) is written by one
+    kernel launch (``eqa_orbit_expand_fwd``) instead of G x (pad, rotate, flip, crop) + ``torch.cat``.
+    """
+
+    def __init__(self, canonicalization_network: torch.nn.Module, canonicalization_hyperparams: Any, in_shape: tuple):
+        super().__init__(canonicalization_network, canonicalization_hyperparams, in_shape)
+        self.group_type = canonicalization_hyperparams.group_type
+        self.num_rotations = canonicalization_hyperparams.num_rotations
+        self.artifact_err_wt = canonicalization_hyperparams.artifact_err_wt
+        self.num_group = _num_group(self.group_type, self.num_rotations)
+        self.out_vector_size = canonicalization_network.out_vector_size
+        size = canonicalization_hyperparams.resize_shape
+        self.group_augment_size = int(size)
+        gray = self.in_shape[0] == 1
+        self.group_augment_pad = 0 if gray else math.ceil(self.group_augment_size * 0.5)
+        self.crop_group_augment = torch.nn.Identity() if gray else CenterCrop(self.group_augment_size)
+        self.pad_group_augment = torch.nn.Identity() if gray else EdgePad(self.group_augment_pad)
+        self.reference_vector = torch.nn.Parameter(
+            torch.randn(1, self.out_vector_size), requires_grad=canonicalization_hyperparams.learn_ref_vec)
+        self.group_info_dict = {"num_rotations": self.num_rotations, "num_group": self.num_group}
+
+    def group_augment(self, x: torch.Tensor) -> torch.Tensor:
+        """(B, C, s, s) -> (G*B, C, s, s), element-major (reference :387-427)."""
+        s = x.shape[-1]
+        pad = self.group_augment_pad
+        theta, flags = device_tables("orbit", self.num_rotations, self.group_type == "roto-reflection",
+                                     (s + 2 * pad, s + 2 * pad), x.device)
+        return ops.orbit_expand(x.detach() if not x.requires_grad else x, theta, flags, pad)
+
+    def _rotate_batch(self, x: torch.Tensor, rot_index: torch.Tensor, sign: float) -> torch.Tensor:
+        """pad -> rotate(sign * index * 360/N) -> crop for a per-image rotation index (artifact branch)."""
+        s = x.shape[-1]
+        pad = self.group_augment_pad
+        theta = geometry.rotation_theta(sign * geometry.group_angles(self.num_rotations) * 1.0, (s + 2 * pad, s + 2 * pad))
+        return ops.group_action(x, rot_index.to(torch.int32), theta.to(x.device), None, None, pad, (s, s), (pad, pad))
+
+    def get_group_activations(self, x: torch.Tensor) -> torch.Tensor:
+        """Cosine similarity of every view's embedding with the reference vector -> (B, G) (:429-481)."""
+        x = self.transformations_before_canonicalization_network_forward(x)
+        x_augmented = self.group_augment(x)
+        vector_out = self.canonicalization_network(x_augmented)
+        self.canonicalization_info_dict = {"vector_out": vector_out}
+
+        if self.artifact_err_wt:
+            # a random rotation and back, to penalise interpolation artifacts (reference :448-473)
+            rot_idx = torch.randint(0, self.num_rotations, (x_augmented.shape[0],), device=x.device)
+            x_dummy = self._rotate_batch(x_augmented, rot_idx, -1.0)
+            x_dummy = self._rotate_batch(x_dummy, rot_idx, +1.0)
+            vector_out_dummy = self.canonicalization_network(x_dummy)
+            self.canonicalization_info_dict.update({"vector_out_dummy": vector_out_dummy})
+
+        scalar_out = F.cosine_similarity(self.reference_vector.repeat(vector_out.shape[0], 1), vector_out)
+        return scalar_out.reshape(self.num_group, -1).T
+
+    def get_optimization_specific_loss(self) -> torch.Tensor:
+        """mean |off-diagonal Gram of the G view embeddings| + artifact_err_wt * MSE (reference :483-512)."""
+        vectors = self.canonicalization_info_dict["vector_out"]
+        artifact = 0
+        if self.artifact_err_wt:
+            artifact = F.mse_loss(self.canonicalization_info_dict["vector_out_dummy"], vectors)
+        v = vectors.reshape(self.num_group, -1, self.out_vector_size).permute((1, 0, 2))
+        gram = v @ v.permute((0, 2, 1))
+        mask = 1.0 - torch.eye(self.num_group, device=self.device)
+        return torch.abs(gram * mask).mean() + self.artifact_err_wt * artifact

@@ -1,0 +1,40 @@
+"""CustomEquivariantNetwork: lifting conv (+ ReLU + 1x1 group convs) and group pooling.
+
+Reference: equiadapt/images/canonicalization_networks/custom_equivariant_networks.py:14-93.
+"""
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_layers import (
+    RotationEquivariantConv,
+    RotationEquivariantConvLift,
+    RotoReflectionEquivariantConv,
+    RotoReflectionEquivariantConvLift,
+)
+from equiadapt_amd.images.canonicalization_networks.pooling import group_pool
+
+
+class CustomEquivariantNetwork(nn.Module):
+    """(B, C, H, W) -> (B, G) group activations; ``group_type`` in {"rotation", "roto-reflection"}."""
+
+    def __init__(self, in_shape: Tuple[int, ...], out_channels: int, kernel_size: int, group_type: str = "rotation",
+                 num_rotations: int = 4, num_layers: int = 1,
+                 device: str = "cuda" if torch.cuda.is_available() else "cpu"):
+        super().__init__()
+        if group_type == "rotation":
+            lift, conv = RotationEquivariantConvLift, RotationEquivariantConv
+        elif group_type == "roto-reflection":
+            lift, conv = RotoReflectionEquivariantConvLift, RotoReflectionEquivariantConv
+        else:
+            raise ValueError("group_type must be rotation or roto-reflection for now.")
+        layers = [lift(in_shape[0], out_channels, kernel_size, num_rotations, device=device)]
+        for _ in range(num_layers - 1):
+            layers += [nn.ReLU(), conv(out_channels, out_channels, 1, num_rotations, device=device)]
+        self.eqv_network = nn.Sequential(*layers)
+        self.group_type = group_type
+        self.num_rotations = num_rotations
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return group_pool(self.eqv_network(x))

@@ -1,0 +1,142 @@
+"""C_n / D_n lifting and group convolutions with the reference's parameter shapes and semantics.
+
+Reference: equiadapt/images/canonicalization_networks/custom_group_equivariant_layers.py.
+The reference rebuilds the expanded filter bank on every forward by *resampling* the k x k filters with
+``kornia.geometry.rotate`` (bilinear!) and ``hflip``.  Rotating a k x k image bilinearly is a fixed
+linear map on R^(k*k); here that map is computed ONCE per (k, group) by pushing the k*k unit images
+through the HIP resampling kernel (``eqa_orbit_expand_fwd``), giving E matrices A_e (k^2 x k^2).  The
+expanded bank is then one tiny einsum -- differentiable, no resampling in the training loop, and
+bit-compatible with what the kernel (hence the reference op sequence) produces.
+Parameter names/shapes (``weights``, ``bias``) match the reference so its checkpoints load.
+"""
+import math
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from equiadapt_amd import ops
+from equiadapt_amd.images import geometry
+
+_bank_cache: Dict[tuple, torch.Tensor] = {}
+
+
+def filter_action_matrices(kernel_size: int, num_rotations: int, reflections: bool, device: torch.device) -> torch.Tensor:
+    """(E, k*k, k*k): A_e maps a flattened filter to ``[hflip](rotate(filter, +angle_e))``.
+
+    rotate = kornia semantics on a (k, k) frame, zero fill (custom_group_equivariant_layers.py:77-83,
+    :184-190: rotation first, then hflip for the reflected half).
+    """
+    key = (kernel_size, num_rotations, reflections, str(device))
+    hit = _bank_cache.get(key)
+    if hit is not None:
+        return hit
+    k, N = kernel_size, num_rotations
+    E = 2 * N if reflections else N
+    if k == 1:  # a 1x1 filter is its own rotation / reflection
+        mats = torch.ones(E, 1, 1, device=device)
+    else:
+        ang = torch.linspace(0.0, 360.0, steps=N + 1, dtype=torch.float32)[:N]
+        theta = geometry.rotation_theta(ang, (k, k))
+        flags = torch.zeros(N, dtype=torch.int32)
+        if reflections:
+            theta = torch.cat([theta, theta], dim=0)
+            flags = torch.cat([flags, torch.full((N,), geometry.FLIP_DST, dtype=torch.int32)])
+        basis = torch.eye(k * k, device=device).view(1, k * k, k, k)
+        out = ops.orbit_expand(basis, theta.to(device), flags.to(device), 0)  # (E, k*k [q], k, k [p])
+        mats = out.reshape(E, k * k, k * k).transpose(1, 2).contiguous()      # A[e, p, q]
+    _bank_cache[key] = mats
+    return mats
+
+
+def _slot_table(num_rotations: int, reflections: bool) -> torch.Tensor:
+    """src_slot[e, m]: which input group slot of the stored weight feeds slot m of output element e.
+
+    rotation: (m - e) mod N (reference :283-293).  roto-reflection (reference :430-456):
+      e <  N : [ (m - e) mod N | N + (m' + e) mod N ]
+      e >= N : [ N + (m + n) mod N | (m' - n) mod N ]   with n = e - N.
+    """
+    N = num_rotations
+    m = torch.arange(N)
+    n = torch.arange(N)[:, None]
+    fwd = (m[None, :] - n) % N
+    if not reflections:
+        return fwd
+    inv = (m[None, :] + n) % N
+    upper = torch.cat([fwd, inv + N], dim=1)
+    lower = torch.cat([inv + N, fwd], dim=1)
+    return torch.cat([upper, lower], dim=0)
+
+
+class _GroupConvBase(nn.Module):
+    reflections = False
+    lifting = True
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, num_rotations: int = 4,
+                 stride: int = 1, padding: int = 0, bias: bool = True, device: str = "cuda"):
+        super().__init__()
+        E = 2 * num_rotations if self.reflections else num_rotations
+        shape = (out_channels, in_channels, kernel_size, kernel_size) if self.lifting else \
+            (out_channels, in_channels, E, kernel_size, kernel_size)
+        self.weights = nn.Parameter(torch.empty(*shape, device=device))
+        nn.init.kaiming_uniform_(self.weights, a=math.sqrt(5))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels, device=device))
+        else:
+            self.bias = None  # type: ignore
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.stride, self.padding = stride, padding
+        self.num_rotations, self.kernel_size = num_rotations, kernel_size
+        self.num_group_elements = E
+        if not self.lifting:
+            self.register_buffer("src_slot", _slot_table(num_rotations, self.reflections), persistent=False)
+        self._cached_bank: Tuple[int, torch.Tensor] = (-1, None)  # type: ignore
+
+    def expanded_weights(self) -> torch.Tensor:
+        """The dense conv filter bank: (O*E, I, k, k) for lifting, (O*E, I*E, k, k) otherwise."""
+        w = self.weights
+        if not self.training and not torch.is_grad_enabled():
+            ver, bank = self._cached_bank
+            if ver == w._version and bank is not None and bank.device == w.device:
+                return bank
+        O, I, E, k = self.out_channels, self.in_channels, self.num_group_elements, self.kernel_size
+        A = filter_action_matrices(k, self.num_rotations, self.reflections, w.device)  # (E, p, q)
+        if self.lifting:
+            bank = torch.einsum("epq,oiq->oeip", A, w.reshape(O, I, k * k)).reshape(O * E, I, k, k)
+        else:
+            wp = w.reshape(O, I, E, k * k)[:, :, self.src_slot]            # (O, I, E[e], E[m], q)
+            bank = torch.einsum("epq,oiemq->oeimp", A, wp).reshape(O * E, I * E, k, k)
+        if not self.training and not torch.is_grad_enabled():
+            self._cached_bank = (w._version, bank)
+        return bank
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        if not self.lifting:
+            x = x.flatten(1, 2)
+        x = F.conv2d(x, self.expanded_weights(), stride=self.stride, padding=self.padding)
+        x = x.reshape(B, self.out_channels, self.num_group_elements, x.shape[2], x.shape[3])
+        if self.bias is not None:
+            x = x + self.bias[None, :, None, None, None]
+        return x
+
+
+class RotationEquivariantConvLift(_GroupConvBase):
+    """Z2 -> C_n lifting convolution; weights (O, I, k, k) (reference :9-111)."""
+    reflections, lifting = False, True
+
+
+class RotoReflectionEquivariantConvLift(_GroupConvBase):
+    """Z2 -> D_n lifting convolution; weights (O, I, k, k) (reference :114-226)."""
+    reflections, lifting = True, True
+
+
+class RotationEquivariantConv(_GroupConvBase):
+    """C_n -> C_n group convolution; weights (O, I, N, k, k) (reference :229-361)."""
+    reflections, lifting = False, False
+
+
+class RotoReflectionEquivariantConv(_GroupConvBase):
+    """D_n -> D_n group convolution; weights (O, I, 2N, k, k) (reference :364-538)."""
+    reflections, lifting = True, False

@@ -1,0 +1,116 @@
+"""Host logic: the per-group-element tables the resampling kernels consume (see include/eqa_hip.h).
+
+For a discrete group there are only E distinct geometric maps, so everything the reference recomputes
+per call and per sample (rotation matrix -> homography -> normalise -> inverse -> affine grid) is
+evaluated ONCE per (group, frame size) here, in fp32 and with the same torch op chain kornia 0.7.0 uses
+(``rotate`` -> ``get_rotation_matrix2d`` -> ``warp_affine`` -> ``normalize_homography`` -> ``inverse``),
+so the E 2x3 matrices are bit-identical to what the reference would hand to ``F.affine_grid``.
+The tables are E*6 floats / E ints / E*G ints; they live on the device as non-persistent module buffers.
+"""
+import functools
+from typing import Optional, Tuple
+
+import torch
+
+FLIP_SRC = 1  # sample the horizontally flipped frame (flip applied before the rotation)
+FLIP_DST = 2  # flip the result horizontally (flip applied after the rotation)
+
+
+def group_angles(num_rotations: int) -> torch.Tensor:
+    """Angles of the rotation subgroup in degrees: linspace(0, 360, N + 1)[:N].
+
+    Reference: images/canonicalization/discrete_group.py:110-112.
+    """
+    return torch.linspace(0.0, 360.0, num_rotations + 1)[:num_rotations]
+
+
+def _pixel_to_norm(height: int, width: int, eps: float = 1e-14) -> torch.Tensor:
+    m = torch.tensor([[1.0, 0.0, -1.0], [0.0, 1.0, -1.0], [0.0, 0.0, 1.0]])
+    m[0, 0] = m[0, 0] * 2.0 / (eps if width == 1 else width - 1.0)
+    m[1, 1] = m[1, 1] * 2.0 / (eps if height == 1 else height - 1.0)
+    return m.unsqueeze(0)
+
+
+def rotation_theta(angles_deg: torch.Tensor, frame_hw: Tuple[int, int]) -> torch.Tensor:
+    """(E,) angles -> (E, 6) normalised sampling matrices for ``rotate(img, angle)`` on an (Hp, Wp) frame.
+
+    Mirrors kornia.geometry.transform.rotate as called at images/canonicalization/discrete_group.py:213
+    and images/utils.py:57,82 (centre ((Wp-1)/2, (Hp-1)/2), bilinear, zeros, align_corners=True).
+    """
+    Hp, Wp = frame_hw
+    ang = torch.deg2rad(angles_deg.to(torch.float32).reshape(-1))
+    E = ang.shape[0]
+    cos_a, sin_a = torch.cos(ang), torch.sin(ang)
+    rot = torch.stack([cos_a, sin_a, -sin_a, cos_a], dim=-1).view(E, 2, 2)
+    center = torch.tensor([float(Wp - 1) / 2, float(Hp - 1) / 2]).expand(E, -1)
+    unit = (torch.zeros(E, 2, 2) + torch.eye(2)) * torch.ones_like(center).unsqueeze(2).repeat(1, 1, 2)
+    sr = rot @ unit
+    alpha, beta = sr[:, 0, 0], sr[:, 0, 1]
+    cx, cy = center[..., 0], center[..., 1]
+    one = torch.tensor(1.0)
+    M = torch.zeros(E, 3, 3)
+    M[:, 0:2, 0:2] = sr
+    M[:, 0, 2] = (one - alpha) * cx - beta * cy
+    M[:, 1, 2] = beta * cx + (one - alpha) * cy
+    M[:, 2, 2] = 1.0
+    norm = _pixel_to_norm(Hp, Wp)
+    dst_norm_from_src_norm = norm @ (M @ torch.linalg.inv(norm))
+    return torch.linalg.inv(dst_norm_from_src_norm)[:, :2, :].reshape(E, 6).contiguous()
+
+
+@functools.lru_cache(maxsize=64)
+def canonicalize_tables(num_rotations: int, reflections: bool, frame_hw: Tuple[int, int]):
+    """I5 tables: element e = (reflection, rotation index); rotate by -angle, flip the SOURCE when reflected."""
+    ang = group_angles(num_rotations)
+    theta = rotation_theta(-ang, frame_hw)
+    if reflections:
+        theta = torch.cat([theta, theta], dim=0)
+        flags = torch.cat([torch.zeros(num_rotations), torch.full((num_rotations,), FLIP_SRC)]).to(torch.int32)
+    else:
+        flags = torch.zeros(num_rotations, dtype=torch.int32)
+    return theta, flags
+
+
+@functools.lru_cache(maxsize=64)
+def orbit_tables(num_rotations: int, reflections: bool, frame_hw: Tuple[int, int]):
+    """I8 tables: rotate by -angle, flip the RESULT for the reflected half (discrete_group.py:400-408)."""
+    ang = torch.linspace(0, 360, num_rotations + 1)[:-1]
+    theta = rotation_theta(-ang, frame_hw)
+    if reflections:
+        theta = torch.cat([theta, theta], dim=0)
+        flags = torch.cat([torch.zeros(num_rotations), torch.full((num_rotations,), FLIP_DST)]).to(torch.int32)
+    else:
+        flags = torch.zeros(num_rotations, dtype=torch.int32)
+    return theta, flags
+
+
+@functools.lru_cache(maxsize=64)
+def invert_tables(num_rotations: int, reflections: bool, frame_hw: Tuple[int, int]):
+    """I7 tables (images/utils.py:54-89).
+
+    rotate by +angle; when the group has reflections the result is flipped for elements whose reflection
+    indicator is ZERO (``x*r + hflip(x)*(1-r)``) -- the reference's convention, opposite to I5.
+    chan_map[e, g] = input group slot feeding output slot g for "regular" features:
+    ``shift = angles/360*N``; first half rolled by ``shift.long()``, reflected half by ``(-shift).long()``
+    (roll_by_gather, images/utils.py:8-29: out[g] = in[(g - s) mod N]).
+    """
+    N = num_rotations
+    ang = group_angles(N)
+    theta = rotation_theta(ang, frame_hw)
+    shift = ang / 360.0 * N
+    s_pos, s_neg = shift.long(), (-shift).long()
+    g = torch.arange(N)
+    first = (g[None, :] - s_pos[:, None]) % N          # (N elements, N slots)
+    if not reflections:
+        return theta, torch.zeros(N, dtype=torch.int32), first.to(torch.int32)
+    second = N + (g[None, :] - s_neg[:, None]) % N
+    per_rot = torch.cat([first, second], dim=1)       # (N, 2N)
+    chan_map = torch.cat([per_rot, per_rot], dim=0)    # elements e and e+N share the rotation index
+    theta = torch.cat([theta, theta], dim=0)
+    flags = torch.cat([torch.full((N,), FLIP_DST), torch.zeros(N)]).to(torch.int32)
+    return theta, flags, chan_map.to(torch.int32).contiguous()
+
+
+def center_crop_offset(full: int, crop: int) -> int:
+    """torchvision CenterCrop: int(round((full - crop) / 2.0)) with Python's round-half-even."""
+    return int(round((full - crop) / 2.0))

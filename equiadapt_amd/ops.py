@@ -1,0 +1,213 @@
+"""Tensor-level entry points over the C ABI (include/eqa_hip.h).
+
+Every function takes ROCm ("cuda") fp32 tensors, launches on torch's current HIP stream and returns
+torch tensors; nothing here computes on the CPU.  torch is plumbing only: device memory + streams.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from equiadapt_amd import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class KernelTimer:
+    """HIP-event bracket around named launches, recorded on the stream the kernels run on.
+
+    ``with ops.KernelTimer() as t: ...`` then ``t.summary()`` -> {name: (launches, mean_ms)} after a
+    device synchronise.  Used by bench.py for the live per-kernel duration behind ``roofline.achieved``.
+    """
+
+    active: "Optional[KernelTimer]" = None
+
+    def __init__(self):
+        self.events = {}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v)) for k, v in self.events.items()}
+
+
+class _timed:
+    def __init__(self, name: str):
+        self.t = KernelTimer.active
+        self.name = name
+
+    def __enter__(self):
+        if self.t is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if self.t is not None:
+            self.b.record()
+            self.t.events.setdefault(self.name, []).append((self.a, self.b))
+
+
+def _need(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: equiadapt_amd runs on an MI355X (ROCm) device only, no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype} (the hot path computes in fp32 like the reference)")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype) -> Tuple[Optional[torch.Tensor], Optional[int]]:
+    if t is None:
+        return None, None
+    t = _need(t, name, dtype)
+    return t, t.data_ptr()
+
+
+def group_action(
+    src: torch.Tensor,
+    gidx: Optional[torch.Tensor],
+    theta: torch.Tensor,
+    flags: Optional[torch.Tensor],
+    chan_map: Optional[torch.Tensor],
+    pad: int,
+    out_hw: Tuple[int, int],
+    top_left: Tuple[int, int],
+    n_out: Optional[int] = None,
+) -> torch.Tensor:
+    """Generic discrete group action on image planes (eqa_group_action_fwd)."""
+    lib = _lib.load()
+    src = _need(src, "src")
+    theta = _need(theta, "theta")
+    B, C, H, W = src.shape
+    E = theta.shape[0]
+    gidx, p_gidx = _opt(gidx, "gidx", torch.int32)
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    chan_map, p_map = _opt(chan_map, "chan_map", torch.int32)
+    G = chan_map.shape[1] if chan_map is not None else 1
+    if n_out is None:
+        n_out = B if gidx is not None else E * B
+    OH, OW = out_hw
+    dst = torch.empty((n_out, C, OH, OW), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        st = lib.eqa_group_action_fwd(src.data_ptr(), dst.data_ptr(), p_gidx, theta.data_ptr(), p_flags, p_map, E, G,
+                                      n_out, B, C, H, W, pad, OH, OW, top_left[0], top_left[1], _stream())
+    _lib.check(st, "eqa_group_action_fwd")
+    return dst
+
+
+def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int) -> torch.Tensor:
+    """I5: fused pad(edge) -> [hflip] -> rotate -> center-crop (eqa_canon_transform_fwd)."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    gidx = _need(gidx, "gidx", torch.int32)
+    theta = _need(theta, "theta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    B, C, H, W = x.shape
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device), _timed("canon_transform"):
+        st = lib.eqa_canon_transform_fwd(x.data_ptr(), y.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags,
+                                         theta.shape[0], B, C, H, W, pad, _stream())
+    _lib.check(st, "eqa_canon_transform_fwd")
+    return y
+
+
+def invert_action(f: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor],
+                  chan_map: Optional[torch.Tensor]) -> torch.Tensor:
+    """I7: rotate(+theta) zero-corner -> flip -> regular-representation roll (eqa_invert_action_fwd)."""
+    lib = _lib.load()
+    f = _need(f, "feature_map")
+    gidx = _need(gidx, "gidx", torch.int32)
+    theta = _need(theta, "theta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    chan_map, p_map = _opt(chan_map, "chan_map", torch.int32)
+    G = chan_map.shape[1] if chan_map is not None else 1
+    B, C, H, W = f.shape
+    out = torch.empty_like(f)
+    with torch.cuda.device(f.device), _timed("invert_action"):
+        st = lib.eqa_invert_action_fwd(f.data_ptr(), out.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, p_map,
+                                       theta.shape[0], G, B, C, H, W, _stream())
+    _lib.check(st, "eqa_invert_action_fwd")
+    return out
+
+
+def orbit_expand(x: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int) -> torch.Tensor:
+    """I8: all E group views of every image, element-major (eqa_orbit_expand_fwd)."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    theta = _need(theta, "theta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    B, C, S, S2 = x.shape
+    if S != S2:
+        raise ValueError("orbit_expand expects square images (the reference crops to a square resize_shape)")
+    E = theta.shape[0]
+    y = torch.empty((E * B, C, S, S), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_orbit_expand_fwd(x.data_ptr(), y.data_ptr(), theta.data_ptr(), p_flags, E, B, C, S, pad, _stream())
+    _lib.check(st, "eqa_orbit_expand_fwd")
+    return y
+
+
+def group_pool_argmax(feature_map: torch.Tensor, want_index: bool = True) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """I3+I4: (B, Cf, G, H', W') -> activations (B, G) [mean over Cf, H', W'] and argmax index (B,) int32."""
+    lib = _lib.load()
+    feature_map = _need(feature_map, "feature_map")
+    B, Cf, G, Hf, Wf = feature_map.shape
+    HW = Hf * Wf
+    act = torch.empty((B, G), dtype=torch.float32, device=feature_map.device)
+    gidx = torch.empty((B,), dtype=torch.int32, device=feature_map.device) if want_index else None
+    nbytes = lib.eqa_group_pool_workspace_bytes(B, Cf, G, HW)
+    ws = torch.empty((max(nbytes, 8) // 8,), dtype=torch.float64, device=feature_map.device)
+    with torch.cuda.device(feature_map.device), _timed("group_pool"):
+        st = lib.eqa_group_pool_argmax(feature_map.data_ptr(), act.data_ptr(), gidx.data_ptr() if want_index else None,
+                                       ws.data_ptr(), B, Cf, G, HW, _stream())
+    _lib.check(st, "eqa_group_pool_argmax")
+    return act, gidx
+
+
+def group_argmax(act: torch.Tensor) -> torch.Tensor:
+    """I4: first-maximum argmax over the group axis, (B, G) -> (B,) int32."""
+    lib = _lib.load()
+    act = _need(act.detach(), "group_activations")
+    B, G = act.shape
+    gidx = torch.empty((B,), dtype=torch.int32, device=act.device)
+    with torch.cuda.device(act.device):
+        st = lib.eqa_group_argmax(act.data_ptr(), gidx.data_ptr(), B, G, _stream())
+    _lib.check(st, "eqa_group_argmax")
+    return gidx
+
+
+def so3_rotate(x: torch.Tensor, R: torch.Tensor, transpose: bool = False) -> torch.Tensor:
+    """P4: y[b] = R[b] @ x[b] (or R[b]^T @ x[b]);  x:(B,3,N), R:(B,3,3)."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    R = _need(R, "R")
+    B, three, N = x.shape
+    if three != 3 or tuple(R.shape) != (B, 3, 3):
+        raise ValueError("so3_rotate expects x:(B,3,N) and R:(B,3,3)")
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_so3_rotate(x.data_ptr(), R.data_ptr(), y.data_ptr(), B, N, int(transpose), _stream())
+    _lib.check(st, "eqa_so3_rotate")
+    return y
+
+
+def gram_schmidt(v: torch.Tensor) -> torch.Tensor:
+    """P3: batched classical Gram-Schmidt on the rows of (B,3,3)."""
+    lib = _lib.load()
+    v = _need(v, "vectors")
+    if v.dim() != 3 or v.shape[1:] != (3, 3):
+        raise ValueError("gram_schmidt expects (B,3,3)")
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        st = lib.eqa_gram_schmidt(v.data_ptr(), out.data_ptr(), v.shape[0], _stream())
+    _lib.check(st, "eqa_gram_schmidt")
+    return out

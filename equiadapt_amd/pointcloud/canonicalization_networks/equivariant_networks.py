@@ -1,0 +1,66 @@
+"""VNSmall: the SO(3)-equivariant canonicalization network for point clouds.
+
+Reference: equiadapt/pointcloud/canonicalization_networks/equivariant_networks.py (knn :15-33,
+get_graph_feature_cross :36-76, VNSmall :79-150).  Hyperparameters are read by attribute
+(``n_knn``, ``pooling``), so a SimpleNamespace / dataclass / DictConfig all work.
+"""
+from typing import Any, Optional
+
+import torch
+import torch.nn as nn
+
+from equiadapt_amd.pointcloud.canonicalization_networks.vector_neuron_layers import (
+    VNBatchNorm,
+    VNLinearLeakyReLU,
+    VNMaxPool,
+    mean_pool,
+)
+
+
+def knn(x: torch.Tensor, k: int) -> torch.Tensor:
+    """(B, 3, N) -> (B, N, k) indices of the k nearest points (self included), by -||xi-xj||^2 top-k."""
+    inner = -2 * torch.matmul(x.transpose(2, 1), x)
+    xx = torch.sum(x**2, dim=1, keepdim=True)
+    return (-xx - inner - xx.transpose(2, 1)).topk(k=k, dim=-1)[1]
+
+
+def get_graph_feature_cross(x: torch.Tensor, k: int = 20, idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(B, 1, 3, N) -> (B, 3, 3, N, k) edge features [neighbour - centre, centre, neighbour x centre]."""
+    B, N = x.size(0), x.size(3)
+    x = x.view(B, -1, N)
+    if idx is None:
+        idx = knn(x, k=k)
+    flat = (idx + torch.arange(0, B, device=idx.device).view(-1, 1, 1) * N).view(-1)
+    dims = x.size(1) // 3
+    pts = x.transpose(2, 1).contiguous()
+    nbr = pts.view(B * N, -1)[flat, :].view(B, N, k, dims, 3)
+    ctr = pts.view(B, N, 1, dims, 3).expand(B, N, k, dims, 3)
+    cross = torch.cross(nbr, ctr, dim=-1)
+    return torch.cat((nbr - ctr, ctr, cross), dim=3).permute(0, 3, 4, 1, 2).contiguous()
+
+
+class VNSmall(nn.Module):
+    """(B, 3, N) point cloud -> (B, 3, 3): three vectors that rotate with the cloud."""
+
+    def __init__(self, hyperparams: Any):
+        super().__init__()
+        self.n_knn = hyperparams.n_knn
+        self.pooling = hyperparams.pooling
+        self.conv_pos = VNLinearLeakyReLU(3, 64 // 3, dim=5, negative_slope=0.0)
+        self.conv1 = VNLinearLeakyReLU(64 // 3, 64 // 3, dim=4, negative_slope=0.0)
+        self.bn1 = VNBatchNorm(64 // 3, dim=4)
+        self.conv2 = VNLinearLeakyReLU(64 // 3, 12 // 3, dim=4, negative_slope=0.0)
+        self.dropout = nn.Dropout(p=0.5)
+        if self.pooling == "max":
+            self.pool = VNMaxPool(64 // 3)
+        elif self.pooling == "mean":
+            self.pool = mean_pool  # type: ignore
+        else:
+            raise ValueError(f"Pooling type {self.pooling} not supported")
+
+    def forward(self, point_cloud: torch.Tensor) -> torch.Tensor:
+        feat = get_graph_feature_cross(point_cloud.unsqueeze(1), k=self.n_knn)
+        out = self.pool(self.conv_pos(feat))
+        out = self.bn1(self.conv1(out))
+        out = self.dropout(self.conv2(out))
+        return out.mean(dim=-1)[:, :3]

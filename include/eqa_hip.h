@@ -1,0 +1,128 @@
+/*
+ * eqa_hip.h -- C ABI of libeqa_hip.so, the MI355X (gfx950) implementation of equiadapt's
+ * canonicalization hot path.
+ *
+ * The reference (arnab39/equiadapt) is pure Python and has no FFI; its boundary is the
+ * torch.nn.Module contract of BaseCanonicalization.  This header defines the native boundary
+ * underneath that contract: one entry point per fused op sequence of SURVEY.md section 8a, each citing the
+ * reference lines (relative to the reference repo root) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to caller-owned memory (e.g. torch tensor .data_ptr());
+ *    the library allocates nothing and keeps no state between calls;
+ *  - tensors are dense row-major ("contiguous NCHW") fp32 unless stated; indices are int32;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are asynchronous and
+ *    stream-ordered, so they can be captured in a hipGraph;
+ *  - return 0 on success, EQA_ERR_* (< 0) otherwise; nothing throws across the boundary.
+ *
+ * "Group element tables".  A discrete group element e in [0, E) is described by three small device
+ * tables that the host builds once per (group, frame size):
+ *    theta[e*6 .. e*6+5]  the 2x3 matrix handed to torch's affine_grid by kornia.warp_affine
+ *                         (normalised [-1,1] coords, align_corners=True), i.e. the map from an
+ *                         OUTPUT pixel of the sampling frame to the SOURCE location;
+ *    flags[e]             EQA_FLIP_SRC: sample the horizontally flipped frame (flip BEFORE rotation);
+ *                         EQA_FLIP_DST: flip the result horizontally (flip AFTER rotation);
+ *    chan_map[e*G + g]    for "regular" features: which input group slot feeds output slot g
+ *                         (NULL = identity / "scalar" features).
+ */
+#ifndef EQA_HIP_H
+#define EQA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQA_OK 0
+#define EQA_ERR_INVALID_ARG (-1)
+#define EQA_ERR_LAUNCH (-2)
+#define EQA_ERR_UNSUPPORTED (-3)
+
+#define EQA_FLIP_SRC 1
+#define EQA_FLIP_DST 2
+
+/* library / build identification: returns the ABI version (currently 1). */
+int eqa_abi_version(void);
+
+/* Debug/benchmark knobs (process-global, not part of the data path):
+ *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels. */
+int eqa_set_option(int key, int value);
+
+/*
+ * I5 -- fused  pad(edge) -> [hflip blend] -> rotate(-theta_g) -> center-crop.
+ * Replaces equiadapt/images/canonicalization/discrete_group.py:207-215
+ *   (self.pad :62-66, K.geometry.hflip blend :209-211, K.geometry.rotate :213, self.crop :67-71).
+ * x:(B,C,H,W) -> y:(B,C,H,W).  The sampling frame is (H+2*pad, W+2*pad); only the H x W pixels the
+ * reference keeps are computed.  pad = 0 reproduces the grayscale branch (no pad/crop, zero corners).
+ * gidx:(B) group element per image; theta:(E,6); flags:(E).
+ */
+int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const float* theta,
+                            const int32_t* flags, int num_elements, int B, int C, int H, int W, int pad,
+                            void* stream);
+
+/*
+ * I7 -- invert_canonicalization / get_action_on_image_features:
+ *   rotate(+theta_g) with zero corners -> hflip blend (flipped when the reflection indicator is 0)
+ *   -> for "regular" features a cyclic roll of the group axis.
+ * Replaces equiadapt/images/utils.py:32-94 and roll_by_gather :8-29
+ *   (called from images/canonicalization/discrete_group.py:240-259).
+ * f:(B,C,H,W) -> out:(B,C,H,W); chan_map:(E,G) or NULL ("scalar"); C % G == 0 when chan_map != NULL.
+ */
+int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const float* theta,
+                          const int32_t* flags, const int32_t* chan_map, int num_elements, int G, int B, int C,
+                          int H, int W, void* stream);
+
+/*
+ * I8 -- orbit expansion (group_augment): for every group element e,
+ *   pad(edge) -> rotate(-deg_e) -> [hflip AFTER the rotation] -> center-crop(S), concatenated
+ *   element-major: y[(e*B + b)] = action_e(x[b]).   x:(B,C,S,S) -> y:(E*B,C,S,S).
+ * Replaces equiadapt/images/canonicalization/discrete_group.py:387-427
+ *   (rotate_and_maybe_reflect :387-409, group_augment :411-427).
+ */
+int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int32_t* flags, int num_elements,
+                         int B, int C, int S, int pad, void* stream);
+
+/*
+ * Generic form of the three entry points above (also used for GroupInference-style orbits and the
+ * artifact branch, discrete_group.py:448-473): out image n uses element
+ *   e = gidx ? gidx[n] : n / B   and source image   b = gidx ? n : n % B.
+ * Source planes are (H,W); the frame is (H+2*pad, W+2*pad); the output is the (OH,OW) window of the
+ * frame whose top-left corner is (top,left).
+ */
+int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, const float* theta,
+                         const int32_t* flags, const int32_t* chan_map, int num_elements, int G, int n_out,
+                         int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream);
+
+/*
+ * I3 + I4 -- group pooling and orientation argmax.
+ * feat:(B, Cf, G, HW) fp32 (the canonicalization network's last feature map, group axis second)
+ *   act[b,g]  = mean over (Cf, HW)                              (escnn_networks.py:106-115,
+ *                                                                custom_equivariant_networks.py:91)
+ *   gidx[b]   = argmax_g act[b,g], first index on ties          (common/basecanonicalization.py:233-235)
+ * workspace: at least eqa_group_pool_workspace_bytes(B, Cf, G, HW) bytes of device scratch.
+ */
+int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW);
+int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* workspace, int B, int Cf, int G,
+                          int HW, void* stream);
+
+/* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
+int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);
+
+/*
+ * P4 -- SO(3) action on point clouds:  y[b] = R[b] x[b]   (transpose = 0)  or  R[b]^T x[b] (transpose = 1).
+ * Replaces torch.bmm(x^T, R^T)^T at equiadapt/pointcloud/canonicalization/continuous_group.py:74-79.
+ * x,y:(B,3,N); R:(B,3,3).
+ */
+int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream);
+
+/*
+ * P3 -- batched 3x3 classical Gram-Schmidt on rows (no epsilon, no handedness fix).
+ * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
+ */
+int eqa_gram_schmidt(const float* v, float* out, int B, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQA_HIP_H */

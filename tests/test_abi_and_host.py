@@ -1,0 +1,101 @@
+"""CPU-only: the C-ABI library loads and exports every symbol of include/eqa_hip.h; host-side tables."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "eqa_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eqa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from equiadapt_amd import _lib
+
+    _lib.build()
+    names = _header_functions()
+    assert len(names) >= 10
+    assert sorted(_lib.SIGNATURES) == names, "ctypes SIGNATURES and include/eqa_hip.h disagree"
+    lib = ctypes.CDLL(_lib.SO_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libeqa_hip.so does not export {n}"
+    assert _lib.load().eqa_abi_version() == 1
+    # argument validation happens before any device work, so it is checkable without a GPU
+    assert _lib.load().eqa_set_option(99, 0) == -1
+    assert _lib.load().eqa_group_pool_workspace_bytes(4, 32, 8, 7056) > 0
+
+
+def test_ops_refuse_cpu_tensors_loudly():
+    from equiadapt_amd import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.so3_rotate(torch.zeros(1, 3, 4), torch.eye(3)[None])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.group_argmax(torch.zeros(2, 4))
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    from equiadapt_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EqaLibraryError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_theta_tables_equal_the_oracle_chain():
+    """The product's tables are bit-identical to what the oracle's kornia restatement gives affine_grid."""
+    from equiadapt_amd.images import geometry as g
+    from oracle import image_ops as io
+
+    for N, hw in [(8, (448, 448)), (4, (64, 48)), (8, (224, 224)), (6, (30, 31))]:
+        ang = g.group_angles(N)
+        assert torch.equal(ang, io.group_angles(N))
+        for sign in (1.0, -1.0):
+            c = torch.tensor([float(hw[1] - 1) / 2, float(hw[0] - 1) / 2]).expand(N, -1)
+            ref = io.kornia_affine_theta(io.kornia_rotation_matrix2d(c, sign * ang), hw, hw).reshape(N, 6)
+            assert torch.equal(g.rotation_theta(sign * ang, hw), ref)
+
+
+def test_invert_channel_map_is_roll_by_gather():
+    from equiadapt_amd.images import geometry as g
+    from oracle import image_ops as io
+
+    for N, refl in [(4, False), (8, False), (4, True), (6, True), (6, False)]:
+        E = 2 * N if refl else N
+        theta, flags, cmap = g.invert_tables(N, refl, (8, 8))
+        assert theta.shape == (E, 6) and cmap.shape == (E, E)
+        x = torch.arange(E, dtype=torch.float32).view(1, 1, E, 1, 1)
+        for e in range(E):
+            ang = g.group_angles(N)[e % N].reshape(1)
+            shift = ang / 360.0 * N
+            if refl:
+                want = torch.cat([io.roll_by_gather(x[:, :, :N], shift), io.roll_by_gather(x[:, :, N:], -shift)], dim=2)
+                assert flags[e].item() == (g.FLIP_DST if e < N else 0)  # flipped when the indicator is 0
+            else:
+                want = io.roll_by_gather(x, shift)
+            assert want.flatten().long().tolist() == cmap[e].tolist(), (N, refl, e)
+
+
+def test_canonicalize_and_orbit_flags():
+    from equiadapt_amd.images import geometry as g
+
+    th, fl = g.canonicalize_tables(4, True, (16, 16))
+    assert fl.tolist() == [0] * 4 + [g.FLIP_SRC] * 4 and torch.equal(th[:4], th[4:])
+    th, fl = g.orbit_tables(4, True, (16, 16))
+    assert fl.tolist() == [0] * 4 + [g.FLIP_DST] * 4
+    assert g.center_crop_offset(225, 180) == 22 and g.center_crop_offset(227, 180) == 24  # round-half-even
+
+
+def test_reference_shape_contract_pre_transform():
+    """reference tests/images/canonicalization/test_continuous_group.py:89-91: (1,3,64,64) -> (1,3,32,32)."""
+    from equiadapt_amd.images.transforms import CenterCrop, Resize
+
+    x = torch.randn(1, 3, 64, 64)
+    assert Resize(32)(CenterCrop(58)(x)).shape == (1, 3, 32, 32)
