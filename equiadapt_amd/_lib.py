@@ -12,7 +12,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libeqa_hip.so")
+SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
 SOURCES = [os.path.join(CSRC, "eqa_hip.hip")]
 INCLUDE = os.path.join(ROOT, "include")
 

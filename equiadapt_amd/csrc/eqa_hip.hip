@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "eqa_hip.h"
 
 namespace {
@@ -16,6 +18,8 @@ constexpr int kTile = 32;      // output tile edge (px): 256 threads x 4 px
 constexpr int kBox = 50;       // staged source window edge: 31*sqrt(2) + neighbour + guard < 50
 constexpr int kLdsStride = 51; // odd dword stride: the 8x4-lane gather pattern is bank-conflict-free at 0/90/180/270 deg
 constexpr int kXcd = 8;
+constexpr int kMaxMapG = 64;   // channel-map row cached in LDS
+constexpr int kRowIters = (kBox + 3) / 4;  // window rows per wave (4 waves interleave rows)
 
 int g_force_direct = 0;
 
@@ -29,131 +33,132 @@ struct ActionArgs {
   int E, G, n_out, B, C;
   int H, W, pad, Hp, Wp;
   int OH, OW, top, left;
-  int tiles_x, tiles;
   float half_w, half_h, step_x, step_y;
   int force_direct;
 };
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 // torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
 __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
   return idx < (steps >> 1) ? (-1.0f + step * (float)idx) : (1.0f - step * (float)(steps - 1 - idx));
 }
 
-struct Sampler {
-  float t0, t1, t2, t3, t4, t5;
-  float half_w, half_h, step_x, step_y;
-  int Hp, Wp, OW, top, left;
-  bool flip_dst;
-  // frame-pixel source location of output pixel (i, j): affine_grid + grid_sample(align_corners=True) unnormalise
-  __device__ __forceinline__ void operator()(int i, int j, float& ix, float& iy) const {
-    const int fj = left + j;
-    const int fx = flip_dst ? (Wp - 1 - fj) : fj;
-    const int fy = top + i;
-    const float xn = lin_m1_p1(fx, Wp, step_x);
-    const float yn = lin_m1_p1(fy, Hp, step_y);
-    const float gx = t0 * xn + t1 * yn + t2;
-    const float gy = t3 * xn + t4 * yn + t5;
-    ix = (gx + 1.0f) * half_w;
-    iy = (gy + 1.0f) * half_h;
-  }
-};
+#ifndef EQA_ACTION_WAVES
+#define EQA_ACTION_WAVES 1
+#endif
+#ifndef EQA_FORCE_CH
+#define EQA_FORCE_CH 0
+#endif
 
-// One block = one 32x32 output tile of one output image, all channels (CH at a time through LDS).
-// Thread t owns 4 consecutive pixels of row t/8 -> float4 stores, 128 B per 8 lanes.
+// One block = one 32x32 output tile of one output image, all channels, CH channels per LDS stage.
+//   grid = (8 * tiles_x, tiles_y, ceil(n_out / 8)):  blockIdx.x & 7 is the XCD the dispatcher deals the block
+//   to, so each XCD works on whole images (n = 8*z + xcd) and the overlapping source windows of neighbouring
+//   tiles hit in that XCD's private L2.  No integer division anywhere in the kernel.
+// Thread t owns 4 consecutive pixels of tile row t/8 (float4 stores, 128 B per 8 lanes).
+// Sampling arithmetic = torch affine_grid + grid_sample(bilinear, zeros, align_corners=True) on the
+// (Hp, Wp) frame, the frame itself being the edge-replicated (pad) and optionally h-flipped source.
 template <int CH, bool VEC>
-__global__ __launch_bounds__(kThreads) void group_action_kernel(const ActionArgs a) {
+__global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kernel(const ActionArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kPlane = kBox * kLdsStride;
 
-  // XCD-aware decode: blocks are dealt round-robin to the 8 XCDs, so give every XCD whole images --
-  // overlapping source windows of neighbouring tiles then hit in that XCD's L2 instead of re-reading HBM.
-  const int bid = blockIdx.x;
-  const int xcd = bid & (kXcd - 1);
-  const int slot = bid >> 3;
-  const int img_local = slot / a.tiles;
-  const int tile = slot - img_local * a.tiles;
-  const int n = img_local * kXcd + xcd;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: row math stays on the SALU
+  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
   if (n >= a.n_out) return;
+  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
 
   int e, b;
   if (a.gidx) {
     e = a.gidx[n];
     b = n;
-  } else {
+  } else {  // orbit mode: element-major output, n = e * B + b
     e = n / a.B;
     b = n - e * a.B;
   }
   e = min(max(e, 0), a.E - 1);
   const int fl = a.flags ? a.flags[e] : 0;
   const float* th = a.theta + e * 6;
-  Sampler S{th[0], th[1], th[2], th[3], th[4], th[5], a.half_w, a.half_h, a.step_x, a.step_y,
-            a.Hp,  a.Wp,  a.OW,  a.top, a.left, (fl & EQA_FLIP_DST) != 0};
-  const bool flip_src = (fl & EQA_FLIP_SRC) != 0;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
 
-  const int ty = tile / a.tiles_x;
-  const int tx = tile - ty * a.tiles_x;
-  const int i0 = ty * kTile, j0 = tx * kTile;
+  // frame column of output column j (post-flip: hflip of the rotated frame, then the crop)
+  auto frame_x = [&](int j) { return flip_dst ? (a.Wp - 1 - (a.left + j)) : (a.left + j); };
+
+  // ---- source window of the tile.  The map is affine in the normalised coords, so the extremes are sums of
+  // per-axis extremes; a 1e-3 px guard covers the rounding difference to the per-pixel evaluation below.
   const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
-
-  // source window of the tile: the map is affine, so its extremes are at the 4 corners.
-  float cx[4], cy[4];
-  S(i0, j0, cx[0], cy[0]);
-  S(i0, j1, cx[1], cy[1]);
-  S(i1, j0, cx[2], cy[2]);
-  S(i1, j1, cx[3], cy[3]);
-  float minx = fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3]));
-  float maxx = fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3]));
-  float miny = fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3]));
-  float maxy = fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3]));
-  // keep one ring of out-of-frame (zero) pixels at most; guard the floor against 1-ulp wobble
-  minx = fmaxf(minx - 1e-3f, -1.0f);
-  miny = fmaxf(miny - 1e-3f, -1.0f);
-  maxx = fminf(maxx + 1e-3f, (float)(a.Wp - 1));
-  maxy = fminf(maxy + 1e-3f, (float)(a.Hp - 1));
-  const int x_lo = (int)floorf(minx), y_lo = (int)floorf(miny);
-  // at least 2x2 so that the (clamped) neighbour reads of fully off-frame pixels stay inside staged data
-  const int x_hi = max((int)floorf(maxx) + 1, x_lo + 1), y_hi = max((int)floorf(maxy) + 1, y_lo + 1);
+  const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
+  const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
+  auto fmn = [](float p, float q) { return p < q ? p : q; };
+  auto fmx = [](float p, float q) { return p > q ? p : q; };
+  const float gx_lo = fmn(t0 * xa, t0 * xb) + fmn(t1 * ya, t1 * yb) + t2;
+  const float gx_hi = fmx(t0 * xa, t0 * xb) + fmx(t1 * ya, t1 * yb) + t2;
+  const float gy_lo = fmn(t3 * xa, t3 * xb) + fmn(t4 * ya, t4 * yb) + t5;
+  const float gy_hi = fmx(t3 * xa, t3 * xb) + fmx(t4 * ya, t4 * yb) + t5;
+  const float minx_f = (gx_lo + 1.0f) * a.half_w - 1e-3f, maxx_f = (gx_hi + 1.0f) * a.half_w + 1e-3f;
+  const float miny_f = (gy_lo + 1.0f) * a.half_h - 1e-3f, maxy_f = (gy_hi + 1.0f) * a.half_h + 1e-3f;
+  // keep at most one ring of off-frame (zero) pixels
+  const int x_lo = (int)floorf(fmx(minx_f, -1.0f)), y_lo = (int)floorf(fmx(miny_f, -1.0f));
+  // at least 2x2 so the clamped neighbour reads of fully off-frame pixels stay inside staged data
+  const int x_hi = max((int)floorf(fmn(maxx_f, (float)(a.Wp - 1))) + 1, x_lo + 1);
+  const int y_hi = max((int)floorf(fmn(maxy_f, (float)(a.Hp - 1))) + 1, y_lo + 1);
   const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
   const bool use_lds = (bw <= kBox) && (bh <= kBox) && !a.force_direct;
 
-  // per-thread pixels
-  const int tid = threadIdx.x;
+  // ---- per-thread output pixels
   const int r = tid >> 3, q = tid & 7;
   const int i = i0 + r, jb = j0 + 4 * q;
-  const bool row_ok = i < a.OH;
-
   int lidx[4];         // LDS path: index of the north-west neighbour inside the staged window
   int gx0[4], gy0[4];  // direct path: frame coords of the north-west neighbour
-  bool live[4];        // false: all four neighbours are off the frame -> exact zero (never multiply garbage)
+  bool live[4];        // false: all four neighbours are off the frame -> exact zero
   float w00[4], w01[4], w10[4], w11[4];
+  auto pixel_setup = [&](int pi, int pj) {
+    const float yn = lin_m1_p1(a.top + pi, a.Hp, a.step_y);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float ix, iy;
-    S(i, jb + k, ix, iy);
-    const float xf = floorf(ix), yf = floorf(iy);
-    const float wx1 = ix - xf, wy1 = iy - yf;
-    const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-    // neighbours entirely off the frame contribute zero (grid_sample padding_mode="zeros")
-    const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
-    const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
-    live[k] = xin && yin;
-    const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
-    gx0[k] = xi;
-    gy0[k] = yi;
-    const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
-    lidx[k] = ly * kLdsStride + lx;
-    w00[k] = wy0 * wx0;  // nw
-    w01[k] = wy0 * wx1;  // ne
-    w10[k] = wy1 * wx0;  // sw
-    w11[k] = wy1 * wx1;  // se
+    for (int k = 0; k < 4; ++k) {
+      // affine_grid: [xn, yn, 1] . theta^T ; grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
+      const float xn = lin_m1_p1(frame_x(pj + k), a.Wp, a.step_x);
+      const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
+      const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+      const float xf = floorf(ix), yf = floorf(iy);
+      const float wx1 = ix - xf, wy1 = iy - yf;
+      const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+      // neighbours entirely off the frame contribute zero (grid_sample padding_mode="zeros")
+      const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+      const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+      live[k] = xin && yin;
+      const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
+      gx0[k] = xi;
+      gy0[k] = yi;
+      // (pixels of a partial tile beyond OW/OH are computed but never stored: keep their reads in the window)
+      const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
+      lidx[k] = ly * kLdsStride + lx;
+      w00[k] = wy0 * wx0;  // nw
+      w01[k] = wy0 * wx1;  // ne
+      w10[k] = wy1 * wx0;  // sw
+      w11[k] = wy1 * wx1;  // se
+    }
+  };
+
+  // the element's channel-map row (regular features) goes to LDS once
+  int* s_cmap = reinterpret_cast<int*>(smem + CH * kPlane);
+  const bool has_cmap = a.chan_map != nullptr;
+  if (has_cmap) {
+    if (tid < a.G) s_cmap[tid] = a.chan_map[e * a.G + tid];
+    __syncthreads();
   }
 
-  const size_t src_plane = (size_t)a.H * a.W;
-  const size_t dst_plane = (size_t)a.OH * a.OW;
-  const int32_t* cmap = a.chan_map ? a.chan_map + e * a.G : nullptr;
-  const float inv_bw = 1.0f / (float)bw;
-  const int box_elems = bh * bw;
+  // staging role of this thread: window column `lane`; the 4 waves interleave window rows
+  const bool col_ok = lane < bw;
+  const int col_fx = x_lo + lane;
+  const bool col_inside = (unsigned)col_fx < (unsigned)a.Wp;
+  const unsigned col_off = (unsigned)min(max((flip_src ? (a.Wp - 1 - col_fx) : col_fx) - a.pad, 0), a.W - 1) * 4u;
 
-  // frame pixel -> source value (edge-replicated pad, optional pre-flip, zero outside the frame)
+  // frame pixel -> source offset (edge-replicated pad, optional pre-flip); `inside` = not zero padding
   auto src_offset = [&](int fy, int fx, bool& inside) -> int {
     inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
     int sx = flip_src ? (a.Wp - 1 - fx) : fx;
@@ -162,32 +167,69 @@ __global__ __launch_bounds__(kThreads) void group_action_kernel(const ActionArgs
     return sy * a.W + sx;
   };
 
-  for (int c0 = 0; c0 < a.C; c0 += CH) {
-    const float* planes[CH];
+  const size_t src_plane = (size_t)a.H * a.W;
+  const size_t dst_plane = (size_t)a.OH * a.OW;
+  const bool row_ok = i < a.OH;
+
+  // plane base pointers of one stage (wave-uniform; readfirstlane makes that provable)
+  auto stage_planes = [&](int c0, const float* (&planes)[CH]) {
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
       const int c = min(c0 + cc, a.C - 1);
-      const int cs = cmap ? (c / a.G) * a.G + cmap[c % a.G] : c;
+      const int cs = __builtin_amdgcn_readfirstlane(has_cmap ? (c / a.G) * a.G + s_cmap[c % a.G] : c);
       planes[cc] = a.src + ((size_t)b * a.C + cs) * src_plane;
     }
-    float acc[CH][4];
-    if (use_lds) {
-      __syncthreads();  // previous stage's gathers are done with the window
-      for (int idx = tid; idx < box_elems; idx += kThreads) {
-        const int y = (int)(((float)idx + 0.5f) * inv_bw);
-        const int x = idx - y * bw;
-        bool inside;
-        const int off = src_offset(y_lo + y, x_lo + x, inside);
+  };
+  // Stage one window with direct-to-LDS DMA (global_load_lds_dword): each instruction moves one window-row
+  // segment L2/HBM -> LDS (LDS address = M0 row base + lane*4; global address per lane = plane + clamped row,
+  // computed on the SALU, + clamped/flipped column).  No staging VGPRs, no ds_write, no select.  Off-frame
+  // rows/columns (padding_mode="zeros") are zero-filled by the lanes/rows that own them.
+  auto stage_issue = [&](const float* const (&planes)[CH]) {
+    if (col_ok) {
+      // rolled on purpose: the DMA has no result registers, so it issues back to back anyway, and the row
+      // address math stays in-loop instead of dozens of hoisted 64-bit address pairs
+#pragma unroll 1
+      for (int y = wave; y < bh; y += 4) {
+        const int fy = y_lo + y;
+        float* lrow = smem + y * kLdsStride;
+        if (col_inside && ((unsigned)fy < (unsigned)a.Hp)) {
+          const unsigned row_off = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u;
 #pragma unroll
-        for (int cc = 0; cc < CH; ++cc) {
-          const float v = inside ? planes[cc][off] : 0.0f;
-          smem[cc * (kBox * kLdsStride) + y * kLdsStride + x] = v;
+          for (int cc = 0; cc < CH; ++cc) {
+            const char* g = reinterpret_cast<const char*>(planes[cc]) + row_off;
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + col_off), (lptr_t)(lrow + cc * kPlane), 4, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) lrow[cc * kPlane + lane] = 0.0f;
         }
       }
-      __syncthreads();
+    }
+  };
+
+  const float* planes[CH];
+  stage_planes(0, planes);
+  if (use_lds) stage_issue(planes);
+  {
+    // the per-pixel setup does not depend on the loads: it runs while the DMA is in flight.  The empty asm makes
+    // its inputs opaque here so the compiler cannot hoist the arithmetic above the DMA issue.
+    int pi = i, pj = jb;
+    asm volatile("" : "+v"(pi), "+v"(pj));
+    pixel_setup(pi, pj);
+  }
+
+  for (int c0 = 0; c0 < a.C; c0 += CH) {
+    float acc[CH][4];
+    if (use_lds) {
+      if (c0 > 0) {
+        stage_planes(c0, planes);
+        __syncthreads();  // previous stage's gathers are done with the window
+        stage_issue(planes);
+      }
+      __syncthreads();  // (hipcc drains the DMA with s_waitcnt vmcnt(0) ahead of this barrier)
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
-        const float* s = smem + cc * (kBox * kLdsStride);
+        const float* s = smem + cc * kPlane;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
@@ -197,17 +239,37 @@ __global__ __launch_bounds__(kThreads) void group_action_kernel(const ActionArgs
         }
       }
     } else {
+      // direct gather (window too large for LDS, or forced): rare fallback, same arithmetic.  Rolled loops on
+      // purpose: it must not inflate the register budget of the LDS path it shares the kernel with.
+      if (c0 > 0) stage_planes(c0, planes);
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          bool in00, in01, in10, in11;
-          const int o00 = src_offset(gy0[k], gx0[k], in00), o01 = src_offset(gy0[k], gx0[k] + 1, in01);
-          const int o10 = src_offset(gy0[k] + 1, gx0[k], in10), o11 = src_offset(gy0[k] + 1, gx0[k] + 1, in11);
-          const float nw = in00 ? planes[cc][o00] : 0.0f, ne = in01 ? planes[cc][o01] : 0.0f;
-          const float sw = in10 ? planes[cc][o10] : 0.0f, se = in11 ? planes[cc][o11] : 0.0f;
-          const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
-          acc[cc][k] = live[k] ? v : 0.0f;
+        for (int k = 0; k < 4; ++k) acc[cc][k] = 0.0f;
+      }
+#pragma unroll 1
+      for (int t = 0; t < 4 * CH; ++t) {
+        const int cc = t >> 2, k = t & 3;
+        // (dynamic k: read the per-pixel state through selects, not indexed registers)
+        const int gx = k == 0 ? gx0[0] : k == 1 ? gx0[1] : k == 2 ? gx0[2] : gx0[3];
+        const int gy = k == 0 ? gy0[0] : k == 1 ? gy0[1] : k == 2 ? gy0[2] : gy0[3];
+        const float a00 = k == 0 ? w00[0] : k == 1 ? w00[1] : k == 2 ? w00[2] : w00[3];
+        const float a01 = k == 0 ? w01[0] : k == 1 ? w01[1] : k == 2 ? w01[2] : w01[3];
+        const float a10 = k == 0 ? w10[0] : k == 1 ? w10[1] : k == 2 ? w10[2] : w10[3];
+        const float a11 = k == 0 ? w11[0] : k == 1 ? w11[1] : k == 2 ? w11[2] : w11[3];
+        const bool lv = k == 0 ? live[0] : k == 1 ? live[1] : k == 2 ? live[2] : live[3];
+        const float* pl = cc == 0 ? planes[0] : (cc == 1 ? planes[CH > 1 ? 1 : 0] : planes[CH > 2 ? 2 : 0]);
+        bool in00, in01, in10, in11;
+        const int o00 = src_offset(gy, gx, in00), o01 = src_offset(gy, gx + 1, in01);
+        const int o10 = src_offset(gy + 1, gx, in10), o11 = src_offset(gy + 1, gx + 1, in11);
+        const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
+        float v = (in00 ? v00 : 0.0f) * a00 + (in01 ? v01 : 0.0f) * a01 + (in10 ? v10 : 0.0f) * a10 + (in11 ? v11 : 0.0f) * a11;
+        v = lv ? v : 0.0f;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2)
+            if (c2 == cc && k2 == k) acc[c2][k2] = v;
         }
       }
     }
@@ -231,14 +293,15 @@ __global__ __launch_bounds__(kThreads) void group_action_kernel(const ActionArgs
 
 template <int CH>
 int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
-  const int imgs_per_xcd = (a.n_out + kXcd - 1) / kXcd;
-  const long long nblocks = (long long)kXcd * imgs_per_xcd * a.tiles;
-  if (nblocks <= 0 || nblocks > 0x7fffffffLL) return EQA_ERR_INVALID_ARG;
-  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float);
+  const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
+  const int groups = (a.n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
+  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + kMaxMapG * sizeof(int);
   if (vec)
-    hipLaunchKernelGGL((group_action_kernel<CH, true>), dim3((unsigned)nblocks), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((group_action_kernel<CH, true>), grid, dim3(kThreads), lds, st, a);
   else
-    hipLaunchKernelGGL((group_action_kernel<CH, false>), dim3((unsigned)nblocks), dim3(kThreads), lds, st, a);
+    hipLaunchKernelGGL((group_action_kernel<CH, false>), grid, dim3(kThreads), lds, st, a);
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
@@ -251,15 +314,14 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
   const int Hp = H + 2 * pad, Wp = W + 2 * pad;
   if (Hp < 2 || Wp < 2 || top + OH > Hp || left + OW > Wp) return EQA_ERR_INVALID_ARG;
   if (chan_map && (G <= 0 || C % G != 0)) return EQA_ERR_INVALID_ARG;
-  if ((long long)H * W > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
+  if (chan_map && G > kMaxMapG) return EQA_ERR_UNSUPPORTED;
+  if ((long long)H * W >= (1LL << 30) || (long long)OH * OW >= (1LL << 30)) return EQA_ERR_UNSUPPORTED;  // 32-bit byte offsets
   if (n_out == 0) return EQA_OK;
   ActionArgs a;
   a.src = src; a.dst = dst; a.gidx = gidx; a.theta = theta; a.flags = flags; a.chan_map = chan_map;
   a.E = E; a.G = chan_map ? G : 1; a.n_out = n_out; a.B = B; a.C = C;
   a.H = H; a.W = W; a.pad = pad; a.Hp = Hp; a.Wp = Wp;
   a.OH = OH; a.OW = OW; a.top = top; a.left = left;
-  a.tiles_x = (OW + kTile - 1) / kTile;
-  a.tiles = a.tiles_x * ((OH + kTile - 1) / kTile);
   a.half_w = (float)(Wp - 1) / 2.0f;
   a.half_h = (float)(Hp - 1) / 2.0f;
   a.step_x = 2.0f / (float)(Wp - 1);
@@ -267,9 +329,13 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
   a.force_direct = g_force_direct;
   const bool vec = (OW % 4 == 0) && (((uintptr_t)dst & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
+#if EQA_FORCE_CH
+  return launch_action_ch<EQA_FORCE_CH>(a, vec, st);
+#else
   if (C % 3 == 0) return launch_action_ch<3>(a, vec, st);
   if (C % 2 == 0) return launch_action_ch<2>(a, vec, st);
   return launch_action_ch<1>(a, vec, st);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

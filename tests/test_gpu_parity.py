@@ -185,7 +185,8 @@ def test_lds_and_direct_paths_agree(dev):
         b = ops.canon_transform(x, gidx, theta, flags, 48)
     finally:
         lib.eqa_set_option(0, 0)
-    assert torch.equal(a, b)
+    # same arithmetic, but the compiler contracts the four multiply-adds differently in the two branches
+    assert (a - b).abs().max().item() <= 2e-6
 
 
 def test_c4_is_rot90_and_identity_element(dev):
@@ -200,19 +201,21 @@ def test_c4_is_rot90_and_identity_element(dev):
         gidx = torch.full((64,), k, device=dev, dtype=torch.int32)
         y = ops.canon_transform(x, gidx, theta, flags, 112)
         # canonicalize rotates by -angle: element k undoes a +k*90 deg rotation == rot90(k=-k)
-        assert (y - torch.rot90(x, -k, (-2, -1))).abs().max().item() <= 1e-4
+        # white noise: the reference's own cos(90 deg) = -4.4e-8 and grid rounding move samples by ~3e-5 px
+        assert (y - torch.rot90(x, -k, (-2, -1))).abs().max().item() <= PIX_MAX
     # invert(canonicalize(x)) == x on the inscribed disc (C8, scalar features)
     th_c, fl_c = device_tables("canonicalize", 8, False, (448, 448), dev)
     th_i, fl_i, _ = device_tables("invert", 8, False, (224, 224), dev)
     gidx = (torch.arange(64, device=dev) % 8).to(torch.int32)
-    xs = torch.nn.functional.avg_pool2d(x, 9, 1, 4)
-    back = ops.invert_action(ops.canon_transform(xs, gidx, th_c, fl_c, 112), gidx, th_i, fl_i, None)
     yy, xx = torch.meshgrid(torch.arange(224.0, device=dev), torch.arange(224.0, device=dev), indexing="ij")
+    # a smooth analytic image (curvature ~2.5e-3 / px^2): bilinear resampling error ~ curvature / 8 per pass
+    base = torch.sin(0.05 * xx + 0.3) * torch.cos(0.04 * yy) + 0.01 * xx
+    xs = (base[None, None] * torch.linspace(0.5, 1.5, 64 * 3, device=dev).view(64, 3, 1, 1)).contiguous()
+    back = ops.invert_action(ops.canon_transform(xs, gidx, th_c, fl_c, 112), gidx, th_i, fl_i, None)
     disc = ((yy - 111.5) ** 2 + (xx - 111.5) ** 2) < 105.0**2
-    # two bilinear passes at 45 deg blur a smooth image slightly; exact for the 90-deg elements
     err = ((back - xs).abs() * disc).amax(dim=(1, 2, 3))
-    assert err[gidx.long() % 2 == 0].max().item() <= 1e-4
-    assert err.max().item() <= 0.05
+    assert err[gidx.long() % 2 == 0].max().item() <= 1e-4   # multiples of 90 deg: a permutation
+    assert err.max().item() <= 2e-3                          # 45 deg: two bilinear passes of a smooth image
 
 
 def test_group_pool_argmax(dev):

@@ -1,0 +1,69 @@
+"""Kernel micro-benchmarks (HIP events) for tuning: python tools/kbench.py [--batch 256] [--reps 30]."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from equiadapt_amd import ops  # noqa: E402
+from equiadapt_amd.images.utils import device_tables  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--hw", type=int, default=224)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, S = args.batch, args.hw
+    x = torch.randn(B, 3, S, S, device=dev)
+    y = torch.empty_like(x)
+    th_c, fl_c = device_tables("canonicalize", 8, False, (2 * S, 2 * S), dev)
+    th_i, fl_i, cm_i = device_tables("invert", 8, False, (S, S), dev)
+    nbytes = 2 * x.numel() * 4
+    ms = timeit(lambda: y.copy_(x), args.reps)
+    print(f"torch copy_ (reference stream)      {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    for name, g in [("all 0 deg", torch.zeros(B)), ("all 45 deg", torch.ones(B)), ("all 90 deg", torch.full((B,), 2)),
+                    ("random C8", torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)))]:
+        gidx = g.to(dev, torch.int32)
+        ms = timeit(lambda: ops.canon_transform(x, gidx, th_c, fl_c, S // 2), args.reps)
+        print(f"canon_transform  {name:12s}       {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s  {B/ms*1e3:10.0f} img/s")
+        ms = timeit(lambda: ops.invert_action(x, gidx, th_i, fl_i, None), args.reps)
+        print(f"invert scalar    {name:12s}       {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s  {B/ms*1e3:10.0f} img/s")
+    gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
+    f8 = torch.randn(B, 8, S, S, device=dev)
+    ms = timeit(lambda: ops.invert_action(f8, gidx, th_i, fl_i, cm_i), args.reps)
+    print(f"invert regular C=8 random            {ms*1e3:8.1f} us  {2*f8.numel()*4/ms/1e6:8.1f} GB/s")
+    from equiadapt_amd import _lib
+    _lib.load().eqa_set_option(0, 1)
+    ms = timeit(lambda: ops.canon_transform(x, gidx, th_c, fl_c, S // 2), args.reps)
+    print(f"canon_transform  random, DIRECT path {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    _lib.load().eqa_set_option(0, 0)
+    fm = torch.randn(B, 32, 8, 84, 84, device=dev)
+    ms = timeit(lambda: ops.group_pool_argmax(fm), args.reps)
+    print(f"group_pool_argmax (B,32,8,84,84)     {ms*1e3:8.1f} us  {fm.numel()*4/ms/1e6:8.1f} GB/s")
+    ms = timeit(lambda: torch.mean(fm, dim=(1, 3, 4)), args.reps)
+    print(f"torch.mean same                      {ms*1e3:8.1f} us  {fm.numel()*4/ms/1e6:8.1f} GB/s")
+    pc = torch.randn(4096, 3, 1024, device=dev)
+    R = torch.randn(4096, 3, 3, device=dev)
+    ms = timeit(lambda: ops.so3_rotate(pc, R), args.reps)
+    print(f"so3_rotate (4096,3,1024)             {ms*1e3:8.1f} us  {2*pc.numel()*4/ms/1e6:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
