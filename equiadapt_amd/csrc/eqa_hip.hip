@@ -15,8 +15,9 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kTile = 32;      // output tile edge (px): 256 threads x 4 px
-constexpr int kBox = 50;       // staged source window edge: 31*sqrt(2) + neighbour + guard < 50
-constexpr int kLdsStride = 51; // odd dword stride: the 8x4-lane gather pattern is bank-conflict-free at 0/90/180/270 deg
+constexpr int kBox = 47;       // staged source window edge: floor(31*sqrt(2)) + neighbour + floor/guard slack = 47
+constexpr int kLdsStride = 47; // odd dword stride: the 8x4-lane gather pattern is bank-conflict-free at 0/90/180/270 deg
+                               // 3 channels x 47 x 47 x 4 B = 26.5 KB -> 6 blocks per CU (160 KB LDS)
 constexpr int kXcd = 8;
 constexpr int kMaxMapG = 64;   // channel-map row cached in LDS
 constexpr int kRowIters = (kBox + 3) / 4;  // window rows per wave (4 waves interleave rows)
@@ -41,8 +42,12 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 // torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
+// Written select-style (one integer select, one fma-shaped op, one select) so it stays branch-free.
 __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
-  return idx < (steps >> 1) ? (-1.0f + step * (float)idx) : (1.0f - step * (float)(steps - 1 - idx));
+  const bool lo = idx < (steps >> 1);
+  const float k = (float)(lo ? idx : steps - 1 - idx);
+  const float up = -1.0f + step * k, dn = 1.0f - step * k;
+  return lo ? up : dn;
 }
 
 #ifndef EQA_ACTION_WAVES
@@ -167,44 +172,84 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
     return sy * a.W + sx;
   };
 
-  const size_t src_plane = (size_t)a.H * a.W;
-  const size_t dst_plane = (size_t)a.OH * a.OW;
+  const unsigned src_plane = (unsigned)(a.H * a.W);
+  const unsigned dst_plane = (unsigned)(a.OH * a.OW);
   const bool row_ok = i < a.OH;
+  float* const dst_img = a.dst + (size_t)n * ((size_t)a.C * dst_plane);
 
   // plane base pointers of one stage (wave-uniform; readfirstlane makes that provable)
+  const float* const src_img = a.src + (size_t)b * ((size_t)a.C * src_plane);  // one 64-bit multiply per block
   auto stage_planes = [&](int c0, const float* (&planes)[CH]) {
 #pragma unroll
     for (int cc = 0; cc < CH; ++cc) {
       const int c = min(c0 + cc, a.C - 1);
       const int cs = __builtin_amdgcn_readfirstlane(has_cmap ? (c / a.G) * a.G + s_cmap[c % a.G] : c);
-      planes[cc] = a.src + ((size_t)b * a.C + cs) * src_plane;
+      planes[cc] = src_img + (unsigned)cs * (unsigned)src_plane;  // C*H*W < 2^30 (checked on the host)
     }
   };
   // Stage one window with direct-to-LDS DMA (global_load_lds_dword): each instruction moves one window-row
-  // segment L2/HBM -> LDS (LDS address = M0 row base + lane*4; global address per lane = plane + clamped row,
-  // computed on the SALU, + clamped/flipped column).  No staging VGPRs, no ds_write, no select.  Off-frame
-  // rows/columns (padding_mode="zeros") are zero-filled by the lanes/rows that own them.
+  // segment L2/HBM -> LDS.  LDS address = M0 (row base, per channel) + lane*4; global address = plane (SGPR
+  // pair, saddr form) + [clamped row offset (SALU) + clamped/flipped column offset] (one VGPR add per row, shared
+  // by the CH channels).  No staging VGPRs, no ds_write, no select, no 64-bit address VALU.
+  // Off-frame rows/columns (padding_mode="zeros") are zero-filled afterwards by the lanes/rows that own them;
+  // those never issue a DMA, so there is no ordering problem.
+  // Inline asm because hipcc will not pick the saddr form for the builtin.  It does not count these loads:
+  // stage_wait() below is the s_waitcnt.  M0 is saved/restored inside the statement (cdna guide 5.7).
+  const bool lane_dma = col_ok && col_inside;
+  const bool any_zero = (x_lo < 0) || (y_lo < 0) || (x_hi > a.Wp - 1) || (y_hi > a.Hp - 1);
   auto stage_issue = [&](const float* const (&planes)[CH]) {
-    if (col_ok) {
-      // rolled on purpose: the DMA has no result registers, so it issues back to back anyway, and the row
-      // address math stays in-loop instead of dozens of hoisted 64-bit address pairs
+    if (lane_dma) {
+      // window rows inside the frame: [ya, yb); this wave takes ya + ((wave - ya) mod 4), +4, ...
+      const int ya = max(-y_lo, 0), yb = min(bh, a.Hp - y_lo);
 #pragma unroll 1
-      for (int y = wave; y < bh; y += 4) {
+      for (int y = ya + ((wave - ya) & 3); y < yb; y += 4) {
         const int fy = y_lo + y;
-        float* lrow = smem + y * kLdsStride;
-        if (col_inside && ((unsigned)fy < (unsigned)a.Hp)) {
-          const unsigned row_off = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u;
-#pragma unroll
-          for (int cc = 0; cc < CH; ++cc) {
-            const char* g = reinterpret_cast<const char*>(planes[cc]) + row_off;
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + col_off), (lptr_t)(lrow + cc * kPlane), 4, 0, 0);
+        {
+          const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
+          const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * kLdsStride);
+          unsigned keep;
+          if (CH == 1) {
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                "s_mov_b32 m0, %[keep]"
+                : [keep] "=&s"(keep)
+                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0])
+                : "memory");
+          } else if (CH == 2) {
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                "s_add_u32 m0, %[l], %[pb]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p1]\n\t"
+                "s_mov_b32 m0, %[keep]"
+                : [keep] "=&s"(keep)
+                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0]), [p1] "s"(planes[CH > 1 ? 1 : 0]), [pb] "i"(kPlane * 4)
+                : "memory", "scc");
+          } else {
+            asm volatile(
+                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                "s_add_u32 m0, %[l], %[pb]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p1]\n\t"
+                "s_add_u32 m0, %[l], %[pb2]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p2]\n\t"
+                "s_mov_b32 m0, %[keep]"
+                : [keep] "=&s"(keep)
+                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0]), [p1] "s"(planes[CH > 1 ? 1 : 0]),
+                  [p2] "s"(planes[CH > 2 ? 2 : 0]), [pb] "i"(kPlane * 4), [pb2] "i"(kPlane * 8)
+                : "memory", "scc");
           }
-        } else {
-#pragma unroll
-          for (int cc = 0; cc < CH; ++cc) lrow[cc * kPlane + lane] = 0.0f;
         }
       }
     }
+    if (any_zero && col_ok) {  // rare: tiles touching the zero ring of an unpadded frame
+#pragma unroll 1
+      for (int y = wave; y < bh; y += 4) {
+        if (!(col_inside && ((unsigned)(y_lo + y) < (unsigned)a.Hp))) {
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) smem[cc * kPlane + y * kLdsStride + lane] = 0.0f;
+        }
+      }
+    }
+  };
+  auto stage_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed in LDS
+    __syncthreads();                                   // ... and so has every other wave's
   };
 
   const float* planes[CH];
@@ -226,7 +271,7 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
         __syncthreads();  // previous stage's gathers are done with the window
         stage_issue(planes);
       }
-      __syncthreads();  // (hipcc drains the DMA with s_waitcnt vmcnt(0) ahead of this barrier)
+      stage_wait();
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
         const float* s = smem + cc * kPlane;
@@ -277,9 +322,9 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
         if (c0 + cc < a.C) {
-          float* o = a.dst + ((size_t)n * a.C + (c0 + cc)) * dst_plane + (size_t)i * a.OW + jb;
-          if (VEC && jb + 3 < a.OW) {
-            *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+          float* o = dst_img + (unsigned)(c0 + cc) * dst_plane + (unsigned)(i * a.OW + jb);
+          if (VEC) {  // OW % 4 == 0 and jb % 4 == 0: a pixel quad is entirely inside or entirely outside the row
+            if (jb < a.OW) *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -297,7 +342,7 @@ int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   const int groups = (a.n_out + kXcd - 1) / kXcd;
   if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
-  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + kMaxMapG * sizeof(int);
+  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + (a.chan_map ? kMaxMapG * sizeof(int) : 0);
   if (vec)
     hipLaunchKernelGGL((group_action_kernel<CH, true>), grid, dim3(kThreads), lds, st, a);
   else
@@ -315,7 +360,7 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
   if (Hp < 2 || Wp < 2 || top + OH > Hp || left + OW > Wp) return EQA_ERR_INVALID_ARG;
   if (chan_map && (G <= 0 || C % G != 0)) return EQA_ERR_INVALID_ARG;
   if (chan_map && G > kMaxMapG) return EQA_ERR_UNSUPPORTED;
-  if ((long long)H * W >= (1LL << 30) || (long long)OH * OW >= (1LL << 30)) return EQA_ERR_UNSUPPORTED;  // 32-bit byte offsets
+  if ((long long)C * H * W >= (1LL << 30) || (long long)C * OH * OW >= (1LL << 30)) return EQA_ERR_UNSUPPORTED;  // 32-bit offsets inside one image
   if (n_out == 0) return EQA_OK;
   ActionArgs a;
   a.src = src; a.dst = dst; a.gidx = gidx; a.theta = theta; a.flags = flags; a.chan_map = chan_map;
