@@ -36,6 +36,10 @@ struct ActionArgs {
   int OH, OW, top, left;
   float half_w, half_h, step_x, step_y;
   int force_direct;
+  // backward only
+  const float* gout;  // dL/d(output), shape of dst
+  float* gsrc;        // dL/d(source), shape of src, pre-zeroed (nullable)
+  float* partial;     // per (output image, tile) partial of dL/d(angle [rad]) (nullable)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -48,6 +52,12 @@ __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
   const float k = (float)(lo ? idx : steps - 1 - idx);
   const float up = -1.0f + step * k, dn = 1.0f - step * k;
   return lo ? up : dn;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
 }
 
 #ifndef EQA_ACTION_WAVES
@@ -336,6 +346,121 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the group action.  y[n,c,i,j] = sum_k w_k(phi) * frame[c, nbr_k(i,j; phi)]  (bilinear, 4 neighbours)
+//   ANGLE: dL/dphi = sum gy * (dy/dix * dix/dphi + dy/diy * diy/dphi), with the source point rotating about the frame
+//          centre c:  s = c + R(phi)^-1 (dst - c)  =>  ds/dphi = (-(s_y - c_y), s_x - c_x)  [per radian],
+//          dy/dix = wy0 (ne - nw) + wy1 (se - sw),  dy/diy = wx0 (sw - nw) + wx1 (se - ne)
+//          (what autograd derives through kornia's rotation-matrix -> affine_grid -> grid_sample chain,
+//          discrete_group.py:213 / images/utils.py:57).  One partial per (output image, tile): deterministic.
+//   INPUT: adjoint of the gather: scatter gy * w_k to the (clamped = replicate-pad adjoint, flipped, channel-mapped)
+//          source pixels with hardware float atomics (same approach as torch's grid_sampler backward).
+// Same grid decomposition as the forward kernel; direct gathers (L1/L2), no LDS staging: correctness first.
+template <bool ANGLE, bool INPUT>
+__global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const ActionArgs a) {
+  __shared__ float s_red[4];
+  const int tid = threadIdx.x;
+  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
+  if (n >= a.n_out) return;
+  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
+  int e, b;
+  if (a.gidx) {
+    e = a.gidx[n];
+    b = n;
+  } else {
+    e = n / a.B;
+    b = n - e * a.B;
+  }
+  e = min(max(e, 0), a.E - 1);
+  const int fl = a.flags ? a.flags[e] : 0;
+  const float* th = a.theta + e * 6;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+  const float cx = a.half_w, cy = a.half_h;  // frame centre ((Wp-1)/2, (Hp-1)/2)
+
+  const int r = tid >> 3, q = tid & 7;
+  const int i = i0 + r, jb = j0 + 4 * q;
+  const bool row_ok = i < a.OH;
+  int gx0[4], gy0[4];
+  bool live[4];
+  float wx1[4], wy1[4], armx[4], army[4];
+  const float yn = lin_m1_p1(a.top + i, a.Hp, a.step_y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int fj = a.left + jb + k;
+    const float xn = lin_m1_p1(flip_dst ? (a.Wp - 1 - fj) : fj, a.Wp, a.step_x);
+    const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
+    const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+    const float xf = floorf(ix), yf = floorf(iy);
+    wx1[k] = ix - xf;
+    wy1[k] = iy - yf;
+    const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+    const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+    live[k] = xin && yin && row_ok && (jb + k < a.OW);
+    gx0[k] = xin ? (int)xf : -1;
+    gy0[k] = yin ? (int)yf : -1;
+    armx[k] = -(iy - cy);
+    army[k] = ix - cx;
+  }
+  auto src_offset = [&](int fy, int fx, bool& inside) -> int {
+    inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
+    int sx = flip_src ? (a.Wp - 1 - fx) : fx;
+    sx = min(max(sx - a.pad, 0), a.W - 1);
+    const int sy = min(max(fy - a.pad, 0), a.H - 1);
+    return sy * a.W + sx;
+  };
+  int off[4][4];
+  bool in[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    off[k][0] = src_offset(gy0[k], gx0[k], in[k][0]);
+    off[k][1] = src_offset(gy0[k], gx0[k] + 1, in[k][1]);
+    off[k][2] = src_offset(gy0[k] + 1, gx0[k], in[k][2]);
+    off[k][3] = src_offset(gy0[k] + 1, gx0[k] + 1, in[k][3]);
+  }
+
+  const unsigned src_plane = (unsigned)(a.H * a.W), dst_plane = (unsigned)(a.OH * a.OW);
+  const size_t img_off = (size_t)b * ((size_t)a.C * src_plane);
+  const float* const src_img = a.src + img_off;
+  const float* const gout_img = a.gout + (size_t)n * ((size_t)a.C * dst_plane);
+  float sum = 0.0f;
+#pragma unroll 1
+  for (int c = 0; c < a.C; ++c) {
+    const int cs = a.chan_map ? (c / a.G) * a.G + a.chan_map[e * a.G + c % a.G] : c;
+    const float* pl = src_img + (unsigned)cs * src_plane;
+    const float* go = gout_img + (unsigned)c * dst_plane + (unsigned)(i * a.OW + jb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!live[k]) continue;
+      const float g = go[k];
+      const float wx0 = 1.0f - wx1[k], wy0 = 1.0f - wy1[k];
+      if (ANGLE) {
+        const float nw = in[k][0] ? pl[off[k][0]] : 0.0f, ne = in[k][1] ? pl[off[k][1]] : 0.0f;
+        const float sw = in[k][2] ? pl[off[k][2]] : 0.0f, se = in[k][3] ? pl[off[k][3]] : 0.0f;
+        const float dix = wy0 * (ne - nw) + wy1[k] * (se - sw);
+        const float diy = wx0 * (sw - nw) + wx1[k] * (se - ne);
+        sum += g * (dix * armx[k] + diy * army[k]);
+      }
+      if (INPUT) {
+        float* gp = a.gsrc + img_off + (size_t)cs * src_plane;
+        if (in[k][0]) unsafeAtomicAdd(gp + off[k][0], g * wy0 * wx0);
+        if (in[k][1]) unsafeAtomicAdd(gp + off[k][1], g * wy0 * wx1[k]);
+        if (in[k][2]) unsafeAtomicAdd(gp + off[k][2], g * wy1[k] * wx0);
+        if (in[k][3]) unsafeAtomicAdd(gp + off[k][3], g * wy1[k] * wx1[k]);
+      }
+    }
+  }
+  if (ANGLE) {
+    sum = wave_sum_f(sum);
+    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      const int tiles_x = (int)(gridDim.x >> 3);
+      a.partial[((size_t)n * gridDim.y + blockIdx.y) * tiles_x + (blockIdx.x >> 3)] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+  }
+}
+
 template <int CH>
 int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
@@ -350,19 +475,17 @@ int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
-int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
-                  const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
-                  int OW, int top, int left, void* stream) {
-  if (!src || !dst || !theta || E <= 0 || n_out < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 ||
-      OH <= 0 || OW <= 0 || top < 0 || left < 0)
+int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t* gidx, const float* theta,
+                     const int32_t* flags, const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W,
+                     int pad, int OH, int OW, int top, int left) {
+  if (!src || !theta || E <= 0 || n_out < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 || OH <= 0 || OW <= 0 ||
+      top < 0 || left < 0)
     return EQA_ERR_INVALID_ARG;
   const int Hp = H + 2 * pad, Wp = W + 2 * pad;
   if (Hp < 2 || Wp < 2 || top + OH > Hp || left + OW > Wp) return EQA_ERR_INVALID_ARG;
   if (chan_map && (G <= 0 || C % G != 0)) return EQA_ERR_INVALID_ARG;
   if (chan_map && G > kMaxMapG) return EQA_ERR_UNSUPPORTED;
   if ((long long)C * H * W >= (1LL << 30) || (long long)C * OH * OW >= (1LL << 30)) return EQA_ERR_UNSUPPORTED;  // 32-bit offsets inside one image
-  if (n_out == 0) return EQA_OK;
-  ActionArgs a;
   a.src = src; a.dst = dst; a.gidx = gidx; a.theta = theta; a.flags = flags; a.chan_map = chan_map;
   a.E = E; a.G = chan_map ? G : 1; a.n_out = n_out; a.B = B; a.C = C;
   a.H = H; a.W = W; a.pad = pad; a.Hp = Hp; a.Wp = Wp;
@@ -372,6 +495,18 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
   a.step_x = 2.0f / (float)(Wp - 1);
   a.step_y = 2.0f / (float)(Hp - 1);
   a.force_direct = g_force_direct;
+  a.gout = nullptr; a.gsrc = nullptr; a.partial = nullptr;
+  return EQA_OK;
+}
+
+int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                  const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
+                  int OW, int top, int left, void* stream) {
+  if (!dst) return EQA_ERR_INVALID_ARG;
+  ActionArgs a;
+  const int rc = fill_action_args(a, src, dst, gidx, theta, flags, chan_map, E, G, n_out, B, C, H, W, pad, OH, OW, top, left);
+  if (rc != EQA_OK) return rc;
+  if (n_out == 0) return EQA_OK;
   const bool vec = (OW % 4 == 0) && (((uintptr_t)dst & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
 #if EQA_FORCE_CH
@@ -592,6 +727,36 @@ int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int
   if ((long long)num_elements * B > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
   return launch_action(x, y, nullptr, theta, flags, nullptr, num_elements, 1, num_elements * B, B, C, S, S, pad, S, S,
                        pad, pad, stream);
+}
+
+int eqa_group_action_bwd_tiles(int OH, int OW) {
+  if (OH <= 0 || OW <= 0) return 0;
+  return ((OH + kTile - 1) / kTile) * ((OW + kTile - 1) / kTile);
+}
+
+int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                         const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
+                         int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                         int top, int left, void* stream) {
+  if (!grad_out || (!grad_src && !grad_angle_partial)) return EQA_ERR_INVALID_ARG;
+  ActionArgs a;
+  const int rc = fill_action_args(a, src, nullptr, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad,
+                                  OH, OW, top, left);
+  if (rc != EQA_OK) return rc;
+  if (n_out == 0) return EQA_OK;
+  a.gout = grad_out; a.gsrc = grad_src; a.partial = grad_angle_partial;
+  const int tiles_x = (OW + kTile - 1) / kTile, tiles_y = (OH + kTile - 1) / kTile;
+  const int groups = (n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (grad_src && grad_angle_partial)
+    hipLaunchKernelGGL((group_action_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_angle_partial)
+    hipLaunchKernelGGL((group_action_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((group_action_bwd_kernel<false, true>), grid, dim3(kThreads), 0, st, a);
+  return launch_status();
 }
 
 int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {

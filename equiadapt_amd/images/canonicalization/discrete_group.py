@@ -32,17 +32,38 @@ from equiadapt_amd.images.utils import (
 
 
 class _CanonTransformFn(torch.autograd.Function):
-    """y = crop(rotate(flip?(pad(x)), -rotation)).  Forward: fused HIP kernel driven by the int index."""
+    """y = crop(rotate(flip?(pad(x)), -rotation)).
+
+    Forward: the fused HIP kernel, driven by the int32 element index (``rotation`` / ``reflection`` are the
+    reference's straight-through tensors and only matter for autograd).  Backward (eqa_group_action_bwd):
+    d/d rotation -- the path through which the task loss trains the canonicalizer in the reference (autograd
+    through kornia's grid, discrete_group.py:213) --, d/d x, and d/d reflection = <g, T(hflip x) - T(x)>.
+    """
 
     @staticmethod
-    def forward(ctx, x, rotation, reflection, gidx, theta, flags, pad):
+    def forward(ctx, x, rotation, reflection, gidx, theta, flags, pad, num_rotations):
+        ctx.save_for_backward(x, gidx, theta, flags if flags is not None else torch.empty(0))
+        ctx.pad, ctx.num_rotations, ctx.has_flags = pad, num_rotations, flags is not None
         return ops.canon_transform(x, gidx, theta, flags, pad)
 
     @staticmethod
     def backward(ctx, grad_y):
-        raise NotImplementedError(
-            "backward through the canonicalizing transform (d/d-angle and d/d-input kernels) is not built "
-            "yet; train the canonicalizer with the prior loss or run under torch.no_grad()")
+        x, gidx, theta, flags = ctx.saved_tensors
+        flags = flags if ctx.has_flags else None
+        pad, N = ctx.pad, ctx.num_rotations
+        need_x, need_rot, need_ref = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        grad_y = grad_y.contiguous()
+        gx = g_rot = g_ref = None
+        if need_x or need_rot:
+            gx, g_ang = ops.group_action_bwd(x, grad_y, gidx, theta, flags, None, pad, (pad, pad), need_x, need_rot)
+            if need_rot:
+                g_rot = -g_ang  # the kernel differentiates w.r.t. the rotate() angle, which is -rotation here
+        if need_ref:
+            ridx = gidx % N
+            y0 = ops.canon_transform(x, ridx, theta, flags, pad)
+            y1 = ops.canon_transform(x, ridx + N, theta, flags, pad)
+            g_ref = (grad_y * (y1 - y0)).sum(dim=(1, 2, 3))
+        return gx, g_rot, g_ref, None, None, None, None, None
 
 
 class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
@@ -135,7 +156,8 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
         H, W = x.shape[-2:]
         pad = self.pad_size
         theta, flags = device_tables("canonicalize", self.num_rotations, reflections, (H + 2 * pad, W + 2 * pad), x.device)
-        x = _CanonTransformFn.apply(x, element["rotation"], element.get("reflection"), gidx, theta, flags, pad)
+        x = _CanonTransformFn.apply(x, element["rotation"], element.get("reflection"), gidx, theta, flags, pad,
+                                    self.num_rotations)
 
         if targets:
             # boxes and masks follow the image (reference :217-236).  NOTE (reference behaviour kept): when the
@@ -224,7 +246,7 @@ class OptimizedGroupEquivariantImageCanonicalization(DiscreteGroupImageCanonical
         pad = self.group_augment_pad
         theta, flags = device_tables("orbit", self.num_rotations, self.group_type == "roto-reflection",
                                      (s + 2 * pad, s + 2 * pad), x.device)
-        return ops.orbit_expand(x.detach() if not x.requires_grad else x, theta, flags, pad)
+        return ops.orbit_expand(x, theta, flags, pad)
 
     def _rotate_batch(self, x: torch.Tensor, rot_index: torch.Tensor, sign: float) -> torch.Tensor:
         """pad -> rotate(sign * index * 360/N) -> crop for a per-image rotation index (artifact branch)."""

@@ -43,15 +43,35 @@ def group_index_from_element(group_element_dict: dict, num_rotations: int) -> to
 
 
 class _InvertActionFn(torch.autograd.Function):
+    """out = roll(flip?(rotate(f, +rotation))).  Backward: adjoint scatter for d/d f (the prediction network's output
+    usually needs it), d/d rotation, and d/d reflection = <g, out(r=1) - out(r=0)> (see _CanonTransformFn)."""
+
     @staticmethod
-    def forward(ctx, feature_map, gidx, theta, flags, chan_map):
+    def forward(ctx, feature_map, rotation, reflection, gidx, theta, flags, chan_map, num_rotations):
+        none = torch.empty(0)
+        ctx.save_for_backward(feature_map, gidx, theta, flags if flags is not None else none,
+                              chan_map if chan_map is not None else none)
+        ctx.has = (flags is not None, chan_map is not None)
+        ctx.num_rotations = num_rotations
         return ops.invert_action(feature_map, gidx, theta, flags, chan_map)
 
     @staticmethod
     def backward(ctx, grad_out):
-        raise NotImplementedError(
-            "backward through invert_canonicalization (adjoint resampling kernel) is not built yet; "
-            "call it under torch.no_grad() / on detached outputs")
+        f, gidx, theta, flags, chan_map = ctx.saved_tensors
+        flags = flags if ctx.has[0] else None
+        chan_map = chan_map if ctx.has[1] else None
+        N = ctx.num_rotations
+        need_f, need_rot, need_ref = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
+        grad_out = grad_out.contiguous()
+        gf = g_rot = g_ref = None
+        if need_f or need_rot:
+            gf, g_rot = ops.group_action_bwd(f, grad_out, gidx, theta, flags, chan_map, 0, (0, 0), need_f, need_rot)
+        if need_ref:
+            ridx = gidx % N
+            o0 = ops.invert_action(f, ridx, theta, flags, chan_map)
+            o1 = ops.invert_action(f, ridx + N, theta, flags, chan_map)
+            g_ref = (grad_out * (o1 - o0)).sum(dim=(1, 2, 3))
+        return gf, g_rot, g_ref, None, None, None, None, None
 
 
 def get_action_on_image_features(feature_map: torch.Tensor, group_info_dict: dict, group_element_dict: dict,
@@ -78,7 +98,8 @@ def get_action_on_image_features(feature_map: torch.Tensor, group_info_dict: dic
     else:
         chan_map = None
     gidx = group_index_from_element(group_element_dict, num_rotations)
-    return _InvertActionFn.apply(feature_map, gidx, theta, flags, chan_map)
+    return _InvertActionFn.apply(feature_map, group_element_dict.get("rotation"), group_element_dict.get("reflection"),
+                                 gidx, theta, flags, chan_map, num_rotations)
 
 
 def roll_by_gather(feature_map: torch.Tensor, shifts: torch.Tensor) -> torch.Tensor:

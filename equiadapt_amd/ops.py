@@ -104,6 +104,47 @@ def group_action(
     return dst
 
 
+def group_action_bwd(
+    src: torch.Tensor,
+    grad_out: torch.Tensor,
+    gidx: Optional[torch.Tensor],
+    theta: torch.Tensor,
+    flags: Optional[torch.Tensor],
+    chan_map: Optional[torch.Tensor],
+    pad: int,
+    top_left: Tuple[int, int],
+    want_src: bool,
+    want_angle: bool,
+) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """Backward of ``group_action`` (eqa_group_action_bwd).
+
+    Returns (dL/d src or None, dL/d angle or None); the angle gradient is per output image and w.r.t. the
+    ``angle`` argument IN DEGREES of the ``rotate(img, angle)`` that ``theta`` encodes.
+    """
+    lib = _lib.load()
+    src = _need(src, "src")
+    grad_out = _need(grad_out, "grad_out")
+    theta = _need(theta, "theta")
+    B, C, H, W = src.shape
+    n_out, C2, OH, OW = grad_out.shape
+    assert C2 == C
+    E = theta.shape[0]
+    gidx, p_gidx = _opt(gidx, "gidx", torch.int32)
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    chan_map, p_map = _opt(chan_map, "chan_map", torch.int32)
+    G = chan_map.shape[1] if chan_map is not None else 1
+    g_src = torch.zeros_like(src) if want_src else None
+    tiles = lib.eqa_group_action_bwd_tiles(OH, OW)
+    partial = torch.empty((n_out, tiles), dtype=torch.float32, device=src.device) if want_angle else None
+    with torch.cuda.device(src.device):
+        st = lib.eqa_group_action_bwd(src.data_ptr(), grad_out.data_ptr(), p_gidx, theta.data_ptr(), p_flags, p_map,
+                                      g_src.data_ptr() if want_src else None, partial.data_ptr() if want_angle else None,
+                                      E, G, n_out, B, C, H, W, pad, OH, OW, top_left[0], top_left[1], _stream())
+    _lib.check(st, "eqa_group_action_bwd")
+    g_angle = partial.sum(dim=1) * (3.141592653589793 / 180.0) if want_angle else None
+    return g_src, g_angle
+
+
 def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int) -> torch.Tensor:
     """I5: fused pad(edge) -> [hflip] -> rotate -> center-crop (eqa_canon_transform_fwd)."""
     lib = _lib.load()

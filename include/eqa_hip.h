@@ -95,6 +95,24 @@ int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, cons
                          int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream);
 
 /*
+ * Backward of eqa_group_action_fwd (and so of I5 / I7 / I8), what the reference obtains from autograd through
+ * K.geometry.rotate (discrete_group.py:213, images/utils.py:57,82):
+ *   grad_src            dL/d(src), shape of src, MUST be zero-filled by the caller; accumulated with float atomics
+ *                       (NULL = not wanted);
+ *   grad_angle_partial  (n_out, eqa_group_action_bwd_tiles(OH, OW)) partial sums of dL/d(phi) in RADIANS of the
+ *                       rotation angle that theta encodes (d theta = rotation about the frame centre); the caller sums
+ *                       over the tile axis (deterministic) and scales by pi/180 and the sign of its angle convention
+ *                       (NULL = not wanted).
+ * grad_out has the shape of dst.  The gradient w.r.t. a reflection indicator is a difference of two forward
+ * transforms dotted with grad_out and needs no kernel of its own.
+ */
+int eqa_group_action_bwd_tiles(int OH, int OW);
+int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                         const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
+                         int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                         int top, int left, void* stream);
+
+/*
  * I3 + I4 -- group pooling and orientation argmax.
  * feat:(B, Cf, G, HW) fp32 (the canonicalization network's last feature map, group axis second)
  *   act[b,g]  = mean over (Cf, HW)                              (escnn_networks.py:106-115,
