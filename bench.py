@@ -169,7 +169,8 @@ def main():
         total_images = B * world * args.steps
         n_ct, ms_ct = ktimes.get("canon_transform", (0, float("nan")))
         n_iv, ms_iv = ktimes.get("invert_action", (0, float("nan")))
-        n_gp, ms_gp = ktimes.get("group_pool", (0, float("nan")))
+        n_gp, ms_gp = ktimes.get("group_pool", (0, None))
+        n_ws, ms_ws = ktimes.get("window_sums", (0, None))
         ach = B * BYTES_TRANSFORM / (ms_ct * 1e-3) / 1e9
         ga_bytes = 2 * B * BYTES_TRANSFORM
         line = {
@@ -193,7 +194,7 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": None, "launches_timed": n_ct, "avg_launch_ms": ms_ct,
                          "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
-            "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv, "group_pool": ms_gp},
+            "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv, "group_pool": ms_gp, "window_sums": ms_ws},
             "group_action": {"images_s_per_gpu": B / (ga_ms * 1e-3), "ms": ga_ms,
                              "achieved_GBs": ga_bytes / (ga_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

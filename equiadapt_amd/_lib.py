@@ -33,6 +33,7 @@ SIGNATURES = {
     "eqa_group_action_bwd": (_int, [_vp] * 8 + [_int] * 12 + [_vp]),
     "eqa_group_pool_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_group_pool_argmax": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
+    "eqa_window_sums": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),
     "eqa_group_argmax": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_so3_rotate": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "eqa_gram_schmidt": (_int, [_vp, _vp, _int, _vp]),

@@ -623,6 +623,69 @@ int pool_splits(int B, int Cf) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Window sums: the exact linear shortcut for "last convolution -> group mean".
+//   mean_{o,y,x} conv(h, W)[o,g,y,x] = (1/count) * sum_{c,u,v} (sum_o W[(o,g),c,u,v]) * S[c,u,v] + mean(bias),
+//   S[c,u,v] = sum_{y<OH, x<OW} act(h[c, y+u, x+v]),  OH = H-k+1, OW = W-k+1,  act = relu?(scale*h + shift).
+// One block per (image, channel) plane: the plane is read from HBM exactly once (float4), transformed and parked in
+// LDS; column totals and the k-1 leading / trailing rows give the k row-window sums per column, then the same trick
+// across columns gives the k*k outputs.  fp64 accumulation (the consumer compares orientations by tiny margins).
+// HBM-bound: H*W*4 bytes per plane in, k*k*8 bytes out.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxWinK = 8;
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void window_sums_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu,
+                                                              double* __restrict__ out, int C, int H, int W, int k) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  const int HW = H * W;
+  float* sp = ws_smem;                                                   // [H*W] transformed plane
+  double* cs = reinterpret_cast<double*>(ws_smem + ((HW + 3) & ~3));      // [k][W] row-window sums per column
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
+  const float* p = x + (size_t)plane * HW;
+  const int tid = threadIdx.x;
+  auto act = [&](float v) {
+    v = v * sc + sh;
+    return (relu && v < 0.0f) ? 0.0f : v;
+  };
+  if (VEC) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* s4 = reinterpret_cast<float4*>(sp);
+    for (int i = tid; i < (HW >> 2); i += kThreads) {
+      float4 t = p4[i];
+      t.x = act(t.x); t.y = act(t.y); t.z = act(t.z); t.w = act(t.w);
+      s4[i] = t;
+    }
+  } else {
+    for (int i = tid; i < HW; i += kThreads) sp[i] = act(p[i]);
+  }
+  __syncthreads();
+  const int OH = H - k + 1, OW = W - k + 1;
+  // column x: total over rows, minus the u leading and the (k-1-u) trailing rows -> rows [u, u+OH)
+  for (int xcol = tid; xcol < W; xcol += kThreads) {
+    double tot = 0.0;
+    for (int y = 0; y < H; ++y) tot += (double)sp[y * W + xcol];
+    double pre = 0.0;
+    for (int u = 0; u < k; ++u) {
+      double suf = 0.0;
+      for (int y = u + OH; y < H; ++y) suf += (double)sp[y * W + xcol];
+      cs[u * W + xcol] = tot - pre - suf;
+      pre += (double)sp[u * W + xcol];
+    }
+  }
+  __syncthreads();
+  // output (u, v): columns [v, v+OW) of row-window u.  One thread per output; k*k <= 64 of them.
+  if (tid < k * k) {
+    const int u = tid / k, v = tid - u * k;
+    double acc = 0.0;
+    for (int xcol = v; xcol < v + OW; ++xcol) acc += cs[u * W + xcol];
+    out[(size_t)plane * (k * k) + tid] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // P4 / P3: SO(3) action on point clouds, batched Gram-Schmidt
 // ------------------------------------------------------------------------------------------------
 
@@ -793,6 +856,22 @@ int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream
   if (G > 64) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   hipLaunchKernelGGL(group_argmax_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, act, gidx, B, G);
+  return launch_status();
+}
+
+int eqa_window_sums(const float* x, const float* scale, const float* shift, int relu, double* out, int B, int C, int H,
+                    int W, int k, void* stream) {
+  if (!x || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || k > H || k > W) return EQA_ERR_INVALID_ARG;
+  if (k > kMaxWinK) return EQA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)((H * W + 3) & ~3) * sizeof(float) + (size_t)k * W * sizeof(double);
+  if (lds > 64 * 1024 || (long long)B * C > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;  // plane must fit one block's LDS
+  if (B == 0) return EQA_OK;
+  const bool vec = ((H * W) % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((window_sums_kernel<true>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
+  else
+    hipLaunchKernelGGL((window_sums_kernel<false>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
   return launch_status();
 }
 

@@ -111,6 +111,20 @@ class _GroupConvBase(nn.Module):
             self._cached_bank = (w._version, bank)
         return bank
 
+    def mean_response_weights(self) -> torch.Tensor:
+        """(E, Cin*k*k) fp64: the expanded bank summed over output fields (see pooling.conv_then_group_pool)."""
+        w = self.weights
+        ver, hit = getattr(self, "_cached_weff", (-1, None))
+        if ver == w._version and hit is not None and hit.device == w.device:
+            return hit
+        bank = self.expanded_weights().detach()
+        weff = bank.view(self.out_channels, self.num_group_elements, -1).double().sum(0)
+        self._cached_weff = (w._version, weff)
+        return weff
+
+    def supports_linear_tail(self) -> bool:
+        return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]
         if not self.lifting:

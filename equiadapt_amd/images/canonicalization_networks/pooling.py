@@ -22,3 +22,22 @@ def group_pool(feature_map: torch.Tensor) -> torch.Tensor:
     """``torch.mean(feature_map, dim=(1, 3, 4))`` (reference: escnn_networks.py:115,
     custom_equivariant_networks.py:91) as one pass over the map (eqa_group_pool_argmax)."""
     return _GroupPoolFn.apply(feature_map)
+
+
+def conv_then_group_pool(h: torch.Tensor, layer, scale=None, shift=None, relu: bool = False) -> torch.Tensor:
+    """``group_pool(layer(act(h)))`` WITHOUT running the convolution (inference fast path; exact up to fp rounding).
+
+    The mean over (fields, space) of a convolution is linear in its input, so
+        act[b, g] = sum_{c,u,v} Weff[g,c,u,v] * S[b,c,u,v] / count + mean(bias),
+    with Weff = the filter bank summed over output fields and S the k*k shifted-window sums of each input plane
+    (``eqa_window_sums``, one pass over ``h``; ``act(t) = [relu](scale*t + shift)`` per channel folds the previous
+    layer's bias / eval-mode batch-norm / ReLU into that pass).  ``layer`` is a group conv with stride 1, padding 0.
+    """
+    k, E, O = layer.kernel_size, layer.num_group_elements, layer.out_channels
+    B, _, H, W = h.shape
+    S = ops.window_sums(h, k, scale, shift, relu)                       # (B, Cin, k, k) fp64
+    weff = layer.mean_response_weights()                                # (E, Cin*k*k) fp64
+    act = S.flatten(1) @ weff.t() / float(O * (H - k + 1) * (W - k + 1))
+    if layer.bias is not None:
+        act = act + layer.bias.detach().double().mean()
+    return act.float()

@@ -214,6 +214,22 @@ def group_pool_argmax(feature_map: torch.Tensor, want_index: bool = True) -> Tup
     return act, gidx
 
 
+def window_sums(x: torch.Tensor, k: int, scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None,
+                relu: bool = False) -> torch.Tensor:
+    """(B,C,H,W) fp32 -> (B,C,k,k) fp64 sums of act(x) over the k*k shifted (H-k+1)x(W-k+1) windows
+    (eqa_window_sums); act(t) = [relu](scale[c]*t + shift[c])."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    B, C, H, W = x.shape
+    scale, p_scale = _opt(scale, "scale", torch.float32)
+    shift, p_shift = _opt(shift, "shift", torch.float32)
+    out = torch.empty((B, C, k, k), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device), _timed("window_sums"):
+        st = lib.eqa_window_sums(x.data_ptr(), p_scale, p_shift, int(relu), out.data_ptr(), B, C, H, W, k, _stream())
+    _lib.check(st, "eqa_window_sums")
+    return out
+
+
 def group_argmax(act: torch.Tensor) -> torch.Tensor:
     """I4: first-maximum argmax over the group axis, (B, G) -> (B,) int32."""
     lib = _lib.load()

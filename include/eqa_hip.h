@@ -124,6 +124,18 @@ int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW);
 int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* workspace, int B, int Cf, int G,
                           int HW, void* stream);
 
+/*
+ * I2 tail + I3 -- exact linear shortcut for "last convolution -> group mean" (escnn_networks.py:88-115,
+ * custom_equivariant_networks.py:80-93): since the mean over (fields, space) of a convolution is linear in its input,
+ *   act[b,g] = (1/count) * sum_{c,u,v} Weff[g,c,u,v] * S[b,c,u,v] + mean(bias),   Weff = sum over fields of the filter bank,
+ * where S are the k*k shifted-window sums of each input plane.  This entry point computes S in one pass over the
+ * feature map, applying the previous layer's per-channel affine (bias / eval-mode batch-norm) and ReLU on the fly:
+ *   S[b,c,u,v] = sum_{y < H-k+1, x < W-k+1} act(x[b,c,y+u,x+v]),   act(t) = relu ? max(scale[c]*t + shift[c], 0) : ...
+ * x:(B,C,H,W) fp32; scale, shift:(C) or NULL; out:(B,C,k,k) fp64.  k <= 8, one plane must fit 64 KB of LDS.
+ */
+int eqa_window_sums(const float* x, const float* scale, const float* shift, int relu, double* out, int B, int C, int H,
+                    int W, int k, void* stream);
+
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);
 
