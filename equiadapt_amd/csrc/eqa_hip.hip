@@ -748,6 +748,207 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
   o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
 }
 
+// ------------------------------------------------------------------------------------------------
+// P1 + P2: fused VNSmall forward (eval mode, mean pooling): kNN graph -> cross edge features -> VN linear / VN batch-norm
+// / direction-gated ReLU (3->21) -> mean over neighbours -> (21->21) + VN batch-norm -> (21->4) -> mean over points.
+// Reference: pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn, get_graph_feature_cross),
+// :128-150 (VNSmall.forward), vector_neuron_layers.py:251-273, :303-324.
+// The reference materialises ten (B,21,3,N,k) tensors (5 MB per cloud each); here a cloud is 12 KB in LDS and every
+// intermediate lives in registers: one thread = one point, its k nearest neighbours kept as a sorted register list
+// while it streams over the cloud (LDS broadcast reads), then its k edges are pushed through the layers one by one.
+// Packed parameter buffer (floats), eval-mode batch-norms pre-folded to scale/shift of the vector NORM:
+//   [0,63) pos.Wf(21x3)  [63,126) pos.Wd  [126,147) pos.bn scale  [147,168) pos.bn shift
+//   [168,609) c1.Wf(21x21)  [609,1050) c1.Wd  [1050,1071) c1.bn scale  [1071,1092) c1.bn shift
+//   [1092,1113) bn1 scale  [1113,1134) bn1 shift
+//   [1134,1218) c2.Wf(4x21)  [1218,1302) c2.Wd  [1302,1306) c2.bn scale  [1306,1310) c2.bn shift
+// ------------------------------------------------------------------------------------------------
+constexpr int kVnC = 21, kVnK = 20, kVnThreads = 128, kVnParams = 1310;
+constexpr float kVnEps = 1e-6f;
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ float dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// VN batch-norm (eval): q * BN(|q| + EPS) / (|q| + EPS);  then direction-gated ReLU with slope 0
+__device__ __forceinline__ V3 vn_bn(V3 q, float scale, float shift) {
+  const float n = sqrtf(dot3(q, q)) + kVnEps;
+  const float r = (n * scale + shift) / n;
+  return v3(q.x * r, q.y * r, q.z * r);
+}
+__device__ __forceinline__ V3 vn_relu(V3 q, const V3& d) {
+  const float dp = dot3(q, d);
+  if (dp < 0.0f) {
+    const float t = dp / (dot3(d, d) + kVnEps);
+    q.x -= t * d.x; q.y -= t * d.y; q.z -= t * d.z;
+  }
+  return q;
+}
+
+__global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
+                                                                 float* __restrict__ partial, int N, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float vn_smem[];
+  float4* pts = reinterpret_cast<float4*>(vn_smem);  // [Npad] (x, y, z, |p|^2): one ds_read_b128 per candidate
+  __shared__ float s_part[kVnThreads / 64][12];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * 3 * N;
+  const int Npad = (N + 3) & ~3;
+  for (int i = tid; i < Npad; i += kVnThreads) {
+    if (i < N) {
+      const float a = xb[i], c = xb[N + i], d = xb[2 * (size_t)N + i];
+      pts[i] = make_float4(a, c, d, a * a + c * c + d * d);  // torch.sum(x**2, dim=1)
+    } else {
+      pts[i] = make_float4(0.f, 0.f, 0.f, INFINITY);  // padding: value -inf, never selected
+    }
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kVnThreads + tid;
+  const bool active = n < N;
+  const int ni = active ? n : N - 1;
+  const float4 c4 = pts[ni];
+  const V3 ctr = v3(c4.x, c4.y, c4.z);
+  const float cn = c4.w;
+
+  // ---- kNN: k largest of  -|xj|^2 + 2 xi.xj - |xi|^2  (the reference's expansion, equivariant_networks.py:28-30),
+  // kept sorted (descending) in registers; strict '>' so that the earlier index wins ties.  Candidates are scanned
+  // four at a time (independent LDS reads and arithmetic), with one cheap test before the insertion code.
+  float bv[kVnK];
+  int bi[kVnK];
+#pragma unroll
+  for (int t = 0; t < kVnK; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
+  auto insert = [&](float val, int j) {
+    if (val > bv[kVnK - 1]) {
+      float cv = val;
+      int ci = j;
+#pragma unroll
+      for (int t = 0; t < kVnK; ++t) {
+        const bool sw = cv > bv[t];
+        const float tv = bv[t];
+        const int ti = bi[t];
+        bv[t] = sw ? cv : tv;
+        bi[t] = sw ? ci : ti;
+        cv = sw ? tv : cv;
+        ci = sw ? ti : ci;
+      }
+    }
+  };
+  auto score = [&](const float4& p) {
+    const float inner = -2.0f * (ctr.x * p.x + ctr.y * p.y + ctr.z * p.z);
+    return (-p.w - inner) - cn;
+  };
+  for (int j = 0; j < Npad; j += 4) {
+    const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
+    const float v0 = score(p0), v1 = score(p1), v2 = score(p2), v3_ = score(p3);
+    const float best = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3_));
+    if (best > bv[kVnK - 1]) {
+      insert(v0, j);
+      insert(v1, j + 1);
+      insert(v2, j + 2);
+      insert(v3_, j + 3);
+    }
+  }
+
+  // ---- conv_pos on the k edges + mean over neighbours
+  V3 pooled[kVnC];
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) pooled[c] = v3(0.f, 0.f, 0.f);
+  const float* Wf = prm;
+  const float* Wd = prm + 63;
+  const float* bsc = prm + 126;
+  const float* bsh = prm + 147;
+#pragma unroll 1
+  for (int t = 0; t < kVnK; ++t) {
+    // (dynamic t: pick the t-th neighbour index through a select chain, the list lives in registers)
+    int j = bi[0];
+#pragma unroll
+    for (int u = 1; u < kVnK; ++u) j = (t == u) ? bi[u] : j;
+    const float4 nb4 = pts[j];
+    const V3 nb = v3(nb4.x, nb4.y, nb4.z);
+    const V3 f0 = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);                                   // neighbour - centre
+    const V3 f2 = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);  // nbr x ctr
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      const float a0 = Wf[c * 3], a1 = Wf[c * 3 + 1], a2 = Wf[c * 3 + 2];
+      const float d0 = Wd[c * 3], d1 = Wd[c * 3 + 1], d2 = Wd[c * 3 + 2];
+      V3 q = v3(a0 * f0.x + a1 * ctr.x + a2 * f2.x, a0 * f0.y + a1 * ctr.y + a2 * f2.y, a0 * f0.z + a1 * ctr.z + a2 * f2.z);
+      const V3 d = v3(d0 * f0.x + d1 * ctr.x + d2 * f2.x, d0 * f0.y + d1 * ctr.y + d2 * f2.y, d0 * f0.z + d1 * ctr.z + d2 * f2.z);
+      q = vn_relu(vn_bn(q, bsc[c], bsh[c]), d);
+      pooled[c].x += q.x; pooled[c].y += q.y; pooled[c].z += q.z;
+    }
+  }
+  const float inv_k = 1.0f / (float)kVnK;
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) { pooled[c].x *= inv_k; pooled[c].y *= inv_k; pooled[c].z *= inv_k; }
+
+  // ---- conv1 (21->21) + its VN-BN + ReLU, then bn1
+  V3 h1[kVnC];
+  {
+    const float* W1f = prm + 168;
+    const float* W1d = prm + 609;
+    const float* s1 = prm + 1050;
+    const float* t1 = prm + 1071;
+    const float* s2 = prm + 1092;
+    const float* t2 = prm + 1113;
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < kVnC; ++a) {
+        const float wf = W1f[c * kVnC + a], wd = W1d[c * kVnC + a];
+        q.x += wf * pooled[a].x; q.y += wf * pooled[a].y; q.z += wf * pooled[a].z;
+        d.x += wd * pooled[a].x; d.y += wd * pooled[a].y; d.z += wd * pooled[a].z;
+      }
+      q = vn_relu(vn_bn(q, s1[c], t1[c]), d);
+      h1[c] = vn_bn(q, s2[c], t2[c]);
+    }
+  }
+  // ---- conv2 (21->4) -> this point's contribution to the mean over points
+  float outv[12];
+  {
+    const float* W2f = prm + 1134;
+    const float* W2d = prm + 1218;
+    const float* s3 = prm + 1302;
+    const float* t3 = prm + 1306;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < kVnC; ++a) {
+        const float wf = W2f[c * kVnC + a], wd = W2d[c * kVnC + a];
+        q.x += wf * h1[a].x; q.y += wf * h1[a].y; q.z += wf * h1[a].z;
+        d.x += wd * h1[a].x; d.y += wd * h1[a].y; d.z += wd * h1[a].z;
+      }
+      q = vn_relu(vn_bn(q, s3[c], t3[c]), d);
+      outv[c * 3] = active ? q.x : 0.f;
+      outv[c * 3 + 1] = active ? q.y : 0.f;
+      outv[c * 3 + 2] = active ? q.z : 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const float sres = wave_sum_f(outv[c]);
+    if ((tid & 63) == 0) s_part[tid >> 6][c] = sres;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < kVnThreads / 64; ++w) acc += s_part[w][tid];
+    partial[((size_t)b * nblk + blockIdx.x) * 12 + tid] = acc;
+  }
+}
+
+// (B, nblk, 12) partial sums -> (B,3,3): mean over the N points, first three of the four output channels
+__global__ void vnsmall_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int nblk, float inv_n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 9) return;
+  const int b = i / 9, c = i - b * 9;
+  float acc = 0.f;
+  for (int k = 0; k < nblk; ++k) acc += partial[((size_t)b * nblk + k) * 12 + c];
+  out[i] = acc * inv_n;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
 }  // namespace
@@ -885,6 +1086,26 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
     hipLaunchKernelGGL((so3_rotate_kernel<true>), dim3(((N >> 2) + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
   else
     hipLaunchKernelGGL((so3_rotate_kernel<false>), dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  return launch_status();
+}
+
+int64_t eqa_vnsmall_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (int64_t)B * ((N + kVnThreads - 1) / kVnThreads) * 12 * (int64_t)sizeof(float);
+}
+
+int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
+                    void* stream) {
+  if (!x || !params || !out || !workspace || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
+  if (k != kVnK || pooling != 0 || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20, mean pooling
+  const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float);
+  if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (N + kVnThreads - 1) / kVnThreads;
+  hipLaunchKernelGGL(vnsmall_fwd_kernel, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
   return launch_status();
 }
 

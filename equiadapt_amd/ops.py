@@ -268,3 +268,19 @@ def gram_schmidt(v: torch.Tensor) -> torch.Tensor:
         st = lib.eqa_gram_schmidt(v.data_ptr(), out.data_ptr(), v.shape[0], _stream())
     _lib.check(st, "eqa_gram_schmidt")
     return out
+
+
+def vnsmall_forward(x: torch.Tensor, params: torch.Tensor, k: int = 20) -> torch.Tensor:
+    """P1+P2 fused: (B,3,N) point clouds + packed VNSmall parameters -> (B,3,3) equivariant vectors (eqa_vnsmall_fwd)."""
+    lib = _lib.load()
+    x = _need(x, "point_cloud")
+    params = _need(params, "params")
+    B, three, N = x.shape
+    if three != 3 or params.numel() != 1310:
+        raise ValueError("vnsmall_forward expects x:(B,3,N) and 1310 packed parameters")
+    out = torch.empty((B, 3, 3), dtype=torch.float32, device=x.device)
+    ws = torch.empty((max(lib.eqa_vnsmall_workspace_bytes(B, N), 4) // 4,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("vnsmall_fwd"):
+        st = lib.eqa_vnsmall_fwd(x.data_ptr(), params.data_ptr(), out.data_ptr(), ws.data_ptr(), B, N, k, 0, _stream())
+    _lib.check(st, "eqa_vnsmall_fwd")
+    return out

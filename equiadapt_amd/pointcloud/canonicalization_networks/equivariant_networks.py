@@ -58,7 +58,37 @@ class VNSmall(nn.Module):
         else:
             raise ValueError(f"Pooling type {self.pooling} not supported")
 
+    def packed_parameters(self) -> torch.Tensor:
+        """The 1310 floats the fused kernel consumes (layout: csrc/eqa_hip.hip), eval-mode batch-norms folded to a
+        scale/shift of the vector norm.  Cached per parameter version."""
+        tensors = list(self.parameters()) + [b for b in self.buffers()]
+        key = tuple(t._version for t in tensors) + (str(tensors[0].device),)
+        hit = getattr(self, "_packed", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+
+        def fold(bn):
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            return scale, bn.bias - bn.running_mean * scale
+
+        parts = []
+        for lay, bn in ((self.conv_pos, self.conv_pos.batchnorm.bn2d), (self.conv1, self.conv1.batchnorm.bn1d)):
+            sc, sh = fold(bn)
+            parts += [lay.map_to_feat.weight.flatten(), lay.map_to_dir.weight.flatten(), sc, sh]
+        parts += list(fold(self.bn1.bn1d))
+        sc, sh = fold(self.conv2.batchnorm.bn1d)
+        parts += [self.conv2.map_to_feat.weight.flatten(), self.conv2.map_to_dir.weight.flatten(), sc, sh]
+        packed = torch.cat([p.detach().float() for p in parts]).contiguous()
+        assert packed.numel() == 1310
+        self._packed = (key, packed)
+        return packed
+
     def forward(self, point_cloud: torch.Tensor) -> torch.Tensor:
+        if (point_cloud.is_cuda and not self.training and not torch.is_grad_enabled() and self.pooling == "mean"
+                and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32):
+            from equiadapt_amd import ops
+
+            return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn)
         feat = get_graph_feature_cross(point_cloud.unsqueeze(1), k=self.n_knn)
         out = self.pool(self.conv_pos(feat))
         out = self.bn1(self.conv1(out))

@@ -147,6 +147,21 @@ int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream
 int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream);
 
 /*
+ * P1 + P2 -- fused VNSmall forward (eval mode): kNN graph, cross edge features, the vector-neuron layers and the
+ * mean over points in one kernel; a cloud is staged once in LDS, every intermediate lives in registers.
+ * Replaces equiadapt/pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn,
+ * get_graph_feature_cross) and :128-150 (VNSmall.forward) with vector_neuron_layers.py:251-273, :303-324.
+ * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; k must be 20, pooling 0 (= "mean").
+ * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in eqa_hip.hip).
+ * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  Other k / "max" pooling / training: EQA_ERR_UNSUPPORTED
+ * (the host keeps an op-by-op path for those).
+ */
+#define EQA_VNSMALL_PARAMS 1310
+int64_t eqa_vnsmall_workspace_bytes(int B, int N);
+int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
+                    void* stream);
+
+/*
  * P3 -- batched 3x3 classical Gram-Schmidt on rows (no epsilon, no handedness fix).
  * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
  */

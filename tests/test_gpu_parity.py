@@ -367,3 +367,31 @@ def test_linear_tail_fast_path_equals_conv_path(dev, group_type):
         else:
             want = onets.custom_equivariant_network(x, sd, group_type, 4, len(net.eqv_network) // 2 + 1)
         assert torch.allclose(fast, want, atol=2e-5, rtol=1e-3), type(net).__name__
+
+
+def test_fused_vnsmall_matches_reference_golden_and_op_path(dev, golden):
+    """eqa_vnsmall_fwd (one kernel) vs the reference-generated vectors and vs the op-by-op module path."""
+    import equiadapt_amd as ea
+
+    c = golden("pointcloud.pt")["mean"]
+    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    net = ea.VNSmall(hp)
+    net.load_state_dict(c["state"])
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        fused = net(c["x"].to(dev)).cpu()
+    assert torch.allclose(fused, c["vnsmall_out"], atol=2e-6, rtol=1e-4)
+    torch.manual_seed(13)
+    for (B, N) in [(3, 1024), (2, 300), (5, 64), (1, 20)]:
+        x = torch.randn(B, 3, N, device=dev)
+        with torch.no_grad():
+            fused = net(x)
+        with torch.enable_grad():
+            slow = net(x).detach()  # grad mode -> op-by-op torch path
+        assert torch.allclose(fused, slow, atol=3e-6, rtol=1e-4), (B, N)
+    # equivariance: rotating the cloud rotates the three output vectors
+    x = torch.randn(4, 3, 512, device=dev)
+    R = torch.linalg.qr(torch.randn(4, 3, 3, device=dev)).Q
+    with torch.no_grad():
+        v, vr = net(x), net(torch.bmm(R, x))
+    assert torch.allclose(vr, torch.bmm(v, R.transpose(1, 2)), atol=1e-5)
