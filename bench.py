@@ -172,6 +172,13 @@ def main():
         n_gp, ms_gp = ktimes.get("group_pool", (0, None))
         n_ws, ms_ws = ktimes.get("window_sums", (0, None))
         ach = B * BYTES_TRANSFORM / (ms_ct * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch
+        # correction; tools/collect_traffic.sh).  Counters cannot be collected inside this process, so the committed
+        # measurement of the same kernel / shape is reported; null when it does not match this run's shape.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_group_action.json")
+        if os.path.exists(tpath) and B == 256:
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         ga_bytes = 2 * B * BYTES_TRANSFORM
         line = {
             "metric": "canonicalize+invert images/sec (224x224 C8)",
@@ -192,7 +199,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective)"},
             "roofline": {"bound": "hbm", "kernel": "group_action_kernel<3,true> via eqa_canon_transform_fwd",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None, "launches_timed": n_ct, "avg_launch_ms": ms_ct,
+                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01/traffic_group_action.json)",
+                         "launches_timed": n_ct, "avg_launch_ms": ms_ct,
                          "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv, "group_pool": ms_gp, "window_sums": ms_ws},
             "group_action": {"images_s_per_gpu": B / (ga_ms * 1e-3), "ms": ga_ms,
