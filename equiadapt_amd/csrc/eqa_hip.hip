@@ -749,6 +749,95 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
+// I1: centre crop + antialiased bilinear resize (torchvision CenterCrop + Resize on a tensor ==
+// F.interpolate(bilinear, antialias=True, align_corners=False); discrete_group.py:174-188).
+// Separable like torch's kernel and in the same order: horizontal pass (fp32 intermediates), then vertical pass.
+// The per-output-index tap ranges and normalised triangle weights are built on the host with torch's own formula
+// (UpSampleKernel.cpp _compute_indices_min_size_weights_aa) and passed as small tables; the crop is folded into the
+// tap start indices.  One block = one (image, channel) plane x a band of kAaBand output rows; the band's horizontally
+// resampled input rows live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAaBand = 8;
+
+__global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 const float* __restrict__ wx, const int32_t* __restrict__ x0,
+                                                                 const float* __restrict__ wy, const int32_t* __restrict__ y0,
+                                                                 int H, int W, int OH, int OW, int K, int max_rows) {
+  extern __shared__ __attribute__((aligned(16))) float aa_tmp[];  // [max_rows][OW]
+  const int plane = blockIdx.y;
+  const int r0 = blockIdx.x * kAaBand, r1 = min(r0 + kAaBand, OH);
+  const int ybeg = y0[r0];
+  const int yend = min(y0[r1 - 1] + K, H);  // taps past a row's own range carry zero weight
+  const int nrows = min(yend - ybeg, max_rows);
+  const float* src = x + (size_t)plane * H * W;
+  for (int idx = threadIdx.x; idx < nrows * OW; idx += kThreads) {
+    const int ry = idx / OW, ox = idx - ry * OW;
+    const float* row = src + (size_t)(ybeg + ry) * W;
+    const int xs = x0[ox];
+    float acc = 0.0f;
+    for (int j = 0; j < K; ++j) acc += wx[ox * K + j] * row[min(xs + j, W - 1)];
+    aa_tmp[ry * OW + ox] = acc;
+  }
+  __syncthreads();
+  float* dst = y + (size_t)plane * OH * OW;
+  for (int idx = threadIdx.x; idx < (r1 - r0) * OW; idx += kThreads) {
+    const int r = idx / OW, ox = idx - r * OW;
+    const int oy = r0 + r;
+    const int ys = y0[oy] - ybeg;
+    float acc = 0.0f;
+    for (int j = 0; j < K; ++j) acc += wy[oy * K + j] * aa_tmp[min(ys + j, nrows - 1) * OW + ox];
+    dst[(size_t)oy * OW + ox] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// I6: nearest-neighbour action on uint8 masks (torchvision.transforms.functional.rotate defaults on a uint8 tensor:
+// half-pixel base grid, theta rescaled by (0.5 W, 0.5 H), grid_sample(nearest, zeros, align_corners=False), round;
+// images/utils.py:125-136, optionally after flip_masks :112-122).  rtheta[e] = the RESCALED 3x2 matrix in the order
+// (r00, r10, r20, r01, r11, r21): gx = xb*r00 + yb*r10 + r20, gy = xb*r01 + yb*r11 + r21.
+// One thread = 4 consecutive output pixels (one 32-bit store).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void mask_action_nearest_kernel(const uint8_t* __restrict__ m, uint8_t* __restrict__ out,
+                                                                      const int32_t* __restrict__ eidx,
+                                                                      const float* __restrict__ rtheta,
+                                                                      const int32_t* __restrict__ flags, int E, int H, int W) {
+  const int n = blockIdx.z;
+  const int i = blockIdx.y;
+  const int jb = (blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (jb >= W) return;
+  const int e = min(max(eidx[n], 0), E - 1);
+  const float* t = rtheta + e * 6;
+  const bool flip = flags && (flags[e] & EQA_FLIP_SRC);
+  const uint8_t* src = m + (size_t)n * H * W;
+  const float yb = ((float)i + 0.5f) - 0.5f * (float)H;
+  uint8_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = jb + k;
+    const float xb = ((float)j + 0.5f) - 0.5f * (float)W;
+    const float gx = xb * t[0] + yb * t[1] + t[2];
+    const float gy = xb * t[3] + yb * t[4] + t[5];
+    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float xr = rintf(ix), yr = rintf(iy);  // std::nearbyint: round half to even
+    uint8_t val = 0;
+    if (xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1)) {
+      const int sx = flip ? (W - 1 - (int)xr) : (int)xr;
+      val = src[(size_t)(int)yr * W + sx];
+    }
+    v[k] = val;
+  }
+  uint8_t* o = out + (size_t)n * H * W + (size_t)i * W + jb;
+  if (jb + 3 < W && ((((uintptr_t)o) & 3) == 0)) {
+    *reinterpret_cast<uint32_t*>(o) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (jb + k < W) o[k] = v[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // P1 + P2: fused VNSmall forward (eval mode, mean pooling): kNN graph -> cross edge features -> VN linear / VN batch-norm
 // / direction-gated ReLU (3->21) -> mean over neighbours -> (21->21) + VN batch-norm -> (21->4) -> mean over points.
 // Reference: pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn, get_graph_feature_cross),
@@ -1086,6 +1175,28 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
     hipLaunchKernelGGL((so3_rotate_kernel<true>), dim3(((N >> 2) + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
   else
     hipLaunchKernelGGL((so3_rotate_kernel<false>), dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  return launch_status();
+}
+
+int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t* x0, const float* wy, const int32_t* y0,
+                       int planes, int H, int W, int OH, int OW, int K, int max_rows, void* stream) {
+  if (!x || !y || !wx || !x0 || !wy || !y0 || planes < 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || max_rows <= 0)
+    return EQA_ERR_INVALID_ARG;
+  const size_t lds = (size_t)max_rows * OW * sizeof(float);
+  if (lds > 96 * 1024 || planes > 65535) return EQA_ERR_UNSUPPORTED;
+  if (planes == 0) return EQA_OK;
+  hipLaunchKernelGGL(crop_resize_aa_kernel, dim3((OH + kAaBand - 1) / kAaBand, planes), dim3(kThreads), lds, (hipStream_t)stream,
+                     x, y, wx, x0, wy, y0, H, W, OH, OW, K, max_rows);
+  return launch_status();
+}
+
+int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                            int num_elements, int n_masks, int H, int W, void* stream) {
+  if (!m || !out || !eidx || !rtheta || num_elements <= 0 || n_masks < 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (n_masks > 65535 || H > 65535) return EQA_ERR_UNSUPPORTED;
+  if (n_masks == 0) return EQA_OK;
+  hipLaunchKernelGGL(mask_action_nearest_kernel, dim3((W / 4 + kThreads) / kThreads, H, n_masks), dim3(kThreads), 0,
+                     (hipStream_t)stream, m, out, eidx, rtheta, flags, num_elements, H, W);
   return launch_status();
 }
 

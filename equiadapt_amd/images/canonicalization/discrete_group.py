@@ -22,6 +22,7 @@ from equiadapt_amd.common.basecanonicalization import DiscreteGroupCanonicalizat
 from equiadapt_amd.images import geometry
 from equiadapt_amd.images.transforms import CenterCrop, EdgePad, Resize
 from equiadapt_amd.images.utils import (
+    canonicalize_masks,
     device_tables,
     flip_boxes,
     flip_masks,
@@ -103,7 +104,7 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
                 hit = (rot.to(device), ref.to(device))
             else:
                 hit = (angles.to(device), None)
-            self._consts = {key: hit}
+            self._consts[key] = hit
         return hit
 
     def groupactivations_to_groupelement(self, group_activations: torch.Tensor,
@@ -141,8 +142,24 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
         return element
 
     def transformations_before_canonicalization_network_forward(self, x: torch.Tensor) -> torch.Tensor:
-        """Centre crop by ``input_crop_ratio`` then resize to ``resize_shape`` (reference :174-188)."""
-        return self.resize_canonization(self.crop_canonization(x))
+        """Centre crop by ``input_crop_ratio`` then resize to ``resize_shape`` (reference :174-188).
+
+        On the device, without autograd, crop + antialiased resize run as one kernel (``eqa_crop_resize_aa``)."""
+        crop, resize = self.crop_canonization, self.resize_canonization
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and isinstance(resize, Resize)
+                and resize.antialias):
+            from equiadapt_amd.images.transforms import resized_output_size
+
+            out_hw = resized_output_size(crop.size, resize.size)
+            if out_hw[0] <= crop.size[0] and out_hw[1] <= crop.size[1]:  # down-sampling (the reference's use)
+                key = (tuple(x.shape[-2:]), crop.size, out_hw, str(x.device))
+                tabs = self._consts.get(key)
+                if tabs is None:
+                    t = geometry.aa_resize_tables(tuple(x.shape[-2:]), crop.size, out_hw)
+                    tabs = tuple(v.to(x.device) if isinstance(v, torch.Tensor) else v for v in t)
+                    self._consts[key] = tabs
+                return ops.crop_resize_aa(x, tabs, out_hw)
+        return resize(crop(x))
 
     # -- the hot path ------------------------------------------------------------------------------
 
@@ -166,12 +183,19 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
             if reflections:
                 for t in range(len(targets)):
                     targets[t]["boxes"] = flip_boxes(targets[t]["boxes"], image_width)
-                    targets[t]["masks"] = flip_masks(targets[t]["masks"])
-            # one device->host copy for the whole batch instead of a sync per sample
-            rot_host = element["rotation"].detach().cpu()
             for t in range(len(targets)):
                 targets[t]["boxes"] = rotate_boxes(targets[t]["boxes"], element["rotation"][t], image_width)
-                targets[t]["masks"] = rotate_masks(targets[t]["masks"], -rot_host[t].item())
+            masks = [t_["masks"] for t_ in targets]
+            if all(m.is_cuda and m.dtype == torch.uint8 and m.dim() == 3 for m in masks):
+                # every mask of the batch in one nearest-neighbour kernel launch, element index read on the device
+                new = canonicalize_masks(masks, gidx, self.num_rotations, flip_all=reflections)
+                for t in range(len(targets)):
+                    targets[t]["masks"] = new[t]
+            else:  # other dtypes: op-by-op, one device->host copy for the whole batch
+                rot_host = element["rotation"].detach().cpu()
+                for t in range(len(targets)):
+                    m = flip_masks(targets[t]["masks"]) if reflections else targets[t]["masks"]
+                    targets[t]["masks"] = rotate_masks(m, -rot_host[t].item())
             return x, targets
         return x
 

@@ -8,6 +8,7 @@ so the E 2x3 matrices are bit-identical to what the reference would hand to ``F.
 The tables are E*6 floats / E ints / E*G ints; they live on the device as non-persistent module buffers.
 """
 import functools
+import math
 from typing import Optional, Tuple
 
 import torch
@@ -114,3 +115,75 @@ def invert_tables(num_rotations: int, reflections: bool, frame_hw: Tuple[int, in
 def center_crop_offset(full: int, crop: int) -> int:
     """torchvision CenterCrop: int(round((full - crop) / 2.0)) with Python's round-half-even."""
     return int(round((full - crop) / 2.0))
+
+
+# ---- I1: antialiased bilinear resize taps (torch aten/native/cpu/UpSampleKernel.cpp, HelperInterpBase) -------------
+
+
+def _aa_axis(in_size: int, out_size: int, offset: int):
+    """Per output index: first input tap (+ crop ``offset``) and K normalised triangle weights, as torch computes them
+    for ``F.interpolate(mode="bilinear", antialias=True, align_corners=False)`` on fp32 data."""
+    import numpy as np
+
+    f32 = np.float32
+    scale = f32(in_size) / f32(out_size)                      # area_pixel_compute_scale, no explicit scale factor
+    support = f32(1.0) * scale if scale >= 1.0 else f32(1.0)  # interp_size * 0.5 = 1 for bilinear
+    K = int(math.ceil(float(support))) * 2 + 1
+    invscale = f32(1.0) / scale if scale >= 1.0 else f32(1.0)
+    w = np.zeros((out_size, K), dtype=np.float32)
+    start = np.zeros((out_size,), dtype=np.int32)
+    for i in range(out_size):
+        center = scale * f32(i + 0.5)
+        xmin = max(int(float(center - support) + 0.5), 0)
+        xsize = min(int(float(center + support) + 0.5), in_size) - xmin
+        xsize = min(max(xsize, 0), K)
+        total = f32(0.0)
+        for j in range(xsize):
+            t = f32(abs((float(f32(j + xmin) - center) + 0.5) * float(invscale)))
+            wj = f32(1.0) - t if t < 1.0 else f32(0.0)
+            w[i, j] = wj
+            total = f32(total + wj)
+        if total != 0.0:
+            w[i, :xsize] = w[i, :xsize] / total
+        start[i] = xmin + offset
+    return w, start, K
+
+
+@functools.lru_cache(maxsize=32)
+def aa_resize_tables(in_hw: Tuple[int, int], crop_hw: Tuple[int, int], out_hw: Tuple[int, int], band: int = 8):
+    """Tables for ``eqa_crop_resize_aa``: centre crop (torchvision offset rule) folded into the tap starts."""
+    H, W = in_hw
+    ch, cw = crop_hw
+    top, left = center_crop_offset(H, ch), center_crop_offset(W, cw)
+    wy, y0, Ky = _aa_axis(ch, out_hw[0], top)
+    wx, x0, Kx = _aa_axis(cw, out_hw[1], left)
+    K = max(Kx, Ky)
+    import numpy as np
+
+    def pad(w):
+        out = np.zeros((w.shape[0], K), dtype=np.float32)
+        out[:, : w.shape[1]] = w
+        return out
+
+    max_rows = 1
+    for r0 in range(0, out_hw[0], band):
+        r1 = min(r0 + band, out_hw[0])
+        max_rows = max(max_rows, min(int(y0[r1 - 1]) + K, H) - int(y0[r0]))
+    return (torch.from_numpy(pad(wx)), torch.from_numpy(x0), torch.from_numpy(pad(wy)), torch.from_numpy(y0), K, max_rows)
+
+
+# ---- I6: torchvision nearest-neighbour rotation of masks -------------------------------------------------------------
+
+
+def mask_rotation_table(angles_deg, hw: Tuple[int, int]) -> torch.Tensor:
+    """(E, 6) rescaled inverse affine matrices of ``transforms.functional.rotate(mask, angle)`` (nearest, no expand):
+    _get_inverse_affine_matrix(center 0, -angle) then ``theta^T / (0.5 w, 0.5 h)`` -- order r00,r10,r20,r01,r11,r21."""
+    h, w = hw
+    rows = []
+    for a in angles_deg:
+        rot = math.radians(-float(a))
+        c, s_ = math.cos(rot), math.sin(rot)
+        rows.append([c, s_, 0.0, -s_, c, 0.0])
+    theta = torch.tensor(rows, dtype=torch.float32).reshape(-1, 2, 3)
+    resc = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)   # (E, 3, 2)
+    return torch.stack([resc[:, 0, 0], resc[:, 1, 0], resc[:, 2, 0], resc[:, 0, 1], resc[:, 1, 1], resc[:, 2, 1]], dim=1).contiguous()

@@ -132,6 +132,10 @@ def rotate_masks(masks: torch.Tensor, angle: float) -> torch.Tensor:
     """
     import math
 
+    if masks.is_cuda and masks.dtype == torch.uint8 and masks.dim() == 3:
+        rtheta = geometry.mask_rotation_table([float(angle)], tuple(masks.shape[-2:])).to(masks.device)
+        eidx = torch.zeros(masks.shape[0], dtype=torch.int32, device=masks.device)
+        return ops.mask_action_nearest(masks, eidx, rtheta, None)
     squeeze = masks.dim() == 3
     img = masks.unsqueeze(0) if squeeze else masks
     out_dtype = img.dtype
@@ -152,6 +156,30 @@ def rotate_masks(masks: torch.Tensor, angle: float) -> torch.Tensor:
     if cast:
         out = torch.round(out).to(out_dtype)
     return out.squeeze(0) if squeeze else out
+
+
+def canonicalize_masks(mask_list, group_index: torch.Tensor, num_rotations: int, flip_all: bool):
+    """All samples' masks in ONE launch: mask k of sample t is (flipped if ``flip_all``, the reference's behaviour
+    whenever the group has reflections, then) rotated by -angle of sample t's group element.  No host sync: the element
+    index stays on the device.  Reference: discrete_group.py:217-236 (per-sample Python loop with ``.item()``)."""
+    counts = [int(m.shape[0]) for m in mask_list]
+    if sum(counts) == 0:
+        return list(mask_list)
+    H, W = mask_list[0].shape[-2:]
+    dev = mask_list[0].device
+    key = ("mask", num_rotations, flip_all, (H, W), str(dev))
+    hit = _device_tables.get(key)
+    if hit is None:
+        ang = geometry.group_angles(num_rotations)
+        rtheta = geometry.mask_rotation_table((-ang).tolist(), (H, W)).to(dev)
+        flags = torch.full((num_rotations,), geometry.FLIP_SRC if flip_all else 0, dtype=torch.int32, device=dev)
+        hit = (rtheta, flags)
+        _device_tables[key] = hit
+    rtheta, flags = hit
+    ridx = (group_index % num_rotations).to(torch.int32)
+    eidx = torch.repeat_interleave(ridx, torch.tensor(counts, device=dev), output_size=sum(counts)).to(torch.int32)
+    out = ops.mask_action_nearest(torch.cat(list(mask_list), dim=0).contiguous(), eidx, rtheta, flags)
+    return list(torch.split(out, counts, dim=0))
 
 
 def rotate_points(origin: List[float], point: torch.Tensor, angle: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

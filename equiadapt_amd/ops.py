@@ -284,3 +284,34 @@ def vnsmall_forward(x: torch.Tensor, params: torch.Tensor, k: int = 20) -> torch
         st = lib.eqa_vnsmall_fwd(x.data_ptr(), params.data_ptr(), out.data_ptr(), ws.data_ptr(), B, N, k, 0, _stream())
     _lib.check(st, "eqa_vnsmall_fwd")
     return out
+
+
+def crop_resize_aa(x: torch.Tensor, tables, out_hw: Tuple[int, int]) -> torch.Tensor:
+    """I1: centre crop + antialiased bilinear resize in one kernel (eqa_crop_resize_aa).  ``tables`` from
+    ``geometry.aa_resize_tables`` already moved to x.device."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    wx, x0, wy, y0, K, max_rows = tables
+    B, C, H, W = x.shape
+    y = torch.empty((B, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("crop_resize_aa"):
+        st = lib.eqa_crop_resize_aa(x.data_ptr(), y.data_ptr(), wx.data_ptr(), x0.data_ptr(), wy.data_ptr(), y0.data_ptr(),
+                                    B * C, H, W, out_hw[0], out_hw[1], K, max_rows, _stream())
+    _lib.check(st, "eqa_crop_resize_aa")
+    return y
+
+
+def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor]) -> torch.Tensor:
+    """I6: nearest-neighbour rotation (+ optional pre-flip) of (n,H,W) uint8 masks, element index per mask."""
+    lib = _lib.load()
+    masks = _need(masks, "masks", torch.uint8)
+    eidx = _need(eidx, "eidx", torch.int32)
+    rtheta = _need(rtheta, "rtheta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    n, H, W = masks.shape
+    out = torch.empty_like(masks)
+    with torch.cuda.device(masks.device):
+        st = lib.eqa_mask_action_nearest(masks.data_ptr(), out.data_ptr(), eidx.data_ptr(), rtheta.data_ptr(), p_flags,
+                                         rtheta.shape[0], n, H, W, _stream())
+    _lib.check(st, "eqa_mask_action_nearest")
+    return out

@@ -95,6 +95,27 @@ int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, cons
                          int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream);
 
 /*
+ * I1 -- centre crop + antialiased bilinear resize of the canonicalization network's input
+ * (transforms.CenterCrop -> transforms.Resize on a tensor == F.interpolate(bilinear, antialias=True,
+ * align_corners=False); equiadapt/images/canonicalization/discrete_group.py:174-188, built :73-92).
+ * Separable (horizontal, then vertical, fp32 intermediates) like torch's kernel.  The caller supplies, per output
+ * column / row, the first input tap (crop offset included) and K normalised weights (zero-padded), computed with
+ * torch's formula: wx:(OW,K) x0:(OW) wy:(OH,K) y0:(OH).  x:(planes,H,W) -> y:(planes,OH,OW); max_rows >= the number of
+ * input rows any band of 8 output rows touches.
+ */
+int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t* x0, const float* wy, const int32_t* y0,
+                       int planes, int H, int W, int OH, int OW, int K, int max_rows, void* stream);
+
+/*
+ * I6 -- nearest-neighbour group action on uint8 masks: torchvision.transforms.functional.rotate defaults
+ * (equiadapt/images/utils.py:125-136 rotate_masks, after the optional flip_masks :112-122).
+ * m,out:(n_masks,H,W) uint8; eidx:(n_masks) element per mask; rtheta:(E,6) the inverse affine matrix already rescaled by
+ * (0.5 W, 0.5 H) in the order r00,r10,r20,r01,r11,r21; flags:(E) EQA_FLIP_SRC = flip the mask before rotating.
+ */
+int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                            int num_elements, int n_masks, int H, int W, void* stream);
+
+/*
  * Backward of eqa_group_action_fwd (and so of I5 / I7 / I8), what the reference obtains from autograd through
  * K.geometry.rotate (discrete_group.py:213, images/utils.py:57,82):
  *   grad_src            dL/d(src), shape of src, MUST be zero-filled by the caller; accumulated with float atomics

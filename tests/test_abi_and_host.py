@@ -99,3 +99,33 @@ def test_reference_shape_contract_pre_transform():
 
     x = torch.randn(1, 3, 64, 64)
     assert Resize(32)(CenterCrop(58)(x)).shape == (1, 3, 32, 32)
+
+
+def test_aa_resize_tables_reproduce_torch_interpolate():
+    """Host tables of eqa_crop_resize_aa applied with plain torch on the CPU == CenterCrop + F.interpolate(antialias)."""
+    import math
+
+    from equiadapt_amd.images import geometry as g
+    from oracle import image_ops as io
+
+    torch.manual_seed(0)
+    for (H, W, ratio, size) in [(224, 224, 0.8, 96), (64, 64, 0.9, 32), (50, 70, 0.8, (24, 40)), (33, 33, 1.0, 17)]:
+        x = torch.randn(2, 3, H, W)
+        crop = (math.ceil(H * ratio), math.ceil(W * ratio))
+        out_hw = io.tv_resize_output_size(crop, size)
+        wx, x0, wy, y0, K, max_rows = g.aa_resize_tables((H, W), crop, out_hw)
+        cols = (x0[:, None].long() + torch.arange(K)[None, :]).clamp(max=W - 1)      # (OW, K)
+        tmp = (x[:, :, :, cols] * wx[None, None, None]).sum(-1)                      # horizontal pass (B,C,H,OW)
+        rows = (y0[:, None].long() + torch.arange(K)[None, :]).clamp(max=H - 1)      # (OH, K)
+        got = (tmp[:, :, rows, :] * wy[None, None, :, :, None]).sum(3)               # vertical pass (B,C,OH,OW)
+        want = io.pre_canonicalization_transform(x, (3, H, W), ratio, size)
+        assert got.shape == want.shape and (got - want).abs().max().item() < 2e-6
+        assert max_rows >= 1
+
+
+def test_mask_rotation_table_matches_torchvision_restatement():
+    from equiadapt_amd.images import geometry as g
+
+    t = g.mask_rotation_table([0.0, 90.0], (8, 12))
+    assert t.shape == (2, 6)
+    assert torch.allclose(t[0], torch.tensor([1 / 6.0, 0.0, 0.0, 0.0, 1 / 4.0, 0.0]), atol=1e-7)

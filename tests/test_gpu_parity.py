@@ -395,3 +395,64 @@ def test_fused_vnsmall_matches_reference_golden_and_op_path(dev, golden):
     with torch.no_grad():
         v, vr = net(x), net(torch.bmm(R, x))
     assert torch.allclose(vr, torch.bmm(v, R.transpose(1, 2)), atol=1e-5)
+
+
+def test_crop_resize_aa_matches_torch_interpolate(dev):
+    """I1: eqa_crop_resize_aa vs torchvision semantics (CenterCrop -> F.interpolate(antialias=True)) on the CPU."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.images import geometry
+
+    torch.manual_seed(14)
+    for (H, W, ratio, size) in [(224, 224, 0.8, 96), (64, 64, 0.9, 32), (50, 70, 0.8, (24, 40)), (33, 33, 1.0, 17)]:
+        x = torch.randn(3, 3, H, W)
+        want = io.pre_canonicalization_transform(x, (3, H, W), ratio, size)
+        import math
+        crop = (math.ceil(H * ratio), math.ceil(W * ratio))
+        out_hw = io.tv_resize_output_size(crop, size)
+        tabs = tuple(v.to(dev) if isinstance(v, torch.Tensor) else v for v in geometry.aa_resize_tables((H, W), crop, out_hw))
+        got = ops.crop_resize_aa(x.to(dev), tabs, out_hw).cpu()
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() <= 2e-6, (H, W, ratio, size)
+
+
+def test_mask_action_nearest_bit_exact(dev, golden):
+    """I6: uint8 nearest rotation -- bit-exact against the oracle's torchvision restatement."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.images.utils import canonicalize_masks
+
+    g = torch.Generator().manual_seed(15)
+    for (H, W) in [(32, 32), (40, 56), (224, 224)]:
+        m = (torch.rand(5, H, W, generator=g) > 0.5).to(torch.uint8) * 255
+        for ang in (-45.0, 90.0, 135.0, -270.0, 0.0, 315.0):
+            want = io.rotate_masks(m, ang)
+            got = ea.rotate_masks(m.to(dev), ang).cpu()
+            assert torch.equal(got, want), (H, W, ang)
+    # batched, per-sample element, with the reference's "flip every target" behaviour for D_n
+    masks = [(torch.rand(n, 48, 48, generator=g) > 0.5).to(torch.uint8) for n in (2, 0, 3, 1)]
+    gidx = torch.tensor([1, 6, 3, 4])
+    got = canonicalize_masks([m.to(dev) for m in masks], gidx.to(dev, torch.int32), 4, flip_all=True)
+    ang = io.group_angles(4)
+    for t, m in enumerate(masks):
+        want = io.rotate_masks(io.flip_masks(m), -ang[gidx[t] % 4].item()) if m.shape[0] else m
+        assert torch.equal(got[t].cpu(), want), t
+
+
+def test_canonicalize_with_targets(dev):
+    """Targets branch (reference discrete_group.py:217-238): boxes and masks follow the image."""
+    import equiadapt_amd as ea
+
+    torch.manual_seed(16)
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 4, 5, "rotation", 4, 1, device="cpu")
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=32)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 64, 64)).to(dev).eval()
+    x = torch.randn(3, 3, 64, 64)
+    targets = [{"boxes": torch.tensor([[4.0, 8.0, 20.0, 30.0]]).to(dev), "masks": (torch.rand(2, 64, 64) > 0.5).to(torch.uint8).to(dev)}
+               for _ in range(3)]
+    ref_t = [{k: v.clone().cpu() for k, v in t.items()} for t in targets]
+    with torch.no_grad():
+        y, out_t = can(x.to(dev), targets)
+    rot = can.canonicalization_info_dict["group_element"]["rotation"].cpu()
+    for t in range(3):
+        assert torch.equal(out_t[t]["masks"].cpu(), io.rotate_masks(ref_t[t]["masks"], -rot[t].item()))
+        assert torch.allclose(out_t[t]["boxes"].cpu(), io.rotate_boxes(ref_t[t]["boxes"], rot[t], 64), atol=1e-4)
+    _close(y, io.canonicalize_images(x, rot, None, (3, 64, 64)))
