@@ -60,6 +60,17 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
+// ablation switches for tools/ablate.sh (never set in the product build)
+#ifdef EQA_ABL_NOLOAD
+#define EQA_ABL_YB(yb) (a.force_direct == 12345 ? (yb) : 0)
+#else
+#define EQA_ABL_YB(yb) (yb)
+#endif
+#ifdef EQA_ABL_NOSTORE
+#define EQA_ABL_STORE_OK(v) ((v) == 123.456f)
+#else
+#define EQA_ABL_STORE_OK(v) true
+#endif
 #ifndef EQA_ACTION_WAVES
 #define EQA_ACTION_WAVES 1
 #endif
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
       gy0[k] = yi;
       // (pixels of a partial tile beyond OW/OH are computed but never stored: keep their reads in the window)
       const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
-      lidx[k] = ly * kLdsStride + lx;
+      lidx[k] = ly * (CH * kLdsStride) + lx;
       w00[k] = wy0 * wx0;  // nw
       w01[k] = wy0 * wx1;  // ne
       w10[k] = wy1 * wx0;  // sw
@@ -204,55 +215,51 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
   // Off-frame rows/columns (padding_mode="zeros") are zero-filled afterwards by the lanes/rows that own them;
   // those never issue a DMA, so there is no ordering problem.
   // Inline asm because hipcc will not pick the saddr form for the builtin.  It does not count these loads:
-  // stage_wait() below is the s_waitcnt.  M0 is saved/restored inside the statement (cdna guide 5.7).
+  // stage_wait() below is the s_waitcnt.  M0 (compiler-reserved) is saved once before the row loop and restored
+  // after it; every statement that reads M0 writes it first (cdna guide 5.7).
   const bool lane_dma = col_ok && col_inside;
   const bool any_zero = (x_lo < 0) || (y_lo < 0) || (x_hi > a.Wp - 1) || (y_hi > a.Hp - 1);
+  // LDS layout [window row][channel][column]: one M0 write per row serves all CH channels, each DMA adding its
+  // channel's row offset through the instruction's immediate (which shifts the global address too, so the plane
+  // base handed to the DMA is pre-biased by -cc*kRowB).
+  constexpr int kRowB = kLdsStride * 4;  // bytes of one channel's row
   auto stage_issue = [&](const float* const (&planes)[CH]) {
     if (lane_dma) {
       // window rows inside the frame: [ya, yb); this wave takes ya + ((wave - ya) mod 4), +4, ...
       const int ya = max(-y_lo, 0), yb = min(bh, a.Hp - y_lo);
+      const char* p0 = reinterpret_cast<const char*>(planes[0]);
+      const char* p1 = reinterpret_cast<const char*>(planes[CH > 1 ? 1 : 0]) - kRowB;
+      const char* p2 = reinterpret_cast<const char*>(planes[CH > 2 ? 2 : 0]) - 2 * kRowB;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
 #pragma unroll 1
-      for (int y = ya + ((wave - ya) & 3); y < yb; y += 4) {
+      for (int y = ya + ((wave - ya) & 3); y < EQA_ABL_YB(yb); y += 4) {
         const int fy = y_lo + y;
-        {
-          const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
-          const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * kLdsStride);
-          unsigned keep;
-          if (CH == 1) {
-            asm volatile(
-                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
-                "s_mov_b32 m0, %[keep]"
-                : [keep] "=&s"(keep)
-                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0])
-                : "memory");
-          } else if (CH == 2) {
-            asm volatile(
-                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
-                "s_add_u32 m0, %[l], %[pb]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p1]\n\t"
-                "s_mov_b32 m0, %[keep]"
-                : [keep] "=&s"(keep)
-                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0]), [p1] "s"(planes[CH > 1 ? 1 : 0]), [pb] "i"(kPlane * 4)
-                : "memory", "scc");
-          } else {
-            asm volatile(
-                "s_mov_b32 %[keep], m0\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
-                "s_add_u32 m0, %[l], %[pb]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p1]\n\t"
-                "s_add_u32 m0, %[l], %[pb2]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p2]\n\t"
-                "s_mov_b32 m0, %[keep]"
-                : [keep] "=&s"(keep)
-                : [v] "v"(voff), [l] "s"(lrow), [p0] "s"(planes[0]), [p1] "s"(planes[CH > 1 ? 1 : 0]),
-                  [p2] "s"(planes[CH > 2 ? 2 : 0]), [pb] "i"(kPlane * 4), [pb2] "i"(kPlane * 8)
-                : "memory", "scc");
-          }
+        const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
+        const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * (CH * kLdsStride));
+        if (CH == 1) {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0) : "memory");
+        } else if (CH == 2) {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                       "global_load_lds_dword %[v], %[p1] offset:%[o1]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0), [p1] "s"(p1), [o1] "i"(kRowB) : "memory");
+        } else {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                       "global_load_lds_dword %[v], %[p1] offset:%[o1]\n\t"
+                       "global_load_lds_dword %[v], %[p2] offset:%[o2]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [o1] "i"(kRowB),
+                          [o2] "i"(2 * kRowB) : "memory");
         }
       }
+      asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
     }
     if (any_zero && col_ok) {  // rare: tiles touching the zero ring of an unpadded frame
 #pragma unroll 1
       for (int y = wave; y < bh; y += 4) {
         if (!(col_inside && ((unsigned)(y_lo + y) < (unsigned)a.Hp))) {
 #pragma unroll
-          for (int cc = 0; cc < CH; ++cc) smem[cc * kPlane + y * kLdsStride + lane] = 0.0f;
+          for (int cc = 0; cc < CH; ++cc) smem[(y * CH + cc) * kLdsStride + lane] = 0.0f;
         }
       }
     }
@@ -284,11 +291,11 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
       stage_wait();
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
-        const float* s = smem + cc * kPlane;
+        const float* s = smem + cc * kLdsStride;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
-          const float sw = s[lidx[k] + kLdsStride], se = s[lidx[k] + kLdsStride + 1];
+          const float sw = s[lidx[k] + CH * kLdsStride], se = s[lidx[k] + CH * kLdsStride + 1];
           const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
           acc[cc][k] = live[k] ? v : 0.0f;
         }
@@ -334,7 +341,8 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
         if (c0 + cc < a.C) {
           float* o = dst_img + (unsigned)(c0 + cc) * dst_plane + (unsigned)(i * a.OW + jb);
           if (VEC) {  // OW % 4 == 0 and jb % 4 == 0: a pixel quad is entirely inside or entirely outside the row
-            if (jb < a.OW) *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+            if (jb < a.OW && EQA_ABL_STORE_OK(acc[cc][0]))
+              *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
