@@ -694,6 +694,156 @@ __global__ __launch_bounds__(kThreads) void window_sums_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// Channels-last (NHWC) companions: MIOpen's fp32 implicit-GEMM convolutions run natively in NHWC, so the inference path
+// of the canonicalization network stays in that layout end to end (no NCHW<->NHWC transposes).
+//  * bias_relu_nhwc_kernel: x[p][c] = max(x[p][c] + bias[c], 0) in place, float4 over channels.
+//  * window_sums_nhwc: same S[b,c,u,v] as window_sums_kernel, for a (B,H,W,C) buffer.  Rows are cut into segments:
+//    each of the 2(k-1) border rows alone, the interior in bands.  A segment kernel streams its rows once (a wave reads
+//    one pixel's channels = contiguous floats per instruction) and emits, per channel, the segment total and the sums of
+//    the k-1 leading / trailing columns.  Every window sum is then total - excluded rows - excluded columns + their
+//    intersections (inclusion-exclusion), assembled per (image, channel) in fp64 by a small finalize kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bias_relu_nhwc_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                                 size_t n_vec, int C4) {
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n_vec; i += stride) {
+    const int c4 = (int)(i % (size_t)C4);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+    v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
+constexpr int kWsMaxBorder = kMaxWinK - 1;  // k - 1 <= 7
+
+// segment s of image b: rows [seg_y0(s), seg_y1(s)).  Output per (b, s, c): 1 + 2(k-1) floats
+//   [0] total, [1 + j] column j, [1 + (k-1) + j] column W-k+1+j      (j < k-1), all over the segment's rows.
+__device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands, int& y0, int& y1) {
+  const int nb = k - 1;
+  if (s < nb) { y0 = s; y1 = s + 1; return; }                       // top border rows
+  if (s < 2 * nb) { y0 = H - nb + (s - nb); y1 = y0 + 1; return; }  // bottom border rows
+  const int lo = nb, hi = H - nb;                                   // interior rows, cut into nbands bands
+  const int band = s - 2 * nb, rows = hi - lo;
+  y0 = lo + (int)(((long long)rows * band) / nbands);
+  y1 = lo + (int)(((long long)rows * (band + 1)) / nbands);
+}
+
+__global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                           const float* __restrict__ shift, int relu,
+                                                                           float* __restrict__ part, int C, int H, int W, int k,
+                                                                           int nbands) {
+  __shared__ float4 s_tot[4][64];  // only the totals need a cross-wave sum; a border column has ONE owner wave
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int nseg = gridDim.x;
+  int y0, y1;
+  ws_segment_rows(s, H, k, nbands, y0, y1);
+  const int nb = k - 1, nval = 1 + 2 * nb;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Q = C >> 2;  // channel quads
+  const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * H * W * C);
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    const int q = q0 + lane;
+    const bool on = q < Q;
+    const int qq = on ? q : Q - 1;
+    const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[qq] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? reinterpret_cast<const float4*>(shift)[qq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](int y, int xc) {
+      float4 v = xb[((size_t)y * W + xc) * Q + qq];
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      return v;
+    };
+    float4 acc[1 + 2 * kWsMaxBorder];
+#pragma unroll
+    for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = y0; y < y1; ++y) {
+      // the 4 waves take pixels x = wave, wave+4, ...: each load instruction reads one pixel's channels, contiguous
+      float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+      int xc = wave;
+      for (; xc + 4 < W; xc += 8) {
+        const float4 a = ld(y, xc), c2 = ld(y, xc + 4);
+        t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
+        t1.x += c2.x; t1.y += c2.y; t1.z += c2.z; t1.w += c2.w;
+      }
+      if (xc < W) { const float4 a = ld(y, xc); t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w; }
+      acc[0].x += t0.x + t1.x; acc[0].y += t0.y + t1.y; acc[0].z += t0.z + t1.z; acc[0].w += t0.w + t1.w;
+      // border columns (static j, wave-uniform owner): re-read from L1
+#pragma unroll
+      for (int j = 0; j < kWsMaxBorder; ++j) {
+        if (j < nb) {
+          if ((j & 3) == wave) { const float4 a = ld(y, j); acc[1 + j].x += a.x; acc[1 + j].y += a.y; acc[1 + j].z += a.z; acc[1 + j].w += a.w; }
+          const int xr = W - nb + j;
+          if ((xr & 3) == wave) {
+            const float4 a = ld(y, xr);
+            acc[1 + kWsMaxBorder + j].x += a.x; acc[1 + kWsMaxBorder + j].y += a.y;
+            acc[1 + kWsMaxBorder + j].z += a.z; acc[1 + kWsMaxBorder + j].w += a.w;
+          }
+        }
+      }
+    }
+    auto put = [&](int i, const float4& v) {  // value index i of this lane's 4 channels
+      float* o = part + ((((size_t)b * nseg + s) * Q + q) * 4) * nval + i;
+      o[0] = v.x; o[nval] = v.y; o[2 * nval] = v.z; o[3 * nval] = v.w;
+    };
+    __syncthreads();
+    s_tot[wave][lane] = acc[0];
+#pragma unroll
+    for (int j = 0; j < kWsMaxBorder; ++j) {
+      if (j < nb && on) {
+        if ((j & 3) == wave) put(1 + j, acc[1 + j]);
+        if (((W - nb + j) & 3) == wave) put(1 + nb + j, acc[1 + kWsMaxBorder + j]);
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && on) {
+      const float4 a = s_tot[0][lane], b2 = s_tot[1][lane], c2 = s_tot[2][lane], d = s_tot[3][lane];
+      put(0, make_float4((a.x + b2.x) + (c2.x + d.x), (a.y + b2.y) + (c2.y + d.y), (a.z + b2.z) + (c2.z + d.z), (a.w + b2.w) + (c2.w + d.w)));
+    }
+  }
+}
+
+// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64
+__global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
+                                                                            int B, int C, int k, int nseg) {
+  const int idx = blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  const int nb = k - 1, nval = 1 + 2 * nb;
+  auto P = [&](int s, int i) { return (double)part[(((size_t)b * nseg + s) * C + c) * nval + i]; };
+  double tot = 0.0, col[2 * kWsMaxBorder];
+#pragma unroll
+  for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = 0.0;
+  for (int s = 0; s < nseg; ++s) {
+    tot += P(s, 0);
+    for (int j = 0; j < 2 * nb; ++j) col[j] += P(s, 1 + j);
+  }
+  // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
+  // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
+  for (int u = 0; u < k; ++u) {
+    for (int v = 0; v < k; ++v) {
+      double acc = tot;
+      for (int r = 0; r < nb; ++r) {
+        const bool top_ex = r < u, bot_ex = r >= u;
+        if (top_ex) acc -= P(r, 0);
+        if (bot_ex) acc -= P(nb + r, 0);
+      }
+      for (int j = 0; j < nb; ++j) {
+        const bool l_ex = j < v, r_ex = j >= v;
+        if (l_ex) acc -= col[j];
+        if (r_ex) acc -= col[nb + j];
+        for (int r = 0; r < nb; ++r) {  // excluded rows x excluded columns were subtracted twice
+          if (r < u) acc += (l_ex ? P(r, 1 + j) : 0.0) + (r_ex ? P(r, 1 + nb + j) : 0.0);
+          if (r >= u) acc += (l_ex ? P(nb + r, 1 + j) : 0.0) + (r_ex ? P(nb + r, 1 + nb + j) : 0.0);
+        }
+      }
+      out[((size_t)b * C + c) * (k * k) + u * k + v] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // P4 / P3: SO(3) action on point clouds, batched Gram-Schmidt
 // ------------------------------------------------------------------------------------------------
 
@@ -1170,6 +1320,47 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
     hipLaunchKernelGGL((window_sums_kernel<true>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
   else
     hipLaunchKernelGGL((window_sums_kernel<false>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
+  return launch_status();
+}
+
+int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream) {
+  if (!x || !bias || n_pixels < 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (((uintptr_t)x | (uintptr_t)bias) & 15)) return EQA_ERR_UNSUPPORTED;
+  if (n_pixels == 0) return EQA_OK;
+  const size_t n_vec = (size_t)n_pixels * (C / 4);
+  const unsigned blocks = (unsigned)((n_vec + kThreads - 1) / kThreads < 8192 ? (n_vec + kThreads - 1) / kThreads : 8192);
+  hipLaunchKernelGGL(bias_relu_nhwc_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, bias, n_vec, C / 4);
+  return launch_status();
+}
+
+static int ws_nhwc_bands(int H, int k) {
+  const int interior = H - 2 * (k - 1);
+  int nb = (interior + 9) / 10;  // ~10 rows per band
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k) {
+  if (B <= 0 || C <= 0 || H <= 0 || k <= 0) return 0;
+  const int nseg = 2 * (k - 1) + ws_nhwc_bands(H, k);
+  return (int64_t)B * nseg * C * (1 + 2 * (k - 1)) * (int64_t)sizeof(float);
+}
+
+int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
+                         int B, int C, int H, int W, int k, void* stream) {
+  if (!x || !out || !workspace || B < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
+  // needs disjoint top / bottom (left / right) border sets and at least one interior row
+  if (k > kMaxWinK || C % 4 != 0 || H < 2 * (k - 1) + 1 || W < 2 * (k - 1) + 1 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (scale && (((uintptr_t)scale) & 15)) || (shift && (((uintptr_t)shift) & 15))) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbands = ws_nhwc_bands(H, k);
+  const int nseg = 2 * (k - 1) + nbands;
+  hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
+                     (float*)workspace, C, H, W, k, nbands);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+                     (const float*)workspace, out, B, C, k, nseg);
   return launch_status();
 }
 

@@ -85,23 +85,32 @@ class ESCNNEquivariantNetwork(nn.Module):
         bank = conv.expanded_weights() * scale.repeat_interleave(E)[:, None, None, None]
         b = conv.bias if conv.bias is not None else torch.zeros_like(scale)
         bias = (b * scale + shift).repeat_interleave(E)
-        bank, bias = bank.contiguous(), bias.contiguous()
+        # channels-last: MIOpen's fp32 implicit-GEMM kernels are NHWC; keeping the bank (and the activations) in that
+        # layout removes the NCHW<->NHWC transposes around every convolution
+        bank, bias = bank.contiguous(memory_format=torch.channels_last), bias.contiguous()
         self._fold_cache[id(conv)] = (key, bank, bias)
         return bank, bias
 
     def _forward_inference(self, x: torch.Tensor) -> torch.Tensor:
         """eval + no_grad: conv(+folded BN) -> ReLU ... -> [last conv + group mean as window sums]."""
+        from equiadapt_amd import ops
+
         mods = list(self.eqv_network)
         convs = [m for m in mods if hasattr(m, "expanded_weights")]
         norms = [m for m in mods if isinstance(m, _InnerBatchNorm)]
-        h = x
+        nhwc = (self.out_channels * self.num_group_elements) % 4 == 0
+        h = x.contiguous(memory_format=torch.channels_last) if nhwc else x
         for i, (conv, bn) in enumerate(zip(convs[:-1], norms)):
             bank, bias = self._folded(conv, bn)
             if i == len(convs) - 2:
                 # bias + ReLU of this layer are applied inside the window-sum pass of the next (last) layer
                 c = F.conv2d(h, bank)
                 return conv_then_group_pool(c, convs[-1], shift=bias, relu=True)
-            h = torch.relu_(F.conv2d(h, bank, bias))
+            h = F.conv2d(h, bank)
+            if nhwc and h.is_contiguous(memory_format=torch.channels_last):
+                ops.bias_relu_nhwc_(h, bias)                      # one fused in-place pass
+            else:
+                h = torch.relu_(h + bias[None, :, None, None])
         raise AssertionError("unreachable: the network always has at least two convolutions")
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

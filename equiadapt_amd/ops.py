@@ -219,11 +219,19 @@ def window_sums(x: torch.Tensor, k: int, scale: Optional[torch.Tensor] = None, s
     """(B,C,H,W) fp32 -> (B,C,k,k) fp64 sums of act(x) over the k*k shifted (H-k+1)x(W-k+1) windows
     (eqa_window_sums); act(t) = [relu](scale[c]*t + shift[c])."""
     lib = _lib.load()
-    x = _need(x, "x")
     B, C, H, W = x.shape
     scale, p_scale = _opt(scale, "scale", torch.float32)
     shift, p_shift = _opt(shift, "shift", torch.float32)
     out = torch.empty((B, C, k, k), dtype=torch.float64, device=x.device)
+    if (x.is_cuda and x.dtype == torch.float32 and C % 4 == 0 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last) and H > 2 * (k - 1) and W > 2 * (k - 1)):
+        # (B,H,W,C) in memory: the channels-last kernels read it as it is
+        ws = torch.empty((max(lib.eqa_window_sums_nhwc_workspace_bytes(B, C, H, k), 4) // 4,), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device), _timed("window_sums"):
+            st = lib.eqa_window_sums_nhwc(x.data_ptr(), p_scale, p_shift, int(relu), out.data_ptr(), ws.data_ptr(), B, C, H, W, k, _stream())
+        _lib.check(st, "eqa_window_sums_nhwc")
+        return out
+    x = _need(x, "x")
     with torch.cuda.device(x.device), _timed("window_sums"):
         st = lib.eqa_window_sums(x.data_ptr(), p_scale, p_shift, int(relu), out.data_ptr(), B, C, H, W, k, _stream())
     _lib.check(st, "eqa_window_sums")
@@ -315,3 +323,16 @@ def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.T
                                          rtheta.shape[0], n, H, W, _stream())
     _lib.check(st, "eqa_mask_action_nearest")
     return out
+
+
+def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """In place x = relu(x + bias[c]) on a channels-last (B,C,H,W) tensor (eqa_bias_relu_nhwc)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("bias_relu_nhwc_ expects a channels-last fp32 tensor on the device")
+    bias = _need(bias, "bias")
+    B, C, H, W = x.shape
+    with torch.cuda.device(x.device), _timed("bias_relu"):
+        st = lib.eqa_bias_relu_nhwc(x.data_ptr(), bias.data_ptr(), B * H * W, C, _stream())
+    _lib.check(st, "eqa_bias_relu_nhwc")
+    return x

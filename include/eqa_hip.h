@@ -157,6 +157,18 @@ int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* wo
 int eqa_window_sums(const float* x, const float* scale, const float* shift, int relu, double* out, int B, int C, int H,
                     int W, int k, void* stream);
 
+/*
+ * Channels-last companions of the canonicalization-network inference path (MIOpen's fp32 convs run natively in NHWC):
+ *   eqa_bias_relu_nhwc    x[p][c] = max(x[p][c] + bias[c], 0) in place; x:(n_pixels, C), C % 4 == 0
+ *                         (bias / folded eval batch-norm + ReLU between two convolutions, escnn_networks.py:67-85);
+ *   eqa_window_sums_nhwc  eqa_window_sums for a (B,H,W,C) buffer; out:(B,C,k,k) fp64 as above;
+ *                         workspace: eqa_window_sums_nhwc_workspace_bytes(B, C, H, k) bytes.
+ */
+int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream);
+int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k);
+int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
+                         int B, int C, int H, int W, int k, void* stream);
+
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);
 

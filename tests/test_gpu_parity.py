@@ -531,3 +531,22 @@ def test_cfg5_shape_d4_1024(dev):
     out = canonicalize_masks(masks, gidx.to(dev, torch.int32), 4, flip_all=True)
     for e in (1, 6):
         assert torch.equal(out[e].cpu(), io.rotate_masks(io.flip_masks(masks[e].cpu()), -ang[e].item()))
+
+
+def test_channels_last_kernels(dev):
+    """eqa_window_sums_nhwc / eqa_bias_relu_nhwc against the NCHW kernel and plain torch."""
+    from equiadapt_amd import ops
+
+    torch.manual_seed(19)
+    for (B, C, H, W, k) in [(3, 8, 20, 24, 5), (2, 256, 88, 88, 5), (2, 12, 11, 13, 3), (1, 4, 9, 9, 1), (2, 68, 30, 30, 5)]:
+        x = torch.randn(B, C, H, W, device=dev)
+        scale, shift = (torch.rand(C, device=dev) + 0.5), torch.randn(C, device=dev) * 0.3
+        xcl = x.contiguous(memory_format=torch.channels_last)
+        for relu in (True, False):
+            want = ops.window_sums(x, k, scale, shift, relu)
+            got = ops.window_sums(xcl, k, scale, shift, relu)
+            assert torch.allclose(got, want, atol=2e-3, rtol=1e-6), (B, C, H, W, k, relu)  # fp32 segment partials
+        bias = torch.randn(C, device=dev)
+        y = xcl.clone()
+        ops.bias_relu_nhwc_(y, bias)
+        assert torch.equal(y, torch.relu(x + bias[None, :, None, None]))
