@@ -5,7 +5,14 @@ Public names mirror ``equiadapt/__init__.py`` of the reference for the classes o
 ``include/eqa_hip.h``).  There is no CPU fallback: ops raise if the library is missing or a tensor is
 not on a ROCm device.
 """
-from equiadapt_amd.common.basecanonicalization import (  # noqa: F401
+import os as _os
+
+# MIOpen's one-time algorithm search (first convolution of each shape in a process) also times its *naive reference*
+# solver; for the channels-last 256->256 5x5 layer of the canonicalization network that is 16 runs of 6.7 s (measured,
+# profiles/r01).  Excluding that debug solver keeps the real search (1.6 s) and the same winner.  Overridable.
+_os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+
+from equiadapt_amd.common.basecanonicalization import (  # noqa: E402,F401
     BaseCanonicalization,
     ContinuousGroupCanonicalization,
     DiscreteGroupCanonicalization,
