@@ -550,3 +550,38 @@ def test_channels_last_kernels(dev):
         y = xcl.clone()
         ops.bias_relu_nhwc_(y, bias)
         assert torch.equal(y, torch.relu(x + bias[None, :, None, None]))
+
+
+def test_step_is_hipgraph_capturable(dev):
+    """canonicalize + invert launch only stream-ordered kernels and never sync the host, so a whole inference step can
+    be captured into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed on new data."""
+    import equiadapt_amd as ea
+
+    torch.manual_seed(20)
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 4, 5, "rotation", 8, 2, device="cpu")
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=32)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 64, 64)).to(dev).eval()
+    x_static = torch.randn(8, 3, 64, 64, device=dev)
+    f_static = torch.randn(8, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        for _ in range(2):  # warm-up outside capture (table uploads, MIOpen search)
+            can(x_static)
+            can.invert_canonicalization(f_static, induced_rep_type="scalar")
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            y_static = can(x_static)
+            inv_static = can.invert_canonicalization(f_static, induced_rep_type="scalar")
+            idx_static = can.canonicalization_info_dict["group_index"]
+        for seed in (1, 2):
+            xn = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(seed)).to(dev)
+            fn = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(10 + seed)).to(dev)
+            x_static.copy_(xn)
+            f_static.copy_(fn)
+            g.replay()
+            torch.cuda.synchronize()
+            y_g, inv_g, idx_g = y_static.clone(), inv_static.clone(), idx_static.clone()
+            y_e = can(xn)
+            inv_e = can.invert_canonicalization(fn, induced_rep_type="scalar")
+            assert torch.equal(idx_g, can.canonicalization_info_dict["group_index"])
+            assert torch.equal(y_g, y_e) and torch.equal(inv_g, inv_e)
