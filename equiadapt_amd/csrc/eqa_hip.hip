@@ -955,43 +955,67 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
 // (r00, r10, r20, r01, r11, r21): gx = xb*r00 + yb*r10 + r20, gy = xb*r01 + yb*r11 + r21.
 // One thread = 4 consecutive output pixels (one 32-bit store).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void mask_action_nearest_kernel(const uint8_t* __restrict__ m, uint8_t* __restrict__ out,
-                                                                      const int32_t* __restrict__ eidx,
-                                                                      const float* __restrict__ rtheta,
-                                                                      const int32_t* __restrict__ flags, int E, int H, int W) {
-  const int n = blockIdx.z;
+// Generic form (T = uint8 masks or fp32 images): output plane p of (n_planes) samples source plane p % src_mod with
+// element eidx[p]; the sampling frame is the source plane edge-padded by `pad`, the output the (OH,OW) window at
+// (top,left) of the frame -- GroupInference's pad(0.4 H) -> [hflip] -> rotate(+deg) -> CenterCrop on float images
+// (examples/images/classification/inference_utils.py:100-123: torchvision rotate defaults to NEAREST) uses all of it.
+template <typename T>
+struct Pack4;
+template <>
+struct Pack4<uint8_t> {
+  typedef uint32_t type;
+  static __device__ __forceinline__ type make(const uint8_t (&v)[4]) {
+    return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  }
+};
+template <>
+struct Pack4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ type make(const float (&v)[4]) { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nearest_action_kernel(const T* __restrict__ m, T* __restrict__ out,
+                                                                 const int32_t* __restrict__ eidx,
+                                                                 const float* __restrict__ rtheta,
+                                                                 const int32_t* __restrict__ flags, int E, int H, int W,
+                                                                 int pad, int OH, int OW, int top, int left, int src_mod) {
+  const int p = blockIdx.z;
   const int i = blockIdx.y;
   const int jb = (blockIdx.x * kThreads + threadIdx.x) * 4;
-  if (jb >= W) return;
-  const int e = min(max(eidx[n], 0), E - 1);
+  if (jb >= OW) return;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int e = min(max(eidx[p], 0), E - 1);
   const float* t = rtheta + e * 6;
   const bool flip = flags && (flags[e] & EQA_FLIP_SRC);
-  const uint8_t* src = m + (size_t)n * H * W;
-  const float yb = ((float)i + 0.5f) - 0.5f * (float)H;
-  uint8_t v[4];
+  const T* src = m + (size_t)(src_mod > 0 ? p % src_mod : p) * H * W;
+  const float yb = ((float)(top + i) + 0.5f) - 0.5f * (float)Hp;
+  T v[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int j = jb + k;
-    const float xb = ((float)j + 0.5f) - 0.5f * (float)W;
+    const int j = left + jb + k;
+    const float xb = ((float)j + 0.5f) - 0.5f * (float)Wp;
     const float gx = xb * t[0] + yb * t[1] + t[2];
     const float gy = xb * t[3] + yb * t[4] + t[5];
-    const float ix = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
-    const float iy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    const float ix = ((gx + 1.0f) * (float)Wp - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * (float)Hp - 1.0f) / 2.0f;
     const float xr = rintf(ix), yr = rintf(iy);  // std::nearbyint: round half to even
-    uint8_t val = 0;
-    if (xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1)) {
-      const int sx = flip ? (W - 1 - (int)xr) : (int)xr;
-      val = src[(size_t)(int)yr * W + sx];
+    T val = (T)0;
+    if (xr >= 0.0f && xr <= (float)(Wp - 1) && yr >= 0.0f && yr <= (float)(Hp - 1)) {
+      const int fx = flip ? (Wp - 1 - (int)xr) : (int)xr;
+      const int sx = min(max(fx - pad, 0), W - 1), sy = min(max((int)yr - pad, 0), H - 1);
+      val = src[(size_t)sy * W + sx];
     }
     v[k] = val;
   }
-  uint8_t* o = out + (size_t)n * H * W + (size_t)i * W + jb;
-  if (jb + 3 < W && ((((uintptr_t)o) & 3) == 0)) {
-    *reinterpret_cast<uint32_t*>(o) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  T* o = out + (size_t)p * OH * OW + (size_t)i * OW + jb;
+  typedef typename Pack4<T>::type P4;
+  if (jb + 3 < OW && ((((uintptr_t)o) & (sizeof(P4) - 1)) == 0)) {
+    *reinterpret_cast<P4*>(o) = Pack4<T>::make(v);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (jb + k < W) o[k] = v[k];
+      if (jb + k < OW) o[k] = v[k];
   }
 }
 
@@ -1196,6 +1220,19 @@ __global__ void vnsmall_finalize_kernel(const float* __restrict__ partial, float
   out[i] = acc * inv_n;
 }
 
+template <typename T>
+int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta, const int32_t* flags, int E,
+                          int n_planes, int H, int W, int pad, int OH, int OW, int top, int left, int src_mod, void* stream) {
+  if (!m || !out || !eidx || !rtheta || E <= 0 || n_planes < 0 || H <= 0 || W <= 0 || pad < 0 || OH <= 0 || OW <= 0 ||
+      top < 0 || left < 0 || top + OH > H + 2 * pad || left + OW > W + 2 * pad || src_mod < 0)
+    return EQA_ERR_INVALID_ARG;
+  if (n_planes > 65535 || OH > 65535) return EQA_ERR_UNSUPPORTED;
+  if (n_planes == 0) return EQA_OK;
+  hipLaunchKernelGGL((nearest_action_kernel<T>), dim3((OW / 4 + kThreads) / kThreads, OH, n_planes), dim3(kThreads), 0,
+                     (hipStream_t)stream, m, out, eidx, rtheta, flags, E, H, W, pad, OH, OW, top, left, src_mod);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
 }  // namespace
@@ -1391,12 +1428,13 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
 
 int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
                             int num_elements, int n_masks, int H, int W, void* stream) {
-  if (!m || !out || !eidx || !rtheta || num_elements <= 0 || n_masks < 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
-  if (n_masks > 65535 || H > 65535) return EQA_ERR_UNSUPPORTED;
-  if (n_masks == 0) return EQA_OK;
-  hipLaunchKernelGGL(mask_action_nearest_kernel, dim3((W / 4 + kThreads) / kThreads, H, n_masks), dim3(kThreads), 0,
-                     (hipStream_t)stream, m, out, eidx, rtheta, flags, num_elements, H, W);
-  return launch_status();
+  return launch_nearest<uint8_t>(m, out, eidx, rtheta, flags, num_elements, n_masks, H, W, 0, H, W, 0, 0, 0, stream);
+}
+
+int eqa_image_action_nearest(const float* x, float* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                             int num_elements, int n_planes, int src_mod, int H, int W, int pad, int OH, int OW, int top,
+                             int left, void* stream) {
+  return launch_nearest<float>(x, out, eidx, rtheta, flags, num_elements, n_planes, H, W, pad, OH, OW, top, left, src_mod, stream);
 }
 
 int64_t eqa_vnsmall_workspace_bytes(int B, int N) {

@@ -336,3 +336,21 @@ def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
         st = lib.eqa_bias_relu_nhwc(x.data_ptr(), bias.data_ptr(), B * H * W, C, _stream())
     _lib.check(st, "eqa_bias_relu_nhwc")
     return x
+
+
+def image_action_nearest(x: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor],
+                         pad: int, out_hw: Tuple[int, int], top_left: Tuple[int, int], n_planes: int, src_mod: int) -> torch.Tensor:
+    """fp32 planes (P,H,W) -> (n_planes, OH, OW): nearest-neighbour action with edge pad + crop (eqa_image_action_nearest)."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    eidx = _need(eidx, "eidx", torch.int32)
+    rtheta = _need(rtheta, "rtheta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    P, H, W = x.shape
+    out = torch.empty((n_planes, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_image_action_nearest(x.data_ptr(), out.data_ptr(), eidx.data_ptr(), rtheta.data_ptr(), p_flags,
+                                          rtheta.shape[0], n_planes, src_mod, H, W, pad, out_hw[0], out_hw[1],
+                                          top_left[0], top_left[1], _stream())
+    _lib.check(st, "eqa_image_action_nearest")
+    return out

@@ -116,6 +116,17 @@ int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx,
                             int num_elements, int n_masks, int H, int W, void* stream);
 
 /*
+ * (f).2 -- nearest-neighbour group action on fp32 image planes with edge padding and a crop window: the test-time orbit
+ * of GroupInference (examples/images/classification/inference_utils.py:100-123: transforms.Pad(0.4 H, edge) ->
+ * [hflip] -> transforms.functional.rotate(+deg) [NEAREST by default] -> CenterCrop).
+ * x:(src planes,H,W); out plane p samples source plane (src_mod > 0 ? p % src_mod : p) with element eidx[p];
+ * frame = (H+2 pad, W+2 pad); out:(n_planes,OH,OW) = the window at (top,left); rtheta rescaled by the FRAME size.
+ */
+int eqa_image_action_nearest(const float* x, float* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                             int num_elements, int n_planes, int src_mod, int H, int W, int pad, int OH, int OW, int top,
+                             int left, void* stream);
+
+/*
  * Backward of eqa_group_action_fwd (and so of I5 / I7 / I8), what the reference obtains from autograd through
  * K.geometry.rotate (discrete_group.py:213, images/utils.py:57,82):
  *   grad_src            dL/d(src), shape of src, MUST be zero-filled by the caller; accumulated with float atomics

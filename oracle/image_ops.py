@@ -434,3 +434,21 @@ def rotate_exact_fp64(x: torch.Tensor, angle_deg: torch.Tensor, pad: int = 0, cr
             vals = xd[bidx, :, qy, qx].permute(0, 3, 1, 2)  # (B, C, ch, cw)
             out += (wy * wx * inside)[:, None] * vals
     return out
+
+
+def group_inference_orbit(x: torch.Tensor, num_rotations: int, group_type: str) -> torch.Tensor:
+    """Row (f).2: the test-time orbit of GroupInference, examples/images/classification/inference_utils.py:100-123.
+
+    pad(edge, ceil(0.4 H)) -> [hflip] -> torchvision rotate(+deg) (NEAREST on tensors) -> CenterCrop(H, W);
+    returns (E, B, C, H, W) in the reference's element order (rotations, then rotations of the reflection).
+    """
+    B, C, H, W = x.shape
+    pad = math.ceil(H * 0.4)
+    degrees = torch.linspace(0, 360, num_rotations + 1)[:-1]
+    xp = tv_pad_edge(x, pad)
+    outs = []
+    for flip in ([False, True] if group_type == "roto-reflection" else [False]):
+        src = xp.flip(-1) if flip else xp
+        for d in degrees:
+            outs.append(tv_center_crop(tv_rotate_nearest(src, d.item()), (H, W)))
+    return torch.stack(outs, dim=0)

@@ -585,3 +585,32 @@ def test_step_is_hipgraph_capturable(dev):
             inv_e = can.invert_canonicalization(fn, induced_rep_type="scalar")
             assert torch.equal(idx_g, can.canonicalization_info_dict["group_index"])
             assert torch.equal(y_g, y_e) and torch.equal(inv_g, inv_e)
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 4), ("roto-reflection", 4), ("rotation", 8)])
+def test_group_inference_orbit_and_metrics(dev, group_type, N):
+    """GroupInference (reference examples/images/classification/inference_utils.py): orbit bit-exact vs the oracle
+    (nearest sampling moves pixels, it does not interpolate), metrics computed like the reference."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.inference import get_inference_method
+
+    torch.manual_seed(21)
+    x = torch.randn(5, 3, 32, 40)
+    hp = types.SimpleNamespace(method="group", group_type=group_type, num_rotations=N)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(3 * 32 * 40, 4)).to(dev)
+    inf = get_inference_method(ea.IdentityCanonicalization(), net, 4, hp, (3, 32, 40))
+    orbit = inf.group_orbit(x.to(dev)).cpu()
+    want = io.group_inference_orbit(x, N, group_type)
+    assert orbit.shape == want.shape
+    assert torch.equal(orbit, want)
+    y = torch.tensor([0, 1, 2, 3, 0], device=dev)
+    with torch.no_grad():
+        m = inf.get_inference_metrics(x.to(dev), y)
+        logits0 = net(want[0].to(dev))
+    E = N if group_type == "rotation" else 2 * N
+    assert set(f"test/acc_group_element_{i}" for i in range(E)) <= set(m)
+    assert torch.isclose(m["test/acc"].cpu(), (logits0.argmax(-1) == y).float().mean().cpu())
+    van = get_inference_method(ea.IdentityCanonicalization(), net, 4, types.SimpleNamespace(method="vanilla"))
+    assert "test/acc" in van.get_inference_metrics(x.to(dev), y)
+    with pytest.raises(ValueError):
+        get_inference_method(None, None, 4, types.SimpleNamespace(method="ensemble"))
