@@ -844,6 +844,94 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Winograd F(2x2, 5x5) transforms for the 256->256 5x5 layer of the canonicalization network (inference, channels-last).
+// Cook-Toom at the points {0, 1, -1, 2, -2, inf}: 36 multiplies per 2x2 output tile and channel pair instead of 100.
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A         B^T integer (below), G rational -> applied to the static filters
+// offline in fp64, A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,1]].  The channel contraction of the 36 transformed planes is a
+// plain strided-batched fp32 GEMM (library); these two kernels are the HBM-bound ends:
+//   input  : x (nimg, H, W, C) -> V (36, tiles, C),  tile (ty,tx) = rows 2ty..2ty+5, cols 2tx..2tx+5
+//   output : M (36, tiles, C)  -> y (nimg, OH, OW, C) = [relu](A^T M A + bias),  OH = H-4, OW = W-4 (both even)
+// One thread = one (tile, channel): all accesses are contiguous over channels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino_bt(const float (&d)[6], float (&t)[6]) {
+  t[0] = 4.0f * d[0] - 5.0f * d[2] + d[4];
+  t[1] = 4.0f * (d[1] + d[2]) - (d[3] + d[4]);
+  t[2] = 4.0f * (d[2] - d[1]) + (d[3] - d[4]);
+  t[3] = 2.0f * (d[3] - d[1]) + (d[4] - d[2]);
+  t[4] = 2.0f * (d[1] - d[3]) + (d[4] - d[2]);
+  t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
+}
+
+__global__ __launch_bounds__(kThreads) void winograd_f2k5_input_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                      int H, int W, int C, int TY, int TX, size_t tiles) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t tile = blockIdx.x;  // = (img * TY + ty) * TX + tx
+  const int tx = (int)(tile % TX);
+  const size_t r = tile / TX;
+  const int ty = (int)(r % TY);
+  const size_t img = r / TY;
+  const float* p = x + ((img * H + 2 * ty) * (size_t)W + 2 * tx) * C + c;
+  float d[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) d[i][j] = p[((size_t)i * W + j) * C];
+  // columns: t = B^T d
+  float t[6][6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float col[6] = {d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]};
+    float o[6];
+    wino_bt(col, o);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+  }
+  // rows: V = t B
+  float* vout = V + tile * C + c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    float o[6];
+    wino_bt(t[i], o);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) vout[(size_t)(i * 6 + j) * tiles * C] = o[j];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void winograd_f2k5_output_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                                       int relu, float* __restrict__ y, int OH, int OW, int C,
+                                                                       int TY, int TX, size_t tiles) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t tile = blockIdx.x;
+  const int tx = (int)(tile % TX);
+  const size_t r = tile / TX;
+  const int ty = (int)(r % TY);
+  const size_t img = r / TY;
+  const float* mp = M + tile * C + c;
+  float s0[6], s1[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    float m[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)(i * 6 + j) * tiles * C];
+    s0[j] = (m[0] + m[1]) + (m[2] + m[3]) + m[4];
+    s1[j] = (m[1] - m[2]) + 2.0f * (m[3] - m[4]) + m[5];
+  }
+  const float b = bias ? bias[c] : 0.0f;
+  float o00 = (s0[0] + s0[1]) + (s0[2] + s0[3]) + s0[4] + b;
+  float o01 = (s0[1] - s0[2]) + 2.0f * (s0[3] - s0[4]) + s0[5] + b;
+  float o10 = (s1[0] + s1[1]) + (s1[2] + s1[3]) + s1[4] + b;
+  float o11 = (s1[1] - s1[2]) + 2.0f * (s1[3] - s1[4]) + s1[5] + b;
+  if (relu) { o00 = fmaxf(o00, 0.f); o01 = fmaxf(o01, 0.f); o10 = fmaxf(o10, 0.f); o11 = fmaxf(o11, 0.f); }
+  float* q = y + ((img * OH + 2 * ty) * (size_t)OW + 2 * tx) * C + c;
+  q[0] = o00;
+  q[C] = o01;
+  q[(size_t)OW * C] = o10;
+  q[(size_t)OW * C + C] = o11;
+}
+
+// ------------------------------------------------------------------------------------------------
 // P4 / P3: SO(3) action on point clouds, batched Gram-Schmidt
 // ------------------------------------------------------------------------------------------------
 
@@ -1357,6 +1445,31 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
     hipLaunchKernelGGL((window_sums_kernel<true>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
   else
     hipLaunchKernelGGL((window_sums_kernel<false>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
+  return launch_status();
+}
+
+int eqa_winograd_f2k5_input(const float* x, float* V, int nimg, int H, int W, int C, void* stream) {
+  if (!x || !V || nimg < 0 || H < 6 || W < 6 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (((H - 4) & 1) || ((W - 4) & 1)) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  const int TY = (H - 4) / 2, TX = (W - 4) / 2;
+  const size_t tiles = (size_t)nimg * TY * TX;
+  if (tiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(winograd_f2k5_input_kernel, dim3((unsigned)tiles, (C + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                     (hipStream_t)stream, x, V, H, W, C, TY, TX, tiles);
+  return launch_status();
+}
+
+int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
+                             void* stream) {
+  if (!M || !y || nimg < 0 || OH < 2 || OW < 2 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if ((OH & 1) || (OW & 1)) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  const int TY = OH / 2, TX = OW / 2;
+  const size_t tiles = (size_t)nimg * TY * TX;
+  if (tiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(winograd_f2k5_output_kernel, dim3((unsigned)tiles, (C + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                     (hipStream_t)stream, M, bias, relu, y, OH, OW, C, TY, TX, tiles);
   return launch_status();
 }
 

@@ -180,6 +180,17 @@ int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k);
 int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
                          int B, int C, int H, int W, int k, void* stream);
 
+/*
+ * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(2x2, 5x5), channels-last:
+ *   eqa_winograd_f2k5_input   x:(nimg,H,W,C) -> V:(36, nimg*TY*TX, C), TY = (H-4)/2, TX = (W-4)/2   (B^T d B)
+ *   [ strided-batched fp32 GEMM by the caller:  M[xi] = V[xi] (tiles x Cin) . U[xi] (Cin x Cout),  U = G g G^T ]
+ *   eqa_winograd_f2k5_output  M:(36, nimg*TY*TX, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  OH, OW even
+ * Cook-Toom points {0, 1, -1, 2, -2, inf}; matrices in csrc/eqa_hip.hip and images/canonicalization_networks/winograd.py.
+ */
+int eqa_winograd_f2k5_input(const float* x, float* V, int nimg, int H, int W, int C, void* stream);
+int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
+                             void* stream);
+
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);
 

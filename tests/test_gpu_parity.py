@@ -614,3 +614,27 @@ def test_group_inference_orbit_and_metrics(dev, group_type, N):
     assert "test/acc" in van.get_inference_metrics(x.to(dev), y)
     with pytest.raises(ValueError):
         get_inference_method(None, None, 4, types.SimpleNamespace(method="ensemble"))
+
+
+def test_winograd_conv_matches_direct(dev):
+    """Winograd F(2x2,5x5) (transform kernels + batched GEMM) vs F.conv2d in fp64 and vs MIOpen's fp32 direct conv."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd.images.canonicalization_networks import winograd
+
+    torch.manual_seed(22)
+    for (B, Cin, Cout, H, W) in [(3, 32, 48, 12, 16), (2, 64, 64, 30, 30), (70, 32, 32, 10, 10), (2, 256, 256, 20, 20)]:
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        g = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cin ** 0.5)
+        bias = torch.randn(Cout, device=dev)
+        assert winograd.applicable(x, Cin, Cout)
+        got = winograd.conv5x5(x, winograd.transform_filters(g), bias, relu=True)
+        assert got.is_contiguous(memory_format=torch.channels_last) and got.shape == (B, Cout, H - 4, W - 4)
+        exact = torch.relu(F.conv2d(x.double(), g.double(), bias.double()))
+        direct = torch.relu(F.conv2d(x, g, bias))
+        e_w = (got.double() - exact).abs().max().item()
+        e_d = (direct.double() - exact).abs().max().item()
+        scale = exact.abs().max().item()
+        assert e_w <= 2e-5 * scale, (e_w, e_d, scale)   # fp32 Winograd: a few ulp-amplifications above the direct conv
+        got2 = winograd.conv5x5(x, winograd.transform_filters(g), None, relu=False)
+        assert (got2.double() - F.conv2d(x.double(), g.double())).abs().max().item() <= 2e-5 * scale
