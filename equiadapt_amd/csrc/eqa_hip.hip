@@ -862,7 +862,10 @@ __device__ __forceinline__ void wino_bt(const float (&d)[6], float (&t)[6]) {
   t[5] = 4.0f * d[1] - 5.0f * d[3] + d[5];
 }
 
+// Optional on-the-fly activation of the INPUT: d = relu(x + in_bias[c]) (the previous layer's folded bias / batch-norm
+// and ReLU), which removes a separate pass over the previous feature map.
 __global__ __launch_bounds__(kThreads) void winograd_f2k5_input_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                      const float* __restrict__ in_bias, int in_relu,
                                                                       int H, int W, int C, int TY, int TX, size_t tiles) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
@@ -872,11 +875,15 @@ __global__ __launch_bounds__(kThreads) void winograd_f2k5_input_kernel(const flo
   const int ty = (int)(r % TY);
   const size_t img = r / TY;
   const float* p = x + ((img * H + 2 * ty) * (size_t)W + 2 * tx) * C + c;
+  const float ib = in_bias ? in_bias[c] : 0.0f;
   float d[6][6];
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) d[i][j] = p[((size_t)i * W + j) * C];
+    for (int j = 0; j < 6; ++j) {
+      const float v = p[((size_t)i * W + j) * C] + ib;
+      d[i][j] = (in_relu && v < 0.0f) ? 0.0f : v;
+    }
   // columns: t = B^T d
   float t[6][6];
 #pragma unroll
@@ -1448,7 +1455,8 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
   return launch_status();
 }
 
-int eqa_winograd_f2k5_input(const float* x, float* V, int nimg, int H, int W, int C, void* stream) {
+int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                            void* stream) {
   if (!x || !V || nimg < 0 || H < 6 || W < 6 || C <= 0) return EQA_ERR_INVALID_ARG;
   if (((H - 4) & 1) || ((W - 4) & 1)) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
@@ -1456,7 +1464,7 @@ int eqa_winograd_f2k5_input(const float* x, float* V, int nimg, int H, int W, in
   const size_t tiles = (size_t)nimg * TY * TX;
   if (tiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(winograd_f2k5_input_kernel, dim3((unsigned)tiles, (C + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                     (hipStream_t)stream, x, V, H, W, C, TY, TX, tiles);
+                     (hipStream_t)stream, x, V, in_bias, in_relu, H, W, C, TY, TX, tiles);
   return launch_status();
 }
 

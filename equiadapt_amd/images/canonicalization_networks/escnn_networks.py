@@ -109,23 +109,31 @@ class ESCNNEquivariantNetwork(nn.Module):
         norms = [m for m in mods if isinstance(m, _InnerBatchNorm)]
         nhwc = (self.out_channels * self.num_group_elements) % 4 == 0
         h = x.contiguous(memory_format=torch.channels_last) if nhwc else x
+        pending = None  # bias of the previous layer whose (bias + ReLU) has not been applied to `h` yet
         for i, (conv, bn) in enumerate(zip(convs[:-1], norms)):
             bank, bias = self._folded(conv, bn)
+            last_before_tail = i == len(convs) - 2
             use_wino = (nhwc and not conv.lifting and conv.kernel_size == 5 and conv.stride == 1 and conv.padding == 0
                         and winograd.applicable(h, bank.shape[1], bank.shape[0]))
             if use_wino:
-                # 5x5 regular->regular layer: Winograd F(2x2,5x5), bias + ReLU fused into its output transform
-                h = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True)
-                if i == len(convs) - 2:
+                # 5x5 regular->regular layer: Winograd F(2x2,5x5).  The previous layer's bias + ReLU ride on its input
+                # loads, its own bias + ReLU on its output transform.
+                h = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True,
+                                     in_bias=pending, in_relu=pending is not None)
+                pending = None
+                if last_before_tail:
                     return conv_then_group_pool(h, convs[-1])
                 continue
-            if i == len(convs) - 2:
+            if pending is not None:  # the next consumer cannot absorb it: apply in one fused pass
+                ops.bias_relu_nhwc_(h, pending)
+                pending = None
+            if last_before_tail:
                 # bias + ReLU of this layer are applied inside the window-sum pass of the next (last) layer
                 c = F.conv2d(h, bank)
                 return conv_then_group_pool(c, convs[-1], shift=bias, relu=True)
             h = F.conv2d(h, bank)
             if nhwc and h.is_contiguous(memory_format=torch.channels_last):
-                ops.bias_relu_nhwc_(h, bias)                      # one fused in-place pass
+                pending = bias                                    # deferred: fused into whatever reads h next
             else:
                 h = torch.relu_(h + bias[None, :, None, None])
         raise AssertionError("unreachable: the network always has at least two convolutions")

@@ -47,8 +47,10 @@ def applicable(x: torch.Tensor, cin: int, cout: int) -> bool:
             and (W - 4) % 2 == 0 and cin >= 32 and cout >= 32 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
-    """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(x, g) + bias), g given as U."""
+def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
+            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False) -> torch.Tensor:
+    """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as U;
+    act(x) = [relu](x + in_bias[c]) is applied while the input tiles are loaded (previous layer's epilogue)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     Cout = U.shape[2]
@@ -61,11 +63,12 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
     M = torch.empty((36, chunk * TY * TX, Cout), dtype=torch.float32, device=x.device)
     xs, ys = x.data_ptr(), y.data_ptr()
     p_bias = bias.data_ptr() if bias is not None else None
+    p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     with torch.cuda.device(x.device):
         for b0 in range(0, B, chunk):
             n = min(chunk, B - b0)
             t = n * TY * TX
-            st = lib.eqa_winograd_f2k5_input(xs + b0 * H * W * Cin * 4, V.data_ptr(), n, H, W, Cin, stream)
+            st = lib.eqa_winograd_f2k5_input(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
             _lib.check(st, "eqa_winograd_f2k5_input")
             if n == chunk:
                 torch.bmm(V, U, out=M)

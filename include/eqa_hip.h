@@ -182,12 +182,15 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
 
 /*
  * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(2x2, 5x5), channels-last:
- *   eqa_winograd_f2k5_input   x:(nimg,H,W,C) -> V:(36, nimg*TY*TX, C), TY = (H-4)/2, TX = (W-4)/2   (B^T d B)
+ *   eqa_winograd_f2k5_input   x:(nimg,H,W,C) -> V:(36, nimg*TY*TX, C), TY = (H-4)/2, TX = (W-4)/2   (B^T d B), with
+ *                             d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c]  (in_bias NULL = 0): the previous
+ *                             layer's bias / folded batch-norm / ReLU applied while loading
  *   [ strided-batched fp32 GEMM by the caller:  M[xi] = V[xi] (tiles x Cin) . U[xi] (Cin x Cout),  U = G g G^T ]
  *   eqa_winograd_f2k5_output  M:(36, nimg*TY*TX, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  OH, OW even
  * Cook-Toom points {0, 1, -1, 2, -2, inf}; matrices in csrc/eqa_hip.hip and images/canonicalization_networks/winograd.py.
  */
-int eqa_winograd_f2k5_input(const float* x, float* V, int nimg, int H, int W, int C, void* stream);
+int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                            void* stream);
 int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                              void* stream);
 

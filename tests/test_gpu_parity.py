@@ -638,3 +638,8 @@ def test_winograd_conv_matches_direct(dev):
         assert e_w <= 2e-5 * scale, (e_w, e_d, scale)   # fp32 Winograd: a few ulp-amplifications above the direct conv
         got2 = winograd.conv5x5(x, winograd.transform_filters(g), None, relu=False)
         assert (got2.double() - F.conv2d(x.double(), g.double())).abs().max().item() <= 2e-5 * scale
+        # fused input activation: conv(relu(x + in_bias))
+        ib = torch.randn(Cin, device=dev)
+        got3 = winograd.conv5x5(x, winograd.transform_filters(g), bias, relu=True, in_bias=ib, in_relu=True)
+        want3 = torch.relu(F.conv2d(torch.relu(x.double() + ib.double()[None, :, None, None]), g.double(), bias.double()))
+        assert (got3.double() - want3).abs().max().item() <= 2e-5 * want3.abs().max().item()
