@@ -804,41 +804,61 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
   }
 }
 
-// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64
+// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64.  Block = one image x 32 channels; the 8 thread groups of a block
+// split the segment axis for the totals (fixed assignment + fixed-order combine: deterministic), then one thread per
+// channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
+constexpr int kFinCh = 32, kFinParts = kThreads / kFinCh;
+
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
                                                                             int B, int C, int k, int nseg) {
-  const int idx = blockIdx.x * kThreads + threadIdx.x;
-  if (idx >= B * C) return;
-  const int b = idx / C, c = idx - b * C;
+  __shared__ double s_sum[kFinParts][kFinCh][1 + 2 * kWsMaxBorder];
+  const int b = blockIdx.y;
+  const int cl = threadIdx.x % kFinCh, pr = threadIdx.x / kFinCh;
+  const int c = blockIdx.x * kFinCh + cl;
+  const bool on = c < C;
   const int nb = k - 1, nval = 1 + 2 * nb;
   auto P = [&](int s, int i) { return (double)part[(((size_t)b * nseg + s) * C + c) * nval + i]; };
+  double acc[1 + 2 * kWsMaxBorder];
+#pragma unroll
+  for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = 0.0;
+  if (on) {
+    for (int s = pr; s < nseg; s += kFinParts) {
+      const float* q = part + (((size_t)b * nseg + s) * C + c) * nval;
+#pragma unroll
+      for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i)
+        if (i < nval) acc[i] += (double)q[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) s_sum[pr][cl][i] = acc[i];
+  __syncthreads();
+  if (pr != 0 || !on) return;
   double tot = 0.0, col[2 * kWsMaxBorder];
 #pragma unroll
   for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = 0.0;
-  for (int s = 0; s < nseg; ++s) {
-    tot += P(s, 0);
-    for (int j = 0; j < 2 * nb; ++j) col[j] += P(s, 1 + j);
+  for (int q = 0; q < kFinParts; ++q) {
+    tot += s_sum[q][cl][0];
+    for (int j = 0; j < 2 * nb; ++j) col[j] += s_sum[q][cl][1 + j];
   }
   // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
   // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
   for (int u = 0; u < k; ++u) {
     for (int v = 0; v < k; ++v) {
-      double acc = tot;
+      double a = tot;
       for (int r = 0; r < nb; ++r) {
-        const bool top_ex = r < u, bot_ex = r >= u;
-        if (top_ex) acc -= P(r, 0);
-        if (bot_ex) acc -= P(nb + r, 0);
+        if (r < u) a -= P(r, 0);
+        if (r >= u) a -= P(nb + r, 0);
       }
       for (int j = 0; j < nb; ++j) {
         const bool l_ex = j < v, r_ex = j >= v;
-        if (l_ex) acc -= col[j];
-        if (r_ex) acc -= col[nb + j];
+        if (l_ex) a -= col[j];
+        if (r_ex) a -= col[nb + j];
         for (int r = 0; r < nb; ++r) {  // excluded rows x excluded columns were subtracted twice
-          if (r < u) acc += (l_ex ? P(r, 1 + j) : 0.0) + (r_ex ? P(r, 1 + nb + j) : 0.0);
-          if (r >= u) acc += (l_ex ? P(nb + r, 1 + j) : 0.0) + (r_ex ? P(nb + r, 1 + nb + j) : 0.0);
+          if (r < u) a += (l_ex ? P(r, 1 + j) : 0.0) + (r_ex ? P(r, 1 + nb + j) : 0.0);
+          if (r >= u) a += (l_ex ? P(nb + r, 1 + j) : 0.0) + (r_ex ? P(nb + r, 1 + nb + j) : 0.0);
         }
       }
-      out[((size_t)b * C + c) * (k * k) + u * k + v] = acc;
+      out[((size_t)b * C + c) * (k * k) + u * k + v] = a;
     }
   }
 }
@@ -936,6 +956,78 @@ __global__ __launch_bounds__(kThreads) void winograd_f2k5_output_kernel(const fl
   q[C] = o01;
   q[(size_t)OW * C] = o10;
   q[(size_t)OW * C + C] = o11;
+}
+
+// Output transform fused with the window-sum segments of the NEXT (last, linearised) layer: instead of writing the
+// (nimg, OH, OW, C) activation and re-reading it, every output row becomes one "segment" in the format of
+// window_sums_nhwc_finalize_kernel -- per channel [row total, first NB columns, last NB columns] -- with the segment
+// order that kernel expects: rows 0..NB-1, rows OH-NB..OH-1, then the interior rows.  One block = one tile row (two
+// output rows) of one image x 256 channels, looping over the TX tiles.  NB = k_last - 1 must be even (2-wide tiles).
+template <int NB>
+__global__ __launch_bounds__(kThreads) void winograd_f2k5_output_sums_kernel(const float* __restrict__ M, const float* __restrict__ bias,
+                                                                            int relu, float* __restrict__ part, int OH, int OW,
+                                                                            int C, int TY, int TX, size_t tiles, int nseg) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const int ty = blockIdx.x % TY;
+  const size_t img = blockIdx.x / TY;
+  const float b = bias ? bias[c] : 0.0f;
+  constexpr int NV = 1 + 2 * NB;
+  float acc[2][NV > 1 ? NV : 1];
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[r][i] = 0.0f;
+  auto tile_out = [&](int tx, float (&o)[2][2]) {
+    const float* mp = M + ((img * TY + ty) * (size_t)TX + tx) * C + c;
+    float s0[6], s1[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      float m[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) m[i] = mp[(size_t)(i * 6 + j) * tiles * C];
+      s0[j] = (m[0] + m[1]) + (m[2] + m[3]) + m[4];
+      s1[j] = (m[1] - m[2]) + 2.0f * (m[3] - m[4]) + m[5];
+    }
+    o[0][0] = (s0[0] + s0[1]) + (s0[2] + s0[3]) + s0[4] + b;
+    o[0][1] = (s0[1] - s0[2]) + 2.0f * (s0[3] - s0[4]) + s0[5] + b;
+    o[1][0] = (s1[0] + s1[1]) + (s1[2] + s1[3]) + s1[4] + b;
+    o[1][1] = (s1[1] - s1[2]) + 2.0f * (s1[3] - s1[4]) + s1[5] + b;
+    if (relu) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r) { o[r][0] = fmaxf(o[r][0], 0.f); o[r][1] = fmaxf(o[r][1], 0.f); }
+    }
+  };
+  constexpr int HB = NB / 2;  // border tiles per side
+  // left border tiles (static column indices), interior, right border tiles
+#pragma unroll
+  for (int t = 0; t < HB; ++t) {
+    float o[2][2];
+    tile_out(t, o);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { acc[r][0] += o[r][0] + o[r][1]; acc[r][1 + 2 * t] += o[r][0]; acc[r][2 + 2 * t] += o[r][1]; }
+  }
+  for (int tx = HB; tx < TX - HB; ++tx) {
+    float o[2][2];
+    tile_out(tx, o);
+    acc[0][0] += o[0][0] + o[0][1];
+    acc[1][0] += o[1][0] + o[1][1];
+  }
+#pragma unroll
+  for (int t = 0; t < HB; ++t) {
+    float o[2][2];
+    tile_out(TX - HB + t, o);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { acc[r][0] += o[r][0] + o[r][1]; acc[r][1 + NB + 2 * t] += o[r][0]; acc[r][2 + NB + 2 * t] += o[r][1]; }
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int y = 2 * ty + r;
+    const int seg = y < NB ? y : (y >= OH - NB ? NB + (y - (OH - NB)) : 2 * NB + (y - NB));
+    float* o = part + ((img * nseg + seg) * (size_t)C + c) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = acc[r][i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1481,6 +1573,36 @@ int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float*
   return launch_status();
 }
 
+int64_t eqa_winograd_f2k5_output_sums_workspace_bytes(int nimg, int OH, int C, int k_next) {
+  if (nimg <= 0 || OH <= 0 || C <= 0 || k_next <= 0) return 0;
+  return (int64_t)nimg * OH * C * (1 + 2 * (k_next - 1)) * (int64_t)sizeof(float);
+}
+
+int eqa_winograd_f2k5_output_sums(const float* M, const float* bias, int relu, double* S, void* workspace, int nimg,
+                                  int OH, int OW, int C, int k_next, void* stream) {
+  if (!M || !S || !workspace || nimg < 0 || OH < 2 || OW < 2 || C <= 0 || k_next <= 0) return EQA_ERR_INVALID_ARG;
+  const int nb = k_next - 1;
+  // even border width (2-wide tiles), disjoint borders with an interior, same limits as eqa_window_sums_nhwc
+  if ((OH & 1) || (OW & 1) || (nb != 4 && nb != 2) || OH < 2 * nb + 2 || OW < 2 * nb + 2 || k_next > kMaxWinK)
+    return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  const int TY = OH / 2, TX = OW / 2;
+  const size_t tiles = (size_t)nimg * TY * TX;
+  if (tiles > 0x7fffffffULL || (size_t)nimg * TY > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)((size_t)nimg * TY), (C + kThreads - 1) / kThreads);
+  const int nseg = OH;  // one segment per output row
+  if (nb == 4)
+    hipLaunchKernelGGL((winograd_f2k5_output_sums_kernel<4>), grid, dim3(kThreads), 0, st, M, bias, relu, (float*)workspace, OH, OW, C, TY, TX, tiles, nseg);
+  else
+    hipLaunchKernelGGL((winograd_f2k5_output_sums_kernel<2>), grid, dim3(kThreads), 0, st, M, bias, relu, (float*)workspace, OH, OW, C, TY, TX, tiles, nseg);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  if (nimg > 65535) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, nimg), dim3(kThreads), 0, st,
+                     (const float*)workspace, S, nimg, C, k_next, nseg);
+  return launch_status();
+}
+
 int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream) {
   if (!x || !bias || n_pixels < 0 || C <= 0) return EQA_ERR_INVALID_ARG;
   if (C % 4 != 0 || (((uintptr_t)x | (uintptr_t)bias) & 15)) return EQA_ERR_UNSUPPORTED;
@@ -1517,7 +1639,7 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
   hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
                      (float*)workspace, C, H, W, k, nbands);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
-  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((B * C + kThreads - 1) / kThreads), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, st,
                      (const float*)workspace, out, B, C, k, nseg);
   return launch_status();
 }

@@ -25,7 +25,11 @@ from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_lay
     RotoReflectionEquivariantConvLift,
 )
 from equiadapt_amd.images.canonicalization_networks import winograd
-from equiadapt_amd.images.canonicalization_networks.pooling import conv_then_group_pool, group_pool
+from equiadapt_amd.images.canonicalization_networks.pooling import (
+    conv_then_group_pool,
+    group_pool,
+    window_sums_to_activations,
+)
 
 
 class _InnerBatchNorm(nn.BatchNorm3d):
@@ -118,6 +122,13 @@ class ESCNNEquivariantNetwork(nn.Module):
             if use_wino:
                 # 5x5 regular->regular layer: Winograd F(2x2,5x5).  The previous layer's bias + ReLU ride on its input
                 # loads, its own bias + ReLU on its output transform.
+                tail = convs[-1]
+                if last_before_tail and winograd.sums_applicable(h, tail.kernel_size):
+                    # the activation of this layer is consumed only through the next layer's window sums: emit those
+                    # straight from the output transform, the feature map is never written
+                    S = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True, in_bias=pending,
+                                         in_relu=pending is not None, sums_k=tail.kernel_size)
+                    return window_sums_to_activations(S, tail, h.shape[-2] - 4, h.shape[-1] - 4)
                 h = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True,
                                      in_bias=pending, in_relu=pending is not None)
                 pending = None

@@ -36,6 +36,12 @@ def conv_then_group_pool(h: torch.Tensor, layer, scale=None, shift=None, relu: b
     k, E, O = layer.kernel_size, layer.num_group_elements, layer.out_channels
     B, _, H, W = h.shape
     S = ops.window_sums(h, k, scale, shift, relu)                       # (B, Cin, k, k) fp64
+    return window_sums_to_activations(S, layer, H, W)
+
+
+def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.Tensor:
+    """The GEMV half of ``conv_then_group_pool``: (B, Cin, k, k) fp64 window sums of the (H, W) input -> (B, G)."""
+    k, O = layer.kernel_size, layer.out_channels
     weff = layer.mean_response_weights()                                # (E, Cin*k*k) fp64
     act = S.flatten(1) @ weff.t() / float(O * (H - k + 1) * (W - k + 1))
     if layer.bias is not None:

@@ -47,8 +47,15 @@ def applicable(x: torch.Tensor, cin: int, cout: int) -> bool:
             and (W - 4) % 2 == 0 and cin >= 32 and cout >= 32 and x.is_contiguous(memory_format=torch.channels_last))
 
 
+def sums_applicable(x: torch.Tensor, k_next: int) -> bool:
+    """Can the output transform emit the next layer's window sums directly (eqa_winograd_f2k5_output_sums)?"""
+    OH, OW = x.shape[-2] - 4, x.shape[-1] - 4
+    nb = k_next - 1
+    return nb in (2, 4) and OH >= 2 * nb + 2 and OW >= 2 * nb + 2
+
+
 def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False) -> torch.Tensor:
+            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
     """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as U;
     act(x) = [relu](x + in_bias[c]) is applied while the input tiles are loaded (previous layer's epilogue)."""
     lib = _lib.load()
@@ -56,12 +63,21 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
     Cout = U.shape[2]
     OH, OW = H - 4, W - 4
     TY, TX = OH // 2, OW // 2
-    y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if sums_k:
+        # fused tail: return the (B, Cout, k, k) fp64 window sums of the activation instead of the activation itself
+        S = torch.empty((B, Cout, sums_k, sums_k), dtype=torch.float64, device=x.device)
+        y = None
+    else:
+        y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stream = torch.cuda.current_stream().cuda_stream
     chunk = min(CHUNK_IMAGES, B)
     V = torch.empty((36, chunk * TY * TX, Cin), dtype=torch.float32, device=x.device)
     M = torch.empty((36, chunk * TY * TX, Cout), dtype=torch.float32, device=x.device)
-    xs, ys = x.data_ptr(), y.data_ptr()
+    xs = x.data_ptr()
+    ys = y.data_ptr() if y is not None else 0
+    if sums_k:
+        ws = torch.empty((max(lib.eqa_winograd_f2k5_output_sums_workspace_bytes(chunk, OH, Cout, sums_k), 4) // 4,),
+                         dtype=torch.float32, device=x.device)
     p_bias = bias.data_ptr() if bias is not None else None
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     with torch.cuda.device(x.device):
@@ -75,6 +91,11 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
             else:  # last, smaller chunk: the kernels address (36, t, C) densely
                 Vn, Mn = V.view(-1)[: 36 * t * Cin].view(36, t, Cin), M.view(-1)[: 36 * t * Cout].view(36, t, Cout)
                 torch.bmm(Vn, U, out=Mn)
-            st = lib.eqa_winograd_f2k5_output(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
-            _lib.check(st, "eqa_winograd_f2k5_output")
-    return y
+            if sums_k:
+                st = lib.eqa_winograd_f2k5_output_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,
+                                                       ws.data_ptr(), n, OH, OW, Cout, sums_k, stream)
+                _lib.check(st, "eqa_winograd_f2k5_output_sums")
+            else:
+                st = lib.eqa_winograd_f2k5_output(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
+                _lib.check(st, "eqa_winograd_f2k5_output")
+    return S if sums_k else y

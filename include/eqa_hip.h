@@ -193,6 +193,12 @@ int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int 
                             void* stream);
 int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                              void* stream);
+/* Output transform fused with eqa_window_sums_nhwc of the NEXT layer (kernel size k_next in {3, 5}): the activation is
+ * never written; S:(nimg, C, k_next, k_next) fp64 window sums of [relu](A^T M A + bias).
+ * workspace: eqa_winograd_f2k5_output_sums_workspace_bytes(nimg, OH, C, k_next) bytes. */
+int64_t eqa_winograd_f2k5_output_sums_workspace_bytes(int nimg, int OH, int C, int k_next);
+int eqa_winograd_f2k5_output_sums(const float* M, const float* bias, int relu, double* S, void* workspace, int nimg,
+                                  int OH, int OW, int C, int k_next, void* stream);
 
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);

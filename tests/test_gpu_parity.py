@@ -638,6 +638,12 @@ def test_winograd_conv_matches_direct(dev):
         assert e_w <= 2e-5 * scale, (e_w, e_d, scale)   # fp32 Winograd: a few ulp-amplifications above the direct conv
         got2 = winograd.conv5x5(x, winograd.transform_filters(g), None, relu=False)
         assert (got2.double() - F.conv2d(x.double(), g.double())).abs().max().item() <= 2e-5 * scale
+        # fused tail: window sums of the activation straight from the output transform
+        if H - 4 >= 10 and W - 4 >= 10:
+            from equiadapt_amd import ops
+            S = winograd.conv5x5(x, winograd.transform_filters(g), bias, relu=True, sums_k=5)
+            S_ref = ops.window_sums(got, 5)
+            assert torch.allclose(S, S_ref, atol=1e-3, rtol=1e-6), (B, Cin, Cout, H, W)
         # fused input activation: conv(relu(x + in_bias))
         ib = torch.randn(Cin, device=dev)
         got3 = winograd.conv5x5(x, winograd.transform_filters(g), bias, relu=True, in_bias=ib, in_relu=True)
