@@ -52,7 +52,6 @@ def cpu_baseline(sample: int, reps: int):
     from oracle import nets as onets
 
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     can = build_canonicalizer("cpu")
     sd = {k: v for k, v in can.canonicalization_network.state_dict().items()}
     g = torch.Generator().manual_seed(0)
@@ -68,6 +67,21 @@ def cpu_baseline(sample: int, reps: int):
         return y, out
 
     with torch.no_grad():
+        # these ops are small; on a many-core host the fastest thread count is well below the core count, so a
+        # quick calibration picks it (reported as `cores`): the baseline should be the CPU's best, not a strawman
+        best = (float("inf"), cores)
+        xs, fs = x, f
+        x, f = x[:4], f[:4]
+        for nt in sorted({cores, 64, 32, 16, 8} & set(range(1, cores + 1)), reverse=True):
+            torch.set_num_threads(nt)
+            step()
+            t0 = time.perf_counter()
+            step()
+            dt = time.perf_counter() - t0
+            if dt < best[0]:
+                best = (dt, nt)
+        x, f = xs, fs
+        torch.set_num_threads(best[1])
         step()
         ts = []
         for _ in range(reps):
@@ -83,7 +97,7 @@ def cpu_baseline(sample: int, reps: int):
             io.invert_action(f, rot, None, 8, 8, "scalar")
         ga = (time.perf_counter() - t0) / reps
     med = statistics.median(ts)
-    return {"value": sample / med, "unit": "images/s", "cores": cores, "kind": "port",
+    return {"value": sample / med, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": cores, "kind": "port",
             "sample": f"{sample} images x {reps} reps of the same step (oracle/: pre-transform, conv stack, "
                       f"argmax, pad+rotate+crop, invert) on torch-CPU, {torch.get_num_threads()} threads",
             "group_action_only_images_s": sample / ga}
