@@ -486,6 +486,10 @@ int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
 int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t* gidx, const float* theta,
                      const int32_t* flags, const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W,
                      int pad, int OH, int OW, int top, int left) {
+  if (n_out == 0 && B >= 0) {  // empty batch: nothing to validate against (empty tensors have null data pointers)
+    a.n_out = 0;
+    return EQA_OK;
+  }
   if (!src || !theta || E <= 0 || n_out < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 || OH <= 0 || OW <= 0 ||
       top < 0 || left < 0)
     return EQA_ERR_INVALID_ARG;
@@ -510,7 +514,7 @@ int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t*
 int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
                   const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
                   int OW, int top, int left, void* stream) {
-  if (!dst) return EQA_ERR_INVALID_ARG;
+  if (!dst && n_out != 0) return EQA_ERR_INVALID_ARG;
   ActionArgs a;
   const int rc = fill_action_args(a, src, dst, gidx, theta, flags, chan_map, E, G, n_out, B, C, H, W, pad, OH, OW, top, left);
   if (rc != EQA_OK) return rc;
@@ -1482,6 +1486,7 @@ int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, cons
 
 int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const float* theta, const int32_t* flags,
                             int num_elements, int B, int C, int H, int W, int pad, void* stream) {
+  if (B == 0) return EQA_OK;
   if (!gidx) return EQA_ERR_INVALID_ARG;
   // CenterCrop offset of torchvision: int(round((Hp - H) / 2)) == pad exactly, since Hp - H = 2*pad
   return launch_action(x, y, gidx, theta, flags, nullptr, num_elements, 1, B, B, C, H, W, pad, H, W, pad, pad, stream);
@@ -1489,12 +1494,14 @@ int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const
 
 int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const float* theta, const int32_t* flags,
                           const int32_t* chan_map, int num_elements, int G, int B, int C, int H, int W, void* stream) {
+  if (B == 0) return EQA_OK;
   if (!gidx) return EQA_ERR_INVALID_ARG;
   return launch_action(f, out, gidx, theta, flags, chan_map, num_elements, G, B, B, C, H, W, 0, H, W, 0, 0, stream);
 }
 
 int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int32_t* flags, int num_elements, int B,
                          int C, int S, int pad, void* stream) {
+  if (B == 0 && num_elements > 0) return EQA_OK;
   if (num_elements <= 0 || B <= 0) return EQA_ERR_INVALID_ARG;
   if ((long long)num_elements * B > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
   return launch_action(x, y, nullptr, theta, flags, nullptr, num_elements, 1, num_elements * B, B, C, S, S, pad, S, S,
@@ -1510,6 +1517,7 @@ int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t*
                          const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
                          int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
                          int top, int left, void* stream) {
+  if (n_out == 0 && B >= 0) return EQA_OK;
   if (!grad_out || (!grad_src && !grad_angle_partial)) return EQA_ERR_INVALID_ARG;
   ActionArgs a;
   const int rc = fill_action_args(a, src, nullptr, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad,
@@ -1539,9 +1547,9 @@ int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {
 
 int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* workspace, int B, int Cf, int G, int HW,
                           void* stream) {
+  if (B == 0) return EQA_OK;
   if (!feat || !act || !workspace || B < 0 || Cf <= 0 || G <= 0 || HW <= 0) return EQA_ERR_INVALID_ARG;
   if (gidx && G > 64) return EQA_ERR_UNSUPPORTED;
-  if (B == 0) return EQA_OK;
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int splits = pool_splits(B, Cf);
@@ -1561,9 +1569,9 @@ int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* wo
 }
 
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream) {
+  if (B == 0 && G > 0 && G <= 64) return EQA_OK;
   if (!act || !gidx || B < 0 || G <= 0) return EQA_ERR_INVALID_ARG;
   if (G > 64) return EQA_ERR_UNSUPPORTED;
-  if (B == 0) return EQA_OK;
   hipLaunchKernelGGL(group_argmax_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, act, gidx, B, G);
   return launch_status();
 }
@@ -1688,8 +1696,8 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
 }
 
 int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream) {
+  if (B == 0 && N > 0) return EQA_OK;
   if (!x || !R || !y || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
-  if (B == 0) return EQA_OK;
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const bool vec = (N % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
@@ -1744,8 +1752,8 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
 }
 
 int eqa_gram_schmidt(const float* v, float* out, int B, void* stream) {
-  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
   if (B == 0) return EQA_OK;
+  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
   hipLaunchKernelGGL(gram_schmidt_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, out, B);
   return launch_status();
 }

@@ -1,0 +1,141 @@
+"""GPU: edge cases of the C-ABI entry points -- empty and ragged inputs, tiny / odd sizes, argument validation."""
+import ctypes
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import image_ops as io  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_empty_batches(dev):
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    th, fl = device_tables("canonicalize", 4, False, (16, 16), dev)
+    x = torch.empty(0, 3, 8, 8, device=dev)
+    assert ops.canon_transform(x, torch.empty(0, dtype=torch.int32, device=dev), th, fl, 4).shape == (0, 3, 8, 8)
+    assert ops.group_argmax(torch.empty(0, 8, device=dev)).shape == (0,)
+    assert ops.so3_rotate(torch.empty(0, 3, 16, device=dev), torch.empty(0, 3, 3, device=dev)).shape == (0, 3, 16)
+    assert ops.gram_schmidt(torch.empty(0, 3, 3, device=dev)).shape == (0, 3, 3)
+    act, idx = ops.group_pool_argmax(torch.empty(0, 4, 8, 5, 5, device=dev))
+    assert act.shape == (0, 8) and idx.shape == (0,)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 2), (3, 2, 5), (4, 3, 1 + 32), (7, 65, 31), (64, 9, 9), (3, 100, 7)])
+def test_tiny_and_ragged_shapes(dev, shape):
+    """1-pixel-wide frames are rejected by the reference too (affine_grid needs >= 2); everything else must match."""
+    import math
+
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    C, H, W = shape
+    torch.manual_seed(C * 1000 + H * 10 + W)
+    B = 5
+    x = torch.randn(B, C, H, W)
+    gidx = torch.tensor([0, 1, 2, 3, 2])
+    ang = io.group_angles(4)[gidx]
+    pad = math.ceil(W * 0.5)
+    th, fl = device_tables("canonicalize", 4, False, (H + 2 * pad, W + 2 * pad), dev)
+    got = ops.canon_transform(x.to(dev), gidx.to(dev, torch.int32), th, fl, pad).cpu()
+    want = io.canonicalize_images(x, ang, None, (3, H, W))  # in_shape[0] != 1 -> padded branch
+    assert (got - want).abs().max().item() <= 1e-3
+    thi, fli, cm = device_tables("invert", 4, False, (H, W), dev)
+    got = ops.invert_action(x.to(dev), gidx.to(dev, torch.int32), thi, fli, None).cpu()
+    want = io.invert_action(x, ang, None, 4, 4, "scalar")
+    assert (got - want).abs().max().item() <= 1e-3
+
+
+def test_out_of_range_index_is_clamped_not_a_fault(dev):
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    th, fl = device_tables("canonicalize", 4, False, (32, 32), dev)
+    x = torch.randn(3, 3, 16, 16, device=dev)
+    bad = torch.tensor([-5, 99, 2], dtype=torch.int32, device=dev)
+    ok = torch.tensor([0, 3, 2], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.canon_transform(x, bad, th, fl, 8), ops.canon_transform(x, ok, th, fl, 8))
+
+
+def test_non_contiguous_and_wrong_dtype(dev):
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    th, fl = device_tables("canonicalize", 4, False, (32, 32), dev)
+    base = torch.randn(4, 6, 16, 16, device=dev)
+    view = base[:, ::2]                                   # non-contiguous channel slice
+    gidx = torch.tensor([1, 0, 3, 2], dtype=torch.int32, device=dev)
+    assert torch.equal(ops.canon_transform(view, gidx, th, fl, 8), ops.canon_transform(view.contiguous(), gidx, th, fl, 8))
+    with pytest.raises(TypeError):
+        ops.canon_transform(base.half(), gidx, th, fl, 8)
+    with pytest.raises(TypeError):
+        ops.canon_transform(base, gidx.long(), th, fl, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.canon_transform(base.cpu(), gidx, th, fl, 8)
+
+
+def test_c_abi_argument_validation(dev):
+    from equiadapt_amd import _lib
+
+    lib = _lib.load()
+    x = torch.zeros(1, 1, 4, 4, device=dev)
+    th = torch.zeros(1, 6, device=dev)
+    g = torch.zeros(1, dtype=torch.int32, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    # null pointers, non-positive sizes, 1-pixel frames, chan_map with C % G != 0
+    assert lib.eqa_canon_transform_fwd(None, p(x), p(g), p(th), None, 1, 1, 1, 4, 4, 0, None) == -1
+    assert lib.eqa_canon_transform_fwd(p(x), p(x), p(g), p(th), None, 1, 1, 1, 0, 4, 0, None) == -1
+    assert lib.eqa_canon_transform_fwd(p(x), p(x), p(g), p(th), None, 1, 1, 1, 1, 1, 0, None) == -1
+    assert lib.eqa_invert_action_fwd(p(x), p(x), p(g), p(th), None, p(g), 1, 4, 1, 1, 4, 4, None) == -1
+    assert lib.eqa_group_argmax(p(x), p(g), 1, 100, None) == -3          # more than one wave of orientations
+    assert lib.eqa_window_sums(p(x), None, None, 0, p(x), 1, 1, 4, 4, 9, None) == -1
+    assert lib.eqa_vnsmall_fwd(p(x), p(x), p(x), p(x), 1, 64, 8, 0, None) == -3   # fused path is k = 20 only
+    torch.cuda.synchronize()
+
+
+def test_nan_and_inf_inputs_do_not_spread(dev):
+    """A NaN pixel only contaminates outputs whose bilinear footprint touches it (grid_sample semantics)."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    th, fl, _ = device_tables("invert", 4, False, (32, 32), dev)
+    x = torch.randn(1, 1, 32, 32)
+    x[0, 0, 10, 12] = float("nan")
+    g = torch.tensor([1], dtype=torch.int32)
+    got = ops.invert_action(x.to(dev), g.to(dev), th, fl, None).cpu()
+    want = io.invert_action(x, io.group_angles(4)[g.long()], None, 4, 4, "scalar")
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert torch.isnan(got).sum().item() <= 4
+
+
+def test_large_channel_count_regular_features(dev):
+    from equiadapt_amd.images.utils import get_action_on_image_features
+
+    torch.manual_seed(5)
+    N, G = 8, 8
+    f = torch.randn(2, 256, 40, 40)
+    gidx = torch.tensor([3, 6])
+    rot = io.group_angles(N)[gidx]
+    want = io.invert_action(f, rot, None, N, G, "regular")
+    got = get_action_on_image_features(f.to(dev), {"num_rotations": N, "num_group": G},
+                                       {"rotation": rot.to(dev), "group_index": gidx.to(dev, torch.int32)}, "regular")
+    assert (got.cpu() - want).abs().max().item() <= 1e-3
+
+
+def test_canonicalizer_rejects_bad_in_shape():
+    import equiadapt_amd as ea
+
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=32)
+    net = torch.nn.Identity()
+    net.group_type, net.num_rotations = "rotation", 4
+    with pytest.raises(AssertionError):
+        ea.GroupEquivariantImageCanonicalization(net, hp, (3, 32))
