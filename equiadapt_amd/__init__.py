@@ -38,6 +38,7 @@ from equiadapt_amd.images.utils import (  # noqa: F401
     rotate_masks,
     rotate_points,
 )
+from equiadapt_amd.nbody.canonicalization.euclidean_group import EuclideanGroupNBody  # noqa: F401
 from equiadapt_amd.pointcloud.canonicalization.continuous_group import (  # noqa: F401
     ContinuousGroupPointcloudCanonicalization,
     EquivariantPointcloudCanonicalization,

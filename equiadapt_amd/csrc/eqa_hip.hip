@@ -1461,6 +1461,51 @@ int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta,
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
+// (f).4 -- n-body E(3) canonicalization: modified Gram-Schmidt and the per-row rigid action
+// (nbody/canonicalization/euclidean_group.py:87-157).  Tiny tensors (nodes x 3): one thread per row.
+__global__ __launch_bounds__(kThreads) void modified_gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* p = v + (size_t)b * 9;
+  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  a0 /= n; a1 /= n; a2 /= n;
+  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
+  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  b0 /= n; b1 /= n; b2 /= n;
+  d = c0 * a0 + c1 * a1 + c2 * a2;
+  c0 -= d * a0; c1 -= d * a1; c2 -= d * a2;
+  d = c0 * b0 + c1 * b1 + c2 * b2;  // modified GS: second projection uses the UPDATED third vector
+  c0 -= d * b0; c1 -= d * b1; c2 -= d * b2;
+  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  c0 /= n; c1 /= n; c2 /= n;
+  float* o = out + (size_t)b * 9;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+}
+
+// mode 0: out = x R + t            (invert_canonicalization :126-137; t may be NULL)
+// mode 1: out = x R^T - t R^T      (canonicalize :108-124, the two products subtracted as the reference does)
+__global__ __launch_bounds__(kThreads) void rigid_rows_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                             const float* __restrict__ t, float* __restrict__ out, int M, int mode) {
+  const int m = blockIdx.x * kThreads + threadIdx.x;
+  if (m >= M) return;
+  const float* r = R + (size_t)m * 9;
+  const float x0 = x[(size_t)m * 3], x1 = x[(size_t)m * 3 + 1], x2 = x[(size_t)m * 3 + 2];
+  const float t0 = t ? t[(size_t)m * 3] : 0.f, t1 = t ? t[(size_t)m * 3 + 1] : 0.f, t2 = t ? t[(size_t)m * 3 + 2] : 0.f;
+  float* o = out + (size_t)m * 3;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (mode == 0) {
+      o[j] = (x0 * r[j] + x1 * r[3 + j] + x2 * r[6 + j]) + (j == 0 ? t0 : j == 1 ? t1 : t2);
+    } else {
+      const float a = x0 * r[3 * j] + x1 * r[3 * j + 1] + x2 * r[3 * j + 2];
+      const float b = t0 * r[3 * j] + t1 * r[3 * j + 1] + t2 * r[3 * j + 2];
+      o[j] = t ? a - b : a;
+    }
+  }
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
 }  // namespace
@@ -1748,6 +1793,20 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
   hipLaunchKernelGGL(vnsmall_fwd_kernel, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
+  return launch_status();
+}
+
+int eqa_modified_gram_schmidt(const float* v, float* out, int B, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(modified_gram_schmidt_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, out, B);
+  return launch_status();
+}
+
+int eqa_rigid_rows(const float* x, const float* R, const float* t, float* out, int M, int mode, void* stream) {
+  if (M == 0) return EQA_OK;
+  if (!x || !R || !out || M < 0 || (mode != 0 && mode != 1)) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(rigid_rows_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, R, t, out, M, mode);
   return launch_status();
 }
 

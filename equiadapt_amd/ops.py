@@ -354,3 +354,27 @@ def image_action_nearest(x: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tens
                                           top_left[0], top_left[1], _stream())
     _lib.check(st, "eqa_image_action_nearest")
     return out
+
+
+def modified_gram_schmidt(v: torch.Tensor) -> torch.Tensor:
+    """(B,3,3) -> orthonormal rows by MODIFIED Gram-Schmidt (n-body canonicalizer; eqa_modified_gram_schmidt)."""
+    lib = _lib.load()
+    v = _need(v, "vectors")
+    out = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        st = lib.eqa_modified_gram_schmidt(v.data_ptr(), out.data_ptr(), v.shape[0], _stream())
+    _lib.check(st, "eqa_modified_gram_schmidt")
+    return out
+
+
+def rigid_rows(x: torch.Tensor, R: torch.Tensor, t: Optional[torch.Tensor], inverse: bool) -> torch.Tensor:
+    """Per-row rigid action on (M,3) row vectors: x R + t (inverse=False) or x R^T - t R^T (inverse=True)."""
+    lib = _lib.load()
+    x = _need(x, "x")
+    R = _need(R, "R")
+    t, p_t = _opt(t, "t", torch.float32)
+    out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_rigid_rows(x.data_ptr(), R.data_ptr(), p_t, out.data_ptr(), x.shape[0], int(inverse), _stream())
+    _lib.check(st, "eqa_rigid_rows")
+    return out

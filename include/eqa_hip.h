@@ -231,6 +231,16 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
  */
 int eqa_gram_schmidt(const float* v, float* out, int B, void* stream);
 
+/*
+ * (f).4 -- E(3) canonicalization of n-body systems (equiadapt/nbody/canonicalization/euclidean_group.py):
+ *   eqa_modified_gram_schmidt  rows of (B,3,3), modified GS (:139-157);
+ *   eqa_rigid_rows             per node m: mode 0  out = x R + t  (invert_canonicalization :126-137),
+ *                                          mode 1  out = x R^T - t R^T  (canonicalize :108-124); t may be NULL.
+ * x,t,out:(M,3) row vectors; R:(M,3,3).
+ */
+int eqa_modified_gram_schmidt(const float* v, float* out, int B, void* stream);
+int eqa_rigid_rows(const float* x, const float* R, const float* t, float* out, int M, int mode, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,3 +142,21 @@ def continuous_identity_metric(rep: torch.Tensor) -> torch.Tensor:
 def nbody_invert(position: torch.Tensor, rotation: torch.Tensor, translation: torch.Tensor) -> torch.Tensor:
     """Row (f).4: x R + t, row-vector convention -- nbody/canonicalization/euclidean_group.py:126-137."""
     return torch.bmm(position[:, None, :], rotation).squeeze() + translation
+
+
+def modified_gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
+    """Row (f).4: nbody/canonicalization/euclidean_group.py:139-157 (second projection uses the updated vector)."""
+    v1 = vectors[:, 0] / torch.norm(vectors[:, 0], dim=1, keepdim=True)
+    v2 = vectors[:, 1] - torch.sum(vectors[:, 1] * v1, dim=1, keepdim=True) * v1
+    v2 = v2 / torch.norm(v2, dim=1, keepdim=True)
+    v3 = vectors[:, 2] - torch.sum(vectors[:, 2] * v1, dim=1, keepdim=True) * v1
+    v3 = v3 - torch.sum(v3 * v2, dim=1, keepdim=True) * v2
+    v3 = v3 / torch.norm(v3, dim=1, keepdim=True)
+    return torch.stack([v1, v2, v3], dim=1)
+
+
+def nbody_canonicalize(loc: torch.Tensor, vel: torch.Tensor, R: torch.Tensor, t: torch.Tensor):
+    """Row (f).4: euclidean_group.py:108-124: loc R^-1 - t R^-1 and vel R^-1 with R^-1 = R^T (row vectors)."""
+    Rinv = R.transpose(1, 2)
+    cl = torch.bmm(loc[:, None, :], Rinv).squeeze() - torch.bmm(t[:, None, :], Rinv).squeeze()
+    return cl, torch.bmm(vel[:, None, :], Rinv).squeeze()

@@ -186,6 +186,27 @@ def main() -> None:
                              "state_after": {k: v.clone() for k, v in net.state_dict().items()}}
     save("pointcloud.pt", payload)
 
+    # ---------------- n-body E(3) canonicalizer (torch-only reference module, fake network) ----------------
+    sys.modules.setdefault("equiadapt.nbody", types.ModuleType("equiadapt.nbody")).__path__ = []
+    sys.modules.setdefault("equiadapt.nbody.canonicalization", types.ModuleType("equiadapt.nbody.canonicalization")).__path__ = []
+    nb = load_by_path("equiadapt.nbody.canonicalization.euclidean_group", "equiadapt/nbody/canonicalization/euclidean_group.py")
+    torch.manual_seed(21)
+    M = 40
+    rot_vec, trans = torch.randn(M, 3, 3), torch.randn(M, 3)
+
+    class FakeNet(torch.nn.Module):
+        def forward(self, nodes, loc, edges, vel, edge_attr, charges):
+            return rot_vec, trans
+
+    can = nb.EuclideanGroupNBody(FakeNet())
+    nodes, loc, vel = torch.randn(M, 1), torch.randn(M, 3), torch.randn(M, 3)
+    cl, cv = can(nodes, loc=loc, edges=None, vel=vel, edge_attr=None, charges=None)
+    pred = torch.randn(M, 3)
+    save("nbody.pt", {"provenance": "reference", "rot_vec": rot_vec, "trans": trans, "loc": loc, "vel": vel,
+                      "rotation": can.canonicalization_info_dict["group_element"]["rotation_matrix"].clone(),
+                      "canonical_loc": cl, "canonical_vel": cv, "pred": pred,
+                      "inverted": can.invert_canonicalization(pred)})
+
     # ---------------- image path: restatement-generated, LABELLED ----------------
     from oracle import image_ops as io
 

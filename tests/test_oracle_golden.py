@@ -85,3 +85,13 @@ def test_image_restatement_fixture_is_labelled_and_reproducible(golden):
     x = g["x"]
     ang = io.group_angles(8)[g["c8"]["gidx"]]
     assert torch.equal(io.canonicalize_images(x, ang, None, (3, 32, 32)), g["c8"]["canon"])
+
+
+def test_nbody_e3_canonicalizer(golden):
+    g = golden("nbody.pt")
+    assert g["provenance"] == "reference"
+    R = po.modified_gram_schmidt(g["rot_vec"])
+    assert torch.equal(R, g["rotation"])
+    cl, cv = po.nbody_canonicalize(g["loc"], g["vel"], R, g["trans"])
+    assert torch.equal(cl, g["canonical_loc"]) and torch.equal(cv, g["canonical_vel"])
+    assert torch.equal(po.nbody_invert(g["pred"], R, g["trans"]), g["inverted"])
