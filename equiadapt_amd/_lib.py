@@ -39,8 +39,11 @@ SIGNATURES = {
     "eqa_window_sums": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),
     "eqa_winograd_f2k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f4k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f4k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output_sums_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_winograd_f2k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_winograd_f4k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_window_sums_nhwc_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_window_sums_nhwc": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),

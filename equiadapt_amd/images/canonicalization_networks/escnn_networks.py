@@ -96,12 +96,12 @@ class ESCNNEquivariantNetwork(nn.Module):
         self._fold_cache[id(conv)] = (key, bank, bias)
         return bank, bias
 
-    def _winograd_filters(self, conv, bn, bank):
-        hit = self._fold_cache.get(("wino", id(conv)))
+    def _winograd_filters(self, conv, bn, bank, m):
+        hit = self._fold_cache.get(("wino", m, id(conv)))
         key = self._fold_cache[id(conv)][0]
         if hit is None or hit[0] != key:
-            hit = (key, winograd.transform_filters(bank))
-            self._fold_cache[("wino", id(conv))] = hit
+            hit = (key, winograd.transform_filters(bank, m))
+            self._fold_cache[("wino", m, id(conv))] = hit
         return hit[1]
 
     def _forward_inference(self, x: torch.Tensor) -> torch.Tensor:
@@ -120,16 +120,20 @@ class ESCNNEquivariantNetwork(nn.Module):
             use_wino = (nhwc and not conv.lifting and conv.kernel_size == 5 and conv.stride == 1 and conv.padding == 0
                         and winograd.applicable(h, bank.shape[1], bank.shape[0]))
             if use_wino:
-                # 5x5 regular->regular layer: Winograd F(2x2,5x5).  The previous layer's bias + ReLU ride on its input
-                # loads, its own bias + ReLU on its output transform.
+                # 5x5 regular->regular layer: Winograd F(m x m, 5x5), m = 4 where the size allows.  The previous layer's
+                # bias + ReLU ride on its input loads, its own bias + ReLU on its output transform.
                 tail = convs[-1]
-                if last_before_tail and winograd.sums_applicable(h, tail.kernel_size):
+                m = winograd.tile_for(h)
+                if last_before_tail and not winograd.sums_applicable(h, tail.kernel_size, m) and \
+                        winograd.sums_applicable(h, tail.kernel_size, 2):
+                    m = 2
+                if last_before_tail and winograd.sums_applicable(h, tail.kernel_size, m):
                     # the activation of this layer is consumed only through the next layer's window sums: emit those
                     # straight from the output transform, the feature map is never written
-                    S = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True, in_bias=pending,
+                    S = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank, m), bias, relu=True, in_bias=pending,
                                          in_relu=pending is not None, sums_k=tail.kernel_size)
                     return window_sums_to_activations(S, tail, h.shape[-2] - 4, h.shape[-1] - 4)
-                h = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank), bias, relu=True,
+                h = winograd.conv5x5(h, self._winograd_filters(conv, bn, bank, m), bias, relu=True,
                                      in_bias=pending, in_relu=pending is not None)
                 pending = None
                 if last_before_tail:

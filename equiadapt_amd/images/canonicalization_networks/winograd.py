@@ -1,44 +1,98 @@
-"""Winograd F(2x2, 5x5) convolution for the 5x5 regular->regular layers of the canonicalization network (inference).
+"""Winograd F(m x m, 5x5) convolution for the 5x5 regular->regular layers of the canonicalization network (inference).
 
-Direct convolution spends 25 multiplies per output and channel pair; Cook-Toom at the points {0, 1, -1, 2, -2, inf}
-needs 36 per 2x2 output tile = 9 per output.  Pipeline (channels-last, fp32 throughout):
+Direct convolution spends 25 multiplies per output and channel pair.  Cook-Toom with N = m + 4 points per axis needs
+N*N per m x m output tile:  m = 2, points {0, 1, -1, 2, -2, inf}: 36/4 = 9 per output;  m = 4, points
+{0, 1, -1, 2, -2, 1/2, -1/2, inf}: 64/16 = 4 per output.  Pipeline (channels-last, fp32 throughout), P = N*N:
 
-    x (B,H,W,Cin) --eqa_winograd_f2k5_input-->  V (36, tiles, Cin)
-    V[xi] @ U[xi]  (strided-batched fp32 GEMM, library)         ->  M (36, tiles, Cout)
-    M --eqa_winograd_f2k5_output--> y (B,H-4,W-4,Cout) = [relu](A^T M A + bias)
+    x (B,H,W,Cin) --eqa_winograd_f{m}k5_input-->  V (tiles, P, Cin)
+    V[:, a] @ U[a]  (strided-batched fp32 GEMM, library)        ->  M (tiles, P, Cout)
+    M --eqa_winograd_f{m}k5_output--> y (B,H-4,W-4,Cout) = [relu](A^T M A + bias)
 
-U = G g G^T is computed once per weight version in fp64 (G carries all the fractions, B^T is integer), so the only extra
-rounding at run time is the two small-integer transforms.  Exact in exact arithmetic; in fp32 the result differs from
-the direct convolution by ~1e-6 relative (tests/test_gpu_parity.py::test_winograd_conv_matches_direct).
-Images are processed in chunks to bound the size of V and M (36/4 x the activation).
+U = G g G^T is computed once per weight version in fp64 (G carries the non-dyadic fractions; B^T and A^T are exact in
+fp32), so the only extra rounding at run time is in the two transforms and the P-plane products.  Exact in exact
+arithmetic (tests/test_abi_and_host.py checks the matrices below in rational arithmetic); in fp32, against an fp64
+convolution with 256 channels: m = 2: 7e-6 of max|y|, m = 4: 9e-6 (direct fp32: 3e-7) --
+tests/test_gpu_parity.py::test_winograd_conv_matches_direct bounds both by 2e-5.
+m = 4 is used whenever 4 divides H-4 and W-4, else m = 2.  Images are processed in chunks to bound the size of V and M.
 """
 import os
-from typing import Optional
+from fractions import Fraction
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from equiadapt_amd import _lib
 
-# scaled filter transform G (6x5): rows for the points 0, 1, -1, 2, -2, inf
-_G = torch.tensor([[1 / 4, 0, 0, 0, 0],
-                   [1 / 6, 1 / 6, 1 / 6, 1 / 6, 1 / 6],
-                   [1 / 6, -1 / 6, 1 / 6, -1 / 6, 1 / 6],
-                   [1 / 24, 1 / 12, 1 / 6, 1 / 3, 2 / 3],
-                   [1 / 24, -1 / 12, 1 / 6, -1 / 3, 2 / 3],
-                   [0, 0, 0, 0, 1]], dtype=torch.float64)
+# interpolation points (the last, implicit one is infinity)
+POINTS = {2: (0, 1, -1, 2, -2), 4: (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2))}
 
 CHUNK_IMAGES = int(os.environ.get("EQA_WINOGRAD_CHUNK", "64"))
+
+
+def _polymul(a: Sequence[Fraction], b: Sequence[Fraction]) -> List[Fraction]:
+    out = [Fraction(0)] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            out[i + j] += x * y
+    return out
+
+
+def cook_toom(m: int, r: int = 5) -> Tuple[list, list, list]:
+    """(A^T, G, B^T) as rational matrices for the correlation y_i = sum_j d_{i+j} g_j, i < m:
+    y = A^T [(G g) * (B^T d)].  Row k of B^T holds the coefficients of prod_{j != k} (x - p_j) (last row: all points),
+    row k of G the powers of p_k over prod_{j != k} (p_k - p_j) -- the kernels' wino_bt / wino_at hard-code B^T and A^T
+    with these signs except rows 1, 2 of m = 2, which are negated in both B^T and G (see `g_matrix`)."""
+    pts = [Fraction(p) for p in POINTS[m]]
+    n = m + r - 1
+    assert len(pts) == n - 1
+    full = [Fraction(1)]
+    for p in pts:
+        full = _polymul(full, [-p, Fraction(1)])
+    bt, g = [], []
+    for k, p in enumerate(pts):
+        q, den = [Fraction(1)], Fraction(1)
+        for j, pj in enumerate(pts):
+            if j != k:
+                q = _polymul(q, [-pj, Fraction(1)])
+                den *= p - pj
+        bt.append(q + [Fraction(0)] * (n - len(q)))
+        g.append([p ** j / den for j in range(r)])
+    bt.append(full)
+    g.append([Fraction(0)] * (r - 1) + [Fraction(1)])
+    at = [[p ** i for p in pts] + [Fraction(1 if i == m - 1 else 0)] for i in range(m)]
+    return at, g, bt
+
+
+def kernel_bt_signs(m: int) -> List[int]:
+    """Sign of the kernels' B^T rows relative to `cook_toom` (wino_bt in csrc/eqa_hip.hip)."""
+    return [1, -1, -1, 1, 1, 1] if m == 2 else [1] * 8
+
+
+def g_matrix(m: int) -> torch.Tensor:
+    """(N, 5) fp64 filter transform matching the kernels' B^T."""
+    _, g, _ = cook_toom(m)
+    sg = kernel_bt_signs(m)
+    return torch.tensor([[float(sg[k] * v) for v in row] for k, row in enumerate(g)], dtype=torch.float64)
 
 
 def enabled() -> bool:
     return os.environ.get("EQA_WINOGRAD", "1") != "0"
 
 
-def transform_filters(bank: torch.Tensor) -> torch.Tensor:
-    """(Cout, Cin, 5, 5) cross-correlation filters -> U (36, Cin, Cout) fp32 = G g G^T, computed in fp64."""
-    G = _G.to(bank.device)
-    u = torch.einsum("ak,oikl,bl->aboi", G, bank.double(), G)          # (6, 6, Cout, Cin)
-    return u.permute(0, 1, 3, 2).reshape(36, bank.shape[1], bank.shape[0]).float().contiguous()
+def tile_for(x: torch.Tensor) -> int:
+    """Output tile size m for an input of this spatial size (EQA_WINOGRAD_TILE=2 forces the small tile)."""
+    H, W = x.shape[-2:]
+    if (H - 4) % 4 == 0 and (W - 4) % 4 == 0 and H >= 8 and W >= 8 and os.environ.get("EQA_WINOGRAD_TILE", "4") != "2":
+        return 4
+    return 2
+
+
+def transform_filters(bank: torch.Tensor, m: int = 2) -> torch.Tensor:
+    """(Cout, Cin, 5, 5) cross-correlation filters -> U (N*N, Cin, Cout) fp32 = G g G^T, computed in fp64."""
+    G = g_matrix(m).to(bank.device)
+    n = m + 4
+    u = torch.einsum("ak,oikl,bl->aboi", G, bank.double(), G)          # (N, N, Cout, Cin)
+    return u.permute(0, 1, 3, 2).reshape(n * n, bank.shape[1], bank.shape[0]).float().contiguous()
 
 
 def applicable(x: torch.Tensor, cin: int, cout: int) -> bool:
@@ -47,22 +101,25 @@ def applicable(x: torch.Tensor, cin: int, cout: int) -> bool:
             and (W - 4) % 2 == 0 and cin >= 32 and cout >= 32 and x.is_contiguous(memory_format=torch.channels_last))
 
 
-def sums_applicable(x: torch.Tensor, k_next: int) -> bool:
-    """Can the output transform emit the next layer's window sums directly (eqa_winograd_f2k5_output_sums)?"""
+def sums_applicable(x: torch.Tensor, k_next: int, m: int = 2) -> bool:
+    """Can the output transform emit the next layer's window sums directly (eqa_winograd_f{m}k5_output_sums)?"""
     OH, OW = x.shape[-2] - 4, x.shape[-1] - 4
     nb = k_next - 1
-    return nb in (2, 4) and OH >= 2 * nb + 2 and OW >= 2 * nb + 2
+    return nb in (2, 4) and nb % m == 0 and OH >= 2 * nb + m and OW >= 2 * nb + m
 
 
 def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
             in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
-    """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as U;
-    act(x) = [relu](x + in_bias[c]) is applied while the input tiles are loaded (previous layer's epilogue)."""
+    """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as
+    U = transform_filters(g, m) (m is read off U's plane count); act(x) = [relu](x + in_bias[c]) is applied while the
+    input tiles are loaded (previous layer's epilogue)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
-    Cout = U.shape[2]
+    P, _, Cout = U.shape
+    m = {36: 2, 64: 4}[P]
+    f_in, f_out, f_sums = (getattr(lib, f"eqa_winograd_f{m}k5_{n}") for n in ("input", "output", "output_sums"))
     OH, OW = H - 4, W - 4
-    TY, TX = OH // 2, OW // 2
+    TY, TX = OH // m, OW // m
     if sums_k:
         # fused tail: return the (B, Cout, k, k) fp64 window sums of the activation instead of the activation itself
         S = torch.empty((B, Cout, sums_k, sums_k), dtype=torch.float64, device=x.device)
@@ -70,9 +127,9 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
     else:
         y = torch.empty((B, Cout, OH, OW), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     stream = torch.cuda.current_stream().cuda_stream
-    chunk = min(CHUNK_IMAGES, B)
-    V = torch.empty((36, chunk * TY * TX, Cin), dtype=torch.float32, device=x.device)
-    M = torch.empty((36, chunk * TY * TX, Cout), dtype=torch.float32, device=x.device)
+    chunk = min(CHUNK_IMAGES * (m * m // 4), B)       # same V / M footprint per chunk for both tile sizes
+    V = torch.empty((chunk * TY * TX, P, Cin), dtype=torch.float32, device=x.device)
+    M = torch.empty((chunk * TY * TX, P, Cout), dtype=torch.float32, device=x.device)
     xs = x.data_ptr()
     ys = y.data_ptr() if y is not None else 0
     if sums_k:
@@ -84,18 +141,15 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
         for b0 in range(0, B, chunk):
             n = min(chunk, B - b0)
             t = n * TY * TX
-            st = lib.eqa_winograd_f2k5_input(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
-            _lib.check(st, "eqa_winograd_f2k5_input")
-            if n == chunk:
-                torch.bmm(V, U, out=M)
-            else:  # last, smaller chunk: the kernels address (36, t, C) densely
-                Vn, Mn = V.view(-1)[: 36 * t * Cin].view(36, t, Cin), M.view(-1)[: 36 * t * Cout].view(36, t, Cout)
-                torch.bmm(Vn, U, out=Mn)
+            st = f_in(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
+            _lib.check(st, f"eqa_winograd_f{m}k5_input")
+            # plane a is the strided matrix V[:, a, :] (row stride P*Cin): no copy, the library takes lda / batch stride
+            torch.bmm(V[:t].permute(1, 0, 2), U, out=M[:t].permute(1, 0, 2))
             if sums_k:
-                st = lib.eqa_winograd_f2k5_output_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,
-                                                       ws.data_ptr(), n, OH, OW, Cout, sums_k, stream)
-                _lib.check(st, "eqa_winograd_f2k5_output_sums")
+                st = f_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,
+                            ws.data_ptr(), n, OH, OW, Cout, sums_k, stream)
+                _lib.check(st, f"eqa_winograd_f{m}k5_output_sums")
             else:
-                st = lib.eqa_winograd_f2k5_output(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
-                _lib.check(st, "eqa_winograd_f2k5_output")
+                st = f_out(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
+                _lib.check(st, f"eqa_winograd_f{m}k5_output")
     return S if sums_k else y

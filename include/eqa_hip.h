@@ -181,23 +181,31 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
                          int B, int C, int H, int W, int k, void* stream);
 
 /*
- * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(2x2, 5x5), channels-last:
- *   eqa_winograd_f2k5_input   x:(nimg,H,W,C) -> V:(36, nimg*TY*TX, C), TY = (H-4)/2, TX = (W-4)/2   (B^T d B), with
- *                             d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c]  (in_bias NULL = 0): the previous
- *                             layer's bias / folded batch-norm / ReLU applied while loading
- *   [ strided-batched fp32 GEMM by the caller:  M[xi] = V[xi] (tiles x Cin) . U[xi] (Cin x Cout),  U = G g G^T ]
- *   eqa_winograd_f2k5_output  M:(36, nimg*TY*TX, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  OH, OW even
- * Cook-Toom points {0, 1, -1, 2, -2, inf}; matrices in csrc/eqa_hip.hip and images/canonicalization_networks/winograd.py.
+ * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(m x m, 5x5), channels-last.
+ * f2k5: m = 2 (6x6 input tiles, 36 planes); f4k5: m = 4 (8x8 input tiles, 64 planes).  N = m + 4, P = N*N:
+ *   eqa_winograd_f{m}k5_input   x:(nimg,H,W,C) -> V:(nimg*TY*TX, P, C), TY = (H-4)/m, TX = (W-4)/m   (B^T d B), with
+ *                               d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c]  (in_bias NULL = 0): the previous
+ *                               layer's bias / folded batch-norm / ReLU applied while loading
+ *   [ strided-batched fp32 GEMM by the caller:  M[:,a] = V[:,a] (tiles x Cin, lda P*Cin) . U[a] (Cin x Cout), a < P ]
+ *   eqa_winograd_f{m}k5_output  M:(nimg*TY*TX, P, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  m | OH, OW
+ * Cook-Toom points {0, 1, -1, 2, -2, [1/2, -1/2,] inf}; matrices in csrc/eqa_hip.hip and
+ * images/canonicalization_networks/winograd.py (U = G g G^T in fp64).  EQA_ERR_UNSUPPORTED when m does not divide H-4, W-4.
  */
 int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                             void* stream);
 int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                              void* stream);
-/* Output transform fused with eqa_window_sums_nhwc of the NEXT layer (kernel size k_next in {3, 5}): the activation is
- * never written; S:(nimg, C, k_next, k_next) fp64 window sums of [relu](A^T M A + bias).
- * workspace: eqa_winograd_f2k5_output_sums_workspace_bytes(nimg, OH, C, k_next) bytes. */
+int eqa_winograd_f4k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                            void* stream);
+int eqa_winograd_f4k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
+                             void* stream);
+/* Output transform fused with eqa_window_sums_nhwc of the NEXT layer (kernel size k_next; k_next - 1 a multiple of m:
+ * {3, 5} for f2k5, {5} for f4k5): the activation is never written; S:(nimg, C, k_next, k_next) fp64 window sums of
+ * [relu](A^T M A + bias).  workspace: eqa_winograd_f2k5_output_sums_workspace_bytes(nimg, OH, C, k_next) bytes (both m). */
 int64_t eqa_winograd_f2k5_output_sums_workspace_bytes(int nimg, int OH, int C, int k_next);
 int eqa_winograd_f2k5_output_sums(const float* M, const float* bias, int relu, double* S, void* workspace, int nimg,
+                                  int OH, int OW, int C, int k_next, void* stream);
+int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, double* S, void* workspace, int nimg,
                                   int OH, int OW, int C, int k_next, void* stream);
 
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */

@@ -1,0 +1,66 @@
+"""Micro-benchmark of the Winograd F(2x2,5x5) pipeline stages at the headline layer shape (64 x 92 x 92 x 256),
+F(m x m, 5x5) with m = 2 or 4:
+python tools/kbench_wino.py [--reps 20].  Variant builds: EQA_LIB=build_variants/libeqa_X.so."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from equiadapt_amd import _lib  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--n", type=int, default=64)
+    ap.add_argument("--hw", type=int, default=92)
+    ap.add_argument("--c", type=int, default=256)
+    ap.add_argument("--m", type=int, default=4, help="output tile size (2 or 4)")
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n, H, C = args.n, args.hw, args.c
+    OH = H - 4
+    m = args.m
+    P = (m + 4) ** 2
+    t = n * (OH // m) ** 2
+    f_in, f_out, f_sums = (getattr(lib, f"eqa_winograd_f{m}k5_{k}") for k in ("input", "output", "output_sums"))
+    x = torch.randn(n, H, H, C, device=dev)
+    V = torch.empty(P * t * C, device=dev)
+    M = torch.randn(P * t * C, device=dev)
+    U = torch.randn(P, C, C, device=dev) * 0.05
+    y = torch.empty(n, OH, OH, C, device=dev)
+    bias = torch.randn(C, device=dev)
+    S = torch.empty(n, C, 5, 5, dtype=torch.float64, device=dev)
+    ws = torch.empty(max(lib.eqa_winograd_f2k5_output_sums_workspace_bytes(n, OH, C, 5), 4) // 4, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    Vb, Mb = V.view(t, P, C).permute(1, 0, 2), M.view(t, P, C).permute(1, 0, 2)
+    gb_v = P * t * C * 4 / 1e9
+    gb_x = x.numel() * 4 / 1e9
+    ms = timeit(lambda: _lib.check(f_in(x.data_ptr(), V.data_ptr(), bias.data_ptr(), 1, n, H, H, C, st), "in"), args.reps)
+    print(f"input transform   {ms*1e3:8.1f} us  {(gb_v + gb_x)/ms*1e3:7.0f} GB/s  (write {gb_v:.2f} GB + read {gb_x:.2f} GB)")
+    ms = timeit(lambda: torch.bmm(Vb, U, out=Mb), args.reps)
+    print(f"batched GEMM      {ms*1e3:8.1f} us  {2*P*t*C*C/ms/1e9:7.1f} TFLOP/s")
+    ms = timeit(lambda: _lib.check(f_out(M.data_ptr(), bias.data_ptr(), 1, y.data_ptr(), n, OH, OH, C, st), "out"), args.reps)
+    print(f"output transform  {ms*1e3:8.1f} us  {(gb_v + y.numel()*4/1e9)/ms*1e3:7.0f} GB/s")
+    ms = timeit(lambda: _lib.check(f_sums(M.data_ptr(), bias.data_ptr(), 1, S.data_ptr(), ws.data_ptr(), n, OH, OH, C, 5, st), "sums"), args.reps)
+    print(f"output + sums     {ms*1e3:8.1f} us  {gb_v/ms*1e3:7.0f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
