@@ -129,3 +129,35 @@ def test_mask_rotation_table_matches_torchvision_restatement():
     t = g.mask_rotation_table([0.0, 90.0], (8, 12))
     assert t.shape == (2, 6)
     assert torch.allclose(t[0], torch.tensor([1 / 6.0, 0.0, 0.0, 0.0, 1 / 4.0, 0.0]), atol=1e-7)
+
+
+def test_winograd_cook_toom_matrices_are_exact():
+    """F(2,5) and F(4,5): y = A^T[(G g) * (B^T d)] equals the 5-tap correlation in rational arithmetic, B^T and A^T are
+    dyadic (exact in fp32), and g_matrix carries the sign convention of the kernels' B^T rows."""
+    import random
+    from fractions import Fraction
+
+    from equiadapt_amd.images.canonicalization_networks import winograd as w
+
+    rng = random.Random(5)
+    for m in (2, 4):
+        at, g, bt = w.cook_toom(m)
+        n = m + 4
+        assert len(bt) == n and len(g) == n and len(at) == m
+        for _ in range(5):
+            d = [Fraction(rng.randint(-99, 99)) for _ in range(n)]
+            f = [Fraction(rng.randint(-99, 99)) for _ in range(5)]
+            U = [sum(g[k][j] * f[j] for j in range(5)) for k in range(n)]
+            V = [sum(bt[k][j] * d[j] for j in range(n)) for k in range(n)]
+            y = [sum(at[i][k] * U[k] * V[k] for k in range(n)) for i in range(m)]
+            assert y == [sum(d[i + j] * f[j] for j in range(5)) for i in range(m)]
+        for row in bt + at:
+            for v in row:
+                assert v.denominator in (1, 2, 4, 8), v   # dyadic: the on-the-fly transforms add no representation error
+        G = w.g_matrix(m)
+        sg = w.kernel_bt_signs(m)
+        assert G.shape == (n, 5) and G.dtype == torch.float64
+        for k in range(n):
+            assert [float(sg[k] * v) for v in g[k]] == G[k].tolist()
+        U = w.transform_filters(torch.randn(3, 2, 5, 5), m)
+        assert U.shape == (n * n, 2, 3) and U.dtype == torch.float32
