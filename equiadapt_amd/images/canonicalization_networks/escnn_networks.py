@@ -12,6 +12,7 @@ BatchNorm3d over (B, fields, G, H, W); PointwiseDropout is element-wise dropout.
 Weights trained with e2cnn can be brought in through their exported dense form
 (``R2Conv.export()`` -> Conv2d, ``InnerBatchNorm.export()`` -> BatchNorm2d): ``load_exported_dense``.
 """
+import os
 from typing import List, Sequence
 
 import torch
@@ -104,6 +105,16 @@ class ESCNNEquivariantNetwork(nn.Module):
             self._fold_cache[("wino", m, id(conv))] = hit
         return hit[1]
 
+    def _lift_weights(self, conv, bank):
+        from equiadapt_amd import ops
+
+        hit = self._fold_cache.get(("lift", id(conv)))
+        key = self._fold_cache[id(conv)][0]
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_lift_weights(bank))
+            self._fold_cache[("lift", id(conv))] = hit
+        return hit[1]
+
     def _forward_inference(self, x: torch.Tensor) -> torch.Tensor:
         """eval + no_grad: conv(+folded BN) -> ReLU ... -> [last conv + group mean as window sums]."""
         from equiadapt_amd import ops
@@ -142,6 +153,14 @@ class ESCNNEquivariantNetwork(nn.Module):
             if pending is not None:  # the next consumer cannot absorb it: apply in one fused pass
                 ops.bias_relu_nhwc_(h, pending)
                 pending = None
+            k = conv.kernel_size
+            if (nhwc and conv.lifting and conv.stride == 1 and conv.padding == 0 and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
+                    and ops.lift_conv_supported(bank.shape[1], k, k, bank.shape[0])):
+                # lifting layer (RGB -> regular fields): hand-written fp32-MFMA implicit GEMM, bias + ReLU in its epilogue
+                h = ops.lift_conv_nhwc(h, self._lift_weights(conv, bank), bias, True, k, k)
+                if last_before_tail:
+                    return conv_then_group_pool(h, convs[-1])
+                continue
             if last_before_tail:
                 # bias + ReLU of this layer are applied inside the window-sum pass of the next (last) layer
                 c = F.conv2d(h, bank)

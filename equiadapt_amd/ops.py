@@ -338,6 +338,42 @@ def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def lift_conv_supported(cin: int, kh: int, kw: int, cout: int) -> bool:
+    """Shapes eqa_lift_conv_nhwc takes (others: the framework's convolution)."""
+    return kh in (3, 5) and 9 <= kw * cin <= 16 and cout % 64 == 0
+
+
+def pack_lift_weights(bank: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, KH, KW) filters -> (KH*8, 2, Cout) operand of eqa_lift_conv_nhwc (layout: include/eqa_hip.h): every
+    filter row of R = KW*Cin floats is split into two 8-element halves starting at 0 and R-8; the elements the halves
+    share get weight 0 in the second one."""
+    Cout, Cin, KH, KW = bank.shape
+    R = KW * Cin
+    rows = bank.permute(2, 3, 1, 0).reshape(KH, R, Cout)                # [ky][j = kx*Cin + ci][co]
+    q = torch.arange(8, device=bank.device)
+    first = rows[:, q]                                                  # (KH, 8, Cout)
+    second = rows[:, (R - 8) + q].clone()
+    second[:, : 16 - R] = 0
+    return torch.stack([first, second], dim=2).reshape(KH * 8, 2, Cout).float().contiguous()
+
+
+def lift_conv_nhwc(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int) -> torch.Tensor:
+    """Channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-kh+1,W-kw+1) = [relu](conv2d(x, w) + bias) on the fp32 MFMA
+    (eqa_lift_conv_nhwc); wpk = pack_lift_weights(w)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("lift_conv_nhwc expects a channels-last fp32 tensor on the device")
+    wpk = _need(wpk, "wpk")
+    bias, p_bias = _opt(bias, "bias", torch.float32)
+    B, Cin, H, W = x.shape
+    Cout = wpk.shape[2]
+    y = torch.empty((B, Cout, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device), _timed("lift_conv"):
+        st = lib.eqa_lift_conv_nhwc(x.data_ptr(), wpk.data_ptr(), p_bias, int(relu), y.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
+    _lib.check(st, "eqa_lift_conv_nhwc")
+    return y
+
+
 def image_action_nearest(x: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor],
                          pad: int, out_hw: Tuple[int, int], top_left: Tuple[int, int], n_planes: int, src_mod: int) -> torch.Tensor:
     """fp32 planes (P,H,W) -> (n_planes, OH, OW): nearest-neighbour action with edge pad + crop (eqa_image_action_nearest)."""

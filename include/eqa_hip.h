@@ -181,6 +181,18 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
                          int B, int C, int H, int W, int k, void* stream);
 
 /*
+ * I2a, lifting convolution in inference (escnn_networks.py:60-66 first R2Conv; custom_group_equivariant_layers.py lifting
+ * layer): few input channels -> Cout channels, KH x KW, stride 1, no padding, channels-last, on the fp32 MFMA.
+ *   y[n,oy,ox,co] = [relu]( sum_{ky,kx,ci} x[n,oy+ky,ox+kx,ci] * w[co,ci,ky,kx] + bias[co] )
+ * x:(nimg,H,W,Cin); y:(nimg,H-KH+1,W-KW+1,Cout); bias:(Cout) or NULL.  Supported: KH in {3,5}, 9 <= R = KW*Cin <= 16,
+ * Cout % 64 == 0 (else EQA_ERR_UNSUPPORTED: use the framework's convolution).
+ * wpk: weights packed (KH*8, 2, Cout):  wpk[(ky*8+q)*2 + h][co] = w[co][ci][ky][kx],  j = (R-8)*h + q, kx = j / Cin,
+ * ci = j % Cin, and 0 where h == 1 and q < 16-R  (the two 8-element halves of a filter row overlap when R < 16).
+ */
+int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
+                       int Cin, int KH, int KW, int Cout, void* stream);
+
+/*
  * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(m x m, 5x5), channels-last.
  * f2k5: m = 2 (6x6 input tiles, 36 planes); f4k5: m = 4 (8x8 input tiles, 64 planes).  N = m + 4, P = N*N:
  *   eqa_winograd_f{m}k5_input   x:(nimg,H,W,C) -> V:(nimg*TY*TX, P, C), TY = (H-4)/m, TX = (W-4)/m   (B^T d B), with

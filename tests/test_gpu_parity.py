@@ -689,3 +689,42 @@ def test_nbody_e3_canonicalizer_matches_reference_golden(dev, golden):
     # autograd path (op-by-op) gives the same numbers
     rv = rot_vec.clone().requires_grad_(True)
     assert torch.allclose(can.modified_gram_schmidt(rv).detach().cpu(), g["rotation"], atol=1e-5)
+
+
+def test_lift_conv_mfma_matches_conv2d(dev):
+    """eqa_lift_conv_nhwc (fp32 MFMA implicit GEMM) vs F.conv2d in fp64.  Tolerance 2e-6 of max|y|: the MFMA is an exact
+    fp32 fmaf chain over K <= 80 terms, same class of rounding as the direct fp32 convolution."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd import _lib, ops
+
+    torch.manual_seed(31)
+    for (B, Cin, K, Cout, H, W) in [(3, 3, 5, 256, 20, 24), (2, 3, 3, 64, 9, 11), (5, 2, 5, 128, 13, 13), (1, 4, 3, 64, 40, 7),
+                                    (2, 5, 3, 192, 12, 12), (64, 3, 5, 64, 33, 33)]:
+        assert ops.lift_conv_supported(Cin, K, K, Cout)
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
+        bias = torch.randn(Cout, device=dev)
+        wpk = ops.pack_lift_weights(w)
+        for (b, relu) in [(bias, True), (None, False), (bias, False)]:
+            got = ops.lift_conv_nhwc(x, wpk, b, relu, K, K)
+            assert got.shape == (B, Cout, H - K + 1, W - K + 1) and got.is_contiguous(memory_format=torch.channels_last)
+            want = F.conv2d(x.double(), w.double(), None if b is None else b.double())
+            want = torch.relu(want) if relu else want
+            scale = want.abs().max().item()
+            assert (got.double() - want).abs().max().item() <= 2e-6 * scale, (B, Cin, K, Cout, H, W)
+    # input at the very end of an allocation: the last receptive field must not be over-read (exact-size buffer)
+    x = torch.randn(1, 3, 5, 5, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(64, 3, 5, 5, device=dev)
+    got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), None, False, 5, 5)
+    assert torch.allclose(got.double(), F.conv2d(x.double(), w.double()), atol=1e-4)
+    # non-finite pixels stay confined to the outputs whose receptive field contains them (zero-weight duplicates are
+    # always elements of the same receptive field)
+    x = torch.randn(1, 3, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
+    x[0, 1, 11, 11] = float("inf")
+    got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), None, False, 5, 5)
+    assert torch.isfinite(got[0, :, :7, :]).all() and torch.isfinite(got[0, :, :, :7]).all() and not torch.isfinite(got[0, :, 7, 7]).all()
+    # unsupported shapes are refused, not approximated
+    lib = _lib.load()
+    assert not ops.lift_conv_supported(1, 5, 5, 64) and not ops.lift_conv_supported(3, 5, 5, 32) and not ops.lift_conv_supported(3, 7, 7, 64)
+    assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 1, 5, 5, 64, None) == -3

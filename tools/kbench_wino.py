@@ -62,5 +62,24 @@ def main():
     print(f"output + sums     {ms*1e3:8.1f} us  {gb_v/ms*1e3:7.0f} GB/s")
 
 
+def lift():
+    from equiadapt_amd import ops
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    x = torch.randn(256, 3, 96, 96, device=dev).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(256, 3, 5, 5, device=dev) / 9).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, device=dev)
+    wpk = ops.pack_lift_weights(w)
+    gf = 2 * 256 * 92 * 92 * 256 * 75 / 1e9
+    ms = timeit(lambda: ops.lift_conv_nhwc(x, wpk, b, True, 5, 5), 20)
+    print(f"lift conv (MFMA)  {ms*1e3:8.1f} us  {gf/ms:7.1f} TFLOP/s (75-tap)  {256*92*92*256*4/ms/1e6:7.0f} GB/s written")
+    ms = timeit(lambda: F.conv2d(x, w), 20)
+    print(f"lift conv (MIOpen){ms*1e3:8.1f} us  {gf/ms:7.1f} TFLOP/s")
+
+
 if __name__ == "__main__":
+    if "--lift" in sys.argv:
+        sys.argv.remove("--lift")
+        lift()
+        sys.exit(0)
     main()
