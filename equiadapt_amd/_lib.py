@@ -37,6 +37,7 @@ SIGNATURES = {
     "eqa_group_pool_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_group_pool_argmax": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_window_sums": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),
+    "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_winograd_f2k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),

@@ -809,42 +809,53 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
   }
 }
 
-// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64.  Block = one image x 32 channels; the 8 thread groups of a block
-// split the segment axis for the totals (fixed assignment + fixed-order combine: deterministic), then one thread per
-// channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
-constexpr int kFinCh = 32, kFinParts = kThreads / kFinCh;
+// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64.  Block = one image x 32 channels.  For a fixed (image, segment) the
+// block's 32 channels x nval values are ONE contiguous run of part, so thread t owns element t of that run (channel t / nval,
+// value t % nval) and walks the segment axis: every load instruction is a contiguous row (the first version gave each
+// thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see DESIGN.md).  Fixed order, deterministic.
+// Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
+constexpr int kFinCh = 32;
+constexpr int kFinVals = 1 + 2 * kWsMaxBorder;
 
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
                                                                             int B, int C, int k, int nseg) {
-  __shared__ double s_sum[kFinParts][kFinCh][1 + 2 * kWsMaxBorder];
+  __shared__ double s_tot[kFinCh * kFinVals];
+  __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
   const int b = blockIdx.y;
-  const int cl = threadIdx.x % kFinCh, pr = threadIdx.x / kFinCh;
-  const int c = blockIdx.x * kFinCh + cl;
-  const bool on = c < C;
+  const int c0 = blockIdx.x * kFinCh;
+  const int nch = min(kFinCh, C - c0);
   const int nb = k - 1, nval = 1 + 2 * nb;
-  auto P = [&](int s, int i) { return (double)part[(((size_t)b * nseg + s) * C + c) * nval + i]; };
-  double acc[1 + 2 * kWsMaxBorder];
-#pragma unroll
-  for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = 0.0;
-  if (on) {
-    for (int s = pr; s < nseg; s += kFinParts) {
-      const float* q = part + (((size_t)b * nseg + s) * C + c) * nval;
-#pragma unroll
-      for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i)
-        if (i < nval) acc[i] += (double)q[i];
+  const int run = nch * nval;  // contiguous elements of this block in one (image, segment) row
+  const float* base = part + ((size_t)b * nseg * C + c0) * nval;
+  const size_t seg_stride = (size_t)C * nval;
+  for (int e = threadIdx.x; e < run; e += kThreads) {
+    const float* q = base + e;
+    double acc = 0.0;
+    int s = 0;
+    for (; s < 2 * nb; ++s) {  // border-row segments are needed individually as well
+      const float v = q[(size_t)s * seg_stride];
+      s_brd[s][e] = v;
+      acc += (double)v;
     }
-  }
+    for (; s + 8 <= nseg; s += 8) {
+      float v[8];
 #pragma unroll
-  for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) s_sum[pr][cl][i] = acc[i];
+      for (int j = 0; j < 8; ++j) v[j] = q[(size_t)(s + j) * seg_stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (double)v[j];
+    }
+    for (; s < nseg; ++s) acc += (double)q[(size_t)s * seg_stride];
+    s_tot[e] = acc;
+  }
   __syncthreads();
-  if (pr != 0 || !on) return;
-  double tot = 0.0, col[2 * kWsMaxBorder];
+  const int cl = threadIdx.x;
+  if (cl >= nch) return;
+  const int c = c0 + cl;
+  auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
+  const double tot = s_tot[cl * nval];
+  double col[2 * kWsMaxBorder];
 #pragma unroll
-  for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = 0.0;
-  for (int q = 0; q < kFinParts; ++q) {
-    tot += s_sum[q][cl][0];
-    for (int j = 0; j < 2 * nb; ++j) col[j] += s_sum[q][cl][1 + j];
-  }
+  for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = j < 2 * nb ? s_tot[cl * nval + 1 + j] : 0.0;
   // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
   // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
   for (int u = 0; u < k; ++u) {
@@ -865,6 +876,42 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
       }
       out[((size_t)b * C + c) * (k * k) + u * k + v] = a;
     }
+  }
+}
+
+// The GEMV that follows the window sums (pooling.window_sums_to_activations; reference: the last convolution followed by
+// torch.mean over (C, H', W') -- escnn_networks.py:115, custom_equivariant_networks.py:91):
+//   act[b][e] = float( scale * sum_j S[b][j] * Wm[e][j] + shift ),  S fp64 (B, K), Wm fp64 (E, K), E <= 16.
+// One block per image, fixed-order tree reduction (deterministic).  rocBLAS' dgemm takes 0.2 ms for this 256 x 6400 x 8 shape.
+constexpr int kGemvMaxE = 16;
+
+__global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __restrict__ S, const double* __restrict__ Wm,
+                                                            float* __restrict__ act, int K, int E, double scale, double shift) {
+  __shared__ double s_red[kThreads / 64][kGemvMaxE];
+  const int b = blockIdx.x;
+  const double* sb = S + (size_t)b * K;
+  double acc[kGemvMaxE];
+#pragma unroll
+  for (int e = 0; e < kGemvMaxE; ++e) acc[e] = 0.0;
+  for (int j = threadIdx.x; j < K; j += kThreads) {
+    const double s = sb[j];
+#pragma unroll
+    for (int e = 0; e < kGemvMaxE; ++e)
+      if (e < E) acc[e] += s * Wm[(size_t)e * K + j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < kGemvMaxE; ++e) {
+    double v = acc[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) s_red[wave][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < E) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) v += s_red[w][threadIdx.x];
+    act[(size_t)b * E + threadIdx.x] = (float)(v * scale + shift);
   }
 }
 
@@ -2009,6 +2056,16 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
     if (OW < 32) EQA_LIFT_LAUNCH(3, true); else EQA_LIFT_LAUNCH(3, false);
   }
 #undef EQA_LIFT_LAUNCH
+  return launch_status();
+}
+
+int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, int K, int E, double scale, double shift,
+                         void* stream) {
+  if (B < 0 || K <= 0 || E <= 0) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
+  if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sums_gemv_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
   return launch_status();
 }
 

@@ -43,7 +43,13 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
     """The GEMV half of ``conv_then_group_pool``: (B, Cin, k, k) fp64 window sums of the (H, W) input -> (B, G)."""
     k, O = layer.kernel_size, layer.out_channels
     weff = layer.mean_response_weights()                                # (E, Cin*k*k) fp64
-    act = S.flatten(1) @ weff.t() / float(O * (H - k + 1) * (W - k + 1))
+    scale = 1.0 / float(O * (H - k + 1) * (W - k + 1))
+    if S.is_cuda and weff.shape[0] <= 16 and not torch.is_grad_enabled():
+        from equiadapt_amd import ops
+
+        shift = 0.0 if layer.bias is None else layer.bias.detach().double().mean()
+        return ops.window_sums_gemv(S.flatten(1), weff, scale, shift)
+    act = S.flatten(1) @ weff.t() * scale
     if layer.bias is not None:
         act = act + layer.bias.detach().double().mean()
     return act.float()

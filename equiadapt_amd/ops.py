@@ -338,6 +338,25 @@ def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def window_sums_gemv(S: torch.Tensor, weff: torch.Tensor, scale: float, shift) -> torch.Tensor:
+    """(B, K) fp64 window sums x (E, K) fp64 mean-response weights -> (B, E) fp32 = scale * S @ weff^T + shift
+    (eqa_window_sums_gemv).  `shift` may be a 0-dim device tensor (the bias mean): it is read without a host sync only
+    if it already is a Python float."""
+    lib = _lib.load()
+    S = _need(S, "S", torch.float64)
+    weff = _need(weff, "weff", torch.float64)
+    B, K = S.shape
+    E = weff.shape[0]
+    act = torch.empty((B, E), dtype=torch.float32, device=S.device)
+    sh = shift if isinstance(shift, float) else 0.0
+    with torch.cuda.device(S.device), _timed("sums_gemv"):
+        st = lib.eqa_window_sums_gemv(S.data_ptr(), weff.data_ptr(), act.data_ptr(), B, K, E, float(scale), sh, _stream())
+    _lib.check(st, "eqa_window_sums_gemv")
+    if not isinstance(shift, float):
+        act += shift.to(torch.float32)
+    return act
+
+
 def lift_conv_supported(cin: int, kh: int, kw: int, cout: int) -> bool:
     """Shapes eqa_lift_conv_nhwc takes (others: the framework's convolution)."""
     return kh in (3, 5) and 9 <= kw * cin <= 16 and cout % 64 == 0

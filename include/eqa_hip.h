@@ -181,6 +181,14 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
                          int B, int C, int H, int W, int k, void* stream);
 
 /*
+ * The GEMV after the window sums (last convolution + mean over channels and positions, escnn_networks.py:115,
+ * custom_equivariant_networks.py:91, collapsed to a linear map):
+ *   act[b][e] = (float)(scale * sum_j S[b][j] * Wm[e][j] + shift);  S:(B,K) fp64, Wm:(E,K) fp64, act:(B,E) fp32, E <= 16.
+ */
+int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, int K, int E, double scale, double shift,
+                         void* stream);
+
+/*
  * I2a, lifting convolution in inference (escnn_networks.py:60-66 first R2Conv; custom_group_equivariant_layers.py lifting
  * layer): few input channels -> Cout channels, KH x KW, stride 1, no padding, channels-last, on the fp32 MFMA.
  *   y[n,oy,ox,co] = [relu]( sum_{ky,kx,ci} x[n,oy+ky,ox+kx,ci] * w[co,ci,ky,kx] + bias[co] )

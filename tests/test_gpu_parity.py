@@ -728,3 +728,22 @@ def test_lift_conv_mfma_matches_conv2d(dev):
     lib = _lib.load()
     assert not ops.lift_conv_supported(1, 5, 5, 64) and not ops.lift_conv_supported(3, 5, 5, 32) and not ops.lift_conv_supported(3, 7, 7, 64)
     assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 1, 5, 5, 64, None) == -3
+
+
+def test_window_sums_gemv_matches_matmul(dev):
+    """eqa_window_sums_gemv vs the fp64 matmul it replaces (fp32 output: equal to within one rounding)."""
+    from equiadapt_amd import _lib, ops
+
+    torch.manual_seed(41)
+    for (B, K, E) in [(5, 6400, 8), (1, 75, 1), (257, 1000, 16), (3, 256, 4)]:
+        S = torch.randn(B, K, dtype=torch.float64, device=dev) * 100
+        Wm = torch.randn(E, K, dtype=torch.float64, device=dev)
+        want = (S @ Wm.t() * 0.37 + 1.25)
+        got = ops.window_sums_gemv(S, Wm, 0.37, 1.25)
+        assert got.dtype == torch.float32 and got.shape == (B, E)
+        assert torch.allclose(got.double(), want, rtol=2e-7, atol=1e-9 * want.abs().max().item())
+        got_t = ops.window_sums_gemv(S, Wm, 0.37, torch.tensor(1.25, dtype=torch.float64, device=dev))
+        assert torch.allclose(got_t.double(), want, rtol=4e-7, atol=1e-6)
+    lib = _lib.load()
+    assert lib.eqa_window_sums_gemv(S.data_ptr(), Wm.data_ptr(), got.data_ptr(), 3, 256, 17, 1.0, 0.0, None) == -3
+    assert lib.eqa_window_sums_gemv(None, None, None, 0, 256, 4, 1.0, 0.0, None) == 0
