@@ -19,6 +19,11 @@ from equiadapt_amd.common.basecanonicalization import (  # noqa: E402,F401
     IdentityCanonicalization,
 )
 from equiadapt_amd.common.utils import gram_schmidt  # noqa: F401
+from equiadapt_amd.images.canonicalization.continuous_group import (  # noqa: F401
+    ContinuousGroupImageCanonicalization,
+    OptimizedSteerableImageCanonicalization,
+    SteerableImageCanonicalization,
+)
 from equiadapt_amd.images.canonicalization.discrete_group import (  # noqa: F401
     DiscreteGroupImageCanonicalization,
     GroupEquivariantImageCanonicalization,

@@ -34,6 +34,7 @@ SIGNATURES = {
     "eqa_image_action_nearest": (_int, [_vp] * 5 + [_int] * 10 + [_vp]),
     "eqa_group_action_bwd_tiles": (_int, [_int, _int]),
     "eqa_group_action_bwd": (_int, [_vp] * 8 + [_int] * 12 + [_vp]),
+    "eqa_group_action_bwd_theta": (_int, [_vp] * 8 + [_int] * 12 + [_vp]),
     "eqa_group_pool_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_group_pool_argmax": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_window_sums": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),

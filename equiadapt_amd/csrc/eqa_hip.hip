@@ -364,10 +364,15 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
 //          discrete_group.py:213 / images/utils.py:57).  One partial per (output image, tile): deterministic.
 //   INPUT: adjoint of the gather: scatter gy * w_k to the (clamped = replicate-pad adjoint, flipped, channel-mapped)
 //          source pixels with hardware float atomics (same approach as torch's grid_sampler backward).
+//   THETA (GRAD == 2): dL/dtheta[6] for a per-sample affine matrix (continuous groups: K.geometry.warp_affine in
+//          images/canonicalization/continuous_group.py:203): ix = ((t0 xn + t1 yn + t2) + 1) half_w  =>
+//          d ix / d(t0, t1, t2) = half_w (xn, yn, 1), likewise iy with half_h; six partials per (output image, tile).
 // Same grid decomposition as the forward kernel; direct gathers (L1/L2), no LDS staging: correctness first.
-template <bool ANGLE, bool INPUT>
+template <int GRAD, bool INPUT>  // GRAD: 0 none, 1 rotation angle, 2 affine matrix
 __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const ActionArgs a) {
-  __shared__ float s_red[4];
+  constexpr bool ANGLE = GRAD != 0;  // needs the image gradient at the sample point
+  constexpr int NS = GRAD == 2 ? 6 : 1;
+  __shared__ float s_red[4][NS];
   const int tid = threadIdx.x;
   const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
   if (n >= a.n_out) return;
@@ -392,7 +397,7 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
   const bool row_ok = i < a.OH;
   int gx0[4], gy0[4];
   bool live[4];
-  float wx1[4], wy1[4], armx[4], army[4];
+  float wx1[4], wy1[4], armx[4], army[4], xns[4];
   const float yn = lin_m1_p1(a.top + i, a.Hp, a.step_y);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -410,6 +415,7 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
     gy0[k] = yin ? (int)yf : -1;
     armx[k] = -(iy - cy);
     army[k] = ix - cx;
+    xns[k] = xn;
   }
   auto src_offset = [&](int fy, int fx, bool& inside) -> int {
     inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
@@ -433,6 +439,7 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
   const float* const src_img = a.src + img_off;
   const float* const gout_img = a.gout + (size_t)n * ((size_t)a.C * dst_plane);
   float sum = 0.0f;
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};  // GRAD == 2: per-pixel sums of g*dix, g*diy over channels
 #pragma unroll 1
   for (int c = 0; c < a.C; ++c) {
     const int cs = a.chan_map ? (c / a.G) * a.G + a.chan_map[e * a.G + c % a.G] : c;
@@ -448,7 +455,8 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
         const float sw = in[k][2] ? pl[off[k][2]] : 0.0f, se = in[k][3] ? pl[off[k][3]] : 0.0f;
         const float dix = wy0 * (ne - nw) + wy1[k] * (se - sw);
         const float diy = wx0 * (sw - nw) + wx1[k] * (se - ne);
-        sum += g * (dix * armx[k] + diy * army[k]);
+        if (GRAD == 1) sum += g * (dix * armx[k] + diy * army[k]);
+        else { sx[k] += g * dix; sy[k] += g * diy; }
       }
       if (INPUT) {
         float* gp = a.gsrc + img_off + (size_t)cs * src_plane;
@@ -460,12 +468,30 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
     }
   }
   if (ANGLE) {
-    sum = wave_sum_f(sum);
-    if ((tid & 63) == 0) s_red[tid >> 6] = sum;
+    float v[NS];
+    if (GRAD == 1) {
+      v[0] = sum;
+    } else {
+#pragma unroll
+      for (int m = 0; m < NS; ++m) v[m] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[0] += sx[k] * xns[k]; v[1] += sx[k] * yn; v[2] += sx[k];
+        v[NS - 3] += sy[k] * xns[k]; v[NS - 2] += sy[k] * yn; v[NS - 1] += sy[k];
+      }
+#pragma unroll
+      for (int m = 0; m < NS; ++m) v[m] *= (m < 3 ? a.half_w : a.half_h);
+    }
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      const float w = wave_sum_f(v[m]);
+      if ((tid & 63) == 0) s_red[tid >> 6][m] = w;
+    }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < NS) {
       const int tiles_x = (int)(gridDim.x >> 3);
-      a.partial[((size_t)n * gridDim.y + blockIdx.y) * tiles_x + (blockIdx.x >> 3)] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      const size_t t = ((size_t)n * gridDim.y + blockIdx.y) * tiles_x + (blockIdx.x >> 3);
+      a.partial[t * NS + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
     }
   }
 }
@@ -1805,6 +1831,35 @@ __global__ __launch_bounds__(kThreads) void rigid_rows_kernel(const float* __res
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
+int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                      const int32_t* flags, const int32_t* chan_map, float* grad_src, float* partial, int num_elements, int G,
+                      int n_out, int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream) {
+  if (n_out == 0 && B >= 0) return EQA_OK;
+  if (!grad_out || (!grad_src && !partial)) return EQA_ERR_INVALID_ARG;
+  ActionArgs a;
+  const int rc = fill_action_args(a, src, nullptr, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad,
+                                  OH, OW, top, left);
+  if (rc != EQA_OK) return rc;
+  if (n_out == 0) return EQA_OK;
+  a.gout = grad_out; a.gsrc = grad_src; a.partial = partial;
+  const int tiles_x = (OW + kTile - 1) / kTile, tiles_y = (OH + kTile - 1) / kTile;
+  const int groups = (n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (!partial)
+    hipLaunchKernelGGL((group_action_bwd_kernel<0, true>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_mode == 1 && grad_src)
+    hipLaunchKernelGGL((group_action_bwd_kernel<1, true>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_mode == 1)
+    hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_src)
+    hipLaunchKernelGGL((group_action_bwd_kernel<2, true>), grid, dim3(kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((group_action_bwd_kernel<2, false>), grid, dim3(kThreads), 0, st, a);
+  return launch_status();
+}
+
 template <int N>
 int launch_wino_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                       void* stream) {
@@ -1926,26 +1981,16 @@ int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t*
                          const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
                          int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
                          int top, int left, void* stream) {
-  if (n_out == 0 && B >= 0) return EQA_OK;
-  if (!grad_out || (!grad_src && !grad_angle_partial)) return EQA_ERR_INVALID_ARG;
-  ActionArgs a;
-  const int rc = fill_action_args(a, src, nullptr, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad,
-                                  OH, OW, top, left);
-  if (rc != EQA_OK) return rc;
-  if (n_out == 0) return EQA_OK;
-  a.gout = grad_out; a.gsrc = grad_src; a.partial = grad_angle_partial;
-  const int tiles_x = (OW + kTile - 1) / kTile, tiles_y = (OH + kTile - 1) / kTile;
-  const int groups = (n_out + kXcd - 1) / kXcd;
-  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
-  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
-  hipStream_t st = (hipStream_t)stream;
-  if (grad_src && grad_angle_partial)
-    hipLaunchKernelGGL((group_action_bwd_kernel<true, true>), grid, dim3(kThreads), 0, st, a);
-  else if (grad_angle_partial)
-    hipLaunchKernelGGL((group_action_bwd_kernel<true, false>), grid, dim3(kThreads), 0, st, a);
-  else
-    hipLaunchKernelGGL((group_action_bwd_kernel<false, true>), grid, dim3(kThreads), 0, st, a);
-  return launch_status();
+  return launch_action_bwd(1, src, grad_out, gidx, theta, flags, chan_map, grad_src, grad_angle_partial, num_elements, G, n_out,
+                           B, C, H, W, pad, OH, OW, top, left, stream);
+}
+
+int eqa_group_action_bwd_theta(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                               const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_theta_partial,
+                               int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                               int top, int left, void* stream) {
+  return launch_action_bwd(2, src, grad_out, gidx, theta, flags, chan_map, grad_src, grad_theta_partial, num_elements, G, n_out,
+                           B, C, H, W, pad, OH, OW, top, left, stream);
 }
 
 int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {

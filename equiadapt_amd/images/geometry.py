@@ -187,3 +187,36 @@ def mask_rotation_table(angles_deg, hw: Tuple[int, int]) -> torch.Tensor:
     theta = torch.tensor(rows, dtype=torch.float32).reshape(-1, 2, 3)
     resc = theta.transpose(1, 2) / torch.tensor([0.5 * w, 0.5 * h], dtype=torch.float32)   # (E, 3, 2)
     return torch.stack([resc[:, 0, 0], resc[:, 1, 0], resc[:, 2, 0], resc[:, 0, 1], resc[:, 1, 1], resc[:, 2, 1]], dim=1).contiguous()
+
+
+def warp_affine_theta(M: torch.Tensor, frame_hw: Tuple[int, int]) -> torch.Tensor:
+    """Per-sample pixel-space matrices of ``K.geometry.warp_affine(x, M, dsize=frame)`` -> (B, 6) rows for the kernels'
+    ``affine_grid(align_corners=True)`` arithmetic.  Differentiable torch ops on M's device (fp64 inside).
+
+    kornia 0.7.0 ``warp_affine``: ``dst_norm_trans_src_norm = N M N^-1`` (``normalize_homography``), inverted, first two
+    rows to ``F.affine_grid``.  With ``M = [A | t]`` and ``N p = s * p - 1``, ``s = (2/(W-1), 2/(H-1))``:
+    ``theta = [S A^-1 S^-1 | S A^-1 (1/s) - S A^-1 t - 1]`` in closed form (reference use: continuous_group.py:203).
+    """
+    H, W = frame_hw
+    Md = M.double()
+    a, b, c, d = Md[:, 0, 0], Md[:, 0, 1], Md[:, 1, 0], Md[:, 1, 1]
+    tx, ty = Md[:, 0, 2], Md[:, 1, 2]
+    det = a * d - b * c
+    ia, ib, ic, id_ = d / det, -b / det, -c / det, a / det               # A^-1
+    sx, sy = 2.0 / max(W - 1, 1e-14), 2.0 / max(H - 1, 1e-14)
+    itx, ity = -(ia * tx + ib * ty), -(ic * tx + id_ * ty)               # -A^-1 t
+    r0 = torch.stack([ia, ib * sx / sy, sx * (ia / sx + ib / sy + itx) - 1.0], dim=1)
+    r1 = torch.stack([ic * sy / sx, id_, sy * (ic / sx + id_ / sy + ity) - 1.0], dim=1)
+    return torch.cat([r0, r1], dim=1).to(M.dtype)
+
+
+def affine_grid_theta_half_pixel(theta: torch.Tensor, frame_hw: Tuple[int, int]) -> torch.Tensor:
+    """(B, 2, 3) matrices meant for ``F.affine_grid / F.grid_sample`` with ``align_corners=False`` -> (B, 6) rows that give the
+    same sampling positions under the kernels' ``align_corners=True`` arithmetic:  x_n^F = x_n^T (W-1)/W and
+    ix = (s W + W - 1)/2 versus (s^T + 1)(W-1)/2  =>  s^T = s W/(W-1)  (reference use: continuous_group.py:386-387)."""
+    H, W = frame_hw
+    t = theta.double()
+    kx, ky = W / max(W - 1, 1e-14), H / max(H - 1, 1e-14)
+    r0 = torch.stack([t[:, 0, 0], t[:, 0, 1] * (H - 1) / H * kx, t[:, 0, 2] * kx], dim=1)
+    r1 = torch.stack([t[:, 1, 0] * (W - 1) / W * ky, t[:, 1, 1], t[:, 1, 2] * ky], dim=1)
+    return torch.cat([r0, r1], dim=1).to(theta.dtype)

@@ -115,11 +115,13 @@ def group_action_bwd(
     top_left: Tuple[int, int],
     want_src: bool,
     want_angle: bool,
+    want_theta: bool = False,
 ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
-    """Backward of ``group_action`` (eqa_group_action_bwd).
+    """Backward of ``group_action`` (eqa_group_action_bwd / eqa_group_action_bwd_theta).
 
     Returns (dL/d src or None, dL/d angle or None); the angle gradient is per output image and w.r.t. the
-    ``angle`` argument IN DEGREES of the ``rotate(img, angle)`` that ``theta`` encodes.
+    ``angle`` argument IN DEGREES of the ``rotate(img, angle)`` that ``theta`` encodes.  With ``want_theta`` the second
+    value is instead dL/d theta, (n_out, 6), for a per-output affine matrix (continuous groups).
     """
     lib = _lib.load()
     src = _need(src, "src")
@@ -135,6 +137,14 @@ def group_action_bwd(
     G = chan_map.shape[1] if chan_map is not None else 1
     g_src = torch.zeros_like(src) if want_src else None
     tiles = lib.eqa_group_action_bwd_tiles(OH, OW)
+    if want_theta:
+        partial = torch.empty((n_out, tiles, 6), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            st = lib.eqa_group_action_bwd_theta(src.data_ptr(), grad_out.data_ptr(), p_gidx, theta.data_ptr(), p_flags, p_map,
+                                                g_src.data_ptr() if want_src else None, partial.data_ptr(),
+                                                E, G, n_out, B, C, H, W, pad, OH, OW, top_left[0], top_left[1], _stream())
+        _lib.check(st, "eqa_group_action_bwd_theta")
+        return g_src, partial.sum(dim=1)
     partial = torch.empty((n_out, tiles), dtype=torch.float32, device=src.device) if want_angle else None
     with torch.cuda.device(src.device):
         st = lib.eqa_group_action_bwd(src.data_ptr(), grad_out.data_ptr(), p_gidx, theta.data_ptr(), p_flags, p_map,

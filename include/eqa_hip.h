@@ -143,6 +143,13 @@ int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t*
                          const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
                          int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
                          int top, int left, void* stream);
+/* Same, for a per-sample AFFINE matrix (continuous groups: K.geometry.warp_affine, images/canonicalization/
+ * continuous_group.py:203): grad_theta_partial (n_out, eqa_group_action_bwd_tiles(OH, OW), 6) partial sums of dL/d(theta
+ * row of the output image's element); the caller sums over the tile axis. */
+int eqa_group_action_bwd_theta(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                               const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_theta_partial,
+                               int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                               int top, int left, void* stream);
 
 /*
  * I3 + I4 -- group pooling and orientation argmax.

@@ -452,3 +452,57 @@ def group_inference_orbit(x: torch.Tensor, num_rotations: int, group_type: str) 
         for d in degrees:
             outs.append(tv_center_crop(tv_rotate_nearest(src, d.item()), (H, W)))
     return torch.stack(outs, dim=0)
+
+
+# --------------------------------------------------------------------------------------
+# continuous-group (SO(2)) image canonicalization -- images/canonicalization/continuous_group.py
+# --------------------------------------------------------------------------------------
+
+
+def steerable_rotation_from_vector(vectors: torch.Tensor) -> torch.Tensor:
+    """(B, 2) -> (B, 2, 2) with rows v1 = v/|v| and v2 = (-v1_y, v1_x)  -- continuous_group.py:246-261, :331-346."""
+    v1 = vectors / torch.norm(vectors, dim=1, keepdim=True)
+    v2 = torch.stack([-v1[:, 1], v1[:, 0]], dim=1)
+    return torch.stack([v1, v2], dim=1)
+
+
+def canonicalize_images_continuous(x: torch.Tensor, rotation_matrices: torch.Tensor, gray: bool = False):
+    """ContinuousGroupImageCanonicalization.canonicalize for group_type "rotation" -- continuous_group.py:162-210.
+
+    Returns (canonical images, the matrices as the reference leaves them: the off-diagonal entries negated IN PLACE at
+    :178, i.e. the inverse rotations -- the info dict of the reference holds these after the call).
+    Note the centre (Hp // 2, Wp // 2) with the HEIGHT in the x role (:192), not kornia.rotate's ((W-1)/2, (H-1)/2).
+    """
+    R = rotation_matrices.clone()
+    R[:, [0, 1], [1, 0]] *= -1
+    H, W = x.shape[-2:]
+    xp = x if gray else tv_pad_edge(x, math.ceil(W * 0.5))
+    alpha, beta = R[:, 0, 0], R[:, 0, 1]
+    cx, cy = xp.shape[-2] // 2, xp.shape[-1] // 2
+    affine_part = torch.stack([(1 - alpha) * cx - beta * cy, beta * cx + (1 - alpha) * cy], dim=1)
+    M = torch.cat([R, affine_part.unsqueeze(-1)], dim=-1)
+    out = kornia_warp_affine(xp, M, (xp.shape[-2], xp.shape[-1]))
+    return (out if gray else tv_center_crop(out, (H, W))), R
+
+
+def continuous_group_augment(x: torch.Tensor, angles: torch.Tensor, gray: bool = False):
+    """OptimizedSteerableImageCanonicalization.group_augment for group_type "rotation" with the random angles given
+    -- continuous_group.py:348-398.  Reference behaviour kept: ``torch.stack((cos, -sin, sin, cos)).reshape(-1, 2, 2)``
+    (:365-367) reshapes a (4, B) tensor, so for B > 1 the "rotation matrices" mix the samples' sines and cosines; the
+    returned ground-truth matrices are those mixed matrices with the off-diagonal negated (:394)."""
+    B = x.shape[0]
+    cos_a, sin_a = torch.cos(angles), torch.sin(angles)
+    rot = torch.zeros(B, 2, 3, dtype=x.dtype)
+    rot[:, :2, :2] = torch.stack((cos_a, -sin_a, sin_a, cos_a)).reshape(-1, 2, 2)
+    H, W = x.shape[-2:]
+    xp = x if gray else tv_pad_edge(x, math.ceil(W * 0.5))
+    grid = F.affine_grid(rot, list(xp.size()), align_corners=False)
+    aug = F.grid_sample(xp, grid, align_corners=False)
+    aug = aug if gray else tv_center_crop(aug, (H, W))
+    rot[:, [0, 1], [1, 0]] *= -1
+    return aug, rot[:, :, :2]
+
+
+def continuous_optimization_loss(rep_augmented: torch.Tensor, rep_augmented_gt: torch.Tensor) -> torch.Tensor:
+    """OptimizedSteerableImageCanonicalization.get_optimization_specific_loss -- continuous_group.py:472-497."""
+    return F.mse_loss(rep_augmented, rep_augmented_gt)

@@ -161,3 +161,52 @@ def test_winograd_cook_toom_matrices_are_exact():
             assert [float(sg[k] * v) for v in g[k]] == G[k].tolist()
         U = w.transform_filters(torch.randn(3, 2, 5, 5), m)
         assert U.shape == (n * n, 2, 3) and U.dtype == torch.float32
+
+
+def test_continuous_group_host_geometry():
+    """warp_affine_theta == kornia's normalise / invert chain (oracle restatement); the half-pixel conversion reproduces
+    F.affine_grid(align_corners=False) sampling positions under align_corners=True arithmetic."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd.images import geometry
+    from oracle import image_ops as o
+
+    torch.manual_seed(3)
+    for (Hp, Wp) in [(40, 48), (33, 33), (448, 448)]:
+        R = o.steerable_rotation_from_vector(torch.randn(6, 2))
+        R[:, [0, 1], [1, 0]] *= -1
+        alpha, beta = R[:, 0, 0], R[:, 0, 1]
+        cx, cy = Hp // 2, Wp // 2
+        M = torch.cat([R, torch.stack([(1 - alpha) * cx - beta * cy, beta * cx + (1 - alpha) * cy], 1).unsqueeze(-1)], -1)
+        got = geometry.warp_affine_theta(M, (Hp, Wp))
+        want = o.kornia_affine_theta(M, (Hp, Wp), (Hp, Wp)).reshape(6, 6)
+        assert torch.allclose(got, want, atol=2e-6)
+        th = torch.randn(4, 2, 3) * 0.5
+        g = F.affine_grid(th, [4, 1, Hp, Wp], align_corners=False)
+        g2 = F.affine_grid(geometry.affine_grid_theta_half_pixel(th, (Hp, Wp)).reshape(4, 2, 3), [4, 1, Hp, Wp], align_corners=True)
+        ix_f, iy_f = ((g[..., 0] + 1) * Wp - 1) / 2, ((g[..., 1] + 1) * Hp - 1) / 2
+        ix_t, iy_t = (g2[..., 0] + 1) * (Wp - 1) / 2, (g2[..., 1] + 1) * (Hp - 1) / 2
+        assert (ix_f - ix_t).abs().max() < 1e-4 * Wp / 40 and (iy_f - iy_t).abs().max() < 1e-4 * Hp / 40
+    # differentiable
+    M = M.clone().requires_grad_(True)
+    geometry.warp_affine_theta(M, (Hp, Wp)).sum().backward()
+    assert torch.isfinite(M.grad).all()
+
+
+def test_continuous_group_reference_api_cases():
+    """The reference's own tests for this class (tests/images/canonicalization/test_continuous_group.py:52-91): construction
+    and the (1,3,64,64) -> (1,3,32,32) pre-transform, hyper-parameters given as a mapping or by attribute."""
+    import types
+
+    import equiadapt_amd as ea
+
+    for hp in ({"input_crop_ratio": 0.9, "resize_shape": (32, 32)},
+               types.SimpleNamespace(input_crop_ratio=0.9, resize_shape=(32, 32))):
+        c = ea.ContinuousGroupImageCanonicalization(torch.nn.Identity(), hp, (3, 64, 64))
+        assert c.pad is not None and c.crop is not None
+        out = c.transformations_before_canonicalization_network_forward(torch.rand(1, 3, 64, 64))
+        assert out.size() == torch.Size([1, 3, 32, 32])
+        with pytest.raises(NotImplementedError):
+            c.get_groupelement(torch.rand(1, 3, 64, 64))
+    g = ea.ContinuousGroupImageCanonicalization(torch.nn.Identity(), hp, (1, 28, 28))
+    assert isinstance(g.pad, torch.nn.Identity) and isinstance(g.resize_canonization, torch.nn.Identity) and g.pad_size == 0

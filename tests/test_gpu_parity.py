@@ -11,6 +11,7 @@ Stated tolerances (SURVEY.md section 8d "Parity report"):
   * point-cloud rotation matrices 1e-4 abs, canonicalized coordinates 5e-4 abs (the reference's own R is
     orthonormal only to ~2e-4); the raw SO(3) action and Gram-Schmidt kernels: 1e-5.
 """
+import math
 import types
 
 import pytest
@@ -747,3 +748,105 @@ def test_window_sums_gemv_matches_matmul(dev):
     lib = _lib.load()
     assert lib.eqa_window_sums_gemv(S.data_ptr(), Wm.data_ptr(), got.data_ptr(), 3, 256, 17, 1.0, 0.0, None) == -3
     assert lib.eqa_window_sums_gemv(None, None, None, 0, 256, 4, 1.0, 0.0, None) == 0
+
+
+class _FixedVectorNet(torch.nn.Module):
+    """Stands in for a steerable network: returns its (B, n_vectors, 2) parameter whatever the input."""
+
+    group_type = "rotation"
+
+    def __init__(self, vectors):
+        super().__init__()
+        self.vectors = torch.nn.Parameter(vectors)
+
+    def forward(self, x):
+        return self.vectors[: x.shape[0]]
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32), (3, 40, 56), (1, 28, 28)])
+def test_steerable_canonicalizer_matches_oracle(dev, shape):
+    """(f).4 SteerableImageCanonicalization: forward vs the oracle's pad -> warp_affine -> crop, the mutated info dict,
+    and the gradients w.r.t. the network output and the image vs autograd through the oracle."""
+    import types
+
+    import equiadapt_amd as ea
+    from oracle import image_ops as o
+
+    torch.manual_seed(51)
+    B = 5
+    C, H, W = shape
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, H), torch.linspace(-1, 1, W), indexing="ij")
+    x = torch.stack([torch.stack([torch.sin(3 * xx + b + c) * torch.cos(2 * yy - c) + 0.3 * xx * yy for c in range(C)]) for b in range(B)])
+    x = x + 0.05 * torch.randn(B, C, H, W)
+    vec = torch.randn(B, 1, 2)
+    hp = types.SimpleNamespace(input_crop_ratio=0.9, resize_shape=(16, 16))
+    can = ea.SteerableImageCanonicalization(_FixedVectorNet(vec.clone().to(dev)), hp, shape).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    got = can.canonicalize(xd)
+    # oracle (CPU autograd)
+    xo = x.clone().requires_grad_(True)
+    vo = vec.clone().requires_grad_(True)
+    want, R_after = o.canonicalize_images_continuous(xo, o.steerable_rotation_from_vector(vo[:, 0]), gray=(C == 1))
+    assert got.shape == want.shape == (B, C, H, W)
+    assert (got.detach().cpu() - want.detach()).abs().max().item() <= PIX_MAX
+    info = can.canonicalization_info_dict
+    assert torch.allclose(info["group_element"]["rotation"].detach().cpu(), R_after.detach(), atol=1e-6)
+    assert info["group_element_matrix_representation"] is info["group_element"]["rotation"]
+    from oracle import pointcloud_ops as po
+
+    assert torch.allclose(can.get_prior_regularization_loss().detach().cpu(), po.continuous_prior_loss(R_after.detach()), atol=1e-6)
+    assert torch.allclose(can.get_identity_metric().detach().cpu(), po.continuous_identity_metric(R_after.detach()), atol=1e-6)
+    wgt = torch.randn(B, C, H, W)
+    (got * wgt.to(dev)).sum().backward()
+    (want * wgt).sum().backward()
+    gv, gv_o = can.canonicalization_network.vectors.grad.cpu(), vo.grad
+    scale = gv_o.abs().max().item()
+    assert (gv - gv_o).abs().max().item() <= 5e-3 * scale, (gv, gv_o)
+    assert (xd.grad.cpu() - xo.grad).abs().max().item() <= 1e-3 * max(xo.grad.abs().max().item(), 1.0)
+    # reference error behaviour
+    with pytest.raises(KeyError):
+        can.invert_canonicalization(got.detach())
+    can.group_type = "roto-reflection"
+    with pytest.raises(NotImplementedError):
+        can.canonicalize(x.to(dev))
+
+
+def test_optimized_steerable_canonicalizer(dev):
+    """(f).4 OptimizedSteerableImageCanonicalization: group_augment vs the oracle (including the reference's (4,B)->(B,2,2)
+    reshape that mixes samples), the regression loss, and one optimisation step end to end."""
+    import types
+
+    import equiadapt_amd as ea
+    from oracle import image_ops as o
+
+    torch.manual_seed(52)
+    B, C, H, W = 4, 3, 32, 32
+    x = torch.randn(B, C, H, W)
+    hp = types.SimpleNamespace(input_crop_ratio=0.9, resize_shape=(16, 16), group_type="rotation")
+    net = ea.ConvNetwork((3, 16, 16), out_channels=8, kernel_size=3, num_layers=2, out_vector_size=2).to(dev)
+    can = ea.OptimizedSteerableImageCanonicalization(net, hp, (C, H, W)).to(dev)
+    angles = torch.tensor([0.3, 1.1, 2.5, 4.0])
+    aug, gt = can.group_augment(x.to(dev), angles.to(dev))
+    aug_o, gt_o = o.continuous_group_augment(x, angles)
+    assert torch.allclose(gt.cpu(), gt_o, atol=1e-6)
+    assert (aug.cpu() - aug_o).abs().max().item() <= PIX_MAX
+    assert not torch.allclose(gt_o[0], torch.tensor([[math.cos(0.3), math.sin(0.3)], [-math.sin(0.3), math.cos(0.3)]]), atol=1e-3)  # the quirk
+    # single image: a plain rotation
+    aug1, gt1 = can.group_augment(x[:1].to(dev), angles[:1].to(dev))
+    aug1_o, gt1_o = o.continuous_group_augment(x[:1], angles[:1])
+    assert torch.allclose(gt1.cpu(), gt1_o, atol=1e-6) and (aug1.cpu() - aug1_o).abs().max().item() <= PIX_MAX
+    # end to end: forward, losses, backward
+    can.train()
+    opt = torch.optim.SGD(can.parameters(), lr=1e-2)
+    y = can(x.to(dev))
+    assert y.shape == (B, C, H, W) and torch.isfinite(y).all()
+    info = can.canonicalization_info_dict
+    want_loss = o.continuous_optimization_loss(info["group_element_matrix_representation_augmented"].detach().cpu(),
+                                               info["group_element_matrix_representation_augmented_gt"].cpu())
+    loss = can.get_optimization_specific_loss()
+    assert torch.allclose(loss.detach().cpu(), want_loss, atol=1e-6)
+    total = loss + can.get_prior_regularization_loss() + y.square().mean()
+    total.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in can.parameters())
+    opt.step()
+    assert 0.0 <= float(1.0 - can.get_identity_metric().detach()) < 4.0
