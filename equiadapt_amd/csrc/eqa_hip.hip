@@ -1585,6 +1585,10 @@ __global__ __launch_bounds__(kThreads) void nearest_action_kernel(const T* __res
 //   [1134,1218) c2.Wf(4x21)  [1218,1302) c2.Wd  [1302,1306) c2.bn scale  [1306,1310) c2.bn shift
 // ------------------------------------------------------------------------------------------------
 constexpr int kVnC = 21, kVnK = 20, kVnThreads = 128, kVnParams = 1310;
+#ifndef EQA_VN_MIN_BLOCKS
+#define EQA_VN_MIN_BLOCKS 3  // waves per SIMD the register allocation must allow (measured 2: 481 k, 3: 531 k, 4: 416 k clouds/s)
+#endif
+constexpr int kVnQueue = 12;  // pending kNN candidates per thread (LDS, 8 bytes each)
 constexpr float kVnEps = 1e-6f;
 
 struct V3 {
@@ -1608,7 +1612,7 @@ __device__ __forceinline__ V3 vn_relu(V3 q, const V3& d) {
   return q;
 }
 
-__global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
+__global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
                                                                  float* __restrict__ partial, int N, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float vn_smem[];
   float4* pts = reinterpret_cast<float4*>(vn_smem);  // [Npad] (x, y, z, |p|^2): one ds_read_b128 per candidate
@@ -1633,8 +1637,14 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
   const float cn = c4.w;
 
   // ---- kNN: k largest of  -|xj|^2 + 2 xi.xj - |xi|^2  (the reference's expansion, equivariant_networks.py:28-30),
-  // kept sorted (descending) in registers; strict '>' so that the earlier index wins ties.  Candidates are scanned
-  // four at a time (independent LDS reads and arithmetic), with one cheap test before the insertion code.
+  // kept sorted (descending) in registers; strict '>' so that the earlier index wins ties.
+  // The sorted insertion is a ~100-instruction chain that the whole wave executes whenever ANY of its 64 points
+  // accepts a candidate -- which is true for ~870 of the 1024 candidates although each point accepts only ~93 (first
+  // version: 181 k VALU instructions per wave, ~145 k of them here, 11 % of the lanes doing useful work).  So a
+  // candidate that beats the point's current 20th score is only APPENDED to a small per-thread queue in LDS (3
+  // instructions), and the queues are drained -- in index order, each entry re-tested against the then-current
+  // threshold, i.e. the same result as immediate insertion -- when any lane's queue could overflow on the next group:
+  // ~185 chain executions per wave instead of ~870.
   float bv[kVnK];
   int bi[kVnK];
 #pragma unroll
@@ -1659,17 +1669,33 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
     const float inner = -2.0f * (ctr.x * p.x + ctr.y * p.y + ctr.z * p.z);
     return (-p.w - inner) - cn;
   };
+  float2* queue = reinterpret_cast<float2*>(vn_smem + 4 * Npad) + tid;  // slot s of this thread: queue[s * kVnThreads]
+  int cnt = 0;
+  auto drain = [&]() {
+#pragma unroll
+    for (int s = 0; s < kVnQueue; ++s) {
+      if (s < cnt) {
+        const float2 e = queue[s * kVnThreads];
+        insert(e.x, __float_as_int(e.y));
+      }
+    }
+    cnt = 0;
+  };
+  auto offer = [&](float v, int j) {
+    if (v > bv[kVnK - 1]) {
+      queue[cnt * kVnThreads] = make_float2(v, __int_as_float(j));
+      ++cnt;
+    }
+  };
   for (int j = 0; j < Npad; j += 4) {
     const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
-    const float v0 = score(p0), v1 = score(p1), v2 = score(p2), v3_ = score(p3);
-    const float best = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3_));
-    if (best > bv[kVnK - 1]) {
-      insert(v0, j);
-      insert(v1, j + 1);
-      insert(v2, j + 2);
-      insert(v3_, j + 3);
-    }
+    offer(score(p0), j);
+    offer(score(p1), j + 1);
+    offer(score(p2), j + 2);
+    offer(score(p3), j + 3);
+    if (__any(cnt > kVnQueue - 4)) drain();  // wave-uniform
   }
+  drain();
 
   // ---- conv_pos on the k edges + mean over neighbours
   V3 pooled[kVnC];
@@ -1681,6 +1707,9 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
   const float* bsh = prm + 147;
 #pragma unroll 1
   for (int t = 0; t < kVnK; ++t) {
+    // compiler barrier: otherwise the 168 loop-invariant scalar weights are hoisted out of the loop and, for want of
+    // SGPRs, parked in VGPRs for its whole duration (the kernel then needs > 256 VGPRs: one wave per SIMD)
+    asm volatile("" ::: "memory");
     // (dynamic t: pick the t-th neighbour index through a select chain, the list lives in registers)
     int j = bi[0];
 #pragma unroll
@@ -1703,8 +1732,11 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
 #pragma unroll
   for (int c = 0; c < kVnC; ++c) { pooled[c].x *= inv_k; pooled[c].y *= inv_k; pooled[c].z *= inv_k; }
 
-  // ---- conv1 (21->21) + its VN-BN + ReLU, then bn1
-  V3 h1[kVnC];
+  // ---- conv1 (21->21) + its VN-BN + ReLU, then bn1; every output channel is folded into conv2's (21->4) two linear
+  // maps as soon as it exists, so the 21 x 3 intermediate never has to be held in registers
+  V3 q2[4], d2[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { q2[o] = v3(0.f, 0.f, 0.f); d2[o] = v3(0.f, 0.f, 0.f); }
   {
     const float* W1f = prm + 168;
     const float* W1d = prm + 609;
@@ -1712,8 +1744,11 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
     const float* t1 = prm + 1071;
     const float* s2 = prm + 1092;
     const float* t2 = prm + 1113;
-#pragma unroll
+    const float* W2f = prm + 1134;
+    const float* W2d = prm + 1218;
+#pragma unroll 1  // rolled: fully unrolled (882 scalar weights in flight) the kernel needs > 256 VGPRs
     for (int c = 0; c < kVnC; ++c) {
+      asm volatile("" ::: "memory");
       V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
 #pragma unroll
       for (int a = 0; a < kVnC; ++a) {
@@ -1722,26 +1757,23 @@ __global__ __launch_bounds__(kVnThreads) void vnsmall_fwd_kernel(const float* __
         d.x += wd * pooled[a].x; d.y += wd * pooled[a].y; d.z += wd * pooled[a].z;
       }
       q = vn_relu(vn_bn(q, s1[c], t1[c]), d);
-      h1[c] = vn_bn(q, s2[c], t2[c]);
+      const V3 hc = vn_bn(q, s2[c], t2[c]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float wf = W2f[o * kVnC + c], wd = W2d[o * kVnC + c];
+        q2[o].x += wf * hc.x; q2[o].y += wf * hc.y; q2[o].z += wf * hc.z;
+        d2[o].x += wd * hc.x; d2[o].y += wd * hc.y; d2[o].z += wd * hc.z;
+      }
     }
   }
-  // ---- conv2 (21->4) -> this point's contribution to the mean over points
+  // ---- conv2's VN-BN + ReLU -> this point's contribution to the mean over points
   float outv[12];
   {
-    const float* W2f = prm + 1134;
-    const float* W2d = prm + 1218;
     const float* s3 = prm + 1302;
     const float* t3 = prm + 1306;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
-#pragma unroll
-      for (int a = 0; a < kVnC; ++a) {
-        const float wf = W2f[c * kVnC + a], wd = W2d[c * kVnC + a];
-        q.x += wf * h1[a].x; q.y += wf * h1[a].y; q.z += wf * h1[a].z;
-        d.x += wd * h1[a].x; d.y += wd * h1[a].y; d.z += wd * h1[a].z;
-      }
-      q = vn_relu(vn_bn(q, s3[c], t3[c]), d);
+      const V3 q = vn_relu(vn_bn(q2[c], s3[c], t3[c]), d2[c]);
       outv[c * 3] = active ? q.x : 0.f;
       outv[c * 3 + 1] = active ? q.y : 0.f;
       outv[c * 3 + 2] = active ? q.z : 0.f;
@@ -2200,7 +2232,7 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
                     void* stream) {
   if (!x || !params || !out || !workspace || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
   if (k != kVnK || pooling != 0 || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20, mean pooling
-  const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float);
+  const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
   if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
