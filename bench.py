@@ -14,6 +14,9 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
   roofline      HBM roofline of the dominant hand-written kernel (the canonicalizing transform),
                 from HIP events recorded inside the timed region;
   group_action  transform+invert only (random group index), the figure the "% HBM roofline" target is about;
+  stages        the canonicalization network's kernels (97 % of the step), each against the roofline that bounds it: the
+                hand-written Winograd transforms (HBM), the library batched fp32 GEMM between them and the hand-written
+                lifting convolution (fp32 MFMA), HIP events inside the timed region;
   cpu_baseline  the CPU oracle (reference op order) on this host, bounded sample, rank 0 / N=1 only.
 """
 import argparse
@@ -30,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
+MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
 H = W = 224
 C = 3
 BYTES_TRANSFORM = 2 * C * H * W * 4  # read + write per image, fp32: 1,204,224 B
@@ -222,6 +226,30 @@ def main():
                              "frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "eqa_canon_transform_fwd + eqa_invert_action_fwd only, seeded random index"},
         }
+        # canonicalization-network stages at this batch: 96x96x3 -> lift 5x5 -> 92x92x256 -> Winograd F(4x4,5x5) -> 88x88x256
+        # (consumed as window sums); algorithmic bytes / flops per launch, fp32
+        px_l, px_w, tiles = B * 92 * 92, B * 88 * 88, B * 22 * 22
+        v_bytes = tiles * 64 * 256 * 4
+        spec = {
+            "winograd_input": ("hbm", px_l * 256 * 4 + v_bytes, "eqa_winograd_f4k5_input (hand-written)"),
+            "winograd_gemm": ("mfma", 2.0 * 64 * tiles * 256 * 256, "64 x [tiles x 256].[256 x 256] strided-batched GEMM (library)"),
+            "winograd_output_sums": ("hbm", v_bytes, "eqa_winograd_f4k5_output_sums incl. finalize (hand-written)"),
+            "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
+        }
+        stages = {}
+        for name, (bound, work, what) in spec.items():
+            n_k, ms_k = ktimes.get(name, (0, None))
+            if not ms_k:
+                continue
+            if bound == "hbm":
+                a = work / (ms_k * 1e-3) / 1e9
+                stages[name] = {"what": what, "ms": ms_k, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": a / HBM_PEAK_GBS, "launches_timed": n_k}
+            else:
+                a = work / (ms_k * 1e-3) / 1e12
+                stages[name] = {"what": what, "ms": ms_k, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TF,
+                                "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TF, "launches_timed": n_k}
+        line["stages"] = stages
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps)
         print(json.dumps(line), flush=True)

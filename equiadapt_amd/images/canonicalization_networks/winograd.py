@@ -22,6 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from equiadapt_amd import _lib
+from equiadapt_amd.ops import _timed
 
 # interpolation points (the last, implicit one is infinity)
 POINTS = {2: (0, 1, -1, 2, -2), 4: (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2))}
@@ -141,15 +142,19 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
         for b0 in range(0, B, chunk):
             n = min(chunk, B - b0)
             t = n * TY * TX
-            st = f_in(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
+            with _timed("winograd_input"):
+                st = f_in(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
             _lib.check(st, f"eqa_winograd_f{m}k5_input")
             # plane a is the strided matrix V[:, a, :] (row stride P*Cin): no copy, the library takes lda / batch stride
-            torch.bmm(V[:t].permute(1, 0, 2), U, out=M[:t].permute(1, 0, 2))
+            with _timed("winograd_gemm"):
+                torch.bmm(V[:t].permute(1, 0, 2), U, out=M[:t].permute(1, 0, 2))
             if sums_k:
-                st = f_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,
-                            ws.data_ptr(), n, OH, OW, Cout, sums_k, stream)
+                with _timed("winograd_output_sums"):
+                    st = f_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,
+                                ws.data_ptr(), n, OH, OW, Cout, sums_k, stream)
                 _lib.check(st, f"eqa_winograd_f{m}k5_output_sums")
             else:
-                st = f_out(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
+                with _timed("winograd_output"):
+                    st = f_out(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
                 _lib.check(st, f"eqa_winograd_f{m}k5_output")
     return S if sums_k else y
