@@ -13,7 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, "eqa_hip.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip")]
+HEADERS = [os.path.join(CSRC, "eqa_common.hpp")]
 INCLUDE = os.path.join(ROOT, "include")
 
 _c_f = ctypes.POINTER(ctypes.c_float)
@@ -69,7 +70,7 @@ class EqaLibraryError(RuntimeError):
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/*.hip -> csrc/libeqa_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    newest_src = max(os.path.getmtime(p) for p in SOURCES + [os.path.join(INCLUDE, "eqa_hip.h")])
+    newest_src = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [os.path.join(INCLUDE, "eqa_hip.h")])
     if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest_src:
         return SO_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -1,0 +1,790 @@
+// libeqa_hip.so, part 1 of 5 -- the group action on images: fused pad / rotate / flip / crop resampling (I5, I7, I8), its
+// backward, the nearest-neighbour action on masks and images (I6, GroupInference) and the crop + antialiased resize (I1).
+// HBM-bound gathers: coalesced global access, LDS-staged source tiles fed by global->LDS DMA, XCD-aware block->image
+// mapping (each XCD's private L2 sees whole images).  C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.1.
+#include "eqa_common.hpp"
+
+namespace {
+
+
+constexpr int kTile = 32;      // output tile edge (px): 256 threads x 4 px
+constexpr int kBox = 47;       // staged source window edge: floor(31*sqrt(2)) + neighbour + floor/guard slack = 47
+constexpr int kLdsStride = 47; // odd dword stride: the 8x4-lane gather pattern is bank-conflict-free at 0/90/180/270 deg
+                               // 3 channels x 47 x 47 x 4 B = 26.5 KB -> 6 blocks per CU (160 KB LDS)
+constexpr int kMaxMapG = 64;   // channel-map row cached in LDS
+constexpr int kRowIters = (kBox + 3) / 4;  // window rows per wave (4 waves interleave rows)
+
+int g_force_direct = 0;
+
+struct ActionArgs {
+  const float* src;
+  float* dst;
+  const int32_t* gidx;
+  const float* theta;
+  const int32_t* flags;
+  const int32_t* chan_map;
+  int E, G, n_out, B, C;
+  int H, W, pad, Hp, Wp;
+  int OH, OW, top, left;
+  float half_w, half_h, step_x, step_y;
+  int force_direct;
+  // backward only
+  const float* gout;  // dL/d(output), shape of dst
+  float* gsrc;        // dL/d(source), shape of src, pre-zeroed (nullable)
+  float* partial;     // per (output image, tile) partial of dL/d(angle [rad]) (nullable)
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
+// Written select-style (one integer select, one fma-shaped op, one select) so it stays branch-free.
+__device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
+  const bool lo = idx < (steps >> 1);
+  const float k = (float)(lo ? idx : steps - 1 - idx);
+  const float up = -1.0f + step * k, dn = 1.0f - step * k;
+  return lo ? up : dn;
+}
+
+
+// ablation switches for tools/ablate.sh (never set in the product build)
+#ifdef EQA_ABL_NOLOAD
+#define EQA_ABL_YB(yb) (a.force_direct == 12345 ? (yb) : 0)
+#else
+#define EQA_ABL_YB(yb) (yb)
+#endif
+#ifdef EQA_ABL_NOSTORE
+#define EQA_ABL_STORE_OK(v) ((v) == 123.456f)
+#else
+#define EQA_ABL_STORE_OK(v) true
+#endif
+#ifndef EQA_ACTION_WAVES
+#define EQA_ACTION_WAVES 1
+#endif
+#ifndef EQA_FORCE_CH
+#define EQA_FORCE_CH 0
+#endif
+
+// One block = one 32x32 output tile of one output image, all channels, CH channels per LDS stage.
+//   grid = (8 * tiles_x, tiles_y, ceil(n_out / 8)):  blockIdx.x & 7 is the XCD the dispatcher deals the block
+//   to, so each XCD works on whole images (n = 8*z + xcd) and the overlapping source windows of neighbouring
+//   tiles hit in that XCD's private L2.  No integer division anywhere in the kernel.
+// Thread t owns 4 consecutive pixels of tile row t/8 (float4 stores, 128 B per 8 lanes).
+// Sampling arithmetic = torch affine_grid + grid_sample(bilinear, zeros, align_corners=True) on the
+// (Hp, Wp) frame, the frame itself being the edge-replicated (pad) and optionally h-flipped source.
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kernel(const ActionArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int kPlane = kBox * kLdsStride;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: row math stays on the SALU
+  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
+  if (n >= a.n_out) return;
+  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
+
+  int e, b;
+  if (a.gidx) {
+    e = a.gidx[n];
+    b = n;
+  } else {  // orbit mode: element-major output, n = e * B + b
+    e = n / a.B;
+    b = n - e * a.B;
+  }
+  e = min(max(e, 0), a.E - 1);
+  const int fl = a.flags ? a.flags[e] : 0;
+  const float* th = a.theta + e * 6;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+
+  // frame column of output column j (post-flip: hflip of the rotated frame, then the crop)
+  auto frame_x = [&](int j) { return flip_dst ? (a.Wp - 1 - (a.left + j)) : (a.left + j); };
+
+  // ---- source window of the tile.  The map is affine in the normalised coords, so the extremes are sums of
+  // per-axis extremes; a 1e-3 px guard covers the rounding difference to the per-pixel evaluation below.
+  const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
+  const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
+  const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
+  auto fmn = [](float p, float q) { return p < q ? p : q; };
+  auto fmx = [](float p, float q) { return p > q ? p : q; };
+  const float gx_lo = fmn(t0 * xa, t0 * xb) + fmn(t1 * ya, t1 * yb) + t2;
+  const float gx_hi = fmx(t0 * xa, t0 * xb) + fmx(t1 * ya, t1 * yb) + t2;
+  const float gy_lo = fmn(t3 * xa, t3 * xb) + fmn(t4 * ya, t4 * yb) + t5;
+  const float gy_hi = fmx(t3 * xa, t3 * xb) + fmx(t4 * ya, t4 * yb) + t5;
+  const float minx_f = (gx_lo + 1.0f) * a.half_w - 1e-3f, maxx_f = (gx_hi + 1.0f) * a.half_w + 1e-3f;
+  const float miny_f = (gy_lo + 1.0f) * a.half_h - 1e-3f, maxy_f = (gy_hi + 1.0f) * a.half_h + 1e-3f;
+  // keep at most one ring of off-frame (zero) pixels
+  const int x_lo = (int)floorf(fmx(minx_f, -1.0f)), y_lo = (int)floorf(fmx(miny_f, -1.0f));
+  // at least 2x2 so the clamped neighbour reads of fully off-frame pixels stay inside staged data
+  const int x_hi = max((int)floorf(fmn(maxx_f, (float)(a.Wp - 1))) + 1, x_lo + 1);
+  const int y_hi = max((int)floorf(fmn(maxy_f, (float)(a.Hp - 1))) + 1, y_lo + 1);
+  const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
+  const bool use_lds = (bw <= kBox) && (bh <= kBox) && !a.force_direct;
+
+  // ---- per-thread output pixels
+  const int r = tid >> 3, q = tid & 7;
+  const int i = i0 + r, jb = j0 + 4 * q;
+  int lidx[4];         // LDS path: index of the north-west neighbour inside the staged window
+  int gx0[4], gy0[4];  // direct path: frame coords of the north-west neighbour
+  bool live[4];        // false: all four neighbours are off the frame -> exact zero
+  float w00[4], w01[4], w10[4], w11[4];
+  auto pixel_setup = [&](int pi, int pj) {
+    const float yn = lin_m1_p1(a.top + pi, a.Hp, a.step_y);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // affine_grid: [xn, yn, 1] . theta^T ; grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
+      const float xn = lin_m1_p1(frame_x(pj + k), a.Wp, a.step_x);
+      const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
+      const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+      const float xf = floorf(ix), yf = floorf(iy);
+      const float wx1 = ix - xf, wy1 = iy - yf;
+      const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+      // neighbours entirely off the frame contribute zero (grid_sample padding_mode="zeros")
+      const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+      const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+      live[k] = xin && yin;
+      const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
+      gx0[k] = xi;
+      gy0[k] = yi;
+      // (pixels of a partial tile beyond OW/OH are computed but never stored: keep their reads in the window)
+      const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
+      lidx[k] = ly * (CH * kLdsStride) + lx;
+      w00[k] = wy0 * wx0;  // nw
+      w01[k] = wy0 * wx1;  // ne
+      w10[k] = wy1 * wx0;  // sw
+      w11[k] = wy1 * wx1;  // se
+    }
+  };
+
+  // the element's channel-map row (regular features) goes to LDS once
+  int* s_cmap = reinterpret_cast<int*>(smem + CH * kPlane);
+  const bool has_cmap = a.chan_map != nullptr;
+  if (has_cmap) {
+    if (tid < a.G) s_cmap[tid] = a.chan_map[e * a.G + tid];
+    __syncthreads();
+  }
+
+  // staging role of this thread: window column `lane`; the 4 waves interleave window rows
+  const bool col_ok = lane < bw;
+  const int col_fx = x_lo + lane;
+  const bool col_inside = (unsigned)col_fx < (unsigned)a.Wp;
+  const unsigned col_off = (unsigned)min(max((flip_src ? (a.Wp - 1 - col_fx) : col_fx) - a.pad, 0), a.W - 1) * 4u;
+
+  // frame pixel -> source offset (edge-replicated pad, optional pre-flip); `inside` = not zero padding
+  auto src_offset = [&](int fy, int fx, bool& inside) -> int {
+    inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
+    int sx = flip_src ? (a.Wp - 1 - fx) : fx;
+    sx = min(max(sx - a.pad, 0), a.W - 1);
+    const int sy = min(max(fy - a.pad, 0), a.H - 1);
+    return sy * a.W + sx;
+  };
+
+  const unsigned src_plane = (unsigned)(a.H * a.W);
+  const unsigned dst_plane = (unsigned)(a.OH * a.OW);
+  const bool row_ok = i < a.OH;
+  float* const dst_img = a.dst + (size_t)n * ((size_t)a.C * dst_plane);
+
+  // plane base pointers of one stage (wave-uniform; readfirstlane makes that provable)
+  const float* const src_img = a.src + (size_t)b * ((size_t)a.C * src_plane);  // one 64-bit multiply per block
+  auto stage_planes = [&](int c0, const float* (&planes)[CH]) {
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc) {
+      const int c = min(c0 + cc, a.C - 1);
+      const int cs = __builtin_amdgcn_readfirstlane(has_cmap ? (c / a.G) * a.G + s_cmap[c % a.G] : c);
+      planes[cc] = src_img + (unsigned)cs * (unsigned)src_plane;  // C*H*W < 2^30 (checked on the host)
+    }
+  };
+  // Stage one window with direct-to-LDS DMA (global_load_lds_dword): each instruction moves one window-row
+  // segment L2/HBM -> LDS.  LDS address = M0 (row base, per channel) + lane*4; global address = plane (SGPR
+  // pair, saddr form) + [clamped row offset (SALU) + clamped/flipped column offset] (one VGPR add per row, shared
+  // by the CH channels).  No staging VGPRs, no ds_write, no select, no 64-bit address VALU.
+  // Off-frame rows/columns (padding_mode="zeros") are zero-filled afterwards by the lanes/rows that own them;
+  // those never issue a DMA, so there is no ordering problem.
+  // Inline asm because hipcc will not pick the saddr form for the builtin.  It does not count these loads:
+  // stage_wait() below is the s_waitcnt.  M0 (compiler-reserved) is saved once before the row loop and restored
+  // after it; every statement that reads M0 writes it first (cdna guide 5.7).
+  const bool lane_dma = col_ok && col_inside;
+  const bool any_zero = (x_lo < 0) || (y_lo < 0) || (x_hi > a.Wp - 1) || (y_hi > a.Hp - 1);
+  // LDS layout [window row][channel][column]: one M0 write per row serves all CH channels, each DMA adding its
+  // channel's row offset through the instruction's immediate (which shifts the global address too, so the plane
+  // base handed to the DMA is pre-biased by -cc*kRowB).
+  constexpr int kRowB = kLdsStride * 4;  // bytes of one channel's row
+  auto stage_issue = [&](const float* const (&planes)[CH]) {
+    if (lane_dma) {
+      // window rows inside the frame: [ya, yb); this wave takes ya + ((wave - ya) mod 4), +4, ...
+      const int ya = max(-y_lo, 0), yb = min(bh, a.Hp - y_lo);
+      const char* p0 = reinterpret_cast<const char*>(planes[0]);
+      const char* p1 = reinterpret_cast<const char*>(planes[CH > 1 ? 1 : 0]) - kRowB;
+      const char* p2 = reinterpret_cast<const char*>(planes[CH > 2 ? 2 : 0]) - 2 * kRowB;
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+#pragma unroll 1
+      for (int y = ya + ((wave - ya) & 3); y < EQA_ABL_YB(yb); y += 4) {
+        const int fy = y_lo + y;
+        const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
+        const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * (CH * kLdsStride));
+        if (CH == 1) {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0) : "memory");
+        } else if (CH == 2) {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                       "global_load_lds_dword %[v], %[p1] offset:%[o1]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0), [p1] "s"(p1), [o1] "i"(kRowB) : "memory");
+        } else {
+          asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]\n\t"
+                       "global_load_lds_dword %[v], %[p1] offset:%[o1]\n\t"
+                       "global_load_lds_dword %[v], %[p2] offset:%[o2]"
+                       :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), [o1] "i"(kRowB),
+                          [o2] "i"(2 * kRowB) : "memory");
+        }
+      }
+      asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+    }
+    if (any_zero && col_ok) {  // rare: tiles touching the zero ring of an unpadded frame
+#pragma unroll 1
+      for (int y = wave; y < bh; y += 4) {
+        if (!(col_inside && ((unsigned)(y_lo + y) < (unsigned)a.Hp))) {
+#pragma unroll
+          for (int cc = 0; cc < CH; ++cc) smem[(y * CH + cc) * kLdsStride + lane] = 0.0f;
+        }
+      }
+    }
+  };
+  auto stage_wait = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA has landed in LDS
+    __syncthreads();                                   // ... and so has every other wave's
+  };
+
+  const float* planes[CH];
+  stage_planes(0, planes);
+  if (use_lds) stage_issue(planes);
+  {
+    // the per-pixel setup does not depend on the loads: it runs while the DMA is in flight.  The empty asm makes
+    // its inputs opaque here so the compiler cannot hoist the arithmetic above the DMA issue.
+    int pi = i, pj = jb;
+    asm volatile("" : "+v"(pi), "+v"(pj));
+    pixel_setup(pi, pj);
+  }
+
+  for (int c0 = 0; c0 < a.C; c0 += CH) {
+    float acc[CH][4];
+    if (use_lds) {
+      if (c0 > 0) {
+        stage_planes(c0, planes);
+        __syncthreads();  // previous stage's gathers are done with the window
+        stage_issue(planes);
+      }
+      stage_wait();
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const float* s = smem + cc * kLdsStride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
+          const float sw = s[lidx[k] + CH * kLdsStride], se = s[lidx[k] + CH * kLdsStride + 1];
+          const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
+          acc[cc][k] = live[k] ? v : 0.0f;
+        }
+      }
+    } else {
+      // direct gather (window too large for LDS, or forced): rare fallback, same arithmetic.  Rolled loops on
+      // purpose: it must not inflate the register budget of the LDS path it shares the kernel with.
+      if (c0 > 0) stage_planes(c0, planes);
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[cc][k] = 0.0f;
+      }
+#pragma unroll 1
+      for (int t = 0; t < 4 * CH; ++t) {
+        const int cc = t >> 2, k = t & 3;
+        // (dynamic k: read the per-pixel state through selects, not indexed registers)
+        const int gx = k == 0 ? gx0[0] : k == 1 ? gx0[1] : k == 2 ? gx0[2] : gx0[3];
+        const int gy = k == 0 ? gy0[0] : k == 1 ? gy0[1] : k == 2 ? gy0[2] : gy0[3];
+        const float a00 = k == 0 ? w00[0] : k == 1 ? w00[1] : k == 2 ? w00[2] : w00[3];
+        const float a01 = k == 0 ? w01[0] : k == 1 ? w01[1] : k == 2 ? w01[2] : w01[3];
+        const float a10 = k == 0 ? w10[0] : k == 1 ? w10[1] : k == 2 ? w10[2] : w10[3];
+        const float a11 = k == 0 ? w11[0] : k == 1 ? w11[1] : k == 2 ? w11[2] : w11[3];
+        const bool lv = k == 0 ? live[0] : k == 1 ? live[1] : k == 2 ? live[2] : live[3];
+        const float* pl = cc == 0 ? planes[0] : (cc == 1 ? planes[CH > 1 ? 1 : 0] : planes[CH > 2 ? 2 : 0]);
+        bool in00, in01, in10, in11;
+        const int o00 = src_offset(gy, gx, in00), o01 = src_offset(gy, gx + 1, in01);
+        const int o10 = src_offset(gy + 1, gx, in10), o11 = src_offset(gy + 1, gx + 1, in11);
+        const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
+        float v = (in00 ? v00 : 0.0f) * a00 + (in01 ? v01 : 0.0f) * a01 + (in10 ? v10 : 0.0f) * a10 + (in11 ? v11 : 0.0f) * a11;
+        v = lv ? v : 0.0f;
+#pragma unroll
+        for (int c2 = 0; c2 < CH; ++c2) {
+#pragma unroll
+          for (int k2 = 0; k2 < 4; ++k2)
+            if (c2 == cc && k2 == k) acc[c2][k2] = v;
+        }
+      }
+    }
+    if (row_ok) {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        if (c0 + cc < a.C) {
+          float* o = dst_img + (unsigned)(c0 + cc) * dst_plane + (unsigned)(i * a.OW + jb);
+          if (VEC) {  // OW % 4 == 0 and jb % 4 == 0: a pixel quad is entirely inside or entirely outside the row
+            if (jb < a.OW && EQA_ABL_STORE_OK(acc[cc][0]))
+              *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              if (jb + k < a.OW) o[k] = acc[cc][k];
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the group action.  y[n,c,i,j] = sum_k w_k(phi) * frame[c, nbr_k(i,j; phi)]  (bilinear, 4 neighbours)
+//   ANGLE: dL/dphi = sum gy * (dy/dix * dix/dphi + dy/diy * diy/dphi), with the source point rotating about the frame
+//          centre c:  s = c + R(phi)^-1 (dst - c)  =>  ds/dphi = (-(s_y - c_y), s_x - c_x)  [per radian],
+//          dy/dix = wy0 (ne - nw) + wy1 (se - sw),  dy/diy = wx0 (sw - nw) + wx1 (se - ne)
+//          (what autograd derives through kornia's rotation-matrix -> affine_grid -> grid_sample chain,
+//          discrete_group.py:213 / images/utils.py:57).  One partial per (output image, tile): deterministic.
+//   INPUT: adjoint of the gather: scatter gy * w_k to the (clamped = replicate-pad adjoint, flipped, channel-mapped)
+//          source pixels with hardware float atomics (same approach as torch's grid_sampler backward).
+//   THETA (GRAD == 2): dL/dtheta[6] for a per-sample affine matrix (continuous groups: K.geometry.warp_affine in
+//          images/canonicalization/continuous_group.py:203): ix = ((t0 xn + t1 yn + t2) + 1) half_w  =>
+//          d ix / d(t0, t1, t2) = half_w (xn, yn, 1), likewise iy with half_h; six partials per (output image, tile).
+// Same grid decomposition as the forward kernel; direct gathers (L1/L2), no LDS staging: correctness first.
+template <int GRAD, bool INPUT>  // GRAD: 0 none, 1 rotation angle, 2 affine matrix
+__global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const ActionArgs a) {
+  constexpr bool ANGLE = GRAD != 0;  // needs the image gradient at the sample point
+  constexpr int NS = GRAD == 2 ? 6 : 1;
+  __shared__ float s_red[4][NS];
+  const int tid = threadIdx.x;
+  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
+  if (n >= a.n_out) return;
+  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
+  int e, b;
+  if (a.gidx) {
+    e = a.gidx[n];
+    b = n;
+  } else {
+    e = n / a.B;
+    b = n - e * a.B;
+  }
+  e = min(max(e, 0), a.E - 1);
+  const int fl = a.flags ? a.flags[e] : 0;
+  const float* th = a.theta + e * 6;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+  const float cx = a.half_w, cy = a.half_h;  // frame centre ((Wp-1)/2, (Hp-1)/2)
+
+  const int r = tid >> 3, q = tid & 7;
+  const int i = i0 + r, jb = j0 + 4 * q;
+  const bool row_ok = i < a.OH;
+  int gx0[4], gy0[4];
+  bool live[4];
+  float wx1[4], wy1[4], armx[4], army[4], xns[4];
+  const float yn = lin_m1_p1(a.top + i, a.Hp, a.step_y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int fj = a.left + jb + k;
+    const float xn = lin_m1_p1(flip_dst ? (a.Wp - 1 - fj) : fj, a.Wp, a.step_x);
+    const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
+    const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+    const float xf = floorf(ix), yf = floorf(iy);
+    wx1[k] = ix - xf;
+    wy1[k] = iy - yf;
+    const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+    const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+    live[k] = xin && yin && row_ok && (jb + k < a.OW);
+    gx0[k] = xin ? (int)xf : -1;
+    gy0[k] = yin ? (int)yf : -1;
+    armx[k] = -(iy - cy);
+    army[k] = ix - cx;
+    xns[k] = xn;
+  }
+  auto src_offset = [&](int fy, int fx, bool& inside) -> int {
+    inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
+    int sx = flip_src ? (a.Wp - 1 - fx) : fx;
+    sx = min(max(sx - a.pad, 0), a.W - 1);
+    const int sy = min(max(fy - a.pad, 0), a.H - 1);
+    return sy * a.W + sx;
+  };
+  int off[4][4];
+  bool in[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    off[k][0] = src_offset(gy0[k], gx0[k], in[k][0]);
+    off[k][1] = src_offset(gy0[k], gx0[k] + 1, in[k][1]);
+    off[k][2] = src_offset(gy0[k] + 1, gx0[k], in[k][2]);
+    off[k][3] = src_offset(gy0[k] + 1, gx0[k] + 1, in[k][3]);
+  }
+
+  const unsigned src_plane = (unsigned)(a.H * a.W), dst_plane = (unsigned)(a.OH * a.OW);
+  const size_t img_off = (size_t)b * ((size_t)a.C * src_plane);
+  const float* const src_img = a.src + img_off;
+  const float* const gout_img = a.gout + (size_t)n * ((size_t)a.C * dst_plane);
+  float sum = 0.0f;
+  float sx[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f};  // GRAD == 2: per-pixel sums of g*dix, g*diy over channels
+#pragma unroll 1
+  for (int c = 0; c < a.C; ++c) {
+    const int cs = a.chan_map ? (c / a.G) * a.G + a.chan_map[e * a.G + c % a.G] : c;
+    const float* pl = src_img + (unsigned)cs * src_plane;
+    const float* go = gout_img + (unsigned)c * dst_plane + (unsigned)(i * a.OW + jb);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (!live[k]) continue;
+      const float g = go[k];
+      const float wx0 = 1.0f - wx1[k], wy0 = 1.0f - wy1[k];
+      if (ANGLE) {
+        const float nw = in[k][0] ? pl[off[k][0]] : 0.0f, ne = in[k][1] ? pl[off[k][1]] : 0.0f;
+        const float sw = in[k][2] ? pl[off[k][2]] : 0.0f, se = in[k][3] ? pl[off[k][3]] : 0.0f;
+        const float dix = wy0 * (ne - nw) + wy1[k] * (se - sw);
+        const float diy = wx0 * (sw - nw) + wx1[k] * (se - ne);
+        if (GRAD == 1) sum += g * (dix * armx[k] + diy * army[k]);
+        else { sx[k] += g * dix; sy[k] += g * diy; }
+      }
+      if (INPUT) {
+        float* gp = a.gsrc + img_off + (size_t)cs * src_plane;
+        if (in[k][0]) unsafeAtomicAdd(gp + off[k][0], g * wy0 * wx0);
+        if (in[k][1]) unsafeAtomicAdd(gp + off[k][1], g * wy0 * wx1[k]);
+        if (in[k][2]) unsafeAtomicAdd(gp + off[k][2], g * wy1[k] * wx0);
+        if (in[k][3]) unsafeAtomicAdd(gp + off[k][3], g * wy1[k] * wx1[k]);
+      }
+    }
+  }
+  if (ANGLE) {
+    float v[NS];
+    if (GRAD == 1) {
+      v[0] = sum;
+    } else {
+#pragma unroll
+      for (int m = 0; m < NS; ++m) v[m] = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[0] += sx[k] * xns[k]; v[1] += sx[k] * yn; v[2] += sx[k];
+        v[NS - 3] += sy[k] * xns[k]; v[NS - 2] += sy[k] * yn; v[NS - 1] += sy[k];
+      }
+#pragma unroll
+      for (int m = 0; m < NS; ++m) v[m] *= (m < 3 ? a.half_w : a.half_h);
+    }
+#pragma unroll
+    for (int m = 0; m < NS; ++m) {
+      const float w = wave_sum_f(v[m]);
+      if ((tid & 63) == 0) s_red[tid >> 6][m] = w;
+    }
+    __syncthreads();
+    if (tid < NS) {
+      const int tiles_x = (int)(gridDim.x >> 3);
+      const size_t t = ((size_t)n * gridDim.y + blockIdx.y) * tiles_x + (blockIdx.x >> 3);
+      a.partial[t * NS + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+    }
+  }
+}
+
+template <int CH>
+int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
+  const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
+  const int groups = (a.n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
+  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + (a.chan_map ? kMaxMapG * sizeof(int) : 0);
+  if (vec)
+    hipLaunchKernelGGL((group_action_kernel<CH, true>), grid, dim3(kThreads), lds, st, a);
+  else
+    hipLaunchKernelGGL((group_action_kernel<CH, false>), grid, dim3(kThreads), lds, st, a);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t* gidx, const float* theta,
+                     const int32_t* flags, const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W,
+                     int pad, int OH, int OW, int top, int left) {
+  if (n_out == 0 && B >= 0) {  // empty batch: nothing to validate against (empty tensors have null data pointers)
+    a.n_out = 0;
+    return EQA_OK;
+  }
+  if (!src || !theta || E <= 0 || n_out < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || pad < 0 || OH <= 0 || OW <= 0 ||
+      top < 0 || left < 0)
+    return EQA_ERR_INVALID_ARG;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  if (Hp < 2 || Wp < 2 || top + OH > Hp || left + OW > Wp) return EQA_ERR_INVALID_ARG;
+  if (chan_map && (G <= 0 || C % G != 0)) return EQA_ERR_INVALID_ARG;
+  if (chan_map && G > kMaxMapG) return EQA_ERR_UNSUPPORTED;
+  if ((long long)C * H * W >= (1LL << 30) || (long long)C * OH * OW >= (1LL << 30)) return EQA_ERR_UNSUPPORTED;  // 32-bit offsets inside one image
+  a.src = src; a.dst = dst; a.gidx = gidx; a.theta = theta; a.flags = flags; a.chan_map = chan_map;
+  a.E = E; a.G = chan_map ? G : 1; a.n_out = n_out; a.B = B; a.C = C;
+  a.H = H; a.W = W; a.pad = pad; a.Hp = Hp; a.Wp = Wp;
+  a.OH = OH; a.OW = OW; a.top = top; a.left = left;
+  a.half_w = (float)(Wp - 1) / 2.0f;
+  a.half_h = (float)(Hp - 1) / 2.0f;
+  a.step_x = 2.0f / (float)(Wp - 1);
+  a.step_y = 2.0f / (float)(Hp - 1);
+  a.force_direct = g_force_direct;
+  a.gout = nullptr; a.gsrc = nullptr; a.partial = nullptr;
+  return EQA_OK;
+}
+
+int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                  const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
+                  int OW, int top, int left, void* stream) {
+  if (!dst && n_out != 0) return EQA_ERR_INVALID_ARG;
+  ActionArgs a;
+  const int rc = fill_action_args(a, src, dst, gidx, theta, flags, chan_map, E, G, n_out, B, C, H, W, pad, OH, OW, top, left);
+  if (rc != EQA_OK) return rc;
+  if (n_out == 0) return EQA_OK;
+  const bool vec = (OW % 4 == 0) && (((uintptr_t)dst & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+#if EQA_FORCE_CH
+  return launch_action_ch<EQA_FORCE_CH>(a, vec, st);
+#else
+  if (C % 3 == 0) return launch_action_ch<3>(a, vec, st);
+  if (C % 2 == 0) return launch_action_ch<2>(a, vec, st);
+  return launch_action_ch<1>(a, vec, st);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// I1: centre crop + antialiased bilinear resize (torchvision CenterCrop + Resize on a tensor ==
+// F.interpolate(bilinear, antialias=True, align_corners=False); discrete_group.py:174-188).
+// Separable like torch's kernel and in the same order: horizontal pass (fp32 intermediates), then vertical pass.
+// The per-output-index tap ranges and normalised triangle weights are built on the host with torch's own formula
+// (UpSampleKernel.cpp _compute_indices_min_size_weights_aa) and passed as small tables; the crop is folded into the
+// tap start indices.  One block = one (image, channel) plane x a band of kAaBand output rows; the band's horizontally
+// resampled input rows live in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kAaBand = 8;
+
+__global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 const float* __restrict__ wx, const int32_t* __restrict__ x0,
+                                                                 const float* __restrict__ wy, const int32_t* __restrict__ y0,
+                                                                 int H, int W, int OH, int OW, int K, int max_rows) {
+  extern __shared__ __attribute__((aligned(16))) float aa_tmp[];  // [max_rows][OW]
+  const int plane = blockIdx.y;
+  const int r0 = blockIdx.x * kAaBand, r1 = min(r0 + kAaBand, OH);
+  const int ybeg = y0[r0];
+  const int yend = min(y0[r1 - 1] + K, H);  // taps past a row's own range carry zero weight
+  const int nrows = min(yend - ybeg, max_rows);
+  const float* src = x + (size_t)plane * H * W;
+  for (int idx = threadIdx.x; idx < nrows * OW; idx += kThreads) {
+    const int ry = idx / OW, ox = idx - ry * OW;
+    const float* row = src + (size_t)(ybeg + ry) * W;
+    const int xs = x0[ox];
+    float acc = 0.0f;
+    for (int j = 0; j < K; ++j) acc += wx[ox * K + j] * row[min(xs + j, W - 1)];
+    aa_tmp[ry * OW + ox] = acc;
+  }
+  __syncthreads();
+  float* dst = y + (size_t)plane * OH * OW;
+  for (int idx = threadIdx.x; idx < (r1 - r0) * OW; idx += kThreads) {
+    const int r = idx / OW, ox = idx - r * OW;
+    const int oy = r0 + r;
+    const int ys = y0[oy] - ybeg;
+    float acc = 0.0f;
+    for (int j = 0; j < K; ++j) acc += wy[oy * K + j] * aa_tmp[min(ys + j, nrows - 1) * OW + ox];
+    dst[(size_t)oy * OW + ox] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// I6: nearest-neighbour action on uint8 masks (torchvision.transforms.functional.rotate defaults on a uint8 tensor:
+// half-pixel base grid, theta rescaled by (0.5 W, 0.5 H), grid_sample(nearest, zeros, align_corners=False), round;
+// images/utils.py:125-136, optionally after flip_masks :112-122).  rtheta[e] = the RESCALED 3x2 matrix in the order
+// (r00, r10, r20, r01, r11, r21): gx = xb*r00 + yb*r10 + r20, gy = xb*r01 + yb*r11 + r21.
+// One thread = 4 consecutive output pixels (one 32-bit store).
+// ------------------------------------------------------------------------------------------------
+// Generic form (T = uint8 masks or fp32 images): output plane p of (n_planes) samples source plane p % src_mod with
+// element eidx[p]; the sampling frame is the source plane edge-padded by `pad`, the output the (OH,OW) window at
+// (top,left) of the frame -- GroupInference's pad(0.4 H) -> [hflip] -> rotate(+deg) -> CenterCrop on float images
+// (examples/images/classification/inference_utils.py:100-123: torchvision rotate defaults to NEAREST) uses all of it.
+template <typename T>
+struct Pack4;
+template <>
+struct Pack4<uint8_t> {
+  typedef uint32_t type;
+  static __device__ __forceinline__ type make(const uint8_t (&v)[4]) {
+    return (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+  }
+};
+template <>
+struct Pack4<float> {
+  typedef float4 type;
+  static __device__ __forceinline__ type make(const float (&v)[4]) { return make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nearest_action_kernel(const T* __restrict__ m, T* __restrict__ out,
+                                                                 const int32_t* __restrict__ eidx,
+                                                                 const float* __restrict__ rtheta,
+                                                                 const int32_t* __restrict__ flags, int E, int H, int W,
+                                                                 int pad, int OH, int OW, int top, int left, int src_mod) {
+  const int p = blockIdx.z;
+  const int i = blockIdx.y;
+  const int jb = (blockIdx.x * kThreads + threadIdx.x) * 4;
+  if (jb >= OW) return;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int e = min(max(eidx[p], 0), E - 1);
+  const float* t = rtheta + e * 6;
+  const bool flip = flags && (flags[e] & EQA_FLIP_SRC);
+  const T* src = m + (size_t)(src_mod > 0 ? p % src_mod : p) * H * W;
+  const float yb = ((float)(top + i) + 0.5f) - 0.5f * (float)Hp;
+  T v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int j = left + jb + k;
+    const float xb = ((float)j + 0.5f) - 0.5f * (float)Wp;
+    const float gx = xb * t[0] + yb * t[1] + t[2];
+    const float gy = xb * t[3] + yb * t[4] + t[5];
+    const float ix = ((gx + 1.0f) * (float)Wp - 1.0f) / 2.0f;
+    const float iy = ((gy + 1.0f) * (float)Hp - 1.0f) / 2.0f;
+    const float xr = rintf(ix), yr = rintf(iy);  // std::nearbyint: round half to even
+    T val = (T)0;
+    if (xr >= 0.0f && xr <= (float)(Wp - 1) && yr >= 0.0f && yr <= (float)(Hp - 1)) {
+      const int fx = flip ? (Wp - 1 - (int)xr) : (int)xr;
+      const int sx = min(max(fx - pad, 0), W - 1), sy = min(max((int)yr - pad, 0), H - 1);
+      val = src[(size_t)sy * W + sx];
+    }
+    v[k] = val;
+  }
+  T* o = out + (size_t)p * OH * OW + (size_t)i * OW + jb;
+  typedef typename Pack4<T>::type P4;
+  if (jb + 3 < OW && ((((uintptr_t)o) & (sizeof(P4) - 1)) == 0)) {
+    *reinterpret_cast<P4*>(o) = Pack4<T>::make(v);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (jb + k < OW) o[k] = v[k];
+  }
+}
+
+template <typename T>
+int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta, const int32_t* flags, int E,
+                          int n_planes, int H, int W, int pad, int OH, int OW, int top, int left, int src_mod, void* stream) {
+  if (!m || !out || !eidx || !rtheta || E <= 0 || n_planes < 0 || H <= 0 || W <= 0 || pad < 0 || OH <= 0 || OW <= 0 ||
+      top < 0 || left < 0 || top + OH > H + 2 * pad || left + OW > W + 2 * pad || src_mod < 0)
+    return EQA_ERR_INVALID_ARG;
+  if (n_planes > 65535 || OH > 65535) return EQA_ERR_UNSUPPORTED;
+  if (n_planes == 0) return EQA_OK;
+  hipLaunchKernelGGL((nearest_action_kernel<T>), dim3((OW / 4 + kThreads) / kThreads, OH, n_planes), dim3(kThreads), 0,
+                     (hipStream_t)stream, m, out, eidx, rtheta, flags, E, H, W, pad, OH, OW, top, left, src_mod);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                      const int32_t* flags, const int32_t* chan_map, float* grad_src, float* partial, int num_elements, int G,
+                      int n_out, int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream) {
+  if (n_out == 0 && B >= 0) return EQA_OK;
+  if (!grad_out || (!grad_src && !partial)) return EQA_ERR_INVALID_ARG;
+  ActionArgs a;
+  const int rc = fill_action_args(a, src, nullptr, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad,
+                                  OH, OW, top, left);
+  if (rc != EQA_OK) return rc;
+  if (n_out == 0) return EQA_OK;
+  a.gout = grad_out; a.gsrc = grad_src; a.partial = partial;
+  const int tiles_x = (OW + kTile - 1) / kTile, tiles_y = (OH + kTile - 1) / kTile;
+  const int groups = (n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
+  hipStream_t st = (hipStream_t)stream;
+  if (!partial)
+    hipLaunchKernelGGL((group_action_bwd_kernel<0, true>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_mode == 1 && grad_src)
+    hipLaunchKernelGGL((group_action_bwd_kernel<1, true>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_mode == 1)
+    hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
+  else if (grad_src)
+    hipLaunchKernelGGL((group_action_bwd_kernel<2, true>), grid, dim3(kThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL((group_action_bwd_kernel<2, false>), grid, dim3(kThreads), 0, st, a);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_abi_version(void) { return 1; }
+
+int eqa_set_option(int key, int value) {
+  if (key == 0) {
+    g_force_direct = value ? 1 : 0;
+    return EQA_OK;
+  }
+  return EQA_ERR_INVALID_ARG;
+}
+
+int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                         const int32_t* chan_map, int num_elements, int G, int n_out, int B, int C, int H, int W,
+                         int pad, int OH, int OW, int top, int left, void* stream) {
+  return launch_action(src, dst, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad, OH, OW, top,
+                       left, stream);
+}
+
+int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const float* theta, const int32_t* flags,
+                            int num_elements, int B, int C, int H, int W, int pad, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!gidx) return EQA_ERR_INVALID_ARG;
+  // CenterCrop offset of torchvision: int(round((Hp - H) / 2)) == pad exactly, since Hp - H = 2*pad
+  return launch_action(x, y, gidx, theta, flags, nullptr, num_elements, 1, B, B, C, H, W, pad, H, W, pad, pad, stream);
+}
+
+int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const float* theta, const int32_t* flags,
+                          const int32_t* chan_map, int num_elements, int G, int B, int C, int H, int W, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!gidx) return EQA_ERR_INVALID_ARG;
+  return launch_action(f, out, gidx, theta, flags, chan_map, num_elements, G, B, B, C, H, W, 0, H, W, 0, 0, stream);
+}
+
+int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int32_t* flags, int num_elements, int B,
+                         int C, int S, int pad, void* stream) {
+  if (B == 0 && num_elements > 0) return EQA_OK;
+  if (num_elements <= 0 || B <= 0) return EQA_ERR_INVALID_ARG;
+  if ((long long)num_elements * B > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
+  return launch_action(x, y, nullptr, theta, flags, nullptr, num_elements, 1, num_elements * B, B, C, S, S, pad, S, S,
+                       pad, pad, stream);
+}
+
+int eqa_group_action_bwd_tiles(int OH, int OW) {
+  if (OH <= 0 || OW <= 0) return 0;
+  return ((OH + kTile - 1) / kTile) * ((OW + kTile - 1) / kTile);
+}
+
+int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                         const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,
+                         int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                         int top, int left, void* stream) {
+  return launch_action_bwd(1, src, grad_out, gidx, theta, flags, chan_map, grad_src, grad_angle_partial, num_elements, G, n_out,
+                           B, C, H, W, pad, OH, OW, top, left, stream);
+}
+
+int eqa_group_action_bwd_theta(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
+                               const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_theta_partial,
+                               int num_elements, int G, int n_out, int B, int C, int H, int W, int pad, int OH, int OW,
+                               int top, int left, void* stream) {
+  return launch_action_bwd(2, src, grad_out, gidx, theta, flags, chan_map, grad_src, grad_theta_partial, num_elements, G, n_out,
+                           B, C, H, W, pad, OH, OW, top, left, stream);
+}
+
+int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t* x0, const float* wy, const int32_t* y0,
+                       int planes, int H, int W, int OH, int OW, int K, int max_rows, void* stream) {
+  if (!x || !y || !wx || !x0 || !wy || !y0 || planes < 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || max_rows <= 0)
+    return EQA_ERR_INVALID_ARG;
+  const size_t lds = (size_t)max_rows * OW * sizeof(float);
+  if (lds > 96 * 1024 || planes > 65535) return EQA_ERR_UNSUPPORTED;
+  if (planes == 0) return EQA_OK;
+  hipLaunchKernelGGL(crop_resize_aa_kernel, dim3((OH + kAaBand - 1) / kAaBand, planes), dim3(kThreads), lds, (hipStream_t)stream,
+                     x, y, wx, x0, wy, y0, H, W, OH, OW, K, max_rows);
+  return launch_status();
+}
+
+int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                            int num_elements, int n_masks, int H, int W, void* stream) {
+  return launch_nearest<uint8_t>(m, out, eidx, rtheta, flags, num_elements, n_masks, H, W, 0, H, W, 0, 0, 0, stream);
+}
+
+int eqa_image_action_nearest(const float* x, float* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
+                             int num_elements, int n_planes, int src_mod, int H, int W, int pad, int OH, int OW, int top,
+                             int left, void* stream) {
+  return launch_nearest<float>(x, out, eidx, rtheta, flags, num_elements, n_planes, H, W, pad, OH, OW, top, left, src_mod, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,406 @@
+// libeqa_hip.so, part 5 of 5 -- point clouds and n-body: fused kNN + VNSmall forward (P1, P2), Gram-Schmidt (P3), SO(3) action
+// (P4), modified Gram-Schmidt and the rigid action on rows (n-body E(3)).  C ABI: include/eqa_hip.h.  DESIGN.md section 3.3, 3.5.
+#include "eqa_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// P4 / P3: SO(3) action on point clouds, batched Gram-Schmidt
+// ------------------------------------------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void so3_rotate_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                             float* __restrict__ y, int N, int transpose) {
+  const int b = blockIdx.y;
+  const float* Rb = R + (size_t)b * 9;
+  float m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = transpose ? Rb[(k % 3) * 3 + k / 3] : Rb[k];
+  const float* xb = x + (size_t)b * 3 * N;
+  float* yb = y + (size_t)b * 3 * N;
+  if (VEC) {
+    const int n4 = N >> 2;
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= n4) return;
+    const float4 p0 = reinterpret_cast<const float4*>(xb)[k];
+    const float4 p1 = reinterpret_cast<const float4*>(xb + N)[k];
+    const float4 p2 = reinterpret_cast<const float4*>(xb + 2 * (size_t)N)[k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      // same accumulation order as a k-ordered dot product: (m0*x0 + m1*x1) + m2*x2
+      float4 o;
+      o.x = m[r * 3] * p0.x + m[r * 3 + 1] * p1.x + m[r * 3 + 2] * p2.x;
+      o.y = m[r * 3] * p0.y + m[r * 3 + 1] * p1.y + m[r * 3 + 2] * p2.y;
+      o.z = m[r * 3] * p0.z + m[r * 3 + 1] * p1.z + m[r * 3 + 2] * p2.z;
+      o.w = m[r * 3] * p0.w + m[r * 3 + 1] * p1.w + m[r * 3 + 2] * p2.w;
+      reinterpret_cast<float4*>(yb + (size_t)r * N)[k] = o;
+    }
+  } else {
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= N) return;
+    const float p0 = xb[k], p1 = xb[N + k], p2 = xb[2 * (size_t)N + k];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) yb[(size_t)r * N + k] = m[r * 3] * p0 + m[r * 3 + 1] * p1 + m[r * 3 + 2] * p2;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* p = v + (size_t)b * 9;
+  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  // e1 = a / |a|   (torch.norm: sqrt of the sum of squares; division, not rsqrt, to stay on the reference's rounding)
+  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  a0 /= n; a1 /= n; a2 /= n;
+  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
+  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  b0 /= n; b1 /= n; b2 /= n;
+  const float d1 = c0 * a0 + c1 * a1 + c2 * a2;
+  const float d2 = c0 * b0 + c1 * b1 + c2 * b2;  // classical GS: both projections use the ORIGINAL c
+  c0 = c0 - d1 * a0 - d2 * b0;
+  c1 = c1 - d1 * a1 - d2 * b1;
+  c2 = c2 - d1 * a2 - d2 * b2;
+  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  c0 /= n; c1 /= n; c2 /= n;
+  float* o = out + (size_t)b * 9;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+}
+
+// ------------------------------------------------------------------------------------------------
+// P1 + P2: fused VNSmall forward (eval mode, mean pooling): kNN graph -> cross edge features -> VN linear / VN batch-norm
+// / direction-gated ReLU (3->21) -> mean over neighbours -> (21->21) + VN batch-norm -> (21->4) -> mean over points.
+// Reference: pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn, get_graph_feature_cross),
+// :128-150 (VNSmall.forward), vector_neuron_layers.py:251-273, :303-324.
+// The reference materialises ten (B,21,3,N,k) tensors (5 MB per cloud each); here a cloud is 12 KB in LDS and every
+// intermediate lives in registers: one thread = one point, its k nearest neighbours kept as a sorted register list
+// while it streams over the cloud (LDS broadcast reads), then its k edges are pushed through the layers one by one.
+// Packed parameter buffer (floats), eval-mode batch-norms pre-folded to scale/shift of the vector NORM:
+//   [0,63) pos.Wf(21x3)  [63,126) pos.Wd  [126,147) pos.bn scale  [147,168) pos.bn shift
+//   [168,609) c1.Wf(21x21)  [609,1050) c1.Wd  [1050,1071) c1.bn scale  [1071,1092) c1.bn shift
+//   [1092,1113) bn1 scale  [1113,1134) bn1 shift
+//   [1134,1218) c2.Wf(4x21)  [1218,1302) c2.Wd  [1302,1306) c2.bn scale  [1306,1310) c2.bn shift
+// ------------------------------------------------------------------------------------------------
+constexpr int kVnC = 21, kVnK = 20, kVnThreads = 128, kVnParams = 1310;
+#ifndef EQA_VN_MIN_BLOCKS
+#define EQA_VN_MIN_BLOCKS 3  // waves per SIMD the register allocation must allow (measured 2: 481 k, 3: 531 k, 4: 416 k clouds/s)
+#endif
+constexpr int kVnQueue = 12;  // pending kNN candidates per thread (LDS, 8 bytes each)
+constexpr float kVnEps = 1e-6f;
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ float dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// VN batch-norm (eval): q * BN(|q| + EPS) / (|q| + EPS);  then direction-gated ReLU with slope 0
+__device__ __forceinline__ V3 vn_bn(V3 q, float scale, float shift) {
+  const float n = sqrtf(dot3(q, q)) + kVnEps;
+  const float r = (n * scale + shift) / n;
+  return v3(q.x * r, q.y * r, q.z * r);
+}
+__device__ __forceinline__ V3 vn_relu(V3 q, const V3& d) {
+  const float dp = dot3(q, d);
+  if (dp < 0.0f) {
+    const float t = dp / (dot3(d, d) + kVnEps);
+    q.x -= t * d.x; q.y -= t * d.y; q.z -= t * d.z;
+  }
+  return q;
+}
+
+__global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
+                                                                 float* __restrict__ partial, int N, int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float vn_smem[];
+  float4* pts = reinterpret_cast<float4*>(vn_smem);  // [Npad] (x, y, z, |p|^2): one ds_read_b128 per candidate
+  __shared__ float s_part[kVnThreads / 64][12];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const float* xb = x + (size_t)b * 3 * N;
+  const int Npad = (N + 3) & ~3;
+  for (int i = tid; i < Npad; i += kVnThreads) {
+    if (i < N) {
+      const float a = xb[i], c = xb[N + i], d = xb[2 * (size_t)N + i];
+      pts[i] = make_float4(a, c, d, a * a + c * c + d * d);  // torch.sum(x**2, dim=1)
+    } else {
+      pts[i] = make_float4(0.f, 0.f, 0.f, INFINITY);  // padding: value -inf, never selected
+    }
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kVnThreads + tid;
+  const bool active = n < N;
+  const int ni = active ? n : N - 1;
+  const float4 c4 = pts[ni];
+  const V3 ctr = v3(c4.x, c4.y, c4.z);
+  const float cn = c4.w;
+
+  // ---- kNN: k largest of  -|xj|^2 + 2 xi.xj - |xi|^2  (the reference's expansion, equivariant_networks.py:28-30),
+  // kept sorted (descending) in registers; strict '>' so that the earlier index wins ties.
+  // The sorted insertion is a ~100-instruction chain that the whole wave executes whenever ANY of its 64 points
+  // accepts a candidate -- which is true for ~870 of the 1024 candidates although each point accepts only ~93 (first
+  // version: 181 k VALU instructions per wave, ~145 k of them here, 11 % of the lanes doing useful work).  So a
+  // candidate that beats the point's current 20th score is only APPENDED to a small per-thread queue in LDS (3
+  // instructions), and the queues are drained -- in index order, each entry re-tested against the then-current
+  // threshold, i.e. the same result as immediate insertion -- when any lane's queue could overflow on the next group:
+  // ~185 chain executions per wave instead of ~870.
+  float bv[kVnK];
+  int bi[kVnK];
+#pragma unroll
+  for (int t = 0; t < kVnK; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
+  auto insert = [&](float val, int j) {
+    if (val > bv[kVnK - 1]) {
+      float cv = val;
+      int ci = j;
+#pragma unroll
+      for (int t = 0; t < kVnK; ++t) {
+        const bool sw = cv > bv[t];
+        const float tv = bv[t];
+        const int ti = bi[t];
+        bv[t] = sw ? cv : tv;
+        bi[t] = sw ? ci : ti;
+        cv = sw ? tv : cv;
+        ci = sw ? ti : ci;
+      }
+    }
+  };
+  auto score = [&](const float4& p) {
+    const float inner = -2.0f * (ctr.x * p.x + ctr.y * p.y + ctr.z * p.z);
+    return (-p.w - inner) - cn;
+  };
+  float2* queue = reinterpret_cast<float2*>(vn_smem + 4 * Npad) + tid;  // slot s of this thread: queue[s * kVnThreads]
+  int cnt = 0;
+  auto drain = [&]() {
+#pragma unroll
+    for (int s = 0; s < kVnQueue; ++s) {
+      if (s < cnt) {
+        const float2 e = queue[s * kVnThreads];
+        insert(e.x, __float_as_int(e.y));
+      }
+    }
+    cnt = 0;
+  };
+  auto offer = [&](float v, int j) {
+    if (v > bv[kVnK - 1]) {
+      queue[cnt * kVnThreads] = make_float2(v, __int_as_float(j));
+      ++cnt;
+    }
+  };
+  for (int j = 0; j < Npad; j += 4) {
+    const float4 p0 = pts[j], p1 = pts[j + 1], p2 = pts[j + 2], p3 = pts[j + 3];
+    offer(score(p0), j);
+    offer(score(p1), j + 1);
+    offer(score(p2), j + 2);
+    offer(score(p3), j + 3);
+    if (__any(cnt > kVnQueue - 4)) drain();  // wave-uniform
+  }
+  drain();
+
+  // ---- conv_pos on the k edges + mean over neighbours
+  V3 pooled[kVnC];
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) pooled[c] = v3(0.f, 0.f, 0.f);
+  const float* Wf = prm;
+  const float* Wd = prm + 63;
+  const float* bsc = prm + 126;
+  const float* bsh = prm + 147;
+#pragma unroll 1
+  for (int t = 0; t < kVnK; ++t) {
+    // compiler barrier: otherwise the 168 loop-invariant scalar weights are hoisted out of the loop and, for want of
+    // SGPRs, parked in VGPRs for its whole duration (the kernel then needs > 256 VGPRs: one wave per SIMD)
+    asm volatile("" ::: "memory");
+    // (dynamic t: pick the t-th neighbour index through a select chain, the list lives in registers)
+    int j = bi[0];
+#pragma unroll
+    for (int u = 1; u < kVnK; ++u) j = (t == u) ? bi[u] : j;
+    const float4 nb4 = pts[j];
+    const V3 nb = v3(nb4.x, nb4.y, nb4.z);
+    const V3 f0 = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);                                   // neighbour - centre
+    const V3 f2 = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);  // nbr x ctr
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      const float a0 = Wf[c * 3], a1 = Wf[c * 3 + 1], a2 = Wf[c * 3 + 2];
+      const float d0 = Wd[c * 3], d1 = Wd[c * 3 + 1], d2 = Wd[c * 3 + 2];
+      V3 q = v3(a0 * f0.x + a1 * ctr.x + a2 * f2.x, a0 * f0.y + a1 * ctr.y + a2 * f2.y, a0 * f0.z + a1 * ctr.z + a2 * f2.z);
+      const V3 d = v3(d0 * f0.x + d1 * ctr.x + d2 * f2.x, d0 * f0.y + d1 * ctr.y + d2 * f2.y, d0 * f0.z + d1 * ctr.z + d2 * f2.z);
+      q = vn_relu(vn_bn(q, bsc[c], bsh[c]), d);
+      pooled[c].x += q.x; pooled[c].y += q.y; pooled[c].z += q.z;
+    }
+  }
+  const float inv_k = 1.0f / (float)kVnK;
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) { pooled[c].x *= inv_k; pooled[c].y *= inv_k; pooled[c].z *= inv_k; }
+
+  // ---- conv1 (21->21) + its VN-BN + ReLU, then bn1; every output channel is folded into conv2's (21->4) two linear
+  // maps as soon as it exists, so the 21 x 3 intermediate never has to be held in registers
+  V3 q2[4], d2[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { q2[o] = v3(0.f, 0.f, 0.f); d2[o] = v3(0.f, 0.f, 0.f); }
+  {
+    const float* W1f = prm + 168;
+    const float* W1d = prm + 609;
+    const float* s1 = prm + 1050;
+    const float* t1 = prm + 1071;
+    const float* s2 = prm + 1092;
+    const float* t2 = prm + 1113;
+    const float* W2f = prm + 1134;
+    const float* W2d = prm + 1218;
+#pragma unroll 1  // rolled: fully unrolled (882 scalar weights in flight) the kernel needs > 256 VGPRs
+    for (int c = 0; c < kVnC; ++c) {
+      asm volatile("" ::: "memory");
+      V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
+#pragma unroll
+      for (int a = 0; a < kVnC; ++a) {
+        const float wf = W1f[c * kVnC + a], wd = W1d[c * kVnC + a];
+        q.x += wf * pooled[a].x; q.y += wf * pooled[a].y; q.z += wf * pooled[a].z;
+        d.x += wd * pooled[a].x; d.y += wd * pooled[a].y; d.z += wd * pooled[a].z;
+      }
+      q = vn_relu(vn_bn(q, s1[c], t1[c]), d);
+      const V3 hc = vn_bn(q, s2[c], t2[c]);
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        const float wf = W2f[o * kVnC + c], wd = W2d[o * kVnC + c];
+        q2[o].x += wf * hc.x; q2[o].y += wf * hc.y; q2[o].z += wf * hc.z;
+        d2[o].x += wd * hc.x; d2[o].y += wd * hc.y; d2[o].z += wd * hc.z;
+      }
+    }
+  }
+  // ---- conv2's VN-BN + ReLU -> this point's contribution to the mean over points
+  float outv[12];
+  {
+    const float* s3 = prm + 1302;
+    const float* t3 = prm + 1306;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const V3 q = vn_relu(vn_bn(q2[c], s3[c], t3[c]), d2[c]);
+      outv[c * 3] = active ? q.x : 0.f;
+      outv[c * 3 + 1] = active ? q.y : 0.f;
+      outv[c * 3 + 2] = active ? q.z : 0.f;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const float sres = wave_sum_f(outv[c]);
+    if ((tid & 63) == 0) s_part[tid >> 6][c] = sres;
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < kVnThreads / 64; ++w) acc += s_part[w][tid];
+    partial[((size_t)b * nblk + blockIdx.x) * 12 + tid] = acc;
+  }
+}
+
+// (B, nblk, 12) partial sums -> (B,3,3): mean over the N points, first three of the four output channels
+__global__ void vnsmall_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int nblk, float inv_n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 9) return;
+  const int b = i / 9, c = i - b * 9;
+  float acc = 0.f;
+  for (int k = 0; k < nblk; ++k) acc += partial[((size_t)b * nblk + k) * 12 + c];
+  out[i] = acc * inv_n;
+}
+
+// (f).4 -- n-body E(3) canonicalization: modified Gram-Schmidt and the per-row rigid action
+// (nbody/canonicalization/euclidean_group.py:87-157).  Tiny tensors (nodes x 3): one thread per row.
+__global__ __launch_bounds__(kThreads) void modified_gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* p = v + (size_t)b * 9;
+  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  a0 /= n; a1 /= n; a2 /= n;
+  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
+  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  b0 /= n; b1 /= n; b2 /= n;
+  d = c0 * a0 + c1 * a1 + c2 * a2;
+  c0 -= d * a0; c1 -= d * a1; c2 -= d * a2;
+  d = c0 * b0 + c1 * b1 + c2 * b2;  // modified GS: second projection uses the UPDATED third vector
+  c0 -= d * b0; c1 -= d * b1; c2 -= d * b2;
+  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  c0 /= n; c1 /= n; c2 /= n;
+  float* o = out + (size_t)b * 9;
+  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+}
+
+// mode 0: out = x R + t            (invert_canonicalization :126-137; t may be NULL)
+// mode 1: out = x R^T - t R^T      (canonicalize :108-124, the two products subtracted as the reference does)
+__global__ __launch_bounds__(kThreads) void rigid_rows_kernel(const float* __restrict__ x, const float* __restrict__ R,
+                                                             const float* __restrict__ t, float* __restrict__ out, int M, int mode) {
+  const int m = blockIdx.x * kThreads + threadIdx.x;
+  if (m >= M) return;
+  const float* r = R + (size_t)m * 9;
+  const float x0 = x[(size_t)m * 3], x1 = x[(size_t)m * 3 + 1], x2 = x[(size_t)m * 3 + 2];
+  const float t0 = t ? t[(size_t)m * 3] : 0.f, t1 = t ? t[(size_t)m * 3 + 1] : 0.f, t2 = t ? t[(size_t)m * 3 + 2] : 0.f;
+  float* o = out + (size_t)m * 3;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (mode == 0) {
+      o[j] = (x0 * r[j] + x1 * r[3 + j] + x2 * r[6 + j]) + (j == 0 ? t0 : j == 1 ? t1 : t2);
+    } else {
+      const float a = x0 * r[3 * j] + x1 * r[3 * j + 1] + x2 * r[3 * j + 2];
+      const float b = t0 * r[3 * j] + t1 * r[3 * j + 1] + t2 * r[3 * j + 2];
+      o[j] = t ? a - b : a;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream) {
+  if (B == 0 && N > 0) return EQA_OK;
+  if (!x || !R || !y || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (N % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+  if (vec)
+    hipLaunchKernelGGL((so3_rotate_kernel<true>), dim3(((N >> 2) + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  else
+    hipLaunchKernelGGL((so3_rotate_kernel<false>), dim3((N + kThreads - 1) / kThreads, B), dim3(kThreads), 0, st, x, R, y, N, transpose);
+  return launch_status();
+}
+
+int64_t eqa_vnsmall_workspace_bytes(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return (int64_t)B * ((N + kVnThreads - 1) / kVnThreads) * 12 * (int64_t)sizeof(float);
+}
+
+int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
+                    void* stream) {
+  if (!x || !params || !out || !workspace || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
+  if (k != kVnK || pooling != 0 || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20, mean pooling
+  const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
+  if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (N + kVnThreads - 1) / kVnThreads;
+  hipLaunchKernelGGL(vnsmall_fwd_kernel, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
+  return launch_status();
+}
+
+int eqa_modified_gram_schmidt(const float* v, float* out, int B, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(modified_gram_schmidt_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, out, B);
+  return launch_status();
+}
+
+int eqa_rigid_rows(const float* x, const float* R, const float* t, float* out, int M, int mode, void* stream) {
+  if (M == 0) return EQA_OK;
+  if (!x || !R || !out || M < 0 || (mode != 0 && mode != 1)) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(rigid_rows_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, R, t, out, M, mode);
+  return launch_status();
+}
+
+int eqa_gram_schmidt(const float* v, float* out, int B, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!v || !out || B < 0) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gram_schmidt_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, out, B);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,498 @@
+// libeqa_hip.so, part 2 of 5 -- reductions of the canonicalization network's feature map: group pooling + argmax (I3, I4),
+// window sums of the linearised last convolution (NCHW and channels-last), their GEMV, bias + ReLU.  C ABI: include/eqa_hip.h.
+#include "eqa_common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// I3 + I4: group pooling (mean over channels and space per group slot) and orientation argmax
+// ------------------------------------------------------------------------------------------------
+
+constexpr int kPoolSplitTarget = 2048;  // blocks wanted in flight for the streaming pass
+
+
+// grid (splits, B).  Block (b, s) streams channels [s*cps, (s+1)*cps) of image b: each wave takes whole
+// (channel, group) planes of HW contiguous floats with float4 loads, reduces them with shuffles and
+// adds the plane sum to its own per-group accumulator in LDS (fp64: the cross-plane sum is the long one).
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void group_pool_partial_kernel(const float* __restrict__ feat,
+                                                                     double* __restrict__ partial, int Cf, int G,
+                                                                     int HW, int cps, int splits) {
+  extern __shared__ __attribute__((aligned(16))) double acc[];  // [4 waves][G]
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int k = tid; k < 4 * G; k += kThreads) acc[k] = 0.0;
+  __syncthreads();
+  const int c_lo = s * cps, c_hi = min(c_lo + cps, Cf);
+  const int planes = (c_hi - c_lo) * G;
+  const float* base = feat + ((size_t)b * Cf + c_lo) * G * HW;
+  for (int p = wave; p < planes; p += 4) {
+    const float* pl = base + (size_t)p * HW;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    if (VEC) {
+      const float4* p4 = reinterpret_cast<const float4*>(pl);
+      const int n4 = HW >> 2;
+      for (int k = lane; k < n4; k += 64) {
+        const float4 t = p4[k];
+        v0 += t.x; v1 += t.y; v2 += t.z; v3 += t.w;
+      }
+    } else {
+      for (int k = lane; k < HW; k += 64) v0 += pl[k];
+    }
+    const float tot = wave_sum_f((v0 + v1) + (v2 + v3));
+    if (lane == 0) acc[wave * G + (p % G)] += (double)tot;
+  }
+  __syncthreads();
+  if (tid < G) partial[((size_t)b * splits + s) * G + tid] = (acc[tid] + acc[G + tid]) + (acc[2 * G + tid] + acc[3 * G + tid]);
+}
+
+// one wave per image: lanes g < G own one orientation each; argmax by butterfly shuffles with
+// (value, index) pairs, smaller index winning ties == torch.argmax's first-maximum rule.
+__device__ __forceinline__ void wave_argmax_store(float v, int g, int G, int32_t* out) {
+  int idx = (g < G) ? g : 0x7fffffff;
+  float val = (g < G) ? v : -INFINITY;
+  // NaN handling as torch: a NaN is "greater" than everything; first NaN wins.
+  bool isn = (g < G) && (v != v);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(val, o, 64);
+    const int oi = __shfl_xor(idx, o, 64);
+    const bool on = __shfl_xor((int)isn, o, 64) != 0;
+    bool take;
+    if (on != isn) take = on;
+    else if (on) take = oi < idx;
+    else take = (ov > val) || (ov == val && oi < idx);
+    if (take) { val = ov; idx = oi; isn = on; }
+  }
+  if (g == 0) *out = idx;
+}
+
+__global__ __launch_bounds__(kThreads) void group_pool_finalize_kernel(const double* __restrict__ partial,
+                                                                      float* __restrict__ act,
+                                                                      int32_t* __restrict__ gidx, int B, int G,
+                                                                      int splits, double inv_count) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  for (int g0 = 0; g0 < G; g0 += 64) {  // G <= 64 in every supported group; loop keeps it general for act
+    const int g = g0 + lane;
+    float a = 0.f;
+    if (g < G) {
+      double sum = 0.0;
+      for (int s = 0; s < splits; ++s) sum += partial[((size_t)b * splits + s) * G + g];
+      a = (float)(sum * inv_count);
+      act[(size_t)b * G + g] = a;
+    }
+    if (G <= 64 && gidx) wave_argmax_store(a, g, G, gidx + b);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void group_argmax_kernel(const float* __restrict__ act, int32_t* __restrict__ gidx,
+                                                               int B, int G) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= B) return;
+  const float a = lane < G ? act[(size_t)b * G + lane] : 0.f;
+  wave_argmax_store(a, lane, G, gidx + b);
+}
+
+int pool_splits(int B, int Cf) {
+  int s = (kPoolSplitTarget + B - 1) / B;
+  if (s > Cf) s = Cf;
+  if (s < 1) s = 1;
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Window sums: the exact linear shortcut for "last convolution -> group mean".
+//   mean_{o,y,x} conv(h, W)[o,g,y,x] = (1/count) * sum_{c,u,v} (sum_o W[(o,g),c,u,v]) * S[c,u,v] + mean(bias),
+//   S[c,u,v] = sum_{y<OH, x<OW} act(h[c, y+u, x+v]),  OH = H-k+1, OW = W-k+1,  act = relu?(scale*h + shift).
+// One block per (image, channel) plane: the plane is read from HBM exactly once (float4), transformed and parked in
+// LDS; column totals and the k-1 leading / trailing rows give the k row-window sums per column, then the same trick
+// across columns gives the k*k outputs.  fp64 accumulation (the consumer compares orientations by tiny margins).
+// HBM-bound: H*W*4 bytes per plane in, k*k*8 bytes out.
+// ------------------------------------------------------------------------------------------------
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void window_sums_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int relu,
+                                                              double* __restrict__ out, int C, int H, int W, int k) {
+  extern __shared__ __attribute__((aligned(16))) float ws_smem[];
+  const int HW = H * W;
+  float* sp = ws_smem;                                                   // [H*W] transformed plane
+  double* cs = reinterpret_cast<double*>(ws_smem + ((HW + 3) & ~3));      // [k][W] row-window sums per column
+  const int plane = blockIdx.x;
+  const int c = plane % C;
+  const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
+  const float* p = x + (size_t)plane * HW;
+  const int tid = threadIdx.x;
+  auto act = [&](float v) {
+    v = v * sc + sh;
+    return (relu && v < 0.0f) ? 0.0f : v;
+  };
+  if (VEC) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    float4* s4 = reinterpret_cast<float4*>(sp);
+    for (int i = tid; i < (HW >> 2); i += kThreads) {
+      float4 t = p4[i];
+      t.x = act(t.x); t.y = act(t.y); t.z = act(t.z); t.w = act(t.w);
+      s4[i] = t;
+    }
+  } else {
+    for (int i = tid; i < HW; i += kThreads) sp[i] = act(p[i]);
+  }
+  __syncthreads();
+  const int OH = H - k + 1, OW = W - k + 1;
+  // column x: total over rows, minus the u leading and the (k-1-u) trailing rows -> rows [u, u+OH)
+  for (int xcol = tid; xcol < W; xcol += kThreads) {
+    double tot = 0.0;
+    for (int y = 0; y < H; ++y) tot += (double)sp[y * W + xcol];
+    double pre = 0.0;
+    for (int u = 0; u < k; ++u) {
+      double suf = 0.0;
+      for (int y = u + OH; y < H; ++y) suf += (double)sp[y * W + xcol];
+      cs[u * W + xcol] = tot - pre - suf;
+      pre += (double)sp[u * W + xcol];
+    }
+  }
+  __syncthreads();
+  // output (u, v): columns [v, v+OW) of row-window u.  One thread per output; k*k <= 64 of them.
+  if (tid < k * k) {
+    const int u = tid / k, v = tid - u * k;
+    double acc = 0.0;
+    for (int xcol = v; xcol < v + OW; ++xcol) acc += cs[u * W + xcol];
+    out[(size_t)plane * (k * k) + tid] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Channels-last (NHWC) companions: MIOpen's fp32 implicit-GEMM convolutions run natively in NHWC, so the inference path
+// of the canonicalization network stays in that layout end to end (no NCHW<->NHWC transposes).
+//  * bias_relu_nhwc_kernel: x[p][c] = max(x[p][c] + bias[c], 0) in place, float4 over channels.
+//  * window_sums_nhwc: same S[b,c,u,v] as window_sums_kernel, for a (B,H,W,C) buffer.  Rows are cut into segments:
+//    each of the 2(k-1) border rows alone, the interior in bands.  A segment kernel streams its rows once (a wave reads
+//    one pixel's channels = contiguous floats per instruction) and emits, per channel, the segment total and the sums of
+//    the k-1 leading / trailing columns.  Every window sum is then total - excluded rows - excluded columns + their
+//    intersections (inclusion-exclusion), assembled per (image, channel) in fp64 by a small finalize kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void bias_relu_nhwc_kernel(float* __restrict__ x, const float* __restrict__ bias,
+                                                                 size_t n_vec, int C4) {
+  const size_t stride = (size_t)gridDim.x * kThreads;
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n_vec; i += stride) {
+    const int c4 = (int)(i % (size_t)C4);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 b = reinterpret_cast<const float4*>(bias)[c4];
+    v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
+
+// segment s of image b: rows [seg_y0(s), seg_y1(s)).  Output per (b, s, c): 1 + 2(k-1) floats
+//   [0] total, [1 + j] column j, [1 + (k-1) + j] column W-k+1+j      (j < k-1), all over the segment's rows.
+__device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands, int& y0, int& y1) {
+  const int nb = k - 1;
+  if (s < nb) { y0 = s; y1 = s + 1; return; }                       // top border rows
+  if (s < 2 * nb) { y0 = H - nb + (s - nb); y1 = y0 + 1; return; }  // bottom border rows
+  const int lo = nb, hi = H - nb;                                   // interior rows, cut into nbands bands
+  const int band = s - 2 * nb, rows = hi - lo;
+  y0 = lo + (int)(((long long)rows * band) / nbands);
+  y1 = lo + (int)(((long long)rows * (band + 1)) / nbands);
+}
+
+__global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                                           const float* __restrict__ shift, int relu,
+                                                                           float* __restrict__ part, int C, int H, int W, int k,
+                                                                           int nbands) {
+  __shared__ float4 s_tot[4][64];  // only the totals need a cross-wave sum; a border column has ONE owner wave
+  const int s = blockIdx.x, b = blockIdx.y;
+  const int nseg = gridDim.x;
+  int y0, y1;
+  ws_segment_rows(s, H, k, nbands, y0, y1);
+  const int nb = k - 1, nval = 1 + 2 * nb;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Q = C >> 2;  // channel quads
+  const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * H * W * C);
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    const int q = q0 + lane;
+    const bool on = q < Q;
+    const int qq = on ? q : Q - 1;
+    const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[qq] : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 sh = shift ? reinterpret_cast<const float4*>(shift)[qq] : make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld = [&](int y, int xc) {
+      float4 v = xb[((size_t)y * W + xc) * Q + qq];
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      return v;
+    };
+    float4 acc[1 + 2 * kWsMaxBorder];
+#pragma unroll
+    for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int y = y0; y < y1; ++y) {
+      // the 4 waves take pixels x = wave, wave+4, ...: each load instruction reads one pixel's channels, contiguous
+      float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
+      int xc = wave;
+      for (; xc + 4 < W; xc += 8) {
+        const float4 a = ld(y, xc), c2 = ld(y, xc + 4);
+        t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
+        t1.x += c2.x; t1.y += c2.y; t1.z += c2.z; t1.w += c2.w;
+      }
+      if (xc < W) { const float4 a = ld(y, xc); t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w; }
+      acc[0].x += t0.x + t1.x; acc[0].y += t0.y + t1.y; acc[0].z += t0.z + t1.z; acc[0].w += t0.w + t1.w;
+      // border columns (static j, wave-uniform owner): re-read from L1
+#pragma unroll
+      for (int j = 0; j < kWsMaxBorder; ++j) {
+        if (j < nb) {
+          if ((j & 3) == wave) { const float4 a = ld(y, j); acc[1 + j].x += a.x; acc[1 + j].y += a.y; acc[1 + j].z += a.z; acc[1 + j].w += a.w; }
+          const int xr = W - nb + j;
+          if ((xr & 3) == wave) {
+            const float4 a = ld(y, xr);
+            acc[1 + kWsMaxBorder + j].x += a.x; acc[1 + kWsMaxBorder + j].y += a.y;
+            acc[1 + kWsMaxBorder + j].z += a.z; acc[1 + kWsMaxBorder + j].w += a.w;
+          }
+        }
+      }
+    }
+    auto put = [&](int i, const float4& v) {  // value index i of this lane's 4 channels
+      float* o = part + ((((size_t)b * nseg + s) * Q + q) * 4) * nval + i;
+      o[0] = v.x; o[nval] = v.y; o[2 * nval] = v.z; o[3 * nval] = v.w;
+    };
+    __syncthreads();
+    s_tot[wave][lane] = acc[0];
+#pragma unroll
+    for (int j = 0; j < kWsMaxBorder; ++j) {
+      if (j < nb && on) {
+        if ((j & 3) == wave) put(1 + j, acc[1 + j]);
+        if (((W - nb + j) & 3) == wave) put(1 + nb + j, acc[1 + kWsMaxBorder + j]);
+      }
+    }
+    __syncthreads();
+    if (wave == 0 && on) {
+      const float4 a = s_tot[0][lane], b2 = s_tot[1][lane], c2 = s_tot[2][lane], d = s_tot[3][lane];
+      put(0, make_float4((a.x + b2.x) + (c2.x + d.x), (a.y + b2.y) + (c2.y + d.y), (a.z + b2.z) + (c2.z + d.z), (a.w + b2.w) + (c2.w + d.w)));
+    }
+  }
+}
+
+// part: (B, nseg, C, nval) -> out (B, C, k, k) fp64.  Block = one image x 32 channels.  For a fixed (image, segment) the
+// block's 32 channels x nval values are ONE contiguous run of part, so thread t owns element t of that run (channel t / nval,
+// value t % nval) and walks the segment axis: every load instruction is a contiguous row (the first version gave each
+// thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see DESIGN.md).  Fixed order, deterministic.
+// Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
+constexpr int kFinVals = 1 + 2 * kWsMaxBorder;
+
+__global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
+                                                                            int B, int C, int k, int nseg) {
+  __shared__ double s_tot[kFinCh * kFinVals];
+  __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
+  const int b = blockIdx.y;
+  const int c0 = blockIdx.x * kFinCh;
+  const int nch = min(kFinCh, C - c0);
+  const int nb = k - 1, nval = 1 + 2 * nb;
+  const int run = nch * nval;  // contiguous elements of this block in one (image, segment) row
+  const float* base = part + ((size_t)b * nseg * C + c0) * nval;
+  const size_t seg_stride = (size_t)C * nval;
+  for (int e = threadIdx.x; e < run; e += kThreads) {
+    const float* q = base + e;
+    double acc = 0.0;
+    int s = 0;
+    for (; s < 2 * nb; ++s) {  // border-row segments are needed individually as well
+      const float v = q[(size_t)s * seg_stride];
+      s_brd[s][e] = v;
+      acc += (double)v;
+    }
+    for (; s + 8 <= nseg; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = q[(size_t)(s + j) * seg_stride];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += (double)v[j];
+    }
+    for (; s < nseg; ++s) acc += (double)q[(size_t)s * seg_stride];
+    s_tot[e] = acc;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x;
+  if (cl >= nch) return;
+  const int c = c0 + cl;
+  auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
+  const double tot = s_tot[cl * nval];
+  double col[2 * kWsMaxBorder];
+#pragma unroll
+  for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = j < 2 * nb ? s_tot[cl * nval + 1 + j] : 0.0;
+  // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
+  // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
+  for (int u = 0; u < k; ++u) {
+    for (int v = 0; v < k; ++v) {
+      double a = tot;
+      for (int r = 0; r < nb; ++r) {
+        if (r < u) a -= P(r, 0);
+        if (r >= u) a -= P(nb + r, 0);
+      }
+      for (int j = 0; j < nb; ++j) {
+        const bool l_ex = j < v, r_ex = j >= v;
+        if (l_ex) a -= col[j];
+        if (r_ex) a -= col[nb + j];
+        for (int r = 0; r < nb; ++r) {  // excluded rows x excluded columns were subtracted twice
+          if (r < u) a += (l_ex ? P(r, 1 + j) : 0.0) + (r_ex ? P(r, 1 + nb + j) : 0.0);
+          if (r >= u) a += (l_ex ? P(nb + r, 1 + j) : 0.0) + (r_ex ? P(nb + r, 1 + nb + j) : 0.0);
+        }
+      }
+      out[((size_t)b * C + c) * (k * k) + u * k + v] = a;
+    }
+  }
+}
+
+// The GEMV that follows the window sums (pooling.window_sums_to_activations; reference: the last convolution followed by
+// torch.mean over (C, H', W') -- escnn_networks.py:115, custom_equivariant_networks.py:91):
+//   act[b][e] = float( scale * sum_j S[b][j] * Wm[e][j] + shift ),  S fp64 (B, K), Wm fp64 (E, K), E <= 16.
+// One block per image, fixed-order tree reduction (deterministic).  rocBLAS' dgemm takes 0.2 ms for this 256 x 6400 x 8 shape.
+constexpr int kGemvMaxE = 16;
+
+__global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __restrict__ S, const double* __restrict__ Wm,
+                                                            float* __restrict__ act, int K, int E, double scale, double shift) {
+  __shared__ double s_red[kThreads / 64][kGemvMaxE];
+  const int b = blockIdx.x;
+  const double* sb = S + (size_t)b * K;
+  double acc[kGemvMaxE];
+#pragma unroll
+  for (int e = 0; e < kGemvMaxE; ++e) acc[e] = 0.0;
+  for (int j = threadIdx.x; j < K; j += kThreads) {
+    const double s = sb[j];
+#pragma unroll
+    for (int e = 0; e < kGemvMaxE; ++e)
+      if (e < E) acc[e] += s * Wm[(size_t)e * K + j];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < kGemvMaxE; ++e) {
+    double v = acc[e];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) s_red[wave][e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < E) {
+    double v = 0.0;
+    for (int w = 0; w < kThreads / 64; ++w) v += s_red[w][threadIdx.x];
+    act[(size_t)b * E + threadIdx.x] = (float)(v * scale + shift);
+  }
+}
+
+}  // namespace
+
+int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream) {
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, stream, part, S, B, C,
+                     k, nseg);
+  return launch_status();
+}
+
+extern "C" {
+
+int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {
+  (void)HW;
+  if (B <= 0 || Cf <= 0 || G <= 0) return 0;
+  return (int64_t)B * pool_splits(B, Cf) * G * (int64_t)sizeof(double);
+}
+
+int eqa_group_pool_argmax(const float* feat, float* act, int32_t* gidx, void* workspace, int B, int Cf, int G, int HW,
+                          void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!feat || !act || !workspace || B < 0 || Cf <= 0 || G <= 0 || HW <= 0) return EQA_ERR_INVALID_ARG;
+  if (gidx && G > 64) return EQA_ERR_UNSUPPORTED;
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int splits = pool_splits(B, Cf);
+  const int cps = (Cf + splits - 1) / splits;
+  const int used = (Cf + cps - 1) / cps;  // splits that own at least one channel
+  double* partial = (double*)workspace;
+  const bool vec = (HW % 4 == 0) && (((uintptr_t)feat & 15) == 0);
+  const size_t lds = (size_t)4 * G * sizeof(double);
+  if (vec)
+    hipLaunchKernelGGL((group_pool_partial_kernel<true>), dim3(used, B), dim3(kThreads), lds, st, feat, partial, Cf, G, HW, cps, used);
+  else
+    hipLaunchKernelGGL((group_pool_partial_kernel<false>), dim3(used, B), dim3(kThreads), lds, st, feat, partial, Cf, G, HW, cps, used);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  const double inv_count = 1.0 / ((double)Cf * (double)HW);
+  hipLaunchKernelGGL(group_pool_finalize_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, st, partial, act, gidx, B, G, used, inv_count);
+  return launch_status();
+}
+
+int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream) {
+  if (B == 0 && G > 0 && G <= 64) return EQA_OK;
+  if (!act || !gidx || B < 0 || G <= 0) return EQA_ERR_INVALID_ARG;
+  if (G > 64) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(group_argmax_kernel, dim3((B + 3) / 4), dim3(kThreads), 0, (hipStream_t)stream, act, gidx, B, G);
+  return launch_status();
+}
+
+int eqa_window_sums(const float* x, const float* scale, const float* shift, int relu, double* out, int B, int C, int H,
+                    int W, int k, void* stream) {
+  if (!x || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0 || k > H || k > W) return EQA_ERR_INVALID_ARG;
+  if (k > kMaxWinK) return EQA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)((H * W + 3) & ~3) * sizeof(float) + (size_t)k * W * sizeof(double);
+  if (lds > 64 * 1024 || (long long)B * C > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;  // plane must fit one block's LDS
+  if (B == 0) return EQA_OK;
+  const bool vec = ((H * W) % 4 == 0) && (((uintptr_t)x & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((window_sums_kernel<true>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
+  else
+    hipLaunchKernelGGL((window_sums_kernel<false>), dim3((unsigned)(B * C)), dim3(kThreads), lds, st, x, scale, shift, relu, out, C, H, W, k);
+  return launch_status();
+}
+
+int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, int K, int E, double scale, double shift,
+                         void* stream) {
+  if (B < 0 || K <= 0 || E <= 0) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
+  if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(sums_gemv_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  return launch_status();
+}
+
+int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream) {
+  if (!x || !bias || n_pixels < 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (((uintptr_t)x | (uintptr_t)bias) & 15)) return EQA_ERR_UNSUPPORTED;
+  if (n_pixels == 0) return EQA_OK;
+  const size_t n_vec = (size_t)n_pixels * (C / 4);
+  const unsigned blocks = (unsigned)((n_vec + kThreads - 1) / kThreads < 8192 ? (n_vec + kThreads - 1) / kThreads : 8192);
+  hipLaunchKernelGGL(bias_relu_nhwc_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, bias, n_vec, C / 4);
+  return launch_status();
+}
+
+static int ws_nhwc_bands(int H, int k) {
+  const int interior = H - 2 * (k - 1);
+  int nb = (interior + 9) / 10;  // ~10 rows per band
+  if (nb < 1) nb = 1;
+  return nb;
+}
+
+int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k) {
+  if (B <= 0 || C <= 0 || H <= 0 || k <= 0) return 0;
+  const int nseg = 2 * (k - 1) + ws_nhwc_bands(H, k);
+  return (int64_t)B * nseg * C * (1 + 2 * (k - 1)) * (int64_t)sizeof(float);
+}
+
+int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
+                         int B, int C, int H, int W, int k, void* stream) {
+  if (!x || !out || !workspace || B < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
+  // needs disjoint top / bottom (left / right) border sets and at least one interior row
+  if (k > kMaxWinK || C % 4 != 0 || H < 2 * (k - 1) + 1 || W < 2 * (k - 1) + 1 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if ((((uintptr_t)x) & 15) || (scale && (((uintptr_t)scale) & 15)) || (shift && (((uintptr_t)shift) & 15))) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nbands = ws_nhwc_bands(H, k);
+  const int nseg = 2 * (k - 1) + nbands;
+  hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
+                     (float*)workspace, C, H, W, k, nbands);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, st,
+                     (const float*)workspace, out, B, C, k, nseg);
+  return launch_status();
+}
+
+}  // extern "C"

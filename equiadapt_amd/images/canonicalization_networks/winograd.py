@@ -65,7 +65,7 @@ def cook_toom(m: int, r: int = 5) -> Tuple[list, list, list]:
 
 
 def kernel_bt_signs(m: int) -> List[int]:
-    """Sign of the kernels' B^T rows relative to `cook_toom` (wino_bt in csrc/eqa_hip.hip)."""
+    """Sign of the kernels' B^T rows relative to `cook_toom` (wino_bt in csrc/winograd.hip)."""
     return [1, -1, -1, 1, 1, 1] if m == 2 else [1] * 8
 
 

@@ -59,7 +59,7 @@ class VNSmall(nn.Module):
             raise ValueError(f"Pooling type {self.pooling} not supported")
 
     def packed_parameters(self) -> torch.Tensor:
-        """The 1310 floats the fused kernel consumes (layout: csrc/eqa_hip.hip), eval-mode batch-norms folded to a
+        """The 1310 floats the fused kernel consumes (layout: csrc/pointcloud.hip), eval-mode batch-norms folded to a
         scale/shift of the vector norm.  Cached per parameter version."""
         tensors = list(self.parameters()) + [b for b in self.buffers()]
         key = tuple(t._version for t in tensors) + (str(tensors[0].device),)

@@ -215,7 +215,7 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
  *                               layer's bias / folded batch-norm / ReLU applied while loading
  *   [ strided-batched fp32 GEMM by the caller:  M[:,a] = V[:,a] (tiles x Cin, lda P*Cin) . U[a] (Cin x Cout), a < P ]
  *   eqa_winograd_f{m}k5_output  M:(nimg*TY*TX, P, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  m | OH, OW
- * Cook-Toom points {0, 1, -1, 2, -2, [1/2, -1/2,] inf}; matrices in csrc/eqa_hip.hip and
+ * Cook-Toom points {0, 1, -1, 2, -2, [1/2, -1/2,] inf}; matrices in csrc/winograd.hip and
  * images/canonicalization_networks/winograd.py (U = G g G^T in fp64).  EQA_ERR_UNSUPPORTED when m does not divide H-4, W-4.
  */
 int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
@@ -251,7 +251,7 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
  * Replaces equiadapt/pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn,
  * get_graph_feature_cross) and :128-150 (VNSmall.forward) with vector_neuron_layers.py:251-273, :303-324.
  * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; k must be 20, pooling 0 (= "mean").
- * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in eqa_hip.hip).
+ * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in csrc/pointcloud.hip).
  * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  Other k / "max" pooling / training: EQA_ERR_UNSUPPORTED
  * (the host keeps an op-by-op path for those).
  */
