@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -39,12 +39,19 @@ SIGNATURES = {
     "eqa_group_pool_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_group_pool_argmax": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_window_sums": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),
+    "eqa_bn_partial_blocks": (ctypes.c_int64, [ctypes.c_int64]),
+    "eqa_bn_stats_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_bn_relu_dropout_nhwc": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_float, ctypes.c_uint32, _vp]),
+    "eqa_bn_bwd_reduce_nhwc": (_int, [_vp] * 5 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_winograd_f2k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f2k5_output_adjoint": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f4k5_output_adjoint": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output_sums_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_winograd_f2k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_winograd_f4k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),

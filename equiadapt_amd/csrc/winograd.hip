@@ -57,6 +57,29 @@ __device__ __forceinline__ void wino_at(const float (&m)[8], float (&y)[4]) {
   y[3] = (d1 + m[7]) + 8.0f * d2 + 0.125f * d3;
 }
 
+// t = A d, A the transpose of A^T above (adjoint of the output transform: dM = A dY A^T, used for the filter gradient)
+__device__ __forceinline__ void wino_a(const float (&d)[2], float (&t)[6]) {
+  t[0] = d[0];
+  t[1] = d[0] + d[1];
+  t[2] = d[0] - d[1];
+  t[3] = d[0] + 2.0f * d[1];
+  t[4] = d[0] - 2.0f * d[1];
+  t[5] = d[1];
+}
+__device__ __forceinline__ void wino_a(const float (&d)[4], float (&t)[8]) {
+  const float e = d[0] + d[2], o = d[1] + d[3];
+  const float e2 = d[0] + 4.0f * d[2], o2 = 2.0f * d[1] + 8.0f * d[3];
+  const float e3 = d[0] + 0.25f * d[2], o3 = 0.5f * d[1] + 0.125f * d[3];
+  t[0] = d[0];
+  t[1] = e + o;
+  t[2] = e - o;
+  t[3] = e2 + o2;
+  t[4] = e2 - o2;
+  t[5] = e3 + o3;
+  t[6] = e3 - o3;
+  t[7] = d[3];
+}
+
 #ifdef EQA_WABL_NOLOAD
 #define WINO_LD(ptr, k) ((float)(threadIdx.x + (k)))
 #else
@@ -197,6 +220,40 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_output_kernel(const floa
     for (int qq = 0; qq < MT; ++qq) q[((size_t)rr * OW + qq) * C] = o[rr][qq];
 }
 
+// Adjoint of the output transform (training: filter gradient dU[a] = V[:, a]^T dM[:, a]):  dM = A dY A^T per tile,
+// dY:(nimg, OH, OW, C) -> dM:(tiles, N*N, C).  Tiles do not overlap on the output side: m*m loads, N*N stores per thread.
+template <int N>
+__global__ __launch_bounds__(kThreads) void winograd_k5_output_adjoint_kernel(const float* __restrict__ dY, float* __restrict__ dM,
+                                                                             int OH, int OW, int C, int TY, int TX) {
+  constexpr int MT = N - 4;
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t tile = blockIdx.x;
+  const int tx = (int)(tile % TX);
+  const size_t r = tile / TX;
+  const int ty = (int)(r % TY);
+  const size_t img = r / TY;
+  const float* p = dY + ((img * OH + MT * ty) * (size_t)OW + MT * tx) * C + c;
+  float w[N][MT];  // w = A d, column by column
+#pragma unroll
+  for (int q = 0; q < MT; ++q) {
+    float d[MT], t[N];
+#pragma unroll
+    for (int rr = 0; rr < MT; ++rr) d[rr] = p[((size_t)rr * OW + q) * C];
+    wino_a(d, t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) w[i][q] = t[i];
+  }
+  float* o = dM + tile * (size_t)(N * N) * C + c;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    float t[N];
+    wino_a(w[i], t);
+#pragma unroll
+    for (int j = 0; j < N; ++j) o[(size_t)(i * N + j) * C] = t[j];
+  }
+}
+
 // Output transform fused with the window-sum segments of the NEXT (last, linearised) layer: instead of writing the
 // (nimg, OH, OW, C) activation and re-reading it, every output row becomes one "segment" in the format of
 // window_sums_nhwc_finalize_kernel -- per channel [row total, first NB columns, last NB columns] -- with the segment
@@ -300,6 +357,20 @@ int launch_wino_output(const float* M, const float* bias, int relu, float* y, in
 }
 
 template <int N>
+int launch_wino_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream) {
+  constexpr int MT = N - 4;
+  if (!dY || !dM || nimg < 0 || OH < MT || OW < MT || C <= 0) return EQA_ERR_INVALID_ARG;
+  if ((OH % MT) || (OW % MT)) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  const int TY = OH / MT, TX = OW / MT;
+  const size_t tiles = (size_t)nimg * TY * TX;
+  if (tiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL((winograd_k5_output_adjoint_kernel<N>), dim3((unsigned)tiles, (C + kThreads - 1) / kThreads),
+                     dim3(kThreads), 0, (hipStream_t)stream, dY, dM, OH, OW, C, TY, TX);
+  return launch_status();
+}
+
+template <int N>
 int launch_wino_output_sums(const float* M, const float* bias, int relu, double* S, void* workspace, int nimg, int OH,
                             int OW, int C, int k_next, void* stream) {
   constexpr int MT = N - 4;
@@ -348,6 +419,13 @@ int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float*
 int eqa_winograd_f4k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                              void* stream) {
   return launch_wino_output<8>(M, bias, relu, y, nimg, OH, OW, C, stream);
+}
+
+int eqa_winograd_f2k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream) {
+  return launch_wino_output_adjoint<6>(dY, dM, nimg, OH, OW, C, stream);
+}
+int eqa_winograd_f4k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream) {
+  return launch_wino_output_adjoint<8>(dY, dM, nimg, OH, OW, C, stream);
 }
 
 int64_t eqa_winograd_f2k5_output_sums_workspace_bytes(int nimg, int OH, int C, int k_next) {

@@ -180,11 +180,26 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
             # boxes and masks follow the image (reference :217-236).  NOTE (reference behaviour kept): when the
             # group has reflections every target is flipped, whatever its own reflection indicator says.
             image_width = x.shape[-1]
-            if reflections:
+            box_list = [t_["boxes"] for t_ in targets]
+            counts = [int(b.shape[0]) for b in box_list]
+            if sum(counts) > 0 and all(b.is_cuda and b.dim() == 2 and b.dtype == box_list[0].dtype for b in box_list):
+                # every box of the batch in one pass (the reference loops over samples, a dozen launches each): the same
+                # elementwise arithmetic with the sample's angle repeated per box, so the numbers are identical
+                all_boxes = torch.cat(box_list, dim=0)
+                if reflections:
+                    all_boxes = flip_boxes(all_boxes, image_width)
+                    # the reference flips the caller's tensors in place before replacing them: keep that side effect
+                    torch._foreach_copy_(box_list, list(all_boxes.split(counts)))
+                per_box = torch.repeat_interleave(element["rotation"], torch.tensor(counts, device=x.device),
+                                                  output_size=sum(counts))
+                for t_, nb in zip(targets, rotate_boxes(all_boxes, per_box, image_width).split(counts)):
+                    t_["boxes"] = nb
+            else:
+                if reflections:
+                    for t in range(len(targets)):
+                        targets[t]["boxes"] = flip_boxes(targets[t]["boxes"], image_width)
                 for t in range(len(targets)):
-                    targets[t]["boxes"] = flip_boxes(targets[t]["boxes"], image_width)
-            for t in range(len(targets)):
-                targets[t]["boxes"] = rotate_boxes(targets[t]["boxes"], element["rotation"][t], image_width)
+                    targets[t]["boxes"] = rotate_boxes(targets[t]["boxes"], element["rotation"][t], image_width)
             masks = [t_["masks"] for t_ in targets]
             if all(m.is_cuda and m.dtype == torch.uint8 and m.dim() == 3 for m in masks):
                 # every mask of the batch in one nearest-neighbour kernel launch, element index read on the device

@@ -27,6 +27,7 @@ from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_lay
 )
 from equiadapt_amd.images.canonicalization_networks import winograd
 from equiadapt_amd.images.canonicalization_networks.pooling import (
+    WindowSumsFunction,
     conv_then_group_pool,
     group_pool,
     window_sums_to_activations,
@@ -35,6 +36,87 @@ from equiadapt_amd.images.canonicalization_networks.pooling import (
 
 class _InnerBatchNorm(nn.BatchNorm3d):
     """Per-field batch norm over (batch, group, space) of a (B, fields, G, H, W) map."""
+
+
+class InnerBnReluDropout(torch.autograd.Function):
+    """dropout(relu(InnerBatchNorm(h))) on a channels-last (B, fields*E, H, W) map, forward and backward on the fused
+    kernels of csrc/batchnorm.hip (eqa_bn_*).  Statistics per field over (batch, group, space) in fp64; running statistics
+    updated like nn.BatchNorm3d (momentum, unbiased variance).  The preceding convolution's bias only shifts the mean (it
+    cancels in the normalised output), so it enters the running mean and nowhere else.  The dropout mask is a hash of a
+    seed drawn from torch's CPU generator; the backward recovers "kept and positive" from y > 0."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        Bn, C, H, W = h.shape
+        Fd = C // E
+        npix = Bn * H * W
+        st = ops._stream()
+        with torch.cuda.device(h.device):
+            if bn.training:
+                nblk = lib.eqa_bn_partial_blocks(npix)
+                part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
+                _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
+                sums = part.sum(0).view(Fd, E, 2).sum(1)                         # (fields, 2) fp64
+                n = npix * E
+                mean = sums[:, 0] / n
+                var = (sums[:, 1] / n - mean * mean).clamp_min(0.0)
+                m = bn.momentum
+                full_mean = mean if conv_bias is None else mean + conv_bias.detach().double()
+                bn.running_mean.mul_(1 - m).add_(m * full_mean.to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1, 1))).to(bn.running_var.dtype))
+                bn.num_batches_tracked += 1
+                mean, var = mean.float(), var.float()
+            else:
+                mean = bn.running_mean if conv_bias is None else bn.running_mean - conv_bias.detach()
+                var = bn.running_var
+            rstd = torch.rsqrt(var + bn.eps)
+            scale_f = weight.detach() * rstd
+            scale = scale_f.repeat_interleave(E).contiguous()
+            shift = (bias.detach() - mean * scale_f).repeat_interleave(E).contiguous()
+            p_eff = float(p) if drop_training else 0.0
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_eff > 0 else 0
+            y = torch.empty_like(h)
+            _lib.check(lib.eqa_bn_relu_dropout_nhwc(h.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), npix, C, p_eff,
+                                                    seed, st), "eqa_bn_relu_dropout_nhwc")
+        ctx.save_for_backward(h, y, weight, mean.repeat_interleave(E).contiguous(), rstd.repeat_interleave(E).contiguous())
+        ctx.E, ctx.p, ctx.batch_stats = E, p_eff, bn.training
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        h, y, weight, mean_c, rstd_c = ctx.saved_tensors
+        E = ctx.E
+        Bn, C, H, W = h.shape
+        Fd = C // E
+        npix = Bn * H * W
+        gy = gy.contiguous(memory_format=torch.channels_last)
+        st = ops._stream()
+        with torch.cuda.device(h.device):
+            nblk = lib.eqa_bn_partial_blocks(npix)
+            part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
+            _lib.check(lib.eqa_bn_bwd_reduce_nhwc(gy.data_ptr(), y.data_ptr(), h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(), ctx.p,
+                                                  part.data_ptr(), npix, C, st), "eqa_bn_bwd_reduce_nhwc")
+            sums = part.sum(0).view(Fd, E, 2).sum(1)                             # per field: sum g, sum g*xhat
+            dbias, dweight = sums[:, 0].float(), sums[:, 1].float()
+            n = npix * E
+            a = (weight * rstd_c.view(Fd, E)[:, 0]).repeat_interleave(E).contiguous()
+            if ctx.batch_stats:
+                b = (sums[:, 0] / n).float().repeat_interleave(E).contiguous()
+                d = (sums[:, 1] / n).float().repeat_interleave(E).contiguous()
+            else:                                                                # running statistics are constants
+                b = torch.zeros(C, device=h.device)
+                d = b
+            dh = torch.empty_like(h)
+            _lib.check(lib.eqa_bn_bwd_apply_nhwc(gy.data_ptr(), y.data_ptr(), h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(),
+                                                 a.data_ptr(), b.data_ptr(), d.data_ptr(), ctx.p, dh.data_ptr(), npix, C, st),
+                       "eqa_bn_bwd_apply_nhwc")
+        return dh, dweight, dbias, None, None, None, None, None
 
 
 class ESCNNEquivariantNetwork(nn.Module):
@@ -172,7 +254,81 @@ class ESCNNEquivariantNetwork(nn.Module):
                 h = torch.relu_(h + bias[None, :, None, None])
         raise AssertionError("unreachable: the network always has at least two convolutions")
 
+    # -- training fast path ------------------------------------------------------------------------------------
+    @staticmethod
+    def _inner_bn(h: torch.Tensor, bn: nn.BatchNorm3d, E: int, conv_bias) -> torch.Tensor:
+        """InnerBatchNorm on a channels-last (B, fields*E, H, W) map: statistics per field over (batch, group, space), fp64
+        accumulation, running statistics updated like nn.BatchNorm3d (momentum, unbiased variance).  The convolution's own
+        bias only shifts the mean (it cancels in the normalised output), so it enters the running mean and nowhere else."""
+        Bn, C, H, W = h.shape
+        Fd = C // E
+        if bn.training:
+            n = Bn * E * H * W
+            s1 = h.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1)
+            s2 = (h * h).sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1)
+            mean = s1 / n
+            var = (s2 / n - mean * mean).clamp_min(0.0)
+            with torch.no_grad():
+                m = bn.momentum
+                full_mean = mean if conv_bias is None else mean + conv_bias.double()
+                bn.running_mean.mul_(1 - m).add_(m * full_mean.to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1, 1))).to(bn.running_var.dtype))
+                bn.num_batches_tracked += 1
+            mean, var = mean.float(), var.float()
+        else:
+            mean = bn.running_mean if conv_bias is None else bn.running_mean - conv_bias
+            var = bn.running_var
+        scale = bn.weight * torch.rsqrt(var + bn.eps)
+        shift = bn.bias - mean * scale
+        return h * scale.repeat_interleave(E)[None, :, None, None] + shift.repeat_interleave(E)[None, :, None, None]
+
+    def _forward_training(self, x: torch.Tensor) -> torch.Tensor:
+        """Same layers as ``self.eqv_network`` + group pooling, with autograd, channels-last: 5x5 regular->regular
+        convolutions through Winograd (``winograd.Conv5x5Function``: forward, d/dx and d/dfilters on the Winograd kernels),
+        the last convolution + group mean as window sums + GEMV (``WindowSumsFunction``), batch-norm / ReLU / dropout as
+        element-wise passes.  Measured on the headline net, B = 256: 353 ms per step through MIOpen -> see DESIGN.md."""
+        mods = list(self.eqv_network)
+        convs = [m for m in mods if hasattr(m, "expanded_weights")]
+        norms = [m for m in mods if isinstance(m, _InnerBatchNorm)]
+        drops = [m for m in mods if isinstance(m, nn.Dropout)]
+        E = self.num_group_elements
+        h = x.contiguous(memory_format=torch.channels_last)
+        for conv, bn, drop in zip(convs[:-1], norms, drops):
+            bank = conv.expanded_weights()
+            if not conv.lifting and conv.kernel_size == 5 and winograd.applicable(h, bank.shape[1], bank.shape[0]):
+                h = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h))
+            else:
+                h = F.conv2d(h, bank.contiguous(memory_format=torch.channels_last))
+            if os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and h.is_contiguous(memory_format=torch.channels_last):
+                h = InnerBnReluDropout.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training)
+            else:  # op-by-op form of the same block (kept as the reference for the fused kernels' test)
+                h = self._inner_bn(h, bn, E, conv.bias)
+                h = F.dropout(torch.relu(h), drop.p, drop.training)
+        tail = convs[-1]
+        k, O = tail.kernel_size, tail.out_channels
+        H, W = h.shape[-2:]
+        S = WindowSumsFunction.apply(h, k)                                          # (B, C, k, k) fp64
+        weff = tail.expanded_weights().view(O, E, -1).double().sum(0)               # (E, C*k*k), differentiable
+        act = S.flatten(1) @ weff.t() / float(O * (H - k + 1) * (W - k + 1))
+        if tail.bias is not None:
+            act = act + tail.bias.double().mean()
+        return act.float()
+
+    def _training_fast_path_ok(self, x: torch.Tensor) -> bool:
+        if self._dense or not x.is_cuda or x.dtype != torch.float32 or os.environ.get("EQA_TRAIN_FAST", "1") == "0":
+            return False
+        if (self.out_channels * self.num_group_elements) % 4 != 0:
+            return False
+        convs = [m for m in self.eqv_network if hasattr(m, "expanded_weights")]
+        if len(convs) < 2 or any(c.stride != 1 or c.padding != 0 for c in convs) or not convs[-1].supports_linear_tail():
+            return False
+        hw = x.shape[-2] - (self.kernel_size - 1) * (len(convs) - 1)
+        k = convs[-1].kernel_size
+        return hw >= 2 * k - 1 and x.shape[-1] - (self.kernel_size - 1) * (len(convs) - 1) >= 2 * k - 1 and hw * hw <= 12288
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if (self.training or torch.is_grad_enabled()) and self._training_fast_path_ok(x):
+            return self._forward_training(x)
         if (not self._dense and not self.training and not torch.is_grad_enabled() and x.is_cuda
                 and self.eqv_network[-1].supports_linear_tail()):
             hw = (x.shape[-2] - (self.kernel_size - 1) * (len([m for m in self.eqv_network if hasattr(m, "expanded_weights")]) - 1))

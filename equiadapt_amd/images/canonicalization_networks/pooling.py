@@ -53,3 +53,42 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
     if layer.bias is not None:
         act = act + layer.bias.detach().double().mean()
     return act.float()
+
+
+class WindowSumsFunction(torch.autograd.Function):
+    """S[b,c,u,v] = sum over the (H-k+1, W-k+1) window at (u, v) of x[b,c] (fp64), with its backward: a pixel (y, x) receives
+    the sum of dS over the windows that contain it.  Rows fall into 2(k-1)+1 classes (the k-1 top rows, the interior, the k-1
+    bottom rows), columns likewise, so the gradient is a (2k-1) x (2k-1) table per (b, c) expanded by two index lookups.
+    Training counterpart of `conv_then_group_pool` (the last convolution + group mean are linear in x)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        from equiadapt_amd import ops
+
+        ctx.k, ctx.shape = k, x.shape
+        ctx.channels_last = x.is_contiguous(memory_format=torch.channels_last)
+        return ops.window_sums(x, k)
+
+    @staticmethod
+    def backward(ctx, dS):
+        k = ctx.k
+        B, C, H, W = ctx.shape
+        nb = k - 1
+        dev = dS.device
+
+        def classes(n):
+            rep = torch.cat([torch.arange(nb), torch.tensor([nb]), torch.arange(n - nb, n)]).to(dev)       # one row per class
+            u = torch.arange(k, device=dev)
+            mask = ((u[None, :] <= rep[:, None]) & (rep[:, None] <= u[None, :] + (n - k))).to(dS.dtype)     # (2nb+1, k)
+            i = torch.arange(n, device=dev)
+            idx = torch.where(i < nb, i, torch.where(i >= n - nb, i - (n - nb) + nb + 1, torch.full_like(i, nb)))
+            return mask, idx
+
+        rm, ty = classes(H)
+        cm, tx = classes(W)
+        table = torch.einsum("tu,bcuv,sv->btsc", rm, dS, cm).float()            # (B, 2nb+1, 2nb+1, C), channels last
+        g = table[:, ty][:, :, tx]                                               # (B, H, W, C)
+        g = g.permute(0, 3, 1, 2)                                                # NCHW view of channels-last memory
+        if not ctx.channels_last:
+            g = g.contiguous()
+        return g, None

@@ -109,6 +109,62 @@ def sums_applicable(x: torch.Tensor, k_next: int, m: int = 2) -> bool:
     return nb in (2, 4) and nb % m == 0 and OH >= 2 * nb + m and OW >= 2 * nb + m
 
 
+def filter_grad(x: torch.Tensor, dY: torch.Tensor, m: int) -> torch.Tensor:
+    """dL/dU (P, Cin, Cout) of y = conv5x5(x, U):  dU[a] = V[:, a]^T dM[:, a]  with V = B^T x B (input transform) and
+    dM = A dY A^T (eqa_winograd_f{m}k5_output_adjoint); x, dY channels-last (B,Cin,H,W) / (B,Cout,H-4,W-4)."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    Cout = dY.shape[1]
+    OH, OW = H - 4, W - 4
+    n = m + 4
+    P = n * n
+    TY, TX = OH // m, OW // m
+    f_in, f_adj = getattr(lib, f"eqa_winograd_f{m}k5_input"), getattr(lib, f"eqa_winograd_f{m}k5_output_adjoint")
+    chunk = min(CHUNK_IMAGES * (m * m // 4), B)
+    V = torch.empty((chunk * TY * TX, P, Cin), dtype=torch.float32, device=x.device)
+    dM = torch.empty((chunk * TY * TX, P, Cout), dtype=torch.float32, device=x.device)
+    dU = torch.zeros((P, Cin, Cout), dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    with torch.cuda.device(x.device):
+        for b0 in range(0, B, chunk):
+            nimg = min(chunk, B - b0)
+            t = nimg * TY * TX
+            _lib.check(f_in(x.data_ptr() + b0 * H * W * Cin * 4, V.data_ptr(), None, 0, nimg, H, W, Cin, stream), "winograd input")
+            _lib.check(f_adj(dY.data_ptr() + b0 * OH * OW * Cout * 4, dM.data_ptr(), nimg, OH, OW, Cout, stream), "winograd output adjoint")
+            # (P, Cin, t) x (P, t, Cout): both operands are strided views of the tile-major buffers, no copies
+            dU.baddbmm_(V[:t].permute(1, 2, 0), dM[:t].permute(1, 0, 2))
+    return dU
+
+
+class Conv5x5Function(torch.autograd.Function):
+    """y = conv2d(x, bank) (5x5, stride 1, no padding, channels-last) through Winograd, with both gradients:
+    dx = conv5x5(zero-pad(dy, 4), flipped + transposed bank)  -- the same kernels --, and
+    dbank = G^T dU G with dU from `filter_grad`.  Training counterpart of the inference path in escnn_networks.py."""
+
+    @staticmethod
+    def forward(ctx, x, bank, m):
+        ctx.save_for_backward(x, bank)
+        ctx.m = m
+        return conv5x5(x, transform_filters(bank.detach(), m), None, False)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bank = ctx.saved_tensors
+        m = ctx.m
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dbank = None
+        if ctx.needs_input_grad[0]:
+            bank_t = bank.detach().flip(-1, -2).transpose(0, 1).contiguous()       # (Cin, Cout, 5, 5)
+            dyp = torch.nn.functional.pad(dy, (4, 4, 4, 4)).contiguous(memory_format=torch.channels_last)
+            dx = conv5x5(dyp, transform_filters(bank_t, m), None, False)
+        if ctx.needs_input_grad[1]:
+            n = m + 4
+            G = g_matrix(m).to(dy.device)
+            dU = filter_grad(x, dy, m).double().view(n, n, bank.shape[1], bank.shape[0])
+            dbank = torch.einsum("ak,bl,abio->oikl", G, G, dU).to(bank.dtype)
+        return dx, dbank, None
+
+
 def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
             in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
     """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as

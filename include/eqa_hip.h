@@ -188,6 +188,27 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
                          int B, int C, int H, int W, int k, void* stream);
 
 /*
+ * Training-mode hidden block of the canonicalization network, channels-last: InnerBatchNorm -> ReLU -> PointwiseDropout
+ * (escnn_networks.py:67-85), forward and backward.  x, y, gy, dx: (n_pixels, C) fp32, C % 4 == 0, 16-byte aligned.
+ *   eqa_bn_stats_nhwc         partial[(blk*C + c)*2 + {0,1}] = sum, sum of squares of channel c over block blk's pixels;
+ *                             blk < eqa_bn_partial_blocks(n_pixels); the caller adds the blocks (fp64, deterministic) and folds
+ *                             the G channels of a field into the per-field mean / variance;
+ *   eqa_bn_relu_dropout_nhwc  y = dropout(relu(x*scale[c] + shift[c])), kept elements scaled by 1/(1-drop_p); the mask is a
+ *                             counter-based hash of (seed, element index); drop_p = 0 disables it;
+ *   eqa_bn_bwd_reduce_nhwc    with g = gy * (y > 0 ? 1/(1-drop_p) : 0) and xhat = (x - mean[c]) * rstd[c]:
+ *                             partial[...] = sum g, sum g*xhat (same layout as above);
+ *   eqa_bn_bwd_apply_nhwc     dx = a[c] * (g - b[c] - xhat * d[c])   (a = gamma*rstd, b = sum g / n, d = sum g xhat / n).
+ */
+int64_t eqa_bn_partial_blocks(int64_t n_pixels);
+int eqa_bn_stats_nhwc(const float* x, double* partial, int64_t n_pixels, int C, void* stream);
+int eqa_bn_relu_dropout_nhwc(const float* x, const float* scale, const float* shift, float* y, int64_t n_pixels, int C,
+                             float drop_p, uint32_t seed, void* stream);
+int eqa_bn_bwd_reduce_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, float drop_p,
+                           double* partial, int64_t n_pixels, int C, void* stream);
+int eqa_bn_bwd_apply_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, const float* a,
+                          const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, void* stream);
+
+/*
  * The GEMV after the window sums (last convolution + mean over channels and positions, escnn_networks.py:115,
  * custom_equivariant_networks.py:91, collapsed to a linear map):
  *   act[b][e] = (float)(scale * sum_j S[b][j] * Wm[e][j] + shift);  S:(B,K) fp64, Wm:(E,K) fp64, act:(B,E) fp32, E <= 16.
@@ -226,6 +247,12 @@ int eqa_winograd_f4k5_input(const float* x, float* V, const float* in_bias, int 
                             void* stream);
 int eqa_winograd_f4k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                              void* stream);
+/* Training (autograd through the Winograd convolution; the reference gets it from autograd through R2Conv's conv2d):
+ * adjoint of the output transform, dM = A dY A^T per tile, dY:(nimg,OH,OW,C) -> dM:(nimg*TY*TX, P, C).  The filter gradient
+ * is then dU[a] = V[:,a]^T dM[:,a] (strided-batched GEMM by the caller, V from eqa_winograd_f{m}k5_input) and the input
+ * gradient a forward Winograd convolution of the zero-padded dY with the flipped, transposed filters. */
+int eqa_winograd_f2k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream);
+int eqa_winograd_f4k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream);
 /* Output transform fused with eqa_window_sums_nhwc of the NEXT layer (kernel size k_next; k_next - 1 a multiple of m:
  * {3, 5} for f2k5, {5} for f4k5): the activation is never written; S:(nimg, C, k_next, k_next) fp64 window sums of
  * [relu](A^T M A + bias).  workspace: eqa_winograd_f2k5_output_sums_workspace_bytes(nimg, OH, C, k_next) bytes (both m). */

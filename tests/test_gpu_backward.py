@@ -184,3 +184,113 @@ def test_training_steps_on_device(dev):
     with torch.enable_grad():
         a_slow = can.canonicalization_network(can.transformations_before_canonicalization_network_forward(x)).detach()
     assert torch.allclose(a_fast, a_slow, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [32, 30])
+def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
+    """ESCNNEquivariantNetwork in train(): the Winograd / window-sum autograd path vs the plain module sequence
+    (F.conv2d + BatchNorm3d + group_pool through autograd) with the same weights: activations, every parameter gradient, the
+    input gradient and the batch-norm running statistics.  size 32 exercises F(4x4,5x5), size 30 F(2x2,5x5)."""
+    import copy
+
+    import equiadapt_amd as ea
+
+    torch.manual_seed(61)
+    net = ea.ESCNNEquivariantNetwork((3, size, size), out_channels=8, kernel_size=5, group_type="rotation", num_rotations=8,
+                                     num_layers=3).to(dev)
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0                                    # same function on both sides
+        if hasattr(m, "bias") and isinstance(getattr(m, "bias"), torch.nn.Parameter):
+            torch.nn.init.normal_(m.bias, std=0.1)
+    ref = copy.deepcopy(net)
+    net.train()
+    ref.train()
+    x = torch.randn(6, 3, size, size, device=dev)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    w = torch.randn(6, 8, device=dev)
+
+    assert net._training_fast_path_ok(x1)
+    a1 = net(x1)
+    monkeypatch.setenv("EQA_TRAIN_FAST", "0")
+    a2 = ref(x2)
+    monkeypatch.delenv("EQA_TRAIN_FAST")
+    assert a1.shape == a2.shape == (6, 8)
+    scale = a2.abs().max().item()
+    assert (a1 - a2).abs().max().item() <= 2e-5 * max(scale, 1.0), (a1 - a2).abs().max().item()
+    (a1 * w).sum().backward()
+    (a2 * w).sum().backward()
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        assert n1 == n2
+        if p1.grad is None:
+            # a convolution bias in front of a batch-norm cancels in the normalised output: exactly zero gradient (the
+            # module path leaves rounding noise there, the fast path does not even touch the parameter)
+            assert n1.endswith("bias") and (p2.grad is None or p2.grad.abs().max().item() <= 1e-5), n1
+            continue
+        g = p2.grad.abs().max().item()
+        assert p1.grad is not None and (p1.grad - p2.grad).abs().max().item() <= 3e-3 * g, (n1, (p1.grad - p2.grad).abs().max().item(), g)
+    gx = x2.grad.abs().max().item()
+    assert (x1.grad - x2.grad).abs().max().item() <= 3e-3 * gx
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        if "running" in n1 or "num_batches" in n1:
+            assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-5), n1
+    # eval mode with autograd enabled: running statistics, same answer as the module path
+    net.eval()
+    ref.eval()
+    b1 = net(x)
+    monkeypatch.setenv("EQA_TRAIN_FAST", "0")
+    b2 = ref(x)
+    assert (b1 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+def test_fused_bn_relu_dropout_block(dev):
+    """InnerBnReluDropout (eqa_bn_*): against the op-by-op block without dropout (values, d/dh, d/dgamma, d/dbeta), and the
+    dropout mask itself: keep rate, 1/(1-p) scaling, reproducible from torch's seed, same mask in the backward."""
+    from equiadapt_amd.images.canonicalization_networks.escnn_networks import ESCNNEquivariantNetwork, InnerBnReluDropout, _InnerBatchNorm
+
+    torch.manual_seed(71)
+    E, Fd, B, H, W = 8, 6, 5, 9, 11
+    h = (torch.randn(B, Fd * E, H, W, device=dev) * 2 + 0.5).contiguous(memory_format=torch.channels_last)
+    for training in (True, False):
+        bn1, bn2 = _InnerBatchNorm(Fd, momentum=0.9).to(dev), _InnerBatchNorm(Fd, momentum=0.9).to(dev)
+        for bn in (bn1, bn2):
+            with torch.no_grad():
+                bn.weight.copy_(torch.linspace(0.5, 1.5, Fd)); bn.bias.copy_(torch.linspace(-0.3, 0.3, Fd))
+                bn.running_mean.copy_(torch.linspace(-0.2, 0.4, Fd)); bn.running_var.copy_(torch.linspace(0.8, 3.0, Fd))
+            bn.train(training)
+        cb = torch.linspace(-1, 1, Fd, device=dev)
+        h1, h2 = h.clone().requires_grad_(True), h.clone().requires_grad_(True)
+        y1 = InnerBnReluDropout.apply(h1, bn1.weight, bn1.bias, bn1, E, cb, 0.5, False)
+        y2 = torch.relu(ESCNNEquivariantNetwork._inner_bn(h2, bn2, E, cb))
+        assert torch.allclose(y1, y2, atol=2e-5)
+        w = torch.randn_like(h)
+        (y1 * w).sum().backward()
+        (y2 * w).sum().backward()
+        assert torch.allclose(h1.grad, h2.grad, atol=2e-4 * h2.grad.abs().max().item())
+        assert torch.allclose(bn1.weight.grad, bn2.weight.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(bn1.bias.grad, bn2.bias.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(bn1.running_mean, bn2.running_mean, atol=1e-5) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)
+    # dropout
+    bn = _InnerBatchNorm(Fd).to(dev).train()
+    big = torch.randn(16, Fd * E, 32, 32, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    torch.manual_seed(5)
+    ya = InnerBnReluDropout.apply(big, bn.weight, bn.bias, bn, E, None, 0.5, True)
+    torch.manual_seed(5)
+    yb = InnerBnReluDropout.apply(big, bn.weight, bn.bias, bn, E, None, 0.5, True)
+    yc = InnerBnReluDropout.apply(big, bn.weight, bn.bias, bn, E, None, 0.5, True)
+    y0 = InnerBnReluDropout.apply(big, bn.weight, bn.bias, bn, E, None, 0.0, True)
+    assert torch.equal(ya, yb) and not torch.equal(ya, yc)
+    pos = y0 > 0
+    kept = (ya > 0) & pos
+    rate = kept.sum().item() / pos.sum().item()
+    assert abs(rate - 0.5) < 5e-3, rate
+    assert torch.allclose(ya[kept], 2.0 * y0[kept], rtol=1e-6)
+    assert (ya[~pos] == 0).all()
+    # per-channel keep rate is uniform too (the hash must not correlate with the channel index)
+    per_c = kept.sum(dim=(0, 2, 3)).float() / pos.sum(dim=(0, 2, 3)).float()
+    assert (per_c - 0.5).abs().max().item() < 0.03
+    g, = torch.autograd.grad(ya.sum(), big)
+    g0, = torch.autograd.grad((y0 * kept * 2.0).sum(), big)      # same function with the mask written out
+    assert torch.allclose(g, g0, atol=1e-4 * g0.abs().max().item())

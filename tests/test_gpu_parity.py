@@ -457,6 +457,22 @@ def test_canonicalize_with_targets(dev):
         assert torch.equal(out_t[t]["masks"].cpu(), io.rotate_masks(ref_t[t]["masks"], -rot[t].item()))
         assert torch.allclose(out_t[t]["boxes"].cpu(), io.rotate_boxes(ref_t[t]["boxes"], rot[t], 64), atol=1e-4)
     _close(y, io.canonicalize_images(x, rot, None, (3, 64, 64)))
+    # reflections, a different number of boxes per image (one image has none): all boxes go through one batched pass
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 4, 5, "roto-reflection", 4, 1, device="cpu")
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 64, 64)).to(dev).eval()
+    nbox = [3, 0, 1, 5]
+    x = torch.randn(4, 3, 64, 64)
+    boxes = [torch.rand(n, 4) * 30 + torch.tensor([0.0, 0.0, 30.0, 30.0]) for n in nbox]
+    targets = [{"boxes": b.clone().to(dev), "masks": (torch.rand(1, 64, 64) > 0.5).to(torch.uint8).to(dev)} for b in boxes]
+    held = [t["boxes"] for t in targets]  # the caller's tensors: the reference flips them in place
+    with torch.no_grad():
+        y, out_t = can(x.to(dev), targets)
+    rot = can.canonicalization_info_dict["group_element"]["rotation"].cpu()
+    for t in range(4):
+        flipped = io.flip_boxes(boxes[t].clone(), 64)
+        assert out_t[t]["boxes"].shape == (nbox[t], 4)
+        assert torch.allclose(out_t[t]["boxes"].cpu(), io.rotate_boxes(flipped, rot[t], 64).reshape(nbox[t], 4), atol=1e-4)
+        assert torch.allclose(held[t].cpu(), flipped)
 
 
 @pytest.mark.parametrize("group_type,N", [("roto-reflection", 4), ("rotation", 8)])

@@ -1,0 +1,138 @@
+"""Throughput of the hot path on every BASELINE.json config shape (1 GPU), with the CPU oracle timed beside it on a bounded
+sample:  python tools/bench_configs.py [--out profiles/r01/configs.json]
+
+  cfg1  CIFAR-10 shape 32x32x3, C4, GroupEquivariantImageCanonicalization + CustomEquivariantNetwork: canonicalize + invert
+  cfg2  224x224x3, C8, ESCNN-shaped network (the headline: bench.py is authoritative, repeated here for the table)
+  cfg4  ModelNet40 shape, 1024 points, SO(3): VNSmall -> Gram-Schmidt -> rotate (the reference defines no invert for clouds)
+  cfg5  COCO shape 1024x1024x3, D4, OptimizedGroupEquivariantImageCanonicalization + ConvNetwork(k7,16ch,3 layers,128):
+        canonicalize with mask targets + invert_canonicalization of a mask-shaped scalar output
+(cfg3 = cfg2 on 8 GPUs: bench.py --gpus 8 under torch.distributed.run.)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import equiadapt_amd as ea  # noqa: E402
+from oracle import image_ops as io  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+from oracle import pointcloud_ops as po  # noqa: E402
+
+
+def gpu_time(fn, reps=20, warm=3):
+    with torch.no_grad():
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def cpu_time(fn, reps=2):
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    res = {}
+
+    # ---- cfg1: CIFAR-10 shape, C4
+    torch.manual_seed(2)
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 8, 5, "rotation", 4, 2, device="cpu")
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=32)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 32, 32))
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    can = can.to(dev).eval()
+    for B in (128, 8192):
+        x = torch.randn(B, 3, 32, 32, device=dev)
+        f = torch.randn(B, 3, 32, 32, device=dev)
+        dt = gpu_time(lambda: (can(x), can.invert_canonicalization(f, induced_rep_type="scalar")))
+        res[f"cfg1_cifar32_c4_B{B}"] = {"images_s": B / dt, "ms": dt * 1e3}
+    xs, fs = torch.randn(128, 3, 32, 32), torch.randn(128, 3, 32, 32)
+
+    def cpu1():
+        acts = onets.custom_equivariant_network(io.pre_canonicalization_transform(xs, (3, 32, 32), 1.0, 32), sd, "rotation", 4, 2)
+        el = io.group_element_from_activations(acts, 4, "rotation", 1.0, training=False)
+        return io.canonicalize_images(xs, el["rotation"], None, (3, 32, 32)), io.invert_action(fs, el["rotation"], None, 4, 4, "scalar")
+    dt = cpu_time(cpu1, 5)
+    res["cfg1_cifar32_c4_cpu_oracle"] = {"images_s": 128 / dt, "ms": dt * 1e3, "sample": "B=128, 16 threads"}
+
+    # ---- cfg2: headline (same construction as bench.py)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    can2 = bench.build_canonicalizer(dev)
+    x = torch.randn(256, 3, 224, 224, device=dev)
+    f = torch.randn(256, 3, 224, 224, device=dev)
+    dt = gpu_time(lambda: (can2(x), can2.invert_canonicalization(f, induced_rep_type="scalar")), reps=10)
+    res["cfg2_224_c8_B256"] = {"images_s": 256 / dt, "ms": dt * 1e3}
+    del can2, x, f
+
+    # ---- cfg4: ModelNet40 shape
+    hp4 = types.SimpleNamespace(n_knn=20, pooling="mean")
+    torch.manual_seed(2)
+    vn = ea.VNSmall(hp4)
+    sd4 = {k: v.clone() for k, v in vn.state_dict().items()}
+    can4 = ea.EquivariantPointcloudCanonicalization(vn, hp4).to(dev).eval()
+    for B in (64, 2048):
+        pc = torch.randn(B, 3, 1024, device=dev)
+        dt = gpu_time(lambda: can4(pc))
+        res[f"cfg4_modelnet1024_so3_B{B}"] = {"clouds_s": B / dt, "ms": dt * 1e3}
+    pcs = torch.randn(4, 3, 1024)
+
+    def cpu4():
+        R = po.gram_schmidt(po.vnsmall_forward(pcs, sd4))
+        return po.canonicalize_pointcloud(pcs, R)
+    dt = cpu_time(cpu4, 2)
+    res["cfg4_modelnet1024_so3_cpu_oracle"] = {"clouds_s": 4 / dt, "ms": dt * 1e3, "sample": "B=4, 16 threads"}
+
+    # ---- cfg5: COCO shape, D4, optimised canonicalizer, masks
+    torch.manual_seed(2)
+    net5 = ea.ConvNetwork((3, 128, 128), out_channels=16, kernel_size=7, num_layers=3, out_vector_size=128)
+    hp5 = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=128, group_type="roto-reflection", num_rotations=4,
+                                artifact_err_wt=0.0, learn_ref_vec=False)
+    can5 = ea.OptimizedGroupEquivariantImageCanonicalization(net5, hp5, (3, 1024, 1024)).to(dev).eval()
+    for B in (4, 32):
+        x = torch.randn(B, 3, 1024, 1024, device=dev)
+        pred = torch.randn(B, 1, 1024, 1024, device=dev)
+        masks = [(torch.rand(3, 1024, 1024, device=dev) > 0.5).to(torch.uint8) for _ in range(B)]
+        boxes = [torch.tensor([[10.0, 20.0, 200.0, 300.0]] * 3, device=dev) for _ in range(B)]
+
+        def step5():
+            targets = [{"boxes": b.clone(), "masks": m} for b, m in zip(boxes, masks)]
+            y, t = can5(x, targets)
+            return y, t, can5.invert_canonicalization(pred, induced_rep_type="scalar")
+        dt = gpu_time(step5, reps=10)
+        res[f"cfg5_coco1024_d4_B{B}"] = {"images_s": B / dt, "ms": dt * 1e3, "note": "3 uint8 masks + 3 boxes per image as targets"}
+    x1 = torch.randn(1, 3, 1024, 1024)
+    ang, refl = torch.tensor([90.0]), torch.tensor([1.0])
+
+    def cpu5():  # transform + invert only (the orbit / network part is a few ms either way)
+        return io.canonicalize_images(x1, ang, refl, (3, 1024, 1024)), io.invert_action(x1[:, :1], ang, refl, 4, 8, "scalar")
+    dt = cpu_time(cpu5, 2)
+    res["cfg5_coco1024_d4_cpu_oracle_transform_only"] = {"images_s": 1 / dt, "ms": dt * 1e3, "sample": "B=1, 16 threads"}
+
+    for k, v in res.items():
+        print(k, json.dumps(v))
+    if args.out:
+        json.dump(res, open(args.out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
