@@ -312,6 +312,11 @@ class ESCNNEquivariantNetwork(nn.Module):
         act = S.flatten(1) @ weff.t() / float(O * (H - k + 1) * (W - k + 1))
         if tail.bias is not None:
             act = act + tail.bias.double().mean()
+        # hidden-layer convolution biases cancel inside the batch-norms (zero gradient); keep them in the graph with that
+        # exact zero so that DistributedDataParallel sees a gradient for every parameter
+        hidden_bias = [c.bias.sum() for c in convs[:-1] if c.bias is not None]
+        if hidden_bias:
+            act = act + 0.0 * torch.stack(hidden_bias).sum().double()
         return act.float()
 
     def _training_fast_path_ok(self, x: torch.Tensor) -> bool:

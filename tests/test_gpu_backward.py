@@ -223,12 +223,13 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     (a2 * w).sum().backward()
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
         assert n1 == n2
-        if p1.grad is None:
-            # a convolution bias in front of a batch-norm cancels in the normalised output: exactly zero gradient (the
-            # module path leaves rounding noise there, the fast path does not even touch the parameter)
-            assert n1.endswith("bias") and (p2.grad is None or p2.grad.abs().max().item() <= 1e-5), n1
-            continue
+        assert p1.grad is not None, n1                    # DistributedDataParallel needs a gradient for every parameter
         g = p2.grad.abs().max().item()
+        if g <= 1e-5:
+            # a convolution bias in front of a batch-norm cancels in the normalised output: exactly zero gradient on the
+            # fast path, rounding noise on the module path
+            assert n1.endswith("bias") and p1.grad.abs().max().item() == 0.0, n1
+            continue
         assert p1.grad is not None and (p1.grad - p2.grad).abs().max().item() <= 3e-3 * g, (n1, (p1.grad - p2.grad).abs().max().item(), g)
     gx = x2.grad.abs().max().item()
     assert (x1.grad - x2.grad).abs().max().item() <= 3e-3 * gx
