@@ -86,7 +86,7 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def wrap_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, bucket_cap_mb: int = 64,
-             find_unused: Optional[bool] = None) -> torch.nn.Module:
+             find_unused: Optional[bool] = None, force: bool = False) -> torch.nn.Module:
     """DistributedDataParallel over the default process group (no-op when not initialised / world size 1).
 
     xGMI is point-to-point, so a ring all-reduce is bound by one ~153 GB/s link; a 64 MB bucket keeps the ~100 MB of
@@ -98,8 +98,8 @@ def wrap_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, buck
     if find_unused is None:
         w = getattr(model, "weights", None)
         find_unused = bool(w is not None and not w.task_weight)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return model
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        return model   # (`force`: wrap a single process too, to exercise DDP's hooks on one GPU)
     ids = [device.index] if device is not None and device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
                                                      find_unused_parameters=find_unused)

@@ -40,12 +40,15 @@ def main():
     ap.add_argument("--group", default="rotation", choices=["rotation", "roto-reflection"])
     ap.add_argument("--num-rotations", type=int, default=4)
     ap.add_argument("--prior-weight", type=float, default=100.0)
+    ap.add_argument("--force-ddp", action="store_true", help="wrap in DistributedDataParallel even with one process")
+    ap.add_argument("--net", default="custom", choices=["custom", "escnn"],
+                    help="canonicalization network: CustomEquivariantNetwork, or the ESCNN-shaped network (Winograd training path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if "RANK" in os.environ:  # under torch.distributed.run, also with a single process (DDP is then still exercised)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     torch.cuda.set_device(local)
@@ -53,11 +56,15 @@ def main():
     torch.manual_seed(0)
 
     S = args.size
-    net = ea.CustomEquivariantNetwork((3, S // 2, S // 2), 8, 5, args.group, args.num_rotations, 2, device="cpu")
+    if args.net == "escnn":
+        net = ea.ESCNNEquivariantNetwork((3, S // 2, S // 2), out_channels=32, kernel_size=5, group_type=args.group,
+                                         num_rotations=args.num_rotations, num_layers=3)
+    else:
+        net = ea.CustomEquivariantNetwork((3, S // 2, S // 2), 8, 5, args.group, args.num_rotations, 2, device="cpu")
     hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=S // 2)
     can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, S, S))
     model = tr.CanonicalizedClassifier(can, small_resnet(), tr.LossWeights(1.0, args.prior_weight)).to(dev)
-    ddp = tr.wrap_ddp(model, dev)
+    ddp = tr.wrap_ddp(model, dev, force=args.force_ddp)
     opt, _ = tr.configure_optimizer(model, 1e-3, 1e-3, kind="adamw")
 
     gen = torch.Generator().manual_seed(100 + rank)
@@ -73,7 +80,7 @@ def main():
     if rank == 0:
         dt = time.perf_counter() - t0
         print(f"{args.steps} steps, {args.batch * world * args.steps / dt:.0f} img/s over {world} GPU(s)")
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
