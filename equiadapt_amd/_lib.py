@@ -30,7 +30,7 @@ SIGNATURES = {
     "eqa_invert_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
     "eqa_orbit_expand_fwd": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
-    "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 7 + [_vp]),
+    "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 9 + [_vp]),
     "eqa_mask_action_nearest": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),
     "eqa_image_action_nearest": (_int, [_vp] * 5 + [_int] * 10 + [_vp]),
     "eqa_group_action_bwd_tiles": (_int, [_int, _int]),
@@ -111,7 +111,7 @@ def load() -> ctypes.CDLL:
                 raise EqaLibraryError(f"{SO_PATH} does not export {name}; rebuild it") from exc
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.eqa_abi_version() != 1:
+        if lib.eqa_abi_version() != 2:
             raise EqaLibraryError("libeqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

@@ -553,6 +553,7 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
 // resampled input rows live in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int kAaBand = 8;
+constexpr int kAaMaxK = 20;  // taps kept in registers by the wide-filter kernel (K = 17 at 8x down-sampling)
 
 __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  const float* __restrict__ wx, const int32_t* __restrict__ x0,
@@ -574,6 +575,71 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
     aa_tmp[ry * OW + ox] = acc;
   }
   __syncthreads();
+  float* dst = y + (size_t)plane * OH * OW;
+  for (int idx = threadIdx.x; idx < (r1 - r0) * OW; idx += kThreads) {
+    const int r = idx / OW, ox = idx - r * OW;
+    const int oy = r0 + r;
+    const int ys = y0[oy] - ybeg;
+    float acc = 0.0f;
+    for (int j = 0; j < K; ++j) acc += wy[oy * K + j] * aa_tmp[min(ys + j, nrows - 1) * OW + ox];
+    dst[(size_t)oy * OW + ox] = acc;
+  }
+}
+
+// Wide filters (K > 8, i.e. down-sampling by more than ~3.5x: config 5 resizes 1024 -> 128 with 17 taps): the K strided
+// global loads per intermediate value of the kernel above become the bottleneck (0.73 ms for 32 x 3 x 1024^2, 9x its HBM
+// time).  Here every needed input row segment is first staged into LDS with coalesced loads, `rpi` rows per iteration,
+// and the taps are taken from LDS.  Neighbouring lanes read addresses ~scale apart; for an even integer stride s = 2^a m
+// (m odd) the row is stored with one pad float every 2^a elements, which makes the lane stride s + m odd (conflict-free).
+__global__ __launch_bounds__(kThreads) void crop_resize_aa_wide_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                      const float* __restrict__ wx, const int32_t* __restrict__ x0,
+                                                                      const float* __restrict__ wy, const int32_t* __restrict__ y0,
+                                                                      int H, int W, int OH, int OW, int K, int max_rows, int xbeg,
+                                                                      int xlen, int pad_shift, int row_stride, int rpi) {
+  extern __shared__ __attribute__((aligned(16))) float aa_tmp[];  // [max_rows][OW] then [rpi][row_stride]
+  float* rowbuf = aa_tmp + (size_t)max_rows * OW;
+  const int plane = blockIdx.y;
+  const int r0 = blockIdx.x * kAaBand, r1 = min(r0 + kAaBand, OH);
+  const int ybeg = y0[r0];
+  const int yend = min(y0[r1 - 1] + K, H);
+  const int nrows = min(yend - ybeg, max_rows);
+  const float* src = x + (size_t)plane * H * W;
+  auto pos = [&](int e) { return pad_shift ? e + (e >> pad_shift) : e; };
+  const bool fixed_col = (kThreads % OW) == 0 && K <= kAaMaxK;
+  const int ox_fixed = threadIdx.x % OW;
+  const int xs_fixed = x0[ox_fixed] - xbeg;
+  float wreg[kAaMaxK];
+#pragma unroll
+  for (int j = 0; j < kAaMaxK; ++j) wreg[j] = (fixed_col && j < K) ? wx[ox_fixed * K + j] : 0.0f;
+  for (int ry0 = 0; ry0 < nrows; ry0 += rpi) {
+    const int nr = min(rpi, nrows - ry0);
+    for (int rr = 0; rr < nr; ++rr) {
+      const float* grow = src + (size_t)(ybeg + ry0 + rr) * W + xbeg;
+      float* lrow = rowbuf + rr * row_stride;
+      for (int e = threadIdx.x; e < xlen; e += kThreads) lrow[pos(e)] = grow[e];  // xbeg + xlen <= W
+    }
+    __syncthreads();
+    if (fixed_col) {  // kThreads % OW == 0: the thread keeps its output column, weights and tap start live in registers
+      for (int rr = threadIdx.x / OW; rr < nr; rr += kThreads / OW) {
+        const float* row = rowbuf + rr * row_stride;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kAaMaxK; ++j)
+          if (j < K) acc += wreg[j] * row[pos(min(xs_fixed + j, xlen - 1))];
+        aa_tmp[(ry0 + rr) * OW + ox_fixed] = acc;
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < nr * OW; idx += kThreads) {
+        const int rr = idx / OW, ox = idx - rr * OW;
+        const float* row = rowbuf + rr * row_stride;
+        const int xs = x0[ox] - xbeg;
+        float acc = 0.0f;
+        for (int j = 0; j < K; ++j) acc += wx[ox * K + j] * row[pos(min(xs + j, xlen - 1))];
+        aa_tmp[(ry0 + rr) * OW + ox] = acc;
+      }
+    }
+    __syncthreads();
+  }
   float* dst = y + (size_t)plane * OH * OW;
   for (int idx = threadIdx.x; idx < (r1 - r0) * OW; idx += kThreads) {
     const int r = idx / OW, ox = idx - r * OW;
@@ -702,7 +768,7 @@ int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, co
 
 extern "C" {
 
-int eqa_abi_version(void) { return 1; }
+int eqa_abi_version(void) { return 2; }  // 2: eqa_crop_resize_aa gained x_begin, x_span
 
 int eqa_set_option(int key, int value) {
   if (key == 0) {
@@ -765,14 +831,30 @@ int eqa_group_action_bwd_theta(const float* src, const float* grad_out, const in
 }
 
 int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t* x0, const float* wy, const int32_t* y0,
-                       int planes, int H, int W, int OH, int OW, int K, int max_rows, void* stream) {
+                       int planes, int H, int W, int OH, int OW, int K, int max_rows, int x_begin, int x_span, void* stream) {
   if (!x || !y || !wx || !x0 || !wy || !y0 || planes < 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0 || K <= 0 || max_rows <= 0)
     return EQA_ERR_INVALID_ARG;
   const size_t lds = (size_t)max_rows * OW * sizeof(float);
   if (lds > 96 * 1024 || planes > 65535) return EQA_ERR_UNSUPPORTED;
   if (planes == 0) return EQA_OK;
-  hipLaunchKernelGGL(crop_resize_aa_kernel, dim3((OH + kAaBand - 1) / kAaBand, planes), dim3(kThreads), lds, (hipStream_t)stream,
-                     x, y, wx, x0, wy, y0, H, W, OH, OW, K, max_rows);
+  const dim3 grid((OH + kAaBand - 1) / kAaBand, planes);
+  if (K > 8 && x_span > 0 && x_begin >= 0 && x_begin + x_span <= W) {
+    // wide filters: stage the input rows in LDS.  Lanes read ~x_span / OW floats apart; make that stride odd.
+    const int stride = (x_span + OW / 2) / OW;
+    const int pad_shift = (stride >= 2 && (stride & 1) == 0) ? __builtin_ctz((unsigned)stride) : 0;
+    const int row_stride = x_span + (pad_shift ? (x_span >> pad_shift) : 0) + 1;
+    // input rows staged per iteration: as many as fit next to the intermediate band (fewer barrier rounds), at most 8
+    const size_t row_bytes = (size_t)row_stride * sizeof(float);
+    const int rpi = (int)std::min<size_t>(8, lds + row_bytes <= 96 * 1024 ? (96 * 1024 - lds) / row_bytes : 0);
+    const size_t lds2 = lds + (size_t)rpi * row_bytes;
+    if (rpi >= 1) {
+      hipLaunchKernelGGL(crop_resize_aa_wide_kernel, grid, dim3(kThreads), lds2, (hipStream_t)stream, x, y, wx, x0, wy, y0, H, W, OH,
+                         OW, K, max_rows, x_begin, x_span, pad_shift, row_stride, rpi);
+      return launch_status();
+    }
+  }
+  hipLaunchKernelGGL(crop_resize_aa_kernel, grid, dim3(kThreads), lds, (hipStream_t)stream, x, y, wx, x0, wy, y0, H, W, OH, OW, K,
+                     max_rows);
   return launch_status();
 }
 

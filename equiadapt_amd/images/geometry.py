@@ -169,7 +169,11 @@ def aa_resize_tables(in_hw: Tuple[int, int], crop_hw: Tuple[int, int], out_hw: T
     for r0 in range(0, out_hw[0], band):
         r1 = min(r0 + band, out_hw[0])
         max_rows = max(max_rows, min(int(y0[r1 - 1]) + K, H) - int(y0[r0]))
-    return (torch.from_numpy(pad(wx)), torch.from_numpy(x0), torch.from_numpy(pad(wy)), torch.from_numpy(y0), K, max_rows)
+    # column range any output column reads (for the wide-filter kernel, which stages input rows in LDS)
+    x_begin = int(x0.min())
+    x_span = min(int(x0.max()) + K, W) - x_begin
+    return (torch.from_numpy(pad(wx)), torch.from_numpy(x0), torch.from_numpy(pad(wy)), torch.from_numpy(y0), K, max_rows,
+            x_begin, x_span)
 
 
 # ---- I6: torchvision nearest-neighbour rotation of masks -------------------------------------------------------------

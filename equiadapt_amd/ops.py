@@ -309,12 +309,12 @@ def crop_resize_aa(x: torch.Tensor, tables, out_hw: Tuple[int, int]) -> torch.Te
     ``geometry.aa_resize_tables`` already moved to x.device."""
     lib = _lib.load()
     x = _need(x, "x")
-    wx, x0, wy, y0, K, max_rows = tables
+    wx, x0, wy, y0, K, max_rows, x_begin, x_span = tables
     B, C, H, W = x.shape
     y = torch.empty((B, C, out_hw[0], out_hw[1]), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("crop_resize_aa"):
         st = lib.eqa_crop_resize_aa(x.data_ptr(), y.data_ptr(), wx.data_ptr(), x0.data_ptr(), wy.data_ptr(), y0.data_ptr(),
-                                    B * C, H, W, out_hw[0], out_hw[1], K, max_rows, _stream())
+                                    B * C, H, W, out_hw[0], out_hw[1], K, max_rows, x_begin, x_span, _stream())
     _lib.check(st, "eqa_crop_resize_aa")
     return y
 

@@ -42,7 +42,7 @@ extern "C" {
 #define EQA_FLIP_SRC 1
 #define EQA_FLIP_DST 2
 
-/* library / build identification: returns the ABI version (currently 1). */
+/* library / build identification: returns the ABI version (currently 2). */
 int eqa_abi_version(void);
 
 /* Debug/benchmark knobs (process-global, not part of the data path):
@@ -101,10 +101,11 @@ int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, cons
  * Separable (horizontal, then vertical, fp32 intermediates) like torch's kernel.  The caller supplies, per output
  * column / row, the first input tap (crop offset included) and K normalised weights (zero-padded), computed with
  * torch's formula: wx:(OW,K) x0:(OW) wy:(OH,K) y0:(OH).  x:(planes,H,W) -> y:(planes,OH,OW); max_rows >= the number of
- * input rows any band of 8 output rows touches.
+ * input rows any band of 8 output rows touches; [x_begin, x_begin + x_span) = the input columns any output column reads
+ * (min x0 .. max x0 + K, clipped to W; x_span <= 0 disables the LDS-staged path used for K > 8).
  */
 int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t* x0, const float* wy, const int32_t* y0,
-                       int planes, int H, int W, int OH, int OW, int K, int max_rows, void* stream);
+                       int planes, int H, int W, int OH, int OW, int K, int max_rows, int x_begin, int x_span, void* stream);
 
 /*
  * I6 -- nearest-neighbour group action on uint8 masks: torchvision.transforms.functional.rotate defaults

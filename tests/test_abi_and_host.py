@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.SO_PATH)
     for n in names:
         assert hasattr(lib, n), f"libeqa_hip.so does not export {n}"
-    assert _lib.load().eqa_abi_version() == 1
+    assert _lib.load().eqa_abi_version() == 2
     # argument validation happens before any device work, so it is checkable without a GPU
     assert _lib.load().eqa_set_option(99, 0) == -1
     assert _lib.load().eqa_group_pool_workspace_bytes(4, 32, 8, 7056) > 0
@@ -113,7 +113,7 @@ def test_aa_resize_tables_reproduce_torch_interpolate():
         x = torch.randn(2, 3, H, W)
         crop = (math.ceil(H * ratio), math.ceil(W * ratio))
         out_hw = io.tv_resize_output_size(crop, size)
-        wx, x0, wy, y0, K, max_rows = g.aa_resize_tables((H, W), crop, out_hw)
+        wx, x0, wy, y0, K, max_rows = g.aa_resize_tables((H, W), crop, out_hw)[:6]
         cols = (x0[:, None].long() + torch.arange(K)[None, :]).clamp(max=W - 1)      # (OW, K)
         tmp = (x[:, :, :, cols] * wx[None, None, None]).sum(-1)                      # horizontal pass (B,C,H,OW)
         rows = (y0[:, None].long() + torch.arange(K)[None, :]).clamp(max=H - 1)      # (OH, K)
