@@ -722,6 +722,88 @@ __global__ __launch_bounds__(kThreads) void nearest_action_kernel(const T* __res
   }
 }
 
+// Tiled form of the kernel above: one block = a 64 x 64 output tile whose source bounding box (the tile corners' images,
+// one pixel of rounding slack) is first staged into LDS row by row, so that the 90-degree elements of C4 / D4 -- whose
+// output rows are source COLUMNS -- no longer touch one cache line per pixel (config 5: 96 uint8 masks of 1024^2 took
+// 0.50 ms, 12x their HBM time, in the row-per-block kernel).  Same arithmetic per pixel, bit-identical results; a pixel
+// whose source falls outside the staged box (never for rotations) is read from global memory.
+constexpr int kNearTile = 64, kNearBox = 96;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nearest_action_tile_kernel(const T* __restrict__ m, T* __restrict__ out,
+                                                                      const int32_t* __restrict__ eidx,
+                                                                      const float* __restrict__ rtheta,
+                                                                      const int32_t* __restrict__ flags, int E, int H, int W,
+                                                                      int pad, int OH, int OW, int top, int left, int src_mod) {
+  __shared__ T s_src[kNearBox * kNearBox];
+  const int p = blockIdx.z;
+  const int i0 = blockIdx.y * kNearTile, j0 = blockIdx.x * kNearTile;
+  const int Hp = H + 2 * pad, Wp = W + 2 * pad;
+  const int e = min(max(eidx[p], 0), E - 1);
+  const float* t = rtheta + e * 6;
+  const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+  const bool flip = flags && (flags[e] & EQA_FLIP_SRC);
+  const T* src = m + (size_t)(src_mod > 0 ? p % src_mod : p) * H * W;
+  auto frame_xy = [&](int i, int j, float& xr, float& yr) {
+    const float yb = ((float)(top + i) + 0.5f) - 0.5f * (float)Hp;
+    const float xb = ((float)(left + j) + 0.5f) - 0.5f * (float)Wp;
+    const float gx = xb * t0 + yb * t1 + t2;
+    const float gy = xb * t3 + yb * t4 + t5;
+    xr = rintf(((gx + 1.0f) * (float)Wp - 1.0f) / 2.0f);  // std::nearbyint: round half to even
+    yr = rintf(((gy + 1.0f) * (float)Hp - 1.0f) / 2.0f);
+  };
+  // source box of the tile: the map is affine before rounding, so its extremes are at the corners
+  const int i1 = min(i0 + kNearTile, OH) - 1, j1 = min(j0 + kNearTile, OW) - 1;
+  float xa, ya, xb_, yb_, xc, yc, xd, yd;
+  frame_xy(i0, j0, xa, ya); frame_xy(i0, j1, xb_, yb_); frame_xy(i1, j0, xc, yc); frame_xy(i1, j1, xd, yd);
+  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - 1, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + 1;
+  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - 1, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + 1;
+  fx0 = max(fx0, 0); fx1 = min(fx1, Wp - 1); fy0 = max(fy0, 0); fy1 = min(fy1, Hp - 1);
+  if (flip) { const int a = Wp - 1 - fx1, b = Wp - 1 - fx0; fx0 = a; fx1 = b; }
+  const int sx0 = min(max(fx0 - pad, 0), W - 1), sx1 = min(max(fx1 - pad, 0), W - 1);
+  const int sy0 = min(max(fy0 - pad, 0), H - 1), sy1 = min(max(fy1 - pad, 0), H - 1);
+  const int bw = sx1 - sx0 + 1, bh = sy1 - sy0 + 1;
+  const bool staged = bw > 0 && bh > 0 && bw <= kNearBox && bh <= kNearBox;  // block-uniform
+  if (staged) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < bh; r += kThreads / 64) {
+      const T* grow = src + (size_t)(sy0 + r) * W + sx0;
+      for (int c = lane; c < bw; c += 64) s_src[r * kNearBox + c] = grow[c];
+    }
+  }
+  __syncthreads();
+  const int jb = j0 + (threadIdx.x & 15) * 4;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const int i = i0 + (threadIdx.x >> 4) + 16 * g;
+    if (i >= OH || jb >= OW) continue;
+    T v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float xr, yr;
+      frame_xy(i, jb + k, xr, yr);
+      T val = (T)0;
+      if (xr >= 0.0f && xr <= (float)(Wp - 1) && yr >= 0.0f && yr <= (float)(Hp - 1)) {
+        const int fx = flip ? (Wp - 1 - (int)xr) : (int)xr;
+        const int sx = min(max(fx - pad, 0), W - 1), sy = min(max((int)yr - pad, 0), H - 1);
+        const int lx = sx - sx0, ly = sy - sy0;
+        val = (staged && (unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) ? s_src[ly * kNearBox + lx]
+                                                                                     : src[(size_t)sy * W + sx];
+      }
+      v[k] = val;
+    }
+    T* o = out + (size_t)p * OH * OW + (size_t)i * OW + jb;
+    typedef typename Pack4<T>::type P4;
+    if (jb + 3 < OW && ((((uintptr_t)o) & (sizeof(P4) - 1)) == 0)) {
+      *reinterpret_cast<P4*>(o) = Pack4<T>::make(v);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (jb + k < OW) o[k] = v[k];
+    }
+  }
+}
+
 template <typename T>
 int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta, const int32_t* flags, int E,
                           int n_planes, int H, int W, int pad, int OH, int OW, int top, int left, int src_mod, void* stream) {
@@ -730,8 +812,13 @@ int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta,
     return EQA_ERR_INVALID_ARG;
   if (n_planes > 65535 || OH > 65535) return EQA_ERR_UNSUPPORTED;
   if (n_planes == 0) return EQA_OK;
-  hipLaunchKernelGGL((nearest_action_kernel<T>), dim3((OW / 4 + kThreads) / kThreads, OH, n_planes), dim3(kThreads), 0,
-                     (hipStream_t)stream, m, out, eidx, rtheta, flags, E, H, W, pad, OH, OW, top, left, src_mod);
+  if (g_force_direct)  // eqa_set_option(0, 1): the row-per-block kernel without LDS staging (tests compare the two)
+    hipLaunchKernelGGL((nearest_action_kernel<T>), dim3((OW / 4 + kThreads) / kThreads, OH, n_planes), dim3(kThreads), 0,
+                       (hipStream_t)stream, m, out, eidx, rtheta, flags, E, H, W, pad, OH, OW, top, left, src_mod);
+  else
+    hipLaunchKernelGGL((nearest_action_tile_kernel<T>),
+                       dim3((OW + kNearTile - 1) / kNearTile, (OH + kNearTile - 1) / kNearTile, n_planes), dim3(kThreads), 0,
+                       (hipStream_t)stream, m, out, eidx, rtheta, flags, E, H, W, pad, OH, OW, top, left, src_mod);
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 

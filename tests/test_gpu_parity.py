@@ -868,3 +868,39 @@ def test_optimized_steerable_canonicalizer(dev):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in can.parameters())
     opt.step()
     assert 0.0 <= float(1.0 - can.get_identity_metric().detach()) < 4.0
+
+
+def test_nearest_action_tiled_equals_direct(dev):
+    """The LDS-tiled nearest-neighbour kernel (default) and the row-per-block kernel (eqa_set_option(0, 1)) give identical
+    bytes / floats: odd sizes, 45-degree elements, flips, padded frames with a cropped window, plane reuse (src_mod)."""
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images import geometry
+
+    lib = _lib.load()
+    torch.manual_seed(81)
+    for (H, W, N) in [(70, 70, 8), (129, 65, 4), (1024, 1024, 4), (33, 200, 8)]:
+        masks = (torch.rand(11, H, W, device=dev) > 0.5).to(torch.uint8) * torch.randint(1, 255, (11, 1, 1), device=dev, dtype=torch.uint8)
+        ang = torch.cat([geometry.group_angles(N)] * 2)
+        rtheta = geometry.mask_rotation_table(-ang, (H, W)).to(dev)
+        flags = torch.cat([torch.zeros(N), torch.ones(N)]).to(dev, torch.int32)
+        eidx = torch.randint(0, 2 * N, (11,), device=dev, dtype=torch.int32)
+        a = ops.mask_action_nearest(masks, eidx, rtheta, flags)
+        lib.eqa_set_option(0, 1)
+        try:
+            b = ops.mask_action_nearest(masks, eidx, rtheta, flags)
+        finally:
+            lib.eqa_set_option(0, 0)
+        assert torch.equal(a, b), (H, W, N)
+    # fp32 images, padded frame, cropped window, each source plane used by several outputs
+    x = torch.randn(6, 50, 50, device=dev)
+    pad, OH, OW, top, left = 20, 50, 50, 20, 20
+    ang = geometry.group_angles(8)
+    rtheta = geometry.mask_rotation_table(ang, (50 + 2 * pad, 50 + 2 * pad)).to(dev)
+    eidx = (torch.arange(48, device=dev) // 6).to(torch.int32)
+    a = ops.image_action_nearest(x, eidx, rtheta, None, pad, (OH, OW), (top, left), 48, 6)
+    lib.eqa_set_option(0, 1)
+    try:
+        b = ops.image_action_nearest(x, eidx, rtheta, None, pad, (OH, OW), (top, left), 48, 6)
+    finally:
+        lib.eqa_set_option(0, 0)
+    assert torch.equal(a, b)
