@@ -482,6 +482,78 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
   }
 }
 
+// Input gradient as a GATHER (no atomics, deterministic, no pre-zeroed buffer) for the un-padded, one-output-per-image
+// case -- the invert action I7 on image-shaped network outputs, which is what a segmentation loss differentiates through.
+// A source pixel s receives g[o] * w(o, s) from the output pixels o whose sample point p(o) lies within one pixel of s;
+// p is affine in o, so the candidates are the integer points of A^-1(s + (-1,1)^2): at most 3 x 3 for a rotation, 4 x 4
+// slots here.  Each candidate's weight is recomputed exactly as the forward computes it (floor, fractional parts).
+// Measured against the atomic scatter: 3.4 ms -> see DESIGN.md for 256 x 3 x 224 x 224.
+template <bool MAPPED>
+__global__ __launch_bounds__(kThreads) void group_action_bwd_gather_kernel(const ActionArgs a) {
+  __shared__ int s_inv[kMaxMapG];
+  const int b = blockIdx.z;
+  const int e = min(max(a.gidx[b], 0), a.E - 1);
+  if (MAPPED) {
+    if (threadIdx.x < a.G) s_inv[a.chan_map[e * a.G + threadIdx.x]] = threadIdx.x;  // inverse of the channel permutation
+    __syncthreads();
+  }
+  const int sx = blockIdx.x * 64 + (threadIdx.x & 63), sy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (sx >= a.W || sy >= a.H) return;
+  const int fl = a.flags ? a.flags[e] : 0;
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+  const float* th = a.theta + e * 6;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const int fx = flip_src ? (a.Wp - 1 - sx) : sx, fy = sy;  // pad == 0: the frame is the source
+  // (jf, i') -> sample point, as an affine map, and its inverse
+  const float a00 = a.half_w * t0 * a.step_x, a01 = a.half_w * t1 * a.step_y, b0 = a.half_w * ((t2 - t0 - t1) + 1.0f);
+  const float a10 = a.half_h * t3 * a.step_x, a11 = a.half_h * t4 * a.step_y, b1 = a.half_h * ((t5 - t3 - t4) + 1.0f);
+  const float det = a00 * a11 - a01 * a10;
+  const float m00 = a11 / det, m01 = -a01 / det, m10 = -a10 / det, m11 = a00 / det;
+  const float px = (float)fx - b0, py = (float)fy - b1;
+  const float jc = m00 * px + m01 * py, ic = m10 * px + m11 * py;
+  const float dj = fabsf(m00) + fabsf(m01) + 0.05f, di = fabsf(m10) + fabsf(m11) + 0.05f;
+  const int j_lo = max((int)ceilf(jc - dj), 0), j_hi = min((int)floorf(jc + dj), a.Wp - 1);
+  const int i_lo = max((int)ceilf(ic - di), 0), i_hi = min((int)floorf(ic + di), a.Hp - 1);
+  float w[16];
+  int off[16];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ii = i_lo + r, jf = j_lo + c;
+      float wt = 0.0f;
+      int o = 0;
+      const int i = ii - a.top, j = (flip_dst ? (a.Wp - 1 - jf) : jf) - a.left;
+      if (ii <= i_hi && jf <= j_hi && i >= 0 && i < a.OH && j >= 0 && j < a.OW) {
+        const float xn = lin_m1_p1(jf, a.Wp, a.step_x), yn = lin_m1_p1(ii, a.Hp, a.step_y);
+        const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
+        const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+        const float xf = floorf(ix), yf = floorf(iy);
+        const float wx1 = ix - xf, wy1 = iy - yf;
+        const float ffx = (float)fx, ffy = (float)fy;
+        const float wx = (ffx == xf) ? 1.0f - wx1 : ((ffx == xf + 1.0f) ? wx1 : 0.0f);
+        const float wy = (ffy == yf) ? 1.0f - wy1 : ((ffy == yf + 1.0f) ? wy1 : 0.0f);
+        wt = wy * wx;
+        o = i * a.OW + j;
+      }
+      w[r * 4 + c] = wt;
+      off[r * 4 + c] = o;
+    }
+  }
+  const size_t src_plane = (size_t)a.H * a.W, dst_plane = (size_t)a.OH * a.OW;
+  const float* gimg = a.gout + (size_t)b * a.C * dst_plane;
+  float* simg = a.gsrc + (size_t)b * a.C * src_plane + (size_t)sy * a.W + sx;
+  for (int cs = 0; cs < a.C; ++cs) {
+    const int c = MAPPED ? (cs / a.G) * a.G + s_inv[cs % a.G] : cs;
+    const float* gp = gimg + (size_t)c * dst_plane;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (w[k] != 0.0f) acc += gp[off[k]] * w[k];
+    simg[(size_t)cs * src_plane] = acc;
+  }
+}
+
 template <int CH>
 int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
@@ -838,6 +910,24 @@ int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, co
   if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
   hipStream_t st = (hipStream_t)stream;
+  // un-padded, one output per image, whole-frame output: the input gradient is an exact gather (no atomics; grad_src need
+  // not be zeroed).  The transform gradient, if wanted too, comes from its own launch of the scatter-free mode.
+  const bool gather = grad_src && pad == 0 && gidx && n_out == B && !g_force_direct;
+  if (gather) {
+    const dim3 ggrid((W + 63) / 64, (H + 3) / 4, B);
+    if (ggrid.y > 65535 || ggrid.z > 65535) return EQA_ERR_UNSUPPORTED;
+    if (chan_map)
+      hipLaunchKernelGGL((group_action_bwd_gather_kernel<true>), ggrid, dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((group_action_bwd_gather_kernel<false>), ggrid, dim3(kThreads), 0, st, a);
+    if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+    if (!partial) return EQA_OK;
+    if (grad_mode == 1)
+      hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
+    else
+      hipLaunchKernelGGL((group_action_bwd_kernel<2, false>), grid, dim3(kThreads), 0, st, a);
+    return launch_status();
+  }
   if (!partial)
     hipLaunchKernelGGL((group_action_bwd_kernel<0, true>), grid, dim3(kThreads), 0, st, a);
   else if (grad_mode == 1 && grad_src)

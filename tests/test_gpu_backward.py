@@ -295,3 +295,39 @@ def test_fused_bn_relu_dropout_block(dev):
     g, = torch.autograd.grad(ya.sum(), big)
     g0, = torch.autograd.grad((y0 * kept * 2.0).sum(), big)      # same function with the mask written out
     assert torch.allclose(g, g0, atol=1e-4 * g0.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_input_gradient_gather_equals_atomic_scatter(dev):
+    """Un-padded input gradient: the deterministic gather (default) against the atomic scatter (eqa_set_option(0, 1)), for
+    rotations incl. 45 degrees, output flips, regular-representation channel maps and non-square, odd sizes; and it is
+    bit-reproducible run to run."""
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import device_tables
+
+    lib = _lib.load()
+    torch.manual_seed(91)
+    for (N, refl, C, H, W, regular) in [(8, False, 3, 37, 37, False), (4, True, 8, 40, 40, True), (8, True, 16, 33, 33, True),
+                                        (8, False, 2, 224, 224, False)]:
+        G = 2 * N if refl else N
+        th, fl, cm = device_tables("invert", N, refl, (H, W), dev)
+        B = 9
+        src = torch.randn(B, C, H, W, device=dev)
+        gy = torch.randn(B, C, H, W, device=dev)
+        gidx = torch.randint(0, G, (B,), device=dev, dtype=torch.int32)
+        cmap = cm if regular else None
+        g1, _ = ops.group_action_bwd(src, gy, gidx, th, fl, cmap, 0, (0, 0), True, False)
+        g1b, _ = ops.group_action_bwd(src, gy, gidx, th, fl, cmap, 0, (0, 0), True, False)
+        lib.eqa_set_option(0, 1)
+        try:
+            g2, _ = ops.group_action_bwd(src, gy, gidx, th, fl, cmap, 0, (0, 0), True, False)
+        finally:
+            lib.eqa_set_option(0, 0)
+        assert torch.equal(g1, g1b)
+        # the two kernels evaluate the sample coordinate with different FMA contraction: at 45 degrees and |coordinate| ~ 100
+        # that is ~1e-5 px, i.e. ~1e-5 of a bilinear weight (both are 7e-5 from the fp64 adjoint at 224 x 224)
+        assert (g1 - g2).abs().max().item() <= 1e-4, (N, refl, C, H, W, (g1 - g2).abs().max().item())
+        # adjoint identity <T x, g> == <x, T^* g>
+        y = ops.group_action(src, gidx, th, fl, cmap, 0, (H, W), (0, 0))
+        lhs, rhs = (y * gy).sum().item(), (src * g1).sum().item()
+        assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)

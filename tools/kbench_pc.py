@@ -45,3 +45,21 @@ th_c, fl_c = device_tables("canonicalize", 8, False, (2 * S, 2 * S), dev)
 for want_src, want_angle in ((False, True), (True, False), (True, True)):
     ms = timeit(lambda: ops.group_action_bwd(x, gy, gidx, th_c, fl_c, None, S // 2, (S // 2, S // 2), want_src, want_angle), 20)
     print(f"group_action_bwd src={want_src} angle={want_angle}: {ms*1e3:8.1f} us")
+
+# un-padded input gradient (invert action): deterministic gather; EQA option 0 = 1 forces the atomic scatter
+from equiadapt_amd import _lib  # noqa: E402
+lib = _lib.load()
+th_i, fl_i, cm_i = device_tables("invert", 8, False, (S, S), dev)
+for name, opt in (("gather", 0), ("atomic scatter", 1)):
+    lib.eqa_set_option(0, opt)
+    ms = timeit(lambda: ops.group_action_bwd(x, gy, gidx, th_i, fl_i, None, 0, (0, 0), True, False), 20)
+    print(f"invert_action input gradient, {name}: {ms*1e3:8.1f} us")
+lib.eqa_set_option(0, 0)
+f8 = torch.randn(64, 64, S, S, device=dev)
+g8 = torch.randn(64, 64, S, S, device=dev)
+gi8 = gidx[:64]
+for name, opt in (("gather", 0), ("atomic scatter", 1)):
+    lib.eqa_set_option(0, opt)
+    ms = timeit(lambda: ops.group_action_bwd(f8, g8, gi8, th_i, fl_i, cm_i, 0, (0, 0), True, False), 10)
+    print(f"invert_action input gradient, regular rep 64x64ch, {name}: {ms*1e3:8.1f} us")
+lib.eqa_set_option(0, 0)
