@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip")]
-HEADERS = [os.path.join(CSRC, "eqa_common.hpp")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip", "vnsmall_train.hip")]
+HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp")]
 INCLUDE = os.path.join(ROOT, "include")
 
 _c_f = ctypes.POINTER(ctypes.c_float)
@@ -44,6 +44,12 @@ SIGNATURES = {
     "eqa_bn_relu_dropout_nhwc": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_float, ctypes.c_uint32, _vp]),
     "eqa_bn_bwd_reduce_nhwc": (_int, [_vp] * 5 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_vn_blocks": (_int, [_int]),
+    "eqa_vn_knn": (_int, [_vp, _vp, _int, _int, _int, _vp]),
+    "eqa_vn_convpos_stats": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp]),
+    "eqa_vn_convpos_fwd": (_int, [_vp] * 7 + [_int, _int, _vp]),
+    "eqa_vn_convpos_bwd_reduce": (_int, [_vp] * 10 + [_int, _int, _vp]),
+    "eqa_vn_convpos_bwd_apply": (_int, [_vp] * 12 + [_int, _int, _vp]),
     "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_winograd_f2k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),

@@ -1,0 +1,317 @@
+// libeqa_hip.so, part 7 -- training passes of VNSmall's first block (P1 + the conv_pos half of P2): kNN graph -> cross edge
+// features -> VNLinearLeakyReLU(3 -> 21, slope 0) with TRAINING-mode VN batch-norm -> mean over the k neighbours
+// (reference: pointcloud/canonicalization_networks/equivariant_networks.py:15-76, :128-140; vector_neuron_layers.py:251-273,
+// :303-324).  Op by op the block materialises ~150 element-wise passes over (B, 21, 3, N, k) tensors (330 MB each at B = 64):
+// 14 of the 15.9 ms of a training step.  Here nothing of that size exists: every pass re-derives the edge features from the
+// 12 KB cloud in LDS and the (B, N, k) neighbour indices, one thread per point:
+//   eqa_vn_knn                 neighbour indices (the queued insertion of the fused eval kernel)
+//   eqa_vn_convpos_stats       per-channel sums of n and n^2, n = |W_f f| + EPS, over all edges  -> batch statistics
+//   eqa_vn_convpos_fwd         q = W_f f; q <- q / n * (n * scale + shift); gate by d = W_d f; mean over k  -> (B, 21, 3, N)
+//   eqa_vn_convpos_bwd_reduce  per-channel sums of g and g * nhat (g = dL/d BN output): d beta, d gamma, batch-norm terms
+//   eqa_vn_convpos_bwd_apply   d W_f, d W_d (126 partial sums per block)
+// No gradient w.r.t. the point coordinates (the cloud is data).  C ABI: include/eqa_hip.h.
+#include "vn_common.hpp"
+
+namespace {
+
+// edge features of (centre, neighbour): [neighbour - centre, centre, neighbour x centre]
+struct VnEdge {
+  V3 f0, f1, f2;
+};
+__device__ __forceinline__ VnEdge vn_edge(const V3& ctr, const float4& nb4) {
+  const V3 nb = v3(nb4.x, nb4.y, nb4.z);
+  VnEdge e;
+  e.f0 = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);
+  e.f1 = ctr;
+  e.f2 = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);
+  return e;
+}
+__device__ __forceinline__ V3 vn_mix(const float* __restrict__ w, const VnEdge& e) {  // w[0..2]: one output channel
+  return v3(w[0] * e.f0.x + w[1] * e.f1.x + w[2] * e.f2.x, w[0] * e.f0.y + w[1] * e.f1.y + w[2] * e.f2.y,
+            w[0] * e.f0.z + w[1] * e.f1.z + w[2] * e.f2.z);
+}
+
+// block-wide sum of NV per-thread values -> out[0..NV) (deterministic: shuffles, then a fixed-order sum over the waves)
+template <int NV>
+__device__ __forceinline__ void vn_block_sum(float (&v)[NV], float* s_red /* [waves][NV] */, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();  // the scratch may still be read from a previous call
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float s = wave_sum_f(v[i]);
+    if (lane == 0) s_red[wave * NV + i] = s;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < NV; i += kVnThreads) {
+    float s = 0.f;
+    for (int w = 0; w < kVnThreads / 64; ++w) s += s_red[w * NV + i];
+    out[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
+                                                                             int N) {
+  extern __shared__ __attribute__((aligned(16))) float vn_smem[];
+  float4* pts = reinterpret_cast<float4*>(vn_smem);
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int Npad = (N + 3) & ~3;
+  vn_stage_cloud(x + (size_t)b * 3 * N, N, Npad, pts, tid);
+  __syncthreads();
+  const int n = blockIdx.x * kVnThreads + tid;
+  const bool active = n < N;
+  const float4 c4 = pts[active ? n : N - 1];
+  int bi[kVnK];
+  vn_knn(pts, Npad, reinterpret_cast<float2*>(vn_smem + 4 * Npad) + tid, v3(c4.x, c4.y, c4.z), c4.w, bi);
+  if (active) {
+    int32_t* o = idx + ((size_t)b * N + n) * kVnK;
+#pragma unroll
+    for (int t = 0; t < kVnK; ++t) o[t] = bi[t];
+  }
+}
+
+// common prologue of the four conv_pos passes: cloud in LDS, this thread's point and its neighbour list
+#define VN_PASS_PROLOGUE                                                                           \
+  extern __shared__ __attribute__((aligned(16))) float vn_smem[];                                  \
+  float4* pts = reinterpret_cast<float4*>(vn_smem);                                                \
+  const int b = blockIdx.y, tid = threadIdx.x;                                                     \
+  const int Npad = (N + 3) & ~3;                                                                   \
+  vn_stage_cloud(x + (size_t)b * 3 * N, N, Npad, pts, tid);                                        \
+  __syncthreads();                                                                                 \
+  const int n = blockIdx.x * kVnThreads + tid;                                                     \
+  const bool active = n < N;                                                                       \
+  const float4 c4 = pts[active ? n : N - 1];                                                       \
+  const V3 ctr = v3(c4.x, c4.y, c4.z);                                                             \
+  const int32_t* nbr = idx + ((size_t)b * N + (active ? n : N - 1)) * kVnK;
+
+__global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                                     const float* __restrict__ Wf, float* __restrict__ partial,
+                                                                     int N) {
+  __shared__ float s_red[(kVnThreads / 64) * 2 * kVnC];
+  VN_PASS_PROLOGUE
+  float acc[2 * kVnC];
+#pragma unroll
+  for (int i = 0; i < 2 * kVnC; ++i) acc[i] = 0.f;
+#pragma unroll 1
+  for (int t = 0; t < kVnK; ++t) {
+    asm volatile("" ::: "memory");  // keep the weights in the scalar cache, not hoisted into VGPRs (see pointcloud.hip)
+    const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      const V3 q = vn_mix(Wf + 3 * c, e);
+      const float nr = active ? sqrtf(dot3(q, q)) + kVnEps : 0.f;
+      acc[2 * c] += nr;
+      acc[2 * c + 1] += nr * nr;
+    }
+  }
+  vn_block_sum<2 * kVnC>(acc, s_red, partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC));
+}
+
+__global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                                   const float* __restrict__ Wf, const float* __restrict__ Wd,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   float* __restrict__ pooled, int N) {
+  VN_PASS_PROLOGUE
+  V3 acc[kVnC];
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) acc[c] = v3(0.f, 0.f, 0.f);
+#pragma unroll 1
+  for (int t = 0; t < kVnK; ++t) {
+    asm volatile("" ::: "memory");
+    const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      const V3 q = vn_relu(vn_bn(vn_mix(Wf + 3 * c, e), scale[c], shift[c]), vn_mix(Wd + 3 * c, e));
+      acc[c].x += q.x; acc[c].y += q.y; acc[c].z += q.z;
+    }
+  }
+  if (active) {
+    const float inv_k = 1.0f / (float)kVnK;
+    float* o = pooled + (size_t)b * kVnC * 3 * N + n;  // (B, 21, 3, N)
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      o[(size_t)(3 * c) * N] = acc[c].x * inv_k;
+      o[(size_t)(3 * c + 1) * N] = acc[c].y * inv_k;
+      o[(size_t)(3 * c + 2) * N] = acc[c].z * inv_k;
+    }
+  }
+}
+
+// One (edge, channel) of the block, forward values and the gradients that do not need batch-wide sums.
+struct VnGrad {
+  V3 q, u, d, g_qn, g_d;  // pre-norm vector, its direction q / n, gate direction, dL/d(normalised vector), dL/d(gate)
+  float nr, nbn, g_nbn;   // n = |q| + EPS, batch-normalised norm, dL/d(nbn)
+};
+__device__ __forceinline__ VnGrad vn_edge_grad(const float* __restrict__ wf, const float* __restrict__ wd, const VnEdge& e,
+                                               float scale, float shift, const V3& g_out) {
+  VnGrad r;
+  r.q = vn_mix(wf, e);
+  r.nr = sqrtf(dot3(r.q, r.q)) + kVnEps;
+  const float inv_n = 1.0f / r.nr;
+  r.u = v3(r.q.x * inv_n, r.q.y * inv_n, r.q.z * inv_n);
+  r.nbn = r.nr * scale + shift;
+  const V3 qn = v3(r.u.x * r.nbn, r.u.y * r.nbn, r.u.z * r.nbn);
+  r.d = vn_mix(wd, e);
+  const float dp = dot3(qn, r.d);
+  if (dp >= 0.0f) {  // kept as is
+    r.g_qn = g_out;
+    r.g_d = v3(0.f, 0.f, 0.f);
+  } else {           // out = qn - alpha d, alpha = <qn, d> / (|d|^2 + EPS)
+    const float rr = 1.0f / (dot3(r.d, r.d) + kVnEps);
+    const float alpha = dp * rr;
+    const float g_alpha = -dot3(g_out, r.d);
+    const float ga_r = g_alpha * rr;
+    r.g_qn = v3(g_out.x + ga_r * r.d.x, g_out.y + ga_r * r.d.y, g_out.z + ga_r * r.d.z);
+    r.g_d = v3(-alpha * g_out.x + ga_r * (qn.x - 2.0f * alpha * r.d.x), -alpha * g_out.y + ga_r * (qn.y - 2.0f * alpha * r.d.y),
+               -alpha * g_out.z + ga_r * (qn.z - 2.0f * alpha * r.d.z));
+  }
+  r.g_nbn = dot3(r.g_qn, r.u);
+  return r;
+}
+
+__global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                                          const float* __restrict__ Wf, const float* __restrict__ Wd,
+                                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                          const float* __restrict__ gpool, float* __restrict__ partial,
+                                                                          int N) {
+  __shared__ float s_red[(kVnThreads / 64) * 2];
+  VN_PASS_PROLOGUE
+  const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;  // idle threads contribute nothing
+  const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
+  int nb[kVnK];
+#pragma unroll
+  for (int t = 0; t < kVnK; ++t) nb[t] = nbr[t];
+  float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC);
+  // channel by channel (the output gradient of a channel is the same for all k edges of the point): two accumulators live
+#pragma unroll 1
+  for (int c = 0; c < kVnC; ++c) {
+    const V3 g_out = v3(gp[(size_t)(3 * c) * N] * inv_k, gp[(size_t)(3 * c + 1) * N] * inv_k, gp[(size_t)(3 * c + 2) * N] * inv_k);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    float acc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < kVnK; ++t) {
+      const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, vn_edge(ctr, pts[nb[t]]), sc, sh, g_out);
+      acc[0] += r.g_nbn;
+      acc[1] += r.g_nbn * (r.nr - mu) * rs;
+    }
+    vn_block_sum<2>(acc, s_red, out + 2 * c);
+  }
+}
+
+// dW_f[c][i] = sum <g_q, f_i>, dW_d[c][i] = sum <g_d, f_i>;  g_q = dL/dq through the direction u = q/n and through the norm:
+//   g_n = gamma rstd (g_nbn - m1 - nhat m2)   (m1 = sum g_nbn / M, m2 = sum g_nbn nhat / M; both 0 with running statistics)
+//   g_q = (g_u - u <g_u, q> / |q|) / n + g_n q / |q|,   g_u = g_qn * nbn
+__global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                                         const float* __restrict__ Wf, const float* __restrict__ Wd,
+                                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                         const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                         const float* __restrict__ gpool, float* __restrict__ partial,
+                                                                         int N) {
+  __shared__ float s_red[(kVnThreads / 64) * 6];
+  VN_PASS_PROLOGUE
+  const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;
+  const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
+  int nb[kVnK];
+#pragma unroll
+  for (int t = 0; t < kVnK; ++t) nb[t] = nbr[t];
+  float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (6 * kVnC);  // [c][W_f 0..2, W_d 0..2]
+#pragma unroll 1
+  for (int c = 0; c < kVnC; ++c) {
+    const V3 g_out = v3(gp[(size_t)(3 * c) * N] * inv_k, gp[(size_t)(3 * c + 1) * N] * inv_k, gp[(size_t)(3 * c + 2) * N] * inv_k);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c], mm1 = m1[c], mm2 = m2[c];
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < kVnK; ++t) {
+      const VnEdge e = vn_edge(ctr, pts[nb[t]]);
+      const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, e, sc, sh, g_out);
+      const float nhat = (r.nr - mu) * rs;
+      // sc = gamma * rstd; idle threads (duplicates of the last point) must not pick up the batch terms -m1 - nhat m2
+      const float g_n = active ? sc * (r.g_nbn - mm1 - nhat * mm2) : 0.0f;
+      const float qlen = fmaxf(r.nr - kVnEps, 1e-30f);
+      const V3 g_u = v3(r.g_qn.x * r.nbn, r.g_qn.y * r.nbn, r.g_qn.z * r.nbn);
+      const float proj = dot3(g_u, r.q) / qlen;
+      const float inv_n = 1.0f / r.nr, gq = g_n / qlen;
+      const V3 g_q = v3((g_u.x - r.u.x * proj) * inv_n + gq * r.q.x, (g_u.y - r.u.y * proj) * inv_n + gq * r.q.y,
+                        (g_u.z - r.u.z * proj) * inv_n + gq * r.q.z);
+      acc[0] += dot3(g_q, e.f0);
+      acc[1] += dot3(g_q, e.f1);
+      acc[2] += dot3(g_q, e.f2);
+      acc[3] += dot3(r.g_d, e.f0);
+      acc[4] += dot3(r.g_d, e.f1);
+      acc[5] += dot3(r.g_d, e.f2);
+    }
+    vn_block_sum<6>(acc, s_red, out + 6 * c);
+  }
+}
+
+inline int vn_check(const void* x, const void* idx, int B, int N, size_t& lds, bool with_queue) {
+  if (B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
+  if (N < kVnK) return EQA_ERR_UNSUPPORTED;
+  lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (with_queue ? (size_t)kVnThreads * kVnQueue * sizeof(float2) : 0);
+  if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  if (!x || !idx) return EQA_ERR_INVALID_ARG;
+  return 1;  // go
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_vn_blocks(int N) { return N <= 0 ? 0 : (N + kVnThreads - 1) / kVnThreads; }
+
+int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream) {
+  if (k != kVnK) return EQA_ERR_UNSUPPORTED;
+  size_t lds;
+  const int rc = vn_check(x, idx, B, N, lds, true);
+  if (rc != 1) return rc;
+  hipLaunchKernelGGL(vn_knn_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, N);
+  return launch_status();
+}
+
+int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, void* stream) {
+  size_t lds;
+  const int rc = vn_check(x, idx, B, N, lds, false);
+  if (rc != 1) return rc;
+  if (!Wf || !partial) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vn_convpos_stats_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, partial, N);
+  return launch_status();
+}
+
+int eqa_vn_convpos_fwd(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale, const float* shift,
+                       float* pooled, int B, int N, void* stream) {
+  size_t lds;
+  const int rc = vn_check(x, idx, B, N, lds, false);
+  if (rc != 1) return rc;
+  if (!Wf || !Wd || !scale || !shift || !pooled) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vn_convpos_fwd_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd, scale,
+                     shift, pooled, N);
+  return launch_status();
+}
+
+int eqa_vn_convpos_bwd_reduce(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, const float* gpool, float* partial, int B,
+                              int N, void* stream) {
+  size_t lds;
+  const int rc = vn_check(x, idx, B, N, lds, false);
+  if (rc != 1) return rc;
+  if (!Wf || !Wd || !scale || !shift || !mean || !rstd || !gpool || !partial) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vn_convpos_bwd_reduce_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd,
+                     scale, shift, mean, rstd, gpool, partial, N);
+  return launch_status();
+}
+
+int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, const float* m1, const float* m2,
+                             const float* gpool, float* partial, int B, int N, void* stream) {
+  size_t lds;
+  const int rc = vn_check(x, idx, B, N, lds, false);
+  if (rc != 1) return rc;
+  if (!Wf || !Wd || !scale || !shift || !mean || !rstd || !m1 || !m2 || !gpool || !partial) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(vn_convpos_bwd_apply_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd,
+                     scale, shift, mean, rstd, m1, m2, gpool, partial, N);
+  return launch_status();
+}
+
+}  // extern "C"

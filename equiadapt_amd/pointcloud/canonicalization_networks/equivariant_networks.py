@@ -4,6 +4,7 @@ Reference: equiadapt/pointcloud/canonicalization_networks/equivariant_networks.p
 get_graph_feature_cross :36-76, VNSmall :79-150).  Hyperparameters are read by attribute
 (``n_knn``, ``pooling``), so a SimpleNamespace / dataclass / DictConfig all work.
 """
+import os
 from typing import Any, Optional
 
 import torch
@@ -37,6 +38,84 @@ def get_graph_feature_cross(x: torch.Tensor, k: int = 20, idx: Optional[torch.Te
     ctr = pts.view(B, N, 1, dims, 3).expand(B, N, k, dims, 3)
     cross = torch.cross(nbr, ctr, dim=-1)
     return torch.cat((nbr - ctr, ctr, cross), dim=3).permute(0, 3, 4, 1, 2).contiguous()
+
+
+class ConvPosMeanPool(torch.autograd.Function):
+    """mean over the k neighbours of VNLinearLeakyReLU(3 -> 21, slope 0)(edge features), with autograd w.r.t. the layer's
+    parameters, on the recompute-everything kernels of csrc/vnsmall_train.hip (eqa_vn_*): (B, 3, N) -> (B, 21, 3, N).
+    Training-mode VN batch-norm: statistics of n = |W_f f| + EPS over all B*N*k edges (fp64 accumulation across blocks),
+    running statistics updated like nn.BatchNorm2d.  No gradient w.r.t. the cloud."""
+
+    @staticmethod
+    def forward(ctx, x, Wf, Wd, gamma, beta, bn, k):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        B, _, N = x.shape
+        x = x.contiguous()
+        Wf_, Wd_ = Wf.detach().contiguous(), Wd.detach().contiguous()
+        C = Wf_.shape[0]
+        st = ops._stream()
+        nblk = B * lib.eqa_vn_blocks(N)
+        dev = x.device
+        with torch.cuda.device(dev):
+            idx = torch.empty((B, N, k), dtype=torch.int32, device=dev)
+            _lib.check(lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, st), "eqa_vn_knn")
+            M = B * N * k
+            if bn.training:
+                part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
+                _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, st),
+                           "eqa_vn_convpos_stats")
+                sums = part.sum(0, dtype=torch.float64)
+                mean = sums[:, 0] / M
+                var = (sums[:, 1] / M - mean * mean).clamp_min(0.0)
+                m = bn.momentum
+                bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
+                bn.running_var.mul_(1 - m).add_(m * (var * (M / max(M - 1, 1))).to(bn.running_var.dtype))
+                bn.num_batches_tracked += 1
+                mean, var = mean.float(), var.float()
+            else:
+                mean, var = bn.running_mean, bn.running_var
+            rstd = torch.rsqrt(var + bn.eps)
+            scale = (gamma.detach() * rstd).contiguous()
+            shift = (beta.detach() - mean * scale).contiguous()
+            pooled = torch.empty((B, C, 3, N), dtype=torch.float32, device=dev)
+            _lib.check(lib.eqa_vn_convpos_fwd(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), Wd_.data_ptr(), scale.data_ptr(),
+                                              shift.data_ptr(), pooled.data_ptr(), B, N, st), "eqa_vn_convpos_fwd")
+        ctx.save_for_backward(x, idx, Wf_, Wd_, scale, shift, mean.contiguous(), rstd.contiguous())
+        ctx.batch_stats, ctx.M = bn.training, M
+        return pooled
+
+    @staticmethod
+    def backward(ctx, gpool):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        x, idx, Wf, Wd, scale, shift, mean, rstd = ctx.saved_tensors
+        B, _, N = x.shape
+        C = Wf.shape[0]
+        gpool = gpool.contiguous()
+        st = ops._stream()
+        nblk = B * lib.eqa_vn_blocks(N)
+        dev = x.device
+        with torch.cuda.device(dev):
+            part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
+            _lib.check(lib.eqa_vn_convpos_bwd_reduce(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
+                                                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gpool.data_ptr(),
+                                                     part.data_ptr(), B, N, st), "eqa_vn_convpos_bwd_reduce")
+            sums = part.sum(0, dtype=torch.float64)
+            dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
+            if ctx.batch_stats:
+                m1, m2 = (sums[:, 0] / ctx.M).float().contiguous(), (sums[:, 1] / ctx.M).float().contiguous()
+            else:
+                m1 = torch.zeros(C, device=dev)
+                m2 = m1
+            wpart = torch.empty((nblk, C, 6), dtype=torch.float32, device=dev)
+            _lib.check(lib.eqa_vn_convpos_bwd_apply(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
+                                                    shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(), m2.data_ptr(),
+                                                    gpool.data_ptr(), wpart.data_ptr(), B, N, st), "eqa_vn_convpos_bwd_apply")
+            dW = wpart.sum(0, dtype=torch.float64).float()
+        return None, dW[:, :3].contiguous(), dW[:, 3:].contiguous(), dgamma, dbeta, None, None
 
 
 class VNSmall(nn.Module):
@@ -89,8 +168,16 @@ class VNSmall(nn.Module):
             from equiadapt_amd import ops
 
             return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn)
-        feat = get_graph_feature_cross(point_cloud.unsqueeze(1), k=self.n_knn)
-        out = self.pool(self.conv_pos(feat))
+        if (point_cloud.is_cuda and torch.is_grad_enabled() and not point_cloud.requires_grad and self.pooling == "mean"
+                and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32
+                and os.environ.get("EQA_TRAIN_FAST", "1") != "0"):
+            # training: the (B, 21, 3, N, k) edge tensors of the first block are never materialised (csrc/vnsmall_train.hip)
+            cp = self.conv_pos
+            out = ConvPosMeanPool.apply(point_cloud, cp.map_to_feat.weight, cp.map_to_dir.weight, cp.batchnorm.bn2d.weight,
+                                        cp.batchnorm.bn2d.bias, cp.batchnorm.bn2d, self.n_knn)
+        else:
+            feat = get_graph_feature_cross(point_cloud.unsqueeze(1), k=self.n_knn)
+            out = self.pool(self.conv_pos(feat))
         out = self.bn1(self.conv1(out))
         out = self.dropout(self.conv2(out))
         return out.mean(dim=-1)[:, :3]

@@ -289,6 +289,33 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
                     void* stream);
 
 /*
+ * Training passes of VNSmall's first block (kNN graph -> cross edge features -> VNLinearLeakyReLU(3 -> 21, slope 0) with
+ * training-mode VN batch-norm -> mean over the k = 20 neighbours; equivariant_networks.py:15-76, :128-140,
+ * vector_neuron_layers.py:251-273, :303-324), forward and the autograd backward w.r.t. the parameters.  Nothing of size
+ * (B, 21, 3, N, k) is materialised: every pass re-derives the edge features from the cloud and the neighbour indices.
+ * x:(B,3,N); idx:(B,N,20) int32; Wf, Wd:(21,3) = conv_pos.map_to_feat / map_to_dir weights; per-channel (21) vectors:
+ * scale = gamma*rstd, shift = beta - mean*scale, mean, rstd of n = |W_f f| + 1e-6 over all B*N*k edges.
+ * Partials are per block, blocks = B * eqa_vn_blocks(N), summed by the caller (fixed order: deterministic).
+ *   eqa_vn_knn                 idx <- the 20 nearest neighbours of every point (self included), best first
+ *   eqa_vn_convpos_stats       partial:(blocks, 21, 2) = sum n, sum n^2
+ *   eqa_vn_convpos_fwd         pooled:(B, 21, 3, N)
+ *   eqa_vn_convpos_bwd_reduce  partial:(blocks, 21, 2) = sum g, sum g*nhat   (g = dL/d BN output; = d beta, d gamma)
+ *   eqa_vn_convpos_bwd_apply   partial:(blocks, 21, 6) = d W_f[c][0..2], d W_d[c][0..2];  m1 = sum g / M, m2 = sum g nhat / M
+ *                              (M = B*N*k; zeros when the batch-norm uses running statistics)
+ */
+int eqa_vn_blocks(int N);
+int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream);
+int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, void* stream);
+int eqa_vn_convpos_fwd(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale, const float* shift,
+                       float* pooled, int B, int N, void* stream);
+int eqa_vn_convpos_bwd_reduce(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
+                              const float* shift, const float* mean, const float* rstd, const float* gpool, float* partial, int B,
+                              int N, void* stream);
+int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
+                             const float* shift, const float* mean, const float* rstd, const float* m1, const float* m2,
+                             const float* gpool, float* partial, int B, int N, void* stream);
+
+/*
  * P3 -- batched 3x3 classical Gram-Schmidt on rows (no epsilon, no handedness fix).
  * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
  */

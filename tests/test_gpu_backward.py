@@ -331,3 +331,73 @@ def test_input_gradient_gather_equals_atomic_scatter(dev):
         y = ops.group_action(src, gidx, th, fl, cmap, 0, (H, W), (0, 0))
         lhs, rhs = (y * gy).sum().item(), (src * g1).sum().item()
         assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.gpu
+def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
+    """VNSmall in train(): the recompute kernels of the first block (eqa_vn_*) vs the op-by-op path with the same weights:
+    output vectors, every parameter gradient, the batch-norm running statistics; and the kNN kernel vs torch.topk."""
+    import copy
+    import types
+
+    import equiadapt_amd as ea
+    from equiadapt_amd import _lib
+    from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import knn
+
+    torch.manual_seed(101)
+    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    net = ea.VNSmall(hp).to(dev)
+    net.dropout.p = 0.0
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    ref = copy.deepcopy(net)
+    x = torch.randn(5, 3, 200, device=dev)
+    # kNN: same neighbour SETS as topk on the reference's score matrix (order within the list is irrelevant for the mean)
+    lib = _lib.load()
+    idx = torch.empty(5, 200, 20, dtype=torch.int32, device=dev)
+    assert lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), 5, 200, 20, None) == 0
+    want = knn(x, 20)
+    assert torch.equal(idx.long().sort(-1).values, want.sort(-1).values)
+    # the block itself, with a FIXED upstream gradient, against the op-by-op block evaluated in fp64
+    from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import ConvPosMeanPool, get_graph_feature_cross
+
+    g_up = torch.randn(5, 21, 3, 200, device=dev)
+    for training in (True, False):
+        fast, op64 = copy.deepcopy(net).train(training), copy.deepcopy(net).double().train(training)
+        cp = fast.conv_pos
+        o1 = ConvPosMeanPool.apply(x, cp.map_to_feat.weight, cp.map_to_dir.weight, cp.batchnorm.bn2d.weight, cp.batchnorm.bn2d.bias,
+                                   cp.batchnorm.bn2d, 20)
+        (o1 * g_up).sum().backward()
+        o2 = op64.conv_pos(get_graph_feature_cross(x.double().unsqueeze(1), 20, want)).mean(-1)
+        (o2 * g_up.double()).sum().backward()
+        assert (o1.double() - o2).abs().max().item() <= 1e-5
+        for p1, p2 in zip(fast.conv_pos.parameters(), op64.conv_pos.parameters()):
+            assert (p1.grad.double() - p2.grad).abs().max().item() <= 1e-4 * p2.grad.abs().max().item()
+        for b1, b2 in zip(fast.conv_pos.buffers(), op64.conv_pos.buffers()):
+            assert torch.allclose(b1.double(), b2.double(), rtol=1e-5, atol=1e-7)
+    # the whole network.  Its later VN-ReLU gates (<q, d> >= 0) can flip on the 1e-6 differences between the two paths'
+    # pooled features; with 1000 points one flipped gate moves a gradient entry by up to ~1 %: hence the loose bound here.
+    for training in (True, False):
+        net.train(training)
+        ref.train(training)
+        w = torch.randn(5, 3, 3, device=dev)
+        for p in list(net.parameters()) + list(ref.parameters()):
+            p.grad = None
+        a1 = net(x)
+        monkeypatch.setenv("EQA_TRAIN_FAST", "0")
+        a2 = ref(x)
+        monkeypatch.delenv("EQA_TRAIN_FAST")
+        assert torch.allclose(a1, a2, atol=2e-5 * max(a2.abs().max().item(), 1.0))
+        (a1 * w).sum().backward()
+        (a2 * w).sum().backward()
+        for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+            assert (p1.grad is None) == (p2.grad is None), n1
+            if p2.grad is None:
+                continue
+            g = max(p2.grad.abs().max().item(), 1e-6)
+            assert (p1.grad - p2.grad).abs().max().item() <= 5e-2 * g, (training, n1, (p1.grad - p2.grad).abs().max().item(), g)
+        for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+            assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-6), n1
