@@ -139,3 +139,56 @@ def test_canonicalizer_rejects_bad_in_shape():
     net.group_type, net.num_rotations = "rotation", 4
     with pytest.raises(AssertionError):
         ea.GroupEquivariantImageCanonicalization(net, hp, (3, 32))
+
+
+@pytest.mark.gpu
+def test_random_shapes_all_actions_vs_oracle(dev):
+    """Seeded sweep over random (group, N, C, H, W, B): canonicalize, invert (scalar and regular) and the orbit expansion
+    against the oracle, plus LDS path == direct path.  Catches indexing slips that fixed shapes do not exercise (widths not
+    a multiple of 4, tiles straddling the image edge, channel counts that are not a multiple of the group order's slots)."""
+    import math
+    import random
+
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import device_tables
+
+    lib = _lib.load()
+    rng = random.Random(1234)
+    for it in range(24):
+        refl = rng.random() < 0.5
+        N = rng.choice([2, 4, 8, 3, 6])
+        G = 2 * N if refl else N
+        group_type = "roto-reflection" if refl else "rotation"
+        H = rng.choice([5, 7, 16, 31, 33, 48, 64, 70])
+        W = H if rng.random() < 0.6 else rng.choice([6, 9, 20, 37, 52, 66])
+        C = rng.choice([1, 2, 3, 5, 8])
+        B = rng.choice([1, 3, 6])
+        torch.manual_seed(it)
+        x = torch.randn(B, C, H, W)
+        gidx = torch.randint(0, G, (B,))
+        ang = torch.cat([io.group_angles(N)] * (2 if refl else 1))[gidx]
+        ref = (gidx >= N).float() if refl else None
+        pad = math.ceil(W * 0.5)
+        th, fl = device_tables("canonicalize", N, refl, (H + 2 * pad, W + 2 * pad), dev)
+        got = ops.canon_transform(x.to(dev), gidx.to(dev, torch.int32), th, fl, pad)
+        want = io.canonicalize_images(x, ang, ref, (3, H, W))
+        assert (got.cpu() - want).abs().max().item() <= 1e-3, ("canonicalize", it, group_type, N, C, H, W)
+        lib.eqa_set_option(0, 1)
+        try:
+            direct = ops.canon_transform(x.to(dev), gidx.to(dev, torch.int32), th, fl, pad)
+        finally:
+            lib.eqa_set_option(0, 0)
+        assert (got - direct).abs().max().item() <= 2e-6, ("lds vs direct", it)
+        thi, fli, cm = device_tables("invert", N, refl, (H, W), dev)
+        got = ops.invert_action(x.to(dev), gidx.to(dev, torch.int32), thi, fli, None).cpu()
+        want = io.invert_action(x, ang, ref, N, G, "scalar")
+        assert (got - want).abs().max().item() <= 1e-3, ("invert scalar", it, group_type, N, C, H, W)
+        f = torch.randn(B, 2 * G, H, W)
+        got = ops.invert_action(f.to(dev), gidx.to(dev, torch.int32), thi, fli, cm).cpu()
+        want = io.invert_action(f, ang, ref, N, G, "regular")
+        assert (got - want).abs().max().item() <= 1e-3, ("invert regular", it, group_type, N, H, W)
+        if H == W:  # the optimised canonicalizer's orbit is defined on square crops
+            tho, flo = device_tables("orbit", N, refl, (H + 2 * pad, W + 2 * pad), dev)
+            got = ops.orbit_expand(x.to(dev), tho, flo, pad).cpu()
+            want = io.orbit_expand(x, N, group_type, H)
+            assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-3, ("orbit", it, group_type, N, C, H)
