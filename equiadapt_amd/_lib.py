@@ -56,6 +56,8 @@ SIGNATURES = {
     "eqa_winograd_f2k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f2k5_input_padded": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
+    "eqa_winograd_f4k5_input_padded": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output_adjoint": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_output_adjoint": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output_sums_workspace_bytes": (ctypes.c_int64, [_int] * 4),

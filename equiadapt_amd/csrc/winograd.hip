@@ -104,11 +104,13 @@ __device__ __forceinline__ float wino_act(float v, float ib, int in_relu) {
 // as (B^T d) B: the vertical transform u[:, col] = B^T d[:, col] depends only on the input column, so it is computed
 // once per column and the N-column window slides by m per tile: m*N loads per tile instead of N*N.  The next tile's
 // columns are requested before the current tile's N*N stores are issued (the memory pipeline is in-order per CU).
-template <int N>
+// PAD: the logical input is x zero-padded by `pad` pixels on every side (the input gradient of the convolution is a
+// forward convolution of the padded output gradient); out-of-range taps read as 0 and are not activated.
+template <int N, bool PAD>
 __global__ __launch_bounds__(kThreads) void winograd_k5_input_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                                     const float* __restrict__ in_bias, int in_relu,
                                                                     int H, int W, int C, int TY, int TX, int nstrip,
-                                                                    int strip_len, size_t nwork) {
+                                                                    int strip_len, size_t nwork, int pad) {
   constexpr int MT = N - 4;
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
@@ -125,14 +127,23 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_input_kernel(const float
   const size_t img = r / TY;
   const int tx0 = s * strip_len;
   const int tx1 = min(TX, tx0 + strip_len);
-  const float* p = x + ((img * H + MT * ty) * (size_t)W + MT * tx0) * C + c;
+  // (with PAD the pointer may start before the image; it is only dereferenced for in-range rows / columns)
+  const int gy0 = MT * ty - (PAD ? pad : 0), gx0 = MT * tx0 - (PAD ? pad : 0);
+  const float* p = x + ((ptrdiff_t)(img * H) + gy0) * (ptrdiff_t)W * C + (ptrdiff_t)gx0 * C + c;
   const float ib = in_bias ? in_bias[c] : 0.0f;
+  auto tap = [&](const float* q, int i, int k, int gx_base, int tag) -> float {
+    if (PAD) {
+      const bool in = (unsigned)(gy0 + i) < (unsigned)H && (unsigned)(gx_base + k) < (unsigned)W;
+      return in ? wino_act(WINO_LD(q + ((ptrdiff_t)i * W + k) * C, tag), ib, in_relu) : 0.0f;
+    }
+    return wino_act(WINO_LD(q + ((ptrdiff_t)i * W + k) * C, tag), ib, in_relu);
+  };
   float u[N][N];  // u[i][k] = (B^T d)[i][window column k]
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     float d[N], t[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) d[i] = wino_act(WINO_LD(p + ((size_t)i * W + k) * C, i * N + k), ib, in_relu);
+    for (int i = 0; i < N; ++i) d[i] = tap(p, i, k, gx0, i * N + k);
     wino_bt(d, t);
 #pragma unroll
     for (int i = 0; i < N; ++i) u[i][k] = t[i];
@@ -142,11 +153,12 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_input_kernel(const float
     float nx[MT][N];
     const bool more = tx + 1 < tx1;  // uniform
     if (more) {
-      const float* pn = p + (size_t)(MT * (tx - tx0) + N) * C;
+      const int off = MT * (tx - tx0) + N;
+      const float* pn = p + (ptrdiff_t)off * C;
 #pragma unroll
       for (int k = 0; k < MT; ++k)
 #pragma unroll
-        for (int i = 0; i < N; ++i) nx[k][i] = WINO_LD(pn + ((size_t)i * W + k) * C, i * MT + k + tx);
+        for (int i = 0; i < N; ++i) nx[k][i] = tap(pn, i, k, gx0 + off, i * MT + k + tx);  // activated here
     }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -165,7 +177,7 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_input_kernel(const float
       for (int k = 0; k < MT; ++k) {
         float d[N], t[N];
 #pragma unroll
-        for (int i = 0; i < N; ++i) d[i] = wino_act(nx[k][i], ib, in_relu);
+        for (int i = 0; i < N; ++i) d[i] = nx[k][i];
         wino_bt(d, t);
 #pragma unroll
         for (int i = 0; i < N; ++i) u[i][N - MT + k] = t[i];
@@ -320,12 +332,13 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_output_sums_kernel(const
 
 template <int N>
 int launch_wino_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                      void* stream) {
+                      void* stream, int pad = 0) {
   constexpr int MT = N - 4;
-  if (!x || !V || nimg < 0 || H < N || W < N || C <= 0) return EQA_ERR_INVALID_ARG;
-  if (((H - 4) % MT) || ((W - 4) % MT)) return EQA_ERR_UNSUPPORTED;
+  const int Hl = H + 2 * pad, Wl = W + 2 * pad;  // logical (zero-padded) input
+  if (!x || !V || nimg < 0 || pad < 0 || H <= 0 || W <= 0 || Hl < N || Wl < N || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (((Hl - 4) % MT) || ((Wl - 4) % MT)) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
-  const int TY = (H - 4) / MT, TX = (W - 4) / MT;
+  const int TY = (Hl - 4) / MT, TX = (Wl - 4) / MT;
   // strips: enough blocks to fill 256 CUs x their resident blocks, long enough that the N*N-load prologue is amortised
   // (m*N further loads per tile); measured for m = 2 at 64 x 92 x 92 x 256: whole rows 1112 us, 8-tile strips 1289 us
   const int cb = (C + kThreads - 1) / kThreads;
@@ -336,8 +349,12 @@ int launch_wino_input(const float* x, float* V, const float* in_bias, int in_rel
   nstrip = (TX + strip_len - 1) / strip_len;
   const size_t nwork = rows * nstrip;
   if (nwork > 0x7fffffffULL || rows * TX > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL((winograd_k5_input_kernel<N>), dim3((unsigned)nwork, cb), dim3(kThreads), 0, (hipStream_t)stream, x,
-                     V, in_bias, in_relu, H, W, C, TY, TX, nstrip, strip_len, nwork);
+  if (pad)
+    hipLaunchKernelGGL((winograd_k5_input_kernel<N, true>), dim3((unsigned)nwork, cb), dim3(kThreads), 0, (hipStream_t)stream,
+                       x, V, in_bias, in_relu, H, W, C, TY, TX, nstrip, strip_len, nwork, pad);
+  else
+    hipLaunchKernelGGL((winograd_k5_input_kernel<N, false>), dim3((unsigned)nwork, cb), dim3(kThreads), 0, (hipStream_t)stream,
+                       x, V, in_bias, in_relu, H, W, C, TY, TX, nstrip, strip_len, nwork, 0);
   return launch_status();
 }
 
@@ -409,6 +426,13 @@ int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int 
 int eqa_winograd_f4k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                             void* stream) {
   return launch_wino_input<8>(x, V, in_bias, in_relu, nimg, H, W, C, stream);
+}
+
+int eqa_winograd_f2k5_input_padded(const float* x, float* V, int nimg, int H, int W, int C, int pad, void* stream) {
+  return launch_wino_input<6>(x, V, nullptr, 0, nimg, H, W, C, stream, pad);
+}
+int eqa_winograd_f4k5_input_padded(const float* x, float* V, int nimg, int H, int W, int C, int pad, void* stream) {
+  return launch_wino_input<8>(x, V, nullptr, 0, nimg, H, W, C, stream, pad);
 }
 
 int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,

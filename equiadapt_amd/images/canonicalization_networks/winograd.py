@@ -28,6 +28,7 @@ from equiadapt_amd.ops import _timed
 POINTS = {2: (0, 1, -1, 2, -2), 4: (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1, 2))}
 
 CHUNK_IMAGES = int(os.environ.get("EQA_WINOGRAD_CHUNK", "64"))
+KEEP_V_FOR_BACKWARD = os.environ.get("EQA_WINOGRAD_KEEP_V", "1") != "0"
 
 
 def _polymul(a: Sequence[Fraction], b: Sequence[Fraction]) -> List[Fraction]:
@@ -109,7 +110,7 @@ def sums_applicable(x: torch.Tensor, k_next: int, m: int = 2) -> bool:
     return nb in (2, 4) and nb % m == 0 and OH >= 2 * nb + m and OW >= 2 * nb + m
 
 
-def filter_grad(x: torch.Tensor, dY: torch.Tensor, m: int) -> torch.Tensor:
+def filter_grad(x: torch.Tensor, dY: torch.Tensor, m: int, V_saved: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dL/dU (P, Cin, Cout) of y = conv5x5(x, U):  dU[a] = V[:, a]^T dM[:, a]  with V = B^T x B (input transform) and
     dM = A dY A^T (eqa_winograd_f{m}k5_output_adjoint); x, dY channels-last (B,Cin,H,W) / (B,Cout,H-4,W-4)."""
     lib = _lib.load()
@@ -121,7 +122,8 @@ def filter_grad(x: torch.Tensor, dY: torch.Tensor, m: int) -> torch.Tensor:
     TY, TX = OH // m, OW // m
     f_in, f_adj = getattr(lib, f"eqa_winograd_f{m}k5_input"), getattr(lib, f"eqa_winograd_f{m}k5_output_adjoint")
     chunk = min(CHUNK_IMAGES * (m * m // 4), B)
-    V = torch.empty((chunk * TY * TX, P, Cin), dtype=torch.float32, device=x.device)
+    have_V = V_saved is not None and chunk == B
+    V = V_saved if have_V else torch.empty((chunk * TY * TX, P, Cin), dtype=torch.float32, device=x.device)
     dM = torch.empty((chunk * TY * TX, P, Cout), dtype=torch.float32, device=x.device)
     dU = torch.zeros((P, Cin, Cout), dtype=torch.float32, device=x.device)
     stream = torch.cuda.current_stream().cuda_stream
@@ -129,7 +131,8 @@ def filter_grad(x: torch.Tensor, dY: torch.Tensor, m: int) -> torch.Tensor:
         for b0 in range(0, B, chunk):
             nimg = min(chunk, B - b0)
             t = nimg * TY * TX
-            _lib.check(f_in(x.data_ptr() + b0 * H * W * Cin * 4, V.data_ptr(), None, 0, nimg, H, W, Cin, stream), "winograd input")
+            if not have_V:
+                _lib.check(f_in(x.data_ptr() + b0 * H * W * Cin * 4, V.data_ptr(), None, 0, nimg, H, W, Cin, stream), "winograd input")
             _lib.check(f_adj(dY.data_ptr() + b0 * OH * OW * Cout * 4, dM.data_ptr(), nimg, OH, OW, Cout, stream), "winograd output adjoint")
             # (P, Cin, t) x (P, t, Cout): both operands are strided views of the tile-major buffers, no copies
             dU.baddbmm_(V[:t].permute(1, 2, 0), dM[:t].permute(1, 0, 2))
@@ -143,38 +146,44 @@ class Conv5x5Function(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bank, m):
-        ctx.save_for_backward(x, bank)
+        keep: list = []
+        y = conv5x5(x, transform_filters(bank.detach(), m), None, False, keep_V=keep if KEEP_V_FOR_BACKWARD else None)
+        ctx.save_for_backward(x, bank, *keep)     # V (P/m^2 times the activation) is kept: HBM is 288 GB, a pass is 2 ms
         ctx.m = m
-        return conv5x5(x, transform_filters(bank.detach(), m), None, False)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, bank = ctx.saved_tensors
+        x, bank, *keep = ctx.saved_tensors
         m = ctx.m
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dbank = None
         if ctx.needs_input_grad[0]:
             bank_t = bank.detach().flip(-1, -2).transpose(0, 1).contiguous()       # (Cin, Cout, 5, 5)
-            dyp = torch.nn.functional.pad(dy, (4, 4, 4, 4)).contiguous(memory_format=torch.channels_last)
-            dx = conv5x5(dyp, transform_filters(bank_t, m), None, False)
+            dx = conv5x5(dy, transform_filters(bank_t, m), None, False, pad=4)   # zero padding inside the input transform
         if ctx.needs_input_grad[1]:
             n = m + 4
             G = g_matrix(m).to(dy.device)
-            dU = filter_grad(x, dy, m).double().view(n, n, bank.shape[1], bank.shape[0])
+            dU = filter_grad(x, dy, m, keep[0] if keep else None).double().view(n, n, bank.shape[1], bank.shape[0])
             dbank = torch.einsum("ak,bl,abio->oikl", G, G, dU).to(bank.dtype)
         return dx, dbank, None
 
 
 def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
+            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0, pad: int = 0,
+            keep_V: Optional[list] = None) -> torch.Tensor:
     """x: channels-last (B,Cin,H,W) -> channels-last (B,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias), g given as
     U = transform_filters(g, m) (m is read off U's plane count); act(x) = [relu](x + in_bias[c]) is applied while the
-    input tiles are loaded (previous layer's epilogue)."""
+    input tiles are loaded (previous layer's epilogue).  ``pad``: convolve x zero-padded by that many pixels (no padded copy
+    is made).  ``keep_V``: a list that receives the transformed input V when the batch is one chunk (training: the filter
+    gradient reuses it instead of transforming x again)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
+    xp_in, (H, W) = (H, W), (H + 2 * pad, W + 2 * pad)   # from here on H, W are the logical (padded) sizes
     P, _, Cout = U.shape
     m = {36: 2, 64: 4}[P]
     f_in, f_out, f_sums = (getattr(lib, f"eqa_winograd_f{m}k5_{n}") for n in ("input", "output", "output_sums"))
+    f_in_pad = getattr(lib, f"eqa_winograd_f{m}k5_input_padded")
     OH, OW = H - 4, W - 4
     TY, TX = OH // m, OW // m
     if sums_k:
@@ -199,7 +208,10 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
             n = min(chunk, B - b0)
             t = n * TY * TX
             with _timed("winograd_input"):
-                st = f_in(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
+                if pad:
+                    st = f_in_pad(xs + b0 * xp_in[0] * xp_in[1] * Cin * 4, V.data_ptr(), n, xp_in[0], xp_in[1], Cin, pad, stream)
+                else:
+                    st = f_in(xs + b0 * H * W * Cin * 4, V.data_ptr(), p_in_bias, int(in_relu), n, H, W, Cin, stream)
             _lib.check(st, f"eqa_winograd_f{m}k5_input")
             # plane a is the strided matrix V[:, a, :] (row stride P*Cin): no copy, the library takes lda / batch stride
             with _timed("winograd_gemm"):
@@ -213,4 +225,6 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
                 with _timed("winograd_output"):
                     st = f_out(M.data_ptr(), p_bias, int(relu), ys + b0 * OH * OW * Cout * 4, n, OH, OW, Cout, stream)
                 _lib.check(st, f"eqa_winograd_f{m}k5_output")
+    if keep_V is not None and chunk == B:
+        keep_V.append(V)
     return S if sums_k else y

@@ -252,6 +252,10 @@ int eqa_winograd_f4k5_output(const float* M, const float* bias, int relu, float*
  * adjoint of the output transform, dM = A dY A^T per tile, dY:(nimg,OH,OW,C) -> dM:(nimg*TY*TX, P, C).  The filter gradient
  * is then dU[a] = V[:,a]^T dM[:,a] (strided-batched GEMM by the caller, V from eqa_winograd_f{m}k5_input) and the input
  * gradient a forward Winograd convolution of the zero-padded dY with the flipped, transposed filters. */
+/* Input transform of x zero-padded by `pad` pixels on every side without materialising the padded tensor (pad = 4 for the
+ * input gradient): V:(nimg*TY*TX, P, C), TY = (H + 2 pad - 4)/m, TX = (W + 2 pad - 4)/m. */
+int eqa_winograd_f2k5_input_padded(const float* x, float* V, int nimg, int H, int W, int C, int pad, void* stream);
+int eqa_winograd_f4k5_input_padded(const float* x, float* V, int nimg, int H, int W, int C, int pad, void* stream);
 int eqa_winograd_f2k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream);
 int eqa_winograd_f4k5_output_adjoint(const float* dY, float* dM, int nimg, int OH, int OW, int C, void* stream);
 /* Output transform fused with eqa_window_sums_nhwc of the NEXT layer (kernel size k_next; k_next - 1 a multiple of m:

@@ -677,6 +677,12 @@ def test_winograd_conv_matches_direct(dev):
             got3 = winograd.conv5x5(x, U, bias, relu=True, in_bias=ib, in_relu=True)
             want3 = torch.relu(F.conv2d(torch.relu(x.double() + ib.double()[None, :, None, None]), g.double(), bias.double()))
             assert (got3.double() - want3).abs().max().item() <= 2e-5 * want3.abs().max().item()
+            # zero padding inside the input transform (no padded copy): against the fp64 convolution with padding=4, same bound
+            if (H + 8 - 4) % m == 0 and (W + 8 - 4) % m == 0:
+                a = winograd.conv5x5(x, U, None, relu=False, pad=4)
+                want_p = F.conv2d(x.double(), g.double(), padding=4)
+                assert a.shape == want_p.shape == (B, Cout, H + 4, W + 4)
+                assert (a.double() - want_p).abs().max().item() <= 2e-5 * want_p.abs().max().item(), (m, H, W)
     assert seen == {2, 4}
     # sizes the large tile does not divide are refused by the entry point itself
     from equiadapt_amd import _lib
