@@ -1,5 +1,6 @@
 """GPU: edge cases of the C-ABI entry points -- empty and ragged inputs, tiny / odd sizes, argument validation."""
 import ctypes
+import os
 import types
 
 import pytest
@@ -192,3 +193,27 @@ def test_random_shapes_all_actions_vs_oracle(dev):
             got = ops.orbit_expand(x.to(dev), tho, flo, pad).cpu()
             want = io.orbit_expand(x, N, group_type, H)
             assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-3, ("orbit", it, group_type, N, C, H)
+
+
+@pytest.mark.gpu
+def test_c_abi_from_plain_c(tmp_path):
+    """examples/c_abi_demo.c: the library driven from plain C (gcc, no Python / torch types in the interface), identity and
+    half-turn elements checked on the host inside the program."""
+    import shutil
+    import subprocess
+
+    from equiadapt_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_demo")
+    csrc = os.path.dirname(_lib.SO_PATH)
+    cmd = ["gcc", "-std=c11", "-D__HIP_PLATFORM_AMD__", os.path.join(root, "examples", "c_abi_demo.c"), "-I", os.path.join(root, "include"),
+           "-I", "/opt/rocm/include", "-L", csrc, "-leqa_hip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{csrc}",
+           "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+    assert "max |error|" in run.stdout
