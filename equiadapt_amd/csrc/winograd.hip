@@ -87,8 +87,12 @@ __device__ __forceinline__ void wino_a(const float (&d)[4], float (&t)[8]) {
 #endif
 #ifdef EQA_WABL_NOSTORE
 #define WINO_ST(ptr, v) do { if ((v) == 1.2345e-30f) *(ptr) = (v); } while (0)
-#else
+#elif defined(EQA_WINO_NO_NT)
 #define WINO_ST(ptr, v) (*(ptr) = (v))
+#else
+// V is written once and next read by the GEMM after 8 GB of other traffic: non-temporal stores keep it out of the caches
+// (measured 2016 vs 2060 us for the 256-image launch)
+#define WINO_ST(ptr, v) __builtin_nontemporal_store((v), (ptr))
 #endif
 #ifndef EQA_WINO_BLOCKS
 #define EQA_WINO_BLOCKS 4096
