@@ -97,6 +97,12 @@ __device__ __forceinline__ void wino_a(const float (&d)[4], float (&t)[8]) {
 #ifndef EQA_WINO_BLOCKS
 #define EQA_WINO_BLOCKS 4096
 #endif
+// M is read exactly once: streaming (non-temporal) loads, measured 1485 vs 1588 us for output + window sums at 256 images
+#ifdef EQA_WINO_NO_NT
+#define WINO_LDM(ptr) (*(ptr))
+#else
+#define WINO_LDM(ptr) __builtin_nontemporal_load(ptr)
+#endif
 // Optional on-the-fly activation of the INPUT: d = relu(x + in_bias[c]) (the previous layer's folded bias / batch-norm
 // and ReLU), which removes a separate pass over the previous feature map.
 __device__ __forceinline__ float wino_act(float v, float ib, int in_relu) {
@@ -199,7 +205,7 @@ __device__ __forceinline__ void wino_tile_out(const float* __restrict__ mp, int 
   for (int j = 0; j < N; ++j) {
     float m[N], y[MT];
 #pragma unroll
-    for (int i = 0; i < N; ++i) m[i] = mp[(size_t)(i * N + j) * C];
+    for (int i = 0; i < N; ++i) m[i] = WINO_LDM(mp + (size_t)(i * N + j) * C);
     wino_at(m, y);
 #pragma unroll
     for (int r = 0; r < MT; ++r) sc[r][j] = y[r];
