@@ -329,7 +329,18 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
           float* o = dst_img + (unsigned)(c0 + cc) * dst_plane + (unsigned)(i * a.OW + jb);
           if (VEC) {  // OW % 4 == 0 and jb % 4 == 0: a pixel quad is entirely inside or entirely outside the row
             if (jb < a.OW && EQA_ABL_STORE_OK(acc[cc][0]))
+#ifdef EQA_ACTION_NT
+            {
+              // opt-in: non-temporal stores.  They win only while the SOURCE fits the 256 MB Infinity Cache (B = 256 launched
+              // back to back: 47 vs 58 us); with the working set in HBM (B = 1024, or inside the real step) both forms run
+              // at the copy ceiling (226 us per 1024 images = 5.44 TB/s) and the regular stores drain after the kernel
+              typedef float f4v __attribute__((ext_vector_type(4)));
+              f4v v4 = {acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]};
+              __builtin_nontemporal_store(v4, reinterpret_cast<f4v*>(o));
+            }
+#else
               *reinterpret_cast<float4*>(o) = make_float4(acc[cc][0], acc[cc][1], acc[cc][2], acc[cc][3]);
+#endif
           } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
