@@ -107,6 +107,43 @@ def cpu_baseline(sample: int, reps: int):
             "group_action_only_images_s": sample / ga}
 
 
+def cpu_baseline_config(name: str, state: dict):
+    """cpu_baseline leg for the other BASELINE configs (used by tools/bench_configs.py): the oracle's op sequence on the host,
+    16 threads, bounded sample.  `state` carries the network weights of the GPU run so both sides compute the same thing."""
+    from oracle import image_ops as io
+    from oracle import nets as onets
+    from oracle import pointcloud_ops as po
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+    def timed(fn, reps):
+        with torch.no_grad():
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+        return (time.perf_counter() - t0) / reps
+
+    if name == "cfg1":
+        xs, fs, sd = torch.randn(128, 3, 32, 32), torch.randn(128, 3, 32, 32), state["sd"]
+
+        def f1():
+            acts = onets.custom_equivariant_network(io.pre_canonicalization_transform(xs, (3, 32, 32), 1.0, 32), sd, "rotation", 4, 2)
+            el = io.group_element_from_activations(acts, 4, "rotation", 1.0, training=False)
+            return io.canonicalize_images(xs, el["rotation"], None, (3, 32, 32)), io.invert_action(fs, el["rotation"], None, 4, 4, "scalar")
+        dt = timed(f1, 5)
+        return {"images_s": 128 / dt, "ms": dt * 1e3, "sample": "B=128, 16 threads"}
+    if name == "cfg4":
+        pcs, sd = torch.randn(4, 3, 1024), state["sd"]
+        dt = timed(lambda: po.canonicalize_pointcloud(pcs, po.gram_schmidt(po.vnsmall_forward(pcs, sd))), 2)
+        return {"clouds_s": 4 / dt, "ms": dt * 1e3, "sample": "B=4, 16 threads"}
+    if name == "cfg5":  # transform + invert only (the orbit / network part is a few ms either way)
+        x1, ang, refl = torch.randn(1, 3, 1024, 1024), torch.tensor([90.0]), torch.tensor([1.0])
+        dt = timed(lambda: (io.canonicalize_images(x1, ang, refl, (3, 1024, 1024)), io.invert_action(x1[:, :1], ang, refl, 4, 8, "scalar")), 2)
+        return {"images_s": 1 / dt, "ms": dt * 1e3, "sample": "B=1, 16 threads"}
+    raise ValueError(name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

@@ -19,9 +19,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import equiadapt_amd as ea  # noqa: E402
-from oracle import image_ops as io  # noqa: E402
-from oracle import nets as onets  # noqa: E402
-from oracle import pointcloud_ops as po  # noqa: E402
+import bench  # noqa: E402  (the CPU-oracle legs live in bench.py next to its cpu_baseline)
 
 
 def gpu_time(fn, reps=20, warm=3):
@@ -33,16 +31,6 @@ def gpu_time(fn, reps=20, warm=3):
         for _ in range(reps):
             fn()
         torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps
-
-
-def cpu_time(fn, reps=2):
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    with torch.no_grad():
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
     return (time.perf_counter() - t0) / reps
 
 
@@ -65,18 +53,9 @@ def main():
         f = torch.randn(B, 3, 32, 32, device=dev)
         dt = gpu_time(lambda: (can(x), can.invert_canonicalization(f, induced_rep_type="scalar")))
         res[f"cfg1_cifar32_c4_B{B}"] = {"images_s": B / dt, "ms": dt * 1e3}
-    xs, fs = torch.randn(128, 3, 32, 32), torch.randn(128, 3, 32, 32)
-
-    def cpu1():
-        acts = onets.custom_equivariant_network(io.pre_canonicalization_transform(xs, (3, 32, 32), 1.0, 32), sd, "rotation", 4, 2)
-        el = io.group_element_from_activations(acts, 4, "rotation", 1.0, training=False)
-        return io.canonicalize_images(xs, el["rotation"], None, (3, 32, 32)), io.invert_action(fs, el["rotation"], None, 4, 4, "scalar")
-    dt = cpu_time(cpu1, 5)
-    res["cfg1_cifar32_c4_cpu_oracle"] = {"images_s": 128 / dt, "ms": dt * 1e3, "sample": "B=128, 16 threads"}
+    res["cfg1_cifar32_c4_cpu_oracle"] = bench.cpu_baseline_config("cfg1", {"sd": sd})
 
     # ---- cfg2: headline (same construction as bench.py)
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
     can2 = bench.build_canonicalizer(dev)
     x = torch.randn(256, 3, 224, 224, device=dev)
     f = torch.randn(256, 3, 224, 224, device=dev)
@@ -94,13 +73,7 @@ def main():
         pc = torch.randn(B, 3, 1024, device=dev)
         dt = gpu_time(lambda: can4(pc))
         res[f"cfg4_modelnet1024_so3_B{B}"] = {"clouds_s": B / dt, "ms": dt * 1e3}
-    pcs = torch.randn(4, 3, 1024)
-
-    def cpu4():
-        R = po.gram_schmidt(po.vnsmall_forward(pcs, sd4))
-        return po.canonicalize_pointcloud(pcs, R)
-    dt = cpu_time(cpu4, 2)
-    res["cfg4_modelnet1024_so3_cpu_oracle"] = {"clouds_s": 4 / dt, "ms": dt * 1e3, "sample": "B=4, 16 threads"}
+    res["cfg4_modelnet1024_so3_cpu_oracle"] = bench.cpu_baseline_config("cfg4", {"sd": sd4})
 
     # ---- cfg5: COCO shape, D4, optimised canonicalizer, masks
     torch.manual_seed(2)
@@ -120,13 +93,7 @@ def main():
             return y, t, can5.invert_canonicalization(pred, induced_rep_type="scalar")
         dt = gpu_time(step5, reps=10)
         res[f"cfg5_coco1024_d4_B{B}"] = {"images_s": B / dt, "ms": dt * 1e3, "note": "3 uint8 masks + 3 boxes per image as targets"}
-    x1 = torch.randn(1, 3, 1024, 1024)
-    ang, refl = torch.tensor([90.0]), torch.tensor([1.0])
-
-    def cpu5():  # transform + invert only (the orbit / network part is a few ms either way)
-        return io.canonicalize_images(x1, ang, refl, (3, 1024, 1024)), io.invert_action(x1[:, :1], ang, refl, 4, 8, "scalar")
-    dt = cpu_time(cpu5, 2)
-    res["cfg5_coco1024_d4_cpu_oracle_transform_only"] = {"images_s": 1 / dt, "ms": dt * 1e3, "sample": "B=1, 16 threads"}
+    res["cfg5_coco1024_d4_cpu_oracle_transform_only"] = bench.cpu_baseline_config("cfg5", {})
 
     for k, v in res.items():
         print(k, json.dumps(v))
