@@ -34,3 +34,16 @@ def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:
     No epsilon and no handedness fix: the result is in O(3), determinant may be -1, like the reference.
     """
     return _GramSchmidtFn.apply(vectors)
+
+
+def update_running_stats(bn: torch.nn.modules.batchnorm._BatchNorm, mean: torch.Tensor, var_unbiased: torch.Tensor) -> None:
+    """What nn.BatchNorm*d does to its buffers in a training-mode forward: num_batches_tracked += 1, then an exponential
+    average with `momentum` (or the cumulative average 1/num_batches_tracked when momentum is None).  No-op when the module
+    does not track running statistics."""
+    if not bn.track_running_stats or bn.running_mean is None:
+        return
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+        m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+        bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
+        bn.running_var.mul_(1 - m).add_(m * var_unbiased.to(bn.running_var.dtype))

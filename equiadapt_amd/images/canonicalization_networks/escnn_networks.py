@@ -25,6 +25,7 @@ from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_lay
     RotoReflectionEquivariantConv,
     RotoReflectionEquivariantConvLift,
 )
+from equiadapt_amd.common.utils import update_running_stats
 from equiadapt_amd.images.canonicalization_networks import winograd
 from equiadapt_amd.images.canonicalization_networks.pooling import (
     WindowSumsFunction,
@@ -55,7 +56,7 @@ class InnerBnReluDropout(torch.autograd.Function):
         npix = Bn * H * W
         st = ops._stream()
         with torch.cuda.device(h.device):
-            if bn.training:
+            if bn.training or bn.running_mean is None:
                 nblk = lib.eqa_bn_partial_blocks(npix)
                 part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
                 _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
@@ -63,11 +64,8 @@ class InnerBnReluDropout(torch.autograd.Function):
                 n = npix * E
                 mean = sums[:, 0] / n
                 var = (sums[:, 1] / n - mean * mean).clamp_min(0.0)
-                m = bn.momentum
                 full_mean = mean if conv_bias is None else mean + conv_bias.detach().double()
-                bn.running_mean.mul_(1 - m).add_(m * full_mean.to(bn.running_mean.dtype))
-                bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1, 1))).to(bn.running_var.dtype))
-                bn.num_batches_tracked += 1
+                update_running_stats(bn, full_mean, var * (n / max(n - 1, 1)))
                 mean, var = mean.float(), var.float()
             else:
                 mean = bn.running_mean if conv_bias is None else bn.running_mean - conv_bias.detach()
@@ -82,7 +80,7 @@ class InnerBnReluDropout(torch.autograd.Function):
             _lib.check(lib.eqa_bn_relu_dropout_nhwc(h.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), npix, C, p_eff,
                                                     seed, st), "eqa_bn_relu_dropout_nhwc")
         ctx.save_for_backward(h, y, weight, mean.repeat_interleave(E).contiguous(), rstd.repeat_interleave(E).contiguous())
-        ctx.E, ctx.p, ctx.batch_stats = E, p_eff, bn.training
+        ctx.E, ctx.p, ctx.batch_stats = E, p_eff, bool(bn.training or bn.running_mean is None)
         return y
 
     @staticmethod
@@ -262,18 +260,15 @@ class ESCNNEquivariantNetwork(nn.Module):
         bias only shifts the mean (it cancels in the normalised output), so it enters the running mean and nowhere else."""
         Bn, C, H, W = h.shape
         Fd = C // E
-        if bn.training:
+        if bn.training or bn.running_mean is None:
             n = Bn * E * H * W
             s1 = h.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1)
             s2 = (h * h).sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1)
             mean = s1 / n
             var = (s2 / n - mean * mean).clamp_min(0.0)
             with torch.no_grad():
-                m = bn.momentum
                 full_mean = mean if conv_bias is None else mean + conv_bias.double()
-                bn.running_mean.mul_(1 - m).add_(m * full_mean.to(bn.running_mean.dtype))
-                bn.running_var.mul_(1 - m).add_(m * (var * (n / max(n - 1, 1))).to(bn.running_var.dtype))
-                bn.num_batches_tracked += 1
+                update_running_stats(bn, full_mean, var * (n / max(n - 1, 1)))
             mean, var = mean.float(), var.float()
         else:
             mean = bn.running_mean if conv_bias is None else bn.running_mean - conv_bias

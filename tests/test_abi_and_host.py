@@ -210,3 +210,22 @@ def test_continuous_group_reference_api_cases():
             c.get_groupelement(torch.rand(1, 3, 64, 64))
     g = ea.ContinuousGroupImageCanonicalization(torch.nn.Identity(), hp, (1, 28, 28))
     assert isinstance(g.pad, torch.nn.Identity) and isinstance(g.resize_canonization, torch.nn.Identity) and g.pad_size == 0
+
+
+def test_update_running_stats_matches_nn_batchnorm():
+    """common.utils.update_running_stats == what nn.BatchNorm2d does to its buffers in a training forward, for a numeric
+    momentum, for momentum=None (cumulative average) and with track_running_stats=False."""
+    from equiadapt_amd.common.utils import update_running_stats
+
+    torch.manual_seed(4)
+    for momentum in (0.1, 0.9, None):
+        a, b = torch.nn.BatchNorm2d(5, momentum=momentum), torch.nn.BatchNorm2d(5, momentum=momentum)
+        for _ in range(3):
+            x = torch.randn(4, 5, 6, 7) * 2 + 1
+            a.train()(x)
+            update_running_stats(b, x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=True))
+        assert torch.allclose(a.running_mean, b.running_mean, atol=1e-6) and torch.allclose(a.running_var, b.running_var, atol=1e-5)
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 3
+    c = torch.nn.BatchNorm2d(5, track_running_stats=False)
+    update_running_stats(c, torch.zeros(5), torch.ones(5))          # no buffers: nothing to do, must not raise
+    assert c.running_mean is None
