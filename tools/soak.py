@@ -1,0 +1,26 @@
+"""Soak: many inference and training steps, memory watched for growth.  python tools/soak.py"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+dev = torch.device("cuda:0")
+can = bench.build_canonicalizer(dev)
+x = torch.randn(256, 3, 224, 224, device=dev); f = torch.randn(256, 3, 224, 224, device=dev)
+marks = []
+with torch.no_grad():
+    for i in range(400):
+        y = can(x); o = can.invert_canonicalization(f, induced_rep_type="scalar")
+        if i in (20, 399):
+            torch.cuda.synchronize(); marks.append((torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
+print("inference: allocated/reserved GB after 20 and 400 steps:", marks)
+assert abs(marks[1][0] - marks[0][0]) < 0.05 and marks[1][1] <= marks[0][1] * 1.05 + 0.1
+can.train(); opt = torch.optim.SGD(can.parameters(), lr=1e-4); marks = []
+w = torch.randn(256, 3, 224, 224, device=dev)
+for i in range(40):
+    opt.zero_grad(set_to_none=True)
+    loss = (can(x) * w).mean() + can.get_prior_regularization_loss()
+    loss.backward(); opt.step()
+    if i in (5, 39):
+        torch.cuda.synchronize(); marks.append((torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9)); assert torch.isfinite(loss)
+print("training: allocated/reserved GB after 5 and 40 steps:", marks)
+assert abs(marks[1][0] - marks[0][0]) < 0.05 and marks[1][1] <= marks[0][1] * 1.05 + 0.1
+print("soak ok")
