@@ -19,7 +19,8 @@ namespace {
 //    0 -> elements 0..7, half 1 -> elements R-8..R-1 (lane stride Cin dwords: conflict-free for odd Cin).  For R < 16 the
 //    halves overlap; the duplicated elements carry weight 0 in half 1 (packing below), so only elements of the pixel's
 //    own receptive field enter its sum.
-//  * Epilogue: bias + ReLU on the accumulators, 128 B (32 channels) per half-wave store.
+//  * The MFMA takes the weights as A and the pixels as B: the accumulators are C[channel][pixel], each lane holds groups of 4
+//    consecutive channels of one pixel; epilogue = bias + ReLU + one 16-byte store per group (8 per tile and wave).
 // Packed weights (host): wpk[(ky*8 + q)*2 + h][co] = w[co][ci][ky][kx],  j = (R-8)*h + q, kx = j / Cin, ci = j % Cin,
 // and 0 where h == 1 and q < 16 - R.
 // MFMA work at the headline shape (256 x 92 rows x 3 tiles, K = 80 incl. padding, 256 channels): 92.6 GFLOP -> 0.59 ms
@@ -80,26 +81,23 @@ __device__ __forceinline__ void lift_tile_pos(unsigned tile, unsigned tiles_per_
   ox0 = MASKED ? 0u : min(tx * 32u, (unsigned)OW - 32u);
 }
 
-// Epilogue of accumulator register i of a finished tile.  C/D map of the 32x32 MFMA: column = lane & 31,
-// row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5): register i of acc0 holds channels 0..31 of pixel r (lanes 0-31) and of
-// pixel r+4 (lanes 32-63), acc1 the same for channels 32..63.  Stored as they are, every instruction writes two 128-byte
-// pieces 4 pixels apart (measured: 960 us, the store path being the limit whatever the schedule).  v_permlane32_swap
-// exchanges acc0's upper half with acc1's lower half: one register then holds the 64 contiguous channels of pixel r, the
-// other those of pixel r+4 -- one 256-byte run per store.
+// Epilogue.  The MFMA is issued with the WEIGHTS as the A operand and the pixels as B, so the 32x32 result is
+// C[channel][pixel]: lane l holds pixel l & 31 and, in register r, channel (r & 3) + 8*(r >> 2) + 4*(l >> 5) of the
+// 32-channel tile -- four groups of four CONSECUTIVE channels.  One group = one 16-byte store per lane: 8 store instructions
+// per tile and wave instead of the 32 dword stores of the pixel-major layout (with 8 waves per CU those 256 store
+// instructions per tile period were suspected of holding the MFMAs of their waves up; measured, the time is the same).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <bool MASKED>
-__device__ __forceinline__ void lift_store_reg(int i, const f32x16& p0, const f32x16& p1, float bias_l, float lo,
-                                               float* __restrict__ o, int Cout, int rows_left) {
-  const int row = (i & 3) + 8 * (i >> 2);
-  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0[i]), __float_as_uint(p1[i]), false, false);
-  const float v0 = fmaxf(__uint_as_float(sw[0]) + bias_l, lo), v1 = fmaxf(__uint_as_float(sw[1]) + bias_l, lo);
+__device__ __forceinline__ void lift_store_group(int g, const f32x16& p, const f32x4& bias4, float lo, float* __restrict__ o,
+                                                 int col, int cols_left) {
+  f32x4 v;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = fmaxf(p[4 * g + k] + bias4[k], lo);
 #ifdef EQA_LABL_NOSTORE
-  if (v0 == 1.2345e-30f) {
-    o[(size_t)row * Cout] = v0;
-    o[(size_t)(row + 4) * Cout] = v1;
-  }
+  if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(o + 8 * g) = v;
 #else
-  if (!MASKED || row < rows_left) o[(size_t)row * Cout] = v0;
-  if (!MASKED || row + 4 < rows_left) o[(size_t)(row + 4) * Cout] = v1;
+  if (!MASKED || col < cols_left) *reinterpret_cast<f32x4*>(o + 8 * g) = v;
 #endif
 }
 
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float
                                                                     unsigned ntiles, size_t x_last) {
   __shared__ float lds[2][KH * kLiftRow];
   constexpr int NM = KH * 16;      // MFMAs per tile and wave (KH*8 k-steps x 2 N-tiles)
-  constexpr int PER = NM / 16;     // MFMAs between two epilogue slices
+  constexpr int PER = NM / 8;      // MFMAs between two epilogue groups
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // a wave past the last 64-channel slice redoes an earlier slice (same values, same addresses) instead of idling: it
   // must take part in the staging and the barriers anyway, and the loop stays branch-free
@@ -124,7 +122,13 @@ __global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float
     b0[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0];
     b1[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0 + 32];
   }
-  const float bias_l = bias ? bias[slice * 64 + lane] : 0.0f;  // after the half swap lane l holds channel slice*64 + l
+  f32x4 bias4[2][4];  // this lane's channels: slice*64 + 32*t + 8*g + 4*h + {0..3}
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bias4[t][gq][k] = bias ? bias[slice * 64 + 32 * t + 8 * gq + 4 * h + k] : 0.0f;
   const float lo = relu ? 0.0f : -__builtin_huge_valf();
   const int n_el = 31 * Cin + R;
   const int a_off = Cin * col + (R - 8) * h;  // this lane's first element inside a staged row
@@ -161,33 +165,34 @@ __global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float
     for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
     // The waves sharing a SIMD fall into step (they wait for the same MFMA pipe), so an epilogue that is a phase of
     // its own leaves the pipe idle: measured 70 % MFMA-busy with 2, 3 or 4 waves per SIMD alike.  Hence the previous
-    // tile's bias / ReLU / stores are issued in 16 slices between this tile's MFMAs.
+    // tile's bias / ReLU / stores are issued in 8 groups between this tile's MFMAs.
     if (have_prev) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int m = PER * i; m < PER * i + PER; ++m) {
           const int step = m >> 1;
-          if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step >> 3][step & 7], b1[step], acc1, 0, 0, 0);
-          else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step >> 3][step & 7], b0[step], acc0, 0, 0, 0);
+          if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[step], a[step >> 3][step & 7], acc1, 0, 0, 0);
+          else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[step], a[step >> 3][step & 7], acc0, 0, 0, 0);
         }
-        lift_store_reg<MASKED>(i, p0, p1, bias_l, lo, po, Cout, p_left);
+        if (i < 4) lift_store_group<MASKED>(i, p0, bias4[0][i], lo, po, col, p_left);
+        else lift_store_group<MASKED>(i - 4, p1, bias4[1][i - 4], lo, po + 32, col, p_left);
         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);  // PER MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // the slice's VALU (swap, add, max, address)
-        __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);    // its two stores
+        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // the group's VALU (add, max)
+        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // its store
       }
     } else {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const int step = m >> 1;
-        if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step >> 3][step & 7], b1[step], acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[step >> 3][step & 7], b0[step], acc0, 0, 0, 0);
+        if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[step], a[step >> 3][step & 7], acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[step], a[step >> 3][step & 7], acc0, 0, 0, 0);
       }
     }
     lift_tile_pos<MASKED>(tile, tiles_per_row, OW, rowid, ox0);
     p0 = acc0;
     p1 = acc1;
-    po = y + ((size_t)rowid * OW + ox0) * Cout + slice * 64 + lane;
+    po = y + ((size_t)rowid * OW + ox0 + col) * Cout + slice * 64 + 4 * h;
     p_left = OW - (int)ox0;
     have_prev = true;
     if (next >= ntiles) break;
@@ -197,7 +202,10 @@ __global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float
     tile = next;
   }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) lift_store_reg<MASKED>(i, p0, p1, bias_l, lo, po, Cout, p_left);
+  for (int g = 0; g < 4; ++g) {
+    lift_store_group<MASKED>(g, p0, bias4[0][g], lo, po, col, p_left);
+    lift_store_group<MASKED>(g, p1, bias4[1][g], lo, po + 32, col, p_left);
+  }
 }
 
 }  // namespace
