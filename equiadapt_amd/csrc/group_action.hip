@@ -636,6 +636,9 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
 // resampled input rows live in LDS.
 // ------------------------------------------------------------------------------------------------
 constexpr int kAaBand = 8;
+#ifndef EQA_AA_WIDE_MIN_K
+#define EQA_AA_WIDE_MIN_K 8  // filters wider than this take the LDS row-staged kernel
+#endif
 constexpr int kAaMaxK = 20;  // taps kept in registers by the wide-filter kernel (K = 17 at 8x down-sampling)
 
 __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -1026,7 +1029,7 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
   if (lds > 96 * 1024 || planes > 65535) return EQA_ERR_UNSUPPORTED;
   if (planes == 0) return EQA_OK;
   const dim3 grid((OH + kAaBand - 1) / kAaBand, planes);
-  if (K > 8 && x_span > 0 && x_begin >= 0 && x_begin + x_span <= W) {
+  if (K > EQA_AA_WIDE_MIN_K && x_span > 0 && x_begin >= 0 && x_begin + x_span <= W) {
     // wide filters: stage the input rows in LDS.  Lanes read ~x_span / OW floats apart; make that stride odd.
     const int stride = (x_span + OW / 2) / OW;
     const int pad_shift = (stride >= 2 && (stride & 1) == 0) ? __builtin_ctz((unsigned)stride) : 0;
