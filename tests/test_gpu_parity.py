@@ -910,3 +910,51 @@ def test_nearest_action_tiled_equals_direct(dev):
     finally:
         lib.eqa_set_option(0, 0)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 8), ("roto-reflection", 4)])
+def test_escnn_four_layers_two_winograd_layers(dev, group_type, N, monkeypatch):
+    """ESCNNEquivariantNetwork with num_layers = 4 and 64 channels (8 fields x |G| = 8): lifting MFMA conv -> two Winograd
+    F(4x4,5x5) layers in sequence (the second consumes the first through the fused bias/ReLU, the last one emits window sums)
+    -> linear tail.  Inference against the oracle; training path against the plain module sequence."""
+    import copy
+
+    import equiadapt_amd as ea
+    from oracle import nets as onets
+
+    torch.manual_seed(111)
+    net = ea.ESCNNEquivariantNetwork((3, 36, 36), 8, 5, group_type, N, 4)
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0.1, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = net.to(dev).eval()
+    x = torch.randn(6, 3, 36, 36)
+    with torch.no_grad():
+        fast = net(x.to(dev)).cpu()
+    G = N if group_type == "rotation" else 2 * N
+    assert fast.shape == (6, G)
+    want = onets.escnn_like_network(x, {k: v.cpu() for k, v in net.state_dict().items()}, group_type, N, 4, 8)
+    assert torch.allclose(fast, want, atol=5e-5, rtol=1e-3), (fast - want).abs().max().item()
+    # training
+    ref = copy.deepcopy(net)
+    net.train()
+    ref.train()
+    xd = x.to(dev)
+    w = torch.randn(6, G, device=dev)
+    a1 = net(xd)
+    monkeypatch.setenv("EQA_TRAIN_FAST", "0")
+    a2 = ref(xd)
+    monkeypatch.delenv("EQA_TRAIN_FAST")
+    assert (a1 - a2).abs().max().item() <= 5e-5 * max(a2.abs().max().item(), 1.0)
+    (a1 * w).sum().backward()
+    (a2 * w).sum().backward()
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        g = p2.grad.abs().max().item()
+        if g <= 1e-5:
+            continue
+        assert (p1.grad - p2.grad).abs().max().item() <= 5e-3 * g, (n1, (p1.grad - p2.grad).abs().max().item(), g)
