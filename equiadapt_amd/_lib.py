@@ -26,6 +26,9 @@ _int = ctypes.c_int
 SIGNATURES = {
     "eqa_abi_version": (_int, []),
     "eqa_set_option": (_int, [_int, _int]),
+    "eqa_get_option": (_int, [_int]),
+    "eqa_fold_edge_pad_workspace_bytes": (ctypes.c_int64, [_int] * 4),
+    "eqa_fold_edge_pad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_canon_transform_fwd": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
     "eqa_invert_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
     "eqa_orbit_expand_fwd": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),

@@ -565,6 +565,49 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_gather_kernel(const
   }
 }
 
+// Adjoint of the replicate ("edge") padding: gsrc[sy][sx] = sum of gframe over the frame pixels that clamp to (sy, sx) --
+// itself for interior pixels, a strip of pad+1 pixels on the borders, a (pad+1)^2 square in the corners.  Together with the
+// gather above run on the padded frame as its source this is the deterministic input gradient of the canonicalizing
+// transform I5 (pad -> [flip] -> rotate -> crop).  Separable: fold the columns of every frame row (the two border sums
+// by a block reduction), then the rows of every column (one thread per column, coalesced over columns).
+__global__ __launch_bounds__(kThreads) void fold_edge_pad_x_kernel(const float* __restrict__ gframe, float* __restrict__ tmp,
+                                                                  int W, int pad) {
+  __shared__ float s_red[2][kThreads / 64];
+  const int Wp = W + 2 * pad;
+  const size_t row = blockIdx.x;  // plane * Hp + fy
+  const float* g = gframe + row * Wp;
+  float* o = tmp + row * W;
+  for (int sx = 1 + threadIdx.x; sx < W - 1; sx += kThreads) o[sx] = g[sx + pad];
+  float l = 0.f, r = 0.f;  // left border: frame columns [0, pad]; right border: [pad + W - 1, Wp - 1]
+  for (int k = threadIdx.x; k <= pad; k += kThreads) { l += g[k]; r += g[pad + W - 1 + k]; }
+  l = wave_sum_f(l);
+  r = wave_sum_f(r);
+  if ((threadIdx.x & 63) == 0) { s_red[0][threadIdx.x >> 6] = l; s_red[1][threadIdx.x >> 6] = r; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f, c = 0.f;
+    for (int w = 0; w < kThreads / 64; ++w) { a += s_red[0][w]; c += s_red[1][w]; }
+    if (W == 1) o[0] = a + c - g[pad];  // both strips contain the single column once too often
+    else { o[0] = a; o[W - 1] = c; }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void fold_edge_pad_y_kernel(const float* __restrict__ tmp, float* __restrict__ gsrc,
+                                                                  int H, int W, int pad) {
+  const int sx = blockIdx.x * kThreads + threadIdx.x;
+  if (sx >= W) return;
+  const int Hp = H + 2 * pad;
+  const size_t plane = blockIdx.y;
+  const float* t = tmp + plane * (size_t)Hp * W + sx;
+  float* o = gsrc + plane * (size_t)H * W + sx;
+  float top = 0.f, bot = 0.f;
+  for (int k = 0; k <= pad; ++k) { top += t[(size_t)k * W]; bot += t[(size_t)(pad + H - 1 + k) * W]; }
+  if (H == 1) { o[0] = top + bot - t[(size_t)pad * W]; return; }
+  o[0] = top;
+  o[(size_t)(H - 1) * W] = bot;
+  for (int sy = 1; sy < H - 1; ++sy) o[(size_t)sy * W] = t[(size_t)(sy + pad) * W];
+}
+
 template <int CH>
 int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
@@ -960,6 +1003,27 @@ int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, co
 extern "C" {
 
 int eqa_abi_version(void) { return 2; }  // 2: eqa_crop_resize_aa gained x_begin, x_span
+
+int eqa_get_option(int key) { return key == 0 ? g_force_direct : EQA_ERR_INVALID_ARG; }
+
+int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad) {
+  if (planes <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
+  return (int64_t)planes * (H + 2 * pad) * W * (int64_t)sizeof(float);
+}
+
+int eqa_fold_edge_pad(const float* gframe, float* gsrc, void* workspace, int planes, int H, int W, int pad, void* stream) {
+  if (planes < 0 || H <= 0 || W <= 0 || pad < 0) return EQA_ERR_INVALID_ARG;
+  if (planes == 0) return EQA_OK;
+  if (!gframe || !gsrc || !workspace) return EQA_ERR_INVALID_ARG;
+  const size_t rows = (size_t)planes * (H + 2 * pad);
+  if (rows > 0x7fffffffULL || planes > 65535) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(fold_edge_pad_x_kernel, dim3((unsigned)rows), dim3(kThreads), 0, st, gframe, (float*)workspace, W, pad);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(fold_edge_pad_y_kernel, dim3((W + kThreads - 1) / kThreads, planes), dim3(kThreads), 0, st,
+                     (const float*)workspace, gsrc, H, W, pad);
+  return launch_status();
+}
 
 int eqa_set_option(int key, int value) {
   if (key == 0) {

@@ -135,6 +135,25 @@ def group_action_bwd(
     flags, p_flags = _opt(flags, "flags", torch.int32)
     chan_map, p_map = _opt(chan_map, "chan_map", torch.int32)
     G = chan_map.shape[1] if chan_map is not None else 1
+    if want_src and pad > 0 and gidx is not None and n_out == B and chan_map is None and not lib.eqa_get_option(0):
+        # edge-padded transform (canonicalize): deterministic, atomics-free input gradient in two steps -- the gather adjoint
+        # on the padded FRAME as its source (dL/d frame), then the adjoint of the replicate padding (strips and corners folded
+        # onto the image borders).  The transform gradient, if wanted, comes from the ordinary call below without grad_src.
+        Hp, Wp = H + 2 * pad, W + 2 * pad
+        g_frame = torch.empty((B, C, Hp, Wp), dtype=torch.float32, device=src.device)
+        with torch.cuda.device(src.device):
+            st = lib.eqa_group_action_bwd(g_frame.data_ptr(), grad_out.data_ptr(), p_gidx, theta.data_ptr(), p_flags, None,
+                                          g_frame.data_ptr(), None, E, 1, n_out, B, C, Hp, Wp, 0, OH, OW, top_left[0], top_left[1],
+                                          _stream())
+            _lib.check(st, "eqa_group_action_bwd (frame gather)")
+            g_src = torch.empty_like(src)
+            ws = torch.empty((lib.eqa_fold_edge_pad_workspace_bytes(B * C, H, W, pad) // 4,), dtype=torch.float32, device=src.device)
+            _lib.check(lib.eqa_fold_edge_pad(g_frame.data_ptr(), g_src.data_ptr(), ws.data_ptr(), B * C, H, W, pad, _stream()),
+                       "eqa_fold_edge_pad")
+        if not (want_angle or want_theta):
+            return g_src, None
+        _, g_t = group_action_bwd(src, grad_out, gidx, theta, flags, chan_map, pad, top_left, False, want_angle, want_theta)
+        return g_src, g_t
     g_src = torch.zeros_like(src) if want_src else None
     tiles = lib.eqa_group_action_bwd_tiles(OH, OW)
     if want_theta:

@@ -48,6 +48,7 @@ int eqa_abi_version(void);
 /* Debug/benchmark knobs (process-global, not part of the data path):
  *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels. */
 int eqa_set_option(int key, int value);
+int eqa_get_option(int key);
 
 /*
  * I5 -- fused  pad(edge) -> [hflip blend] -> rotate(-theta_g) -> center-crop.
@@ -139,6 +140,12 @@ int eqa_image_action_nearest(const float* x, float* out, const int32_t* eidx, co
  * grad_out has the shape of dst.  The gradient w.r.t. a reflection indicator is a difference of two forward
  * transforms dotted with grad_out and needs no kernel of its own.
  */
+/* Adjoint of the replicate ("edge") padding: gframe:(planes, H+2pad, W+2pad) -> gsrc:(planes, H, W), every source pixel
+ * receives the sum over the frame pixels that clamp to it.  With eqa_group_action_bwd run on the padded frame as its (un-padded)
+ * source this is the deterministic input gradient of the canonicalizing transform (discrete_group.py:204-215).
+ * workspace: eqa_fold_edge_pad_workspace_bytes(planes, H, W, pad) bytes. */
+int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad);
+int eqa_fold_edge_pad(const float* gframe, float* gsrc, void* workspace, int planes, int H, int W, int pad, void* stream);
 int eqa_group_action_bwd_tiles(int OH, int OW);
 int eqa_group_action_bwd(const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
                          const int32_t* flags, const int32_t* chan_map, float* grad_src, float* grad_angle_partial,

@@ -401,3 +401,38 @@ def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
             assert (p1.grad - p2.grad).abs().max().item() <= 5e-2 * g, (training, n1, (p1.grad - p2.grad).abs().max().item(), g)
         for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
             assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-6), n1
+
+
+@pytest.mark.gpu
+def test_padded_input_gradient_frame_gather_equals_atomic_scatter(dev):
+    """Edge-padded canonicalize: gather on the padded frame + fold of the pad strips / corners (default) against the atomic
+    scatter (eqa_set_option(0, 1)); with reflections, 45-degree elements, odd sizes; bit-reproducible; adjoint identity."""
+    import math
+
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import device_tables
+
+    lib = _lib.load()
+    torch.manual_seed(93)
+    for (N, refl, C, H, W) in [(8, False, 3, 37, 37), (4, True, 2, 40, 40), (8, True, 3, 33, 47), (8, False, 3, 224, 224)]:
+        G = 2 * N if refl else N
+        pad = math.ceil(W * 0.5)
+        th, fl = device_tables("canonicalize", N, refl, (H + 2 * pad, W + 2 * pad), dev)
+        B = 7
+        src = torch.randn(B, C, H, W, device=dev)
+        gy = torch.randn(B, C, H, W, device=dev)
+        gidx = torch.randint(0, G, (B,), device=dev, dtype=torch.int32)
+        g1, a1 = ops.group_action_bwd(src, gy, gidx, th, fl, None, pad, (pad, pad), True, True)
+        g1b, _ = ops.group_action_bwd(src, gy, gidx, th, fl, None, pad, (pad, pad), True, False)
+        lib.eqa_set_option(0, 1)
+        try:
+            g2, a2 = ops.group_action_bwd(src, gy, gidx, th, fl, None, pad, (pad, pad), True, True)
+        finally:
+            lib.eqa_set_option(0, 0)
+        assert torch.equal(g1, g1b)
+        assert (g1 - g2).abs().max().item() <= 1e-4 * max(g2.abs().max().item(), 1.0), (N, refl, C, H, W, (g1 - g2).abs().max().item())
+        # (two instantiations of the angle kernel: different FMA contraction in sums with cancellation)
+        assert torch.allclose(a1, a2, rtol=2e-3, atol=2e-3 * max(a2.abs().max().item(), 1.0))
+        y = ops.canon_transform(src, gidx, th, fl, pad)
+        lhs, rhs = (y * gy).sum().item(), (src * g1).sum().item()
+        assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)

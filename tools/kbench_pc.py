@@ -42,9 +42,13 @@ x = torch.randn(B, 3, S, S, device=dev)
 gy = torch.randn(B, 3, S, S, device=dev)
 gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
 th_c, fl_c = device_tables("canonicalize", 8, False, (2 * S, 2 * S), dev)
-for want_src, want_angle in ((False, True), (True, False), (True, True)):
-    ms = timeit(lambda: ops.group_action_bwd(x, gy, gidx, th_c, fl_c, None, S // 2, (S // 2, S // 2), want_src, want_angle), 20)
-    print(f"group_action_bwd src={want_src} angle={want_angle}: {ms*1e3:8.1f} us")
+from equiadapt_amd import _lib as _l  # noqa: E402
+for opt, label in ((0, "frame gather + fold"), (1, "atomic scatter")):
+    _l.load().eqa_set_option(0, opt)
+    for want_src, want_angle in ((False, True), (True, False), (True, True)):
+        ms = timeit(lambda: ops.group_action_bwd(x, gy, gidx, th_c, fl_c, None, S // 2, (S // 2, S // 2), want_src, want_angle), 20)
+        print(f"canonicalize backward [{label}] src={want_src} angle={want_angle}: {ms*1e3:8.1f} us")
+_l.load().eqa_set_option(0, 0)
 
 # un-padded input gradient (invert action): deterministic gather; EQA option 0 = 1 forces the atomic scatter
 from equiadapt_amd import _lib  # noqa: E402
