@@ -31,6 +31,31 @@ class ConvNetwork(nn.Module):
         self.final_fc = nn.Sequential(nn.BatchNorm1d(out_dim), nn.Dropout1d(0.5), nn.ReLU(),
                                       nn.Linear(out_dim, out_vector_size))
         self.out_vector_size = out_vector_size
+        self._fold_cache: dict = {}
+
+    def _folded(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+        """Weights and bias of ``bn(conv(.))`` in eval mode (one convolution, no separate normalisation pass); cached per
+        parameter version."""
+        key = (conv.weight._version, None if conv.bias is None else conv.bias._version, bn.weight._version, bn.bias._version,
+               bn.running_mean._version, bn.running_var._version, str(conv.weight.device))
+        hit = self._fold_cache.get(id(conv))
+        if hit is None or hit[0] != key:
+            scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+            bias = conv.bias if conv.bias is not None else torch.zeros_like(scale)
+            hit = (key, (conv.weight * scale[:, None, None, None]).contiguous(), ((bias - bn.running_mean) * scale + bn.bias).contiguous())
+            self._fold_cache[id(conv)] = hit
+        return hit[1], hit[2]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            # inference: eval-mode batch-norms folded into the convolutions (three fewer passes over the feature maps)
+            mods = list(self.enc_network)
+            h = x
+            for conv, bn, act in zip(mods[0::3], mods[1::3], mods[2::3]):
+                if bn.running_mean is None:
+                    h = act(bn(conv(h)))
+                    continue
+                w, b = self._folded(conv, bn)
+                h = act(torch.nn.functional.conv2d(h, w, b, conv.stride, conv.padding, conv.dilation, conv.groups))
+            return self.final_fc(h.reshape(x.shape[0], -1))
         return self.final_fc(self.enc_network(x).reshape(x.shape[0], -1))
