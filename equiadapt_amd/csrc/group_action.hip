@@ -678,7 +678,7 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
 // tap start indices.  One block = one (image, channel) plane x a band of kAaBand output rows; the band's horizontally
 // resampled input rows live in LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int kAaBand = 8;
+constexpr int kAaBand = 8;  // = the `band` the host tables are built for (geometry.aa_resize_tables); 16 / 32 measured slower
 #ifndef EQA_AA_WIDE_MIN_K
 #define EQA_AA_WIDE_MIN_K 8  // filters wider than this take the LDS row-staged kernel
 #endif

@@ -8,6 +8,7 @@ so the E 2x3 matrices are bit-identical to what the reference would hand to ``F.
 The tables are E*6 floats / E ints / E*G ints; they live on the device as non-persistent module buffers.
 """
 import functools
+import os
 import math
 from typing import Optional, Tuple
 
