@@ -9,111 +9,277 @@ namespace {
 // no padding, channels-last.  Implicit GEMM  y[pixel][co] = sum_kk A[pixel][kk] W[kk][co]  on v_mfma_f32_32x32x2_f32
 // (f32 in, f32 accumulate: an exact fmaf chain; 64 FLOP/clk/SIMD = 157 TF peak).
 //  * A wave owns a 64-channel slice and keeps ALL its weights in registers for the whole kernel (KH*8 steps x 2 N-tiles,
-//    one VGPR each: lane l holds W[k = l>>5][co = l&31] of every step); blocks are persistent and loop over M-tiles of 32
+//    one VGPR each: lane l holds W[k = l>>5][co = l&31] of every step); waves are persistent and loop over M-tiles of 32
 //    consecutive pixels of one output row, so the only streamed operand is the 3-channel input.
-//  * The KH input-row segments a tile reads ((31 + KW) * Cin contiguous floats each) are staged into LDS by the whole
-//    block with coalesced dword loads (double-buffered, one barrier per tile) and shared by the four waves.  (First
-//    version: every lane gathered its own rows with unaligned dwordx4 loads at a 12-byte lane stride -- 1040 us, of which
-//    480 us were those loads; this version: see DESIGN.md.)
+//  * Every wave is its own pipeline -- no barrier anywhere.  The KH input-row segments a tile reads ((31 + KW) * Cin
+//    contiguous floats each) come in with <= 4 contiguous 16-byte buffer loads per lane (the descriptor is rebased on the
+//    tile, so the per-lane offsets are loop constants and the hardware range check replaces all clamping), are written to
+//    the wave's private LDS double buffer, and are read back in the MFMA operand layout.  Three tiles are in flight per
+//    wave: tile t in the MFMA pipe, tile t+1 moving LDS -> registers row by row as the MFMAs release the rows of tile t,
+//    tile t+2 moving HBM -> registers -> LDS; the previous tile's epilogue is spread over the same instruction stream.
+//    (Version 1: per-lane gathers with unaligned dwordx4 loads at a 12-byte lane stride -- 1040 us.  Version 2: rows staged
+//    by the block and shared by its four waves behind one barrier per tile -- 945 us; cycle stamps showed each wave
+//    spending as long outside its MFMA stream (LDS round trip, staging, barrier) as inside, and with two waves per SIMD
+//    that cannot overlap completely.)
 //  * One filter row = R = KW*Cin <= 16 contiguous floats.  The two k-halves of the MFMA read 8 floats each from LDS: half
 //    0 -> elements 0..7, half 1 -> elements R-8..R-1 (lane stride Cin dwords: conflict-free for odd Cin).  For R < 16 the
 //    halves overlap; the duplicated elements carry weight 0 in half 1 (packing below), so only elements of the pixel's
 //    own receptive field enter its sum.
 //  * The MFMA takes the weights as A and the pixels as B: the accumulators are C[channel][pixel], each lane holds groups of 4
-//    consecutive channels of one pixel; epilogue = bias + ReLU + one 16-byte store per group (8 per tile and wave).
+//    consecutive channels of one pixel.  The bias is the C operand of the first MFMA of a tile, so the epilogue is
+//    ReLU + one 16-byte store per group (8 per tile and wave).
 // Packed weights (host): wpk[(ky*8 + q)*2 + h][co] = w[co][ci][ky][kx],  j = (R-8)*h + q, kx = j / Cin, ci = j % Cin,
 // and 0 where h == 1 and q < 16 - R.
 // MFMA work at the headline shape (256 x 92 rows x 3 tiles, K = 80 incl. padding, 256 channels): 92.6 GFLOP -> 0.59 ms
-// at the 157 TF peak, 0.67 ms at the 2.1 GHz the chip holds under this load; output 2.22 GB -> 0.37 ms at the write
-// roofline.  Measured 0.96 ms (MIOpen / CK for the same layer: 1.33 ms): PMC SQ_VALU_MFMA_BUSY_CYCLES / active cycles =
-// 70 % (78 % with the stores compiled out, 84 % with loads and stores compiled out) -- see DESIGN.md for what was tried.
+// at the 157 TF peak; output 2.22 GB -> 0.37 ms at the write roofline.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#ifndef EQA_LIFT_BLOCKS
-#define EQA_LIFT_BLOCKS 512
+#ifdef EQA_LIFT_CLOCK
+__device__ unsigned long long g_lift_clock[4 * 2048];
+__device__ unsigned long long g_lift_hist[64];
+__device__ unsigned g_lift_launch;  // debug build: shader cycles and 100 MHz ticks of block 0, wave 0
 #endif
-constexpr int kLiftRow = 192;  // LDS floats per staged input-row segment >= (31 + KW) * Cin = 31*Cin + R <= 31*5 + 16
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#ifndef EQA_LIFT_OCC
+#define EQA_LIFT_OCC 1  // blocks per CU = waves per SIMD
+#endif
+#ifndef EQA_LIFT_WAVES
+#define EQA_LIFT_WAVES (1024 * EQA_LIFT_OCC)  // persistent waves: 256 CUs x 4 SIMDs x occupancy
+#endif
+constexpr int kLiftChunks = 44;             // 16-byte chunks per staged input-row segment: 4*44 >= 31*Cin + R (<= 171)
+constexpr int kLiftRow = 4 * kLiftChunks;   // ... in floats
 
 template <int KH>
-struct LiftStage {  // the block's share of one tile's input rows: element e = tid + 256*k -> (ky = e / kLiftRow, c = e % kLiftRow)
-  static constexpr int kIters = (KH * kLiftRow + kThreads - 1) / kThreads;
-  float v[kIters];
+struct LiftStage {  // a wave's share of one tile's input rows: chunk id = lane + 64*k -> (ky = id / kLiftChunks, c = id % kLiftChunks)
+  static constexpr int kIters = (KH * kLiftChunks + 63) / 64;
+  static constexpr int kFloats = 64 * kIters * 4;  // LDS floats of one buffer: every lane owns a slot, used or not
+  f32x4 v[kIters];
+  unsigned voff[kIters];  // byte offset from the tile's first input element; tile-independent
 };
 
 template <int KH>
-__device__ __forceinline__ void lift_stage_load(const float* __restrict__ x, unsigned rowid, unsigned ox0, int H, int W,
-                                                int Cin, int OH, int n_el, size_t x_last, LiftStage<KH>& g) {
-  const unsigned img = rowid / (unsigned)OH, oy = rowid % (unsigned)OH;  // uniform
-  const size_t base = (((size_t)img * H + oy) * W + ox0) * Cin;
+__device__ __forceinline__ void lift_stage_init(LiftStage<KH>& g, int lane, int W, int Cin, int n_el) {
+  const int nchunk = (n_el + 3) / 4;
 #pragma unroll
   for (int k = 0; k < LiftStage<KH>::kIters; ++k) {
-    const int e = threadIdx.x + kThreads * k;
-    const int ky = e / kLiftRow, c = e % kLiftRow;
-    if (ky < KH && c < n_el) {
-      // a partial tile (OW < 32) reaches past the row end; those values land on pixels that are not stored, the clamp
-      // only keeps the address inside the buffer
-      const size_t idx = base + (size_t)ky * W * Cin + c;
-#ifdef EQA_LABL_NOLOAD
-      g.v[k] = (float)e;
-#else
-      g.v[k] = x[idx < x_last ? idx : x_last];
-#endif
-    }
+    const int id = lane + 64 * k;
+    const int ky = id / kLiftChunks, c = id % kLiftChunks;
+    // slots past the segment re-read its first chunk (no predicate, no branch: the loop body stays one scheduling region)
+    g.voff[k] = (ky < KH && c < nchunk) ? (unsigned)(ky * W * Cin + c * 4) * 4u : 0u;
   }
+}
+
+// Position of a tile of the wave's stream, advanced by `nstreams` tiles at a time without divisions; all wave-uniform.
+struct LiftPos {
+  unsigned tx, oy, img;          // tile column, output row, image
+};
+struct LiftStep {
+  unsigned d_tx, d_oy, d_img;    // the stream's stride, decomposed the same way
+};
+__device__ __forceinline__ void lift_pos_init(unsigned tile, unsigned step, unsigned tiles_per_row, unsigned OH, LiftPos& p,
+                                              LiftStep& d) {
+  const unsigned r0 = tile / tiles_per_row, rs = step / tiles_per_row;
+  p.tx = tile % tiles_per_row; p.oy = r0 % OH; p.img = r0 / OH;
+  d.d_tx = step % tiles_per_row; d.d_oy = rs % OH; d.d_img = rs / OH;
+}
+__device__ __forceinline__ LiftPos lift_pos_next(const LiftPos& p, const LiftStep& d, unsigned tiles_per_row, unsigned OH, bool go) {
+  LiftPos n;
+  n.tx = p.tx + d.d_tx;
+  unsigned carry = n.tx >= tiles_per_row ? 1u : 0u;
+  n.tx -= carry ? tiles_per_row : 0u;
+  n.oy = p.oy + d.d_oy + carry;
+  carry = n.oy >= OH ? 1u : 0u;
+  n.oy -= carry ? OH : 0u;
+  const unsigned carry2 = n.oy >= OH ? 1u : 0u;  // d_oy + carry can reach OH
+  n.oy -= carry2 ? OH : 0u;
+  n.img = p.img + d.d_img + carry + carry2;
+  // past the end of the stream the position stays on the last tile: its loads are redone and never used
+  n.tx = go ? n.tx : p.tx; n.oy = go ? n.oy : p.oy; n.img = go ? n.img : p.img;
+  return n;
+}
+template <bool MASKED>
+__device__ __forceinline__ unsigned lift_ox0(const LiftPos& p, int OW) {
+  // with OW >= 32 the last tile of a row starts at OW - 32 and overlaps its neighbour (the shared pixels are computed twice
+  // from the same operands in the same order and stored twice with the same value), so every tile has 32 valid pixels and
+  // the stores need no predicate; MASKED (OW < 32): one partial tile per row
+  return MASKED ? 0u : min(p.tx * 32u, (unsigned)OW - 32u);
 }
 
 template <int KH>
-__device__ __forceinline__ void lift_stage_store(float* __restrict__ lds, int n_el, const LiftStage<KH>& g) {
+__device__ __forceinline__ void lift_stage_load(const float* __restrict__ x, size_t x_numel, const LiftPos& p, unsigned ox0,
+                                                int H, int W, int Cin, LiftStage<KH>& g) {
+  // uniform: one 32 x 32 -> 64 bit product (input row x row length), not a chain of 64-bit multiplies
+  const size_t base = (size_t)(p.img * (unsigned)H + p.oy) * ((unsigned)W * (unsigned)Cin) + ox0 * (unsigned)Cin;
+  const size_t left = (x_numel - base) * sizeof(float);
+  // a partial tile (OW < 32) and the last rows of the last image reach past the end of x: the range check returns 0 for
+  // those dwords, and they only ever land on pixels that are not stored
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + base), 0,
+                                                                         (int)((left >> 32) ? 0xffffffffu : (unsigned)left), 0x00020000);
 #pragma unroll
   for (int k = 0; k < LiftStage<KH>::kIters; ++k) {
-    const int e = threadIdx.x + kThreads * k;
-    if (e / kLiftRow < KH && e % kLiftRow < n_el) lds[e] = g.v[k];
+#ifdef EQA_LABL_NOLOAD
+    const u32x4 r = {g.voff[k], 1u, 2u, 3u};
+#else
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)g.voff[k], 0, 0);
+#endif
+    g.v[k] = __builtin_bit_cast(f32x4, r);
   }
 }
 
-// Tile -> (output row id = img*OH + oy, first column).  With OW >= 32 the last tile of a row starts at OW - 32 and overlaps
-// its neighbour (the shared pixels are computed twice from the same operands in the same order and stored twice with the
-// same value), so every tile has 32 valid pixels and the stores need no predicate; MASKED (OW < 32): one partial tile.
-template <bool MASKED>
-__device__ __forceinline__ void lift_tile_pos(unsigned tile, unsigned tiles_per_row, int OW, unsigned& rowid, unsigned& ox0) {
-  rowid = tile / tiles_per_row;
-  const unsigned tx = tile % tiles_per_row;
-  ox0 = MASKED ? 0u : min(tx * 32u, (unsigned)OW - 32u);
+// The staged values are first used one tile later (the LDS write of the next step), beyond the loop's exit test, and the
+// compiler sinks loads to their first use: without this "use" at the end of the step that issued them the loads end up
+// directly in front of the LDS write and their whole latency is exposed.
+template <int KH>
+__device__ __forceinline__ void lift_stage_pin(LiftStage<KH>& g) {
+#pragma unroll
+  for (int k = 0; k < LiftStage<KH>::kIters; ++k) asm volatile("" : "+v"(g.v[k]));
 }
 
-// Epilogue.  The MFMA is issued with the WEIGHTS as the A operand and the pixels as B, so the 32x32 result is
-// C[channel][pixel]: lane l holds pixel l & 31 and, in register r, channel (r & 3) + 8*(r >> 2) + 4*(l >> 5) of the
-// 32-channel tile -- four groups of four CONSECUTIVE channels.  One group = one 16-byte store per lane: 8 store instructions
-// per tile and wave instead of the 32 dword stores of the pixel-major layout (with 8 waves per CU those 256 store
-// instructions per tile period were suspected of holding the MFMAs of their waves up; measured, the time is the same).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int KH>
+__device__ __forceinline__ void lift_stage_store(float* __restrict__ lds, int lane, const LiftStage<KH>& g) {
+#pragma unroll
+  for (int k = 0; k < LiftStage<KH>::kIters; ++k) *reinterpret_cast<f32x4*>(lds + 4 * (lane + 64 * k)) = g.v[k];
+}
+
+// Row ky of a staged tile in the MFMA operand layout.  Element (ky 0, q 0) of k-half 1 is a spare (R <= 15: it duplicates an
+// element of half 0 and its packed weight is 0): there the lanes read a constant 1.0 kept behind the stage buffer and the
+// wave's weight registers hold the bias, so the bias is added by the matrix core and costs no vector instruction.
+template <int KH>
+__device__ __forceinline__ void lift_read_row(const float* __restrict__ lds, int ky, int a_off, int a_q0, float (&a)[KH][8]) {
+#pragma unroll
+  for (int q = 0; q < 8; ++q) a[ky][q] = lds[ky == 0 && q == 0 ? a_q0 : ky * kLiftRow + a_off + q];
+}
+
+// Epilogue.  Lane l of a 32x32 accumulator C[channel][pixel] holds pixel l & 31 and, in register r, channel (r & 3) +
+// 8*(r >> 2) + 4*(l >> 5) of the 32-channel tile: stored from there, one instruction writes 32-byte pieces of 32 different
+// pixels (a 128-byte line is completed by four instructions, hundreds of cycles apart), and the stores cost 180 of the
+// kernel's 950 us.  So the tile goes through the wave's LDS once (bias and ReLU on the way in; 68-float pixel pitch:
+// conflict-free both ways) and leaves in pixel-major order: 16 lanes x 16 bytes = the 256 contiguous bytes of one pixel's
+// 64-channel slice, 4 pixels per instruction, 8 instructions per tile.
+constexpr int kLiftTrPitch = 68;
+
+__device__ __forceinline__ void lift_epi_write(int g, const f32x16& p, float* __restrict__ tr) {
+  f32x4 v;  // the raw sums: straight from the accumulator registers into LDS
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = p[4 * g + k];
+  *reinterpret_cast<f32x4*>(tr + 8 * g) = v;  // tr = &lds_tr[col * pitch + 32 * t + 4 * h]
+}
+
+struct LiftEpi {  // loop constants of the epilogue
+  float* tr_w;        // this lane's LDS slot as the owner of pixel `col` (k-half h)
+  const float* tr_r;  // ... and as the writer of pixels (lane >> 4) + 4j, channels 4 * (lane & 15)
+  int lo;             // ReLU as an integer max on the bit patterns (one VALU op; every VALU op costs ~6 cycles of MFMA
+                      // time, tools/micro/mfma_shadow.hip): 0 clamps the negative floats, INT_MIN clamps nothing
+  unsigned out_voff;  // byte offset of (pixel lane >> 4, channel slice*64 + 4 * (lane & 15)) from the tile's first output element
+  unsigned row4;      // bytes of four output pixels
+  int lane;
+};
+
+// The tile's output as a buffer: the descriptor is rebased on the tile (scalar work), the lane part is a loop constant and
+// the pixel group goes into the scalar offset -- no 64-bit vector address arithmetic per store.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lift_out_rsrc(float* __restrict__ y, size_t y_numel, size_t base) {
+  const size_t left = (y_numel - base) * sizeof(float);
+  return __builtin_amdgcn_make_buffer_rsrc(y + base, 0, (int)((left >> 32) ? 0xffffffffu : (unsigned)left), 0x00020000);
+}
 
 template <bool MASKED>
-__device__ __forceinline__ void lift_store_group(int g, const f32x16& p, const f32x4& bias4, float lo, float* __restrict__ o,
-                                                 int col, int cols_left) {
-  f32x4 v;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = fmaxf(p[4 * g + k] + bias4[k], lo);
+__device__ __forceinline__ void lift_epi_store(int j, const f32x4& t, const LiftEpi& e, __amdgpu_buffer_rsrc_t out, int cols_left) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 lo4 = {e.lo, e.lo, e.lo, e.lo};
+  const u32x4 v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, t), lo4));
 #ifdef EQA_LABL_NOSTORE
-  if (v[0] == 1.2345e-30f) *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+  if (v[0] == 12345u)
 #else
-  if (!MASKED || col < cols_left) *reinterpret_cast<f32x4*>(o + 8 * g) = v;
+  if (!MASKED || 4 * j + (e.lane >> 4) < cols_left)
 #endif
+    __builtin_amdgcn_raw_buffer_store_b128(v, out, (int)e.out_voff, (int)(j * e.row4), 0);
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void lift_epi_all(const LiftEpi& e, const f32x16& p0, const f32x16& p1, __amdgpu_buffer_rsrc_t out, int left) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    lift_epi_write(g, p0, e.tr_w);
+    lift_epi_write(g, p1, e.tr_w + 32);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) lift_epi_store<MASKED>(j, *reinterpret_cast<const f32x4*>(e.tr_r + 4 * j * kLiftTrPitch), e, out, left);
+}
+
+// One tile's MFMA stream.  Between the MFMAs: row ky of the NEXT tile moves LDS -> a[ky] as soon as the 16 MFMAs reading
+// a[ky] have issued, and (EPI) the previous tile's accumulators p0 / p1 are clamped and stored in 8 groups.
+template <int KH, bool EPI, bool MASKED>
+__device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float (&b1)[KH * 8], float (&a)[KH][8],
+                                          const float* __restrict__ lds_next, int a_off, int a_q0, f32x16& acc0, f32x16& acc1,
+                                          const f32x16& p0, const f32x16& p1, const LiftEpi& e,
+                                          __amdgpu_buffer_rsrc_t out, int p_left) {
+  f32x16 zero;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
+  constexpr int NG = 8 / (KH - 1);  // output pixel groups per row ky >= 1
+  static_assert(NG * (KH - 1) == 8 && NG % 2 == 0, "epilogue schedule");
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky) {
+    f32x4 t[NG];
+    if (EPI && ky > 0) {  // the previous tile, pixel-major, from LDS ...
+#pragma unroll
+      for (int n = 0; n < NG; ++n) t[n] = *reinterpret_cast<const f32x4*>(e.tr_r + 4 * (NG * (ky - 1) + n) * kLiftTrPitch);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int s = ky * 8 + q;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a[ky][q], s == 0 ? zero : acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a[ky][q], s == 0 ? zero : acc1, 0, 0, 0);
+    }
+    lift_read_row<KH>(lds_next, ky, a_off, a_q0, a);
+    if (EPI) {
+      if (ky == 0) {  // the previous tile: into LDS ...
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          lift_epi_write(g, p0, e.tr_w);
+          lift_epi_write(g, p1, e.tr_w + 32);
+        }
+      } else {        // ... and out: bias, ReLU, store
+#pragma unroll
+        for (int n = 0; n < NG; ++n) lift_epi_store<MASKED>(NG * (ky - 1) + n, t[n], e, out, p_left);
+      }
+    }
+  }
+  // One wave per SIMD: whatever is not issued in the shadow of an MFMA (64 cycles each) idles the matrix pipe, and the
+  // default schedule bunches the MFMAs and leaves the other ~170 instructions of a tile in a few clusters (6400 cycles
+  // per tile against 5120 of MFMA time).  So the whole stream is pinned: behind every MFMA at most one LDS instruction,
+  // one VALU, two SALU and one VMEM instruction, in dependency order.  What that costs (tools/micro/mfma_shadow.hip, one
+  // wave per SIMD, cycles per MFMA): SALU, s_nop, one ds_read or ds_write_b128: 64 (free); two ds_write_b128: 105; four
+  // ds_read_b32: 128; every VALU: +6 wherever it sits (the matrix core and the vector ALU share the issue port) -- hence
+  // no bias add, no accumulator copies and an integer max as the ReLU: 32 VALU instructions per tile.
+#pragma unroll
+  for (int m = 0; m < KH * 16; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);  // one LDS instruction (two writes behind one MFMA cost 40 cycles)
+    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one VALU (each costs ~6 cycles of matrix time wherever it sits)
+    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);  // SALU: free
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // VMEM
+  }
 }
 
 template <int KH, bool MASKED>
-__global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+__global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                                     const float* __restrict__ bias, int relu,
                                                                     float* __restrict__ y, int H, int W, int Cin, int R,
                                                                     int OH, int OW, int Cout, unsigned tiles_per_row,
-                                                                    unsigned ntiles, size_t x_last) {
-  __shared__ float lds[2][KH * kLiftRow];
-  constexpr int NM = KH * 16;      // MFMAs per tile and wave (KH*8 k-steps x 2 N-tiles)
-  constexpr int PER = NM / 8;      // MFMAs between two epilogue groups
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // a wave past the last 64-channel slice redoes an earlier slice (same values, same addresses) instead of idling: it
-  // must take part in the staging and the barriers anyway, and the loop stays branch-free
-  const int slice = (blockIdx.y * 4 + wave) % (Cout / 64);
+                                                                    unsigned ntiles, size_t x_numel, size_t y_numel, unsigned nslices,
+                                                                    unsigned nstreams) {
+  using Stage = LiftStage<KH>;
+  __shared__ float lds_all[kThreads / 64][2][Stage::kFloats + 4];
+  __shared__ float lds_tr_all[kThreads / 64][32 * kLiftTrPitch];
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned gw = blockIdx.x * (kThreads / 64) + wave;  // slices of one tile stream sit in neighbouring waves (x stays in L2)
+  if (gw >= nslices * nstreams) return;
+  const unsigned slice = gw % nslices, stream = gw / nslices;
+  float (&lds)[2][Stage::kFloats + 4] = lds_all[wave];
+  if (lane < 2) lds[lane][Stage::kFloats] = 1.0f;
   const int h = lane >> 5, col = lane & 31;
   const int ch0 = slice * 64 + col;
   float b0[KH * 8], b1[KH * 8];
@@ -122,113 +288,137 @@ __global__ __launch_bounds__(kThreads, 2) void lift_conv_mfma_kernel(const float
     b0[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0];
     b1[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0 + 32];
   }
-  f32x4 bias4[2][4];  // this lane's channels: slice*64 + 32*t + 8*g + 4*h + {0..3}
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) bias4[t][gq][k] = bias ? bias[slice * 64 + 32 * t + 8 * gq + 4 * h + k] : 0.0f;
-  const float lo = relu ? 0.0f : -__builtin_huge_valf();
+  if (h == 1) {  // the spare slot (see lift_read_row): weight = bias, input = 1.0
+    b0[0] = bias ? bias[ch0] : 0.0f;
+    b1[0] = bias ? bias[ch0 + 32] : 0.0f;
+  }
+  LiftEpi epi;
+  epi.tr_w = lds_tr_all[wave] + col * kLiftTrPitch + 4 * h;
+  epi.tr_r = lds_tr_all[wave] + (lane >> 4) * kLiftTrPitch + 4 * (lane & 15);
+  epi.lo = relu ? 0 : (int)0x80000000;
+  epi.out_voff = ((unsigned)(lane >> 4) * Cout + slice * 64 + 4 * (lane & 15)) * 4u;
+  epi.row4 = 4u * Cout * 4u;
+  epi.lane = lane;
   const int n_el = 31 * Cin + R;
   const int a_off = Cin * col + (R - 8) * h;  // this lane's first element inside a staged row
-  unsigned tile = blockIdx.x;
-  if (tile >= ntiles) return;
-  LiftStage<KH> g;
-  unsigned rowid, ox0;
-  lift_tile_pos<MASKED>(tile, tiles_per_row, OW, rowid, ox0);
-  lift_stage_load<KH>(x, rowid, ox0, H, W, Cin, OH, n_el, x_last, g);
-  lift_stage_store<KH>(lds[0], n_el, g);
-  __syncthreads();
-  int buf = 0;
-  f32x16 p0, p1;          // accumulators of the previous tile, stored while the current tile is in the MFMA pipe
-  float* po = y;
-  int p_left = 0;
-  bool have_prev = false;
-  // weights and bias have landed: without this the first use of `bias` INSIDE the loop carries a vmcnt(0) that, from the
-  // second iteration on, waits for the staging loads issued a moment earlier
+  const int a_q0 = h ? Stage::kFloats : a_off;
+  const unsigned count = (ntiles - stream + nstreams - 1) / nstreams;  // tiles of this stream, >= 1
+
+#ifdef EQA_LIFT_CLOCK
+  const unsigned long long clk0 = __builtin_readcyclecounter(), rt0 = __builtin_amdgcn_s_memrealtime();
+  if (gw == 0 && lane == 0) g_lift_hist[atomicAdd(&g_lift_launch, 1u) & 63] = rt0;
+#define LIFT_CLOCK_END() do { if (lane == 0 && gw < 2048) { g_lift_clock[4 * gw] = __builtin_readcyclecounter() - clk0; g_lift_clock[4 * gw + 1] = rt0; g_lift_clock[4 * gw + 2] = __builtin_amdgcn_s_memrealtime(); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_lift_clock[4 * gw + 3] = ((unsigned long long)xcc << 32) | hw; } } while (0)
+#else
+#define LIFT_CLOCK_END() do { } while (0)
+#endif
+  Stage g;
+  lift_stage_init<KH>(g, lane, W, Cin, n_el);
+  LiftPos pA, pB, pC;  // tiles i, i+1, i+2 of the stream
+  LiftStep step;
+  lift_pos_init(stream, nstreams, tiles_per_row, (unsigned)OH, pA, step);
+  pB = lift_pos_next(pA, step, tiles_per_row, (unsigned)OH, 1 < count);
+  pC = lift_pos_next(pB, step, tiles_per_row, (unsigned)OH, 2 < count);
+
+  auto out_of = [&](const LiftPos& p, int& cols_left) -> __amdgpu_buffer_rsrc_t {
+    const unsigned ox0 = lift_ox0<MASKED>(p, OW);
+    cols_left = OW - (int)ox0;
+    return lift_out_rsrc(y, y_numel, (size_t)(p.img * (unsigned)OH + p.oy) * ((unsigned)OW * (unsigned)Cout) + ox0 * (unsigned)Cout);
+  };
+
+  // Tiles i+2 and i+3 of the stream are on their way from HBM while tile i is in the MFMA pipe (register sets G0 / G1;
+  // a load is consumed two steps after it was issued, ~10000 cycles: nothing in the loop waits for memory).
+  Stage G0, G1;
+  G0 = g;
+  G1 = g;
+  float a[KH][8];
+  lift_stage_load<KH>(x, x_numel, pA, lift_ox0<MASKED>(pA, OW), H, W, Cin, G0);
+  lift_stage_store<KH>(lds[0], lane, G0);
+#pragma unroll
+  for (int ky = 0; ky < KH; ++ky) lift_read_row<KH>(lds[0], ky, a_off, a_q0, a);
+  lift_stage_load<KH>(x, x_numel, pB, lift_ox0<MASKED>(pB, OW), H, W, Cin, G1);  // tile 1
+  lift_stage_load<KH>(x, x_numel, pC, lift_ox0<MASKED>(pC, OW), H, W, Cin, G0);  // tile 2
+  LiftPos pD = lift_pos_next(pC, step, tiles_per_row, (unsigned)OH, 3 < count);   // tile 3
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): the loop below starts from a clean slate
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Step i = { tile i+1: registers -> lds[(i+1) & 1];  tile i+3: HBM -> the same registers;  MFMA stream of tile i with a[]
+  // refilling from lds[(i+1) & 1] and the stores of tile i-1 }.  Two accumulator sets take turns (no copies, and no wait for
+  // the last MFMA of a tile before the next one starts): even tiles accumulate in e0 / e1, odd tiles in o0 / o1.
+  f32x16 e0, e1, o0, o1;
+  int left = 0, left_next = 0;
+  __amdgpu_buffer_rsrc_t po = out_of(pA, left);  // where tile 0 goes (stored during step 1)
+  lift_stage_store<KH>(lds[1], lane, G1);
+  lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
+  lift_tile<KH, false, MASKED>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, e0, e1, epi, po, 0);
+  // the first trip of the loop must not inherit a shorter queue than the later ones: the compiler takes the minimum over
+  // both ways in when it counts how many loads and stores may still be in flight at the LDS writes
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  for (;;) {
-    const unsigned next = tile + gridDim.x;
-    if (next < ntiles) {  // the global loads fly under this tile's MFMAs
-      unsigned nr, nx;
-      lift_tile_pos<MASKED>(next, tiles_per_row, OW, nr, nx);
-      lift_stage_load<KH>(x, nr, nx, H, W, Cin, OH, n_el, x_last, g);
+  for (unsigned i = 1;; i += 2) {
+    if (i >= count) {
+      lift_epi_all<MASKED>(epi, e0, e1, po, left);
+      lift_stage_pin<KH>(G0);  // a use on the way out as well: otherwise the compiler sinks the loads below the exit test,
+      lift_stage_pin<KH>(G1);  // in front of their first use one or two steps later
+      LIFT_CLOCK_END();
+      return;
     }
-    float a[KH][8];
-#pragma unroll
-    for (int ky = 0; ky < KH; ++ky)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) a[ky][q] = lds[buf][ky * kLiftRow + a_off + q];
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.0f; acc1[i] = 0.0f; }
-    // The waves sharing a SIMD fall into step (they wait for the same MFMA pipe), so an epilogue that is a phase of
-    // its own leaves the pipe idle: measured 70 % MFMA-busy with 2, 3 or 4 waves per SIMD alike.  Hence the previous
-    // tile's bias / ReLU / stores are issued in 8 groups between this tile's MFMAs.
-    if (have_prev) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-#pragma unroll
-        for (int m = PER * i; m < PER * i + PER; ++m) {
-          const int step = m >> 1;
-          if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[step], a[step >> 3][step & 7], acc1, 0, 0, 0);
-          else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[step], a[step >> 3][step & 7], acc0, 0, 0, 0);
-        }
-        if (i < 4) lift_store_group<MASKED>(i, p0, bias4[0][i], lo, po, col, p_left);
-        else lift_store_group<MASKED>(i - 4, p1, bias4[1][i - 4], lo, po + 32, col, p_left);
-        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);  // PER MFMA
-        __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);    // the group's VALU (add, max)
-        __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // its store
-      }
-    } else {
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        const int step = m >> 1;
-        if (m & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[step], a[step >> 3][step & 7], acc1, 0, 0, 0);
-        else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[step], a[step >> 3][step & 7], acc0, 0, 0, 0);
-      }
+    pA = pB;
+    pB = pC;
+    pC = pD;
+    pD = lift_pos_next(pD, step, tiles_per_row, (unsigned)OH, i + 3 < count);
+    lift_stage_store<KH>(lds[0], lane, G0);
+    lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G0);
+    __amdgpu_buffer_rsrc_t pn = out_of(pA, left_next);  // tile i: scalar work inside the stream, not in front of it
+    lift_tile<KH, true, MASKED>(b0, b1, a, lds[0], a_off, a_q0, o0, o1, e0, e1, epi, po, left);
+    po = pn;
+    left = left_next;
+
+    if (i + 1 >= count) {
+      lift_epi_all<MASKED>(epi, o0, o1, po, left);
+      lift_stage_pin<KH>(G0);
+      lift_stage_pin<KH>(G1);
+      LIFT_CLOCK_END();
+      return;
     }
-    lift_tile_pos<MASKED>(tile, tiles_per_row, OW, rowid, ox0);
-    p0 = acc0;
-    p1 = acc1;
-    po = y + ((size_t)rowid * OW + ox0 + col) * Cout + slice * 64 + 4 * h;
-    p_left = OW - (int)ox0;
-    have_prev = true;
-    if (next >= ntiles) break;
-    lift_stage_store<KH>(lds[buf ^ 1], n_el, g);
-    __syncthreads();  // everyone has read lds[buf ^ 1] two tiles ago (before the previous barrier) and lds[buf] above
-    buf ^= 1;
-    tile = next;
-  }
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    lift_store_group<MASKED>(g, p0, bias4[0][g], lo, po, col, p_left);
-    lift_store_group<MASKED>(g, p1, bias4[1][g], lo, po + 32, col, p_left);
+    pA = pB;
+    pB = pC;
+    pC = pD;
+    pD = lift_pos_next(pD, step, tiles_per_row, (unsigned)OH, i + 4 < count);
+    lift_stage_store<KH>(lds[1], lane, G1);
+    lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
+    pn = out_of(pA, left_next);  // tile i + 1
+    lift_tile<KH, true, MASKED>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, o0, o1, epi, po, left);
+    po = pn;
+    left = left_next;
   }
 }
 
 }  // namespace
 
 extern "C" {
-
+#ifdef EQA_LIFT_CLOCK
+int eqa_debug_lift_hist(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_hist), sizeof(g_lift_hist)) == hipSuccess ? 0 : -1; }
+int eqa_debug_lift_clock(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_clock), sizeof(g_lift_clock)) == hipSuccess ? 0 : -1; }
+#endif
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream) {
   if (!x || !wpk || !y || nimg < 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout <= 0 || H < KH || W < KW) return EQA_ERR_INVALID_ARG;
   const int R = KW * Cin;
-  if ((KH != 3 && KH != 5) || R < 9 || R > 16 || (Cout % 64) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;
+  if ((KH != 3 && KH != 5) || R < 9 || R > 15 || (Cout % 64) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;  // R <= 15: the bias slot
   if (nimg == 0) return EQA_OK;
   const int OH = H - KH + 1, OW = W - KW + 1;
   const unsigned tiles_per_row = (unsigned)(OW + 31) / 32;
   const size_t ntiles = (size_t)nimg * OH * tiles_per_row;
   if (ntiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  const size_t x_last = (size_t)nimg * H * W * Cin - 1;
-  // persistent blocks (the weights live in registers), 2 per CU, each looping over M-tiles
-  const dim3 grid((unsigned)std::min<size_t>(ntiles, EQA_LIFT_BLOCKS), (Cout + 255) / 256);
+  const size_t x_numel = (size_t)nimg * H * W * Cin, y_numel = (size_t)nimg * OH * OW * Cout;
+  // persistent waves (the weights live in registers), 2 per SIMD: `nstreams` tile streams x `nslices` 64-channel slices
+  const unsigned nslices = (unsigned)Cout / 64;
+  const unsigned nstreams = (unsigned)std::min<size_t>(ntiles, std::max(1u, (unsigned)EQA_LIFT_WAVES / nslices));
+  const unsigned waves = nslices * nstreams, per_block = kThreads / 64;
+  const dim3 grid((waves + per_block - 1) / per_block);
   hipStream_t st = (hipStream_t)stream;
 #define EQA_LIFT_LAUNCH(KH_, MASKED_)                                                                                      \
   hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
-                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_last)
+                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams)
   if (KH == 5) {
     if (OW < 32) EQA_LIFT_LAUNCH(5, true); else EQA_LIFT_LAUNCH(5, false);
   } else {

@@ -228,10 +228,11 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
  * I2a, lifting convolution in inference (escnn_networks.py:60-66 first R2Conv; custom_group_equivariant_layers.py lifting
  * layer): few input channels -> Cout channels, KH x KW, stride 1, no padding, channels-last, on the fp32 MFMA.
  *   y[n,oy,ox,co] = [relu]( sum_{ky,kx,ci} x[n,oy+ky,ox+kx,ci] * w[co,ci,ky,kx] + bias[co] )
- * x:(nimg,H,W,Cin); y:(nimg,H-KH+1,W-KW+1,Cout); bias:(Cout) or NULL.  Supported: KH in {3,5}, 9 <= R = KW*Cin <= 16,
+ * x:(nimg,H,W,Cin); y:(nimg,H-KH+1,W-KW+1,Cout); bias:(Cout) or NULL.  Supported: KH in {3,5}, 9 <= R = KW*Cin <= 15,
  * Cout % 64 == 0 (else EQA_ERR_UNSUPPORTED: use the framework's convolution).
  * wpk: weights packed (KH*8, 2, Cout):  wpk[(ky*8+q)*2 + h][co] = w[co][ci][ky][kx],  j = (R-8)*h + q, kx = j / Cin,
- * ci = j % Cin, and 0 where h == 1 and q < 16-R  (the two 8-element halves of a filter row overlap when R < 16).
+ * ci = j % Cin, and 0 where h == 1 and q < 16-R  (the two 8-element halves of a filter row overlap; the kernel uses the
+ * first of those zero slots to add the bias on the matrix core).
  */
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream);

@@ -725,7 +725,8 @@ def test_lift_conv_mfma_matches_conv2d(dev):
 
     torch.manual_seed(31)
     for (B, Cin, K, Cout, H, W) in [(3, 3, 5, 256, 20, 24), (2, 3, 3, 64, 9, 11), (5, 2, 5, 128, 13, 13), (1, 4, 3, 64, 40, 7),
-                                    (2, 5, 3, 192, 12, 12), (64, 3, 5, 64, 33, 33)]:
+                                    (2, 5, 3, 192, 12, 12), (64, 3, 5, 64, 33, 33), (1, 3, 5, 64, 5, 5), (7, 3, 5, 128, 6, 70),
+                                    (300, 3, 3, 64, 10, 37)]:   # incl. streams of 1, 2, 3 tiles per wave and partial tiles
         assert ops.lift_conv_supported(Cin, K, K, Cout)
         x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
@@ -752,7 +753,9 @@ def test_lift_conv_mfma_matches_conv2d(dev):
     # unsupported shapes are refused, not approximated
     lib = _lib.load()
     assert not ops.lift_conv_supported(1, 5, 5, 64) and not ops.lift_conv_supported(3, 5, 5, 32) and not ops.lift_conv_supported(3, 7, 7, 64)
+    assert not ops.lift_conv_supported(4, 3, 4, 64)      # R = 16: no spare k-slot for the bias
     assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 1, 5, 5, 64, None) == -3
+    assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 4, 3, 4, 64, None) == -3
 
 
 def test_window_sums_gemv_matches_matmul(dev):
