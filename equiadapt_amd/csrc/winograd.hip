@@ -277,9 +277,9 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_output_adjoint_kernel(co
 }
 
 // Output transform fused with the window-sum segments of the NEXT (last, linearised) layer: instead of writing the
-// (nimg, OH, OW, C) activation and re-reading it, every output row becomes one "segment" in the format of
-// window_sums_nhwc_finalize_kernel -- per channel [row total, first NB columns, last NB columns] -- with the segment
-// order that kernel expects: rows 0..NB-1, rows OH-NB..OH-1, then the interior rows.  One block = one tile row (m
+// (nimg, OH, OW, C) activation and re-reading it, every border row and every interior tile row becomes one "segment" in
+// the format of window_sums_nhwc_finalize_kernel -- per channel [row total, first NB columns, last NB columns] -- with the
+// segment order that kernel expects: rows 0..NB-1, rows OH-NB..OH-1, then the interior.  One block = one tile row (m
 // output rows) of one image x 256 channels, looping over the TX tiles.  NB = k_last - 1 must be a multiple of m.
 template <int N, int NB>
 __global__ __launch_bounds__(kThreads) void winograd_k5_output_sums_kernel(const float* __restrict__ M, const float* __restrict__ bias,
@@ -330,10 +330,23 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_output_sums_kernel(const
 #pragma unroll
       for (int q = 0; q < MT; ++q) { acc[r][0] += o[r][q]; acc[r][1 + NB + MT * t + q] += o[r][q]; }
   }
+  if (ty >= HB && ty < TY - HB) {
+    // interior tile row: only the sum over its rows is ever needed (the finalize kernel wants the border ROWS one by
+    // one, everything else as a total) -- one segment instead of m, a third of the partial buffer at 88 rows
+    float* o = part + ((img * nseg + 2 * NB + (ty - HB)) * (size_t)C + c) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float a = acc[0][i];
+#pragma unroll
+      for (int r = 1; r < MT; ++r) a += acc[r][i];
+      o[i] = a;
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < MT; ++r) {
     const int y = MT * ty + r;
-    const int seg = y < NB ? y : (y >= OH - NB ? NB + (y - (OH - NB)) : 2 * NB + (y - NB));
+    const int seg = y < NB ? y : NB + (y - (OH - NB));
     float* o = part + ((img * nseg + seg) * (size_t)C + c) * NV;
 #pragma unroll
     for (int i = 0; i < NV; ++i) o[i] = acc[r][i];
@@ -412,7 +425,7 @@ int launch_wino_output_sums(const float* M, const float* bias, int relu, double*
   if ((size_t)nimg * TY > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((unsigned)((size_t)nimg * TY), (C + kThreads - 1) / kThreads);
-  const int nseg = OH;  // one segment per output row
+  const int nseg = 2 * nb + (TY - 2 * (nb / MT));  // the 2 nb border rows one by one + one segment per interior tile row
   float* part = (float*)workspace;
   if (nb == 4) {
     hipLaunchKernelGGL((winograd_k5_output_sums_kernel<N, 4>), grid, dim3(kThreads), 0, st, M, bias, relu, part, OH, OW, C, TY, TX, nseg);
