@@ -695,22 +695,57 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
   const int yend = min(y0[r1 - 1] + K, H);  // taps past a row's own range carry zero weight
   const int nrows = min(yend - ybeg, max_rows);
   const float* src = x + (size_t)plane * H * W;
-  for (int idx = threadIdx.x; idx < nrows * OW; idx += kThreads) {
-    const int ry = idx / OW, ox = idx - ry * OW;
-    const float* row = src + (size_t)(ybeg + ry) * W;
-    const int xs = x0[ox];
-    float acc = 0.0f;
-    for (int j = 0; j < K; ++j) acc += wx[ox * K + j] * row[min(xs + j, W - 1)];
-    aa_tmp[ry * OW + ox] = acc;
+  // K <= EQA_AA_WIDE_MIN_K here.  A thread keeps ONE output column (kThreads / OW rows are worked on at a time, the
+  // threads beyond that idle): tap start and weights are loaded once per block instead of once per value, no division per
+  // value, and the K loads of a value go out together (unrolled with a predicate).  Measured at 256 x 3 x 224^2 -> 96^2:
+  // 123 us with one (row, column) pair per thread and trip, of which 100 us were this pass.
+  const int rows_par = kThreads / OW;
+  if (rows_par >= 1) {
+    const int ox = threadIdx.x % OW, rsub = threadIdx.x / OW;
+    if (rsub < rows_par) {
+      const int xs = x0[ox];
+      float wv[EQA_AA_WIDE_MIN_K];
+      int xo[EQA_AA_WIDE_MIN_K];
+#pragma unroll
+      for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) {
+        wv[j] = j < K ? wx[ox * K + j] : 0.0f;
+        xo[j] = min(xs + j, W - 1);
+      }
+      for (int ry = rsub; ry < nrows; ry += rows_par) {
+        const float* row = src + (size_t)(ybeg + ry) * W;
+        float xv[EQA_AA_WIDE_MIN_K];
+#pragma unroll
+        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) xv[j] = j < K ? row[xo[j]] : 0.0f;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
+          if (j < K) acc += wv[j] * xv[j];
+        aa_tmp[ry * OW + ox] = acc;
+      }
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < nrows * OW; idx += kThreads) {
+      const int ry = idx / OW, ox = idx - ry * OW;
+      const float* row = src + (size_t)(ybeg + ry) * W;
+      const int xs = x0[ox];
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
+        if (j < K) acc += wx[ox * K + j] * row[min(xs + j, W - 1)];
+      aa_tmp[ry * OW + ox] = acc;
+    }
   }
   __syncthreads();
   float* dst = y + (size_t)plane * OH * OW;
   for (int idx = threadIdx.x; idx < (r1 - r0) * OW; idx += kThreads) {
     const int r = idx / OW, ox = idx - r * OW;
     const int oy = r0 + r;
+
     const int ys = y0[oy] - ybeg;
     float acc = 0.0f;
-    for (int j = 0; j < K; ++j) acc += wy[oy * K + j] * aa_tmp[min(ys + j, nrows - 1) * OW + ox];
+#pragma unroll
+    for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
+      if (j < K) acc += wy[oy * K + j] * aa_tmp[min(ys + j, nrows - 1) * OW + ox];
     dst[(size_t)oy * OW + ox] = acc;
   }
 }

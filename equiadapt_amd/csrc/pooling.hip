@@ -313,34 +313,23 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
     s_tot[e] = acc;
   }
   __syncthreads();
-  const int cl = threadIdx.x;
-  if (cl >= nch) return;
-  const int c = c0 + cl;
-  auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
-  const double tot = s_tot[cl * nval];
-  double col[2 * kWsMaxBorder];
-#pragma unroll
-  for (int j = 0; j < 2 * kWsMaxBorder; ++j) col[j] = j < 2 * nb ? s_tot[cl * nval + 1 + j] : 0.0;
+  // One (channel, window) pair per thread and trip (one thread per channel doing its k*k windows in turn left 224 of the
+  // block's 256 threads idle through ~1100 conditional fp64 adds: 110 of the kernel's 124 us).
   // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
   // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
-  for (int u = 0; u < k; ++u) {
-    for (int v = 0; v < k; ++v) {
-      double a = tot;
-      for (int r = 0; r < nb; ++r) {
-        if (r < u) a -= P(r, 0);
-        if (r >= u) a -= P(nb + r, 0);
-      }
-      for (int j = 0; j < nb; ++j) {
-        const bool l_ex = j < v, r_ex = j >= v;
-        if (l_ex) a -= col[j];
-        if (r_ex) a -= col[nb + j];
-        for (int r = 0; r < nb; ++r) {  // excluded rows x excluded columns were subtracted twice
-          if (r < u) a += (l_ex ? P(r, 1 + j) : 0.0) + (r_ex ? P(r, 1 + nb + j) : 0.0);
-          if (r >= u) a += (l_ex ? P(nb + r, 1 + j) : 0.0) + (r_ex ? P(nb + r, 1 + nb + j) : 0.0);
-        }
-      }
-      out[((size_t)b * C + c) * (k * k) + u * k + v] = a;
+  const int kk = k * k;
+  for (int it = threadIdx.x; it < nch * kk; it += kThreads) {
+    const int cl = it / kk, uv = it - cl * kk;
+    const int u = uv / k, v = uv - u * k;
+    auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
+    double a = s_tot[cl * nval];
+    for (int r = 0; r < nb; ++r) a -= r < u ? P(r, 0) : P(nb + r, 0);
+    for (int j = 0; j < nb; ++j) {
+      const int i = j < v ? 1 + j : 1 + nb + j;  // the excluded column of this pair: left border j < v, right border j >= v
+      a -= s_tot[cl * nval + i];
+      for (int r = 0; r < nb; ++r) a += r < u ? P(r, i) : P(nb + r, i);  // excluded rows x excluded columns were subtracted twice
     }
+    out[((size_t)b * C + c0) * kk + it] = a;
   }
 }
 
@@ -358,7 +347,24 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
   double acc[kGemvMaxE];
 #pragma unroll
   for (int e = 0; e < kGemvMaxE; ++e) acc[e] = 0.0;
-  for (int j = threadIdx.x; j < K; j += kThreads) {
+  // five columns per trip: their (1 + E) x 5 loads are in flight together (one column per trip was latency-bound: 84 us for
+  // 13 MB of S and a weight matrix that sits in L2)
+  int j = threadIdx.x;
+  for (; j + 4 * kThreads < K; j += 5 * kThreads) {
+    double s[5], w[5][kGemvMaxE];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      s[u] = sb[j + u * kThreads];
+#pragma unroll
+      for (int e = 0; e < kGemvMaxE; ++e) w[u][e] = e < E ? Wm[(size_t)e * K + j + u * kThreads] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 5; ++u)
+#pragma unroll
+      for (int e = 0; e < kGemvMaxE; ++e)
+        if (e < E) acc[e] += s[u] * w[u][e];
+  }
+  for (; j < K; j += kThreads) {
     const double s = sb[j];
 #pragma unroll
     for (int e = 0; e < kGemvMaxE; ++e)
