@@ -69,6 +69,7 @@ SIGNATURES = {
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_window_sums_nhwc_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_window_sums_nhwc": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_window_sums_bwd_expand_nhwc": (_int, [_vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_group_argmax": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_vnsmall_workspace_bytes": (ctypes.c_int64, [_int, _int]),
     "eqa_vnsmall_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),

@@ -188,6 +188,25 @@ __global__ __launch_bounds__(kThreads) void bias_relu_nhwc_kernel(float* __restr
 }
 
 
+// Backward of the window sums (training): a pixel receives the sum of dS over the windows that contain it, which depends
+// only on the CLASS of its row and of its column -- border index i < nb, interior (class nb), or bottom / right border
+// nb + 1 + (i - (n - nb)).  table:(B, 2nb+1, 2nb+1, C) holds one gradient per class pair (built by the caller from dS, a
+// few KB per image); this kernel expands it to dx:(B,H,W,C): a pure streaming write, one block per (image, row), float4
+// over channels.  (As two torch index lookups the expansion took 1.6 ms of the 53 ms training step; 2.0 GB written.)
+__global__ __launch_bounds__(kThreads) void window_sums_bwd_expand_kernel(const float* __restrict__ table, float* __restrict__ dx,
+                                                                         int H, int W, int C4, int nb) {
+  const int y = blockIdx.x % H;
+  const size_t b = blockIdx.x / H;
+  const int T = 2 * nb + 1;
+  auto cls = [nb](int i, int n) { return i < nb ? i : (i >= n - nb ? i - (n - nb) + nb + 1 : nb); };
+  const float4* trow = reinterpret_cast<const float4*>(table) + (b * T + cls(y, H)) * (size_t)T * C4;
+  float4* orow = reinterpret_cast<float4*>(dx) + (b * H + y) * (size_t)W * C4;
+  for (int i = threadIdx.x; i < W * C4; i += kThreads) {
+    const int x = i / C4, c4 = i - x * C4;
+    orow[i] = trow[cls(x, W) * C4 + c4];
+  }
+}
+
 // segment s of image b: rows [seg_y0(s), seg_y1(s)).  Output per (b, s, c): 1 + 2(k-1) floats
 //   [0] total, [1 + j] column j, [1 + (k-1) + j] column W-k+1+j      (j < k-1), all over the segment's rows.
 __device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands, int& y0, int& y1) {
@@ -467,6 +486,15 @@ int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, voi
   const size_t n_vec = (size_t)n_pixels * (C / 4);
   const unsigned blocks = (unsigned)((n_vec + kThreads - 1) / kThreads < 8192 ? (n_vec + kThreads - 1) / kThreads : 8192);
   hipLaunchKernelGGL(bias_relu_nhwc_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, x, bias, n_vec, C / 4);
+  return launch_status();
+}
+
+int eqa_window_sums_bwd_expand_nhwc(const float* table, float* dx, int B, int H, int W, int C, int k, void* stream) {
+  if (!table || !dx || B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || H < 2 * k - 1 || W < 2 * k - 1) return EQA_ERR_INVALID_ARG;
+  if (C % 4 != 0 || (((uintptr_t)table | (uintptr_t)dx) & 15) || (size_t)B * H > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  if (B == 0) return EQA_OK;
+  hipLaunchKernelGGL(window_sums_bwd_expand_kernel, dim3((unsigned)((size_t)B * H)), dim3(kThreads), 0, (hipStream_t)stream, table,
+                     dx, H, W, C / 4, k - 1);
   return launch_status();
 }
 

@@ -25,6 +25,7 @@ from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_lay
     RotoReflectionEquivariantConv,
     RotoReflectionEquivariantConvLift,
 )
+from equiadapt_amd import ops
 from equiadapt_amd.common.utils import update_running_stats
 from equiadapt_amd.images.canonicalization_networks import winograd
 from equiadapt_amd.images.canonicalization_networks.pooling import (
@@ -37,6 +38,27 @@ from equiadapt_amd.images.canonicalization_networks.pooling import (
 
 class _InnerBatchNorm(nn.BatchNorm3d):
     """Per-field batch norm over (batch, group, space) of a (B, fields, G, H, W) map."""
+
+
+class LiftConvFunction(torch.autograd.Function):
+    """Training counterpart of the lifting convolution in `_forward_inference`: forward on the fp32-MFMA kernel
+    (`eqa_lift_conv_nhwc`, 0.71 ms at the headline shape; the framework's convolution: 1.5 ms), filter gradient through the
+    framework's convolution-weight-gradient (the input image needs no gradient in the canonicalizer; if asked for, it is
+    the framework's too)."""
+
+    @staticmethod
+    def forward(ctx, x, bank):
+        ctx.save_for_backward(x, bank)
+        k = bank.shape[-1]
+        return ops.lift_conv_nhwc(x, ops.pack_lift_weights(bank.detach()), None, False, bank.shape[-2], k)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, bank = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.nn.grad.conv2d_input(x.shape, bank, dy) if ctx.needs_input_grad[0] else None
+        dbank = torch.nn.grad.conv2d_weight(x, bank.shape, dy) if ctx.needs_input_grad[1] else None
+        return dx, dbank
 
 
 class InnerBnReluDropout(torch.autograd.Function):
@@ -292,6 +314,9 @@ class ESCNNEquivariantNetwork(nn.Module):
             bank = conv.expanded_weights()
             if not conv.lifting and conv.kernel_size == 5 and winograd.applicable(h, bank.shape[1], bank.shape[0]):
                 h = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h))
+            elif (conv.lifting and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
+                  and ops.lift_conv_supported(bank.shape[1], conv.kernel_size, conv.kernel_size, bank.shape[0])):
+                h = LiftConvFunction.apply(h, bank)
             else:
                 h = F.conv2d(h, bank.contiguous(memory_format=torch.channels_last))
             if os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and h.is_contiguous(memory_format=torch.channels_last):

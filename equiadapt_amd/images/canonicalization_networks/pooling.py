@@ -58,7 +58,7 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
 class WindowSumsFunction(torch.autograd.Function):
     """S[b,c,u,v] = sum over the (H-k+1, W-k+1) window at (u, v) of x[b,c] (fp64), with its backward: a pixel (y, x) receives
     the sum of dS over the windows that contain it.  Rows fall into 2(k-1)+1 classes (the k-1 top rows, the interior, the k-1
-    bottom rows), columns likewise, so the gradient is a (2k-1) x (2k-1) table per (b, c) expanded by two index lookups.
+    bottom rows), columns likewise, so the gradient is a (2k-1) x (2k-1) table per (b, c), expanded to the map by `eqa_window_sums_bwd_expand_nhwc`.
     Training counterpart of `conv_then_group_pool` (the last convolution + group mean are linear in x)."""
 
     @staticmethod
@@ -86,8 +86,16 @@ class WindowSumsFunction(torch.autograd.Function):
 
         rm, ty = classes(H)
         cm, tx = classes(W)
-        table = torch.einsum("tu,bcuv,sv->btsc", rm, dS, cm).float()            # (B, 2nb+1, 2nb+1, C), channels last
-        g = table[:, ty][:, :, tx]                                               # (B, H, W, C)
+        table = torch.einsum("tu,bcuv,sv->btsc", rm, dS, cm).float().contiguous()  # (B, 2nb+1, 2nb+1, C), channels last
+        if table.is_cuda and C % 4 == 0:
+            from equiadapt_amd import _lib, ops
+
+            g = torch.empty((B, H, W, C), dtype=torch.float32, device=dev)
+            with torch.cuda.device(dev):
+                st = _lib.load().eqa_window_sums_bwd_expand_nhwc(table.data_ptr(), g.data_ptr(), B, H, W, C, k, ops._stream())
+            _lib.check(st, "eqa_window_sums_bwd_expand_nhwc")
+        else:
+            g = table[:, ty][:, :, tx]                                           # (B, H, W, C)
         g = g.permute(0, 3, 1, 2)                                                # NCHW view of channels-last memory
         if not ctx.channels_last:
             g = g.contiguous()

@@ -194,6 +194,14 @@ int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, voi
 int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k);
 int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
                          int B, int C, int H, int W, int k, void* stream);
+/*
+ * Training: backward of eqa_window_sums_nhwc (the reference gets it from autograd through the last R2Conv + torch.mean,
+ * escnn_networks.py:106-115).  A pixel receives the sum of dS over the windows containing it, which depends only on the class
+ * of its row and column (border index i < k-1, interior = k-1, bottom / right border k + (i - (n-k+1))).
+ * table:(B, 2k-1, 2k-1, C) fp32, one gradient per class pair (the caller builds it from dS); dx:(B,H,W,C).
+ * H, W >= 2k-1, C % 4 == 0, 16-byte aligned.
+ */
+int eqa_window_sums_bwd_expand_nhwc(const float* table, float* dx, int B, int H, int W, int C, int k, void* stream);
 
 /*
  * Training-mode hidden block of the canonicalization network, channels-last: InnerBatchNorm -> ReLU -> PointwiseDropout

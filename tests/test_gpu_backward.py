@@ -436,3 +436,39 @@ def test_padded_input_gradient_frame_gather_equals_atomic_scatter(dev):
         y = ops.canon_transform(src, gidx, th, fl, pad)
         lhs, rhs = (y * gy).sum().item(), (src * g1).sum().item()
         assert abs(lhs - rhs) <= 1e-3 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.gpu
+def test_window_sums_backward_expand_matches_index_lookups(dev):
+    """eqa_window_sums_bwd_expand_nhwc (class table -> (B,H,W,C) gradient map) vs the two index lookups it replaces, bit
+    for bit, and the whole WindowSumsFunction backward vs autograd through an explicit unfold-and-sum in fp64."""
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.canonicalization_networks.pooling import WindowSumsFunction
+
+    lib = _lib.load()
+    torch.manual_seed(5)
+    for (B, H, W, C, k) in [(3, 20, 17, 8, 5), (2, 9, 9, 4, 5), (1, 12, 30, 64, 3), (5, 7, 8, 12, 2)]:
+        nb = k - 1
+        T = 2 * nb + 1
+        table = torch.randn(B, T, T, C, device=dev)
+        got = torch.empty(B, H, W, C, device=dev)
+        assert lib.eqa_window_sums_bwd_expand_nhwc(table.data_ptr(), got.data_ptr(), B, H, W, C, k, ops._stream()) == 0
+
+        def idx(n):
+            i = torch.arange(n, device=dev)
+            return torch.where(i < nb, i, torch.where(i >= n - nb, i - (n - nb) + nb + 1, torch.full_like(i, nb)))
+
+        assert torch.equal(got, table[:, idx(H)][:, :, idx(W)]), (B, H, W, C, k)
+        x = torch.randn(B, C, H, W, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        wS = torch.randn(B, C, k, k, device=dev, dtype=torch.float64)
+        (WindowSumsFunction.apply(x, k) * wS).sum().backward()
+        x64 = x.detach().double().requires_grad_(True)
+        S = torch.stack([torch.stack([x64[:, :, u:u + H - k + 1, v:v + W - k + 1].sum((-1, -2)) for v in range(k)], -1)
+                         for u in range(k)], -2)
+        (S * wS).sum().backward()
+        assert torch.allclose(x.grad.double(), x64.grad, rtol=1e-5, atol=1e-5), (B, H, W, C, k)
+    # refused, not approximated: channels not a multiple of 4, map smaller than the two borders
+    t = torch.zeros(1, 9, 9, 6, device=dev)
+    o = torch.zeros(1, 9, 9, 6, device=dev)
+    assert lib.eqa_window_sums_bwd_expand_nhwc(t.data_ptr(), o.data_ptr(), 1, 9, 9, 6, 5, None) == -3
+    assert lib.eqa_window_sums_bwd_expand_nhwc(t.data_ptr(), o.data_ptr(), 1, 8, 9, 8, 5, None) == -1
