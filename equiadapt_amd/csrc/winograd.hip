@@ -141,10 +141,24 @@ __global__ __launch_bounds__(kThreads) void winograd_k5_input_kernel(const float
   const int gy0 = MT * ty - (PAD ? pad : 0), gx0 = MT * tx0 - (PAD ? pad : 0);
   const float* p = x + ((ptrdiff_t)(img * H) + gy0) * (ptrdiff_t)W * C + (ptrdiff_t)gx0 * C + c;
   const float ib = in_bias ? in_bias[c] : 0.0f;
+  // PAD: out-of-range taps load the clamped pixel and select 0 afterwards.  (Row and column are the same for the whole
+  // block, so `in ? load : 0` compiled to a scalar branch around every single load -- no two loads in flight together:
+  // 4.1 ms for the 96x96 padded gradient against 1.8 ms for the unpadded 92x92 forward.)  The clamped row offsets are
+  // computed once per block, the clamped column offset once per column: one add per tap.
+  const float* ximg = x + (ptrdiff_t)(img * H) * (ptrdiff_t)W * C + c;
+  unsigned roff[N];
+  bool rin[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int yy = min(max(gy0 + i, 0), H - 1);
+    roff[i] = PAD ? (unsigned)yy * (unsigned)W * (unsigned)C : 0u;  // launch_wino_input: H * W * C < 2^31 with PAD
+    rin[i] = yy == gy0 + i;
+  }
   auto tap = [&](const float* q, int i, int k, int gx_base, int tag) -> float {
     if (PAD) {
-      const bool in = (unsigned)(gy0 + i) < (unsigned)H && (unsigned)(gx_base + k) < (unsigned)W;
-      return in ? wino_act(WINO_LD(q + ((ptrdiff_t)i * W + k) * C, tag), ib, in_relu) : 0.0f;
+      const int xx = min(max(gx_base + k, 0), W - 1);
+      const float v = wino_act(WINO_LD(ximg + (roff[i] + (unsigned)xx * (unsigned)C), tag), ib, in_relu);
+      return (rin[i] && xx == gx_base + k) ? v : 0.0f;
     }
     return wino_act(WINO_LD(q + ((ptrdiff_t)i * W + k) * C, tag), ib, in_relu);
   };
@@ -372,6 +386,7 @@ int launch_wino_input(const float* x, float* V, const float* in_bias, int in_rel
   nstrip = (TX + strip_len - 1) / strip_len;
   const size_t nwork = rows * nstrip;
   if (nwork > 0x7fffffffULL || rows * TX > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  if (pad && (size_t)H * W * C > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   if (pad)
     hipLaunchKernelGGL((winograd_k5_input_kernel<N, true>), dim3((unsigned)nwork, cb), dim3(kThreads), 0, (hipStream_t)stream,
                        x, V, in_bias, in_relu, H, W, C, TY, TX, nstrip, strip_len, nwork, pad);
