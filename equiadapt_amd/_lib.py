@@ -35,6 +35,7 @@ SIGNATURES = {
     "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
     "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 9 + [_vp]),
     "eqa_mask_action_nearest": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),
+    "eqa_boxes_action": (_int, [_vp] * 5 + [_int, ctypes.c_float, _int, _vp]),
     "eqa_image_action_nearest": (_int, [_vp] * 5 + [_int] * 10 + [_vp]),
     "eqa_group_action_bwd_tiles": (_int, [_int, _int]),
     "eqa_group_action_bwd": (_int, [_vp] * 8 + [_int] * 12 + [_vp]),

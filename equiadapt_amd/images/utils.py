@@ -158,6 +158,33 @@ def rotate_masks(masks: torch.Tensor, angle: float) -> torch.Tensor:
     return out.squeeze(0) if squeeze else out
 
 
+def owner_table(counts, device) -> torch.Tensor:
+    """int32 (sum(counts),): index of the sample each box / mask of a batch belongs to.  Built on the host from the list
+    lengths (known without a sync) and cached per length pattern: a training loop sees the same few patterns again and again,
+    and ``repeat_interleave`` with a device count tensor costs an upload plus three launches every call."""
+    key = ("owner", tuple(counts), str(device))
+    hit = _device_tables.get(key)
+    if hit is None:
+        if sum(1 for k in _device_tables if k[0] == "owner") > 256:
+            for k in [k for k in _device_tables if k[0] == "owner"]:
+                del _device_tables[k]
+        hit = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32), torch.tensor(counts)).to(device)
+        _device_tables[key] = hit
+    return hit
+
+
+def canonicalize_boxes(box_list, rotation_deg: torch.Tensor, width: int, flip_all: bool):
+    """All samples' (n_t, 4) boxes in ONE launch (``eqa_boxes_action``): flipped when the group has reflections (every box,
+    the reference's behaviour), then rotated by the sample's angle.  The caller's tensors receive the flipped values in place,
+    as in the reference.  Reference: discrete_group.py:217-236 with flip_boxes / rotate_boxes (images/utils.py:97-109,161-187)."""
+    counts = [int(b.shape[0]) for b in box_list]
+    all_boxes = torch.cat(list(box_list), dim=0).contiguous()
+    new, flipped = ops.boxes_action(all_boxes, owner_table(counts, all_boxes.device), rotation_deg.contiguous(), width, flip_all)
+    if flipped is not None:
+        torch._foreach_copy_(list(box_list), list(flipped.split(counts)))
+    return list(new.split(counts))
+
+
 def canonicalize_masks(mask_list, group_index: torch.Tensor, num_rotations: int, flip_all: bool):
     """All samples' masks in ONE launch: mask k of sample t is (flipped if ``flip_all``, the reference's behaviour
     whenever the group has reflections, then) rotated by -angle of sample t's group element.  No host sync: the element
@@ -177,7 +204,7 @@ def canonicalize_masks(mask_list, group_index: torch.Tensor, num_rotations: int,
         _device_tables[key] = hit
     rtheta, flags = hit
     ridx = (group_index % num_rotations).to(torch.int32)
-    eidx = torch.repeat_interleave(ridx, torch.tensor(counts, device=dev), output_size=sum(counts)).to(torch.int32)
+    eidx = ridx[owner_table(counts, dev).long()]
     out = ops.mask_action_nearest(torch.cat(list(mask_list), dim=0).contiguous(), eidx, rtheta, flags)
     return list(torch.split(out, counts, dim=0))
 

@@ -354,6 +354,24 @@ def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.T
     return out
 
 
+def boxes_action(boxes: torch.Tensor, img_of_box: torch.Tensor, rotation_deg: torch.Tensor, width: float,
+                 flip_all: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """I6: every (n,4) xyxy box flipped (if ``flip_all``) and rotated by its image's angle about (width/2, width/2), one
+    launch (eqa_boxes_action).  Returns (new boxes, boxes after the flip or None)."""
+    lib = _lib.load()
+    boxes = _need(boxes, "boxes")
+    img_of_box = _need(img_of_box, "img_of_box", torch.int32)
+    rotation_deg = _need(rotation_deg, "rotation_deg")
+    out = torch.empty_like(boxes)
+    flipped = torch.empty_like(boxes) if flip_all else None
+    with torch.cuda.device(boxes.device):
+        st = lib.eqa_boxes_action(boxes.data_ptr(), img_of_box.data_ptr(), rotation_deg.data_ptr(),
+                                  flipped.data_ptr() if flip_all else None, out.data_ptr(), boxes.shape[0], float(width),
+                                  int(flip_all), _stream())
+    _lib.check(st, "eqa_boxes_action")
+    return out, flipped
+
+
 def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
     """In place x = relu(x + bias[c]) on a channels-last (B,C,H,W) tensor (eqa_bias_relu_nhwc)."""
     lib = _lib.load()

@@ -118,6 +118,16 @@ int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx,
                             int num_elements, int n_masks, int H, int W, void* stream);
 
 /*
+ * I6 -- the boxes of a batch follow their images: flip_boxes (equiadapt/images/utils.py:97-109; applied to EVERY box when
+ * the group has reflections, discrete_group.py:220-224) then rotate_boxes (:161-187: both corners rotated about
+ * (width/2, width/2) by the image's angle in degrees, rotate_points :139-158, and re-sorted into x0<=x1, y0<=y1).
+ * boxes,out:(n,4) xyxy fp32, 16-byte aligned; img_of_box:(n) image of each box; rotation_deg:(B) per image;
+ * flipped:(n,4) or NULL receives the boxes after the flip (the reference flips the caller's tensors in place).
+ */
+int eqa_boxes_action(const float* boxes, const int32_t* img_of_box, const float* rotation_deg, float* flipped, float* out,
+                     int n, float width, int flip_all, void* stream);
+
+/*
  * (f).2 -- nearest-neighbour group action on fp32 image planes with edge padding and a crop window: the test-time orbit
  * of GroupInference (examples/images/classification/inference_utils.py:100-123: transforms.Pad(0.4 H, edge) ->
  * [hflip] -> transforms.functional.rotate(+deg) [NEAREST by default] -> CenterCrop).

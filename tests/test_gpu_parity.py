@@ -961,3 +961,34 @@ def test_escnn_four_layers_two_winograd_layers(dev, group_type, N, monkeypatch):
         if g <= 1e-5:
             continue
         assert (p1.grad - p2.grad).abs().max().item() <= 5e-3 * g, (n1, (p1.grad - p2.grad).abs().max().item(), g)
+
+
+def test_boxes_action_matches_flip_and_rotate_boxes(dev):
+    """eqa_boxes_action (one launch for every box of the batch) vs the reference's op sequence flip_boxes -> rotate_boxes
+    per sample (images/utils.py:97-109,161-187), incl. the in-place flip of the caller's tensors and empty box lists.
+    Same fp32 arithmetic; allowed difference: 2 ulp of the coordinate range (cos / sin come from the same library)."""
+    from equiadapt_amd.images.utils import canonicalize_boxes, flip_boxes, rotate_boxes
+
+    torch.manual_seed(77)
+    W = 1024
+    counts = [3, 0, 7, 1, 12, 5]
+    rot = torch.tensor([0.0, 45.0, 90.0, 135.0, 270.0, 315.0], device=dev)
+    for flip_all in (False, True):
+        boxes = []
+        for n in counts:
+            xy = torch.rand(n, 2, 2, device=dev) * W
+            boxes.append(torch.cat([xy.min(1).values, xy.max(1).values], dim=1).contiguous())
+        mine_in = [b.clone() for b in boxes]
+        ref_in = [b.clone() for b in boxes]
+        want = []
+        for t, b in enumerate(ref_in):
+            if flip_all:
+                b = flip_boxes(b, W)
+            want.append(rotate_boxes(b, rot[t], W))
+        got = canonicalize_boxes(mine_in, rot, W, flip_all)
+        for t in range(len(counts)):
+            assert got[t].shape == (counts[t], 4)
+            assert torch.equal(mine_in[t], ref_in[t])                      # the caller's tensors: flipped in place or untouched
+            if counts[t]:
+                assert (got[t] - want[t]).abs().max().item() <= 2.5e-4, (flip_all, t, (got[t] - want[t]).abs().max().item())
+                assert (got[t][:, 0] <= got[t][:, 2]).all() and (got[t][:, 1] <= got[t][:, 3]).all()
