@@ -117,8 +117,16 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
         """
         if group_index is None:
             group_index = self.group_index(group_activations)
-        onehot = self.groupactivations_to_groupelementonehot(group_activations, group_index)
         rot_comp, ref_comp = self._group_constants(group_activations.device)
+        if not self.training and self.gradient_trick == "straight_through":
+            # eval mode: the one-hot is the hard one, so sum(onehot * table) IS table[index] (one term, the rest exact zeros):
+            # two lookups instead of one_hot / multiply / reduce per component (the step is launch-bound at small batches)
+            element = {"rotation": torch.index_select(rot_comp, 0, group_index)}
+            if ref_comp is not None:
+                element["reflection"] = torch.index_select(ref_comp, 0, group_index)
+            element["group_index"] = group_index
+            return element
+        onehot = self.groupactivations_to_groupelementonehot(group_activations, group_index)
         element = {"rotation": torch.sum(onehot * rot_comp, dim=-1)}
         if ref_comp is not None:
             element["reflection"] = torch.sum(onehot * ref_comp, dim=-1)

@@ -122,6 +122,17 @@ class _GroupConvBase(nn.Module):
         self._cached_weff = (w._version, weff)
         return weff
 
+    def mean_bias_value(self) -> float:
+        """mean(bias) as a Python float, cached per parameter version (inference: one host read when the weights change,
+        then no launches at all for the bias of the linearised last layer)."""
+        if self.bias is None:
+            return 0.0
+        ver, hit = getattr(self, "_cached_bias_mean", (-1, 0.0))
+        if ver != self.bias._version:
+            hit = float(self.bias.detach().double().mean().item())
+            self._cached_bias_mean = (self.bias._version, hit)
+        return hit
+
     def supports_linear_tail(self) -> bool:
         return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
 

@@ -47,8 +47,7 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
     if S.is_cuda and weff.shape[0] <= 16 and not torch.is_grad_enabled():
         from equiadapt_amd import ops
 
-        shift = 0.0 if layer.bias is None else layer.bias.detach().double().mean()
-        return ops.window_sums_gemv(S.flatten(1), weff, scale, shift)
+        return ops.window_sums_gemv(S.flatten(1), weff, scale, layer.mean_bias_value())
     act = S.flatten(1) @ weff.t() * scale
     if layer.bias is not None:
         act = act + layer.bias.detach().double().mean()
