@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip", "vnsmall_train.hip")]
-HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "pointcloud.hip", "vnsmall_train.hip", "fftconv.hip")]
+HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
 _c_f = ctypes.POINTER(ctypes.c_float)
@@ -67,6 +67,10 @@ SIGNATURES = {
     "eqa_winograd_f2k5_output_sums_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_winograd_f2k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_winograd_f4k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48k5_tiles": (ctypes.c_int64, [_int]),
+    "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
+    "eqa_fft48k5_output_sums": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_window_sums_nhwc_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_window_sums_nhwc": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),

@@ -1,0 +1,255 @@
+// libeqa_hip.so, part 8 -- 5x5 stride-1 group convolutions in inference as an overlap-save FFT convolution (I2a).
+// C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+//
+// Winograd F(4x4,5x5) needs 4 multiplies per output and a 4x expansion of the activations (V, M: 8.1 GB each at the
+// headline shape); its library GEMM runs at the clock-limited fp32 roofline, so only fewer multiplies help.  A 48x48
+// real FFT tile gives 44x44 outputs -- two tiles cover the 88 output rows / columns exactly -- with 48 x 25 complex
+// frequencies: 4 real multiplies per complex one make 2.48 per output, and the spectra are only 1.24x the activations.
+// Per frequency f = (ky, kx) the channel contraction is a complex matrix product, done by the GEMM library as a REAL one
+// through [Ar | Ai] . [[Br, Bi], [-Bi, Br]] = [Cr | Ci]  (A: tiles x 2 Cin, B: 2 Cin x 2 Cout, batched over 1200 f).
+// conv2d is a cross-correlation: B holds conj(FFT(filter)) / 48^2, computed once per weight version on the host side.
+// fp32 throughout; error vs an fp64 convolution ~1e-6 of max|y| (Winograd F(4,5): 9e-6).
+//
+// Four streaming kernels, one thread per channel (channels-last: every load and store instruction of a wave is one
+// contiguous run of channels), one 48-point transform per thread held in registers (fft48.inc, generated, 819 flops):
+//   rows_fwd   x (nimg,H,W,C) -> T (nimg,H,TX,25,2,C): real rows of 48 pixels (tile columns 44 tx .. 44 tx + 47, zero
+//              beyond W), previous layer's bias / ReLU applied while loading
+//   cols_fwd   T -> V (1200, M, 2C): columns of 48 rows (44 ty .. 44 ty + 47, zero beyond H), M = nimg*TY*TX tiles
+//   [ batched GEMM by the caller: Mo[f] = V[f] . B[f] ]
+//   cols_inv   Mo (1200, M, 2C) -> T2 (nimg,OH,TX,25,2,C): inverse over ky, rows 44..47 of a tile (circular wrap) dropped
+//   rows_inv   T2 -> y (nimg,OH,OW,C) = [relu](. + bias), or -> the window-sum segments of the next (last, linearised)
+//              layer in the format of window_sums_nhwc_finalize_kernel (one segment per output row)
+#include "eqa_common.hpp"
+
+namespace {
+
+constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
+#include "fft48.inc"
+
+#define FFT_LDG(p) __builtin_nontemporal_load(p)
+#define FFT_STG(p, v) __builtin_nontemporal_store((v), (p))
+
+__global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ T,
+                                                                 const float* __restrict__ in_bias, int in_relu, int H, int W,
+                                                                 int C, int TX) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const int xt = blockIdx.x % TX;
+  const size_t row = blockIdx.x / TX;  // img * H + y
+  const float ib = in_bias ? in_bias[c] : 0.0f;
+  const float* p = x + (row * W + (size_t)kFftO * xt) * C + c;
+  const int nvalid = min(kFftN, W - kFftO * xt);  // uniform
+  float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+  for (int j = 0; j < kFftN; ++j) {
+    // columns beyond the image: the clamped pixel is loaded and replaced by 0 (a uniform `j < nvalid ? load : 0` would
+    // become a scalar branch around every load)
+    float v = p[(size_t)min(j, nvalid - 1) * C] + ib;
+    v = in_relu ? fmaxf(v, 0.0f) : v;
+    re[j] = j < nvalid ? v : 0.0f;
+    im[j] = 0.0f;
+  }
+  fft48(re, im, ore, oim);
+  float* o = T + ((row * TX + xt) * kFftH) * 2 * (size_t)C + c;
+#pragma unroll
+  for (int k = 0; k < kFftH; ++k) {
+    o[(size_t)(2 * k) * C] = ore[k];
+    o[(size_t)(2 * k + 1) * C] = oim[k];
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* __restrict__ T, float* __restrict__ V, int H, int C,
+                                                                 int TY, int TX, size_t M) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const int kx = blockIdx.x % kFftH;
+  const size_t m = blockIdx.x / kFftH;  // (img * TY + ty) * TX + tx
+  const int tx = (int)(m % TX);
+  const int ty = (int)((m / TX) % TY);
+  const size_t img = m / ((size_t)TX * TY);
+  const int y0 = kFftO * ty;
+  const int nvalid = min(kFftN, H - y0);  // uniform
+  const size_t pitch = (size_t)TX * kFftH * 2 * C;  // one image row of T
+  const float* p = T + ((img * H + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
+  float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+  for (int i = 0; i < kFftN; ++i) {
+    const size_t off = (size_t)min(i, nvalid - 1) * pitch;
+    const float a = p[off], b = p[off + C];
+    re[i] = i < nvalid ? a : 0.0f;
+    im[i] = i < nvalid ? b : 0.0f;
+  }
+  fft48(re, im, ore, oim);
+  float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+  const size_t fpitch = (size_t)kFftH * M * 2 * C;  // from ky to ky + 1
+#pragma unroll
+  for (int ky = 0; ky < kFftN; ++ky) {
+    FFT_STG(o + ky * fpitch, ore[ky]);
+    FFT_STG(o + ky * fpitch + C, oim[ky]);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* __restrict__ Mo, float* __restrict__ T2, int OH, int C,
+                                                                 int TY, int TX, size_t M) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const int kx = blockIdx.x % kFftH;
+  const size_t m = blockIdx.x / kFftH;
+  const int tx = (int)(m % TX);
+  const int ty = (int)((m / TX) % TY);
+  const size_t img = m / ((size_t)TX * TY);
+  const float* p = Mo + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+  const size_t fpitch = (size_t)kFftH * M * 2 * C;
+  float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+  for (int ky = 0; ky < kFftN; ++ky) {
+    re[ky] = FFT_LDG(p + ky * fpitch);
+    im[ky] = FFT_LDG(p + ky * fpitch + C);
+  }
+  fft48(im, re, oim, ore);  // inverse: real and imaginary parts swapped in and out (1 / 48^2 is in the filter spectra)
+  const int y0 = kFftO * ty;
+  const int nrows = min(kFftO, OH - y0);  // uniform; rows 44..47 of the tile are the circular wrap-around
+  const size_t pitch = (size_t)TX * kFftH * 2 * C;
+  float* o = T2 + ((img * OH + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
+#pragma unroll
+  for (int i = 0; i < kFftO; ++i) {
+    if (i < nrows) {
+      o[i * pitch] = ore[i];
+      o[i * pitch + C] = oim[i];
+    }
+  }
+}
+
+// NB = k_next - 1 border columns on each side are needed one by one for the window sums; 0: plain output
+template <int NB>
+__global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* __restrict__ T2, const float* __restrict__ bias, int relu,
+                                                                 float* __restrict__ out, int OH, int OW, int C, int TX) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t row = blockIdx.x;  // img * OH + y
+  const int y = (int)(row % OH);
+  const size_t img = row / OH;
+  const float b = bias ? bias[c] : 0.0f;
+  constexpr int NV = 1 + 2 * NB;
+  float acc[NV > 1 ? NV : 1];
+#pragma unroll
+  for (int i = 0; i < (NV > 1 ? NV : 1); ++i) acc[i] = 0.0f;
+  for (int tx = 0; tx < TX; ++tx) {
+    const float* p = T2 + ((row * TX + tx) * kFftH) * 2 * (size_t)C + c;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+    for (int k = 0; k < kFftH; ++k) {
+      re[k] = p[(size_t)(2 * k) * C];
+      im[k] = p[(size_t)(2 * k + 1) * C];
+    }
+#pragma unroll
+    for (int k = kFftH; k < kFftN; ++k) {  // the other half of a real signal's spectrum
+      re[k] = re[kFftN - k];
+      im[k] = -im[kFftN - k];
+    }
+    fft48(im, re, oim, ore);
+    const int x0 = kFftO * tx;
+    const int ncols = min(kFftO, OW - x0);  // uniform
+    if (NB == 0) {
+      float* o = out + (row * OW + x0) * (size_t)C + c;
+#pragma unroll
+      for (int j = 0; j < kFftO; ++j) {
+        if (j < ncols) {
+          const float v = ore[j] + b;
+          o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
+        }
+      }
+    } else {
+      float tot = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kFftO; ++j) {
+        float v = ore[j] + b;
+        v = relu ? fmaxf(v, 0.0f) : v;
+        v = j < ncols ? v : 0.0f;
+        tot += v;
+        const int xx = x0 + j;  // uniform
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          if (xx == q) acc[1 + q] += v;
+          if (xx == OW - NB + q) acc[1 + NB + q] += v;
+        }
+      }
+      acc[0] += tot;
+    }
+  }
+  if (NB > 0) {
+    // one segment per output row, in the order window_sums_nhwc_finalize_kernel expects: rows 0..NB-1, OH-NB..OH-1, interior
+    const int seg = y < NB ? y : (y >= OH - NB ? NB + (y - (OH - NB)) : 2 * NB + (y - NB));
+    float* o = out + ((img * OH + seg) * (size_t)C + c) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = acc[i];
+  }
+}
+
+int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
+
+int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                      void* stream) {
+  if (!x || !T || !V || !fft_dims_ok(nimg, H, W, C)) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  const int TY = (int)eqa_fft48k5_tiles(H), TX = (int)eqa_fft48k5_tiles(W);
+  const size_t M = (size_t)nimg * TY * TX;
+  if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned cb = (C + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)nimg * H * TX), cb), dim3(kThreads), 0, st, x, T, in_bias, in_relu,
+                     H, W, C, TX);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)(M * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C, TY, TX, M);
+  return launch_status();
+}
+
+static int fft_output_common(const float* Mo, float* T2, int nimg, int OH, int OW, int C, hipStream_t st) {
+  const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
+  const size_t M = (size_t)nimg * TY * TX;
+  if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fft48_cols_inv_kernel, dim3((unsigned)(M * kFftH), (C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, Mo, T2,
+                     OH, C, TY, TX, M);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
+                       void* stream) {
+  if (!Mo || !T2 || !y || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = fft_output_common(Mo, T2, nimg, OH, OW, C, st);
+  if (rc != EQA_OK) return rc;
+  const int TX = (OW + kFftO - 1) / kFftO;
+  hipLaunchKernelGGL((fft48_rows_inv_kernel<0>), dim3((unsigned)((size_t)nimg * OH), (C + kThreads - 1) / kThreads), dim3(kThreads), 0,
+                     st, T2, bias, relu, y, OH, OW, C, TX);
+  return launch_status();
+}
+
+int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int relu, double* S, void* workspace, int nimg,
+                            int OH, int OW, int C, int k_next, void* stream) {
+  if (!Mo || !T2 || !S || !workspace || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0 || k_next <= 0) return EQA_ERR_INVALID_ARG;
+  const int nb = k_next - 1;
+  if ((nb != 4 && nb != 2) || OH < 2 * nb + 1 || OW < 2 * nb + 1 || k_next > kMaxWinK || nimg > 65535) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = fft_output_common(Mo, T2, nimg, OH, OW, C, st);
+  if (rc != EQA_OK) return rc;
+  const int TX = (OW + kFftO - 1) / kFftO;
+  const dim3 grid((unsigned)((size_t)nimg * OH), (C + kThreads - 1) / kThreads);
+  float* part = (float*)workspace;  // (nimg, OH, C, 1 + 2 nb) floats
+  if (nb == 4)
+    hipLaunchKernelGGL((fft48_rows_inv_kernel<4>), grid, dim3(kThreads), 0, st, T2, bias, relu, part, OH, OW, C, TX);
+  else
+    hipLaunchKernelGGL((fft48_rows_inv_kernel<2>), grid, dim3(kThreads), 0, st, T2, bias, relu, part, OH, OW, C, TX);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, OH, st);
+}
+
+}  // extern "C"

@@ -27,7 +27,7 @@ from equiadapt_amd.images.canonicalization_networks.custom_group_equivariant_lay
 )
 from equiadapt_amd import ops
 from equiadapt_amd.common.utils import update_running_stats
-from equiadapt_amd.images.canonicalization_networks import winograd
+from equiadapt_amd.images.canonicalization_networks import fftconv, winograd
 from equiadapt_amd.images.canonicalization_networks.pooling import (
     WindowSumsFunction,
     conv_then_group_pool,
@@ -207,6 +207,14 @@ class ESCNNEquivariantNetwork(nn.Module):
             self._fold_cache[("wino", m, id(conv))] = hit
         return hit[1]
 
+    def _fft_filters(self, conv, bank):
+        hit = self._fold_cache.get(("fft", id(conv)))
+        key = self._fold_cache[id(conv)][0]
+        if hit is None or hit[0] != key:
+            hit = (key, fftconv.filter_spectra(bank))
+            self._fold_cache[("fft", id(conv))] = hit
+        return hit[1]
+
     def _lift_weights(self, conv, bank):
         from equiadapt_amd import ops
 
@@ -230,8 +238,23 @@ class ESCNNEquivariantNetwork(nn.Module):
         for i, (conv, bn) in enumerate(zip(convs[:-1], norms)):
             bank, bias = self._folded(conv, bn)
             last_before_tail = i == len(convs) - 2
-            use_wino = (nhwc and not conv.lifting and conv.kernel_size == 5 and conv.stride == 1 and conv.padding == 0
-                        and winograd.applicable(h, bank.shape[1], bank.shape[0]))
+            is_5x5 = nhwc and not conv.lifting and conv.kernel_size == 5 and conv.stride == 1 and conv.padding == 0
+            if is_5x5 and fftconv.applicable(h, bank.shape[1], bank.shape[0]):
+                # 5x5 regular->regular layer whose output the 44-pixel FFT tiles fit: overlap-save FFT convolution, 2.5
+                # multiplies per output (Winograd F(4x4,5x5): 4).  Same fusions as below: the previous layer's bias + ReLU
+                # on the input loads, this layer's on the way out, window sums instead of the map in front of the tail.
+                tail = convs[-1]
+                Bf = self._fft_filters(conv, bank)
+                if last_before_tail and tail.kernel_size in (3, 5) and tail.supports_linear_tail() and \
+                        min(h.shape[-2:]) - 4 >= 2 * tail.kernel_size - 1:
+                    S = fftconv.conv5x5(h, Bf, bias, True, pending, pending is not None, sums_k=tail.kernel_size)
+                    return window_sums_to_activations(S, tail, h.shape[-2] - 4, h.shape[-1] - 4)
+                h = fftconv.conv5x5(h, Bf, bias, True, pending, pending is not None)
+                pending = None
+                if last_before_tail:
+                    return conv_then_group_pool(h, convs[-1])
+                continue
+            use_wino = is_5x5 and winograd.applicable(h, bank.shape[1], bank.shape[0])
             if use_wino:
                 # 5x5 regular->regular layer: Winograd F(m x m, 5x5), m = 4 where the size allows.  The previous layer's
                 # bias + ReLU ride on its input loads, its own bias + ReLU on its output transform.

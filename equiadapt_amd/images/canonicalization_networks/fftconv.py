@@ -1,0 +1,87 @@
+"""5x5 stride-1 convolutions as an overlap-save FFT convolution on 48x48 tiles (inference path of the regular -> regular
+layers, reference: equiadapt/images/canonicalization_networks/escnn_networks.py:67-91).
+
+48x48 real FFT tiles produce 44x44 outputs each; per frequency the channel contraction is a complex matrix product that the
+GEMM library runs as a real one (see include/eqa_hip.h, eqa_fft48k5_*).  Where the tiles fit the output (88 = 2 x 44 at the
+headline shape) this needs 2.5 real multiplies per output against 4 for Winograd F(4x4,5x5), and spectra of 1.24x the
+activation size against 4x.  fp32 throughout."""
+import os
+from typing import Optional
+
+import torch
+
+from equiadapt_amd import _lib
+from equiadapt_amd.ops import _timed
+
+N, NH, OUT = 48, 25, 44
+ENABLED = os.environ.get("EQA_CONV5_FFT", "1") != "0"
+
+
+def tiles(n: int) -> int:
+    return 0 if n <= 4 else (n - 4 + OUT - 1) // OUT
+
+
+def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) -> bool:
+    """Channels-last fp32 device tensor, 5x5 kernel, and tiles that fit the output to within ``max_waste`` (the FFT work is
+    per tile: 88 outputs per axis = 2 tiles exactly, 84 would waste 5 %, 50 would waste 43 % -> Winograd)."""
+    if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        return False
+    H, W = x.shape[-2:]
+    if H < 16 or W < 16 or x.shape[1] != cin:
+        return False
+    oh, ow = H - 4, W - 4
+    return tiles(H) * OUT <= max_waste * oh and tiles(W) * OUT <= max_waste * ow
+
+
+def filter_spectra(bank: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency."""
+    Cout, Cin = bank.shape[:2]
+    wp = torch.zeros(Cout, Cin, N, N, dtype=torch.float64, device=bank.device)
+    wp[:, :, :5, :5] = bank.double()
+    W = torch.fft.rfft2(wp).conj() / float(N * N)                # (Cout, Cin, 48, 25)
+    Wr = W.real.permute(2, 3, 1, 0).reshape(N * NH, Cin, Cout)
+    Wi = W.imag.permute(2, 3, 1, 0).reshape(N * NH, Cin, Cout)
+    top = torch.cat([Wr, Wi], dim=2)                              # rows Re(A): [ Br |  Bi ]
+    bot = torch.cat([-Wi, Wr], dim=2)                             # rows Im(A): [-Bi |  Br ]
+    return torch.cat([top, bot], dim=1).float().contiguous()
+
+
+def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
+            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
+    """x: channels-last (nimg,Cin,H,W) -> channels-last (nimg,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias) with
+    B = filter_spectra(g) and act(x) = [relu](x + in_bias[c]) applied while loading; ``sums_k`` > 0: return instead the
+    (nimg, Cout, sums_k, sums_k) fp64 window sums of that output (the linearised last layer consumes only those)."""
+    lib = _lib.load()
+    nimg, Cin, H, W = x.shape
+    Cout = B.shape[2] // 2
+    assert B.shape == (N * NH, 2 * Cin, 2 * Cout)
+    OH, OW = H - 4, W - 4
+    TY, TX = tiles(H), tiles(W)
+    M = nimg * TY * TX
+    dev = x.device
+    st = torch.cuda.current_stream().cuda_stream
+    T = torch.empty(nimg * H * TX * NH * 2 * Cin, dtype=torch.float32, device=dev)
+    V = torch.empty((N * NH, M, 2 * Cin), dtype=torch.float32, device=dev)
+    p_in_bias = in_bias.data_ptr() if in_bias is not None else None
+    p_bias = bias.data_ptr() if bias is not None else None
+    with torch.cuda.device(dev):
+        with _timed("fft_input"):
+            _lib.check(lib.eqa_fft48k5_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st),
+                       "eqa_fft48k5_input")
+        del T
+        with _timed("fft_gemm"):
+            Mo = torch.bmm(V, B)
+        del V
+        T2 = torch.empty(nimg * OH * TX * NH * 2 * Cout, dtype=torch.float32, device=dev)
+        if sums_k:
+            S = torch.empty((nimg, Cout, sums_k, sums_k), dtype=torch.float64, device=dev)
+            ws = torch.empty(nimg * OH * Cout * (2 * sums_k - 1), dtype=torch.float32, device=dev)
+            with _timed("fft_output_sums"):
+                _lib.check(lib.eqa_fft48k5_output_sums(Mo.data_ptr(), T2.data_ptr(), p_bias, int(relu), S.data_ptr(), ws.data_ptr(),
+                                                       nimg, OH, OW, Cout, sums_k, st), "eqa_fft48k5_output_sums")
+            return S
+        y = torch.empty((nimg, Cout, OH, OW), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        with _timed("fft_output"):
+            _lib.check(lib.eqa_fft48k5_output(Mo.data_ptr(), T2.data_ptr(), p_bias, int(relu), y.data_ptr(), nimg, OH, OW, Cout, st),
+                       "eqa_fft48k5_output")
+        return y
