@@ -229,3 +229,26 @@ def test_update_running_stats_matches_nn_batchnorm():
     c = torch.nn.BatchNorm2d(5, track_running_stats=False)
     update_running_stats(c, torch.zeros(5), torch.ones(5))          # no buffers: nothing to do, must not raise
     assert c.running_mean is None
+
+
+def test_fft_filter_spectra_real_form_reproduces_conv2d():
+    """Host side of the FFT convolution (fftconv.filter_spectra): with the tile spectra taken by torch.fft in the layout the
+    kernels write -- V[f][m] = [Re | Im] over channels, f = ky*25 + kx -- the real-form batched product and the inverse
+    transform give conv2d.  Pins the [[Br, Bi], [-Bi, Br]] block layout, the conjugate (cross-correlation) and the 1/48^2."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(3)
+    B, Cin, Cout = 2, 3, 5
+    x = torch.randn(B, Cin, 48, 48, dtype=torch.float64)
+    w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
+    Bm = fftconv.filter_spectra(w.float()).double()                         # (1200, 2 Cin, 2 Cout)
+    X = torch.fft.rfft2(x)                                                  # (B, Cin, 48, 25)
+    V = torch.cat([X.real, X.imag], dim=1).permute(2, 3, 0, 1).reshape(1200, B, 2 * Cin)
+    Mo = torch.bmm(V, Bm)                                                   # (1200, B, 2 Cout)
+    Y = torch.complex(Mo[..., :Cout], Mo[..., Cout:]).reshape(48, 25, B, Cout).permute(2, 3, 0, 1)
+    y = torch.fft.irfft2(Y, s=(48, 48)) * (48 * 48)                         # the spectra carry 1/48^2; irfft2 divides again
+    want = F.conv2d(x, w)
+    assert (y[:, :, :44, :44] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert fftconv.tiles(92) == 2 and fftconv.tiles(48) == 1 and fftconv.tiles(49) == 2 and fftconv.tiles(4) == 0

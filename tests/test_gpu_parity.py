@@ -992,3 +992,69 @@ def test_boxes_action_matches_flip_and_rotate_boxes(dev):
             if counts[t]:
                 assert (got[t] - want[t]).abs().max().item() <= 2.5e-4, (flip_all, t, (got[t] - want[t]).abs().max().item())
                 assert (got[t][:, 0] <= got[t][:, 2]).all() and (got[t][:, 1] <= got[t][:, 3]).all()
+
+
+def test_fft48_convolution_matches_conv2d(dev):
+    """eqa_fft48k5_* (overlap-save FFT convolution, 48x48 tiles, complex GEMM as a real one) vs F.conv2d in fp64: plain
+    output and the fused window sums, tiles that fit exactly (92 -> 88 = 2 x 44), partial tiles, one tile, non-square maps,
+    the previous layer's bias + ReLU on the loads.  Tolerance 5e-6 of max|y| (measured 2-4e-7; Winograd F(4,5): 9e-6)."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(48)
+    cases = [(2, 8, 12, 92, 92), (3, 16, 8, 60, 97), (1, 4, 4, 48, 48), (2, 4, 8, 20, 33), (1, 64, 64, 92, 92), (2, 12, 4, 137, 49)]
+    for (B, Cin, Cout, H, W) in cases:
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cin ** 0.5)
+        b, ib = torch.randn(Cout, device=dev), torch.randn(Cin, device=dev)
+        Bm = fftconv.filter_spectra(w)
+        assert Bm.shape == (1200, 2 * Cin, 2 * Cout)
+        for (relu, in_relu) in [(False, False), (True, True)]:
+            xin = torch.relu(x.double() + ib.double()[None, :, None, None]) if in_relu else x.double()
+            want = F.conv2d(xin, w.double(), b.double())
+            want = torch.relu(want) if relu else want
+            got = fftconv.conv5x5(x, Bm, b, relu, ib if in_relu else None, in_relu)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+            scale = want.abs().max().item()
+            assert (got.double() - want).abs().max().item() <= 5e-6 * scale, (B, Cin, Cout, H, W, relu)
+            OH, OW = H - 4, W - 4
+            for k in (5, 3):
+                if min(OH, OW) < 2 * k - 1:
+                    continue
+                S = fftconv.conv5x5(x, Bm, b, relu, ib if in_relu else None, in_relu, sums_k=k)
+                Sw = torch.stack([torch.stack([want[:, :, u:u + OH - k + 1, v:v + OW - k + 1].sum((-1, -2)) for v in range(k)], -1)
+                                  for u in range(k)], -2)
+                assert S.dtype == torch.float64 and ((S - Sw).abs().max() <= 2e-6 * Sw.abs().max().clamp_min(scale)), (B, H, W, k)
+    # which shapes take this path: tiles must fit the output to within 12 %
+    xs = torch.zeros(1, 4, 92, 92, device=dev).contiguous(memory_format=torch.channels_last)
+    assert fftconv.applicable(xs, 4, 4) and fftconv.tiles(92) == 2 and fftconv.tiles(93) == 3
+    assert not fftconv.applicable(torch.zeros(1, 4, 60, 60, device=dev).contiguous(memory_format=torch.channels_last), 4, 4)
+    assert _lib.load().eqa_fft48k5_tiles(92) == 2
+
+
+def test_escnn_inference_fft_path_equals_winograd_and_module_paths(dev, monkeypatch):
+    """ESCNNEquivariantNetwork at the headline geometry (96 -> lift 92 -> 5x5 -> 88 -> linearised tail), reduced width:
+    the FFT path (default), the Winograd path and the plain module sequence give the same activations and group index."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(9)
+    net = ea.ESCNNEquivariantNetwork((3, 96, 96), out_channels=8, kernel_size=5, group_type="rotation", num_rotations=8,
+                                     num_layers=3).to(dev).eval()
+    for m in net.modules():  # non-trivial batch-norm statistics
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(5, 3, 96, 96, device=dev)
+    with torch.no_grad():
+        assert fftconv.ENABLED
+        a_fft = net(x)
+        monkeypatch.setattr(fftconv, "ENABLED", False)
+        a_wino = net(x)
+        a_mod = ea.images.canonicalization_networks.pooling.group_pool(net.eqv_network(x))
+    scale = a_mod.abs().max().item()
+    assert (a_fft - a_mod).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    assert (a_wino - a_mod).abs().max().item() <= 2e-5 * max(scale, 1.0)
+    assert torch.equal(a_fft.argmax(1), a_mod.argmax(1))
