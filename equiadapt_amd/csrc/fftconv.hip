@@ -59,11 +59,11 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* _
 }
 
 __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* __restrict__ T, float* __restrict__ V, int H, int C,
-                                                                 int TY, int TX, size_t M) {
+                                                                 int TY, int TX, size_t M, size_t m0) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
   const int kx = blockIdx.x % kFftH;
-  const size_t m = blockIdx.x / kFftH;  // (img * TY + ty) * TX + tx
+  const size_t m = blockIdx.x / kFftH;  // (img * TY + ty) * TX + tx, img counted inside this chunk of images
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
     im[i] = i < nvalid ? b : 0.0f;
   }
   fft48(re, im, ore, oim);
-  float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+  float* o = V + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + c;
   const size_t fpitch = (size_t)kFftH * M * 2 * C;  // from ky to ky + 1
 #pragma unroll
   for (int ky = 0; ky < kFftN; ++ky) {
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
 }
 
 __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* __restrict__ Mo, float* __restrict__ T2, int OH, int C,
-                                                                 int TY, int TX, size_t M) {
+                                                                 int TY, int TX, size_t M, size_t m0) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
   const int kx = blockIdx.x % kFftH;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
-  const float* p = Mo + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+  const float* p = Mo + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + c;
   const size_t fpitch = (size_t)kFftH * M * 2 * C;
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
@@ -123,12 +123,13 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
 // NB = k_next - 1 border columns on each side are needed one by one for the window sums; 0: plain output
 template <int NB>
 __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* __restrict__ T2, const float* __restrict__ bias, int relu,
-                                                                 float* __restrict__ out, int OH, int OW, int C, int TX) {
+                                                                 float* __restrict__ out, int OH, int OW, int C, int TX,
+                                                                 size_t img0) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
-  const size_t row = blockIdx.x;  // img * OH + y
+  const size_t row = blockIdx.x;  // img * OH + y inside this chunk of images (T2 is chunk-local, `out` is not)
   const int y = (int)(row % OH);
-  const size_t img = row / OH;
+  const size_t img = img0 + row / OH;
   const float b = bias ? bias[c] : 0.0f;
   constexpr int NV = 1 + 2 * NB;
   float acc[NV > 1 ? NV : 1];
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
     const int x0 = kFftO * tx;
     const int ncols = min(kFftO, OW - x0);  // uniform
     if (NB == 0) {
-      float* o = out + (row * OW + x0) * (size_t)C + c;
+      float* o = out + ((img * OH + y) * OW + x0) * (size_t)C + c;
 #pragma unroll
       for (int j = 0; j < kFftO; ++j) {
         if (j < ncols) {
@@ -190,9 +191,45 @@ int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W
 
 }  // namespace
 
+// The row pass writes an intermediate the column pass reads straight back.  Both run on chunks of images small enough for
+// that intermediate (9.4 MB per 92 x 92 x 256 image) to stay in the 256 MB Infinity Cache.
+#ifndef EQA_FFT_CHUNK_BYTES
+#define EQA_FFT_CHUNK_BYTES (96ull << 20)
+#endif
+static int fft_chunk_images(int nimg, int rows, int TX, int C) {
+  const size_t per_img = (size_t)rows * TX * kFftH * 2 * C * sizeof(float);
+  size_t n = EQA_FFT_CHUNK_BYTES / (per_img ? per_img : 1);
+  if (n < 1) n = 1;
+  return (int)(n < (size_t)nimg ? n : (size_t)nimg);
+}
+
+template <int NB>
+static int fft_output_impl(const float* Mo, float* T2, const float* bias, int relu, float* out, int nimg, int OH, int OW, int C,
+                           hipStream_t st) {
+  const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
+  const size_t M = (size_t)nimg * TY * TX;
+  if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  const unsigned cb = (C + kThreads - 1) / kThreads;
+  const int chunk = fft_chunk_images(nimg, OH, TX, C);
+  for (int i0 = 0; i0 < nimg; i0 += chunk) {
+    const int n = std::min(chunk, nimg - i0);
+    hipLaunchKernelGGL(fft48_cols_inv_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2, OH, C,
+                       TY, TX, M, (size_t)i0 * TY * TX);
+    hipLaunchKernelGGL((fft48_rows_inv_kernel<NB>), dim3((unsigned)((size_t)n * OH), cb), dim3(kThreads), 0, st, T2, bias, relu, out, OH,
+                       OW, C, TX, (size_t)i0);
+  }
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
 extern "C" {
 
 int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
+
+int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int cols, int C) {
+  if (nimg <= 0 || rows <= 0 || cols <= 0 || C <= 0) return 0;
+  const int TX = (cols + kFftO - 1) / kFftO;  // callers pass the OUTPUT width (input width - 4) for either direction
+  return (int64_t)fft_chunk_images(nimg, rows, TX, C) * rows * TX * kFftH * 2 * C * (int64_t)sizeof(float);
+}
 
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                       void* stream) {
@@ -203,33 +240,23 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const unsigned cb = (C + kThreads - 1) / kThreads;
-  hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)nimg * H * TX), cb), dim3(kThreads), 0, st, x, T, in_bias, in_relu,
-                     H, W, C, TX);
-  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
-  hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)(M * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C, TY, TX, M);
+  const int chunk = fft_chunk_images(nimg, H, TX, C);
+  for (int i0 = 0; i0 < nimg; i0 += chunk) {
+    const int n = std::min(chunk, nimg - i0);
+    hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
+                       x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX);
+    hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
+                       TY, TX, M, (size_t)i0 * TY * TX);
+  }
   return launch_status();
-}
-
-static int fft_output_common(const float* Mo, float* T2, int nimg, int OH, int OW, int C, hipStream_t st) {
-  const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
-  const size_t M = (size_t)nimg * TY * TX;
-  if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_cols_inv_kernel, dim3((unsigned)(M * kFftH), (C + kThreads - 1) / kThreads), dim3(kThreads), 0, st, Mo, T2,
-                     OH, C, TY, TX, M);
-  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream) {
   if (!Mo || !T2 || !y || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
   if (nimg == 0) return EQA_OK;
-  hipStream_t st = (hipStream_t)stream;
-  const int rc = fft_output_common(Mo, T2, nimg, OH, OW, C, st);
-  if (rc != EQA_OK) return rc;
-  const int TX = (OW + kFftO - 1) / kFftO;
-  hipLaunchKernelGGL((fft48_rows_inv_kernel<0>), dim3((unsigned)((size_t)nimg * OH), (C + kThreads - 1) / kThreads), dim3(kThreads), 0,
-                     st, T2, bias, relu, y, OH, OW, C, TX);
-  return launch_status();
+  const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream);
+  return rc != EQA_OK ? rc : launch_status();
 }
 
 int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int relu, double* S, void* workspace, int nimg,
@@ -239,16 +266,10 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   if ((nb != 4 && nb != 2) || OH < 2 * nb + 1 || OW < 2 * nb + 1 || k_next > kMaxWinK || nimg > 65535) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int rc = fft_output_common(Mo, T2, nimg, OH, OW, C, st);
-  if (rc != EQA_OK) return rc;
-  const int TX = (OW + kFftO - 1) / kFftO;
-  const dim3 grid((unsigned)((size_t)nimg * OH), (C + kThreads - 1) / kThreads);
   float* part = (float*)workspace;  // (nimg, OH, C, 1 + 2 nb) floats
-  if (nb == 4)
-    hipLaunchKernelGGL((fft48_rows_inv_kernel<4>), grid, dim3(kThreads), 0, st, T2, bias, relu, part, OH, OW, C, TX);
-  else
-    hipLaunchKernelGGL((fft48_rows_inv_kernel<2>), grid, dim3(kThreads), 0, st, T2, bias, relu, part, OH, OW, C, TX);
-  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  const int rc = nb == 4 ? fft_output_impl<4>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st)
+                         : fft_output_impl<2>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st);
+  if (rc != EQA_OK) return rc;
   return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, OH, st);
 }
 

@@ -60,7 +60,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     M = nimg * TY * TX
     dev = x.device
     st = torch.cuda.current_stream().cuda_stream
-    T = torch.empty(nimg * H * TX * NH * 2 * Cin, dtype=torch.float32, device=dev)
+    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
     V = torch.empty((N * NH, M, 2 * Cin), dtype=torch.float32, device=dev)
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     p_bias = bias.data_ptr() if bias is not None else None
@@ -72,7 +72,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
         with _timed("fft_gemm"):
             Mo = torch.bmm(V, B)
         del V
-        T2 = torch.empty(nimg * OH * TX * NH * 2 * Cout, dtype=torch.float32, device=dev)
+        T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dev)
         if sums_k:
             S = torch.empty((nimg, Cout, sums_k, sums_k), dtype=torch.float64, device=dev)
             ws = torch.empty(nimg * OH * Cout * (2 * sums_k - 1), dtype=torch.float32, device=dev)

@@ -299,14 +299,17 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  * f = ky*25 + kx; 2.5 real multiplies per output where the tiles fit (Winograd F(4x4,5x5): 4).  Channels-last, fp32.
  *   eqa_fft48k5_input   x:(nimg,H,W,C) -> V:(1200, M, 2C), M = nimg*TY*TX tiles, V[f][m] = [Re | Im] of the tile's spectrum
  *                       over the C channels; d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c] applied while loading.
- *                       T: workspace of nimg*H*TX*25*2*C floats.
+ *                       T: workspace of eqa_fft48k5_workspace_bytes(nimg, H, W - 4, C) bytes (the two passes run on chunks
+ *                       of images whose intermediate stays cache-resident).
  *   [ batched fp32 GEMM by the caller: Mo[f] = V[f] (M x 2Cin) . B[f] (2Cin x 2Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
  *     Br + i Bi = conj(FFT48x48(filter[co][ci]))[ky][kx] / 2304, rows ci, columns co ]
- *   eqa_fft48k5_output  Mo:(1200, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of nimg*OH*TX*25*2*C floats.
+ *   eqa_fft48k5_output  Mo:(1200, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of
+ *                       eqa_fft48k5_workspace_bytes(nimg, OH, OW, C) bytes.
  *   eqa_fft48k5_output_sums  ... -> S:(nimg,C,k_next,k_next) fp64, the window sums of eqa_window_sums_nhwc of that output
  *                       (k_next in {3,5}); workspace: nimg*OH*C*(2*k_next-1) floats.
  */
 int64_t eqa_fft48k5_tiles(int n);
+int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                       void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
