@@ -19,6 +19,8 @@
 //   cols_inv   Mo (1200, M, 2C) -> T2 (nimg,OH,TX,25,2,C): inverse over ky, rows 44..47 of a tile (circular wrap) dropped
 //   rows_inv   T2 -> y (nimg,OH,OW,C) = [relu](. + bias), or -> the window-sum segments of the next (last, linearised)
 //              layer in the format of window_sums_nhwc_finalize_kernel (one segment per output row)
+#include <cstdlib>
+
 #include "eqa_common.hpp"
 
 namespace {
@@ -187,6 +189,77 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
   }
 }
 
+// Row and column pass of the forward transform in ONE kernel: a block owns one 48 x 48 tile x 16 channels, the row
+// spectra (48 x 25 complex x 16 channels = 154 KB) go through LDS instead of through a 2.4 GB intermediate in HBM that is
+// written and read straight back (the two-pass form moves 9.5 GB and runs at the copy rate: 1.75 ms; this one moves 4.7).
+// 768 threads: phase 1, thread (y, c) transforms row y; phase 2, thread (kx, c), 400 of them, transforms column kx.
+// A wave reads 4 pixels x 16 channels = 4 runs of 64 bytes; the 16 channel groups of a tile are dealt to the same XCD so
+// that the other halves of the 128-byte lines come out of its L2.
+constexpr int kFusCh = 16;
+constexpr int kFusThreads = kFftN * kFusCh;                       // 768
+constexpr int kFusKxPitch = kFftN * 2 * kFusCh + kFusCh;          // floats per kx slab (+16: slabs start 16 banks apart)
+constexpr int kFusLds = kFftH * kFusKxPitch;                      // 38,800 floats = 155,200 bytes
+
+__global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                      const float* __restrict__ in_bias, int in_relu, int H, int W,
+                                                                      int C, int TY, int TX, size_t M, unsigned nwork) {
+  extern __shared__ float lds[];
+  // XCD-aware order: consecutive work items (the channel groups of one tile) on one XCD
+  const unsigned bid = blockIdx.x;
+  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
+  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kXcd;
+  const int ngrp = C / kFusCh;
+  const int grp = work % ngrp;
+  const size_t m = work / ngrp;  // (img * TY + ty) * TX + tx
+  const int tx = (int)(m % TX);
+  const int ty = (int)((m / TX) % TY);
+  const size_t img = m / ((size_t)TX * TY);
+  const int cl = threadIdx.x % kFusCh;
+  const int c = grp * kFusCh + cl;
+  {
+    const int y = threadIdx.x / kFusCh;  // 0..47
+    const int gy = kFftO * ty + y;
+    const int nvalid = min(kFftN, W - kFftO * tx);  // uniform
+    const float ib = in_bias ? in_bias[c] : 0.0f;
+    const float* p = x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
+    const bool row_in = gy < H;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+    for (int j = 0; j < kFftN; ++j) {
+      float v = p[(size_t)min(j, nvalid - 1) * C] + ib;
+      v = in_relu ? fmaxf(v, 0.0f) : v;
+      re[j] = (row_in && j < nvalid) ? v : 0.0f;
+      im[j] = 0.0f;
+    }
+    fft48(re, im, ore, oim);
+    float* o = lds + (y * 2) * kFusCh + cl;
+#pragma unroll
+    for (int k = 0; k < kFftH; ++k) {
+      o[k * kFusKxPitch] = ore[k];
+      o[k * kFusKxPitch + kFusCh] = oim[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < kFftH * kFusCh) {
+    const int kx = threadIdx.x / kFusCh;
+    const float* q = lds + kx * kFusKxPitch + cl;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+    for (int i = 0; i < kFftN; ++i) {
+      re[i] = q[(i * 2) * kFusCh];
+      im[i] = q[(i * 2 + 1) * kFusCh];
+    }
+    fft48(re, im, ore, oim);
+    float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+    const size_t fpitch = (size_t)kFftH * M * 2 * C;
+#pragma unroll
+    for (int ky = 0; ky < kFftN; ++ky) {
+      FFT_STG(o + ky * fpitch, ore[ky]);
+      FFT_STG(o + ky * fpitch + C, oim[ky]);
+    }
+  }
+}
+
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
 }  // namespace
@@ -239,6 +312,18 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
+  if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
+    static const bool lds_ok =
+        hipFuncSetAttribute((const void*)fft48_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
+    if (lds_ok) {
+      const unsigned nwork = (unsigned)(M * (C / kFusCh));
+      hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
+                         W, C, TY, TX, M, nwork);
+      return launch_status();
+    }
+    (void)hipGetLastError();
+  }
   const unsigned cb = (C + kThreads - 1) / kThreads;
   const int chunk = fft_chunk_images(nimg, H, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
