@@ -29,7 +29,7 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : E
 
 // pooling.hip: part (B, nseg, C, 1 + 2(k-1)) row segments -> S (B, C, k, k) fp64; used by eqa_window_sums_nhwc and by the
 // Winograd output transform fused with the window sums
-int launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream);
+int launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream, int sub = 1);
 
 }  // namespace eqa
 

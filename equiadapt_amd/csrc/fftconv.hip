@@ -260,6 +260,97 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
   }
 }
 
+// The inverse counterpart: column pass (thread (kx, c), 400 of them), LDS, row pass (thread (y, c), 44 x 16 of them) and the
+// epilogue.  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
+// row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
+template <int NB>
+__global__ __launch_bounds__(kFusThreads) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                                      int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
+                                                                      int TX, size_t M, unsigned nwork) {
+  extern __shared__ float lds[];
+  const unsigned bid = blockIdx.x;
+  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
+  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kXcd;
+  const int ngrp = C / kFusCh;
+  const int grp = work % ngrp;
+  const size_t m = work / ngrp;
+  const int tx = (int)(m % TX);
+  const int ty = (int)((m / TX) % TY);
+  const size_t img = m / ((size_t)TX * TY);
+  const int cl = threadIdx.x % kFusCh;
+  const int c = grp * kFusCh + cl;
+  if (threadIdx.x < kFftH * kFusCh) {
+    const int kx = threadIdx.x / kFusCh;
+    const float* p = Mo + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+    const size_t fpitch = (size_t)kFftH * M * 2 * C;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+    for (int ky = 0; ky < kFftN; ++ky) {
+      re[ky] = FFT_LDG(p + ky * fpitch);
+      im[ky] = FFT_LDG(p + ky * fpitch + C);
+    }
+    fft48(im, re, oim, ore);
+    float* q = lds + kx * kFusKxPitch + cl;
+#pragma unroll
+    for (int i = 0; i < kFftO; ++i) {  // rows 44..47: the circular wrap-around
+      q[(i * 2) * kFusCh] = ore[i];
+      q[(i * 2 + 1) * kFusCh] = oim[i];
+    }
+  }
+  __syncthreads();
+  const int y = threadIdx.x / kFusCh;
+  const int gy = kFftO * ty + y;
+  if (y >= kFftO || gy >= OH) return;
+  const float* q = lds + (y * 2) * kFusCh + cl;
+  float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+  for (int k = 0; k < kFftH; ++k) {
+    re[k] = q[k * kFusKxPitch];
+    im[k] = q[k * kFusKxPitch + kFusCh];
+  }
+#pragma unroll
+  for (int k = kFftH; k < kFftN; ++k) {
+    re[k] = re[kFftN - k];
+    im[k] = -im[kFftN - k];
+  }
+  fft48(im, re, oim, ore);
+  const float b = bias ? bias[c] : 0.0f;
+  const int x0 = kFftO * tx;
+  const int ncols = min(kFftO, OW - x0);  // uniform
+  if (NB == 0) {
+    float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
+#pragma unroll
+    for (int j = 0; j < kFftO; ++j) {
+      if (j < ncols) {
+        const float v = ore[j] + b;
+        o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
+      }
+    }
+  } else {
+    constexpr int NV = 1 + 2 * NB;
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kFftO; ++j) {
+      float v = ore[j] + b;
+      v = relu ? fmaxf(v, 0.0f) : v;
+      v = j < ncols ? v : 0.0f;
+      acc[0] += v;
+      const int xx = x0 + j;  // uniform
+#pragma unroll
+      for (int qn = 0; qn < NB; ++qn) {
+        if (xx == qn) acc[1 + qn] += v;
+        if (xx == OW - NB + qn) acc[1 + NB + qn] += v;
+      }
+    }
+    const int seg = gy < NB ? gy : (gy >= OH - NB ? NB + (gy - (OH - NB)) : 2 * NB + (gy - NB));
+    float* o = out + (((img * OH + seg) * TX + tx) * (size_t)C + c) * NV;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = acc[i];
+  }
+}
+
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
 }  // namespace
@@ -278,10 +369,24 @@ static int fft_chunk_images(int nimg, int rows, int TX, int C) {
 
 template <int NB>
 static int fft_output_impl(const float* Mo, float* T2, const float* bias, int relu, float* out, int nimg, int OH, int OW, int C,
-                           hipStream_t st) {
+                           hipStream_t st, int* sub) {
   const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  *sub = 1;
+  static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
+  if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
+    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   kFusLds * 4) == hipSuccess;
+    if (lds_ok) {
+      const unsigned nwork = (unsigned)(M * (C / kFusCh));
+      hipLaunchKernelGGL((fft48_inv_fused_kernel<NB>), dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, Mo, bias, relu, out,
+                         OH, OW, C, TY, TX, M, nwork);
+      *sub = TX;
+      return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+    }
+    (void)hipGetLastError();
+  }
   const unsigned cb = (C + kThreads - 1) / kThreads;
   const int chunk = fft_chunk_images(nimg, OH, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
@@ -340,7 +445,8 @@ int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, 
                        void* stream) {
   if (!Mo || !T2 || !y || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
   if (nimg == 0) return EQA_OK;
-  const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream);
+  int sub = 1;
+  const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream, &sub);
   return rc != EQA_OK ? rc : launch_status();
 }
 
@@ -351,11 +457,12 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   if ((nb != 4 && nb != 2) || OH < 2 * nb + 1 || OW < 2 * nb + 1 || k_next > kMaxWinK || nimg > 65535) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
-  float* part = (float*)workspace;  // (nimg, OH, C, 1 + 2 nb) floats
-  const int rc = nb == 4 ? fft_output_impl<4>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st)
-                         : fft_output_impl<2>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st);
+  float* part = (float*)workspace;  // (nimg, OH, TX, C, 1 + 2 nb) floats
+  int sub = 1;
+  const int rc = nb == 4 ? fft_output_impl<4>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &sub)
+                         : fft_output_impl<2>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &sub);
   if (rc != EQA_OK) return rc;
-  return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, OH, st);
+  return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, OH * sub, st, sub);
 }
 
 }  // extern "C"

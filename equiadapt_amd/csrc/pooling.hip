@@ -301,8 +301,10 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
 // Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
 constexpr int kFinVals = 1 + 2 * kWsMaxBorder;
 
+// `sub` > 1: every segment arrives in `sub` pieces (one per tile column of the producer), laid out as consecutive segments;
+// the pieces of a border row are added up first (in fp32, as a single producer thread would have).
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
-                                                                            int B, int C, int k, int nseg) {
+                                                                            int B, int C, int k, int nseg, int sub) {
   __shared__ double s_tot[kFinCh * kFinVals];
   __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
   const int b = blockIdx.y;
@@ -317,10 +319,12 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
     double acc = 0.0;
     int s = 0;
     for (; s < 2 * nb; ++s) {  // border-row segments are needed individually as well
-      const float v = q[(size_t)s * seg_stride];
+      float v = q[(size_t)(s * sub) * seg_stride];
+      for (int t = 1; t < sub; ++t) v += q[(size_t)(s * sub + t) * seg_stride];
       s_brd[s][e] = v;
       acc += (double)v;
     }
+    s *= sub;
     for (; s + 8 <= nseg; s += 8) {
       float v[8];
 #pragma unroll
@@ -407,10 +411,11 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
 
 }  // namespace
 
-int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream) {
+int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream, int sub) {
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
+  // nseg counts the pieces: rows (or row groups) x sub
   hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, stream, part, S, B, C,
-                     k, nseg);
+                     k, nseg, sub);
   return launch_status();
 }
 
@@ -525,7 +530,7 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
                      (float*)workspace, C, H, W, k, nbands);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, st,
-                     (const float*)workspace, out, B, C, k, nseg);
+                     (const float*)workspace, out, B, C, k, nseg, 1);
   return launch_status();
 }
 

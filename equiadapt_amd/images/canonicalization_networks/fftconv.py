@@ -75,7 +75,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
         T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dev)
         if sums_k:
             S = torch.empty((nimg, Cout, sums_k, sums_k), dtype=torch.float64, device=dev)
-            ws = torch.empty(nimg * OH * Cout * (2 * sums_k - 1), dtype=torch.float32, device=dev)
+            ws = torch.empty(nimg * OH * TX * Cout * (2 * sums_k - 1), dtype=torch.float32, device=dev)
             with _timed("fft_output_sums"):
                 _lib.check(lib.eqa_fft48k5_output_sums(Mo.data_ptr(), T2.data_ptr(), p_bias, int(relu), S.data_ptr(), ws.data_ptr(),
                                                        nimg, OH, OW, Cout, sums_k, st), "eqa_fft48k5_output_sums")

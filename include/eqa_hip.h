@@ -306,7 +306,7 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  *   eqa_fft48k5_output  Mo:(1200, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of
  *                       eqa_fft48k5_workspace_bytes(nimg, OH, OW, C) bytes.
  *   eqa_fft48k5_output_sums  ... -> S:(nimg,C,k_next,k_next) fp64, the window sums of eqa_window_sums_nhwc of that output
- *                       (k_next in {3,5}); workspace: nimg*OH*C*(2*k_next-1) floats.
+ *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
