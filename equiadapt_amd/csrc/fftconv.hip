@@ -28,8 +28,17 @@ namespace {
 constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
 #include "fft48.inc"
 
-#define FFT_LDG(p) __builtin_nontemporal_load(p)
-#define FFT_STG(p, v) __builtin_nontemporal_store((v), (p))
+// spectra in HBM (V, Mo): complex numbers, re and im interleaved, streamed once each way
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fft_stg2(float2* p, float re, float im) {
+  f32x2 v = {re, im};
+  __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(p));
+}
+__device__ __forceinline__ void fft_ldg2(const float2* p, float& re, float& im) {
+  const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+  re = v[0];
+  im = v[1];
+}
 
 __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ T,
                                                                  const float* __restrict__ in_bias, int in_relu, int H, int W,
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* _
 }
 
 __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* __restrict__ T, float* __restrict__ V, int H, int C,
-                                                                 int TY, int TX, size_t M, size_t m0) {
+                                                                 int TY, int TX, size_t M, size_t m0, int G) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
   const int kx = blockIdx.x % kFftH;
@@ -82,12 +91,13 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
     im[i] = i < nvalid ? b : 0.0f;
   }
   fft48(re, im, ore, oim);
-  float* o = V + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + c;
+  // rows of V: [Re x G | Im x G] per group of G channels (G = 16: what a block of the fused kernel owns; G = 1: interleaved)
+  float* o = V + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + (c / G) * 2 * G + c % G;
   const size_t fpitch = (size_t)kFftH * M * 2 * C;  // from ky to ky + 1
 #pragma unroll
   for (int ky = 0; ky < kFftN; ++ky) {
-    FFT_STG(o + ky * fpitch, ore[ky]);
-    FFT_STG(o + ky * fpitch + C, oim[ky]);
+    __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
+    __builtin_nontemporal_store(oim[ky], o + ky * fpitch + G);
   }
 }
 
@@ -100,14 +110,11 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
-  const float* p = Mo + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + c;
-  const size_t fpitch = (size_t)kFftH * M * 2 * C;
+  const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)kx * M + m0 + m) * (size_t)C + c;
+  const size_t fpitch = (size_t)kFftH * M * C;
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
-  for (int ky = 0; ky < kFftN; ++ky) {
-    re[ky] = FFT_LDG(p + ky * fpitch);
-    im[ky] = FFT_LDG(p + ky * fpitch + C);
-  }
+  for (int ky = 0; ky < kFftN; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
   fft48(im, re, oim, ore);  // inverse: real and imaginary parts swapped in and out (1 / 48^2 is in the filter spectra)
   const int y0 = kFftO * ty;
   const int nrows = min(kFftO, OH - y0);  // uniform; rows 44..47 of the tile are the circular wrap-around
@@ -250,63 +257,63 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
       im[i] = q[(i * 2 + 1) * kFusCh];
     }
     fft48(re, im, ore, oim);
-    float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + c;
+    // [Re x 16 | Im x 16] per channel group: the block's 128 bytes of a (frequency, tile) row are one run.  (Measured against
+    // interleaved complex with 8-byte stores: 1.18 vs 1.42 ms; the inverse prefers 8-byte loads of interleaved complex.)
+    float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + grp * 2 * kFusCh + cl;
     const size_t fpitch = (size_t)kFftH * M * 2 * C;
 #pragma unroll
     for (int ky = 0; ky < kFftN; ++ky) {
-      FFT_STG(o + ky * fpitch, ore[ky]);
-      FFT_STG(o + ky * fpitch + C, oim[ky]);
+      __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
+      __builtin_nontemporal_store(oim[ky], o + ky * fpitch + kFusCh);
     }
   }
 }
 
-// The inverse counterpart: column pass (thread (kx, c), 400 of them), LDS, row pass (thread (y, c), 44 x 16 of them) and the
-// epilogue.  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
+// The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
+// as interleaved complex with 8-byte loads (128 bytes per (frequency, tile) row and block).  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
 // row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
-template <int NB>
-__global__ __launch_bounds__(kFusThreads) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+template <int NB, int CH>
+__global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                       int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
                                                                       int TX, size_t M, unsigned nwork) {
   extern __shared__ float lds[];
+  constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
   const unsigned bid = blockIdx.x;
   const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
   const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kXcd;
-  const int ngrp = C / kFusCh;
+  const int ngrp = C / CH;
   const int grp = work % ngrp;
   const size_t m = work / ngrp;
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
-  const int cl = threadIdx.x % kFusCh;
-  const int c = grp * kFusCh + cl;
-  if (threadIdx.x < kFftH * kFusCh) {
-    const int kx = threadIdx.x / kFusCh;
-    const float* p = Mo + ((size_t)kx * M + m) * 2 * (size_t)C + c;
-    const size_t fpitch = (size_t)kFftH * M * 2 * C;
+  const int cl = threadIdx.x % CH;
+  const int c = grp * CH + cl;
+  if (threadIdx.x < kFftH * CH) {
+    const int kx = threadIdx.x / CH;
+    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)kx * M + m) * (size_t)C + c;
+    const size_t fpitch = (size_t)kFftH * M * C;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
-    for (int ky = 0; ky < kFftN; ++ky) {
-      re[ky] = FFT_LDG(p + ky * fpitch);
-      im[ky] = FFT_LDG(p + ky * fpitch + C);
-    }
+    for (int ky = 0; ky < kFftN; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
     fft48(im, re, oim, ore);
-    float* q = lds + kx * kFusKxPitch + cl;
+    float* q = lds + kx * kPitch + cl;
 #pragma unroll
     for (int i = 0; i < kFftO; ++i) {  // rows 44..47: the circular wrap-around
-      q[(i * 2) * kFusCh] = ore[i];
-      q[(i * 2 + 1) * kFusCh] = oim[i];
+      q[(i * 2) * CH] = ore[i];
+      q[(i * 2 + 1) * CH] = oim[i];
     }
   }
   __syncthreads();
-  const int y = threadIdx.x / kFusCh;
+  const int y = threadIdx.x / CH;
   const int gy = kFftO * ty + y;
   if (y >= kFftO || gy >= OH) return;
-  const float* q = lds + (y * 2) * kFusCh + cl;
+  const float* q = lds + (y * 2) * CH + cl;
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
   for (int k = 0; k < kFftH; ++k) {
-    re[k] = q[k * kFusKxPitch];
-    im[k] = q[k * kFusKxPitch + kFusCh];
+    re[k] = q[k * kPitch];
+    im[k] = q[k * kPitch + CH];
   }
 #pragma unroll
   for (int k = kFftH; k < kFftN; ++k) {
@@ -353,6 +360,12 @@ __global__ __launch_bounds__(kFusThreads) void fft48_inv_fused_kernel(const floa
 
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
+#ifndef EQA_FFT_INV_CH
+#define EQA_FFT_INV_CH 16
+#endif
+constexpr int kInvCh = EQA_FFT_INV_CH;  // channels per block of the fused inverse (8, two blocks per CU: 1.54 ms; 16: 1.25 ms)
+int fft_group_in(int C) { return C % kFusCh == 0 ? kFusCh : 1; }
+
 }  // namespace
 
 // The row pass writes an intermediate the column pass reads straight back.  Both run on chunks of images small enough for
@@ -375,13 +388,14 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   *sub = 1;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
-  if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
-    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   kFusLds * 4) == hipSuccess;
+  if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass) {
+    constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
+    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB, kInvCh>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     if (lds_ok) {
-      const unsigned nwork = (unsigned)(M * (C / kFusCh));
-      hipLaunchKernelGGL((fft48_inv_fused_kernel<NB>), dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, Mo, bias, relu, out,
-                         OH, OW, C, TY, TX, M, nwork);
+      const unsigned nwork = (unsigned)(M * (C / kInvCh));
+      hipLaunchKernelGGL((fft48_inv_fused_kernel<NB, kInvCh>), dim3(nwork), dim3(kFftN * kInvCh), lds_bytes, st, Mo, bias, relu, out, OH,
+                         OW, C, TY, TX, M, nwork);
       *sub = TX;
       return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
     }
@@ -400,6 +414,11 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
 }
 
 extern "C" {
+
+int eqa_fft48k5_group(int C, int side) {
+  if (C <= 0 || (side != 0 && side != 1)) return EQA_ERR_INVALID_ARG;
+  return side == 0 ? fft_group_in(C) : 1;
+}
 
 int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
 
@@ -436,7 +455,7 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
     hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
                        x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX);
     hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
-                       TY, TX, M, (size_t)i0 * TY * TX);
+                       TY, TX, M, (size_t)i0 * TY * TX, fft_group_in(C));
   }
   return launch_status();
 }

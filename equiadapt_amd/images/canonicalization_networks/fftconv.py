@@ -33,9 +33,23 @@ def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) ->
     return tiles(H) * OUT <= max_waste * oh and tiles(W) * OUT <= max_waste * ow
 
 
-def filter_spectra(bank: torch.Tensor) -> torch.Tensor:
-    """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency."""
+def _order(C: int, G: int) -> torch.Tensor:
+    """Position p of a 2C-wide row -> index into [Re(0..C-1), Im(0..C-1)]: groups of G channels, [Re x G | Im x G] each."""
+    p = torch.arange(2 * C)
+    grp, r = p // (2 * G), p % (2 * G)
+    return (r // G) * C + grp * G + r % G
+
+
+def group_sizes(cin: int, cout: int):
+    """Channels per [Re | Im] group in the rows of V (16: what a block of the fused forward kernel owns) and of Mo (1)."""
+    return (16 if cin % 16 == 0 else 1), 1
+
+
+def filter_spectra(bank: torch.Tensor, groups=None) -> torch.Tensor:
+    """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency.  Rows
+    follow the rows of V, columns the rows of Mo (``group_sizes``; ``groups`` = (Cin, Cout) gives the plain [Re | Im] order)."""
     Cout, Cin = bank.shape[:2]
+    gin, gout = groups if groups is not None else group_sizes(Cin, Cout)
     wp = torch.zeros(Cout, Cin, N, N, dtype=torch.float64, device=bank.device)
     wp[:, :, :5, :5] = bank.double()
     W = torch.fft.rfft2(wp).conj() / float(N * N)                # (Cout, Cin, 48, 25)
@@ -43,7 +57,9 @@ def filter_spectra(bank: torch.Tensor) -> torch.Tensor:
     Wi = W.imag.permute(2, 3, 1, 0).reshape(N * NH, Cin, Cout)
     top = torch.cat([Wr, Wi], dim=2)                              # rows Re(A): [ Br |  Bi ]
     bot = torch.cat([-Wi, Wr], dim=2)                             # rows Im(A): [-Bi |  Br ]
-    return torch.cat([top, bot], dim=1).float().contiguous()
+    full = torch.cat([top, bot], dim=1)                           # rows [Re ci | Im ci], columns [Re co | Im co]
+    full = full[:, _order(Cin, gin).to(bank.device)][:, :, _order(Cout, gout).to(bank.device)]
+    return full.float().contiguous()
 
 
 def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,

@@ -297,18 +297,20 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  * I2a, the same 5x5 stride-1 group convolutions (escnn_networks.py:67-91) as an overlap-save FFT convolution: 48x48 real
  * FFT tiles give 44x44 outputs each (tiles per axis: eqa_fft48k5_tiles(n) = ceil((n-4)/44)), 48 x 25 complex frequencies
  * f = ky*25 + kx; 2.5 real multiplies per output where the tiles fit (Winograd F(4x4,5x5): 4).  Channels-last, fp32.
- *   eqa_fft48k5_input   x:(nimg,H,W,C) -> V:(1200, M, 2C), M = nimg*TY*TX tiles, V[f][m] = [Re | Im] of the tile's spectrum
- *                       over the C channels; d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c] applied while loading.
+ *   eqa_fft48k5_input   x:(nimg,H,W,C) -> V:(1200, M, 2C), M = nimg*TY*TX tiles, V[f][m] = the tile's spectrum over the C
+ *                       channels, [Re x G | Im x G] per group of G = eqa_fft48k5_group(C, 0) channels (16, or 1 = interleaved); d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c] applied while loading.
  *                       T: workspace of eqa_fft48k5_workspace_bytes(nimg, H, W - 4, C) bytes (the two passes run on chunks
  *                       of images whose intermediate stays cache-resident).
  *   [ batched fp32 GEMM by the caller: Mo[f] = V[f] (M x 2Cin) . B[f] (2Cin x 2Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
- *     Br + i Bi = conj(FFT48x48(filter[co][ci]))[ky][kx] / 2304, rows ci, columns co ]
+ *     Br + i Bi = conj(FFT48x48(filter[co][ci]))[ky][kx] / 2304, rows ordered like the rows of V, columns like the rows of
+ *     Mo: complex numbers with re and im interleaved (group size eqa_fft48k5_group(Cout, 1) = 1) ]
  *   eqa_fft48k5_output  Mo:(1200, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of
  *                       eqa_fft48k5_workspace_bytes(nimg, OH, OW, C) bytes.
  *   eqa_fft48k5_output_sums  ... -> S:(nimg,C,k_next,k_next) fp64, the window sums of eqa_window_sums_nhwc of that output
  *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
+int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                       void* stream);

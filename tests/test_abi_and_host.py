@@ -243,7 +243,7 @@ def test_fft_filter_spectra_real_form_reproduces_conv2d():
     B, Cin, Cout = 2, 3, 5
     x = torch.randn(B, Cin, 48, 48, dtype=torch.float64)
     w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
-    Bm = fftconv.filter_spectra(w.float()).double()                         # (1200, 2 Cin, 2 Cout)
+    Bm = fftconv.filter_spectra(w.float(), groups=(Cin, Cout)).double()     # (1200, 2 Cin, 2 Cout), plain [Re | Im] order
     X = torch.fft.rfft2(x)                                                  # (B, Cin, 48, 25)
     V = torch.cat([X.real, X.imag], dim=1).permute(2, 3, 0, 1).reshape(1200, B, 2 * Cin)
     Mo = torch.bmm(V, Bm)                                                   # (1200, B, 2 Cout)
@@ -252,3 +252,22 @@ def test_fft_filter_spectra_real_form_reproduces_conv2d():
     want = F.conv2d(x, w)
     assert (y[:, :, :44, :44] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
     assert fftconv.tiles(92) == 2 and fftconv.tiles(48) == 1 and fftconv.tiles(49) == 2 and fftconv.tiles(4) == 0
+    # interleaved orders: groups of G channels, [Re x G | Im x G] each -- a permutation of the plain order
+    o = fftconv._order(32, 8)
+    assert sorted(o.tolist()) == list(range(64)) and o[:16].tolist() == list(range(8)) + list(range(32, 40))
+    assert fftconv._order(3, 1).tolist() == [0, 3, 1, 4, 2, 5]                      # re/im interleaved: the kernels' layout
+    wq = torch.randn(4, 3, 5, 5)
+    Bi, Bp = fftconv.filter_spectra(wq, groups=(1, 1)), fftconv.filter_spectra(wq, groups=(3, 4))
+    assert Bi.shape == (1200, 6, 8) and torch.equal(Bi, Bp[:, fftconv._order(3, 1)][:, :, fftconv._order(4, 1)])
+    assert fftconv.group_sizes(256, 256) == (16, 1) and fftconv.group_sizes(12, 8) == (1, 1)
+
+
+def test_fft_group_rule_matches_the_library():
+    """The [Re | Im] grouping of V's rows is decided in two places (fftconv.group_sizes for the filter spectra, the library for
+    the kernels): they must agree."""
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    lib = _lib.load()
+    for c in (4, 12, 16, 64, 250, 256):
+        assert (lib.eqa_fft48k5_group(c, 0), lib.eqa_fft48k5_group(c, 1)) == fftconv.group_sizes(c, c)
