@@ -8,9 +8,11 @@
 // Per frequency f = (ky, kx) the channel contraction is a complex matrix product, done by the GEMM library as a REAL one
 // through [Ar | Ai] . [[Br, Bi], [-Bi, Br]] = [Cr | Ci]  (A: tiles x 2 Cin, B: 2 Cin x 2 Cout, batched over 1200 f).
 // conv2d is a cross-correlation: B holds conj(FFT(filter)) / 48^2, computed once per weight version on the host side.
-// fp32 throughout; error vs an fp64 convolution ~1e-6 of max|y| (Winograd F(4,5): 9e-6).
+// fp32 throughout; error vs an fp64 convolution 2-4e-7 of max|y| (Winograd F(4,5): 9e-6).
 //
-// Four streaming kernels, one thread per channel (channels-last: every load and store instruction of a wave is one
+// Default: the two FUSED kernels further down (row pass, LDS, column pass in one block).  Their two-pass ancestors stay as
+// the path for channel counts that are not a multiple of 16 and as the ablation (EQA_FFT_TWO_PASS=1):
+// four streaming kernels, one thread per channel (channels-last: every load and store instruction of a wave is one
 // contiguous run of channels), one 48-point transform per thread held in registers (fft48.inc, generated, 819 flops):
 //   rows_fwd   x (nimg,H,W,C) -> T (nimg,H,TX,25,2,C): real rows of 48 pixels (tile columns 44 tx .. 44 tx + 47, zero
 //              beyond W), previous layer's bias / ReLU applied while loading
@@ -28,7 +30,7 @@ namespace {
 constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
 #include "fft48.inc"
 
-// spectra in HBM (V, Mo): complex numbers, re and im interleaved, streamed once each way
+// Mo in HBM: complex numbers, re and im interleaved, read once with 8-byte non-temporal loads
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fft_stg2(float2* p, float re, float im) {
   f32x2 v = {re, im};
