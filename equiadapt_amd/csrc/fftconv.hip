@@ -32,10 +32,6 @@ constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
 
 // Mo in HBM: complex numbers, re and im interleaved, read once with 8-byte non-temporal loads
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void fft_stg2(float2* p, float re, float im) {
-  f32x2 v = {re, im};
-  __builtin_nontemporal_store(v, reinterpret_cast<f32x2*>(p));
-}
 __device__ __forceinline__ void fft_ldg2(const float2* p, float& re, float& im) {
   const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
   re = v[0];
