@@ -305,54 +305,78 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   __syncthreads();
   const int y = threadIdx.x / CH;
   const int gy = kFftO * ty + y;
-  if (y >= kFftO || gy >= OH) return;
-  const float* q = lds + (y * 2) * CH + cl;
-  float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+  const bool valid = y < kFftO && gy < OH;
+  constexpr int NV = 1 + 2 * NB;
+  float acc[NV];
 #pragma unroll
-  for (int k = 0; k < kFftH; ++k) {
-    re[k] = q[k * kPitch];
-    im[k] = q[k * kPitch + CH];
-  }
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+  if (valid) {
+    const float* q = lds + (y * 2) * CH + cl;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
-  for (int k = kFftH; k < kFftN; ++k) {
-    re[k] = re[kFftN - k];
-    im[k] = -im[kFftN - k];
-  }
-  fft48(im, re, oim, ore);
-  const float b = bias ? bias[c] : 0.0f;
-  const int x0 = kFftO * tx;
-  const int ncols = min(kFftO, OW - x0);  // uniform
-  if (NB == 0) {
-    float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
+    for (int k = 0; k < kFftH; ++k) {
+      re[k] = q[k * kPitch];
+      im[k] = q[k * kPitch + CH];
+    }
 #pragma unroll
-    for (int j = 0; j < kFftO; ++j) {
-      if (j < ncols) {
-        const float v = ore[j] + b;
-        o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
+    for (int k = kFftH; k < kFftN; ++k) {
+      re[k] = re[kFftN - k];
+      im[k] = -im[kFftN - k];
+    }
+    fft48(im, re, oim, ore);
+    const float b = bias ? bias[c] : 0.0f;
+    const int x0 = kFftO * tx;
+    const int ncols = min(kFftO, OW - x0);  // uniform
+    if (NB == 0) {
+      float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
+#pragma unroll
+      for (int j = 0; j < kFftO; ++j) {
+        if (j < ncols) {
+          const float v = ore[j] + b;
+          o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kFftO; ++j) {
+        float v = ore[j] + b;
+        v = relu ? fmaxf(v, 0.0f) : v;
+        v = j < ncols ? v : 0.0f;
+        acc[0] += v;
+        const int xx = x0 + j;  // uniform
+#pragma unroll
+        for (int qn = 0; qn < NB; ++qn) {
+          if (xx == qn) acc[1 + qn] += v;
+          if (xx == OW - NB + qn) acc[1 + NB + qn] += v;
+        }
       }
     }
-  } else {
-    constexpr int NV = 1 + 2 * NB;
-    float acc[NV];
+  }
+  if (NB > 0) {
+    // Window-sum pieces.  Segments (the order window_sums_nhwc_finalize_kernel expects): the NB top rows, the NB bottom rows,
+    // then ONE per tile row for its interior rows -- those are only ever needed as a sum, which the block forms here in a
+    // fixed order (LDS is free once every thread has read its row spectrum) instead of writing 44 pieces per tile column.
+    const int nseg = 2 * NB + TY;
+    const bool border = gy < NB || gy >= OH - NB;
+    if (valid && border) {
+      const int seg = gy < NB ? gy : NB + (gy - (OH - NB));
+      float* o = out + (((img * nseg + seg) * TX + tx) * (size_t)C + c) * NV;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
-#pragma unroll
-    for (int j = 0; j < kFftO; ++j) {
-      float v = ore[j] + b;
-      v = relu ? fmaxf(v, 0.0f) : v;
-      v = j < ncols ? v : 0.0f;
-      acc[0] += v;
-      const int xx = x0 + j;  // uniform
-#pragma unroll
-      for (int qn = 0; qn < NB; ++qn) {
-        if (xx == qn) acc[1 + qn] += v;
-        if (xx == OW - NB + qn) acc[1 + NB + qn] += v;
-      }
+      for (int i = 0; i < NV; ++i) o[i] = acc[i];
     }
-    const int seg = gy < NB ? gy : (gy >= OH - NB ? NB + (gy - (OH - NB)) : 2 * NB + (gy - NB));
-    float* o = out + (((img * OH + seg) * TX + tx) * (size_t)C + c) * NV;
+    __syncthreads();
+    if (y < kFftO) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) o[i] = acc[i];
+      for (int i = 0; i < NV; ++i) lds[(y * NV + i) * CH + cl] = (valid && !border) ? acc[i] : 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV * CH) {
+      const int i = threadIdx.x / CH;
+      float t = 0.0f;
+      for (int r = 0; r < kFftO; ++r) t += lds[(r * NV + i) * CH + cl];
+      // tile rows made of border rows only (OH <= 2 NB + ...) contribute an all-zero piece: harmless
+      out[(((img * nseg + 2 * NB + ty) * TX + tx) * (size_t)C + c) * NV + i] = t;
+    }
   }
 }
 
@@ -380,11 +404,11 @@ static int fft_chunk_images(int nimg, int rows, int TX, int C) {
 
 template <int NB>
 static int fft_output_impl(const float* Mo, float* T2, const float* bias, int relu, float* out, int nimg, int OH, int OW, int C,
-                           hipStream_t st, int* sub) {
+                           hipStream_t st, int* fused) {
   const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  *sub = 1;
+  *fused = 0;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
   if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass) {
     constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
@@ -394,7 +418,7 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
       const unsigned nwork = (unsigned)(M * (C / kInvCh));
       hipLaunchKernelGGL((fft48_inv_fused_kernel<NB, kInvCh>), dim3(nwork), dim3(kFftN * kInvCh), lds_bytes, st, Mo, bias, relu, out, OH,
                          OW, C, TY, TX, M, nwork);
-      *sub = TX;
+      *fused = 1;
       return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
     }
     (void)hipGetLastError();
@@ -462,8 +486,8 @@ int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, 
                        void* stream) {
   if (!Mo || !T2 || !y || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
   if (nimg == 0) return EQA_OK;
-  int sub = 1;
-  const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream, &sub);
+  int fused = 0;
+  const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream, &fused);
   return rc != EQA_OK ? rc : launch_status();
 }
 
@@ -475,11 +499,14 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   if (nimg == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;  // (nimg, OH, TX, C, 1 + 2 nb) floats
-  int sub = 1;
-  const int rc = nb == 4 ? fft_output_impl<4>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &sub)
-                         : fft_output_impl<2>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &sub);
+  int fused = 0;
+  const int rc = nb == 4 ? fft_output_impl<4>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &fused)
+                         : fft_output_impl<2>(Mo, T2, bias, relu, part, nimg, OH, OW, C, st, &fused);
   if (rc != EQA_OK) return rc;
-  return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, OH * sub, st, sub);
+  // fused path: 2 nb border rows + one segment per tile row, each in `sub` = TX pieces; two-pass path: one per output row
+  const int sub = fused ? (OW + kFftO - 1) / kFftO : 1;
+  const int nseg = fused ? 2 * nb + (OH + kFftO - 1) / kFftO : OH;
+  return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, nseg * sub, st, sub);
 }
 
 }  // extern "C"
