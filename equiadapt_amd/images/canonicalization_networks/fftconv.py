@@ -15,6 +15,9 @@ from equiadapt_amd.ops import _timed
 
 N, NH, OUT = 48, 25, 44
 ENABLED = os.environ.get("EQA_CONV5_FFT", "1") != "0"
+# The filter spectra (1200 x 2Cin x 2Cout floats: 1.26 GB at 256 channels) are streamed once per call, the Winograd filters are
+# 17 MB: below ~32 tiles (8 images of 92 x 92) the Winograd path is faster (measured: B=4 0.29 vs 0.37 ms, B=8 0.48 vs 0.46 ms).
+MIN_TILES = int(os.environ.get("EQA_FFT_MIN_TILES", "32"))
 
 
 def tiles(n: int) -> int:
@@ -22,14 +25,17 @@ def tiles(n: int) -> int:
 
 
 def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) -> bool:
-    """Channels-last fp32 device tensor, 5x5 kernel, and tiles that fit the output to within ``max_waste`` (the FFT work is
-    per tile: 88 outputs per axis = 2 tiles exactly, 84 would waste 5 %, 50 would waste 43 % -> Winograd)."""
+    """Channels-last fp32 device tensor, 5x5 kernel, enough tiles to amortise the filter spectra (``MIN_TILES``), and tiles
+    that fit the output to within ``max_waste`` (the FFT work is per tile: 88 outputs per axis = 2 tiles exactly, 84 would
+    waste 5 %, 50 would waste 43 % -> Winograd)."""
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         return False
     H, W = x.shape[-2:]
     if H < 16 or W < 16 or x.shape[1] != cin:
         return False
     oh, ow = H - 4, W - 4
+    if x.shape[0] * tiles(H) * tiles(W) < MIN_TILES:
+        return False
     return tiles(H) * OUT <= max_waste * oh and tiles(W) * OUT <= max_waste * ow
 
 

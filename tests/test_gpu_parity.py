@@ -1028,9 +1028,10 @@ def test_fft48_convolution_matches_conv2d(dev):
                                   for u in range(k)], -2)
                 assert S.dtype == torch.float64 and ((S - Sw).abs().max() <= 2e-6 * Sw.abs().max().clamp_min(scale)), (B, H, W, k)
     # which shapes take this path: tiles must fit the output to within 12 %
-    xs = torch.zeros(1, 4, 92, 92, device=dev).contiguous(memory_format=torch.channels_last)
+    xs = torch.zeros(8, 4, 92, 92, device=dev).contiguous(memory_format=torch.channels_last)
     assert fftconv.applicable(xs, 4, 4) and fftconv.tiles(92) == 2 and fftconv.tiles(93) == 3
-    assert not fftconv.applicable(torch.zeros(1, 4, 60, 60, device=dev).contiguous(memory_format=torch.channels_last), 4, 4)
+    assert not fftconv.applicable(xs[:4], 4, 4)            # too few tiles to amortise streaming the filter spectra
+    assert not fftconv.applicable(torch.zeros(8, 4, 60, 60, device=dev).contiguous(memory_format=torch.channels_last), 4, 4)
     assert _lib.load().eqa_fft48k5_tiles(92) == 2
 
 
@@ -1047,9 +1048,9 @@ def test_escnn_inference_fft_path_equals_winograd_and_module_paths(dev, monkeypa
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             m.running_mean.normal_(0, 0.2)
             m.running_var.uniform_(0.5, 1.5)
-    x = torch.randn(5, 3, 96, 96, device=dev)
+    x = torch.randn(9, 3, 96, 96, device=dev)
     with torch.no_grad():
-        assert fftconv.ENABLED
+        assert fftconv.ENABLED and fftconv.applicable(torch.zeros(9, 64, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 64, 64)
         a_fft = net(x)
         monkeypatch.setattr(fftconv, "ENABLED", False)
         a_wino = net(x)

@@ -13,7 +13,7 @@ import bench  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     can = bench.build_canonicalizer(dev)
-    for B in (1, 4, 16, 64, 256):
+    for B in [int(v) for v in os.environ.get("EQA_LAT_BATCHES", "1,4,16,64,256").split(",")]:
         x = torch.randn(B, 3, 224, 224, device=dev)
         f = torch.randn(B, 3, 224, 224, device=dev)
 
