@@ -271,3 +271,27 @@ def test_fft_group_rule_matches_the_library():
     lib = _lib.load()
     for c in (4, 12, 16, 64, 250, 256):
         assert (lib.eqa_fft48k5_group(c, 0), lib.eqa_fft48k5_group(c, 1)) == fftconv.group_sizes(c, c)
+
+
+def test_generated_fft48_is_current_and_correct():
+    """csrc/fft48.inc is generated (tools/gen_fft48.py): the committed file equals what the generator renders now, and the
+    operation list, run in numpy with fp32 rounding, is the 48-point DFT (vs numpy.fft, forward and -- with re / im swapped --
+    inverse)."""
+    import importlib.util
+    import os
+
+    import numpy as np
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_fft48", os.path.join(root, "tools", "gen_fft48.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.render() == open(os.path.join(root, "equiadapt_amd", "csrc", "fft48.inc")).read()
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        z = rng.standard_normal(48) + 1j * rng.standard_normal(48)
+        want = np.fft.fft(z)
+        assert np.abs(gen.evaluate(z) - want).max() <= 4e-6 * np.abs(want).max()
+        sw = gen.evaluate(z.imag + 1j * z.real)                      # inverse = forward on swapped parts, swapped back
+        inv = sw.imag + 1j * sw.real
+        assert np.abs(inv - np.fft.ifft(z) * 48).max() <= 4e-6 * np.abs(want).max()
