@@ -380,6 +380,51 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   }
 }
 
+// Filter spectra for the batched GEMM: bank (Cout, Cin, 5, 5) -> B (1200, 2 Cin, 2 Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
+// Br + i Bi = conj(FFT48x48(filter))[ky][kx] / 48^2 = sum_{u,v} w[u][v] (cos t + i sin t) / 2304, t = 2 pi (ky u + kx v) / 48.
+// Rows follow the rows of V ([Re x G | Im x G] per group of G input channels), columns the rows of Mo (interleaved complex).
+// One thread per (ci, co) keeps its 25 taps in registers and walks the 1200 frequencies (fp64 accumulation, twiddles from a
+// 48-entry table): 0.3 ms for 256 x 256 filters, against 13.6 ms for the same through torch.fft + concatenations -- cheap
+// enough to run every training step.
+__global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const float* __restrict__ bank, float* __restrict__ B, int Cout,
+                                                                       int Cin, int G) {
+  __shared__ double tw_c[kFftN], tw_s[kFftN];
+  if (threadIdx.x < kFftN) {
+    const double t = 6.283185307179586476925286766559 * threadIdx.x / kFftN;
+    tw_c[threadIdx.x] = cos(t);
+    tw_s[threadIdx.x] = sin(t);
+  }
+  __syncthreads();
+  const int co = blockIdx.y * kThreads + threadIdx.x;
+  const int ci = blockIdx.x;
+  if (co >= Cout) return;
+  double w[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) w[i] = bank[((size_t)co * Cin + ci) * 25 + i];
+  const int r0 = (ci / G) * 2 * G + ci % G, r1 = r0 + G;
+  const size_t fstride = (size_t)2 * Cin * 2 * Cout;
+  float2* o0 = reinterpret_cast<float2*>(B + (size_t)r0 * 2 * Cout) + co;
+  float2* o1 = reinterpret_cast<float2*>(B + (size_t)r1 * 2 * Cout) + co;
+  constexpr double inv = 1.0 / (kFftN * kFftN);
+  for (int ky = 0; ky < kFftN; ++ky) {
+    for (int kx = 0; kx < kFftH; ++kx) {
+      double br = 0.0, bi = 0.0;
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+          const int t = (ky * u + kx * v) % kFftN;
+          br += w[u * 5 + v] * tw_c[t];
+          bi += w[u * 5 + v] * tw_s[t];
+        }
+      const float fr = (float)(br * inv), fi = (float)(bi * inv);
+      const size_t f = (size_t)(ky * kFftH + kx) * (fstride / 2);  // in float2
+      o0[f] = make_float2(fr, fi);
+      o1[f] = make_float2(-fi, fr);
+    }
+  }
+}
+
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
 #ifndef EQA_FFT_INV_CH
@@ -443,6 +488,14 @@ int eqa_fft48k5_group(int C, int side) {
 }
 
 int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
+
+int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, void* stream) {
+  if (!bank || !B || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)B & 7) || Cin > 65535) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fft48_filter_spectra_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, bank,
+                     B, Cout, Cin, fft_group_in(Cin));
+  return launch_status();
+}
 
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int cols, int C) {
   if (nimg <= 0 || rows <= 0 || cols <= 0 || C <= 0) return 0;

@@ -18,6 +18,7 @@ ENABLED = os.environ.get("EQA_CONV5_FFT", "1") != "0"
 # The filter spectra (1200 x 2Cin x 2Cout floats: 1.26 GB at 256 channels) are streamed once per call, the Winograd filters are
 # 17 MB: below ~32 tiles (8 images of 92 x 92) the Winograd path is faster (measured: B=4 0.29 vs 0.37 ms, B=8 0.48 vs 0.46 ms).
 MIN_TILES = int(os.environ.get("EQA_FFT_MIN_TILES", "32"))
+TRAIN_FORWARD = os.environ.get("EQA_FFT_TRAIN", "1") != "0"     # forward pass of winograd.Conv5x5Function through this path
 
 
 def tiles(n: int) -> int:
@@ -55,6 +56,13 @@ def filter_spectra(bank: torch.Tensor, groups=None) -> torch.Tensor:
     """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency.  Rows
     follow the rows of V, columns the rows of Mo (``group_sizes``; ``groups`` = (Cin, Cout) gives the plain [Re | Im] order)."""
     Cout, Cin = bank.shape[:2]
+    if groups is None and bank.is_cuda and bank.dtype == torch.float32:
+        lib = _lib.load()                                         # on the device: one kernel (eqa_fft48k5_filter_spectra)
+        B = torch.empty((N * NH, 2 * Cin, 2 * Cout), dtype=torch.float32, device=bank.device)
+        with torch.cuda.device(bank.device):
+            _lib.check(lib.eqa_fft48k5_filter_spectra(bank.contiguous().data_ptr(), B.data_ptr(), Cout, Cin,
+                                                      torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_filter_spectra")
+        return B
     gin, gout = groups if groups is not None else group_sizes(Cin, Cout)
     wp = torch.zeros(Cout, Cin, N, N, dtype=torch.float64, device=bank.device)
     wp[:, :, :5, :5] = bank.double()

@@ -310,6 +310,8 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
+/* bank:(Cout,Cin,5,5) -> B:(1200, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step) */
+int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, void* stream);
 int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,

@@ -187,11 +187,12 @@ def test_training_steps_on_device(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("size", [32, 30])
+@pytest.mark.parametrize("size", [32, 30, 96])
 def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     """ESCNNEquivariantNetwork in train(): the Winograd / window-sum autograd path vs the plain module sequence
     (F.conv2d + BatchNorm3d + group_pool through autograd) with the same weights: activations, every parameter gradient, the
-    input gradient and the batch-norm running statistics.  size 32 exercises F(4x4,5x5), size 30 F(2x2,5x5)."""
+    input gradient and the batch-norm running statistics.  size 32 exercises F(4x4,5x5), size 30 F(2x2,5x5), size 96 (batch 9:
+    36 tiles) the FFT convolution in the forward pass with the Winograd kernels in the backward pass."""
     import copy
 
     import equiadapt_amd as ea
@@ -207,16 +208,22 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     ref = copy.deepcopy(net)
     net.train()
     ref.train()
-    x = torch.randn(6, 3, size, size, device=dev)
+    nb = 9 if size == 96 else 6
+    x = torch.randn(nb, 3, size, size, device=dev)
     x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
-    w = torch.randn(6, 8, device=dev)
+    w = torch.randn(nb, 8, device=dev)
+    if size == 96:
+        from equiadapt_amd.images.canonicalization_networks import fftconv
+
+        assert fftconv.TRAIN_FORWARD and fftconv.applicable(
+            torch.zeros(nb, 64, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 64, 64)
 
     assert net._training_fast_path_ok(x1)
     a1 = net(x1)
     monkeypatch.setenv("EQA_TRAIN_FAST", "0")
     a2 = ref(x2)
     monkeypatch.delenv("EQA_TRAIN_FAST")
-    assert a1.shape == a2.shape == (6, 8)
+    assert a1.shape == a2.shape == (nb, 8)
     scale = a2.abs().max().item()
     assert (a1 - a2).abs().max().item() <= 2e-5 * max(scale, 1.0), (a1 - a2).abs().max().item()
     (a1 * w).sum().backward()

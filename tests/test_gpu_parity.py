@@ -1059,3 +1059,17 @@ def test_escnn_inference_fft_path_equals_winograd_and_module_paths(dev, monkeypa
     assert (a_fft - a_mod).abs().max().item() <= 2e-5 * max(scale, 1.0)
     assert (a_wino - a_mod).abs().max().item() <= 2e-5 * max(scale, 1.0)
     assert torch.equal(a_fft.argmax(1), a_mod.argmax(1))
+
+
+def test_fft_filter_spectra_kernel_matches_host_construction(dev):
+    """eqa_fft48k5_filter_spectra (one kernel, fp64 accumulation) vs the host construction through torch.fft in fp64, for the
+    grouped ([Re x 16 | Im x 16]) and the interleaved row order."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(12)
+    for (Cout, Cin) in [(64, 32), (24, 12), (256, 256), (5, 3)]:
+        w = torch.randn(Cout, Cin, 5, 5, device=dev)
+        got = fftconv.filter_spectra(w)
+        want = fftconv.filter_spectra(w, groups=fftconv.group_sizes(Cin, Cout))      # host path (explicit groups)
+        assert got.shape == want.shape == (1200, 2 * Cin, 2 * Cout)
+        assert (got - want).abs().max().item() <= 2e-7 * want.abs().max().item() + 1e-12, (Cout, Cin)
