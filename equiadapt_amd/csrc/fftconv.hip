@@ -40,14 +40,14 @@ __device__ __forceinline__ void fft_ldg2(const float2* p, float& re, float& im) 
 
 __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ T,
                                                                  const float* __restrict__ in_bias, int in_relu, int H, int W,
-                                                                 int C, int TX) {
+                                                                 int C, int TX, int win) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
   const int xt = blockIdx.x % TX;
   const size_t row = blockIdx.x / TX;  // img * H + y
   const float ib = in_bias ? in_bias[c] : 0.0f;
   const float* p = x + (row * W + (size_t)kFftO * xt) * C + c;
-  const int nvalid = min(kFftN, W - kFftO * xt);  // uniform
+  const int nvalid = min(win, W - kFftO * xt);  // uniform; win = 48: activation tiles (overlap 4), 44: gradient tiles (disjoint)
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
   for (int j = 0; j < kFftN; ++j) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* _
 }
 
 __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* __restrict__ T, float* __restrict__ V, int H, int C,
-                                                                 int TY, int TX, size_t M, size_t m0, int G) {
+                                                                 int TY, int TX, size_t M, size_t m0, int G, int win) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
   if (c >= C) return;
   const int kx = blockIdx.x % kFftH;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
   const int y0 = kFftO * ty;
-  const int nvalid = min(kFftN, H - y0);  // uniform
+  const int nvalid = min(win, H - y0);  // uniform
   const size_t pitch = (size_t)TX * kFftH * 2 * C;  // one image row of T
   const float* p = T + ((img * H + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
@@ -207,7 +207,7 @@ constexpr int kFusLds = kFftH * kFusKxPitch;                      // 38,800 floa
 
 __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                                       const float* __restrict__ in_bias, int in_relu, int H, int W,
-                                                                      int C, int TY, int TX, size_t M, unsigned nwork) {
+                                                                      int C, int TY, int TX, size_t M, unsigned nwork, int win) {
   extern __shared__ float lds[];
   // XCD-aware order: consecutive work items (the channel groups of one tile) on one XCD
   const unsigned bid = blockIdx.x;
@@ -224,10 +224,10 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
   {
     const int y = threadIdx.x / kFusCh;  // 0..47
     const int gy = kFftO * ty + y;
-    const int nvalid = min(kFftN, W - kFftO * tx);  // uniform
+    const int nvalid = min(win, W - kFftO * tx);  // uniform
     const float ib = in_bias ? in_bias[c] : 0.0f;
     const float* p = x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
-    const bool row_in = gy < H;
+    const bool row_in = gy < H && y < win;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
 #pragma unroll
     for (int j = 0; j < kFftN; ++j) {
@@ -425,6 +425,51 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
   }
 }
 
+// Filter gradient in the frequency domain (training).  With G = the spectra of the output-gradient tiles (44 x 44, zero-padded
+// to 48: eqa_fft48k5_grad_transform) and V those of the input tiles, D[f] = V[f]^T . G[f] (real form, one batched GEMM over
+// the tiles) holds  Dr = D[re ci][re co] + D[im ci][im co],  Di = D[im ci][re co] - D[re ci][im co]  of  X_f^T conj(G_f), and
+//   dW[co][ci][u][v] = 1/48^2 sum_f wgt(kx) (cos t Dr - sin t Di),  t = 2 pi (ky u + kx v) / 48,
+// wgt = 2 for the frequencies whose conjugate partner is not stored (0 < kx < 24), else 1 -- the correlation theorem; no
+// wrap-around because a 44-wide gradient tile shifted by up to 4 stays inside the 48-wide input tile.
+__global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float* __restrict__ D, float* __restrict__ dbank, int Cout,
+                                                                    int Cin, int Gin, int Gout) {
+  __shared__ double tw_c[kFftN], tw_s[kFftN];
+  if (threadIdx.x < kFftN) {
+    const double t = 6.283185307179586476925286766559 * threadIdx.x / kFftN;
+    tw_c[threadIdx.x] = cos(t);
+    tw_s[threadIdx.x] = sin(t);
+  }
+  __syncthreads();
+  const int co = blockIdx.y * kThreads + threadIdx.x;
+  const int ci = blockIdx.x;
+  if (co >= Cout) return;
+  const int r0 = (ci / Gin) * 2 * Gin + ci % Gin, r1 = r0 + Gin;
+  const int c0 = (co / Gout) * 2 * Gout + co % Gout, c1 = c0 + Gout;
+  const size_t ld = (size_t)2 * Cout, fstride = (size_t)2 * Cin * ld;
+  double acc[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) acc[i] = 0.0;
+  for (int ky = 0; ky < kFftN; ++ky) {
+    for (int kx = 0; kx < kFftH; ++kx) {
+      const float* d = D + (size_t)(ky * kFftH + kx) * fstride;
+      const double wgt = (kx == 0 || kx == kFftH - 1) ? 1.0 : 2.0;
+      const double dr = wgt * ((double)d[r0 * ld + c0] + (double)d[r1 * ld + c1]);
+      const double di = wgt * ((double)d[r1 * ld + c0] - (double)d[r0 * ld + c1]);
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+#pragma unroll
+        for (int v = 0; v < 5; ++v) {
+          const int t = (ky * u + kx * v) % kFftN;
+          acc[u * 5 + v] += tw_c[t] * dr - tw_s[t] * di;
+        }
+    }
+  }
+  constexpr double inv = 1.0 / (kFftN * kFftN);
+  float* o = dbank + ((size_t)co * Cin + ci) * 25;
+#pragma unroll
+  for (int i = 0; i < 25; ++i) o[i] = (float)(acc[i] * inv);
+}
+
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
 #ifndef EQA_FFT_INV_CH
@@ -503,14 +548,10 @@ int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int cols, int C) {
   return (int64_t)fft_chunk_images(nimg, rows, TX, C) * rows * TX * kFftH * 2 * C * (int64_t)sizeof(float);
 }
 
-int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                      void* stream) {
-  if (!x || !T || !V || !fft_dims_ok(nimg, H, W, C)) return EQA_ERR_INVALID_ARG;
-  if (nimg == 0) return EQA_OK;
-  const int TY = (int)eqa_fft48k5_tiles(H), TX = (int)eqa_fft48k5_tiles(W);
+static int fft_forward_impl(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                            int TY, int TX, int win, hipStream_t st) {
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  hipStream_t st = (hipStream_t)stream;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
   if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
     static const bool lds_ok =
@@ -518,7 +559,7 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
       hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
-                         W, C, TY, TX, M, nwork);
+                         W, C, TY, TX, M, nwork, win);
       return launch_status();
     }
     (void)hipGetLastError();
@@ -528,10 +569,33 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
     const int n = std::min(chunk, nimg - i0);
     hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
-                       x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX);
+                       x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX, win);
     hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
-                       TY, TX, M, (size_t)i0 * TY * TX, fft_group_in(C));
+                       TY, TX, M, (size_t)i0 * TY * TX, fft_group_in(C), win);
   }
+  return launch_status();
+}
+
+int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                      void* stream) {
+  if (!x || !T || !V || !fft_dims_ok(nimg, H, W, C)) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  return fft_forward_impl(x, T, V, in_bias, in_relu, nimg, H, W, C, (int)eqa_fft48k5_tiles(H), (int)eqa_fft48k5_tiles(W), kFftN,
+                          (hipStream_t)stream);
+}
+
+int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream) {
+  if (!dy || !T || !G || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  return fft_forward_impl(dy, T, G, nullptr, 0, nimg, OH, OW, C, (OH + kFftO - 1) / kFftO, (OW + kFftO - 1) / kFftO, kFftO,
+                          (hipStream_t)stream);
+}
+
+int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream) {
+  if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (Cin > 65535) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fft48_filter_grad_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
+                     dbank, Cout, Cin, fft_group_in(Cin), fft_group_in(Cout));
   return launch_status();
 }
 

@@ -77,10 +77,12 @@ def filter_spectra(bank: torch.Tensor, groups=None) -> torch.Tensor:
 
 
 def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
-            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0) -> torch.Tensor:
+            in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0,
+            keep_V: Optional[list] = None) -> torch.Tensor:
     """x: channels-last (nimg,Cin,H,W) -> channels-last (nimg,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias) with
     B = filter_spectra(g) and act(x) = [relu](x + in_bias[c]) applied while loading; ``sums_k`` > 0: return instead the
-    (nimg, Cout, sums_k, sums_k) fp64 window sums of that output (the linearised last layer consumes only those)."""
+    (nimg, Cout, sums_k, sums_k) fp64 window sums of that output (the linearised last layer consumes only those).
+    ``keep_V``: a list that receives the input spectra V (training: the filter gradient reuses them)."""
     lib = _lib.load()
     nimg, Cin, H, W = x.shape
     Cout = B.shape[2] // 2
@@ -101,6 +103,8 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
         del T
         with _timed("fft_gemm"):
             Mo = torch.bmm(V, B)
+        if keep_V is not None:
+            keep_V.append(V)
         del V
         T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dev)
         if sums_k:
@@ -115,3 +119,28 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
             _lib.check(lib.eqa_fft48k5_output(Mo.data_ptr(), T2.data_ptr(), p_bias, int(relu), y.data_ptr(), nimg, OH, OW, Cout, st),
                        "eqa_fft48k5_output")
         return y
+
+
+def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int) -> torch.Tensor:
+    """d loss / d filter bank (Cout, Cin, 5, 5) of y = conv2d(x, bank) from V = the spectra of x's tiles (``keep_V`` of the
+    forward pass) and the output gradient dy (channels-last): spectra of the disjoint 44 x 44 gradient tiles, one batched GEMM
+    over the tiles per frequency (D[f] = V[f]^T G[f]), and the inverse transform restricted to the 5 x 5 support
+    (eqa_fft48k5_grad_transform / _filter_grad).  2.5 multiplies per output as in the forward pass; Winograd's filter gradient
+    (`winograd.filter_grad`) needs 4 and a 4x larger transformed gradient."""
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    dev = dy.device
+    M = V.shape[1]
+    assert V.shape == (N * NH, M, 2 * cin) and M == nimg * tiles(OH + 4) * tiles(OW + 4)
+    st = torch.cuda.current_stream().cuda_stream
+    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dev)
+    G = torch.empty((N * NH, M, 2 * Cout), dtype=torch.float32, device=dev)
+    dbank = torch.empty((Cout, cin, 5, 5), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout, st),
+                   "eqa_fft48k5_grad_transform")
+        del T
+        D = torch.bmm(V.transpose(1, 2), G)                       # (1200, 2 Cin, 2 Cout)
+        del G
+        _lib.check(lib.eqa_fft48k5_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, st), "eqa_fft48k5_filter_grad")
+    return dbank

@@ -149,13 +149,15 @@ class Conv5x5Function(torch.autograd.Function):
         from equiadapt_amd.images.canonicalization_networks import fftconv
 
         keep: list = []
-        if fftconv.TRAIN_FORWARD and fftconv.applicable(x, bank.shape[1], bank.shape[0]):
-            # the forward pass alone as an FFT convolution (2.5 instead of 4 multiplies per output; the filter spectra are
-            # rebuilt by one kernel); the backward then recomputes the Winograd-domain input for the filter gradient
-            y = fftconv.conv5x5(x, fftconv.filter_spectra(bank.detach()), None, False)
+        ctx.fft = fftconv.TRAIN_FORWARD and fftconv.applicable(x, bank.shape[1], bank.shape[0])
+        if ctx.fft:
+            # forward pass and filter gradient as an FFT convolution (2.5 instead of 4 multiplies per output; the filter
+            # spectra are rebuilt by one kernel, the input spectra are kept for the filter gradient); the input gradient
+            # stays on the Winograd kernels (its 92 outputs per axis would need three 44-pixel tiles)
+            y = fftconv.conv5x5(x, fftconv.filter_spectra(bank.detach()), None, False, keep_V=keep)
         else:
             y = conv5x5(x, transform_filters(bank.detach(), m), None, False, keep_V=keep if KEEP_V_FOR_BACKWARD else None)
-        ctx.save_for_backward(x, bank, *keep)     # V (P/m^2 times the activation) is kept: HBM is 288 GB, a pass is 2 ms
+        ctx.save_for_backward(x, bank, *keep)     # V is kept: HBM is 288 GB, recomputing it is a 1-2 ms pass
         ctx.m = m
         return y
 
@@ -168,7 +170,11 @@ class Conv5x5Function(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             bank_t = bank.detach().flip(-1, -2).transpose(0, 1).contiguous()       # (Cin, Cout, 5, 5)
             dx = conv5x5(dy, transform_filters(bank_t, m), None, False, pad=4)   # zero padding inside the input transform
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and ctx.fft:
+            from equiadapt_amd.images.canonicalization_networks import fftconv
+
+            dbank = fftconv.filter_grad(keep[0], dy, bank.shape[1]).to(bank.dtype)
+        elif ctx.needs_input_grad[1]:
             n = m + 4
             G = g_matrix(m).to(dy.device)
             dU = filter_grad(x, dy, m, keep[0] if keep else None).double().view(n, n, bank.shape[1], bank.shape[0])

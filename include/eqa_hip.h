@@ -318,6 +318,14 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
                       void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
+/* Training, filter gradient in the frequency domain (the reference gets it from autograd through R2Conv's conv2d):
+ *   eqa_fft48k5_grad_transform  dy:(nimg,OH,OW,C) -> G:(1200, M, 2C): spectra of the DISJOINT 44 x 44 output-gradient tiles,
+ *                               zero-padded to 48 x 48, same row layout as V; T: eqa_fft48k5_workspace_bytes(nimg, OH, OW, C).
+ *   [ batched GEMM by the caller: D[f] = V[f]^T (2Cin x M) . G[f] (M x 2Cout), V from eqa_fft48k5_input of the layer's input ]
+ *   eqa_fft48k5_filter_grad     D:(1200, 2Cin, 2Cout) -> dbank:(Cout,Cin,5,5) = d loss / d filter (fp64 accumulation).
+ */
+int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream);
+int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream);
 int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int relu, double* S, void* workspace, int nimg,
                             int OH, int OW, int C, int k_next, void* stream);
 
