@@ -99,6 +99,8 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
   }
 }
 
+// FULL (overlap-add, the input gradient): all 48 rows are results, stored tile by tile: T2 (nimg, TY, 48, TX, 25, 2, C)
+template <bool FULL>
 __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* __restrict__ Mo, float* __restrict__ T2, int OH, int C,
                                                                  int TY, int TX, size_t M, size_t m0) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
@@ -114,9 +116,18 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
 #pragma unroll
   for (int ky = 0; ky < kFftN; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
   fft48(im, re, oim, ore);  // inverse: real and imaginary parts swapped in and out (1 / 48^2 is in the filter spectra)
+  const size_t pitch = (size_t)TX * kFftH * 2 * C;
+  if (FULL) {
+    float* o = T2 + (((img * TY + ty) * kFftN) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
+#pragma unroll
+    for (int i = 0; i < kFftN; ++i) {
+      o[i * pitch] = ore[i];
+      o[i * pitch + C] = oim[i];
+    }
+    return;
+  }
   const int y0 = kFftO * ty;
   const int nrows = min(kFftO, OH - y0);  // uniform; rows 44..47 of the tile are the circular wrap-around
-  const size_t pitch = (size_t)TX * kFftH * 2 * C;
   float* o = T2 + ((img * OH + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
 #pragma unroll
   for (int i = 0; i < kFftO; ++i) {
@@ -124,6 +135,53 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
       o[i * pitch] = ore[i];
       o[i * pitch + C] = oim[i];
     }
+  }
+}
+
+// Input gradient (training), row pass with overlap-add.  A 44 x 44 output-gradient tile convolved with the 5 x 5 filters is a
+// 48 x 48 block of the input gradient (44 + 5 - 1: the circular transform wraps nothing); blocks of neighbouring tiles overlap
+// by 4.  Thread = (image, input row y, channel): the row spectra of the (at most two) tile rows that reach y are added before
+// the row transform (it is linear), the 4 overlapping columns of consecutive tile columns are carried in registers: every
+// input-gradient element is written once, in a fixed order.
+__global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const float* __restrict__ T2, float* __restrict__ dx, int H, int W,
+                                                                     int C, int TY, int TX) {
+  const int c = blockIdx.y * kThreads + threadIdx.x;
+  if (c >= C) return;
+  const size_t row = blockIdx.x;  // img * H + y
+  const int y = (int)(row % H);
+  const size_t img = row / H;
+  const int t1 = min(y / kFftO, TY - 1), i1 = y - kFftO * t1;  // i1 <= 47 because H <= 44 TY + 4
+  const bool two = i1 < kFftN - kFftO && t1 > 0;               // rows 44..47 of the tile row above reach y as well
+  const size_t pitch = (size_t)TX * kFftH * 2 * C;
+  const float* p1 = T2 + ((img * TY + t1) * kFftN + i1) * pitch + c;
+  const float* p0 = two ? T2 + ((img * TY + t1 - 1) * kFftN + i1 + kFftO) * pitch + c : p1;
+  float carry[kFftN - kFftO] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float* o = dx + row * (size_t)W * C + c;
+  for (int tx = 0; tx < TX; ++tx) {
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+#pragma unroll
+    for (int k = 0; k < kFftH; ++k) {
+      const size_t off = ((size_t)tx * kFftH + k) * 2 * C;
+      const float a = p1[off], b = p1[off + C], a0 = p0[off], b0 = p0[off + C];
+      re[k] = two ? a + a0 : a;
+      im[k] = two ? b + b0 : b;
+    }
+#pragma unroll
+    for (int k = kFftH; k < kFftN; ++k) {
+      re[k] = re[kFftN - k];
+      im[k] = -im[kFftN - k];
+    }
+    fft48(im, re, oim, ore);
+    const int x0 = kFftO * tx;
+#pragma unroll
+    for (int j = 0; j < kFftN - kFftO; ++j) ore[j] += carry[j];
+    const bool last = tx == TX - 1;  // uniform
+#pragma unroll
+    for (int j = 0; j < kFftN; ++j) {
+      if ((j < kFftO || last) && x0 + j < W) o[(size_t)(x0 + j) * C] = ore[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kFftN - kFftO; ++j) carry[j] = ore[kFftO + j];
   }
 }
 
@@ -386,8 +444,9 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
 // One thread per (ci, co) keeps its 25 taps in registers and walks the 1200 frequencies (fp64 accumulation, twiddles from a
 // 48-entry table): 0.3 ms for 256 x 256 filters, against 13.6 ms for the same through torch.fft + concatenations -- cheap
 // enough to run every training step.
+// `sgn` = +1: the correlation form above (forward pass); -1: FFT(filter) itself, for the convolution of the input gradient.
 __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const float* __restrict__ bank, float* __restrict__ B, int Cout,
-                                                                       int Cin, int G) {
+                                                                       int Cin, int G, float sgn) {
   __shared__ double tw_c[kFftN], tw_s[kFftN];
   if (threadIdx.x < kFftN) {
     const double t = 6.283185307179586476925286766559 * threadIdx.x / kFftN;
@@ -417,7 +476,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
           br += w[u * 5 + v] * tw_c[t];
           bi += w[u * 5 + v] * tw_s[t];
         }
-      const float fr = (float)(br * inv), fi = (float)(bi * inv);
+      const float fr = (float)(br * inv), fi = sgn * (float)(bi * inv);
       const size_t f = (size_t)(ky * kFftH + kx) * (fstride / 2);  // in float2
       o0[f] = make_float2(fr, fi);
       o1[f] = make_float2(-fi, fr);
@@ -517,7 +576,7 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   const int chunk = fft_chunk_images(nimg, OH, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
     const int n = std::min(chunk, nimg - i0);
-    hipLaunchKernelGGL(fft48_cols_inv_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2, OH, C,
+    hipLaunchKernelGGL((fft48_cols_inv_kernel<false>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2, OH, C,
                        TY, TX, M, (size_t)i0 * TY * TX);
     hipLaunchKernelGGL((fft48_rows_inv_kernel<NB>), dim3((unsigned)((size_t)n * OH), cb), dim3(kThreads), 0, st, T2, bias, relu, out, OH,
                        OW, C, TX, (size_t)i0);
@@ -534,11 +593,32 @@ int eqa_fft48k5_group(int C, int side) {
 
 int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
 
-int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, void* stream) {
+int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, int correlate, void* stream) {
   if (!bank || !B || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (((uintptr_t)B & 7) || Cin > 65535) return EQA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(fft48_filter_spectra_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, bank,
-                     B, Cout, Cin, fft_group_in(Cin));
+                     B, Cout, Cin, fft_group_in(Cin), correlate ? 1.0f : -1.0f);
+  return launch_status();
+}
+
+int eqa_fft48k5_input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, void* stream) {
+  if (!Cg || !T2 || !dx || nimg < 0 || H < 5 || W < 5 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  const int OH = H - 4, OW = W - 4;
+  const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
+  const size_t M = (size_t)nimg * TY * TX;
+  if ((size_t)nimg * H > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned cb = (C + kThreads - 1) / kThreads;
+  // chunks of images, as in the other two-pass paths (T2 holds 48 rows per tile row here)
+  const int chunk = fft_chunk_images(nimg, TY * kFftN, TX, C);
+  for (int i0 = 0; i0 < nimg; i0 += chunk) {
+    const int n = std::min(chunk, nimg - i0);
+    hipLaunchKernelGGL((fft48_cols_inv_kernel<true>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Cg, T2, OH,
+                       C, TY, TX, M, (size_t)i0 * TY * TX);
+    hipLaunchKernelGGL(fft48_rows_inv_add_kernel, dim3((unsigned)((size_t)n * H), cb), dim3(kThreads), 0, st, T2,
+                       dx + (size_t)i0 * H * W * C, H, W, C, TY, TX);
+  }
   return launch_status();
 }
 

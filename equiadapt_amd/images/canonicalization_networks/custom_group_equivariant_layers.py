@@ -101,7 +101,7 @@ class _GroupConvBase(nn.Module):
             if ver == w._version and bank is not None and bank.device == w.device:
                 return bank
         O, I, E, k = self.out_channels, self.in_channels, self.num_group_elements, self.kernel_size
-        A = filter_action_matrices(k, self.num_rotations, self.reflections, w.device)  # (E, p, q)
+        A = filter_action_matrices(k, self.num_rotations, self.reflections, w.device).to(w.dtype)  # (E, p, q)
         if self.lifting:
             bank = torch.einsum("epq,oiq->oeip", A, w.reshape(O, I, k * k)).reshape(O * E, I, k, k)
         else:

@@ -52,7 +52,7 @@ def group_sizes(cin: int, cout: int):
     return (16 if cin % 16 == 0 else 1), 1
 
 
-def filter_spectra(bank: torch.Tensor, groups=None) -> torch.Tensor:
+def filter_spectra(bank: torch.Tensor, groups=None, correlate: bool = True) -> torch.Tensor:
     """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency.  Rows
     follow the rows of V, columns the rows of Mo (``group_sizes``; ``groups`` = (Cin, Cout) gives the plain [Re | Im] order)."""
     Cout, Cin = bank.shape[:2]
@@ -60,9 +60,10 @@ def filter_spectra(bank: torch.Tensor, groups=None) -> torch.Tensor:
         lib = _lib.load()                                         # on the device: one kernel (eqa_fft48k5_filter_spectra)
         B = torch.empty((N * NH, 2 * Cin, 2 * Cout), dtype=torch.float32, device=bank.device)
         with torch.cuda.device(bank.device):
-            _lib.check(lib.eqa_fft48k5_filter_spectra(bank.contiguous().data_ptr(), B.data_ptr(), Cout, Cin,
+            _lib.check(lib.eqa_fft48k5_filter_spectra(bank.contiguous().data_ptr(), B.data_ptr(), Cout, Cin, int(correlate),
                                                       torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_filter_spectra")
         return B
+    assert correlate, "the host construction is the correlation (forward) form"
     gin, gout = groups if groups is not None else group_sizes(Cin, Cout)
     wp = torch.zeros(Cout, Cin, N, N, dtype=torch.float64, device=bank.device)
     wp[:, :, :5, :5] = bank.double()
@@ -121,7 +122,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
         return y
 
 
-def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int) -> torch.Tensor:
+def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int, G: Optional[torch.Tensor] = None) -> torch.Tensor:
     """d loss / d filter bank (Cout, Cin, 5, 5) of y = conv2d(x, bank) from V = the spectra of x's tiles (``keep_V`` of the
     forward pass) and the output gradient dy (channels-last): spectra of the disjoint 44 x 44 gradient tiles, one batched GEMM
     over the tiles per frequency (D[f] = V[f]^T G[f]), and the inverse transform restricted to the 5 x 5 support
@@ -133,14 +134,45 @@ def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int) -> torch.Tensor:
     M = V.shape[1]
     assert V.shape == (N * NH, M, 2 * cin) and M == nimg * tiles(OH + 4) * tiles(OW + 4)
     st = torch.cuda.current_stream().cuda_stream
-    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dev)
-    G = torch.empty((N * NH, M, 2 * Cout), dtype=torch.float32, device=dev)
+    if G is None:
+        G = grad_spectra(dy)
     dbank = torch.empty((Cout, cin, 5, 5), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout, st),
-                   "eqa_fft48k5_grad_transform")
-        del T
         D = torch.bmm(V.transpose(1, 2), G)                       # (1200, 2 Cin, 2 Cout)
-        del G
         _lib.check(lib.eqa_fft48k5_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, st), "eqa_fft48k5_filter_grad")
     return dbank
+
+
+def input_grad(dy: torch.Tensor, bank: torch.Tensor, G: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """d loss / d x (channels-last (nimg, Cin, OH+4, OW+4)) of y = conv2d(x, bank): the full convolution of dy with the
+    filters, tile by tile in the frequency domain with overlap-add (eqa_fft48k5_input_grad).  ``G``: the gradient-tile
+    spectra if the caller already has them (`grad_spectra`)."""
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    Cin = bank.shape[1]
+    dev = dy.device
+    if G is None:
+        G = grad_spectra(dy)
+    B2 = filter_spectra(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)      # (1200, 2 Cout, 2 Cin)
+    st = torch.cuda.current_stream().cuda_stream
+    H, W = OH + 4, OW + 4
+    dx = torch.empty((nimg, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        Cg = torch.bmm(G, B2)                                     # (1200, M, 2 Cin)
+        T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, N * tiles(H), OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.eqa_fft48k5_input_grad(Cg.data_ptr(), T2.data_ptr(), dx.data_ptr(), nimg, H, W, Cin, st), "eqa_fft48k5_input_grad")
+    return dx
+
+
+def grad_spectra(dy: torch.Tensor) -> torch.Tensor:
+    """Spectra of the disjoint 44 x 44 tiles of an output gradient (channels-last), (1200, M, 2 Cout): shared by the filter
+    gradient and the input gradient."""
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    M = nimg * tiles(OH + 4) * tiles(OW + 4)
+    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dy.device)
+    G = torch.empty((N * NH, M, 2 * Cout), dtype=torch.float32, device=dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout,
+                                                  torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_grad_transform")
+    return G

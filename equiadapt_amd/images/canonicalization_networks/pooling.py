@@ -20,7 +20,10 @@ class _GroupPoolFn(torch.autograd.Function):
 
 def group_pool(feature_map: torch.Tensor) -> torch.Tensor:
     """``torch.mean(feature_map, dim=(1, 3, 4))`` (reference: escnn_networks.py:115,
-    custom_equivariant_networks.py:91) as one pass over the map (eqa_group_pool_argmax)."""
+    custom_equivariant_networks.py:91) as one pass over the map (eqa_group_pool_argmax; fp32 -- a module converted to
+    another dtype, e.g. ``.double()`` for a reference computation, takes torch's reduction)."""
+    if feature_map.dtype != torch.float32:
+        return torch.mean(feature_map, dim=(1, 3, 4))
     return _GroupPoolFn.apply(feature_map)
 
 

@@ -151,9 +151,8 @@ class Conv5x5Function(torch.autograd.Function):
         keep: list = []
         ctx.fft = fftconv.TRAIN_FORWARD and fftconv.applicable(x, bank.shape[1], bank.shape[0])
         if ctx.fft:
-            # forward pass and filter gradient as an FFT convolution (2.5 instead of 4 multiplies per output; the filter
-            # spectra are rebuilt by one kernel, the input spectra are kept for the filter gradient); the input gradient
-            # stays on the Winograd kernels (its 92 outputs per axis would need three 44-pixel tiles)
+            # forward pass and both gradients as FFT convolutions (2.5 instead of 4 multiplies per output; the filter spectra
+            # are rebuilt by one kernel, the input spectra are kept for the filter gradient)
             y = fftconv.conv5x5(x, fftconv.filter_spectra(bank.detach()), None, False, keep_V=keep)
         else:
             y = conv5x5(x, transform_filters(bank.detach(), m), None, False, keep_V=keep if KEEP_V_FOR_BACKWARD else None)
@@ -167,14 +166,20 @@ class Conv5x5Function(torch.autograd.Function):
         m = ctx.m
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dbank = None
+        if ctx.fft:
+            # both gradients in the frequency domain, from one transform of the output gradient's 44 x 44 tiles
+            from equiadapt_amd.images.canonicalization_networks import fftconv
+
+            G = fftconv.grad_spectra(dy)
+            if ctx.needs_input_grad[0]:
+                dx = fftconv.input_grad(dy, bank, G)
+            if ctx.needs_input_grad[1]:
+                dbank = fftconv.filter_grad(keep[0], dy, bank.shape[1], G).to(bank.dtype)
+            return dx, dbank, None
         if ctx.needs_input_grad[0]:
             bank_t = bank.detach().flip(-1, -2).transpose(0, 1).contiguous()       # (Cin, Cout, 5, 5)
             dx = conv5x5(dy, transform_filters(bank_t, m), None, False, pad=4)   # zero padding inside the input transform
-        if ctx.needs_input_grad[1] and ctx.fft:
-            from equiadapt_amd.images.canonicalization_networks import fftconv
-
-            dbank = fftconv.filter_grad(keep[0], dy, bank.shape[1]).to(bank.dtype)
-        elif ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1]:
             n = m + 4
             G = g_matrix(m).to(dy.device)
             dU = filter_grad(x, dy, m, keep[0] if keep else None).double().view(n, n, bank.shape[1], bank.shape[0])

@@ -310,8 +310,10 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
-/* bank:(Cout,Cin,5,5) -> B:(1200, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step) */
-int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, void* stream);
+/* bank:(Cout,Cin,5,5) -> B:(1200, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step);
+ * correlate = 0: FFT(filter)/2304 instead of its conjugate (a convolution: the input gradient, with bank = the filters with
+ * their channel axes swapped, (Cin,Cout,5,5)) */
+int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, int correlate, void* stream);
 int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
@@ -326,6 +328,10 @@ int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, 
  */
 int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream);
 int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream);
+/* Training, input gradient: Cg:(1200, M, 2C) = G[f] . B2[f] (B2 = eqa_fft48k5_filter_spectra of the channel-swapped bank with
+ * correlate = 0) -> dx:(nimg,H,W,C), H = OH + 4: every 44 x 44 gradient tile yields a 48 x 48 block, blocks overlap by 4 and are
+ * added in a fixed order.  T2: eqa_fft48k5_workspace_bytes(nimg, 48*TY, OW, C) bytes. */
+int eqa_fft48k5_input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, void* stream);
 int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int relu, double* S, void* workspace, int nimg,
                             int OH, int OW, int C, int k_next, void* stream);
 

@@ -205,12 +205,16 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
             m.p = 0.0                                    # same function on both sides
         if hasattr(m, "bias") and isinstance(getattr(m, "bias"), torch.nn.Parameter):
             torch.nn.init.normal_(m.bias, std=0.1)
-    ref = copy.deepcopy(net)
+    # size 96: the reference is the module sequence in fp64 (the fp32 module path goes through whatever convolution kernels the
+    # framework's auto-tuner picks on the box -- on some boxes kernels that are themselves 1e-2 off in the input gradient; the
+    # FFT path is within 2e-6 of fp64, closer than any fp32 module path)
+    ref = copy.deepcopy(net).double() if size == 96 else copy.deepcopy(net)
+    rdt = torch.float64 if size == 96 else torch.float32
     net.train()
     ref.train()
     nb = 9 if size == 96 else 6
     x = torch.randn(nb, 3, size, size, device=dev)
-    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().to(rdt).requires_grad_(True)
     w = torch.randn(nb, 8, device=dev)
     if size == 96:
         from equiadapt_amd.images.canonicalization_networks import fftconv
@@ -227,7 +231,7 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     scale = a2.abs().max().item()
     assert (a1 - a2).abs().max().item() <= 2e-5 * max(scale, 1.0), (a1 - a2).abs().max().item()
     (a1 * w).sum().backward()
-    (a2 * w).sum().backward()
+    (a2 * w.to(rdt)).sum().backward()
     for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
         assert n1 == n2
         assert p1.grad is not None, n1                    # DistributedDataParallel needs a gradient for every parameter
@@ -237,12 +241,10 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
             # fast path, rounding noise on the module path
             assert n1.endswith("bias") and p1.grad.abs().max().item() == 0.0, n1
             continue
-        # (size 96: sums over 9 x 92 x 92 positions on both sides, and the module path's MIOpen kernels differ between a cold and a
-        # warm kernel database: twice the bound)
-        rtol = 6e-3 if size == 96 else 3e-3
+        rtol = 5e-5 if size == 96 else 3e-3      # measured against fp64: FFT path 1-2e-6, Winograd path up to 8e-4
         assert p1.grad is not None and (p1.grad - p2.grad).abs().max().item() <= rtol * g, (n1, (p1.grad - p2.grad).abs().max().item(), g)
     gx = x2.grad.abs().max().item()
-    assert (x1.grad - x2.grad).abs().max().item() <= (6e-3 if size == 96 else 3e-3) * gx
+    assert (x1.grad - x2.grad).abs().max().item() <= (5e-5 if size == 96 else 3e-3) * gx, ((x1.grad - x2.grad).abs().max().item(), gx)
     for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
         if "running" in n1 or "num_batches" in n1:
             assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-5), n1
@@ -251,7 +253,7 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     ref.eval()
     b1 = net(x)
     monkeypatch.setenv("EQA_TRAIN_FAST", "0")
-    b2 = ref(x)
+    b2 = ref(x.to(rdt))
     assert (b1 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1.0)
 
 
@@ -502,3 +504,21 @@ def test_fft_filter_gradient_matches_conv2d_weight(dev):
         want = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double())
         assert got.shape == want.shape
         assert (got.double() - want).abs().max().item() <= 5e-6 * want.abs().max().item(), (B, Cin, Cout, H, W)
+
+
+@pytest.mark.gpu
+def test_fft_input_gradient_matches_conv2d_input(dev, monkeypatch):
+    """fftconv.input_grad (gradient-tile spectra x FFT(filter), inverse with overlap-add of the 48 x 48 blocks) vs
+    torch.nn.grad.conv2d_input in fp64, fused and two-pass transforms, exact and partial tiles; and run twice: bit-identical
+    (every element is written once, in a fixed order)."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(32)
+    for (B, Cin, Cout, H, W) in [(3, 16, 32, 92, 92), (2, 8, 12, 60, 97), (2, 64, 16, 92, 92), (2, 4, 4, 48, 50), (1, 16, 16, 140, 49)]:
+        w = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cout ** 0.5)
+        dy = torch.randn(B, Cout, H - 4, W - 4, device=dev).contiguous(memory_format=torch.channels_last)
+        got = fftconv.input_grad(dy, w)
+        want = torch.nn.grad.conv2d_input((B, Cin, H, W), w.double(), dy.double())
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert (got.double() - want).abs().max().item() <= 5e-6 * want.abs().max().item(), (B, Cin, Cout, H, W)
+        assert torch.equal(got, fftconv.input_grad(dy, w))
