@@ -77,7 +77,53 @@ def lift():
     print(f"lift conv (MIOpen){ms*1e3:8.1f} us  {gf/ms:7.1f} TFLOP/s")
 
 
+def fft():
+    """The FFT convolution's stages at the headline shape (256 x 92 x 92 x 256 -> 88 x 88 x 256): forward transform, batched GEMM,
+    inverse transform + window sums; and the training-side pieces."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    n, C, H = 256, 256, 92
+    x = torch.randn(n, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(C, C, 5, 5, device=dev) / 80
+    bias = torch.randn(C, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    OH = H - 4
+    M = n * 4
+    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, H, OH, C), 4) // 4, device=dev)
+    V = torch.empty(1200, M, 2 * C, device=dev)
+    spectra = V.numel() * 4 / 1e9
+    ms = timeit(lambda: _lib.check(lib.eqa_fft48k5_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), bias.data_ptr(), 1, n, H, H, C, st), "in"), 10)
+    print(f"fft forward transform   {ms*1e3:8.1f} us  {(x.numel()*4/1e9 + spectra)/ms*1e3:7.0f} GB/s  (read {x.numel()*4/1e9:.2f} GB + write {spectra:.2f} GB)")
+    ms = timeit(lambda: fftconv.filter_spectra(w), 5)
+    print(f"filter spectra          {ms*1e3:8.1f} us")
+    B = fftconv.filter_spectra(w)
+    Mo = torch.empty(1200, M, 2 * C, device=dev)
+    ms = timeit(lambda: torch.bmm(V, B, out=Mo), 10)
+    print(f"batched GEMM            {ms*1e3:8.1f} us  {2*1200*M*512*512/ms/1e9:7.1f} TFLOP/s")
+    T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, OH, OH, C), 4) // 4, device=dev)
+    S = torch.empty(n, C, 5, 5, dtype=torch.float64, device=dev)
+    ws = torch.empty(n * OH * 2 * C * 9, device=dev)
+    ms = timeit(lambda: _lib.check(lib.eqa_fft48k5_output_sums(Mo.data_ptr(), T2.data_ptr(), bias.data_ptr(), 1, S.data_ptr(), ws.data_ptr(), n, OH, OH, C, 5, st), "out"), 10)
+    print(f"fft inverse + sums      {ms*1e3:8.1f} us  {spectra/ms*1e3:7.0f} GB/s")
+    y = torch.empty(n, C, OH, OH, device=dev).contiguous(memory_format=torch.channels_last)
+    ms = timeit(lambda: _lib.check(lib.eqa_fft48k5_output(Mo.data_ptr(), T2.data_ptr(), bias.data_ptr(), 1, y.data_ptr(), n, OH, OH, C, st), "out"), 10)
+    print(f"fft inverse (map)       {ms*1e3:8.1f} us  {(spectra + y.numel()*4/1e9)/ms*1e3:7.0f} GB/s")
+    del T, T2, ws
+    dy = torch.randn(n, C, OH, OH, device=dev).contiguous(memory_format=torch.channels_last)
+    ms = timeit(lambda: fftconv.grad_spectra(dy), 5)
+    print(f"gradient-tile spectra   {ms*1e3:8.1f} us")
+    G = fftconv.grad_spectra(dy)
+    ms = timeit(lambda: fftconv.filter_grad(V, dy, C, G), 5)
+    print(f"filter gradient         {ms*1e3:8.1f} us  (GEMM over the tiles + inverse on the 5x5 support)")
+    ms = timeit(lambda: fftconv.input_grad(dy, w, G), 5)
+    print(f"input gradient          {ms*1e3:8.1f} us  (spectra of the swapped bank + GEMM + overlap-add inverse)")
+
+
 if __name__ == "__main__":
+    if "--fft" in sys.argv:
+        fft()
+        sys.exit(0)
     if "--lift" in sys.argv:
         sys.argv.remove("--lift")
         lift()
