@@ -1073,3 +1073,47 @@ def test_fft_filter_spectra_kernel_matches_host_construction(dev):
         want = fftconv.filter_spectra(w, groups=fftconv.group_sizes(Cin, Cout))      # host path (explicit groups)
         assert got.shape == want.shape == (1200, 2 * Cin, 2 * Cout)
         assert (got - want).abs().max().item() <= 2e-7 * want.abs().max().item() + 1e-12, (Cout, Cin)
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 8), ("roto-reflection", 4)])
+def test_headline_geometry_end_to_end_against_oracle_fft_path(dev, group_type, N):
+    """The headline pipeline at its real geometry -- 224x224x3, crop 0.8, resize 96, lift 5x5 -> 92, 5x5 -> 88, linearised tail --
+    with 8 fields (64 channels) and 9 images, so that the hidden layer takes the FFT convolution (36 tiles).  Activations,
+    group index, canonicalized images and the inverted prediction against the CPU oracle."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+    from oracle import nets as onets
+
+    torch.manual_seed(2024)
+    net = ea.ESCNNEquivariantNetwork((3, 96, 96), 8, 5, group_type, N, 3)
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0.1, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    with torch.no_grad():                     # a random-init net separates the orientations of noise by ~1e-5: widen the margins
+        [m for m in net.eqv_network if hasattr(m, "expanded_weights")][-1].weights.mul_(100.0)
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=96)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 224, 224)).to(dev).eval()
+    G = can.num_group
+    assert fftconv.ENABLED and fftconv.applicable(
+        torch.zeros(9, 8 * G, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 8 * G, 8 * G)
+    x = torch.randn(9, 3, 224, 224)
+    f = torch.randn(9, 3, 224, 224)
+    with torch.no_grad():
+        y = can(x.to(dev))
+        acts = can.canonicalization_info_dict["group_activations"].cpu()
+        gidx = can.canonicalization_info_dict["group_index"].cpu().long()
+        inv = can.invert_canonicalization(f.to(dev), induced_rep_type="scalar")
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    xin = io.pre_canonicalization_transform(x, (3, 224, 224), 0.8, 96)
+    acts_ref = onets.escnn_like_network(xin, sd, group_type, N, 3, 8)
+    scale = acts_ref.abs().max().item()
+    assert (acts - acts_ref).abs().max().item() <= 2e-5 * max(scale, 1.0), ((acts - acts_ref).abs().max().item(), scale)
+    top2 = acts_ref.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * max(scale, 1.0)
+    assert clear.sum() >= 5 and torch.equal(gidx[clear], acts_ref.argmax(-1)[clear]), clear.sum()
+    el = io.group_element_from_activations(acts, N, group_type, 1.0, training=False)
+    _close(y, io.canonicalize_images(x, el["rotation"], el.get("reflection"), (3, 224, 224)))      # white-noise images: the
+    _close(inv, io.invert_action(f, el["rotation"], el.get("reflection"), N, G, "scalar"))           # loose pixel budget
