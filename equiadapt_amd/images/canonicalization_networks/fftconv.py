@@ -1,5 +1,7 @@
-"""5x5 stride-1 convolutions as an overlap-save FFT convolution on 48x48 tiles (inference path of the regular -> regular
-layers, reference: equiadapt/images/canonicalization_networks/escnn_networks.py:67-91).
+"""5x5 stride-1 convolutions as an overlap-save FFT convolution on 48x48 tiles: the regular -> regular layers of the
+canonicalization network (reference: equiadapt/images/canonicalization_networks/escnn_networks.py:67-91) in inference
+(`conv5x5`) and in training (`conv5x5` with ``keep_V``, `grad_spectra`, `filter_grad`, `input_grad`; used by
+`winograd.Conv5x5Function`).
 
 48x48 real FFT tiles produce 44x44 outputs each; per frequency the channel contraction is a complex matrix product that the
 GEMM library runs as a real one (see include/eqa_hip.h, eqa_fft48k5_*).  Where the tiles fit the output (88 = 2 x 44 at the
