@@ -273,12 +273,12 @@ def main():
             "winograd_output_sums": ("hbm", v_bytes, "eqa_winograd_f4k5_output_sums incl. finalize (hand-written)"),
             "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
         }
-        # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1200 frequencies;
+        # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1154 stored frequencies;
         # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written)
-        m_tiles, spectra = B * 4, 1200 * B * 4 * 512 * 4
+        m_tiles, spectra = B * 4, 1154 * B * 4 * 512 * 4
         spec.update({
             "fft_input": ("hbm", px_l * 256 * 4 + spectra, "eqa_fft48k5_input: row + column FFT-48 passes (hand-written)"),
-            "fft_gemm": ("mfma", 2.0 * 1200 * m_tiles * 512 * 512, "1200 x [tiles x 512].[512 x 512] batched GEMM, complex as real (library)"),
+            "fft_gemm": ("mfma", 2.0 * 1154 * m_tiles * 512 * 512, "1154 x [tiles x 512].[512 x 512] batched GEMM, complex as real (library)"),
             "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
         })
         stages = {}

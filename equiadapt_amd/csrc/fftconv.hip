@@ -6,7 +6,7 @@
 // real FFT tile gives 44x44 outputs -- two tiles cover the 88 output rows / columns exactly -- with 48 x 25 complex
 // frequencies: 4 real multiplies per complex one make 2.48 per output, and the spectra are only 1.24x the activations.
 // Per frequency f = (ky, kx) the channel contraction is a complex matrix product, done by the GEMM library as a REAL one
-// through [Ar | Ai] . [[Br, Bi], [-Bi, Br]] = [Cr | Ci]  (A: tiles x 2 Cin, B: 2 Cin x 2 Cout, batched over 1200 f).
+// through [Ar | Ai] . [[Br, Bi], [-Bi, Br]] = [Cr | Ci]  (A: tiles x 2 Cin, B: 2 Cin x 2 Cout, batched over the stored frequencies).
 // conv2d is a cross-correlation: B holds conj(FFT(filter)) / 48^2, computed once per weight version on the host side.
 // fp32 throughout; error vs an fp64 convolution 2-4e-7 of max|y| (Winograd F(4,5): 9e-6).
 //
@@ -16,9 +16,9 @@
 // contiguous run of channels), one 48-point transform per thread held in registers (fft48.inc, generated, 819 flops):
 //   rows_fwd   x (nimg,H,W,C) -> T (nimg,H,TX,25,2,C): real rows of 48 pixels (tile columns 44 tx .. 44 tx + 47, zero
 //              beyond W), previous layer's bias / ReLU applied while loading
-//   cols_fwd   T -> V (1200, M, 2C): columns of 48 rows (44 ty .. 44 ty + 47, zero beyond H), M = nimg*TY*TX tiles
+//   cols_fwd   T -> V (F, M, 2C), F = 1154 stored frequencies (below): columns of 48 rows (44 ty .. 44 ty + 47, zero beyond H), M = nimg*TY*TX tiles
 //   [ batched GEMM by the caller: Mo[f] = V[f] . B[f] ]
-//   cols_inv   Mo (1200, M, 2C) -> T2 (nimg,OH,TX,25,2,C): inverse over ky, rows 44..47 of a tile (circular wrap) dropped
+//   cols_inv   Mo (F, M, 2C) -> T2 (nimg,OH,TX,25,2,C): inverse over ky, rows 44..47 of a tile (circular wrap) dropped
 //   rows_inv   T2 -> y (nimg,OH,OW,C) = [relu](. + bias), or -> the window-sum segments of the next (last, linearised)
 //              layer in the format of window_sums_nhwc_finalize_kernel (one segment per output row)
 #include <cstdlib>
@@ -30,12 +30,41 @@ namespace {
 constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
 #include "fft48.inc"
 
+// Stored frequencies.  A real tile's spectrum is Hermitian: X[-ky][-kx] = conj(X[ky][kx]).  Keeping kx = 0..24 uses that for
+// 0 < kx < 24; in the columns kx = 0 and kx = 24 (their own mirror images) the rows ky = 25..47 are the conjugates of rows
+// 23..1 and are not stored either: 48 x 23 + 2 x 25 = 1154 frequencies instead of 1200 (the GEMM runs per frequency).
+// Index: f = ky * 23 + (kx - 1) for 0 < kx < 24, then 1104 + 2 ky + (kx == 24) for the two edge columns, ky <= 24.
+constexpr int kFftInner = kFftH - 2;
+constexpr int kFftF = kFftN * kFftInner + 2 * kFftH;
+__device__ __forceinline__ bool fft_edge(int kx) { return kx == 0 || kx == kFftH - 1; }
+__device__ __forceinline__ int fft_f0(int kx) { return kx == 0 ? kFftN * kFftInner : (kx == kFftH - 1 ? kFftN * kFftInner + 1 : kx - 1); }
+__device__ __forceinline__ int fft_fstep(int kx) { return fft_edge(kx) ? 2 : kFftInner; }
+__device__ __forceinline__ int fft_nky(int kx) { return fft_edge(kx) ? kFftH : kFftN; }
+
 // Mo in HBM: complex numbers, re and im interleaved, read once with 8-byte non-temporal loads
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void fft_ldg2(const float2* p, float& re, float& im) {
   const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
   re = v[0];
   im = v[1];
+}
+
+// One column of Mo (48 ky of one kx, tile and channel) for the inverse transform.  Edge columns store rows 0..24 only; their
+// rows 25..47 are the conjugates of rows 23..1.  Written so that the mirror costs no per-row select: rows >= 25 are addressed as
+// base2 + (ky - 25) * step2 with per-thread constants (forward or backward through the stored rows) and their imaginary parts
+// get a per-thread sign mask.
+__device__ __forceinline__ void fft_load_column(const float2* __restrict__ p, size_t fpitch, bool edge, float (&re)[kFftN],
+                                                float (&im)[kFftN]) {
+#pragma unroll
+  for (int ky = 0; ky < kFftH; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
+  const float2* base2 = edge ? p + (size_t)(kFftH - 2) * fpitch : p + (size_t)kFftH * fpitch;
+  const ptrdiff_t step2 = edge ? -(ptrdiff_t)fpitch : (ptrdiff_t)fpitch;
+  const unsigned flip = edge ? 0x80000000u : 0u;
+#pragma unroll
+  for (int ky = kFftH; ky < kFftN; ++ky) {
+    fft_ldg2(base2 + (ky - kFftH) * step2, re[ky], im[ky]);
+    im[ky] = __uint_as_float(__float_as_uint(im[ky]) ^ flip);
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ T,
@@ -90,12 +119,15 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
   }
   fft48(re, im, ore, oim);
   // rows of V: [Re x G | Im x G] per group of G channels (G = 16: what a block of the fused kernel owns; G = 1: interleaved)
-  float* o = V + ((size_t)kx * M + m0 + m) * 2 * (size_t)C + (c / G) * 2 * G + c % G;
-  const size_t fpitch = (size_t)kFftH * M * 2 * C;  // from ky to ky + 1
+  float* o = V + ((size_t)fft_f0(kx) * M + m0 + m) * 2 * (size_t)C + (c / G) * 2 * G + c % G;
+  const size_t fpitch = (size_t)fft_fstep(kx) * M * 2 * C;  // from ky to ky + 1
+  const int nky = fft_nky(kx);
 #pragma unroll
   for (int ky = 0; ky < kFftN; ++ky) {
-    __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
-    __builtin_nontemporal_store(oim[ky], o + ky * fpitch + G);
+    if (ky < nky) {
+      __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
+      __builtin_nontemporal_store(oim[ky], o + ky * fpitch + G);
+    }
   }
 }
 
@@ -110,11 +142,10 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
-  const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)kx * M + m0 + m) * (size_t)C + c;
-  const size_t fpitch = (size_t)kFftH * M * C;
+  const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m0 + m) * (size_t)C + c;
+  const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
   float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
-#pragma unroll
-  for (int ky = 0; ky < kFftN; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
+  fft_load_column(p, fpitch, fft_edge(kx), re, im);
   fft48(im, re, oim, ore);  // inverse: real and imaginary parts swapped in and out (1 / 48^2 is in the filter spectra)
   const size_t pitch = (size_t)TX * kFftH * 2 * C;
   if (FULL) {
@@ -315,12 +346,15 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     fft48(re, im, ore, oim);
     // [Re x 16 | Im x 16] per channel group: the block's 128 bytes of a (frequency, tile) row are one run.  (Measured against
     // interleaved complex with 8-byte stores: 1.18 vs 1.42 ms; the inverse prefers 8-byte loads of interleaved complex.)
-    float* o = V + ((size_t)kx * M + m) * 2 * (size_t)C + grp * 2 * kFusCh + cl;
-    const size_t fpitch = (size_t)kFftH * M * 2 * C;
+    float* o = V + ((size_t)fft_f0(kx) * M + m) * 2 * (size_t)C + grp * 2 * kFusCh + cl;
+    const size_t fpitch = (size_t)fft_fstep(kx) * M * 2 * C;
+    const int nky = fft_nky(kx);
 #pragma unroll
     for (int ky = 0; ky < kFftN; ++ky) {
-      __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
-      __builtin_nontemporal_store(oim[ky], o + ky * fpitch + kFusCh);
+      if (ky < nky) {
+        __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
+        __builtin_nontemporal_store(oim[ky], o + ky * fpitch + kFusCh);
+      }
     }
   }
 }
@@ -347,11 +381,10 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   const int c = grp * CH + cl;
   if (threadIdx.x < kFftH * CH) {
     const int kx = threadIdx.x / CH;
-    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)kx * M + m) * (size_t)C + c;
-    const size_t fpitch = (size_t)kFftH * M * C;
+    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m) * (size_t)C + c;
+    const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
-#pragma unroll
-    for (int ky = 0; ky < kFftN; ++ky) fft_ldg2(p + ky * fpitch, re[ky], im[ky]);
+    fft_load_column(p, fpitch, fft_edge(kx), re, im);
     fft48(im, re, oim, ore);
     float* q = lds + kx * kPitch + cl;
 #pragma unroll
@@ -438,10 +471,10 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   }
 }
 
-// Filter spectra for the batched GEMM: bank (Cout, Cin, 5, 5) -> B (1200, 2 Cin, 2 Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
+// Filter spectra for the batched GEMM: bank (Cout, Cin, 5, 5) -> B (F, 2 Cin, 2 Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
 // Br + i Bi = conj(FFT48x48(filter))[ky][kx] / 48^2 = sum_{u,v} w[u][v] (cos t + i sin t) / 2304, t = 2 pi (ky u + kx v) / 48.
 // Rows follow the rows of V ([Re x G | Im x G] per group of G input channels), columns the rows of Mo (interleaved complex).
-// One thread per (ci, co) keeps its 25 taps in registers and walks the 1200 frequencies (fp64 accumulation, twiddles from a
+// One thread per (ci, co) keeps its 25 taps in registers and walks the frequencies (fp64 accumulation, twiddles from a
 // 48-entry table): 0.3 ms for 256 x 256 filters, against 13.6 ms for the same through torch.fft + concatenations -- cheap
 // enough to run every training step.
 // `sgn` = +1: the correlation form above (forward pass); -1: FFT(filter) itself, for the convolution of the input gradient.
@@ -466,7 +499,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
   float2* o1 = reinterpret_cast<float2*>(B + (size_t)r1 * 2 * Cout) + co;
   constexpr double inv = 1.0 / (kFftN * kFftN);
   // separable: S_u(kx) = sum_v w[u][v] e^{i t kx v} once per kx, then sum_u e^{i t ky u} S_u for the 48 ky
-  // (25 x (50 + 48 x 20) multiply-adds per filter instead of 1200 x 50, and a fifth of the table look-ups)
+  // (25 x (50 + 48 x 20) multiply-adds per filter instead of 1200 x 50 in the direct form, and a fifth of the table look-ups)
   for (int kx = 0; kx < kFftH; ++kx) {
     double sr[5], si[5];
 #pragma unroll
@@ -480,7 +513,8 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
         si[u] += w[u * 5 + v] * tw_s[t];
       }
     }
-    for (int ky = 0; ky < kFftN; ++ky) {
+    const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
+    for (int ky = 0; ky < nky; ++ky) {
       double br = 0.0, bi = 0.0;
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
@@ -490,7 +524,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
         bi += c * si[u] + sn * sr[u];
       }
       const float fr = (float)(br * inv), fi = sgn * (float)(bi * inv);
-      const size_t f = (size_t)(ky * kFftH + kx) * (fstride / 2);  // in float2
+      const size_t f = (size_t)(f0 + ky * fstep) * (fstride / 2);  // in float2
       o0[f] = make_float2(fr, fi);
       o1[f] = make_float2(-fi, fr);
     }
@@ -500,8 +534,8 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
 // Filter gradient in the frequency domain (training).  With G = the spectra of the output-gradient tiles (44 x 44, zero-padded
 // to 48: eqa_fft48k5_grad_transform) and V those of the input tiles, D[f] = V[f]^T . G[f] (real form, one batched GEMM over
 // the tiles) holds  Dr = D[re ci][re co] + D[im ci][im co],  Di = D[im ci][re co] - D[re ci][im co]  of  X_f^T conj(G_f), and
-//   dW[co][ci][u][v] = 1/48^2 sum_f wgt(kx) (cos t Dr - sin t Di),  t = 2 pi (ky u + kx v) / 48,
-// wgt = 2 for the frequencies whose conjugate partner is not stored (0 < kx < 24), else 1 -- the correlation theorem; no
+//   dW[co][ci][u][v] = 1/48^2 sum_f wgt(f) (cos t Dr - sin t Di),  t = 2 pi (ky u + kx v) / 48,
+// wgt = 2 for the stored frequencies whose conjugate partner is not stored, 1 for the self-conjugate ones -- the correlation theorem; no
 // wrap-around because a 44-wide gradient tile shifted by up to 4 stays inside the 48-wide input tile.
 __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float* __restrict__ D, float* __restrict__ dbank, int Cout,
                                                                     int Cin, int Gin, int Gout) {
@@ -523,12 +557,15 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
   for (int i = 0; i < 25; ++i) acc[i] = 0.0;
   // separable, like the spectra kernel: A_u(kx) = sum_ky e^{i t ky u} D(ky, kx), then dW[u][v] += Re(e^{i t kx v} A_u(kx))
   for (int kx = 0; kx < kFftH; ++kx) {
-    const double wgt = (kx == 0 || kx == kFftH - 1) ? 1.0 : 2.0;
+    const bool edge = fft_edge(kx);
+    const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
     double ar[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, ai[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int ky = 0; ky < kFftN; ++ky) {
-      const float* d = D + (size_t)(ky * kFftH + kx) * fstride;
-      const double dr = (double)d[r0 * ld + c0] + (double)d[r1 * ld + c1];
-      const double di = (double)d[r1 * ld + c0] - (double)d[r0 * ld + c1];
+    for (int ky = 0; ky < nky; ++ky) {
+      const float* d = D + (size_t)(f0 + ky * fstep) * fstride;
+      // weight 2 for every stored frequency whose conjugate partner is not stored; 1 for the four self-conjugate ones
+      const double wgt = (edge && (ky == 0 || ky == kFftH - 1)) ? 1.0 : 2.0;
+      const double dr = wgt * ((double)d[r0 * ld + c0] + (double)d[r1 * ld + c1]);
+      const double di = wgt * ((double)d[r1 * ld + c0] - (double)d[r0 * ld + c1]);
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
         const int t = (ky * u) % kFftN;
@@ -542,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
 #pragma unroll
       for (int v = 0; v < 5; ++v) {
         const int t = (kx * v) % kFftN;
-        acc[u * 5 + v] += wgt * (tw_c[t] * ar[u] - tw_s[t] * ai[u]);
+        acc[u * 5 + v] += tw_c[t] * ar[u] - tw_s[t] * ai[u];
       }
   }
   constexpr double inv = 1.0 / (kFftN * kFftN);
@@ -612,6 +649,8 @@ int eqa_fft48k5_group(int C, int side) {
   if (C <= 0 || (side != 0 && side != 1)) return EQA_ERR_INVALID_ARG;
   return side == 0 ? fft_group_in(C) : 1;
 }
+
+int eqa_fft48k5_frequencies(void) { return kFftF; }
 
 int64_t eqa_fft48k5_tiles(int n) { return n <= 4 ? 0 : (n - 4 + kFftO - 1) / kFftO; }
 

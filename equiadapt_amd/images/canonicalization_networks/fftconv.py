@@ -16,11 +16,22 @@ from equiadapt_amd import _lib
 from equiadapt_amd.ops import _timed
 
 N, NH, OUT = 48, 25, 44
+F = N * (NH - 2) + 2 * NH     # 1154 stored frequencies: the conjugate-redundant half of the kx = 0 / 24 columns is dropped
 ENABLED = os.environ.get("EQA_CONV5_FFT", "1") != "0"
-# The filter spectra (1200 x 2Cin x 2Cout floats: 1.26 GB at 256 channels) are streamed once per call, the Winograd filters are
+# The filter spectra (1154 x 2Cin x 2Cout floats: 1.21 GB at 256 channels) are streamed once per call, the Winograd filters are
 # 17 MB: below ~32 tiles (8 images of 92 x 92) the Winograd path is faster (measured: B=4 0.29 vs 0.37 ms, B=8 0.48 vs 0.46 ms).
 MIN_TILES = int(os.environ.get("EQA_FFT_MIN_TILES", "32"))
 TRAIN_FORWARD = os.environ.get("EQA_FFT_TRAIN", "1") != "0"     # forward pass of winograd.Conv5x5Function through this path
+
+
+def freq_index():
+    """(ky, kx) of stored frequency f, in the kernels' order: f = 23 ky + kx - 1 for 0 < kx < 24 (all 48 ky), then
+    1104 + 2 ky + (kx == 24) for the edge columns, ky <= 24."""
+    ky = torch.arange(N).repeat_interleave(NH - 2)
+    kx = torch.arange(1, NH - 1).repeat(N)
+    eky = torch.arange(NH).repeat_interleave(2)
+    ekx = torch.tensor([0, NH - 1]).repeat(NH)
+    return torch.cat([ky, eky]), torch.cat([kx, ekx])
 
 
 def tiles(n: int) -> int:
@@ -55,12 +66,12 @@ def group_sizes(cin: int, cout: int):
 
 
 def filter_spectra(bank: torch.Tensor, groups=None, correlate: bool = True) -> torch.Tensor:
-    """(Cout, Cin, 5, 5) -> B:(1200, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency.  Rows
+    """(Cout, Cin, 5, 5) -> B:(F, 2 Cin, 2 Cout) fp32, the real form of conj(FFT(filter)) / 48^2 per frequency.  Rows
     follow the rows of V, columns the rows of Mo (``group_sizes``; ``groups`` = (Cin, Cout) gives the plain [Re | Im] order)."""
     Cout, Cin = bank.shape[:2]
     if groups is None and bank.is_cuda and bank.dtype == torch.float32:
         lib = _lib.load()                                         # on the device: one kernel (eqa_fft48k5_filter_spectra)
-        B = torch.empty((N * NH, 2 * Cin, 2 * Cout), dtype=torch.float32, device=bank.device)
+        B = torch.empty((F, 2 * Cin, 2 * Cout), dtype=torch.float32, device=bank.device)
         with torch.cuda.device(bank.device):
             _lib.check(lib.eqa_fft48k5_filter_spectra(bank.contiguous().data_ptr(), B.data_ptr(), Cout, Cin, int(correlate),
                                                       torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_filter_spectra")
@@ -70,8 +81,10 @@ def filter_spectra(bank: torch.Tensor, groups=None, correlate: bool = True) -> t
     wp = torch.zeros(Cout, Cin, N, N, dtype=torch.float64, device=bank.device)
     wp[:, :, :5, :5] = bank.double()
     W = torch.fft.rfft2(wp).conj() / float(N * N)                # (Cout, Cin, 48, 25)
-    Wr = W.real.permute(2, 3, 1, 0).reshape(N * NH, Cin, Cout)
-    Wi = W.imag.permute(2, 3, 1, 0).reshape(N * NH, Cin, Cout)
+    ky, kx = freq_index()
+    W = W[:, :, ky.to(W.device), kx.to(W.device)]                # (Cout, Cin, F)
+    Wr = W.real.permute(2, 1, 0).contiguous()
+    Wi = W.imag.permute(2, 1, 0).contiguous()
     top = torch.cat([Wr, Wi], dim=2)                              # rows Re(A): [ Br |  Bi ]
     bot = torch.cat([-Wi, Wr], dim=2)                             # rows Im(A): [-Bi |  Br ]
     full = torch.cat([top, bot], dim=1)                           # rows [Re ci | Im ci], columns [Re co | Im co]
@@ -89,14 +102,14 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     lib = _lib.load()
     nimg, Cin, H, W = x.shape
     Cout = B.shape[2] // 2
-    assert B.shape == (N * NH, 2 * Cin, 2 * Cout)
+    assert B.shape == (F, 2 * Cin, 2 * Cout)
     OH, OW = H - 4, W - 4
     TY, TX = tiles(H), tiles(W)
     M = nimg * TY * TX
     dev = x.device
     st = torch.cuda.current_stream().cuda_stream
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
-    V = torch.empty((N * NH, M, 2 * Cin), dtype=torch.float32, device=dev)
+    V = torch.empty((F, M, 2 * Cin), dtype=torch.float32, device=dev)
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     p_bias = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(dev):
@@ -134,13 +147,13 @@ def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int, G: Optional[torch.T
     nimg, Cout, OH, OW = dy.shape
     dev = dy.device
     M = V.shape[1]
-    assert V.shape == (N * NH, M, 2 * cin) and M == nimg * tiles(OH + 4) * tiles(OW + 4)
+    assert V.shape == (F, M, 2 * cin) and M == nimg * tiles(OH + 4) * tiles(OW + 4)
     st = torch.cuda.current_stream().cuda_stream
     if G is None:
         G = grad_spectra(dy)
     dbank = torch.empty((Cout, cin, 5, 5), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        D = torch.bmm(V.transpose(1, 2), G)                       # (1200, 2 Cin, 2 Cout)
+        D = torch.bmm(V.transpose(1, 2), G)                       # (F, 2 Cin, 2 Cout)
         _lib.check(lib.eqa_fft48k5_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, st), "eqa_fft48k5_filter_grad")
     return dbank
 
@@ -155,25 +168,25 @@ def input_grad(dy: torch.Tensor, bank: torch.Tensor, G: Optional[torch.Tensor] =
     dev = dy.device
     if G is None:
         G = grad_spectra(dy)
-    B2 = filter_spectra(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)      # (1200, 2 Cout, 2 Cin)
+    B2 = filter_spectra(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)      # (F, 2 Cout, 2 Cin)
     st = torch.cuda.current_stream().cuda_stream
     H, W = OH + 4, OW + 4
     dx = torch.empty((nimg, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     with torch.cuda.device(dev):
-        Cg = torch.bmm(G, B2)                                     # (1200, M, 2 Cin)
+        Cg = torch.bmm(G, B2)                                     # (F, M, 2 Cin)
         T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, N * tiles(H), OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
         _lib.check(lib.eqa_fft48k5_input_grad(Cg.data_ptr(), T2.data_ptr(), dx.data_ptr(), nimg, H, W, Cin, st), "eqa_fft48k5_input_grad")
     return dx
 
 
 def grad_spectra(dy: torch.Tensor) -> torch.Tensor:
-    """Spectra of the disjoint 44 x 44 tiles of an output gradient (channels-last), (1200, M, 2 Cout): shared by the filter
+    """Spectra of the disjoint 44 x 44 tiles of an output gradient (channels-last), (F, M, 2 Cout): shared by the filter
     gradient and the input gradient."""
     lib = _lib.load()
     nimg, Cout, OH, OW = dy.shape
     M = nimg * tiles(OH + 4) * tiles(OW + 4)
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dy.device)
-    G = torch.empty((N * NH, M, 2 * Cout), dtype=torch.float32, device=dy.device)
+    G = torch.empty((F, M, 2 * Cout), dtype=torch.float32, device=dy.device)
     with torch.cuda.device(dy.device):
         _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout,
                                                   torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_grad_transform")

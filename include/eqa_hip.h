@@ -295,22 +295,25 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
 
 /*
  * I2a, the same 5x5 stride-1 group convolutions (escnn_networks.py:67-91) as an overlap-save FFT convolution: 48x48 real
- * FFT tiles give 44x44 outputs each (tiles per axis: eqa_fft48k5_tiles(n) = ceil((n-4)/44)), 48 x 25 complex frequencies
- * f = ky*25 + kx; 2.5 real multiplies per output where the tiles fit (Winograd F(4x4,5x5): 4).  Channels-last, fp32.
- *   eqa_fft48k5_input   x:(nimg,H,W,C) -> V:(1200, M, 2C), M = nimg*TY*TX tiles, V[f][m] = the tile's spectrum over the C
+ * FFT tiles give 44x44 outputs each (tiles per axis: eqa_fft48k5_tiles(n) = ceil((n-4)/44)).  Of the 48 x 25 complex
+ * frequencies (ky, kx <= 24) of a real tile, F = eqa_fft48k5_frequencies() = 1154 are stored: f = 23 ky + kx - 1 for 0 < kx < 24,
+ * then 1104 + 2 ky + (kx == 24) for kx in {0, 24} and ky <= 24 (the rest of those two columns are conjugates).  2.4 real
+ * multiplies per output where the tiles fit (Winograd F(4x4,5x5): 4).  Channels-last, fp32.
+ *   eqa_fft48k5_input   x:(nimg,H,W,C) -> V:(F, M, 2C), M = nimg*TY*TX tiles, V[f][m] = the tile's spectrum over the C
  *                       channels, [Re x G | Im x G] per group of G = eqa_fft48k5_group(C, 0) channels (16, or 1 = interleaved); d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c] applied while loading.
  *                       T: workspace of eqa_fft48k5_workspace_bytes(nimg, H, W - 4, C) bytes (the two passes run on chunks
  *                       of images whose intermediate stays cache-resident).
  *   [ batched fp32 GEMM by the caller: Mo[f] = V[f] (M x 2Cin) . B[f] (2Cin x 2Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
  *     Br + i Bi = conj(FFT48x48(filter[co][ci]))[ky][kx] / 2304, rows ordered like the rows of V, columns like the rows of
  *     Mo: complex numbers with re and im interleaved (group size eqa_fft48k5_group(Cout, 1) = 1) ]
- *   eqa_fft48k5_output  Mo:(1200, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of
+ *   eqa_fft48k5_output  Mo:(F, M, 2C) -> y:(nimg,OH,OW,C) = [relu](ifft + bias); T2: workspace of
  *                       eqa_fft48k5_workspace_bytes(nimg, OH, OW, C) bytes.
  *   eqa_fft48k5_output_sums  ... -> S:(nimg,C,k_next,k_next) fp64, the window sums of eqa_window_sums_nhwc of that output
  *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
-/* bank:(Cout,Cin,5,5) -> B:(1200, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step);
+int eqa_fft48k5_frequencies(void);
+/* bank:(Cout,Cin,5,5) -> B:(F, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step);
  * correlate = 0: FFT(filter)/2304 instead of its conjugate (a convolution: the input gradient, with bank = the filters with
  * their channel axes swapped, (Cin,Cout,5,5)) */
 int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, int correlate, void* stream);
@@ -321,14 +324,14 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
 /* Training, filter gradient in the frequency domain (the reference gets it from autograd through R2Conv's conv2d):
- *   eqa_fft48k5_grad_transform  dy:(nimg,OH,OW,C) -> G:(1200, M, 2C): spectra of the DISJOINT 44 x 44 output-gradient tiles,
+ *   eqa_fft48k5_grad_transform  dy:(nimg,OH,OW,C) -> G:(F, M, 2C): spectra of the DISJOINT 44 x 44 output-gradient tiles,
  *                               zero-padded to 48 x 48, same row layout as V; T: eqa_fft48k5_workspace_bytes(nimg, OH, OW, C).
  *   [ batched GEMM by the caller: D[f] = V[f]^T (2Cin x M) . G[f] (M x 2Cout), V from eqa_fft48k5_input of the layer's input ]
- *   eqa_fft48k5_filter_grad     D:(1200, 2Cin, 2Cout) -> dbank:(Cout,Cin,5,5) = d loss / d filter (fp64 accumulation).
+ *   eqa_fft48k5_filter_grad     D:(F, 2Cin, 2Cout) -> dbank:(Cout,Cin,5,5) = d loss / d filter (fp64 accumulation).
  */
 int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream);
 int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream);
-/* Training, input gradient: Cg:(1200, M, 2C) = G[f] . B2[f] (B2 = eqa_fft48k5_filter_spectra of the channel-swapped bank with
+/* Training, input gradient: Cg:(F, M, 2C) = G[f] . B2[f] (B2 = eqa_fft48k5_filter_spectra of the channel-swapped bank with
  * correlate = 0) -> dx:(nimg,H,W,C), H = OH + 4: every 44 x 44 gradient tile yields a 48 x 48 block, blocks overlap by 4 and are
  * added in a fixed order.  T2: eqa_fft48k5_workspace_bytes(nimg, 48*TY, OW, C) bytes. */
 int eqa_fft48k5_input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, void* stream);

@@ -243,11 +243,18 @@ def test_fft_filter_spectra_real_form_reproduces_conv2d():
     B, Cin, Cout = 2, 3, 5
     x = torch.randn(B, Cin, 48, 48, dtype=torch.float64)
     w = torch.randn(Cout, Cin, 5, 5, dtype=torch.float64)
-    Bm = fftconv.filter_spectra(w.float(), groups=(Cin, Cout)).double()     # (1200, 2 Cin, 2 Cout), plain [Re | Im] order
+    Bm = fftconv.filter_spectra(w.float(), groups=(Cin, Cout)).double()     # (F, 2 Cin, 2 Cout), plain [Re | Im] order
     X = torch.fft.rfft2(x)                                                  # (B, Cin, 48, 25)
-    V = torch.cat([X.real, X.imag], dim=1).permute(2, 3, 0, 1).reshape(1200, B, 2 * Cin)
-    Mo = torch.bmm(V, Bm)                                                   # (1200, B, 2 Cout)
-    Y = torch.complex(Mo[..., :Cout], Mo[..., Cout:]).reshape(48, 25, B, Cout).permute(2, 3, 0, 1)
+    ky, kx = fftconv.freq_index()                                           # the F = 1154 stored frequencies, kernels' order
+    assert len(ky) == fftconv.F == 1154
+    Xs = X[:, :, ky, kx]                                                    # (B, Cin, F)
+    V = torch.cat([Xs.real, Xs.imag], dim=1).permute(2, 0, 1).contiguous()  # (F, B, 2 Cin)
+    Mo = torch.bmm(V, Bm)                                                   # (F, B, 2 Cout)
+    Ys = torch.complex(Mo[..., :Cout], Mo[..., Cout:]).permute(1, 2, 0)     # (B, Cout, F)
+    Y = torch.zeros(B, Cout, 48, 25, dtype=torch.complex128)
+    Y[:, :, ky, kx] = Ys
+    for col in (0, 24):                                                     # the dropped halves of the two edge columns
+        Y[:, :, 25:, col] = Y[:, :, 1:24, col].flip(2).conj()
     y = torch.fft.irfft2(Y, s=(48, 48)) * (48 * 48)                         # the spectra carry 1/48^2; irfft2 divides again
     want = F.conv2d(x, w)
     assert (y[:, :, :44, :44] - want).abs().max().item() <= 1e-5 * want.abs().max().item()
@@ -258,7 +265,7 @@ def test_fft_filter_spectra_real_form_reproduces_conv2d():
     assert fftconv._order(3, 1).tolist() == [0, 3, 1, 4, 2, 5]                      # re/im interleaved: the kernels' layout
     wq = torch.randn(4, 3, 5, 5)
     Bi, Bp = fftconv.filter_spectra(wq, groups=(1, 1)), fftconv.filter_spectra(wq, groups=(3, 4))
-    assert Bi.shape == (1200, 6, 8) and torch.equal(Bi, Bp[:, fftconv._order(3, 1)][:, :, fftconv._order(4, 1)])
+    assert Bi.shape == (fftconv.F, 6, 8) and torch.equal(Bi, Bp[:, fftconv._order(3, 1)][:, :, fftconv._order(4, 1)])
     assert fftconv.group_sizes(256, 256) == (16, 1) and fftconv.group_sizes(12, 8) == (1, 1)
 
 
@@ -271,6 +278,7 @@ def test_fft_group_rule_matches_the_library():
     lib = _lib.load()
     for c in (4, 12, 16, 64, 250, 256):
         assert (lib.eqa_fft48k5_group(c, 0), lib.eqa_fft48k5_group(c, 1)) == fftconv.group_sizes(c, c)
+    assert lib.eqa_fft48k5_frequencies() == fftconv.F
 
 
 def test_generated_fft48_is_current_and_correct():

@@ -1010,7 +1010,7 @@ def test_fft48_convolution_matches_conv2d(dev):
         w = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cin ** 0.5)
         b, ib = torch.randn(Cout, device=dev), torch.randn(Cin, device=dev)
         Bm = fftconv.filter_spectra(w)
-        assert Bm.shape == (1200, 2 * Cin, 2 * Cout)
+        assert Bm.shape == (fftconv.F, 2 * Cin, 2 * Cout) and fftconv.F == 1154
         for (relu, in_relu) in [(False, False), (True, True)]:
             xin = torch.relu(x.double() + ib.double()[None, :, None, None]) if in_relu else x.double()
             want = F.conv2d(xin, w.double(), b.double())
@@ -1071,7 +1071,7 @@ def test_fft_filter_spectra_kernel_matches_host_construction(dev):
         w = torch.randn(Cout, Cin, 5, 5, device=dev)
         got = fftconv.filter_spectra(w)
         want = fftconv.filter_spectra(w, groups=fftconv.group_sizes(Cin, Cout))      # host path (explicit groups)
-        assert got.shape == want.shape == (1200, 2 * Cin, 2 * Cout)
+        assert got.shape == want.shape == (fftconv.F, 2 * Cin, 2 * Cout)
         assert (got - want).abs().max().item() <= 2e-7 * want.abs().max().item() + 1e-12, (Cout, Cin)
 
 

@@ -16,8 +16,8 @@ B = 256
 alg = {  # algorithmic bytes per launch, fp32
     "winograd_k5_input_kernel": B * 92 * 92 * 256 * 4 + B * 484 * 64 * 256 * 4,
     "winograd_k5_output_sums_kernel": B * 484 * 64 * 256 * 4,
-    "fft48_fwd_fused_kernel": B * 92 * 92 * 256 * 4 + 1200 * B * 4 * 512 * 4,
-    "fft48_inv_fused_kernel": 1200 * B * 4 * 512 * 4 + B * 10 * 2 * 256 * 9 * 4,
+    "fft48_fwd_fused_kernel": B * 92 * 92 * 256 * 4 + 1154 * B * 4 * 512 * 4,
+    "fft48_inv_fused_kernel": 1154 * B * 4 * 512 * 4 + B * 10 * 2 * 256 * 9 * 4,
     "lift_conv_mfma_kernel": B * 96 * 96 * 3 * 4 + B * 92 * 92 * 256 * 4,
     "crop_resize_aa_kernel": B * 3 * 180 * 180 * 4 + B * 3 * 96 * 96 * 4,
     "window_sums_nhwc_finalize_kernel": B * 10 * 2 * 256 * 9 * 4 + B * 256 * 25 * 8,  # 8 border rows + 2 tile rows, x 2 tile columns

@@ -91,16 +91,16 @@ def fft():
     OH = H - 4
     M = n * 4
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, H, OH, C), 4) // 4, device=dev)
-    V = torch.empty(1200, M, 2 * C, device=dev)
+    V = torch.empty(fftconv.F, M, 2 * C, device=dev)
     spectra = V.numel() * 4 / 1e9
     ms = timeit(lambda: _lib.check(lib.eqa_fft48k5_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), bias.data_ptr(), 1, n, H, H, C, st), "in"), 10)
     print(f"fft forward transform   {ms*1e3:8.1f} us  {(x.numel()*4/1e9 + spectra)/ms*1e3:7.0f} GB/s  (read {x.numel()*4/1e9:.2f} GB + write {spectra:.2f} GB)")
     ms = timeit(lambda: fftconv.filter_spectra(w), 5)
     print(f"filter spectra          {ms*1e3:8.1f} us")
     B = fftconv.filter_spectra(w)
-    Mo = torch.empty(1200, M, 2 * C, device=dev)
+    Mo = torch.empty(fftconv.F, M, 2 * C, device=dev)
     ms = timeit(lambda: torch.bmm(V, B, out=Mo), 10)
-    print(f"batched GEMM            {ms*1e3:8.1f} us  {2*1200*M*512*512/ms/1e9:7.1f} TFLOP/s")
+    print(f"batched GEMM            {ms*1e3:8.1f} us  {2*fftconv.F*M*512*512/ms/1e9:7.1f} TFLOP/s")
     T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, OH, OH, C), 4) // 4, device=dev)
     S = torch.empty(n, C, 5, 5, dtype=torch.float64, device=dev)
     ws = torch.empty(n * OH * 2 * C * 9, device=dev)
