@@ -362,11 +362,24 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
 // The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
 // as interleaved complex with 8-byte loads (128 bytes per (frequency, tile) row and block).  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
 // row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
+#ifdef EQA_FFT_CLOCK
+// Debug build: shader-cycle stamps of one block of the fused inverse (thread 0, a column-role thread): [0] loads issued and
+// returned, [1] column transform + LDS writes, [2] wait at the barrier, [3] row transform + epilogue, [4] window-sum pieces.
+__device__ unsigned long long g_fft_clock[8];
+#define FFT_CLOCK_BEGIN() const bool clk_on = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0; unsigned long long clk_t = __builtin_readcyclecounter()
+#define FFT_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (clk_on) g_fft_clock[i] = n_ - clk_t; clk_t = n_; } while (0)
+#define FFT_CLOCK_LOADS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FFT_CLOCK(0); } while (0)
+#else
+#define FFT_CLOCK_BEGIN() do { } while (0)
+#define FFT_CLOCK(i) do { } while (0)
+#define FFT_CLOCK_LOADS() do { } while (0)
+#endif
 template <int NB, int CH>
 __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                       int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
                                                                       int TX, size_t M, unsigned nwork) {
   extern __shared__ float lds[];
+  FFT_CLOCK_BEGIN();
   constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
   const unsigned bid = blockIdx.x;
   const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
@@ -385,6 +398,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
     const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
     fft_load_column(p, fpitch, fft_edge(kx), re, im);
+    FFT_CLOCK_LOADS();
     fft48(im, re, oim, ore);
     float* q = lds + kx * kPitch + cl;
 #pragma unroll
@@ -393,7 +407,9 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       q[(i * 2 + 1) * CH] = oim[i];
     }
   }
+  FFT_CLOCK(1);
   __syncthreads();
+  FFT_CLOCK(2);
   const int y = threadIdx.x / CH;
   const int gy = kFftO * ty + y;
   const bool valid = y < kFftO && gy < OH;
@@ -443,6 +459,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       }
     }
   }
+  FFT_CLOCK(3);
   if (NB > 0) {
     // Window-sum pieces.  Segments (the order window_sums_nhwc_finalize_kernel expects): the NB top rows, the NB bottom rows,
     // then ONE per tile row for its interior rows -- those are only ever needed as a sum, which the block forms here in a
@@ -469,6 +486,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       out[(((img * nseg + 2 * NB + ty) * TX + tx) * (size_t)C + c) * NV + i] = t;
     }
   }
+  FFT_CLOCK(4);
 }
 
 // Filter spectra for the batched GEMM: bank (Cout, Cin, 5, 5) -> B (F, 2 Cin, 2 Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
@@ -644,6 +662,9 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
 }
 
 extern "C" {
+#ifdef EQA_FFT_CLOCK
+int eqa_debug_fft_clock(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fft_clock), sizeof(g_fft_clock)) == hipSuccess ? 0 : -1; }
+#endif
 
 int eqa_fft48k5_group(int C, int side) {
   if (C <= 0 || (side != 0 && side != 1)) return EQA_ERR_INVALID_ARG;
