@@ -68,6 +68,7 @@ SIGNATURES = {
     "eqa_winograd_f2k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_winograd_f4k5_output_sums": (_int, [_vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_tiles": (ctypes.c_int64, [_int]),
+    "eqa_fft48k5_tile_pitch": (ctypes.c_int64, [ctypes.c_int64]),
     "eqa_fft48k5_frequencies": (_int, []),
     "eqa_fft48k5_filter_spectra": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "eqa_fft48k5_input_grad": (_int, [_vp, _vp, _vp] + [_int] * 4 + [_vp]),

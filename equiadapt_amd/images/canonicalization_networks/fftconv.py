@@ -92,6 +92,14 @@ def filter_spectra(bank: torch.Tensor, groups=None, correlate: bool = True) -> t
     return full.float().contiguous()
 
 
+def spectra_buffer(M: int, width: int, device) -> torch.Tensor:
+    """(F, M, width) fp32 view of a buffer with eqa_fft48k5_tile_pitch(M) = M | 1 rows per frequency -- the layout every
+    eqa_fft48k5_* entry point reads and writes (an even tile count such as 1024 would put all the frequencies of a tile
+    into the same HBM channel).  The batched GEMMs run on the view; the padding row is never touched."""
+    pitch = _lib.load().eqa_fft48k5_tile_pitch(M)
+    return torch.empty((F, pitch, width), dtype=torch.float32, device=device)[:, :M]
+
+
 def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
             in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0,
             keep_V: Optional[list] = None) -> torch.Tensor:
@@ -109,7 +117,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     dev = x.device
     st = torch.cuda.current_stream().cuda_stream
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
-    V = torch.empty((F, M, 2 * Cin), dtype=torch.float32, device=dev)
+    V = spectra_buffer(M, 2 * Cin, dev)
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     p_bias = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(dev):
@@ -118,7 +126,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
                        "eqa_fft48k5_input")
         del T
         with _timed("fft_gemm"):
-            Mo = torch.bmm(V, B)
+            Mo = torch.bmm(V, B, out=spectra_buffer(M, 2 * Cout, dev))
         if keep_V is not None:
             keep_V.append(V)
         del V
@@ -173,7 +181,7 @@ def input_grad(dy: torch.Tensor, bank: torch.Tensor, G: Optional[torch.Tensor] =
     H, W = OH + 4, OW + 4
     dx = torch.empty((nimg, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     with torch.cuda.device(dev):
-        Cg = torch.bmm(G, B2)                                     # (F, M, 2 Cin)
+        Cg = torch.bmm(G, B2, out=spectra_buffer(G.shape[1], 2 * Cin, dev))       # (F, M, 2 Cin)
         T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, N * tiles(H), OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
         _lib.check(lib.eqa_fft48k5_input_grad(Cg.data_ptr(), T2.data_ptr(), dx.data_ptr(), nimg, H, W, Cin, st), "eqa_fft48k5_input_grad")
     return dx
@@ -186,7 +194,7 @@ def grad_spectra(dy: torch.Tensor) -> torch.Tensor:
     nimg, Cout, OH, OW = dy.shape
     M = nimg * tiles(OH + 4) * tiles(OW + 4)
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, OH, OW, Cout), 4) // 4, dtype=torch.float32, device=dy.device)
-    G = torch.empty((F, M, 2 * Cout), dtype=torch.float32, device=dy.device)
+    G = spectra_buffer(M, 2 * Cout, dy.device)
     with torch.cuda.device(dy.device):
         _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout,
                                                   torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_grad_transform")

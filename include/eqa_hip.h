@@ -312,6 +312,10 @@ int eqa_winograd_f4k5_output_sums(const float* M, const float* bias, int relu, d
  *                       (k_next in {3,5}); workspace: nimg*OH*TX*C*(2*k_next-1) floats, TX = ceil(OW/44).
  */
 int64_t eqa_fft48k5_tiles(int n);
+/* Rows per stored frequency of every spectra buffer (V, Mo and the gradient-side G, Cg): tiles | 1.  "(F, M, 2C)" above
+ * means M used rows at this pitch; the batched GEMMs take the pitch as their batch stride.  (An even tile count such as 1024
+ * x 256 channels puts the frequencies of a tile exactly 2 MB apart, all in one HBM channel: 1.23 -> 1.01 ms for the inverse.) */
+int64_t eqa_fft48k5_tile_pitch(int64_t tiles);
 int eqa_fft48k5_frequencies(void);
 /* bank:(Cout,Cin,5,5) -> B:(F, 2Cin, 2Cout) as described above (fp64 accumulation; cheap enough to run per training step);
  * correlate = 0: FFT(filter)/2304 instead of its conjugate (a convolution: the input gradient, with bank = the filters with

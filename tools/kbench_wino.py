@@ -83,7 +83,7 @@ def fft():
     from equiadapt_amd.images.canonicalization_networks import fftconv
     lib = _lib.load()
     dev = torch.device("cuda:0")
-    n, C, H = 256, 256, 92
+    n, C, H = int(os.environ.get("KB_N", 256)), 256, 92
     x = torch.randn(n, C, H, H, device=dev).contiguous(memory_format=torch.channels_last)
     w = torch.randn(C, C, 5, 5, device=dev) / 80
     bias = torch.randn(C, device=dev)
@@ -91,14 +91,14 @@ def fft():
     OH = H - 4
     M = n * 4
     T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, H, OH, C), 4) // 4, device=dev)
-    V = torch.empty(fftconv.F, M, 2 * C, device=dev)
+    V = fftconv.spectra_buffer(M, 2 * C, dev)
     spectra = V.numel() * 4 / 1e9
     ms = timeit(lambda: _lib.check(lib.eqa_fft48k5_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), bias.data_ptr(), 1, n, H, H, C, st), "in"), 10)
     print(f"fft forward transform   {ms*1e3:8.1f} us  {(x.numel()*4/1e9 + spectra)/ms*1e3:7.0f} GB/s  (read {x.numel()*4/1e9:.2f} GB + write {spectra:.2f} GB)")
     ms = timeit(lambda: fftconv.filter_spectra(w), 5)
     print(f"filter spectra          {ms*1e3:8.1f} us")
     B = fftconv.filter_spectra(w)
-    Mo = torch.empty(fftconv.F, M, 2 * C, device=dev)
+    Mo = fftconv.spectra_buffer(M, 2 * C, dev)
     ms = timeit(lambda: torch.bmm(V, B, out=Mo), 10)
     print(f"batched GEMM            {ms*1e3:8.1f} us  {2*fftconv.F*M*512*512/ms/1e9:7.1f} TFLOP/s")
     T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(n, OH, OH, C), 4) // 4, device=dev)

@@ -19,7 +19,8 @@ B = fftconv.filter_spectra(w)
 raw = ctypes.CDLL(_lib.SO_PATH)
 if not hasattr(raw, "eqa_debug_fft_clock"):
     sys.exit("this library was built without -DEQA_FFT_CLOCK")
-names = ["loads issued and returned", "column transform + LDS writes", "wait at the barrier", "row transform + epilogue",
+pipe = os.environ.get("EQA_FFT_INV_PIPE") is not None
+names = ["wait for both register sets", "column pass 0", "issue + column pass 1 + issue", "barrier", "3 row passes", "pieces + barrier"] if pipe else ["loads issued and returned", "column transform + LDS writes", "wait at the barrier", "row transform + epilogue",
          "window-sum pieces (2 barriers)"]
 out = (ctypes.c_ulonglong * 8)()
 for rep in range(3):
@@ -27,5 +28,6 @@ for rep in range(3):
         fftconv.conv5x5(x, B, b, True, b, True, sums_k=5)
     torch.cuda.synchronize()
     assert raw.eqa_debug_fft_clock(out) == 0
-    tot = sum(out[:5])
-    print(" | ".join(f"{n}: {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, out[:5])), f"| total {tot} cycles")
+    n = len(names)
+    tot = sum(out[:n])
+    print(" | ".join(f"{n}: {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, out[:n])), f"| total {tot} cycles")
