@@ -364,6 +364,41 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
   }
 }
 
+// Window-sum pieces of one output row of a tile: [sum of the 44 columns, the NB leftmost columns of the map, the NB
+// rightmost].  The leftmost columns live in tile column 0 at j = 0..NB-1.  The rightmost start at j = a (uniform, any
+// value): they are pulled out of the register array by a shift network on the bits of a -- 81 selects on 6 scalar
+// conditions instead of a compare-and-add per column and border (352).
+template <int NB>
+__device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], float b, int relu, int ncols, bool first_col, int a,
+                                               float (&acc)[1 + 2 * NB]) {
+  constexpr int PAD = NB - 1, EXT = 64 + NB;
+  float w[EXT];
+#pragma unroll
+  for (int i = 0; i < EXT; ++i) w[i] = 0.0f;
+  float total = 0.0f;
+#pragma unroll
+  for (int j = 0; j < kFftO; ++j) {
+    float v = ore[j] + b;
+    v = relu ? fmaxf(v, 0.0f) : v;
+    v = j < ncols ? v : 0.0f;
+    total += v;
+    w[PAD + j] = v;
+  }
+  acc[0] = total;
+#pragma unroll
+  for (int q = 0; q < NB; ++q) acc[1 + q] = first_col ? w[PAD + q] : 0.0f;
+  const int ap = a + PAD;  // offset into w of the first wanted column
+  const bool any = ap >= 0 && ap < kFftO + PAD;
+#pragma unroll
+  for (int bit = 32; bit >= 1; bit >>= 1) {
+    const bool on = (ap & bit) != 0;
+#pragma unroll
+    for (int i = 0; i < bit + NB - 1; ++i) w[i] = on ? w[i + bit] : w[i];
+  }
+#pragma unroll
+  for (int q = 0; q < NB; ++q) acc[1 + NB + q] = any ? w[q] : 0.0f;
+}
+
 // The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
 // as interleaved complex with 8-byte loads (128 bytes per (frequency, tile) row and block).  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
 // row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
@@ -439,7 +474,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
     const float b = bias ? bias[c] : 0.0f;
     const int x0 = kFftO * tx;
     const int ncols = min(kFftO, OW - x0);  // uniform
-    if (NB == 0) {
+    if constexpr (NB == 0) {
       float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
 #pragma unroll
       for (int j = 0; j < kFftO; ++j) {
@@ -449,19 +484,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
         }
       }
     } else {
-#pragma unroll
-      for (int j = 0; j < kFftO; ++j) {
-        float v = ore[j] + b;
-        v = relu ? fmaxf(v, 0.0f) : v;
-        v = j < ncols ? v : 0.0f;
-        acc[0] += v;
-        const int xx = x0 + j;  // uniform
-#pragma unroll
-        for (int qn = 0; qn < NB; ++qn) {
-          if (xx == qn) acc[1 + qn] += v;
-          if (xx == OW - NB + qn) acc[1 + NB + qn] += v;
-        }
-      }
+      fft_row_pieces<NB>(ore, b, relu, ncols, tx == 0, OW - NB - x0, acc);
     }
   }
   FFT_CLOCK(3);
