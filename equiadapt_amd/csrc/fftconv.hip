@@ -294,6 +294,20 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
 // 768 threads: phase 1, thread (y, c) transforms row y; phase 2, thread (kx, c), 400 of them, transforms column kx.
 // A wave reads 4 pixels x 16 channels = 4 runs of 64 bytes; the 16 channel groups of a tile are dealt to the same XCD so
 // that the other halves of the 128-byte lines come out of its L2.
+#ifdef EQA_FFT_CLOCK
+// Debug build: shader-cycle stamps of one block of the fused inverse (thread 0, a column-role thread): [0] loads issued and
+// returned, [1] column transform + LDS writes, [2] wait at the barrier, [3] row transform + epilogue, [4] window-sum pieces.
+__device__ unsigned long long g_fft_clock[16];  // [0..4] inverse, [8..12] forward
+#define FFT_CLOCK_BEGIN() const bool clk_on = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0; unsigned long long clk_t = __builtin_readcyclecounter()
+#define FFT_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (clk_on) g_fft_clock[i] = n_ - clk_t; clk_t = n_; } while (0)
+#define FFT_CLOCK_LOADS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FFT_CLOCK(0); } while (0)
+#define FFT_CLOCK_USE(v, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(v) : "memory"); FFT_CLOCK(i); } while (0)
+#else
+#define FFT_CLOCK_BEGIN() do { } while (0)
+#define FFT_CLOCK(i) do { } while (0)
+#define FFT_CLOCK_LOADS() do { } while (0)
+#define FFT_CLOCK_USE(v, i) do { } while (0)
+#endif
 constexpr int kFusCh = 16;
 constexpr int kFusThreads = kFftN * kFusCh;                       // 768
 constexpr int kFusKxPitch = kFftN * 2 * kFusCh + kFusCh;          // floats per kx slab (+16: slabs start 16 banks apart)
@@ -303,6 +317,7 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
                                                                       const float* __restrict__ in_bias, int in_relu, int H, int W,
                                                                       int C, int TY, int TX, size_t M, unsigned nwork, int win) {
   extern __shared__ float lds[];
+  FFT_CLOCK_BEGIN();  // forward stamps: [8] loads, [9] row transform + LDS writes, [10] barrier, [11] LDS reads + column transform, [12] stores issued
   // XCD-aware order: consecutive work items (the channel groups of one tile) on one XCD
   const unsigned bid = blockIdx.x;
   const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
@@ -330,6 +345,7 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
       re[j] = (row_in && j < nvalid) ? v : 0.0f;
       im[j] = 0.0f;
     }
+    FFT_CLOCK_USE(re[0], 8);
     fft48(re, im, ore, oim);
     float* o = lds + (y * 2) * kFusCh + cl;
 #pragma unroll
@@ -338,7 +354,9 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
       o[k * kFusKxPitch + kFusCh] = oim[k];
     }
   }
+  FFT_CLOCK(9);
   __syncthreads();
+  FFT_CLOCK(10);
   if (threadIdx.x < kFftH * kFusCh) {
     const int kx = threadIdx.x / kFusCh;
     const float* q = lds + kx * kFusKxPitch + cl;
@@ -354,6 +372,7 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     float* o = V + ((size_t)fft_f0(kx) * M + m) * 2 * (size_t)C + grp * 2 * kFusCh + cl;
     const size_t fpitch = (size_t)fft_fstep(kx) * M * 2 * C;
     const int nky = fft_nky(kx);
+    FFT_CLOCK_USE(ore[0], 11);
 #pragma unroll
     for (int ky = 0; ky < kFftN; ++ky) {
       if (ky < nky) {
@@ -362,6 +381,7 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
       }
     }
   }
+  FFT_CLOCK(12);
 }
 
 // Window-sum pieces of one output row of a tile: [sum of the 44 columns, the NB leftmost columns of the map, the NB
@@ -402,18 +422,6 @@ __device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], float 
 // The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
 // as interleaved complex with 8-byte loads (128 bytes per (frequency, tile) row and block).  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
 // row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
-#ifdef EQA_FFT_CLOCK
-// Debug build: shader-cycle stamps of one block of the fused inverse (thread 0, a column-role thread): [0] loads issued and
-// returned, [1] column transform + LDS writes, [2] wait at the barrier, [3] row transform + epilogue, [4] window-sum pieces.
-__device__ unsigned long long g_fft_clock[8];
-#define FFT_CLOCK_BEGIN() const bool clk_on = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0; unsigned long long clk_t = __builtin_readcyclecounter()
-#define FFT_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (clk_on) g_fft_clock[i] = n_ - clk_t; clk_t = n_; } while (0)
-#define FFT_CLOCK_LOADS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FFT_CLOCK(0); } while (0)
-#else
-#define FFT_CLOCK_BEGIN() do { } while (0)
-#define FFT_CLOCK(i) do { } while (0)
-#define FFT_CLOCK_LOADS() do { } while (0)
-#endif
 template <int NB, int CH>
 __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                       int relu, float* __restrict__ out, int OH, int OW, int C, int TY,

@@ -3,8 +3,9 @@
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DEQA_FFT_CLOCK equiadapt_amd/csrc/*.hip -o build_variants/libeqa_fftclock.so
   EQA_LIB=$PWD/build_variants/libeqa_fftclock.so python tools/probe_fft_clock.py
 
-Thread 0 of the middle block of the grid (a column-role thread) stamps: the loads (issued and returned), the column
-transform with its LDS writes, the wait at the barrier, the row transform with the epilogue, the window-sum pieces.
+Thread 0 of the middle block of the grid stamps the phases of the fused inverse (loads issued and returned, column
+transform with its LDS writes, wait at the barrier, row transform with the epilogue, window-sum pieces) and of the fused
+forward transform (loads, row transform + LDS writes, barrier, LDS reads + column transform, stores issued).
 Numbers: DESIGN.md section 3.4 (the inverse kernel) and section 6.
 """
 import ctypes, os, sys, torch
@@ -19,10 +20,9 @@ B = fftconv.filter_spectra(w)
 raw = ctypes.CDLL(_lib.SO_PATH)
 if not hasattr(raw, "eqa_debug_fft_clock"):
     sys.exit("this library was built without -DEQA_FFT_CLOCK")
-pipe = os.environ.get("EQA_FFT_INV_PIPE") is not None
-names = ["wait for both register sets", "column pass 0", "issue + column pass 1 + issue", "barrier", "3 row passes", "pieces + barrier"] if pipe else ["loads issued and returned", "column transform + LDS writes", "wait at the barrier", "row transform + epilogue",
+names = ["loads issued and returned", "column transform + LDS writes", "wait at the barrier", "row transform + epilogue",
          "window-sum pieces (2 barriers)"]
-out = (ctypes.c_ulonglong * 8)()
+out = (ctypes.c_ulonglong * 16)()
 for rep in range(3):
     for _ in range(5):
         fftconv.conv5x5(x, B, b, True, b, True, sums_k=5)
@@ -30,4 +30,7 @@ for rep in range(3):
     assert raw.eqa_debug_fft_clock(out) == 0
     n = len(names)
     tot = sum(out[:n])
-    print(" | ".join(f"{n}: {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, out[:n])), f"| total {tot} cycles")
+    print("inverse: " + " | ".join(f"{n}: {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, out[:n])), f"| total {tot} cycles")
+    fn = ["loads issued and returned", "row transform + LDS writes", "wait at the barrier", "LDS reads + column transform", "stores issued"]
+    ft = sum(out[8:13])
+    print("forward: " + " | ".join(f"{n}: {v} ({100 * v / ft:.0f} %)" for n, v in zip(fn, out[8:13])), f"| total {ft} cycles")
