@@ -42,9 +42,9 @@ class _InnerBatchNorm(nn.BatchNorm3d):
 
 class LiftConvFunction(torch.autograd.Function):
     """Training counterpart of the lifting convolution in `_forward_inference`: forward on the fp32-MFMA kernel
-    (`eqa_lift_conv_nhwc`, 0.71 ms at the headline shape; the framework's convolution: 1.5 ms), filter gradient through the
-    framework's convolution-weight-gradient (the input image needs no gradient in the canonicalizer; if asked for, it is
-    the framework's too)."""
+    (`eqa_lift_conv_nhwc`, 0.71 ms at the headline shape; the framework's convolution: 1.5 ms), filter gradient on the
+    matrix cores too (`eqa_lift_conv_wgrad_nhwc`; other shapes: the framework's convolution-weight-gradient).  The input image
+    needs no gradient in the canonicalizer; if asked for, it is the framework's."""
 
     @staticmethod
     def forward(ctx, x, bank):
@@ -57,7 +57,13 @@ class LiftConvFunction(torch.autograd.Function):
         x, bank = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.nn.grad.conv2d_input(x.shape, bank, dy) if ctx.needs_input_grad[0] else None
-        dbank = torch.nn.grad.conv2d_weight(x, bank.shape, dy) if ctx.needs_input_grad[1] else None
+        dbank = None
+        if ctx.needs_input_grad[1]:
+            kh, kw = bank.shape[-2], bank.shape[-1]
+            if ops.lift_conv_wgrad_supported(x, bank.shape[0], kh, kw):
+                dbank = ops.lift_conv_wgrad_nhwc(x, dy, kh, kw)            # fp32 MFMA, 0.8 ms where MIOpen's solvers take 3.1
+            else:
+                dbank = torch.nn.grad.conv2d_weight(x, bank.shape, dy)
         return dx, dbank
 
 

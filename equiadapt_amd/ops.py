@@ -440,6 +440,31 @@ def lift_conv_nhwc(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def lift_conv_wgrad_supported(x: torch.Tensor, cout: int, kh: int, kw: int) -> bool:
+    """Shapes eqa_lift_conv_wgrad_nhwc takes (others: the framework's convolution-weight-gradient)."""
+    B, Cin, H, W = x.shape
+    return bool(_lib.load().eqa_lift_conv_wgrad_supported(B, H, W, Cin, cout, kh, kw))
+
+
+def lift_conv_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
+    """d loss / d filters (Cout, Cin, kh, kw) of y = conv2d(x, w) from channels-last x (B,Cin,H,W) and dy (B,Cout,H-kh+1,W-kw+1)
+    on the fp32 MFMA, deterministic (eqa_lift_conv_wgrad_nhwc)."""
+    lib = _lib.load()
+    for t, name in ((x, "x"), (dy, "dy")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError(f"lift_conv_wgrad_nhwc expects a channels-last fp32 tensor on the device for {name}")
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != (B, Cout, H - kh + 1, W - kw + 1):
+        raise RuntimeError("lift_conv_wgrad_nhwc: dy does not match x and the kernel size")
+    ws = torch.empty(max(lib.eqa_lift_conv_wgrad_workspace_bytes(B, H, W, Cin, Cout, kh, kw), 16) // 4, dtype=torch.float32, device=x.device)
+    dbank = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_lift_conv_wgrad_nhwc(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dbank.data_ptr(), B, H, W, Cin, Cout, kh, kw, _stream())
+    _lib.check(st, "eqa_lift_conv_wgrad_nhwc")
+    return dbank
+
+
 def image_action_nearest(x: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor],
                          pad: int, out_hw: Tuple[int, int], top_left: Tuple[int, int], n_planes: int, src_mod: int) -> torch.Tensor:
     """fp32 planes (P,H,W) -> (n_planes, OH, OW): nearest-neighbour action with edge pad + crop (eqa_image_action_nearest)."""

@@ -256,6 +256,18 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
                        int Cin, int KH, int KW, int Cout, void* stream);
 
 /*
+ * Training: filter gradient of the same lifting convolution (the reference: autograd through e2cnn's R2Conv,
+ * escnn_networks.py:48-66).  dbank:(Cout,Cin,KH,KW) = sum over (n,oy,ox) of dy[n][oy][ox][co] * x[n][oy+ky][ox+kx][ci], both
+ * channels-last; fp32 MFMA (v_mfma_f32_16x16x4_f32), per-wave partials added in a fixed order (deterministic).
+ * eqa_lift_conv_wgrad_supported: KH*KW*Cin <= 80, Cout % 256 == 0, (W-KW+1) / 4 in {7,11,15,23,31} exactly, KH*W*Cin <= 2048.
+ * workspace: eqa_lift_conv_wgrad_workspace_bytes(...) bytes, 16-byte aligned; dy 16-byte aligned.
+ */
+int eqa_lift_conv_wgrad_supported(int nimg, int H, int W, int Cin, int Cout, int KH, int KW);
+int64_t eqa_lift_conv_wgrad_workspace_bytes(int nimg, int H, int W, int Cin, int Cout, int KH, int KW);
+int eqa_lift_conv_wgrad_nhwc(const float* x, const float* dy, void* workspace, float* dbank, int nimg, int H, int W, int Cin,
+                             int Cout, int KH, int KW, void* stream);
+
+/*
  * I2a, 5x5 stride-1 group convolutions in inference (escnn_networks.py:67-91), Winograd F(m x m, 5x5), channels-last.
  * f2k5: m = 2 (6x6 input tiles, 36 planes); f4k5: m = 4 (8x8 input tiles, 64 planes).  N = m + 4, P = N*N:
  *   eqa_winograd_f{m}k5_input   x:(nimg,H,W,C) -> V:(nimg*TY*TX, P, C), TY = (H-4)/m, TX = (W-4)/m   (B^T d B), with

@@ -522,3 +522,30 @@ def test_fft_input_gradient_matches_conv2d_input(dev, monkeypatch):
         assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert (got.double() - want).abs().max().item() <= 5e-6 * want.abs().max().item(), (B, Cin, Cout, H, W)
         assert torch.equal(got, fftconv.input_grad(dy, w))
+
+
+def test_lift_conv_weight_gradient_matches_conv2d_weight(dev):
+    """eqa_lift_conv_wgrad_nhwc (fp32 MFMA, per-wave partials added in a fixed order) vs the fp64 convolution-weight-gradient:
+    the headline shape (96 -> 92, 3 -> 256 channels), the other k-step counts the kernel is instantiated for, two channel
+    blocks, a 3x3 filter; refusal of shapes outside its envelope; bit-identical repeats.  Tolerance 2e-5 of max|dW|."""
+    from equiadapt_amd import ops
+
+    torch.manual_seed(75)
+    cases = [(3, 3, 96, 96, 256, 5, 5), (2, 3, 32, 32, 256, 5, 5), (1, 3, 40, 48, 512, 5, 5), (2, 2, 33, 64, 256, 5, 5), (1, 3, 20, 128, 256, 5, 5),
+             (2, 3, 30, 30, 256, 3, 3), (1, 1, 12, 96, 256, 5, 5)]
+    for (B, Cin, H, W, Cout, kh, kw) in cases:
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        dy = torch.randn(B, Cout, H - kh + 1, W - kw + 1, device=dev).contiguous(memory_format=torch.channels_last)
+        assert ops.lift_conv_wgrad_supported(x, Cout, kh, kw), (B, Cin, H, W, Cout, kh, kw)
+        got = ops.lift_conv_wgrad_nhwc(x, dy, kh, kw)
+        want = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, kh, kw), dy.double())
+        assert got.shape == want.shape
+        err = (got.double() - want).abs().max().item()
+        assert err <= 2e-5 * want.abs().max().item(), (B, Cin, H, W, Cout, kh, kw, err)
+        assert torch.equal(got, ops.lift_conv_wgrad_nhwc(x, dy, kh, kw))
+    x = torch.randn(2, 3, 96, 96, device=dev).contiguous(memory_format=torch.channels_last)
+    assert not ops.lift_conv_wgrad_supported(x, 64, 5, 5)          # channel count not a multiple of 256
+    assert not ops.lift_conv_wgrad_supported(x[:, :, :, :95], 256, 5, 5)   # output width not a multiple of 4
+    assert not ops.lift_conv_wgrad_supported(x, 256, 7, 7)         # 147 taps
+    with pytest.raises(Exception):
+        ops.lift_conv_wgrad_nhwc(x, torch.zeros(2, 64, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 5, 5)
