@@ -46,8 +46,8 @@ SIGNATURES = {
     "eqa_bn_partial_blocks": (ctypes.c_int64, [ctypes.c_int64]),
     "eqa_bn_stats_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_bn_relu_dropout_nhwc": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_float, ctypes.c_uint32, _vp]),
-    "eqa_bn_bwd_reduce_nhwc": (_int, [_vp] * 5 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
-    "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_bn_bwd_reduce_nhwc": (_int, [_vp] * 5 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_uint32, _vp]),
+    "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_uint32, _vp]),
     "eqa_vn_blocks": (_int, [_int]),
     "eqa_vn_knn": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "eqa_vn_convpos_stats": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp]),

@@ -73,11 +73,25 @@ __global__ __launch_bounds__(kThreads) void bn_relu_dropout_nhwc_kernel(const fl
   }
 }
 
+// "Kept and positive" of one channel quad, recomputed exactly as bn_relu_dropout_nhwc_kernel decided it (same expression for
+// the pre-activation, same hash): lets the backward passes skip reading y (one 8.67 MB map per image less in each).
+__device__ __forceinline__ void bn_live_quad(const float4& v, const float4& sc, const float4& sh, size_t i, uint32_t drop_threshold,
+                                             uint32_t seed, bool (&live)[4]) {
+  const float o[4] = {fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
+                      fmaxf(v.w * sc.w + sh.w, 0.f)};
+  const uint32_t base = mix32((uint32_t)i * 0x9E3779B1u + seed) ^ (uint32_t)(i >> 32);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) live[k] = o[k] > 0.f && (!drop_threshold || mix32(base + (uint32_t)k * 0x632BE5ABu) >= drop_threshold);
+}
+
 // g = gy * (y > 0 ? inv_keep : 0)  (gradient at the batch-norm output);  partial sums of g and g * xhat per channel
+template <bool RECOMPUTE>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, float inv_keep,
-                                                                     double* __restrict__ partial, size_t npix, int C) {
+                                                                     double* __restrict__ partial, size_t npix, int C,
+                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                     uint32_t drop_threshold, uint32_t seed) {
   __shared__ float4 s_red[2][kThreads];
   const int Q = C >> 2;
   const int lanes = min(Q, kThreads);
@@ -91,10 +105,18 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
     if (r0 < rows) {
       for (size_t p = p0 + r0; p < p1; p += rows) {
         const size_t i = p * Q + q;
-        const float4 g4 = reinterpret_cast<const float4*>(gy)[i], y4 = reinterpret_cast<const float4*>(y)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
         const float4 x4 = reinterpret_cast<const float4*>(x)[i];
-        const float g0 = y4.x > 0.f ? g4.x * inv_keep : 0.f, g1 = y4.y > 0.f ? g4.y * inv_keep : 0.f;
-        const float g2 = y4.z > 0.f ? g4.z * inv_keep : 0.f, g3 = y4.w > 0.f ? g4.w * inv_keep : 0.f;
+        bool live[4];
+        if (RECOMPUTE) {
+          bn_live_quad(x4, reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q], i, drop_threshold, seed,
+                       live);
+        } else {
+          const float4 y4 = reinterpret_cast<const float4*>(y)[i];
+          live[0] = y4.x > 0.f; live[1] = y4.y > 0.f; live[2] = y4.z > 0.f; live[3] = y4.w > 0.f;
+        }
+        const float g0 = live[0] ? g4.x * inv_keep : 0.f, g1 = live[1] ? g4.y * inv_keep : 0.f;
+        const float g2 = live[2] ? g4.z * inv_keep : 0.f, g3 = live[3] ? g4.w * inv_keep : 0.f;
         s.x += g0; s.y += g1; s.z += g2; s.w += g3;
         sx.x += g0 * (x4.x - mu.x) * rs.x; sx.y += g1 * (x4.y - mu.y) * rs.y;
         sx.z += g2 * (x4.z - mu.z) * rs.z; sx.w += g3 * (x4.w - mu.w) * rs.w;
@@ -119,28 +141,41 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
 // dx = a[c] * (g - b[c] - xhat * d[c]),  xhat = (x - mean[c]) * rstd[c],  g as above.
 // (a = gamma * rstd, b = sum(g) / n, d = sum(g xhat) / n per FIELD, expanded to channels by the caller; with running
 // statistics -- eval mode under autograd -- b = d = 0.)
+template <bool RECOMPUTE>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_nhwc_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                     const float* __restrict__ x, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ a,
                                                                     const float* __restrict__ b, const float* __restrict__ d,
-                                                                    float inv_keep, float* __restrict__ dx, size_t nquad, int Q) {
+                                                                    float inv_keep, float* __restrict__ dx, size_t nquad, int Q,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    uint32_t drop_threshold, uint32_t seed) {
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
     const int q = (int)(i % Q);
-    const float4 g4 = reinterpret_cast<const float4*>(gy)[i], y4 = reinterpret_cast<const float4*>(y)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
     const float4 x4 = reinterpret_cast<const float4*>(x)[i];
+    bool live[4];
+    if (RECOMPUTE) {
+      bn_live_quad(x4, reinterpret_cast<const float4*>(scale)[q], reinterpret_cast<const float4*>(shift)[q], i, drop_threshold, seed, live);
+    } else {
+      const float4 y4 = reinterpret_cast<const float4*>(y)[i];
+      live[0] = y4.x > 0.f; live[1] = y4.y > 0.f; live[2] = y4.z > 0.f; live[3] = y4.w > 0.f;
+    }
     const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
     const float4 a4 = reinterpret_cast<const float4*>(a)[q], b4 = reinterpret_cast<const float4*>(b)[q];
     const float4 d4 = reinterpret_cast<const float4*>(d)[q];
     float4 o;
-    o.x = a4.x * ((y4.x > 0.f ? g4.x * inv_keep : 0.f) - b4.x - (x4.x - mu.x) * rs.x * d4.x);
-    o.y = a4.y * ((y4.y > 0.f ? g4.y * inv_keep : 0.f) - b4.y - (x4.y - mu.y) * rs.y * d4.y);
-    o.z = a4.z * ((y4.z > 0.f ? g4.z * inv_keep : 0.f) - b4.z - (x4.z - mu.z) * rs.z * d4.z);
-    o.w = a4.w * ((y4.w > 0.f ? g4.w * inv_keep : 0.f) - b4.w - (x4.w - mu.w) * rs.w * d4.w);
+    o.x = a4.x * ((live[0] ? g4.x * inv_keep : 0.f) - b4.x - (x4.x - mu.x) * rs.x * d4.x);
+    o.y = a4.y * ((live[1] ? g4.y * inv_keep : 0.f) - b4.y - (x4.y - mu.y) * rs.y * d4.y);
+    o.z = a4.z * ((live[2] ? g4.z * inv_keep : 0.f) - b4.z - (x4.z - mu.z) * rs.z * d4.z);
+    o.w = a4.w * ((live[3] ? g4.w * inv_keep : 0.f) - b4.w - (x4.w - mu.w) * rs.w * d4.w);
     reinterpret_cast<float4*>(dx)[i] = o;
   }
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+inline uint32_t drop_threshold(float drop_p) {
+  return drop_p > 0.0f ? (uint32_t)std::min<double>((double)drop_p * 4294967296.0, 4294967295.0) : 0u;
+}
 inline unsigned stream_blocks(size_t nquad) { return (unsigned)std::min<size_t>((nquad + kThreads - 1) / kThreads, 256 * 32); }
 
 }  // namespace
@@ -166,34 +201,49 @@ int eqa_bn_relu_dropout_nhwc(const float* x, const float* scale, const float* sh
   if (!x || !scale || !shift || !y) return EQA_ERR_INVALID_ARG;
   if ((C & 3) || !aligned16(x) || !aligned16(y) || !aligned16(scale) || !aligned16(shift)) return EQA_ERR_UNSUPPORTED;
   const size_t nquad = (size_t)n_pixels * (C >> 2);
-  const uint32_t thr = drop_p > 0.0f ? (uint32_t)std::min<double>((double)drop_p * 4294967296.0, 4294967295.0) : 0u;
+  const uint32_t thr = drop_threshold(drop_p);
   hipLaunchKernelGGL(bn_relu_dropout_nhwc_kernel, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, x, scale, shift,
                      y, nquad, C >> 2, thr, 1.0f / (1.0f - drop_p), seed);
   return launch_status();
 }
 
 int eqa_bn_bwd_reduce_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, float drop_p,
-                           double* partial, int64_t n_pixels, int C, void* stream) {
+                           double* partial, int64_t n_pixels, int C, const float* scale, const float* shift, uint32_t seed,
+                           void* stream) {
   if (n_pixels < 0 || C <= 0 || !(drop_p >= 0.0f && drop_p < 1.0f)) return EQA_ERR_INVALID_ARG;
   if (n_pixels == 0) return EQA_OK;
-  if (!gy || !y || !x || !mean || !rstd || !partial) return EQA_ERR_INVALID_ARG;
-  if ((C & 3) || !aligned16(gy) || !aligned16(y) || !aligned16(x) || !aligned16(mean) || !aligned16(rstd)) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(bn_bwd_reduce_nhwc_kernel, dim3((unsigned)eqa_bn_partial_blocks(n_pixels)), dim3(kThreads), 0, (hipStream_t)stream,
-                     gy, y, x, mean, rstd, 1.0f / (1.0f - drop_p), partial, (size_t)n_pixels, C);
+  if (!gy || !x || !mean || !rstd || !partial || (!y && (!scale || !shift))) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || !aligned16(gy) || !aligned16(y) || !aligned16(x) || !aligned16(mean) || !aligned16(rstd) || !aligned16(scale) ||
+      !aligned16(shift))
+    return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)eqa_bn_partial_blocks(n_pixels));
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  if (y)
+    hipLaunchKernelGGL(bn_bwd_reduce_nhwc_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean, rstd, inv_keep,
+                       partial, (size_t)n_pixels, C, scale, shift, 0u, seed);
+  else
+    hipLaunchKernelGGL(bn_bwd_reduce_nhwc_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean, rstd, inv_keep,
+                       partial, (size_t)n_pixels, C, scale, shift, drop_threshold(drop_p), seed);
   return launch_status();
 }
 
 int eqa_bn_bwd_apply_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, const float* a,
-                          const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, void* stream) {
+                          const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, const float* scale,
+                          const float* shift, uint32_t seed, void* stream) {
   if (n_pixels < 0 || C <= 0 || !(drop_p >= 0.0f && drop_p < 1.0f)) return EQA_ERR_INVALID_ARG;
   if (n_pixels == 0) return EQA_OK;
-  if (!gy || !y || !x || !mean || !rstd || !a || !b || !d || !dx) return EQA_ERR_INVALID_ARG;
+  if (!gy || !x || !mean || !rstd || !a || !b || !d || !dx || (!y && (!scale || !shift))) return EQA_ERR_INVALID_ARG;
   if ((C & 3) || !aligned16(gy) || !aligned16(y) || !aligned16(x) || !aligned16(dx) || !aligned16(mean) || !aligned16(rstd) ||
-      !aligned16(a) || !aligned16(b) || !aligned16(d))
+      !aligned16(a) || !aligned16(b) || !aligned16(d) || !aligned16(scale) || !aligned16(shift))
     return EQA_ERR_UNSUPPORTED;
   const size_t nquad = (size_t)n_pixels * (C >> 2);
-  hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean, rstd,
-                     a, b, d, 1.0f / (1.0f - drop_p), dx, nquad, C >> 2);
+  const float inv_keep = 1.0f / (1.0f - drop_p);
+  if (y)
+    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel<false>, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean,
+                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, 0u, seed);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel<true>, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean,
+                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, drop_threshold(drop_p), seed);
   return launch_status();
 }
 

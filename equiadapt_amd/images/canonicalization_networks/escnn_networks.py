@@ -72,7 +72,8 @@ class InnerBnReluDropout(torch.autograd.Function):
     kernels of csrc/batchnorm.hip (eqa_bn_*).  Statistics per field over (batch, group, space) in fp64; running statistics
     updated like nn.BatchNorm3d (momentum, unbiased variance).  The preceding convolution's bias only shifts the mean (it
     cancels in the normalised output), so it enters the running mean and nowhere else.  The dropout mask is a hash of a
-    seed drawn from torch's CPU generator; the backward recovers "kept and positive" from y > 0."""
+    seed drawn from torch's CPU generator; the backward recomputes "kept and positive" from h, the affine map and that seed
+    instead of reading y (one map less per pass)."""
 
     @staticmethod
     def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training):
@@ -107,8 +108,9 @@ class InnerBnReluDropout(torch.autograd.Function):
             y = torch.empty_like(h)
             _lib.check(lib.eqa_bn_relu_dropout_nhwc(h.data_ptr(), scale.data_ptr(), shift.data_ptr(), y.data_ptr(), npix, C, p_eff,
                                                     seed, st), "eqa_bn_relu_dropout_nhwc")
-        ctx.save_for_backward(h, y, weight, mean.repeat_interleave(E).contiguous(), rstd.repeat_interleave(E).contiguous())
-        ctx.E, ctx.p, ctx.batch_stats = E, p_eff, bool(bn.training or bn.running_mean is None)
+        # y is not kept for the backward: "kept and positive" is recomputed from h, scale, shift and the seed
+        ctx.save_for_backward(h, weight, mean.repeat_interleave(E).contiguous(), rstd.repeat_interleave(E).contiguous(), scale, shift)
+        ctx.E, ctx.p, ctx.seed, ctx.batch_stats = E, p_eff, seed, bool(bn.training or bn.running_mean is None)
         return y
 
     @staticmethod
@@ -116,7 +118,7 @@ class InnerBnReluDropout(torch.autograd.Function):
         from equiadapt_amd import _lib, ops
 
         lib = _lib.load()
-        h, y, weight, mean_c, rstd_c = ctx.saved_tensors
+        h, weight, mean_c, rstd_c, scale, shift = ctx.saved_tensors
         E = ctx.E
         Bn, C, H, W = h.shape
         Fd = C // E
@@ -126,8 +128,9 @@ class InnerBnReluDropout(torch.autograd.Function):
         with torch.cuda.device(h.device):
             nblk = lib.eqa_bn_partial_blocks(npix)
             part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
-            _lib.check(lib.eqa_bn_bwd_reduce_nhwc(gy.data_ptr(), y.data_ptr(), h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(), ctx.p,
-                                                  part.data_ptr(), npix, C, st), "eqa_bn_bwd_reduce_nhwc")
+            _lib.check(lib.eqa_bn_bwd_reduce_nhwc(gy.data_ptr(), None, h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(), ctx.p,
+                                                  part.data_ptr(), npix, C, scale.data_ptr(), shift.data_ptr(), ctx.seed, st),
+                       "eqa_bn_bwd_reduce_nhwc")
             sums = part.sum(0).view(Fd, E, 2).sum(1)                             # per field: sum g, sum g*xhat
             dbias, dweight = sums[:, 0].float(), sums[:, 1].float()
             n = npix * E
@@ -139,9 +142,9 @@ class InnerBnReluDropout(torch.autograd.Function):
                 b = torch.zeros(C, device=h.device)
                 d = b
             dh = torch.empty_like(h)
-            _lib.check(lib.eqa_bn_bwd_apply_nhwc(gy.data_ptr(), y.data_ptr(), h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(),
-                                                 a.data_ptr(), b.data_ptr(), d.data_ptr(), ctx.p, dh.data_ptr(), npix, C, st),
-                       "eqa_bn_bwd_apply_nhwc")
+            _lib.check(lib.eqa_bn_bwd_apply_nhwc(gy.data_ptr(), None, h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(),
+                                                 a.data_ptr(), b.data_ptr(), d.data_ptr(), ctx.p, dh.data_ptr(), npix, C,
+                                                 scale.data_ptr(), shift.data_ptr(), ctx.seed, st), "eqa_bn_bwd_apply_nhwc")
         return dh, dweight, dbias, None, None, None, None, None
 
 

@@ -224,15 +224,19 @@ int eqa_window_sums_bwd_expand_nhwc(const float* table, float* dx, int B, int H,
  *   eqa_bn_bwd_reduce_nhwc    with g = gy * (y > 0 ? 1/(1-drop_p) : 0) and xhat = (x - mean[c]) * rstd[c]:
  *                             partial[...] = sum g, sum g*xhat (same layout as above);
  *   eqa_bn_bwd_apply_nhwc     dx = a[c] * (g - b[c] - xhat * d[c])   (a = gamma*rstd, b = sum g / n, d = sum g xhat / n).
+ *   In both backward passes y may be NULL: "kept and positive" is then recomputed from x, scale, shift and the seed exactly as
+ *   the forward pass decided it, and the pass reads one map less (scale / shift / seed are ignored when y is given).
  */
 int64_t eqa_bn_partial_blocks(int64_t n_pixels);
 int eqa_bn_stats_nhwc(const float* x, double* partial, int64_t n_pixels, int C, void* stream);
 int eqa_bn_relu_dropout_nhwc(const float* x, const float* scale, const float* shift, float* y, int64_t n_pixels, int C,
                              float drop_p, uint32_t seed, void* stream);
 int eqa_bn_bwd_reduce_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, float drop_p,
-                           double* partial, int64_t n_pixels, int C, void* stream);
+                           double* partial, int64_t n_pixels, int C, const float* scale, const float* shift, uint32_t seed,
+                           void* stream);
 int eqa_bn_bwd_apply_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, const float* a,
-                          const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, void* stream);
+                          const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, const float* scale,
+                          const float* shift, uint32_t seed, void* stream);
 
 /*
  * The GEMV after the window sums (last convolution + mean over channels and positions, escnn_networks.py:115,

@@ -307,6 +307,30 @@ def test_fused_bn_relu_dropout_block(dev):
     g, = torch.autograd.grad(ya.sum(), big)
     g0, = torch.autograd.grad((y0 * kept * 2.0).sum(), big)      # same function with the mask written out
     assert torch.allclose(g, g0, atol=1e-4 * g0.abs().max().item())
+    # the backward passes with y given and with "kept and positive" recomputed (y = NULL) are bit-identical
+    from equiadapt_amd import _lib, ops
+    lib = _lib.load()
+    C, npix = Fd * E, 16 * 32 * 32
+    xh = big.detach()
+    scale = (torch.rand(C, device=dev) + 0.5) * torch.where(torch.arange(C, device=dev) % 3 == 0, -1.0, 1.0)
+    shift, mean, rstd = torch.randn(C, device=dev) * 0.3, torch.randn(C, device=dev) * 0.1, torch.rand(C, device=dev) + 0.5
+    a, b, d = torch.randn(C, device=dev), torch.randn(C, device=dev), torch.randn(C, device=dev)
+    gy = torch.randn_like(xh)
+    st = ops._stream()
+    for p_drop, seed in ((0.5, 1234567), (0.0, 0), (0.25, 7)):
+        yy = torch.empty_like(xh)
+        _lib.check(lib.eqa_bn_relu_dropout_nhwc(xh.data_ptr(), scale.data_ptr(), shift.data_ptr(), yy.data_ptr(), npix, C, p_drop, seed, st), "fwd")
+        nblk = lib.eqa_bn_partial_blocks(npix)
+        outs = []
+        for yptr in (yy.data_ptr(), None):
+            part = torch.zeros((nblk, C, 2), dtype=torch.float64, device=dev)
+            dx = torch.empty_like(xh)
+            _lib.check(lib.eqa_bn_bwd_reduce_nhwc(gy.data_ptr(), yptr, xh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_drop, part.data_ptr(),
+                                                  npix, C, scale.data_ptr(), shift.data_ptr(), seed, st), "reduce")
+            _lib.check(lib.eqa_bn_bwd_apply_nhwc(gy.data_ptr(), yptr, xh.data_ptr(), mean.data_ptr(), rstd.data_ptr(), a.data_ptr(), b.data_ptr(),
+                                                 d.data_ptr(), p_drop, dx.data_ptr(), npix, C, scale.data_ptr(), shift.data_ptr(), seed, st), "apply")
+            outs.append((part, dx))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (p_drop, seed)
 
 
 @pytest.mark.gpu
