@@ -338,12 +338,24 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     const float* p = x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
     const bool row_in = gy < H && y < win;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+    if (nvalid == kFftN && !in_bias && !in_relu) {  // uniform: a full-width tile of a plain map (the headline case) needs no per-pixel work
 #pragma unroll
-    for (int j = 0; j < kFftN; ++j) {
-      float v = p[(size_t)min(j, nvalid - 1) * C] + ib;
-      v = in_relu ? fmaxf(v, 0.0f) : v;
-      re[j] = (row_in && j < nvalid) ? v : 0.0f;
-      im[j] = 0.0f;
+      for (int j = 0; j < kFftN; ++j) {
+        re[j] = p[(size_t)j * C];
+        im[j] = 0.0f;
+      }
+      if (!row_in) {
+#pragma unroll
+        for (int j = 0; j < kFftN; ++j) re[j] = 0.0f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kFftN; ++j) {
+        float v = p[(size_t)min(j, nvalid - 1) * C] + ib;
+        v = in_relu ? fmaxf(v, 0.0f) : v;
+        re[j] = (row_in && j < nvalid) ? v : 0.0f;
+        im[j] = 0.0f;
+      }
     }
     FFT_CLOCK_USE(re[0], 8);
     fft48(re, im, ore, oim);
