@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const floa
   float carry[kFftN - kFftO] = {0.0f, 0.0f, 0.0f, 0.0f};
   float* o = dx + row * (size_t)W * C + c;
   for (int tx = 0; tx < TX; ++tx) {
-    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+    float re[kFftH], im[kFftH], ore[kFftN];
 #pragma unroll
     for (int k = 0; k < kFftH; ++k) {
       const size_t off = ((size_t)tx * kFftH + k) * 2 * C;
@@ -202,12 +202,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const floa
       re[k] = two ? a + a0 : a;
       im[k] = two ? b + b0 : b;
     }
-#pragma unroll
-    for (int k = kFftH; k < kFftN; ++k) {
-      re[k] = re[kFftN - k];
-      im[k] = -im[kFftN - k];
-    }
-    fft48(im, re, oim, ore);
+    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
     const int x0 = kFftO * tx;
 #pragma unroll
     for (int j = 0; j < kFftN - kFftO; ++j) ore[j] += carry[j];
@@ -238,18 +233,13 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
   for (int i = 0; i < (NV > 1 ? NV : 1); ++i) acc[i] = 0.0f;
   for (int tx = 0; tx < TX; ++tx) {
     const float* p = T2 + ((row * TX + tx) * kFftH) * 2 * (size_t)C + c;
-    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+    float re[kFftH], im[kFftH], ore[kFftN];
 #pragma unroll
     for (int k = 0; k < kFftH; ++k) {
       re[k] = p[(size_t)(2 * k) * C];
       im[k] = p[(size_t)(2 * k + 1) * C];
     }
-#pragma unroll
-    for (int k = kFftH; k < kFftN; ++k) {  // the other half of a real signal's spectrum
-      re[k] = re[kFftN - k];
-      im[k] = -im[kFftN - k];
-    }
-    fft48(im, re, oim, ore);
+    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum
     const int x0 = kFftO * tx;
     const int ncols = min(kFftO, OW - x0);  // uniform
     if (NB == 0) {
@@ -479,18 +469,13 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
   if (valid) {
     const float* q = lds + (y * 2) * CH + cl;
-    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+    float re[kFftH], im[kFftH], ore[kFftN];
 #pragma unroll
     for (int k = 0; k < kFftH; ++k) {
       re[k] = q[k * kPitch];
       im[k] = q[k * kPitch + CH];
     }
-#pragma unroll
-    for (int k = kFftH; k < kFftN; ++k) {
-      re[k] = re[kFftN - k];
-      im[k] = -im[kFftN - k];
-    }
-    fft48(im, re, oim, ore);
+    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
     const float b = bias ? bias[c] : 0.0f;
     const int x0 = kFftO * tx;
     const int ncols = min(kFftO, OW - x0);  // uniform

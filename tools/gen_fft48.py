@@ -90,10 +90,67 @@ def build():
     return out
 
 out = build()
+lines_fft = lines
 
-def evaluate(z):
-    """Run the operation list in numpy with float32 rounding after every operation (what the device does without FMA
-    contraction) on the complex vector z (48,)."""
+
+def fft8(y):
+    c = [[None] * 2 for _ in range(4)]                 # c[q1][m2]
+    for m2 in range(2):
+        r = radix4(y[m2], y[2 + m2], y[4 + m2], y[6 + m2])
+        for q1 in range(4):
+            c[q1][m2] = cmul_const(r[q1], m2 * q1, 8)
+    X = [None] * 8
+    for q1 in range(4):
+        X[q1], X[q1 + 4] = cadd(c[q1][0], c[q1][1]), csub(c[q1][0], c[q1][1])
+    return X
+
+
+def fft24(x):
+    a = [[None] * 8 for _ in range(3)]
+    for n2 in range(8):
+        r = radix3(x[n2], x[8 + n2], x[16 + n2])
+        for k1 in range(3):
+            a[k1][n2] = cmul_const(r[k1], n2 * k1, 24)
+    o = [None] * 24
+    for k1 in range(3):
+        X = fft8(a[k1])
+        for k2 in range(8):
+            o[k1 + 3 * k2] = X[k2]
+    return o
+
+
+def build_c2r():
+    """Real output x[0..47] = sum over all 48 frequencies of a Hermitian spectrum given by its half X[0..24] (unscaled inverse,
+    e^{+2 pi i kn/48}; im[0] and im[24] are ignored as in numpy.fft.irfft).  Half-length algorithm: with
+    E_k = X_k + conj(X_{24-k}), O_k = (X_k - conj(X_{24-k})) e^{+2 pi i k/48}, Z_k = E_k + i O_k (k = 0..23; Z_{24-k} follows
+    from the same E_k, O_k), the 24-point inverse transform of Z is x[2n] + i x[2n+1]."""
+    X = [(f"re[{k}]", f"im[{k}]") for k in range(25)]
+    Z = [None] * 24
+    Z[0] = (add(X[0][0], X[24][0]), sub(X[0][0], X[24][0]))
+    for k in range(1, 12):
+        A, B = X[k], X[24 - k]
+        E = (add(A[0], B[0]), sub(A[1], B[1]))
+        D = (sub(A[0], B[0]), add(A[1], B[1]))
+        O = cmul_const(D, 48 - k, 48)
+        Z[k] = (sub(E[0], O[1]), add(E[1], O[0]))
+        Z[24 - k] = (add(E[0], O[1]), sub(O[0], E[1]))
+    Z[12] = (add(X[12][0], X[12][0]), neg(add(X[12][1], X[12][1])))
+    o = fft24([(zi, zr) for (zr, zi) in Z])            # inverse = forward with re / im swapped on the way in and out
+    x = [None] * 48
+    for n in range(24):
+        x[2 * n], x[2 * n + 1] = o[n][1], o[n][0]
+    return x
+
+
+lines = []
+out_c2r = build_c2r()
+lines_c2r = lines
+
+
+def evaluate(z, ops=None, outs=None):
+    """Run an operation list in numpy with float32 rounding after every operation (what the device does without FMA
+    contraction) on the complex vector z; default: the 48-point transform."""
+    ops = lines_fft if ops is None else ops
     vals = {}
     re, im = z.real.astype(np.float32), z.imag.astype(np.float32)
 
@@ -103,7 +160,7 @@ def evaluate(z):
         if tok[0] in "-0123456789" and tok.endswith("f"): return np.float32(float(tok[:-1]))
         return vals[tok]
 
-    for dst, expr in lines:
+    for dst, expr in ops:
         t = expr.split()
         if len(t) == 1:                                   # -a
             vals[dst] = -get(t[0][1:])
@@ -114,15 +171,23 @@ def evaluate(z):
             vals[dst] = np.float32(get(t[0]) * get(t[2])) + get(t[4])
         else:                                             # b - a * c
             vals[dst] = get(t[0]) - np.float32(get(t[2]) * get(t[4]))
+    if outs is not None:
+        return np.array([get(r) for r in outs])
     return np.array([complex(get(r), get(i)) for r, i in out])
 
 
 def render():
     o = ["// GENERATED by tools/gen_fft48.py -- do not edit.  48-point complex DFT, forward sign, natural order in and out.",
-         "// %d floating-point operations, all indices static.  Inverse: call with (im, re) in and (oim, ore) out." % len(lines),
+         "// %d floating-point operations, all indices static.  Inverse: call with (im, re) in and (oim, ore) out." % len(lines_fft),
          "__device__ __forceinline__ void fft48(const float (&re)[48], const float (&im)[48], float (&ore)[48], float (&oim)[48]) {"]
-    o += [f"  const float {dst} = {expr};" for dst, expr in lines]
+    o += [f"  const float {dst} = {expr};" for dst, expr in lines_fft]
     o += [f"  ore[{k}] = {r}; oim[{k}] = {i};" for k, (r, i) in enumerate(out)]
+    o += ["}", "",
+          "// Real 48-point output of a Hermitian spectrum from its half re/im[0..24] (unscaled inverse; im[0], im[24] ignored):",
+          "// one 24-point complex transform of Z_k = E_k + i O_k (see tools/gen_fft48.py build_c2r).  %d operations." % len(lines_c2r),
+          "__device__ __forceinline__ void ifft48_c2r(const float (&re)[25], const float (&im)[25], float (&x)[48]) {"]
+    o += [f"  const float {dst} = {expr};" for dst, expr in lines_c2r]
+    o += [f"  x[{n}] = {v};" for n, v in enumerate(out_c2r)]
     return "\n".join(o + ["}"]) + "\n"
 
 
@@ -132,10 +197,16 @@ if __name__ == "__main__":
         z = rng.standard_normal(48) + 1j * rng.standard_normal(48)
         got = evaluate(z)
         want = np.fft.fft(z.astype(np.complex64).astype(np.complex128))
-        print("ops", len(lines), "max err vs numpy.fft:", np.abs(got - want).max(), "scale", np.abs(want).max())
-        sys.exit(0 if np.abs(got - want).max() < 1e-5 * np.abs(want).max() else 1)
+        print("ops", len(lines_fft), "max err vs numpy.fft:", np.abs(got - want).max(), "scale", np.abs(want).max())
+        ok = np.abs(got - want).max() < 1e-5 * np.abs(want).max()
+        h = (rng.standard_normal(25) + 1j * rng.standard_normal(25)).astype(np.complex64).astype(np.complex128)
+        gotr = evaluate(h, lines_c2r, out_c2r)
+        wantr = np.fft.irfft(h, 48) * 48
+        print("c2r ops", len(lines_c2r), "max err vs numpy.fft.irfft:", np.abs(gotr - wantr).max(), "scale", np.abs(wantr).max())
+        ok = ok and np.abs(gotr - wantr).max() < 1e-5 * np.abs(wantr).max()
+        sys.exit(0 if ok else 1)
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "equiadapt_amd", "csrc", "fft48.inc")
     with open(path, "w") as f:
         f.write(render())
-    print("wrote", path, "with", len(lines), "operations")
+    print("wrote", path, "with", len(lines_fft), "+", len(lines_c2r), "operations")
