@@ -147,6 +147,38 @@ out_c2r = build_c2r()
 lines_c2r = lines
 
 
+def cscale(x, c):
+    return (mulc(x[0], c), mulc(x[1], c))
+
+
+def build_r2c():
+    """Half spectrum X[0..24] (forward sign, unscaled) of the real input re[0..47]: z_n = x[2n] + i x[2n+1], Z = 24-point
+    transform of z, X_k = (Z_k + conj Z_{24-k}) / 2 - i e^{-2 pi i k/48} (Z_k - conj Z_{24-k}) / 2, and X_{24-k} from the same
+    two terms; X_0 = Re Z_0 + Im Z_0, X_24 = Re Z_0 - Im Z_0 (both real), X_12 = conj Z_12."""
+    z = [(f"re[{2 * n}]", f"re[{2 * n + 1}]") for n in range(24)]
+    Z = fft24(z)
+    X = [None] * 25
+    X[0] = (add(Z[0][0], Z[0][1]), "0.0f")
+    X[24] = (sub(Z[0][0], Z[0][1]), "0.0f")
+    X[12] = (Z[12][0], neg(Z[12][1]))
+    for k in range(1, 12):
+        A, B = Z[k], Z[24 - k]
+        S = (add(A[0], B[0]), sub(A[1], B[1]))            # A + conj B
+        T = (sub(A[0], B[0]), add(A[1], B[1]))            # A - conj B
+        # U = -i w^k T / 2,  w = e^{-2 pi i/48}:  -i w^k = e^{-2 pi i (k + 12)/48}
+        c, sn = 0.5 * math.cos(2 * math.pi * (k + 12) / 48), -0.5 * math.sin(2 * math.pi * (k + 12) / 48)
+        U = (fms(T[1], sn, mulc(T[0], c)), fma(T[0], sn, mulc(T[1], c)))
+        Hh = cscale(S, 0.5)
+        X[k] = cadd(Hh, U)
+        X[24 - k] = (sub(Hh[0], U[0]), sub(U[1], Hh[1]))  # conj(S/2 - U)
+    return X
+
+
+lines = []
+out_r2c = build_r2c()
+lines_r2c = lines
+
+
 def evaluate(z, ops=None, outs=None):
     """Run an operation list in numpy with float32 rounding after every operation (what the device does without FMA
     contraction) on the complex vector z; default: the 48-point transform."""
@@ -188,6 +220,12 @@ def render():
           "__device__ __forceinline__ void ifft48_c2r(const float (&re)[25], const float (&im)[25], float (&x)[48]) {"]
     o += [f"  const float {dst} = {expr};" for dst, expr in lines_c2r]
     o += [f"  x[{n}] = {v};" for n, v in enumerate(out_c2r)]
+    o += ["}", "",
+          "// Half spectrum ore/oim[0..24] (forward sign, unscaled) of the real input re[0..47]: one 24-point complex transform of",
+          "// x[2n] + i x[2n+1] and a recombination pass (see tools/gen_fft48.py build_r2c).  %d operations." % len(lines_r2c),
+          "__device__ __forceinline__ void fft48_r2c(const float (&re)[48], float (&ore)[25], float (&oim)[25]) {"]
+    o += [f"  const float {dst} = {expr};" for dst, expr in lines_r2c]
+    o += [f"  ore[{k}] = {r}; oim[{k}] = {i};" for k, (r, i) in enumerate(out_r2c)]
     return "\n".join(o + ["}"]) + "\n"
 
 
@@ -204,9 +242,15 @@ if __name__ == "__main__":
         wantr = np.fft.irfft(h, 48) * 48
         print("c2r ops", len(lines_c2r), "max err vs numpy.fft.irfft:", np.abs(gotr - wantr).max(), "scale", np.abs(wantr).max())
         ok = ok and np.abs(gotr - wantr).max() < 1e-5 * np.abs(wantr).max()
+        xr = rng.standard_normal(48).astype(np.float32)
+        goth = evaluate(xr.astype(np.complex128), lines_r2c, [t for pair in out_r2c for t in pair]).reshape(25, 2)
+        wanth = np.fft.rfft(xr.astype(np.float64))
+        errh = np.abs(goth[:, 0] + 1j * goth[:, 1] - wanth).max()
+        print("r2c ops", len(lines_r2c), "max err vs numpy.fft.rfft:", errh, "scale", np.abs(wanth).max())
+        ok = ok and errh < 1e-5 * np.abs(wanth).max()
         sys.exit(0 if ok else 1)
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "equiadapt_amd", "csrc", "fft48.inc")
     with open(path, "w") as f:
         f.write(render())
-    print("wrote", path, "with", len(lines_fft), "+", len(lines_c2r), "operations")
+    print("wrote", path, "with", len(lines_fft), "+", len(lines_c2r), "+", len(lines_r2c), "operations")
