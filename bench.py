@@ -1,28 +1,49 @@
-"""bench.py -- canonicalize+invert throughput on BASELINE.json's headline config (224x224x3, C8).
+"""bench.py -- canonicalize+invert throughput on BASELINE.json's headline config (224x224x3, C8), 1..N GPUs.
 
-One "step" = one pass of the hot path over one batch that is already resident in HBM:
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+`--gpus N` with N > 1 and no torch.distributed environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one process per GPU, RCCL =
+backend "nccl" on ROCm); under an existing launcher (RANK / WORLD_SIZE set, as the driver does for N > 1) it joins that job.
+
+One "step" of the headline = one pass of the hot path over one batch that is already resident in HBM:
     y   = canonicalizer(x)                      # crop+resize -> canonicalization network -> group pool/argmax
                                                 #   -> fused pad/rotate/crop (eqa_canon_transform_fwd)
     out = canonicalizer.invert_canonicalization(f, induced_rep_type="scalar")     # eqa_invert_action_fwd
 with x, f : (B, 3, 224, 224) fp32 synthetic, and the canonicalization network = ESCNNEquivariantNetwork
 (out_channels=32, kernel_size=5, num_layers=3, C8) on a 96x96 crop+resize -- the reference's default
 (examples/images/classification/configs/canonicalization/group_equivariant.yaml).  The wrapped prediction
-network (ResNet-50) is NOT part of the measured path.  Ranks shard the batch; the forward path has no
-collective, so scaling is weak (per-GPU batch fixed).
+network (ResNet-50) is NOT part of the headline.  Ranks shard the batch; the forward path has no
+collective, so scaling is weak (per-GPU batch fixed); W warm-up steps, then exactly K steps between
+barrier + synchronize pairs, max over ranks.
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
-  roofline      HBM roofline of the dominant hand-written kernel (the canonicalizing transform),
+Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
+  roofline      HBM roofline of the dominant hand-written HBM kernel (the canonicalizing transform),
                 from HIP events recorded inside the timed region;
   group_action  transform+invert only (random group index), the figure the "% HBM roofline" target is about;
-  stages        the canonicalization network's kernels (97 % of the step), each against the roofline that bounds it: the
-                hand-written FFT (or Winograd) transforms (HBM), the library batched fp32 GEMM between them and the
-                hand-written lifting convolution (fp32 MFMA), HIP events inside the timed region;
+  stages        the canonicalization network's kernels, each against the roofline that bounds it (HIP events inside the
+                timed region);
+  self_check    rank 0's first 8 images of the timed workload against the CPU oracle (activations, group index,
+                canonicalized pixels, inverted pixels);
+  train         the data-parallel TRAINING step north_star's >=6x target is about: CanonicalizedClassifier
+                (this canonicalizer + a plain-torch ResNet-50, ~102 MB of fp32 gradients) under DistributedDataParallel,
+                SGD as the reference selects it, synthetic CIFAR-10-shaped batches resized to 224 (B=128 per GPU, the
+                reference's batch size); images/s over all ranks with the RCCL gradient all-reduce inside the step;
+  train_pointcloud  the same for ModelNet40-shaped batches (VNSmall canonicalizer + a PointNet classifier, B=64 per GPU);
+  configs       the other BASELINE configs on every rank (cfg1 CIFAR-10 32x32 C4, cfg4 ModelNet40 SO(3), cfg5 COCO-shape D4
+                with masks), whole-job units/s, the dominant kernel's roofline fraction, and (N=1) the CPU oracle;
   cpu_baseline  the CPU oracle (reference op order) on this host, bounded sample, rank 0 / N=1 only.
+
+`--dry-run` exercises ONLY the launcher logic (self-spawn, rendezvous, barrier, max-over-ranks, the JSON line) on CPU
+over gloo with an empty step; it is what tests/test_distributed_cpu.py runs, and its line says "dry_run": true.  There
+is no CPU path for the product: without --dry-run the script requires an MI355X.
 """
 import argparse
 import json
 import os
+import socket
 import statistics
+import subprocess
 import sys
 import time
 import types
@@ -34,20 +55,62 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide
+VALU_PEAK_WAVE_INSTR_S = 256 * 4 * 2.4e9 / 2  # 256 CUs x 4 SIMD-32, one wave64 VALU instruction per 2 cycles at 2.4 GHz
 H = W = 224
 C = 3
 BYTES_TRANSFORM = 2 * C * H * W * 4  # read + write per image, fp32: 1,204,224 B
 
 
-def build_canonicalizer(device):
+def build_canonicalizer(device, group_type: str = "rotation", num_rotations: int = 8):
     import equiadapt_amd as ea
 
     torch.manual_seed(2)
-    net = ea.ESCNNEquivariantNetwork((3, 96, 96), out_channels=32, kernel_size=5, group_type="rotation",
-                                     num_rotations=8, num_layers=3)
+    net = ea.ESCNNEquivariantNetwork((3, 96, 96), out_channels=32, kernel_size=5, group_type=group_type,
+                                     num_rotations=num_rotations, num_layers=3)
     hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=0.8, resize_shape=96)
     can = ea.GroupEquivariantImageCanonicalization(net, hp, (C, H, W))
     return can.to(device).eval()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU oracle legs (the checker and the stated baseline; never the thing measured)
+# ----------------------------------------------------------------------------------------------------------------------
+def oracle_check(can, x, f, y, inv, acts, gidx, group_type: str = "rotation", num_rotations: int = 8):
+    """cpu_baseline leg, checker side: the HIP results (y, inv, acts, gidx; any device) for the images x / features f (CPU)
+    against the CPU oracle run with the same weights.  Pixels are compared for the group element the HIP path chose, so a
+    near-tie of the activations cannot masquerade as a pixel error; the index itself is compared wherever the oracle's
+    top-2 margin exceeds 1e-4 of the activation scale (relative, because the random-init network's activations
+    on white noise are ~5e-3 with orientation margins of ~1e-5)."""
+    from oracle import image_ops as io
+    from oracle import nets as onets
+
+    net = can.canonicalization_network
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    x, f = x.cpu(), f.cpu()
+    y, inv, acts, gidx = y.detach().cpu(), inv.detach().cpu(), acts.detach().cpu(), gidx.detach().cpu().long()
+    G = 2 * num_rotations if group_type == "roto-reflection" else num_rotations
+    with torch.no_grad():
+        xin = io.pre_canonicalization_transform(x, (C, H, W), 0.8, 96)
+        acts_ref = onets.escnn_like_network(xin, sd, group_type, num_rotations, 3, net.out_channels)
+        scale = acts_ref.abs().max().item()
+        top2 = acts_ref.topk(2, dim=-1).values
+        clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * scale
+        ang = io.group_angles(num_rotations)
+        if group_type == "rotation":
+            rot, refl = ang[gidx], None
+        else:
+            rot, refl = torch.cat([ang, ang])[gidx], (gidx >= num_rotations).float()
+        dy = (y.double() - io.canonicalize_images(x, rot, refl, (C, H, W)).double()).abs()
+        di = (inv.double() - io.invert_action(f, rot, refl, num_rotations, G, "scalar").double()).abs()
+    n_clear = int(clear.sum())
+    match = float((gidx[clear] == acts_ref.argmax(-1)[clear]).float().mean()) if n_clear else 1.0
+    return {"images": int(x.shape[0]), "acts_max_err": (acts - acts_ref).abs().max().item(), "acts_scale": scale,
+            "index_match": match, "n_clear_margin": n_clear,
+            "index_match_all": float((gidx == acts_ref.argmax(-1)).float().mean()),
+            "canonicalize_max_err": dy.max().item(), "canonicalize_rms_err": dy.pow(2).mean().sqrt().item(),
+            "invert_max_err": di.max().item(), "invert_rms_err": di.pow(2).mean().sqrt().item(),
+            "max_err": max(dy.max().item(), di.max().item()),
+            "against": "oracle/ (CPU restatement of the reference op sequence), same weights, rank 0's first images"}
 
 
 def cpu_baseline(sample: int, reps: int):
@@ -108,8 +171,8 @@ def cpu_baseline(sample: int, reps: int):
 
 
 def cpu_baseline_config(name: str, state: dict):
-    """cpu_baseline leg for the other BASELINE configs (used by tools/bench_configs.py): the oracle's op sequence on the host,
-    16 threads, bounded sample.  `state` carries the network weights of the GPU run so both sides compute the same thing."""
+    """cpu_baseline leg for the other BASELINE configs: the oracle's op sequence on the host, 16 threads, bounded sample.
+    `state` carries the network weights of the GPU run so both sides compute the same thing."""
     from oracle import image_ops as io
     from oracle import nets as onets
     from oracle import pointcloud_ops as po
@@ -132,16 +195,295 @@ def cpu_baseline_config(name: str, state: dict):
             el = io.group_element_from_activations(acts, 4, "rotation", 1.0, training=False)
             return io.canonicalize_images(xs, el["rotation"], None, (3, 32, 32)), io.invert_action(fs, el["rotation"], None, 4, 4, "scalar")
         dt = timed(f1, 5)
-        return {"images_s": 128 / dt, "ms": dt * 1e3, "sample": "B=128, 16 threads"}
+        return {"value": 128 / dt, "unit": "images/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port", "sample": "B=128 x 5 reps"}
     if name == "cfg4":
         pcs, sd = torch.randn(4, 3, 1024), state["sd"]
         dt = timed(lambda: po.canonicalize_pointcloud(pcs, po.gram_schmidt(po.vnsmall_forward(pcs, sd))), 2)
-        return {"clouds_s": 4 / dt, "ms": dt * 1e3, "sample": "B=4, 16 threads"}
+        return {"value": 4 / dt, "unit": "clouds/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port", "sample": "B=4 x 2 reps"}
     if name == "cfg5":  # transform + invert only (the orbit / network part is a few ms either way)
         x1, ang, refl = torch.randn(1, 3, 1024, 1024), torch.tensor([90.0]), torch.tensor([1.0])
         dt = timed(lambda: (io.canonicalize_images(x1, ang, refl, (3, 1024, 1024)), io.invert_action(x1[:, :1], ang, refl, 4, 8, "scalar")), 2)
-        return {"images_s": 1 / dt, "ms": dt * 1e3, "sample": "B=1, 16 threads"}
+        return {"value": 1 / dt, "unit": "images/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "B=1 x 2 reps, transform + invert only"}
     raise ValueError(name)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# launcher / communicator
+# ----------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn_under_launcher(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: re-execute under torch.distributed.run, one rank per GPU."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+class Comm:
+    """The process group of this run (or a single process): barrier + device synchronise, max / sum over ranks."""
+
+    def __init__(self, dry_run: bool):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry_run = dry_run
+        self.backend = None
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.backend = "gloo" if dry_run else "nccl"   # "nccl" IS RCCL on ROCm
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
+        if dry_run:
+            self.dev = torch.device("cpu")
+        else:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback (--dry-run tests the launcher only)"
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        if not self.dry_run:
+            torch.cuda.synchronize()
+
+    def reduce(self, value: float, op: str = "max") -> float:
+        if self.world == 1:
+            return value
+        import torch.distributed as dist
+
+        t = torch.tensor([value], device=self.dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        return t.item()
+
+    def gather(self, value: float):
+        if self.world == 1:
+            return [value]
+        import torch.distributed as dist
+
+        t = torch.tensor([value], device=self.dev, dtype=torch.float64)
+        out = [torch.zeros_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t)
+        return [o.item() for o in out]
+
+    def timed(self, step, steps: int, warmup: int):
+        """W untimed steps, then exactly K steps between barrier + synchronize pairs.  -> (max over ranks, per-rank list) seconds."""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        return self.reduce(dt, "max"), self.gather(dt)
+
+    def close(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# legs
+# ----------------------------------------------------------------------------------------------------------------------
+def leg_train_images(comm: Comm, steps: int, warmup: int, batch: int):
+    """Data-parallel training step, image classification (reference: examples/images/classification/model.py:59-127,
+    184-239; train_utils.py:89-91 strategy="ddp").  CIFAR-10-shaped data as the reference feeds it (resized to 224,
+    model_utils.py:21), batch 128 per GPU (configs/dataset/default.yaml), ResNet-50, SGD by the reference's rule."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from resnet50 import ResNet50
+
+    import equiadapt_amd as ea  # noqa: F401
+    from equiadapt_amd import training as tr
+
+    dev = comm.dev
+    can = build_canonicalizer(dev).train()
+    torch.manual_seed(0)
+    pred = ResNet50(num_classes=10)
+    model = tr.CanonicalizedClassifier(can, pred, tr.LossWeights(task_weight=1.0, prior_weight=100.0)).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    ddp = tr.wrap_ddp(model, dev)
+    opt, _ = tr.configure_optimizer(model, 1e-3, 1e-3, kind=None, max_epochs=200,
+                                    prediction_network_architecture="resnet50", dataset_name="cifar10")
+    g = torch.Generator().manual_seed(100 + comm.rank)
+    xs = [torch.randn(batch, C, H, W, generator=g).to(dev) for _ in range(2)]
+    ys = [torch.randint(0, 10, (batch,), generator=g).to(dev) for _ in range(2)]
+    it = [0]
+
+    def step():
+        i = it[0] & 1
+        it[0] += 1
+        return tr.train_step(ddp, opt, xs[i], ys[i], check_nan=False)
+
+    torch.cuda.reset_peak_memory_stats()
+    dt, per_rank = comm.timed(step, steps, warmup)
+    loss = float(step()["loss"])
+    assert loss == loss, "training loss is NaN"
+    res = {"images_s": batch * comm.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+           "batch_per_gpu": batch, "n_gpus": comm.world,
+           "model": "GroupEquivariantImageCanonicalization(ESCNNEquivariantNetwork C8 32ch k5 L3) + ResNet50(10 classes), fp32",
+           "optimizer": type(opt).__name__ + " (reference rule: resnet + non-mnist -> SGD 0.9 / wd 5e-4)",
+           "loss": "1.0 * CE + 100.0 * prior", "parameters": n_params, "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.world > 1 else 0.0,
+           "collective": "DDP bucketed all-reduce over RCCL (64 MB buckets), overlapped with backward" if comm.world > 1 else "none (1 rank)",
+           "per_rank_ms_per_step": [t / steps * 1e3 for t in per_rank], "final_loss": loss,
+           "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "data": "synthetic CIFAR-10-shaped (resized 224x224x3), labels uniform"}
+    del ddp, model, opt, xs, ys
+    torch.cuda.empty_cache()
+    return res
+
+
+def leg_train_pointcloud(comm: Comm, steps: int, warmup: int, batch: int):
+    """Data-parallel training step, point-cloud classification (examples/pointcloud/classification/model.py:77-134,245-300):
+    ModelNet40-shaped clouds (1024 points, B=64 per GPU), VNSmall canonicalizer + PointNet classifier, SGD + cosine."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    from resnet50 import PointNetCls
+
+    import equiadapt_amd as ea
+    from equiadapt_amd import training as tr
+
+    dev = comm.dev
+    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    torch.manual_seed(2)
+    can = ea.EquivariantPointcloudCanonicalization(ea.VNSmall(hp), hp)
+    model = tr.CanonicalizedClassifier(can, PointNetCls(40), tr.LossWeights(task_weight=1.0, prior_weight=100.0)).to(dev).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    ddp = tr.wrap_ddp(model, dev)
+    opt, _ = tr.configure_pointcloud_optimizer(model, 1e-3, 1e-3, "SGD", "cosine", 250)
+    g = torch.Generator().manual_seed(200 + comm.rank)
+    xs = [torch.randn(batch, 3, 1024, generator=g).to(dev) for _ in range(2)]
+    ys = [torch.randint(0, 40, (batch,), generator=g).to(dev) for _ in range(2)]
+    it = [0]
+
+    def step():
+        i = it[0] & 1
+        it[0] += 1
+        return tr.train_step(ddp, opt, xs[i], ys[i], check_nan=False)
+
+    dt, per_rank = comm.timed(step, steps, warmup)
+    loss = float(step()["loss"])
+    assert loss == loss, "training loss is NaN"
+    return {"clouds_s": batch * comm.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "batch_per_gpu": batch, "n_gpus": comm.world, "model": "EquivariantPointcloudCanonicalization(VNSmall k=20 mean) + PointNet(40 classes), fp32",
+            "optimizer": "SGD x100 lr, momentum 0.9, wd 1e-4 (reference rule)", "parameters": n_params,
+            "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.world > 1 else 0.0,
+            "per_rank_ms_per_step": [t / steps * 1e3 for t in per_rank], "final_loss": loss,
+            "data": "synthetic ModelNet40-shaped (B,3,1024) normal clouds, labels uniform"}
+
+
+def leg_configs(comm: Comm, with_cpu: bool):
+    """BASELINE configs other than the headline, on every rank (batch sharded, no collective): whole-job units/s."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import ops
+
+    dev, out = comm.dev, {}
+
+    def run(step, units, reps, warm):
+        with torch.no_grad():
+            dt, _ = comm.timed(step, reps, warm)
+        return units * comm.world * reps / dt, dt / reps * 1e3
+
+    # ---- cfg1: CIFAR-10 shape 32x32x3, C4, CustomEquivariantNetwork (the self-contained net that satisfies the API, SURVEY 8d)
+    torch.manual_seed(2)
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 8, 5, "rotation", 4, 2, device="cpu")
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=32)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 32, 32))
+    sd1 = {k: v.clone() for k, v in net.state_dict().items()}
+    can = can.to(dev).eval()
+    c1 = {"workload": "configs[0] shape: CIFAR-10 32x32x3, C4, GroupEquivariantImageCanonicalization + CustomEquivariantNetwork(8ch,k5,2 layers): "
+                      "canonicalize + invert(scalar)", "unit": "images/s", "batches": {}}
+    for B in (128, 8192):
+        x = torch.randn(B, 3, 32, 32, device=dev)
+        f = torch.randn(B, 3, 32, 32, device=dev)
+        with ops.KernelTimer() as kt:
+            v, ms = run(lambda: (can(x), can.invert_canonicalization(f, induced_rep_type="scalar")), B, 20, 5)
+        n_ct, ms_ct = kt.summary().get("canon_transform", (0, float("nan")))
+        ach = B * 2 * 3 * 32 * 32 * 4 / (ms_ct * 1e-3) / 1e9
+        c1["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
+            "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd", "achieved": ach, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct,
+            "note": "launch-bound at this size: B*24.6 KB per launch" if B == 128 else None}}
+    c1["value"] = c1["batches"]["8192"]["value"]
+    if with_cpu:
+        c1["cpu_baseline"] = cpu_baseline_config("cfg1", {"sd": sd1})
+    out["cfg1"] = c1
+    del can
+
+    # ---- cfg4: ModelNet40 shape, 1024 points, SO(3)
+    hp4 = types.SimpleNamespace(n_knn=20, pooling="mean")
+    torch.manual_seed(2)
+    vn = ea.VNSmall(hp4)
+    sd4 = {k: v.clone() for k, v in vn.state_dict().items()}
+    can4 = ea.EquivariantPointcloudCanonicalization(vn, hp4).to(dev).eval()
+    c4 = {"workload": "configs[3] shape: ModelNet40 (B,3,1024), SO(3): VNSmall(k=20, mean) -> Gram-Schmidt -> rotate "
+                      "(the reference defines no invert for clouds)", "unit": "clouds/s", "batches": {}}
+    # VALU-bound: measured 68k VALU wave-instructions per 64 points (PMC SQ_INSTS_VALU, DESIGN 3.5) -> 1.09 M per cloud, of which
+    # the kNN distance evaluations are the irreducible 1024 x 1024 x ~5 = 82 k; HBM traffic is 12 KB in + 36 B out per cloud.
+    instr_per_cloud = 16 * 68.0e3
+    for B in (64, 2048):
+        pc = torch.randn(B, 3, 1024, device=dev)
+        v, ms = run(lambda: can4(pc), B, 20, 5)
+        per_gpu = v / comm.world
+        c4["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
+            "bound": "valu", "kernel": "vnsmall_fwd_kernel (eqa_vnsmall_fwd)", "achieved": per_gpu * instr_per_cloud / 1e12,
+            "peak": VALU_PEAK_WAVE_INSTR_S / 1e12, "unit": "T wave-instr/s", "frac": per_gpu * instr_per_cloud / VALU_PEAK_WAVE_INSTR_S,
+            "hbm_frac": per_gpu * 12324 / 1e9 / HBM_PEAK_GBS,
+            "note": "1.09 M VALU wave-instructions per cloud (kNN distances 82 k of them) against 12 KB of HBM traffic: issue-bound, not HBM-bound"}}
+    c4["value"] = c4["batches"]["2048"]["value"]
+    if with_cpu:
+        c4["cpu_baseline"] = cpu_baseline_config("cfg4", {"sd": sd4})
+    out["cfg4"] = c4
+    del can4
+
+    # ---- cfg5: COCO shape 1024x1024x3, D4, optimised canonicalizer, mask + box targets, invert of a mask-shaped scalar output
+    torch.manual_seed(2)
+    net5 = ea.ConvNetwork((3, 128, 128), out_channels=16, kernel_size=7, num_layers=3, out_vector_size=128)
+    hp5 = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=128, group_type="roto-reflection", num_rotations=4,
+                                artifact_err_wt=0.0, learn_ref_vec=False)
+    can5 = ea.OptimizedGroupEquivariantImageCanonicalization(net5, hp5, (3, 1024, 1024)).to(dev).eval()
+    c5 = {"workload": "configs[4] shape: COCO 1024x1024x3, D4, OptimizedGroupEquivariantImageCanonicalization + ConvNetwork(k7,16ch,3 layers,128), "
+                      "3 uint8 masks + 3 boxes per image as targets, invert_canonicalization(scalar) of a (B,1,1024,1024) output",
+          "unit": "images/s", "batches": {}}
+    for B in (4, 32):
+        x = torch.randn(B, 3, 1024, 1024, device=dev)
+        pred = torch.randn(B, 1, 1024, 1024, device=dev)
+        masks = [(torch.rand(3, 1024, 1024, device=dev) > 0.5).to(torch.uint8) for _ in range(B)]
+        boxes = [torch.tensor([[10.0, 20.0, 200.0, 300.0]] * 3, device=dev) for _ in range(B)]
+
+        def step5():
+            targets = [{"boxes": b.clone(), "masks": m} for b, m in zip(boxes, masks)]
+            y, t = can5(x, targets)
+            return y, t, can5.invert_canonicalization(pred, induced_rep_type="scalar")
+        with ops.KernelTimer() as kt:
+            v, ms = run(step5, B, 10, 3)
+        ks = kt.summary()
+        n_ct, ms_ct = ks.get("canon_transform", (0, float("nan")))
+        n_mk, ms_mk = ks.get("mask_action", (0, float("nan")))
+        ach = B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct * 1e-3) / 1e9
+        ach_m = B * 3 * 2 * 1024 * 1024 / (ms_mk * 1e-3) / 1e9
+        c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
+            "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct},
+            "mask_kernel": {"kernel": "nearest_action_tile_kernel via eqa_mask_action_nearest (2 B / mask pixel)", "achieved": ach_m,
+                            "unit": "GB/s", "frac": ach_m / HBM_PEAK_GBS, "avg_launch_ms": ms_mk}}
+    c5["value"] = c5["batches"]["32"]["value"]
+    if with_cpu:
+        c5["cpu_baseline"] = cpu_baseline_config("cfg5", {})
+    out["cfg5"] = c5
+    return out
 
 
 def main():
@@ -150,156 +492,181 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU per step")
+    ap.add_argument("--mode", default="all", choices=["all", "forward", "train"],
+                    help="all: headline + train + configs legs in one line (default); forward: headline only; train: the DP training legs only")
+    ap.add_argument("--train-steps", type=int, default=8)
+    ap.add_argument("--train-warmup", type=int, default=3)
+    ap.add_argument("--train-batch", type=int, default=128, help="images per GPU per training step (reference: 128)")
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher logic only, CPU + gloo, empty step")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_launcher(args.gpus))
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL on ROCm
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    comm = Comm(args.dry_run)
+    world, rank, dev = comm.world, comm.rank, comm.dev
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    B = args.batch
+
+    if args.dry_run:
+        z = torch.zeros(16)
+        dt, per_rank = comm.timed(lambda: z.add_(1.0), args.steps, args.warmup)
+        if rank == 0:
+            print(json.dumps({"metric": "canonicalize+invert images/sec (224x224 C8)", "value": None, "unit": "images/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "dry_run": True,
+                              "backend": comm.backend, "ranks": world, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+                              "note": "launcher logic only (CPU, gloo, empty step): no product code ran"}), flush=True)
+        comm.close()
+        return
 
     from equiadapt_amd import ops
     from equiadapt_amd.images.utils import device_tables
 
-    can = build_canonicalizer(dev)
-    B = args.batch
-    x = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)
-    f = torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(1000 + rank)).to(dev)
+    line = {"metric": "canonicalize+invert images/sec (224x224 C8)", "value": None, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 224x224x3 synthetic, C8, GroupEquivariantImageCanonicalization + "
+                                   "ESCNNEquivariantNetwork(32ch,k5,3 layers, crop 0.8, resize 96) forward, "
+                                   "then invert_canonicalization(scalar, 3ch); prediction network excluded",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective in the forward path)"},
+            "rccl_ranks": world if world > 1 else 0, "backend": comm.backend}
 
-    def step():
-        y = can(x)
-        out = can.invert_canonicalization(f, induced_rep_type="scalar")
-        return y, out
+    if args.mode in ("all", "forward"):
+        can = build_canonicalizer(dev)
+        NBUF = 3  # distinct input batches, cycled: no step re-reads the batch the previous step left in the caches
+        xs = [torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(rank * 16 + i)).to(dev) for i in range(NBUF)]
+        fs = [torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(1000 + (rank * 16 + i) * 3)).to(dev) for i in range(NBUF)]
+        it = [0]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        def step():
+            i = it[0] % NBUF
+            it[0] += 1
+            y = can(xs[i])
+            out = can.invert_canonicalization(fs[i], induced_rep_type="scalar")
+            return y, out
 
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        with ops.KernelTimer() as kt:
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step()
-            barrier()
-            elapsed = time.perf_counter() - t0
-        ktimes = kt.summary()
+        with torch.no_grad():
+            with ops.KernelTimer() as kt:
+                elapsed, per_rank = comm.timed(step, args.steps, args.warmup)
+            ktimes = kt.summary()
 
-        # group-action-only leg: the two resampling kernels back to back with a seeded random index
-        gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
-        th_c, fl_c = device_tables("canonicalize", 8, False, (2 * H, 2 * W), dev)
-        th_i, fl_i, _ = device_tables("invert", 8, False, (H, W), dev)
-        for _ in range(3):
-            ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
-            ops.invert_action(f, gidx, th_i, fl_i, None)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 50
-        e0.record()
-        for _ in range(reps):
-            ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
-            ops.invert_action(f, gidx, th_i, fl_i, None)
-        e1.record()
-        torch.cuda.synchronize()
-        ga_ms = e0.elapsed_time(e1) / reps
+            # self check: rank 0's first 8 images of batch 0 against the CPU oracle (seed 0 / seed 1000 as generated above)
+            self_check = None
+            if rank == 0 and not args.no_cpu_baseline:
+                n = min(8, B)
+                y = can(xs[0])
+                acts = can.canonicalization_info_dict["group_activations"]
+                gidx = can.canonicalization_info_dict["group_index"]
+                inv = can.invert_canonicalization(fs[0], induced_rep_type="scalar")
+                self_check = oracle_check(can, xs[0][:n], fs[0][:n], y[:n], inv[:n], acts[:n], gidx[:n])
 
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
+            # group-action-only leg: the two resampling kernels back to back with a seeded random index
+            x, f = xs[0], fs[0]
+            gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
+            th_c, fl_c = device_tables("canonicalize", 8, False, (2 * H, 2 * W), dev)
+            th_i, fl_i, _ = device_tables("invert", 8, False, (H, W), dev)
+            for _ in range(3):
+                ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
+                ops.invert_action(f, gidx, th_i, fl_i, None)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 50
+            e0.record()
+            for _ in range(reps):
+                ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
+                ops.invert_action(f, gidx, th_i, fl_i, None)
+            e1.record()
+            torch.cuda.synchronize()
+            ga_ms = e0.elapsed_time(e1) / reps
+        del xs, fs, x, f, can
+        torch.cuda.empty_cache()
 
-    if rank == 0:
         total_images = B * world * args.steps
         n_ct, ms_ct = ktimes.get("canon_transform", (0, float("nan")))
         n_iv, ms_iv = ktimes.get("invert_action", (0, float("nan")))
-        n_gp, ms_gp = ktimes.get("group_pool", (0, None))
-        n_ws, ms_ws = ktimes.get("window_sums", (0, None))
         ach = B * BYTES_TRANSFORM / (ms_ct * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch
         # correction; tools/collect_traffic.sh).  Counters cannot be collected inside this process, so the committed
         # measurement of the same kernel / shape is reported; null when it does not match this run's shape.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_group_action.json")
-        if os.path.exists(tpath) and B == 256:
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        traffic, tsrc = None, None
+        for rnd in ("r02", "r01"):
+            tpath = os.path.join(ROOT, "profiles", rnd, "traffic_group_action.json")
+            if os.path.exists(tpath) and B == 256:
+                traffic, tsrc = json.load(open(tpath)).get("traffic_bytes_per_launch"), f"profiles/{rnd}/traffic_group_action.json"
+                break
         ga_bytes = 2 * B * BYTES_TRANSFORM
-        line = {
-            "metric": "canonicalize+invert images/sec (224x224 C8)",
-            "value": total_images / elapsed,
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: 224x224x3 synthetic, C8, GroupEquivariantImageCanonicalization + "
-                                   "ESCNNEquivariantNetwork(32ch,k5,3 layers, crop 0.8, resize 96) forward, "
-                                   "then invert_canonicalization(scalar, 3ch); prediction network excluded",
-                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective)"},
+        line.update({
+            "value": total_images / elapsed, "ms_per_step": elapsed / args.steps * 1e3,
+            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "roofline": {"bound": "hbm", "kernel": "group_action_kernel<3,true> via eqa_canon_transform_fwd",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01/traffic_group_action.json)",
-                         "launches_timed": n_ct, "avg_launch_ms": ms_ct,
-                         "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
-            "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv, "group_pool": ms_gp, "window_sums": ms_ws},
+                         "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC, {tsrc})",
+                         "launches_timed": n_ct, "avg_launch_ms": ms_ct, "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
+            "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
             "group_action": {"images_s_per_gpu": B / (ga_ms * 1e-3), "ms": ga_ms,
                              "achieved_GBs": ga_bytes / (ga_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "note": "eqa_canon_transform_fwd + eqa_invert_action_fwd only, seeded random index"},
-        }
-        # canonicalization-network stages at this batch: 96x96x3 -> lift 5x5 -> 92x92x256 -> Winograd F(4x4,5x5) -> 88x88x256
-        # (consumed as window sums); algorithmic bytes / flops per launch, fp32
-        px_l, px_w, tiles = B * 92 * 92, B * 88 * 88, B * 22 * 22
-        v_bytes = tiles * 64 * 256 * 4
-        spec = {
-            "winograd_input": ("hbm", px_l * 256 * 4 + v_bytes, "eqa_winograd_f4k5_input (hand-written)"),
-            "winograd_gemm": ("mfma", 2.0 * 64 * tiles * 256 * 256, "64 x [tiles x 256].[256 x 256] strided-batched GEMM (library)"),
-            "winograd_output_sums": ("hbm", v_bytes, "eqa_winograd_f4k5_output_sums incl. finalize (hand-written)"),
-            "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
-        }
-        # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1154 stored frequencies;
-        # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written)
-        m_tiles, spectra = B * 4, 1154 * B * 4 * 512 * 4
-        spec.update({
-            "fft_input": ("hbm", px_l * 256 * 4 + spectra, "eqa_fft48k5_input: row + column FFT-48 passes (hand-written)"),
-            "fft_gemm": ("mfma", 2.0 * 1154 * m_tiles * 512 * 512, "1154 x [tiles x 512].[512 x 512] batched GEMM, complex as real (library)"),
-            "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
+            "self_check": self_check,
         })
-        stages = {}
-        for name, (bound, work, what) in spec.items():
-            n_k, ms_k = ktimes.get(name, (0, None))
-            if not ms_k:
-                continue
-            if bound == "hbm":
-                a = work / (ms_k * 1e-3) / 1e9
-                stages[name] = {"what": what, "ms": ms_k, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": a / HBM_PEAK_GBS, "launches_timed": n_k}
-            else:
-                a = work / (ms_k * 1e-3) / 1e12
-                stages[name] = {"what": what, "ms": ms_k, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TF,
-                                "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TF, "launches_timed": n_k}
-        line["stages"] = stages
-        if world == 1 and not args.no_cpu_baseline:
+        line["stages"] = stage_table(ktimes, B)
+
+    if args.mode in ("all", "train"):
+        line["train"] = leg_train_images(comm, args.train_steps, args.train_warmup, args.train_batch)
+        line["train_pointcloud"] = leg_train_pointcloud(comm, max(args.train_steps, 20), args.train_warmup + 2, 64)
+        if args.mode == "train":
+            line.update({"metric": "DP training step images/sec (224x224 C8 canonicalizer + ResNet-50)", "value": line["train"]["images_s"],
+                         "ms_per_step": line["train"]["ms_per_step"], "steps": args.train_steps, "warmup": args.train_warmup})
+    if args.mode == "all":
+        line["configs"] = leg_configs(comm, with_cpu=(world == 1 and not args.no_cpu_baseline))
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "forward"):
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps)
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    comm.close()
+
+
+def stage_table(ktimes, B):
+    """The canonicalization network's kernels at this batch against the roofline that bounds each (algorithmic bytes / flops
+    per launch, fp32): 96x96x3 -> lift 5x5 -> 92x92x256 -> 5x5 (FFT or Winograd) -> 88x88x256 consumed as window sums."""
+    px_l, tiles = B * 92 * 92, B * 22 * 22
+    v_bytes = tiles * 64 * 256 * 4
+    spec = {
+        "winograd_input": ("hbm", px_l * 256 * 4 + v_bytes, "eqa_winograd_f4k5_input (hand-written)"),
+        "winograd_gemm": ("mfma", 2.0 * 64 * tiles * 256 * 256, "64 x [tiles x 256].[256 x 256] strided-batched GEMM (library)"),
+        "winograd_output_sums": ("hbm", v_bytes, "eqa_winograd_f4k5_output_sums incl. finalize (hand-written)"),
+        "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
+    }
+    # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1154 stored frequencies;
+    # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written);
+    # flops of the complex channel contraction counted as 4 real multiply-adds per complex one (the 3-multiplication kernel does 3)
+    m_tiles, spectra = B * 4, 1154 * B * 4 * 512 * 4
+    spec.update({
+        "fft_input": ("hbm", px_l * 256 * 4 + spectra, "eqa_fft48k5_input: row + column FFT-48 passes (hand-written)"),
+        "fft_gemm": ("mfma", 2.0 * 1154 * m_tiles * 512 * 512, "1154 x [tiles x 256].[256 x 256] complex products (flops as 4 real products each)"),
+        "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
+    })
+    stages = {}
+    for name, (bound, work, what) in spec.items():
+        n_k, ms_k = ktimes.get(name, (0, None))
+        if not ms_k:
+            continue
+        if bound == "hbm":
+            a = work / (ms_k * 1e-3) / 1e9
+            stages[name] = {"what": what, "ms": ms_k, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": a / HBM_PEAK_GBS, "launches_timed": n_k}
+        else:
+            a = work / (ms_k * 1e-3) / 1e12
+            stages[name] = {"what": what, "ms": ms_k, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TF,
+                            "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TF, "launches_timed": n_k}
+    for name in ("group_pool", "window_sums", "crop_resize"):
+        if name in ktimes:
+            stages[name] = {"ms": ktimes[name][1], "launches_timed": ktimes[name][0]}
+    return stages
 
 
 if __name__ == "__main__":

@@ -347,7 +347,7 @@ def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.T
     flags, p_flags = _opt(flags, "flags", torch.int32)
     n, H, W = masks.shape
     out = torch.empty_like(masks)
-    with torch.cuda.device(masks.device):
+    with torch.cuda.device(masks.device), _timed("mask_action"):
         st = lib.eqa_mask_action_nearest(masks.data_ptr(), out.data_ptr(), eidx.data_ptr(), rtheta.data_ptr(), p_flags,
                                          rtheta.shape[0], n, H, W, _stream())
     _lib.check(st, "eqa_mask_action_nearest")

@@ -64,9 +64,25 @@ class CanonicalizedClassifier(torch.nn.Module):
         return out
 
 
+def select_image_optimizer_kind(prediction_network_architecture: str, dataset_name: str) -> str:
+    """The reference's selection rule for the image classification loop
+    (examples/images/classification/model.py:184-191): SGD + MultiStepLR when the prediction network is a ResNet and the
+    dataset is not an MNIST variant, AdamW otherwise."""
+    return "sgd" if ("resnet" in prediction_network_architecture and "mnist" not in dataset_name) else "adamw"
+
+
 def configure_optimizer(model: CanonicalizedClassifier, prediction_lr: float, canonicalization_lr: float,
-                        kind: str = "adamw", max_epochs: int = 100):
-    """Two parameter groups as in the reference; returns (optimizer, scheduler or None)."""
+                        kind: Optional[str] = "adamw", max_epochs: int = 100,
+                        prediction_network_architecture: Optional[str] = None, dataset_name: Optional[str] = None):
+    """Two parameter groups as in the reference; returns (optimizer, scheduler or None).
+
+    ``kind=None`` applies the reference's own rule from the architecture / dataset names
+    (``select_image_optimizer_kind``); SGD(0.9, wd 5e-4) + MultiStepLR(milestones //6,//3,//2 when max_epochs > 100 else
+    //3,//2; gamma 0.1) or AdamW with defaults (model.py:184-239)."""
+    if kind is None:
+        if prediction_network_architecture is None or dataset_name is None:
+            raise ValueError("kind=None needs prediction_network_architecture and dataset_name (the reference's rule)")
+        kind = select_image_optimizer_kind(prediction_network_architecture, dataset_name)
     groups = [{"params": list(model.prediction_network.parameters()), "lr": prediction_lr},
               {"params": list(model.canonicalizer.parameters()), "lr": canonicalization_lr}]
     if kind == "sgd":
@@ -76,6 +92,25 @@ def configure_optimizer(model: CanonicalizedClassifier, prediction_lr: float, ca
     if kind == "adamw":
         return torch.optim.AdamW(groups), None
     raise ValueError(f"unknown optimizer kind {kind}")
+
+
+def configure_pointcloud_optimizer(model: CanonicalizedClassifier, prediction_lr: float, canonicalization_lr: float,
+                                   optimizer: str = "SGD", lr_scheduler: str = "cosine", num_epochs: int = 250):
+    """The point-cloud classification loop's rule (examples/pointcloud/classification/model.py:245-300):
+    "Adam": Adam(wd 1e-4), no scheduler; "SGD": both learning rates x100, momentum 0.9, wd 1e-4, with
+    CosineAnnealingLR(T_max=num_epochs, eta_min=1e-3) or StepLR(20, 0.7); anything else raises NotImplementedError."""
+    params = lambda scale: [{"params": list(model.prediction_network.parameters()), "lr": prediction_lr * scale},  # noqa: E731
+                            {"params": list(model.canonicalizer.parameters()), "lr": canonicalization_lr * scale}]
+    if optimizer == "Adam":
+        return torch.optim.Adam(params(1), weight_decay=1e-4), None
+    if optimizer == "SGD":
+        opt = torch.optim.SGD(params(100), momentum=0.9, weight_decay=1e-4)
+        if lr_scheduler == "cosine":
+            return opt, torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=num_epochs, eta_min=1e-3)
+        if lr_scheduler == "step":
+            return opt, torch.optim.lr_scheduler.StepLR(opt, step_size=20, gamma=0.7)
+        raise NotImplementedError(f"Unknown learning rate decay schedule {lr_scheduler}")
+    raise NotImplementedError(optimizer)
 
 
 def shard_range(n: int, rank: int, world: int):
@@ -115,13 +150,17 @@ def reduce_metrics(metrics: Dict[str, torch.Tensor]) -> Dict[str, float]:
     return {k: v for k, v in zip(keys, vec.tolist())}
 
 
-def train_step(ddp_model: torch.nn.Module, optimizer: torch.optim.Optimizer, x: torch.Tensor, y: torch.Tensor
-               ) -> Dict[str, torch.Tensor]:
-    """One optimisation step on this rank's shard: forward, backward (DDP all-reduces the gradients), update."""
+def train_step(ddp_model: torch.nn.Module, optimizer: torch.optim.Optimizer, x: torch.Tensor, y: torch.Tensor,
+               check_nan: bool = True) -> Dict[str, torch.Tensor]:
+    """One optimisation step on this rank's shard: forward, backward (DDP all-reduces the gradients), update.
+
+    ``check_nan`` reproduces the reference's ``assert not torch.isnan(loss)`` (model.py:125), which reads the loss on the
+    host (one device synchronisation between forward and backward); a throughput loop passes False and looks at the
+    returned loss whenever it logs."""
     optimizer.zero_grad(set_to_none=True)
     out = ddp_model(x, y)
-    if torch.isnan(out["loss"]):
-        raise FloatingPointError("Loss is NaN")  # the reference asserts the same (model.py:125)
+    if check_nan and torch.isnan(out["loss"]):
+        raise FloatingPointError("Loss is NaN")
     out["loss"].backward()
     optimizer.step()
     return out

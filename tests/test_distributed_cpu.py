@@ -111,3 +111,58 @@ def test_loss_composition_follows_the_reference():
     m.weights.reference_double_contrast = False
     assert m(x, y)["loss"].item() == pytest.approx(11.5)
     assert tr.shard_range(10, 0, 4) == (0, 3) and tr.shard_range(10, 3, 4) == (8, 10)
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_2_self_spawns_two_ranks_dry_run():
+    """`python bench.py --gpus 2` from a plain shell (no launcher environment) must start 2 ranks itself and report n_gpus = 2.
+    --dry-run keeps it to the launcher logic (CPU, gloo, empty step): rendezvous, barrier, max-over-ranks timing, one JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run"],
+                         capture_output=True, text=True, env=env, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["dry_run"] is True and line["backend"] == "gloo"
+    assert line["steps"] == 3 and line["warmup"] == 1 and len(line["per_rank_ms_per_step"]) == 2
+    # N = 1 stays a single process without a process group
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "0", "--dry-run"],
+                         capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["backend"] is None
+
+
+def test_optimizer_selection_rules_follow_the_reference():
+    """examples/images/classification/model.py:184-239 and examples/pointcloud/classification/model.py:245-300."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import training as tr
+
+    assert tr.select_image_optimizer_kind("resnet50", "cifar10") == "sgd"
+    assert tr.select_image_optimizer_kind("resnet50", "rotated_mnist") == "adamw"
+    assert tr.select_image_optimizer_kind("vit", "cifar10") == "adamw"
+    net = torch.nn.Linear(4, 2)
+    m = tr.CanonicalizedClassifier(ea.IdentityCanonicalization(), net)
+    opt, sched = tr.configure_optimizer(m, 1e-3, 2e-3, kind=None, max_epochs=200, prediction_network_architecture="resnet50",
+                                        dataset_name="cifar10")
+    assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["momentum"] == 0.9 and opt.param_groups[0]["weight_decay"] == 5e-4
+    assert [g["lr"] for g in opt.param_groups] == [1e-3, 2e-3] and sched.milestones == {33: 1, 66: 1, 100: 1}
+    opt, sched = tr.configure_optimizer(m, 1e-3, 2e-3, kind=None, prediction_network_architecture="vit", dataset_name="cifar10")
+    assert isinstance(opt, torch.optim.AdamW) and sched is None
+    opt, sched = tr.configure_pointcloud_optimizer(m, 1e-3, 1e-3, "SGD", "cosine", 250)
+    assert isinstance(opt, torch.optim.SGD) and opt.param_groups[0]["lr"] == pytest.approx(0.1) and opt.param_groups[0]["weight_decay"] == 1e-4
+    assert isinstance(sched, torch.optim.lr_scheduler.CosineAnnealingLR) and sched.T_max == 250 and sched.eta_min == 1e-3
+    opt, sched = tr.configure_pointcloud_optimizer(m, 1e-3, 1e-3, "SGD", "step")
+    assert isinstance(sched, torch.optim.lr_scheduler.StepLR) and sched.step_size == 20 and sched.gamma == 0.7
+    opt, sched = tr.configure_pointcloud_optimizer(m, 1e-3, 1e-3, "Adam")
+    assert isinstance(opt, torch.optim.Adam) and sched is None and opt.param_groups[0]["weight_decay"] == 1e-4
+    with pytest.raises(NotImplementedError):
+        tr.configure_pointcloud_optimizer(m, 1e-3, 1e-3, "SGD", "linear")
+    with pytest.raises(NotImplementedError):
+        tr.configure_pointcloud_optimizer(m, 1e-3, 1e-3, "RMSprop")

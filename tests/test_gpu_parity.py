@@ -1120,3 +1120,40 @@ def test_headline_geometry_end_to_end_against_oracle_fft_path(dev, group_type, N
     el = io.group_element_from_activations(acts, N, group_type, 1.0, training=False)
     _close(y, io.canonicalize_images(x, el["rotation"], el.get("reflection"), (3, 224, 224)))      # white-noise images: the
     _close(inv, io.invert_action(f, el["rotation"], el.get("reflection"), N, G, "scalar"))           # loose pixel budget
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 8), ("roto-reflection", 4)])
+def test_bench_configuration_full_width_against_oracle(dev, group_type, N):
+    """The configuration the metric is quoted on, at its own width: exactly bench.build_canonicalizer (32 fields x 8
+    orientations = 256 channels, k5, 3 layers, 224 -> crop 0.8 -> 96), 8 images so that the hidden layer runs the FFT
+    convolution on 256 channels (32 tiles, odd tile pitch, fft48_inv_fused_kernel<4,16>), plus the D4 bank of the same width.
+    Activations, group index, canonicalized images and invert(scalar) against the CPU oracle
+    (reference: examples/images/classification/configs/canonicalization/group_equivariant.yaml:3-11,
+    equiadapt/images/canonicalization_networks/escnn_networks.py:93-117)."""
+    import bench
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+    from oracle import nets as onets
+
+    can = bench.build_canonicalizer(dev, group_type=group_type, num_rotations=N)
+    net = can.canonicalization_network
+    G = can.num_group
+    assert G == 8 and net.out_channels == 32
+    B = 8
+    assert fftconv.ENABLED and fftconv.applicable(
+        torch.zeros(B, 32 * G, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 32 * G, 32 * G)
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    f = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(3))
+    with torch.no_grad():
+        y = can(x.to(dev))
+        acts = can.canonicalization_info_dict["group_activations"].cpu()
+        gidx = can.canonicalization_info_dict["group_index"].cpu().long()
+        inv = can.invert_canonicalization(f.to(dev), induced_rep_type="scalar")
+    chk = bench.oracle_check(can, x, f, y, inv, acts, gidx, group_type=group_type, num_rotations=N)
+    # tolerances of test_headline_geometry_end_to_end_against_oracle_fft_path, the activation bound RELATIVE to their scale
+    # (the random-init bench network gives activations of ~5e-3 on white noise)
+    assert chk["acts_max_err"] <= 2e-5 * chk["acts_scale"], chk
+    assert chk["index_match"] == 1.0, chk
+    assert chk["canonicalize_max_err"] <= PIX_MAX and chk["canonicalize_rms_err"] <= PIX_RMS, chk
+    assert chk["invert_max_err"] <= PIX_MAX and chk["invert_rms_err"] <= PIX_RMS, chk
+    # the random-init bench network separates the orientations of white noise only weakly: the check above must not be vacuous
+    assert chk["n_clear_margin"] >= 4, chk
