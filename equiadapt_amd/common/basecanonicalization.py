@@ -102,7 +102,10 @@ class DiscreteGroupCanonicalization(BaseCanonicalization):
     def get_identity_metric(self) -> torch.Tensor:
         """Fraction of samples mapped to the identity element (:303-311)."""
         info = self.canonicalization_info_dict
-        idx = info["group_index"] if "group_index" in info else info["group_activations"].argmax(dim=-1)
+        # argmax of the ACTIVATIONS like the reference (under gumbel_softmax "group_index" is the sampled element instead)
+        idx = info.get("argmax_index", info.get("group_index"))
+        if idx is None:
+            idx = info["group_activations"].argmax(dim=-1)
         return (idx == 0).float().mean()
 
 

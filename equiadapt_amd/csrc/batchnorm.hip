@@ -28,9 +28,11 @@ __global__ __launch_bounds__(kThreads) void bn_stats_nhwc_kernel(const float* __
   const int q0 = threadIdx.x % lanes, r0 = threadIdx.x / lanes;
   const size_t p0 = (size_t)blockIdx.x * kBnPixPerBlock;
   const size_t p1 = min(npix, p0 + kBnPixPerBlock);
-  for (int q = q0; q < Q; q += lanes) {
+  for (int qb = 0; qb < Q; qb += lanes) {      // uniform trip count: every thread reaches both barriers of every trip
+    const int q = qb + q0;
+    const bool has_q = q < Q;                   // (C / 4 > 256 and not a multiple of 256: the last trip is partial)
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
-    if (r0 < rows) {
+    if (r0 < rows && has_q) {
       for (size_t p = p0 + r0; p < p1; p += rows) {
         const float4 v = reinterpret_cast<const float4*>(x)[p * Q + q];
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_nhwc_kernel(const float* __
     s_red[0][threadIdx.x] = s;
     s_red[1][threadIdx.x] = ss;
     __syncthreads();
-    if (r0 == 0) {
+    if (r0 == 0 && has_q) {
       for (int r = 1; r < rows; ++r) {
         const float4 a = s_red[0][r * lanes + q0], b = s_red[1][r * lanes + q0];
         s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
@@ -99,10 +101,13 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
   const int q0 = threadIdx.x % lanes, r0 = threadIdx.x / lanes;
   const size_t p0 = (size_t)blockIdx.x * kBnPixPerBlock;
   const size_t p1 = min(npix, p0 + kBnPixPerBlock);
-  for (int q = q0; q < Q; q += lanes) {
-    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+  for (int qb = 0; qb < Q; qb += lanes) {      // uniform trip count (see bn_stats_nhwc_kernel)
+    const int q = qb + q0;
+    const bool has_q = q < Q;
+    const int qc = has_q ? q : 0;
+    const float4 mu = reinterpret_cast<const float4*>(mean)[qc], rs = reinterpret_cast<const float4*>(rstd)[qc];
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
-    if (r0 < rows) {
+    if (r0 < rows && has_q) {
       for (size_t p = p0 + r0; p < p1; p += rows) {
         const size_t i = p * Q + q;
         const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
@@ -126,7 +131,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
     s_red[0][threadIdx.x] = s;
     s_red[1][threadIdx.x] = sx;
     __syncthreads();
-    if (r0 == 0) {
+    if (r0 == 0 && has_q) {
       for (int r = 1; r < rows; ++r) {
         const float4 a = s_red[0][r * lanes + q0], b = s_red[1][r * lanes + q0];
         s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;

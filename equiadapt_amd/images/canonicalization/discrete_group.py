@@ -127,6 +127,11 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
             element["group_index"] = group_index
             return element
         onehot = self.groupactivations_to_groupelementonehot(group_activations, group_index)
+        if self.gradient_trick != "straight_through":
+            # gumbel_softmax: the one-hot is a random SAMPLE, not the argmax.  The reference applies the sampled element to
+            # everything (rotation / reflection are sums over this one-hot, discrete_group.py:121-133), so the fused
+            # kernels must consume the sampled index as well -- images, masks, boxes and the invert all see one element.
+            group_index = onehot.detach().argmax(dim=-1).to(torch.int32)
         element = {"rotation": torch.sum(onehot * rot_comp, dim=-1)}
         if ref_comp is not None:
             element["reflection"] = torch.sum(onehot * ref_comp, dim=-1)
@@ -145,7 +150,8 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
         if not hasattr(self, "canonicalization_info_dict"):
             self.canonicalization_info_dict = {}
         # "group_index" stays out of the element dict callers iterate over (they test `"reflection" in ...`)
-        self.canonicalization_info_dict["group_index"] = element.pop("group_index")
+        self.canonicalization_info_dict["group_index"] = element.pop("group_index")   # the element applied (sampled under gumbel)
+        self.canonicalization_info_dict["argmax_index"] = group_index                 # argmax of the activations (identity metric)
         self.canonicalization_info_dict["group_element"] = element
         self.canonicalization_info_dict["group_activations"] = group_activations
         return element
@@ -204,7 +210,7 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
                 for t in range(len(targets)):
                     targets[t]["boxes"] = rotate_boxes(targets[t]["boxes"], element["rotation"][t], image_width)
             masks = [t_["masks"] for t_ in targets]
-            if all(m.is_cuda and m.dtype == torch.uint8 and m.dim() == 3 for m in masks):
+            if all(m.is_cuda and m.dtype == torch.uint8 and m.dim() == 3 and m.shape[-2:] == masks[0].shape[-2:] for m in masks):
                 # every mask of the batch in one nearest-neighbour kernel launch, element index read on the device
                 new = canonicalize_masks(masks, gidx, self.num_rotations, flip_all=reflections)
                 for t in range(len(targets)):

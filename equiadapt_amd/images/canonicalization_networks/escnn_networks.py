@@ -111,6 +111,7 @@ class InnerBnReluDropout(torch.autograd.Function):
         # y is not kept for the backward: "kept and positive" is recomputed from h, scale, shift and the seed
         ctx.save_for_backward(h, weight, mean.repeat_interleave(E).contiguous(), rstd.repeat_interleave(E).contiguous(), scale, shift)
         ctx.E, ctx.p, ctx.seed, ctx.batch_stats = E, p_eff, seed, bool(bn.training or bn.running_mean is None)
+        ctx.has_conv_bias = conv_bias is not None
         return y
 
     @staticmethod
@@ -145,7 +146,69 @@ class InnerBnReluDropout(torch.autograd.Function):
             _lib.check(lib.eqa_bn_bwd_apply_nhwc(gy.data_ptr(), None, h.data_ptr(), mean_c.data_ptr(), rstd_c.data_ptr(),
                                                  a.data_ptr(), b.data_ptr(), d.data_ptr(), ctx.p, dh.data_ptr(), npix, C,
                                                  scale.data_ptr(), shift.data_ptr(), ctx.seed, st), "eqa_bn_bwd_apply_nhwc")
-        return dh, dweight, dbias, None, None, None, None, None
+        # With batch statistics the convolution bias cancels in the normalised output (zero gradient).  With running statistics
+        # (frozen batch-norm under autograd) it does not: out = scale * (h + conv_bias - running_mean) + ..., so
+        # d conv_bias = per-field sum of dh, as the op-by-op path and the reference propagate it.
+        dconv_bias = None
+        if ctx.has_conv_bias and ctx.needs_input_grad[5] and not ctx.batch_stats:
+            dconv_bias = dh.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1).float()
+        return dh, dweight, dbias, None, None, dconv_bias, None, None
+
+
+class _DenseConv(nn.Module):
+    """An exported dense convolution (e2cnn ``R2Conv.export()`` -> nn.Conv2d over fields x group channels, channel index =
+    field * |G| + element) behind the interface the inference fast path expects from a group convolution."""
+
+    def __init__(self, conv: nn.Conv2d, num_group_elements: int, lifting: bool):
+        super().__init__()
+        if conv.kernel_size[0] != conv.kernel_size[1] or conv.stride[0] != conv.stride[1] or conv.padding[0] != conv.padding[1] \
+                or conv.groups != 1 or conv.dilation != (1, 1) or isinstance(conv.padding, str):
+            raise ValueError("exported convolutions must be square, ungrouped, undilated, with numeric padding")
+        if conv.out_channels % num_group_elements:
+            raise ValueError(f"{conv.out_channels} output channels are not a whole number of regular fields of size {num_group_elements}")
+        self.conv = conv
+        self.num_group_elements = num_group_elements
+        self.lifting = lifting
+        self.kernel_size, self.stride, self.padding = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+        self.out_channels = conv.out_channels // num_group_elements          # fields, like the group convolutions
+
+    @property
+    def weights(self):
+        return self.conv.weight
+
+    @property
+    def bias(self):
+        return self.conv.bias                                                # per CHANNEL (fields x |G|)
+
+    def expanded_weights(self) -> torch.Tensor:
+        return self.conv.weight
+
+    def mean_response_weights(self) -> torch.Tensor:
+        w = self.conv.weight
+        ver, hit = getattr(self, "_cached_weff", (-1, None))
+        if ver != w._version or hit is None or hit.device != w.device:
+            hit = w.detach().view(self.out_channels, self.num_group_elements, -1).double().sum(0)
+            self._cached_weff = (w._version, hit)
+        return hit
+
+    def mean_bias_value(self):
+        """Per-ELEMENT mean of the bias over the fields, (|G|,) fp64: an exported bias is constant within a regular field for an
+        equivariant layer, but nothing here relies on that."""
+        b = self.conv.bias
+        if b is None:
+            return 0.0
+        ver, hit = getattr(self, "_cached_bias_mean", (-1, None))
+        if ver != b._version or hit is None:
+            m = b.detach().double().view(self.out_channels, self.num_group_elements).mean(0)
+            hit = float(m[0].item()) if bool((m == m[0]).all().item()) else m
+            self._cached_bias_mean = (b._version, hit)
+        return hit
+
+    def supports_linear_tail(self) -> bool:
+        return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.conv(x)
 
 
 class ESCNNEquivariantNetwork(nn.Module):
@@ -180,12 +243,55 @@ class ESCNNEquivariantNetwork(nn.Module):
         self._fold_cache: dict = {}
 
     def load_exported_dense(self, convs: Sequence[nn.Conv2d], norms: Sequence[nn.BatchNorm2d]) -> None:
-        """Use e2cnn-exported dense layers (Conv2d / BatchNorm2d lists in network order) instead of the
-        filter-bank parameterisation.  Inference only."""
+        """Use exported dense layers (lists in network order) instead of the filter-bank parameterisation: the bridge for
+        weights trained with e2cnn, whose steerable-basis parameters cannot be loaded by key (``R2Conv.export()`` ->
+        ``nn.Conv2d`` over fields x |G| channels, ``InnerBatchNorm.export()`` -> ``nn.BatchNorm2d``; reference network:
+        escnn_networks.py:48-91).  Inference runs through the same fast path as the filter-bank form (FFT / Winograd / MFMA
+        lifting layer, folded batch-norms, linearised last layer); with autograd the plain modules are used."""
         n_conv = sum(1 for m in self.eqv_network if hasattr(m, "expanded_weights"))
         if len(convs) != n_conv or len(norms) != n_conv - 1:
             raise ValueError(f"expected {n_conv} convs and {n_conv - 1} norms")
-        self._dense = (nn.ModuleList(convs), nn.ModuleList(norms))
+        E = self.num_group_elements
+        cin = self.in_channels
+        for i, cv in enumerate(convs):
+            if cv.in_channels != cin:
+                raise ValueError(f"exported conv {i} takes {cv.in_channels} channels, the network feeds it {cin}")
+            cin = cv.out_channels
+        for i, bn in enumerate(norms):
+            if bn.num_features != convs[i].out_channels:
+                raise ValueError(f"exported norm {i} has {bn.num_features} features, conv {i} produces {convs[i].out_channels}")
+        self._dense = (nn.ModuleList(_DenseConv(cv, E, i == 0) for i, cv in enumerate(convs)), nn.ModuleList(norms))
+        self._fold_cache.clear()
+
+    def export_dense(self):
+        """(convs, norms): this network's layers in the exported dense form -- expanded filter banks as ``nn.Conv2d`` (bias per
+        channel), InnerBatchNorm as ``nn.BatchNorm2d`` with every per-field quantity repeated |G| times -- i.e. what
+        ``load_exported_dense`` takes.  Eval-mode equivalent of the filter-bank network."""
+        E = self.num_group_elements
+        convs, norms = [], []
+        with torch.no_grad():
+            for m in self.eqv_network:
+                if hasattr(m, "expanded_weights"):
+                    bank = m.expanded_weights().detach()
+                    cv = nn.Conv2d(bank.shape[1], bank.shape[0], m.kernel_size, m.stride, m.padding, bias=m.bias is not None)
+                    cv = cv.to(bank.device)
+                    cv.weight.copy_(bank)
+                    if m.bias is not None:
+                        cv.bias.copy_(m.bias.detach().repeat_interleave(E))
+                    convs.append(cv)
+                elif isinstance(m, _InnerBatchNorm):
+                    bn = nn.BatchNorm2d(m.num_features * E, eps=m.eps, momentum=m.momentum).to(m.weight.device)
+                    for name in ("weight", "bias", "running_mean", "running_var"):
+                        getattr(bn, name).copy_(getattr(m, name).repeat_interleave(E))
+                    norms.append(bn.eval())
+        return convs, norms
+
+    def _layers(self):
+        """(convs, norms) the forward paths iterate over: the exported dense layers if loaded, else the group convolutions."""
+        if self._dense:
+            return list(self._dense[0]), list(self._dense[1])
+        mods = list(self.eqv_network)
+        return [m for m in mods if hasattr(m, "expanded_weights")], [m for m in mods if isinstance(m, _InnerBatchNorm)]
 
     # -- inference fast path ------------------------------------------------------------------------------------
     def _folded(self, conv, bn):
@@ -197,11 +303,13 @@ class ESCNNEquivariantNetwork(nn.Module):
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
         E = conv.num_group_elements
-        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)                    # per field
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)                    # per field (per channel: exported form)
         shift = bn.bias - bn.running_mean * scale
-        bank = conv.expanded_weights() * scale.repeat_interleave(E)[:, None, None, None]
         b = conv.bias if conv.bias is not None else torch.zeros_like(scale)
-        bias = (b * scale + shift).repeat_interleave(E)
+        bias = b * scale + shift
+        if not isinstance(conv, _DenseConv):
+            scale, bias = scale.repeat_interleave(E), bias.repeat_interleave(E)
+        bank = conv.expanded_weights() * scale[:, None, None, None]
         # channels-last: MIOpen's fp32 implicit-GEMM kernels are NHWC; keeping the bank (and the activations) in that
         # layout removes the NCHW<->NHWC transposes around every convolution
         bank, bias = bank.contiguous(memory_format=torch.channels_last), bias.contiguous()
@@ -238,9 +346,7 @@ class ESCNNEquivariantNetwork(nn.Module):
         """eval + no_grad: conv(+folded BN) -> ReLU ... -> [last conv + group mean as window sums]."""
         from equiadapt_amd import ops
 
-        mods = list(self.eqv_network)
-        convs = [m for m in mods if hasattr(m, "expanded_weights")]
-        norms = [m for m in mods if isinstance(m, _InnerBatchNorm)]
+        convs, norms = self._layers()
         nhwc = (self.out_channels * self.num_group_elements) % 4 == 0
         h = x.contiguous(memory_format=torch.channels_last) if nhwc else x
         pending = None  # bias of the previous layer whose (bias + ReLU) has not been applied to `h` yet
@@ -386,10 +492,11 @@ class ESCNNEquivariantNetwork(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if (self.training or torch.is_grad_enabled()) and self._training_fast_path_ok(x):
             return self._forward_training(x)
-        if (not self._dense and not self.training and not torch.is_grad_enabled() and x.is_cuda
-                and self.eqv_network[-1].supports_linear_tail()):
-            hw = (x.shape[-2] - (self.kernel_size - 1) * (len([m for m in self.eqv_network if hasattr(m, "expanded_weights")]) - 1))
-            if 0 < hw and hw * hw <= 12288:
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
+            convs, norms = self._layers()
+            hw = x.shape[-2] - (self.kernel_size - 1) * (len(convs) - 1)
+            if (convs[-1].supports_linear_tail() and 0 < hw and hw * hw <= 12288 and all(n.running_mean is not None for n in norms)
+                    and all(c.stride == 1 and c.padding == 0 and c.kernel_size == self.kernel_size for c in convs)):
                 return self._forward_inference(x)
         if self._dense:
             convs, norms = self._dense

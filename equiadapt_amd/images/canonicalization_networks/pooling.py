@@ -53,7 +53,8 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
         return ops.window_sums_gemv(S.flatten(1), weff, scale, layer.mean_bias_value())
     act = S.flatten(1) @ weff.t() * scale
     if layer.bias is not None:
-        act = act + layer.bias.detach().double().mean()
+        mb = layer.mean_bias_value()                                    # a float, or one value per element (exported dense form)
+        act = act + (mb if isinstance(mb, float) else mb.to(act.device))
     return act.float()
 
 

@@ -111,3 +111,31 @@ def escnn_like_network(x: torch.Tensor, sd: Dict[str, torch.Tensor], group_type:
                              False, 0.9, 1e-5)
             h = F.relu(h)
     return torch.mean(h, dim=(1, 3, 4))
+
+
+def conv_network(x: torch.Tensor, sd: Dict[str, torch.Tensor], num_layers: int, training: bool = False,
+                 dropout_p: float = 0.5, momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+    """ConvNetwork.forward (custom_nonequivariant_networks.py:19-80), functional on a reference-named ``state_dict``
+    (enc_network.{3i}.{weight,bias}, enc_network.{3i+1}.{weight,bias,running_mean,running_var}, final_fc.0.*, final_fc.3.*).
+
+    :44-57  layer i: Conv2d(stride 2; padding 1 exactly when i % 3 == 2, else 0) -> BatchNorm2d -> GELU (erf form);
+    :70-80  reshape(B, -1) -> BatchNorm1d -> Dropout1d(0.5) -> ReLU -> Linear.
+    ``training`` uses batch statistics and updates the running statistics IN ``sd`` (momentum 0.1, unbiased variance), like
+    the modules; Dropout1d on a 2-D (B, D) input is the reference's call as written: torch treats it as one unbatched
+    (C, L) sample and zeroes whole ROWS (samples) -- pass ``dropout_p=0`` for a deterministic train-mode comparison."""
+    h = x
+    for i in range(num_layers):
+        c, b = f"enc_network.{3 * i}.", f"enc_network.{3 * i + 1}."
+        h = F.conv2d(h, sd[c + "weight"], sd.get(c + "bias"), stride=2, padding=1 if i % 3 == 2 else 0)
+        h = F.batch_norm(h, sd[b + "running_mean"], sd[b + "running_var"], sd[b + "weight"], sd[b + "bias"], training, momentum, eps)
+        if training and b + "num_batches_tracked" in sd:
+            sd[b + "num_batches_tracked"] += 1
+        h = F.gelu(h)
+    h = h.reshape(x.shape[0], -1)
+    h = F.batch_norm(h, sd["final_fc.0.running_mean"], sd["final_fc.0.running_var"], sd["final_fc.0.weight"], sd["final_fc.0.bias"],
+                     training, momentum, eps)
+    if training and "final_fc.0.num_batches_tracked" in sd:
+        sd["final_fc.0.num_batches_tracked"] += 1
+    h = F.dropout1d(h, dropout_p, training)
+    h = F.relu(h)
+    return F.linear(h, sd["final_fc.3.weight"], sd["final_fc.3.bias"])

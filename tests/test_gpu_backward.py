@@ -255,6 +255,18 @@ def test_escnn_training_fast_path_matches_module_path(dev, size, monkeypatch):
     monkeypatch.setenv("EQA_TRAIN_FAST", "0")
     b2 = ref(x.to(rdt))
     assert (b1 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1.0)
+    # frozen batch-norm fine-tuning (running statistics under autograd): the hidden convolution biases do NOT cancel any more
+    # -- out = scale * (h + conv_bias - running_mean) + beta -- and must receive the gradient the module path gives them
+    monkeypatch.delenv("EQA_TRAIN_FAST")
+    net.zero_grad()
+    ref.zero_grad()
+    (b1 * w).sum().backward()
+    (b2 * w.to(rdt)).sum().backward()
+    for (n1, p1), (n2, p2) in zip(net.named_parameters(), ref.named_parameters()):
+        g = p2.grad.abs().max().item()
+        assert g > 1e-6, n1
+        rtol = 5e-5 if size == 96 else 3e-3
+        assert (p1.grad - p2.grad).abs().max().item() <= rtol * g, ("frozen bn", n1, (p1.grad - p2.grad).abs().max().item(), g)
 
 
 @pytest.mark.gpu
@@ -573,3 +585,30 @@ def test_lift_conv_weight_gradient_matches_conv2d_weight(dev):
     assert not ops.lift_conv_wgrad_supported(x, 256, 7, 7)         # 147 taps
     with pytest.raises(Exception):
         ops.lift_conv_wgrad_nhwc(x, torch.zeros(2, 64, 92, 92, device=dev).contiguous(memory_format=torch.channels_last), 5, 5)
+
+
+@pytest.mark.gpu
+def test_fused_bn_block_wide_channels_partial_last_trip(dev):
+    """C = 1536 (D8 with 96 fields): C / 4 = 384 channel quads > 256 threads and not a multiple of 256, so the statistics and
+    backward-reduce kernels make two trips over the quads, the second one partial.  Every thread must still reach both
+    barriers of both trips (uniform trip count) and the partial trip must be correct."""
+    from equiadapt_amd.images.canonicalization_networks.escnn_networks import ESCNNEquivariantNetwork, InnerBnReluDropout, _InnerBatchNorm
+
+    torch.manual_seed(72)
+    E, Fd, B, H, W = 16, 96, 3, 7, 5
+    h = (torch.randn(B, Fd * E, H, W, device=dev) * 1.5 + 0.25).contiguous(memory_format=torch.channels_last)
+    bn1, bn2 = _InnerBatchNorm(Fd, momentum=0.9).to(dev).train(), _InnerBatchNorm(Fd, momentum=0.9).to(dev).train()
+    for bn in (bn1, bn2):
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, Fd)); bn.bias.copy_(torch.linspace(-0.3, 0.3, Fd))
+    h1, h2 = h.clone().requires_grad_(True), h.clone().requires_grad_(True)
+    y1 = InnerBnReluDropout.apply(h1, bn1.weight, bn1.bias, bn1, E, None, 0.5, False)
+    y2 = torch.relu(ESCNNEquivariantNetwork._inner_bn(h2, bn2, E, None))
+    assert torch.allclose(y1, y2, atol=2e-5)
+    w = torch.randn_like(h)
+    (y1 * w).sum().backward()
+    (y2 * w).sum().backward()
+    assert torch.allclose(h1.grad, h2.grad, atol=2e-4 * h2.grad.abs().max().item())
+    assert torch.allclose(bn1.weight.grad, bn2.weight.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(bn1.bias.grad, bn2.bias.grad, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(bn1.running_mean, bn2.running_mean, atol=1e-5) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)

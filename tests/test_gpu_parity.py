@@ -492,6 +492,7 @@ def test_optimized_canonicalizer_end_to_end(dev, group_type, N):
                                artifact_err_wt=0.0, learn_ref_vec=False)
     can = ea.OptimizedGroupEquivariantImageCanonicalization(net, hp, (3, 64, 64))
     cpu_net, ref_vec = copy.deepcopy(net).eval(), can.reference_vector.detach().clone()
+    sd_net = {k: v.clone() for k, v in net.state_dict().items()}
     can = can.to(dev).eval()
     x = torch.randn(6, 3, 64, 64)
     with torch.no_grad():
@@ -502,8 +503,9 @@ def test_optimized_canonicalizer_end_to_end(dev, group_type, N):
         # oracle
         xin = io.pre_canonicalization_transform(x, (3, 64, 64), 0.8, 32)
         orbit = io.orbit_expand(xin, N, group_type, 32)
-        vec = cpu_net(orbit)
-        acts_ref = io.optimized_group_activations(vec, ref_vec, G)
+        from oracle import nets as onets
+        vec = onets.conv_network(orbit, sd_net, 2, training=False)      # the oracle restatement of ConvNetwork (pinned to the
+        acts_ref = io.optimized_group_activations(vec, ref_vec, G)      # reference's own class by tests/golden/conv_network.pt)
         loss_ref = io.optimization_specific_loss(vec, G, 16)
     assert acts.shape == (6, G)
     assert torch.allclose(acts, acts_ref, atol=2e-4, rtol=1e-3)
@@ -1157,3 +1159,66 @@ def test_bench_configuration_full_width_against_oracle(dev, group_type, N):
     assert chk["invert_max_err"] <= PIX_MAX and chk["invert_rms_err"] <= PIX_RMS, chk
     # the random-init bench network separates the orientations of white noise only weakly: the check above must not be vacuous
     assert chk["n_clear_margin"] >= 4, chk
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 8), ("roto-reflection", 4)])
+def test_load_exported_dense_round_trip_and_fast_path(dev, group_type, N):
+    """The bridge for e2cnn-trained weights (escnn_networks.py:48-91 export to Conv2d / BatchNorm2d): this network's own layers
+    exported to the dense form and loaded into a second instance give the same activations -- through the inference fast
+    path (FFT convolution on the 64-channel hidden layer, MFMA lifting layer, linearised tail), through the plain dense
+    modules, and against the CPU oracle driven by the filter-bank state dict."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+    from oracle import nets as onets
+
+    torch.manual_seed(77)
+    net = ea.ESCNNEquivariantNetwork((3, 96, 96), 8, 5, group_type, N, 3)
+    for m in net.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.normal_(0.1, 0.2)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.normal_(0, 0.2)
+    with torch.no_grad():
+        for m in net.eqv_network:
+            if hasattr(m, "expanded_weights"):
+                m.bias.normal_(0, 0.1)
+    net = net.to(dev).eval()
+    G = net.num_group_elements
+    convs, norms = net.export_dense()
+    assert [c.weight.shape for c in convs] == [(8 * G, 3, 5, 5), (8 * G, 8 * G, 5, 5), (8 * G, 8 * G, 5, 5)]
+    other = ea.ESCNNEquivariantNetwork((3, 96, 96), 8, 5, group_type, N, 3).to(dev).eval()
+    other.load_exported_dense(convs, norms)
+    x = torch.randn(9, 3, 96, 96)
+    calls = []
+    orig = fftconv.conv5x5
+    fftconv.conv5x5 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            want = net(x.to(dev)).cpu()
+            n0 = len(calls)
+            got = other(x.to(dev)).cpu()
+        assert n0 == 1 and len(calls) == 2, "the dense form did not take the FFT fast path"
+    finally:
+        fftconv.conv5x5 = orig
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 1e-6 * scale, ((got - want).abs().max().item(), scale)
+    with torch.enable_grad():                                             # plain dense modules (autograd on)
+        mod = other(x.to(dev)).detach().cpu()
+    assert (mod - want).abs().max().item() <= 2e-5 * scale
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    ref = onets.escnn_like_network(x, sd, group_type, N, 3, 8)
+    assert (got - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1.0)
+    # a per-channel bias that is NOT constant within a field (not what an equivariant export produces, but legal input)
+    with torch.no_grad():
+        convs[-1].bias.add_(torch.randn_like(convs[-1].bias))
+    other.load_exported_dense(convs, norms)
+    with torch.no_grad():
+        fast = other(x.to(dev)).cpu()
+    with torch.enable_grad():
+        mod = other(x.to(dev)).detach().cpu()
+    assert (fast - mod).abs().max().item() <= 2e-5 * max(mod.abs().max().item(), 1.0)
+    with pytest.raises(ValueError):
+        other.load_exported_dense(convs[:2], norms)
+    with pytest.raises(ValueError):
+        other.load_exported_dense([convs[0], convs[0], convs[2]], norms)

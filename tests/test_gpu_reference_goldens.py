@@ -1,0 +1,231 @@
+"""Reference-GENERATED training-mode vectors through the PRODUCT on the GPU.
+
+tests/golden/{discrete_group,vn_layers,pointcloud}.pt were produced by running the unmodified reference files
+(tests/golden/make_golden.py).  tests/test_oracle_golden.py pins the CPU oracle to them; here the same vectors go through
+the shipped classes on the device, so the GPU training fast paths are compared with the reference itself and not with this
+repo's own op-by-op path:
+
+  * discrete_group.pt  -> DiscreteGroupCanonicalization.groupactivations_to_groupelementonehot (train + eval, the engineered
+                          tie, the straight-through gradient), prior loss, identity metric
+                          (reference: equiadapt/common/basecanonicalization.py:221-256, 290-311)
+  * vn_layers.pt       -> VNLinearLeakyReLU / VNBatchNorm / VNMaxPool, eval and train mode
+                          (reference: pointcloud/canonicalization_networks/vector_neuron_layers.py:251-364)
+  * pointcloud.pt      -> VNSmall.train() on the fused first block (csrc/vnsmall_train.hip) incl. the running statistics
+                          after the step, and pooling="max" through the fused eval kernel
+                          (reference: pointcloud/canonicalization_networks/equivariant_networks.py:128-150)
+"""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    from equiadapt_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def test_discrete_onehot_ste_gradient_and_losses_on_product(dev, golden):
+    from equiadapt_amd.common.basecanonicalization import DiscreteGroupCanonicalization
+
+    g = golden("discrete_group.pt")
+    assert g["provenance"] == "reference"
+
+    class _Disc(DiscreteGroupCanonicalization):
+        pass
+
+    acts = g["acts"]
+    d = _Disc(torch.nn.Identity(), beta=g["beta"]).to(dev)
+    d.num_group = 8
+    for mode in ("eval", "train"):
+        d.train(mode == "train")
+        a = acts.to(dev).clone().requires_grad_(True)
+        oh = d.groupactivations_to_groupelementonehot(a)
+        assert torch.equal(oh.detach().cpu(), g["cases"][mode]["onehot"]), mode      # hard + soft - soft == hard bit for bit
+        if mode == "train":
+            (oh * torch.arange(8.0, device=dev)).sum().backward()
+            assert torch.allclose(a.grad.cpu(), g["cases"][mode]["grad"], atol=2e-7, rtol=1e-6)
+        else:
+            assert not oh.requires_grad          # eval mode returns the bare one-hot: no graph, as in the reference
+    # the engineered tie at row 3 (columns 2 and 5): the wavefront-shuffle argmax takes the first index, like torch.argmax
+    assert d.group_index(acts.to(dev))[3].item() == 2
+    d.device = dev
+    d.canonicalization_info_dict = {"group_activations": acts.to(dev)}
+    assert torch.allclose(d.get_prior_regularization_loss().cpu(), g["prior_loss"], atol=1e-6, rtol=1e-6)
+    assert torch.equal(d.get_identity_metric().cpu(), g["identity_metric"])
+    d.canonicalization_info_dict["group_index"] = d.group_index(acts.to(dev))
+    assert torch.equal(d.get_identity_metric().cpu(), g["identity_metric"])
+
+
+def test_image_group_element_rotation_sums_match_reference_onehot(dev, golden):
+    """discrete_group.py:94-135 on the product class: rotation = sum(onehot * angles), reflection = sum(onehot * indicator),
+    train mode (STE one-hot) and eval mode (table lookups) against the reference-generated one-hots."""
+    import equiadapt_amd as ea
+
+    g = golden("discrete_group.pt")
+    acts = g["acts"].to(dev)
+
+    class _Net(torch.nn.Module):
+        group_type, num_rotations = "roto-reflection", 4
+
+    hp = types.SimpleNamespace(beta=g["beta"], input_crop_ratio=1.0, resize_shape=16)
+    can = ea.GroupEquivariantImageCanonicalization(_Net(), hp, (3, 16, 16)).to(dev)
+    ang = torch.tensor([0.0, 90.0, 180.0, 270.0] * 2)
+    ind = torch.tensor([0.0] * 4 + [1.0] * 4)
+    for mode in ("eval", "train"):
+        can.train(mode == "train")
+        el = can.groupactivations_to_groupelement(acts.clone().requires_grad_(mode == "train"))
+        oh = g["cases"][mode]["onehot"]
+        assert torch.equal(el["rotation"].detach().cpu(), (oh * ang).sum(-1)), mode
+        assert torch.equal(el["reflection"].detach().cpu(), (oh * ind).sum(-1)), mode
+        assert torch.equal(el["group_index"].cpu().long(), oh.argmax(-1)), mode
+
+
+def test_gumbel_softmax_element_is_applied_consistently(dev):
+    """gradient_trick='gumbel_softmax': the one-hot is a sample.  Image, reported rotation / reflection, masks and the invert
+    must all use THAT element (the reference sums over the sampled one-hot, discrete_group.py:121-133)."""
+    import equiadapt_amd as ea
+    from oracle import image_ops as io
+
+    class _FlatNet(torch.nn.Module):       # near-equal activations: the Gumbel noise decides, so sample != argmax for most images
+        group_type, num_rotations = "roto-reflection", 4
+
+        def forward(self, x):
+            return x.mean(dim=(1, 2, 3))[:, None] * 1e-3 + torch.linspace(0.0, 0.01, 8, device=x.device)[None]
+
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=16)
+    can = ea.GroupEquivariantImageCanonicalization(_FlatNet(), hp, (3, 32, 32)).to(dev).eval()
+    can.gradient_trick = "gumbel_softmax"      # an attribute, as in the reference (basecanonicalization.py:203-219)
+    x = torch.randn(64, 3, 32, 32)
+    masks = [(torch.rand(2, 32, 32) > 0.5).to(torch.uint8) for _ in range(64)]
+    torch.manual_seed(5)
+    with torch.no_grad():
+        targets = [{"boxes": torch.tensor([[2.0, 3.0, 20.0, 25.0]], device=dev), "masks": m.to(dev)} for m in masks]
+        y, t = can(x.to(dev), targets)
+        info = can.canonicalization_info_dict
+        gidx = info["group_index"].cpu().long()
+        rot, refl = info["group_element"]["rotation"].cpu(), info["group_element"]["reflection"].cpu()
+        inv = can.invert_canonicalization(torch.randn(64, 8, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev))
+    amax = info["group_activations"].argmax(-1).cpu()
+    assert (gidx != amax).sum() >= 16, "the sample never left the argmax: the test would be vacuous"
+    ang = torch.tensor([0.0, 90.0, 180.0, 270.0] * 2)
+    assert torch.equal(rot, ang[gidx]) and torch.equal(refl, (gidx >= 4).float())
+    assert (y.cpu() - io.canonicalize_images(x, rot, refl, (3, 32, 32))).abs().max().item() <= 1e-3
+    f = torch.randn(64, 8, 32, 32, generator=torch.Generator().manual_seed(1))
+    assert (inv.cpu() - io.invert_action(f, rot, refl, 4, 8, "regular")).abs().max().item() <= 1e-3
+    for i in (0, 7, 33):
+        want = io.rotate_masks(io.flip_masks(masks[i]), -rot[i].item())
+        assert torch.equal(t[i]["masks"].cpu(), want), i
+    # the identity metric stays the reference's: argmax of the activations (basecanonicalization.py:303-311)
+    assert torch.equal(can.get_identity_metric().cpu(), (amax == 0).float().mean())
+
+
+def test_vn_layers_on_product_match_reference(dev, golden):
+    from equiadapt_amd.pointcloud.canonicalization_networks.vector_neuron_layers import VNBatchNorm, VNLinearLeakyReLU, VNMaxPool
+
+    g = golden("vn_layers.pt")
+    assert g["provenance"] == "reference"
+    lay = VNLinearLeakyReLU(3, 21, dim=5, negative_slope=0.0)
+    lay.load_state_dict(g["lin_state"])
+    lay = lay.to(dev).eval()
+    x5 = g["lin_in"].to(dev)
+    with torch.no_grad():
+        assert torch.allclose(lay(x5).cpu(), g["lin_out_eval"], atol=2e-6, rtol=1e-5)
+    lay.train()
+    out = lay(x5)                                   # grad enabled: the 3-channel maps take the fused multiply-add form
+    assert torch.allclose(out.detach().cpu(), g["lin_out_train"], atol=1e-5, rtol=1e-5)
+    with torch.no_grad():
+        lay.load_state_dict(g["lin_state"])
+        assert torch.allclose(lay(x5).cpu(), g["lin_out_train"], atol=1e-5, rtol=1e-5)       # and the GEMM form
+    bn = VNBatchNorm(21, dim=4)
+    bn.load_state_dict(g["bn_state"])
+    bn = bn.to(dev).eval()
+    with torch.no_grad():
+        assert torch.allclose(bn(g["bn_in"].to(dev)).cpu(), g["bn_out_eval"], atol=2e-6, rtol=1e-5)
+    mp = VNMaxPool(21)
+    mp.load_state_dict(g["pool_state"])
+    mp = mp.to(dev)
+    with torch.no_grad():
+        got = mp(g["pool_in"].to(dev)).cpu()
+    # an argmax over <x, d>: a last-bit difference of the device GEMM can move a near-tie, so the picks must agree almost
+    # everywhere, and wherever they differ the picked sample must still be a maximiser of the score to rounding
+    same = (got == g["pool_out"]).all(dim=2)                                        # (B, C, N)
+    assert same.float().mean().item() >= 0.99
+    d = torch.nn.functional.linear(g["pool_in"].transpose(1, -1), g["pool_state"]["map_to_dir.weight"]).transpose(1, -1)
+    score = (g["pool_in"] * d).sum(2)                                               # (B, C, N, k)
+    idx_got = (g["pool_in"] == got.unsqueeze(-1)).all(dim=2).float().argmax(-1)     # which sample the device picked
+    got_score = torch.gather(score, -1, idx_got.unsqueeze(-1)).squeeze(-1)
+    assert (score.max(dim=-1).values - got_score).abs().max().item() <= 1e-5 * score.abs().max().item()
+    assert torch.equal(g["pool_in"].to(dev).mean(-1).cpu(), g["mean_pool_out"])
+
+
+def test_vnsmall_train_mode_fused_first_block_matches_reference(dev, golden):
+    """pointcloud.pt["mean_train"]: VNSmall in train() (batch statistics, dropout p = 0 as in the generator) on the fused
+    first block; output and every running statistic after the step against the reference's."""
+    import equiadapt_amd as ea
+
+    t = golden("pointcloud.pt")["mean_train"]
+    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    for fast in ("1", "0"):
+        net = ea.VNSmall(hp)
+        net.load_state_dict(t["state"])
+        net.dropout.p = 0.0
+        net = net.to(dev).train()
+        import os
+        old = os.environ.get("EQA_TRAIN_FAST")
+        os.environ["EQA_TRAIN_FAST"] = fast
+        try:
+            out = net(t["x"].to(dev))
+        finally:
+            if old is None:
+                os.environ.pop("EQA_TRAIN_FAST", None)
+            else:
+                os.environ["EQA_TRAIN_FAST"] = old
+        assert out.requires_grad
+        assert torch.allclose(out.detach().cpu(), t["vnsmall_out"], atol=1e-5, rtol=1e-4), fast
+        after = {k: v.cpu() for k, v in net.state_dict().items()}
+        for k, v in t["state_after"].items():
+            if v.dtype.is_floating_point:
+                assert torch.allclose(after[k], v, atol=1e-6, rtol=1e-5), (fast, k)
+            else:
+                assert torch.equal(after[k], v), (fast, k)
+        out.sum().backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_conv_network_on_product_matches_reference_golden(dev, golden):
+    """Row I10 (custom_nonequivariant_networks.py:19-80): the product's ConvNetwork on the device against vectors generated by the
+    reference's own class -- eval mode (the folded-batch-norm inference path), train mode with batch statistics (Dropout1d
+    disabled as in the generator), the running statistics after the step and every parameter gradient."""
+    import equiadapt_amd as ea
+
+    g = golden("conv_network.pt")
+    for c in g["cases"]:
+        in_shape, oc, k, L, V = c["args"]
+        net = ea.ConvNetwork(in_shape, oc, k, L, V)
+        net.load_state_dict(c["state"])
+        net = net.to(dev).eval()
+        x = c["x"].to(dev)
+        with torch.no_grad():
+            out = net(x).cpu()
+        scale = c["out_eval"].abs().max().item()
+        assert (out - c["out_eval"]).abs().max().item() <= 2e-5 * scale, c["args"]
+        with torch.enable_grad():                                  # eval mode with autograd: the module path
+            assert (net(x).detach().cpu() - c["out_eval"]).abs().max().item() <= 2e-5 * scale, c["args"]
+        net.train()
+        net.final_fc[1].p = 0.0
+        out = net(x)
+        assert (out.detach().cpu() - c["out_train"]).abs().max().item() <= 1e-4 * c["out_train"].abs().max().item(), c["args"]
+        (out * c["upstream"].to(dev)).sum().backward()
+        after = net.state_dict()
+        for k_, v in c["state_after_train"].items():
+            assert torch.allclose(after[k_].cpu().float(), v.float(), atol=1e-5, rtol=1e-4), (c["args"], k_)
+        for n, p in net.named_parameters():
+            want = c["grads"][n]
+            assert (p.grad.cpu() - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-6, (c["args"], n)
