@@ -1,0 +1,330 @@
+// libeqa_hip.so, part 10 -- the channel contraction of the overlap-save FFT convolution (I2a) as a hand-written batched
+// COMPLEX GEMM on the fp32 matrix cores, 3-multiplication form.  C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+//
+// Per stored frequency f:  Mo[f] (M x Cout, complex) = V[f] (M x Cin, complex) . B[f] (Cin x Cout, complex).  Through the GEMM
+// library this ran as a real [M x 2Cin].[2Cin x 2Cout] product -- 4 real multiplies per complex one -- at 135-138 TFLOP/s, i.e.
+// at what the fp32 MFMA delivers at the clock the chip holds: only fewer multiplies can make it faster.  Here
+//     T1 = Ar.Br    T2 = Ai.Bi    T3 = (Ar + Ai).(Br + Bi)          Cr = T1 - T2    Ci = T3 - T1 - T2
+// three real products instead of four (-25 % MFMA work) at unchanged HBM traffic: Br + Bi is precomputed once per weight
+// version (eqa_fft48k5_filter_spectra3m), Ar + Ai is formed in registers from the loaded operands (16 adds per 96 MFMAs).
+//
+// v_mfma_f32_32x32x2_f32 issues once per 64 cycles per SIMD and eats one operand register of A and of B each time: the
+// matrix pipe is 16x slower than for bf16, so the operand traffic per MFMA cycle is tiny -- a wave's 64 x 64 (complex) tile needs
+// 20 KB of operands per 6144 cycles of MFMA issue.  Hence NO LDS and NO barriers: every wave is its own pipeline (one wave per
+// SIMD, up to 512 registers), loads its MFMA operand fragments straight from global memory / L2 into registers -- 16 bytes per
+// lane, one K-stage (16 complex k) ahead, double-buffered -- and keeps three accumulator sets (T1, T2, T3: 192 registers).
+// The MFMA sums over k in any order, so a lane's 16 bytes are simply 4 consecutive channels of its row of V:
+//   A fragment: lane l = 32 h + i holds V[row i][channel 16 s + 8 b + 4 h + t], t = 0..3 (b = 0, 1: two loads per stage)
+//   B fragment: lane l = 32 h + j holds B[k = 16 s + 8 b + 4 h + t][col j] -- B3 is stored in exactly this fragment order, so
+//               a wave's B loads are contiguous 1 KB runs
+// and MFMA step (b, t) multiplies the k-pair {16 s + 8 b + t, 16 s + 8 b + 4 + t}.
+// Epilogue.  Stored straight from the accumulator layout a tile is 64 eight-byte stores per lane, and the CU's store path takes
+// ~90 cycles per such instruction: 23 k cycles per tile during which the wave's matrix pipe idles (measured with
+// tools/micro/cgemm3m_bench.hip: 4.08 ms with, 3.46 ms without the stores).  So a finished tile is only COMBINED
+// (Cr = T1 - T2, Ci = T3 - T1 - T2) and parked in the wave's private 32 KB of LDS (64 ds_write_b64, ~1.5 k cycles); it leaves
+// for HBM during the NEXT tile's MFMA stream, two whole 512-byte rows per ds_read_b128 + global_store_dwordx4 pair, 32 / S pairs
+// per K-stage -- LDS and store instructions issue in the shadow of the 64-cycle MFMAs.
+// Work: wave-tile = (frequency, 64 rows, 64 complex columns); the 4 waves of a block take the column tiles of one (f, row tile)
+// (they share the rows of V through L1 / L2); the frequencies are dealt to the XCDs (f mod 8, block b runs on XCD b mod 8) so that a
+// frequency's B panel (0.79 MB at 256 channels) is read from HBM once and then served by that XCD's L2 to its 16 row tiles.
+#include "eqa_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef EQA_CGEMM_CLOCK   // experiment (tools/micro/cgemm3m_bench.hip): shader-cycle stamps per wave [total, stage loops, epilogues, tiles]
+__device__ unsigned long long g_cg_clock[1024 * 4];
+#define CG_STAMP(x) const unsigned long long x = __builtin_readcyclecounter()
+#else
+#define CG_STAMP(x)
+#endif
+
+constexpr int kTileM = 64, kTileN = 64;   // wave tile: rows (tiles of the FFT convolution) x complex output channels
+constexpr int kStageK = 16;               // complex k per stage = one [Re x 16 | Im x 16] group of V
+
+struct OperandSet {                       // one K-stage of MFMA operands: 80 registers
+  f32x4 ar[2][2], ai[2][2];               // [m][b]
+  f32x4 b[3][2][2];                       // [part r/i/s][n][b]
+};
+
+// Operand loads go through buffer descriptors: a wave-uniform descriptor (one frequency of V / of B3, rebuilt per tile by scalar
+// code) + a scalar byte offset (the K-stage, advanced by scalar adds) + a 32-bit lane offset that is constant within a tile.
+// No vector address arithmetic in the MFMA stream (a VALU instruction there costs ~6 MFMA cycles), and rows beyond the buffer
+// read as zero instead of needing a clamp.
+struct StageAddr {
+  __amdgpu_buffer_rsrc_t a, b;   // V[f] (pitch rows), B3[f]
+  unsigned sa, sb;               // byte offsets of the stage: in a row of V; in B3[f] incl. the wave's column tile
+};
+
+__device__ __forceinline__ f32x4 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ void load_stage(OperandSet& o, const StageAddr& at, unsigned aoff0, unsigned aoff1, unsigned boff) {
+  // aoff0 / aoff1: byte offset of this lane's row (the two 32-row subtiles) + 16 h; boff = 16 * lane.
+  // In the order the MFMAs consume them: everything of k-block b = 0, then b = 1.
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    o.ar[0][b] = buf_ld(at.a, aoff0 + 32 * b, at.sa);
+    o.ai[0][b] = buf_ld(at.a, aoff0 + 32 * b + 64, at.sa);
+    o.ar[1][b] = buf_ld(at.a, aoff1 + 32 * b, at.sa);
+    o.ai[1][b] = buf_ld(at.a, aoff1 + 32 * b + 64, at.sa);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) o.b[p][n][b] = buf_ld(at.b, boff + ((n * 3 + p) * 2 + b) * 1024, at.sb);
+  }
+}
+
+__device__ __forceinline__ void mma_stage(const OperandSet& o, f32x16 (&acc)[3][2][2]) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const f32x4 as0 = o.ar[0][b] + o.ai[0][b], as1 = o.ar[1][b] + o.ai[1][b];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float ar = o.ar[m][b][t], ai = o.ai[m][b][t], as = (m ? as1 : as0)[t];
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, o.b[0][n][b][t], acc[0][m][n], 0, 0, 0);
+          acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, o.b[1][n][b][t], acc[1][m][n], 0, 0, 0);
+          acc[2][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, o.b[2][n][b][t], acc[2][m][n], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+constexpr int kLdsRowFloats = 2 * kTileN;                 // one parked row: 64 complex = 128 floats = 512 bytes
+constexpr int kLdsWaveFloats = kTileM * kLdsRowFloats;    // 32 KB per wave
+
+// row pairs [p0, p1) of the parked tile -> Mo: lanes 0..31 carry row 2p, lanes 32..63 row 2p + 1, 16 bytes each
+__device__ __forceinline__ void flush_rows(const float* lds_w, float* mo_prev, int rows_left, size_t mo_row, int lane, int p0, int p1) {
+  for (int p = p0; p < p1; ++p) {
+    const int r = 2 * p + (lane >> 5);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(lds_w + r * kLdsRowFloats + (lane & 31) * 4);
+    if (r < rows_left) {
+#ifdef EQA_CGEMM_NOSTORE
+      asm volatile("" ::"v"(v));
+#else
+      *reinterpret_cast<f32x4*>(mo_prev + (size_t)r * mo_row + (lane & 31) * 4) = v;
+#endif
+    }
+  }
+}
+
+// One K-stage: request the next stage's operands, send NPAIR row pairs of the parked tile on their way, 96 MFMAs -- as ONE
+// scheduling region whose instruction order is then pinned: the LDS reads first, one global load behind every third MFMA (a run of
+// 20 loads would stall the in-order wave for ~300 cycles with the matrix pipe drained), the stores further down.
+// The stores go through a buffer descriptor over the tile's rows that lie inside M (rows beyond it fall outside num_records and
+// are dropped by the hardware): no branch, so the stage stays one basic block.
+template <int NPAIR>
+__device__ __forceinline__ void run_stage(OperandSet& nxt, const OperandSet& cur, f32x16 (&acc)[3][2][2], const StageAddr& at,
+                                          unsigned aoff0, unsigned aoff1, unsigned boff, const float* lds_lane,
+                                          __amdgpu_buffer_rsrc_t mo_rsrc, int mo_voff, int mo_pair_bytes, int p0) {
+  f32x4 park[NPAIR > 0 ? NPAIR : 1];
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) park[k] = *reinterpret_cast<const f32x4*>(lds_lane + (p0 + k) * (2 * kLdsRowFloats));
+  load_stage(nxt, at, aoff0, aoff1, boff);
+  mma_stage(cur, acc);
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) {
+#ifdef EQA_CGEMM_NOSTORE
+    asm volatile("" ::"v"(park[k]));
+#else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, park[k]), mo_rsrc, mo_voff + (p0 + k) * mo_pair_bytes, 0, 0);
+#endif
+  }
+#ifndef EQA_CGEMM_NOPIN
+  __builtin_amdgcn_sched_group_barrier(0x100, NPAIR, 0);            // DS reads
+#pragma unroll
+  for (int k = 0; k < 20; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);              // 3 MFMAs
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);              // 1 global load
+  }
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);              // 1 global store
+  }
+  __builtin_amdgcn_sched_group_barrier(0x008, 36 - 2 * NPAIR, 0);
+#endif
+}
+
+// V (F, pitch, 2 Cin) rows [Re x 16 | Im x 16] per 16 channels; B3 (F, S, Cout/32, 3, 2, 64, 4); Mo (F, pitch, 2 Cout) interleaved
+template <int NPAIR>   // row pairs of the parked tile flushed per K-stage: 32 / S where S divides 32, 0: any S (unpinned flush loop)
+__global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __restrict__ V, const float* __restrict__ B3,
+                                                             float* __restrict__ Mo, int M, int pitch, int Cin, int Cout, int F,
+                                                             int n_rt, int n_ct, int waves_per_xcd) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & (kXcd - 1);
+  const int q = (blockIdx.x >> 3) * 4 + wave;          // this wave's slot among the XCD's waves
+  const int S = Cin / kStageK;                          // stages (even: Cin % 32 == 0)
+  const int wpf = n_rt * n_ct;                          // wave-tiles per frequency
+  const int nf_x = (F - xcd + kXcd - 1) / kXcd;         // frequencies of this XCD: xcd, xcd + 8, ...
+  const int total = nf_x * wpf;                         // < 2^31: checked by the host
+  if (q >= total) return;
+  const int i = lane & 31, h = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * kLdsWaveFloats];
+  float* lds_w = lds_all + wave * kLdsWaveFloats;       // this wave's parking space for one finished tile
+  const size_t mo_row = (size_t)2 * Cout;               // floats per row of Mo
+  float* mo_prev = Mo;                                  // the parked tile: its first row of Mo (wave-uniform), its column tile and
+  int rows_prev = 0, ct_prev = 0;                       // the rows it has inside M
+  const size_t rowf = (size_t)2 * Cin;                  // floats per row of V
+  const size_t b_stage = (size_t)(Cout / 32) * 3 * 2 * 64 * 4;   // floats per (f, stage) of B3
+
+  // a wave-tile u (index in this XCD's sequence): operand descriptors + scalar offsets at stage 0, the lane's row offsets, its
+  // coordinates
+  const unsigned a_stage = 32 * 4, b_stage_bytes = (unsigned)b_stage * 4;     // bytes per K-stage in a row of V / in B3[f]
+  const unsigned v_f_bytes = (unsigned)((size_t)pitch * rowf * 4), b_f_bytes = (unsigned)S * b_stage_bytes;    // < 2^32: host-checked
+  auto locate = [&](int u, StageAddr& at, unsigned& aoff0, unsigned& aoff1, int& f, int& row0, int& ct) {
+#ifdef EQA_CGEMM_SAMETILE     // experiment (tools/micro/cgemm3m_bench.hip): every wave-tile reads tile 0 -- operands always cached
+    u = 0;
+#endif
+    const int fi = u / wpf, r = u - fi * wpf;
+    f = xcd + kXcd * fi;
+    const int rt = r / n_ct;
+    ct = r - rt * n_ct;
+    row0 = rt * kTileM;
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, v_f_bytes, 0x00020000);
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B3) + (size_t)f * S * b_stage, 0, b_f_bytes, 0x00020000);
+    at.sa = 0;
+    at.sb = (unsigned)(2 * ct) * (3 * 2 * 64 * 4 * 4);
+    aoff0 = (unsigned)((size_t)(row0 + i) * rowf + 4 * h) * 4u;      // rows >= pitch fall outside the descriptor and read as 0
+    aoff1 = aoff0 + 32 * (unsigned)rowf * 4u;
+  };
+  const unsigned boff = lane * 16;
+  auto at_stage = [&](const StageAddr& t, int s) { return StageAddr{t.a, t.b, t.sa + s * a_stage, t.sb + s * b_stage_bytes}; };
+
+  StageAddr at;
+  unsigned aoff0, aoff1;
+  int f, row0, ct;
+  locate(q, at, aoff0, aoff1, f, row0, ct);
+  OperandSet s0, s1;
+  CG_STAMP(c_begin);
+#ifdef EQA_CGEMM_CLOCK
+  unsigned long long c_mma = 0, c_epi = 0, c_tiles = 0;
+#endif
+  load_stage(s0, at, aoff0, aoff1, boff);
+  for (int u = q; u < total; u += waves_per_xcd) {
+    CG_STAMP(c0);
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[p][m][n][e] = 0.f;
+    // the tile after this one (or this one again when it is the last: a harmless reload instead of a conditional load)
+    const int un = u + waves_per_xcd < total ? u + waves_per_xcd : u;
+    StageAddr nat;
+    unsigned naoff0, naoff1;
+    int nf, nrow0, nct;
+    locate(un, nat, naoff0, naoff1, nf, nrow0, nct);
+    const float* lds_lane = lds_w + h * kLdsRowFloats + i * 4;
+    // the parked tile's rows inside M as a buffer: base = its first row (whole row of Mo), lane offset = row h, column tile, 16 i
+    const __amdgpu_buffer_rsrc_t mo_rsrc = __builtin_amdgcn_make_buffer_rsrc(mo_prev, 0, rows_prev * (int)mo_row * 4, 0x00020000);
+    const int mo_voff = (h * (int)mo_row + ct_prev * kLdsRowFloats + i * 4) * 4, mo_pair_bytes = 2 * (int)mo_row * 4;
+    for (int s = 0; s < S; s += 2) {
+      // the scheduling barriers keep the next stage's loads INSIDE this stage's MFMA stream: left alone, the compiler sinks them
+      // to their first use (the next stage) to save registers and every stage starts with an exposed HBM round trip
+      const bool more = s + 2 < S;
+      if (NPAIR > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        run_stage<NPAIR>(s1, s0, acc, at_stage(at, s + 1), aoff0, aoff1, boff, lds_lane, mo_rsrc, mo_voff, mo_pair_bytes, s * NPAIR);
+        __builtin_amdgcn_sched_barrier(0);
+        run_stage<NPAIR>(s0, s1, acc, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff, lds_lane,
+                         mo_rsrc, mo_voff, mo_pair_bytes, (s + 1) * NPAIR);
+        __builtin_amdgcn_sched_barrier(0);
+      } else {
+        load_stage(s1, at_stage(at, s + 1), aoff0, aoff1, boff);
+        flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, (32 * s) / S, (32 * (s + 1)) / S);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_stage(s0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(s0, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff);
+        flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, (32 * (s + 1)) / S, (32 * (s + 2)) / S);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_stage(s1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    CG_STAMP(c1);
+    // epilogue: Cr = T1 - T2, Ci = T3 - T1 - T2 into the wave's LDS tile [row][complex column]; accumulator register e of lane
+    // (h, j) is row (e & 3) + 8 (e >> 2) + 4 h, column j of its 32 x 32 block.  (All of the previous tile's rows have left the
+    // LDS: the stage loop above flushed its 32 row pairs; LDS operations of one wave execute in order.)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * m + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const float t1 = acc[0][m][n][e], t2 = acc[1][m][n][e], t3 = acc[2][m][n][e];
+          f32x2v c;
+          c[0] = t1 - t2;
+          c[1] = t3 - t1 - t2;
+          *reinterpret_cast<f32x2v*>(lds_w + r * kLdsRowFloats + (32 * n + i) * 2) = c;
+        }
+      }
+    mo_prev = Mo + ((size_t)f * pitch + row0) * mo_row;
+    rows_prev = min(kTileM, M - row0);
+    ct_prev = ct;
+    at = nat; aoff0 = naoff0; aoff1 = naoff1; f = nf; row0 = nrow0; ct = nct;
+#ifdef EQA_CGEMM_CLOCK
+    CG_STAMP(c2);
+    c_mma += c1 - c0; c_epi += c2 - c1; ++c_tiles;
+#endif
+  }
+  flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, 0, 32);       // the wave's last tile
+#ifdef EQA_CGEMM_CLOCK
+  if (lane == 0) {
+    unsigned long long* o = g_cg_clock + (size_t)(blockIdx.x * 4 + wave) * 4;
+    o[0] = __builtin_readcyclecounter() - c_begin; o[1] = c_mma; o[2] = c_epi; o[3] = c_tiles;
+  }
+#endif
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_fft48k5_cgemm3m_supported(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % kTileN == 0; }
+
+int64_t eqa_fft48k5_spectra3m_floats(int Cin, int Cout) {
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout)) return 0;
+  return (int64_t)eqa_fft48k5_frequencies() * Cin * Cout * 3;
+}
+
+int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, int Cin, int Cout, void* stream) {
+  if (!V || !B3 || !Mo || M < 0 || Cin <= 0 || Cout <= 0) return EQA_ERR_INVALID_ARG;
+  if (M == 0) return EQA_OK;
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || M > 0x3fffff || (int64_t)64 * 2 * Cout * 4 > 0x7fffffff || ((M | 1) + 64) * 2 * (int64_t)Cin * 4 > 0xffffffffLL || (int64_t)Cin * Cout * 3 * 4 > 0xffffffffLL || (((uintptr_t)V | (uintptr_t)B3) & 15) || ((uintptr_t)Mo & 7))
+    return EQA_ERR_UNSUPPORTED;
+  const int F = eqa_fft48k5_frequencies();
+  const int n_rt = (int)((M + kTileM - 1) / kTileM), n_ct = Cout / kTileN;
+  // persistent: one block of 4 waves per CU (the register budget admits one wave per SIMD); 32 blocks per XCD
+  const int blocks = 256;
+  const int S = Cin / kStageK;
+#define EQA_CG_LAUNCH(NP)                                                                                                        \
+  hipLaunchKernelGGL(fft_cgemm3m_kernel<NP>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, B3, Mo, (int)M,                 \
+                     (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rt, n_ct, (blocks / kXcd) * 4)
+  switch (32 % S == 0 ? 32 / S : 0) {     // (8 or 16 pairs per stage would need 32 / 64 registers to park them: dynamic form)
+    case 4: EQA_CG_LAUNCH(4); break;
+    case 2: EQA_CG_LAUNCH(2); break;
+    case 1: EQA_CG_LAUNCH(1); break;
+    default: EQA_CG_LAUNCH(0); break;
+  }
+#undef EQA_CG_LAUNCH
+  return launch_status();
+}
+
+}  // extern "C"

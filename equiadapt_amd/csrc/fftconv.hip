@@ -577,6 +577,75 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
   }
 }
 
+// The same filter spectra in the operand order of the hand-written 3-multiplication complex GEMM (cgemm3m.hip):
+// B3 (F, S = Cin/16, Cout/32, 3 [Br | Bi | Br + Bi], 2 [b], 64 [lane = 32 h + j], 4 [t]) with k = 16 s + 8 b + 4 h + t the input
+// channel and 32 c + j the output channel: a wave's B fragment of one MFMA k-block is one contiguous 1 KB run.  Thread = (output
+// channel, 4 consecutive input channels = t) for one kx: three 16-byte stores per frequency, fully coalesced over the lanes.
+// Br + Bi is the correctly rounded sum of the two STORED floats (fp64 add of the rounded values), so that
+// Ci = (Ar + Ai)(Br + Bi) - Ar Br - Ai Bi cancels against exactly the Br, Bi the other two products see.
+__global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const float* __restrict__ bank, float* __restrict__ B3, int Cout,
+                                                                         int Cin, float sgn) {
+  __shared__ double tw_c[kFftN], tw_s[kFftN];
+  if (threadIdx.x < kFftN) {
+    const double t = 6.283185307179586476925286766559 * threadIdx.x / kFftN;
+    tw_c[threadIdx.x] = cos(t);
+    tw_s[threadIdx.x] = sin(t);
+  }
+  __syncthreads();
+  const int co = blockIdx.y * kThreads + threadIdx.x;
+  const int cq = blockIdx.x;                      // quad of input channels 4 cq .. 4 cq + 3
+  const int kx = blockIdx.z;
+  if (co >= Cout) return;
+  constexpr double inv = 1.0 / (kFftN * kFftN);
+  // S_u(kx) = sum_v w[u][v] e^{i t kx v} for the 4 filters of this thread
+  double sr[4][5], si[4][5];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float* w = bank + ((size_t)co * Cin + 4 * cq + c) * 25;
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      sr[c][u] = 0.0;
+      si[c][u] = 0.0;
+#pragma unroll
+      for (int v = 0; v < 5; ++v) {
+        const int t = (kx * v) % kFftN;
+        const double wv = w[u * 5 + v];
+        sr[c][u] += wv * tw_c[t];
+        si[c][u] += wv * tw_s[t];
+      }
+    }
+  }
+  const int S = Cin / 16;
+  const int k0 = 4 * cq, s = k0 / 16, b = (k0 % 16) / 8, h = (k0 % 8) / 4;
+  const int c32 = co / 32, lane = 32 * h + (co % 32);
+  const size_t per_f = (size_t)Cin * Cout * 3;
+  float4* o = reinterpret_cast<float4*>(B3 + (((((size_t)s * (Cout / 32) + c32) * 3) * 2 + b) * 64 + lane) * 4);   // part 0
+  const size_t part = (size_t)2 * 64;             // float4 between the parts
+  (void)S;
+  const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
+  for (int ky = 0; ky < nky; ++ky) {
+    float fr[4], fi[4], fs[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double br = 0.0, bi = 0.0;
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int t = (ky * u) % kFftN;
+        const double cs = tw_c[t], sn = tw_s[t];
+        br += cs * sr[c][u] - sn * si[c][u];
+        bi += cs * si[c][u] + sn * sr[c][u];
+      }
+      fr[c] = (float)(br * inv);
+      fi[c] = sgn * (float)(bi * inv);
+      fs[c] = (float)((double)fr[c] + (double)fi[c]);
+    }
+    float4* of = o + (size_t)(f0 + ky * fstep) * (per_f / 4);
+    of[0] = make_float4(fr[0], fr[1], fr[2], fr[3]);
+    of[part] = make_float4(fi[0], fi[1], fi[2], fi[3]);
+    of[2 * part] = make_float4(fs[0], fs[1], fs[2], fs[3]);
+  }
+}
+
 // Filter gradient in the frequency domain (training).  With G = the spectra of the output-gradient tiles (44 x 44, zero-padded
 // to 48: eqa_fft48k5_grad_transform) and V those of the input tiles, D[f] = V[f]^T . G[f] (real form, one batched GEMM over
 // the tiles) holds  Dr = D[re ci][re co] + D[im ci][im co],  Di = D[im ci][re co] - D[re ci][im co]  of  X_f^T conj(G_f), and
@@ -710,6 +779,14 @@ int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, i
   if (((uintptr_t)B & 7) || Cin > 65535) return EQA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(fft48_filter_spectra_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, bank,
                      B, Cout, Cin, fft_group_in(Cin), correlate ? 1.0f : -1.0f);
+  return launch_status();
+}
+
+int eqa_fft48k5_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int correlate, void* stream) {
+  if (!bank || !B3 || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)B3 & 15) || Cin % 32 || Cout % 64 || Cin / 4 > 65535) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fft48_filter_spectra3m_kernel, dim3(Cin / 4, (Cout + kThreads - 1) / kThreads, kFftH), dim3(kThreads), 0,
+                     (hipStream_t)stream, bank, B3, Cout, Cin, correlate ? 1.0f : -1.0f);
   return launch_status();
 }
 

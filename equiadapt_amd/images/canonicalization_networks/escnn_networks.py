@@ -328,7 +328,7 @@ class ESCNNEquivariantNetwork(nn.Module):
         hit = self._fold_cache.get(("fft", id(conv)))
         key = self._fold_cache[id(conv)][0]
         if hit is None or hit[0] != key:
-            hit = (key, fftconv.filter_spectra(bank))
+            hit = (key, fftconv.spectra_for(bank))
             self._fold_cache[("fft", id(conv))] = hit
         return hit[1]
 

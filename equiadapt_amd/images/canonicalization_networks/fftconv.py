@@ -22,6 +22,58 @@ ENABLED = os.environ.get("EQA_CONV5_FFT", "1") != "0"
 # 17 MB: below ~32 tiles (8 images of 92 x 92) the Winograd path is faster (measured: B=4 0.29 vs 0.37 ms, B=8 0.48 vs 0.46 ms).
 MIN_TILES = int(os.environ.get("EQA_FFT_MIN_TILES", "32"))
 TRAIN_FORWARD = os.environ.get("EQA_FFT_TRAIN", "1") != "0"     # forward pass of winograd.Conv5x5Function through this path
+# The per-frequency channel contraction: "3m" = the hand-written complex GEMM on the fp32 MFMA in the 3-multiplication form
+# (eqa_fft48k5_cgemm3m; channel counts it takes: Cin % 32 == 0, Cout % 64 == 0), "lib" = the library's real batched GEMM.
+GEMM = os.environ.get("EQA_FFT_GEMM", "3m")
+
+
+class Spectra3M:
+    """Filter spectra in the operand order of eqa_fft48k5_cgemm3m: ``data`` is the flat (F * Cin * Cout * 3) fp32 buffer
+    [Br | Bi | Br + Bi] per (frequency, K-stage, 32 output channels)."""
+
+    __slots__ = ("data", "cin", "cout")
+
+    def __init__(self, data: torch.Tensor, cin: int, cout: int):
+        self.data, self.cin, self.cout = data, cin, cout
+
+
+def gemm3m_supported(cin: int, cout: int) -> bool:
+    return GEMM == "3m" and bool(_lib.load().eqa_fft48k5_cgemm3m_supported(cin, cout))
+
+
+def filter_spectra3m(bank: torch.Tensor, correlate: bool = True) -> Spectra3M:
+    """(Cout, Cin, 5, 5) device bank -> the same spectra as `filter_spectra`, laid out for the 3-multiplication complex GEMM."""
+    lib = _lib.load()
+    Cout, Cin = bank.shape[:2]
+    if not (bank.is_cuda and bank.dtype == torch.float32 and lib.eqa_fft48k5_cgemm3m_supported(Cin, Cout)):
+        raise RuntimeError("filter_spectra3m: fp32 device bank with Cin % 32 == 0 and Cout % 64 == 0 expected")
+    B3 = torch.empty(lib.eqa_fft48k5_spectra3m_floats(Cin, Cout), dtype=torch.float32, device=bank.device)
+    with torch.cuda.device(bank.device):
+        _lib.check(lib.eqa_fft48k5_filter_spectra3m(bank.contiguous().data_ptr(), B3.data_ptr(), Cout, Cin, int(correlate),
+                                                    torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_filter_spectra3m")
+    return Spectra3M(B3, Cin, Cout)
+
+
+def spectra_for(bank: torch.Tensor, correlate: bool = True):
+    """The filter spectra in the form the contraction will consume: `Spectra3M` where the hand-written GEMM takes the channel
+    counts, else the (F, 2Cin, 2Cout) real form for the library GEMM."""
+    Cout, Cin = bank.shape[:2]
+    if bank.is_cuda and bank.dtype == torch.float32 and gemm3m_supported(Cin, Cout):
+        return filter_spectra3m(bank, correlate)
+    return filter_spectra(bank, correlate=correlate)
+
+
+def contract(V: torch.Tensor, B, M: int) -> torch.Tensor:
+    """Mo[f] = V[f] . B[f] for every stored frequency: V (F, M, 2Cin) view of a pitched buffer -> Mo (F, M, 2Cout) likewise."""
+    dev = V.device
+    if isinstance(B, Spectra3M):
+        lib = _lib.load()
+        assert V.shape[2] == 2 * B.cin and V.stride(1) == 2 * B.cin and V.stride(0) == lib.eqa_fft48k5_tile_pitch(M) * 2 * B.cin
+        Mo = spectra_buffer(M, 2 * B.cout, dev)
+        _lib.check(lib.eqa_fft48k5_cgemm3m(V.data_ptr(), B.data.data_ptr(), Mo.data_ptr(), M, B.cin, B.cout,
+                                           torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_cgemm3m")
+        return Mo
+    return torch.bmm(V, B, out=spectra_buffer(M, B.shape[2], dev))
 
 
 def freq_index():
@@ -104,13 +156,17 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
             in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0,
             keep_V: Optional[list] = None) -> torch.Tensor:
     """x: channels-last (nimg,Cin,H,W) -> channels-last (nimg,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias) with
-    B = filter_spectra(g) and act(x) = [relu](x + in_bias[c]) applied while loading; ``sums_k`` > 0: return instead the
+    B = spectra_for(g) (either form) and act(x) = [relu](x + in_bias[c]) applied while loading; ``sums_k`` > 0: return instead the
     (nimg, Cout, sums_k, sums_k) fp64 window sums of that output (the linearised last layer consumes only those).
     ``keep_V``: a list that receives the input spectra V (training: the filter gradient reuses them)."""
     lib = _lib.load()
     nimg, Cin, H, W = x.shape
-    Cout = B.shape[2] // 2
-    assert B.shape == (F, 2 * Cin, 2 * Cout)
+    if isinstance(B, Spectra3M):
+        Cout = B.cout
+        assert B.cin == Cin
+    else:
+        Cout = B.shape[2] // 2
+        assert B.shape == (F, 2 * Cin, 2 * Cout)
     OH, OW = H - 4, W - 4
     TY, TX = tiles(H), tiles(W)
     M = nimg * TY * TX
@@ -126,7 +182,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
                        "eqa_fft48k5_input")
         del T
         with _timed("fft_gemm"):
-            Mo = torch.bmm(V, B, out=spectra_buffer(M, 2 * Cout, dev))
+            Mo = contract(V, B, M)
         if keep_V is not None:
             keep_V.append(V)
         del V
@@ -176,12 +232,12 @@ def input_grad(dy: torch.Tensor, bank: torch.Tensor, G: Optional[torch.Tensor] =
     dev = dy.device
     if G is None:
         G = grad_spectra(dy)
-    B2 = filter_spectra(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)      # (F, 2 Cout, 2 Cin)
+    B2 = spectra_for(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)         # spectra of (Cin, Cout, 5, 5)
     st = torch.cuda.current_stream().cuda_stream
     H, W = OH + 4, OW + 4
     dx = torch.empty((nimg, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
     with torch.cuda.device(dev):
-        Cg = torch.bmm(G, B2, out=spectra_buffer(G.shape[1], 2 * Cin, dev))       # (F, M, 2 Cin)
+        Cg = contract(G, B2, G.shape[1])                                          # (F, M, 2 Cin)
         T2 = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, N * tiles(H), OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
         _lib.check(lib.eqa_fft48k5_input_grad(Cg.data_ptr(), T2.data_ptr(), dx.data_ptr(), nimg, H, W, Cin, st), "eqa_fft48k5_input_grad")
     return dx

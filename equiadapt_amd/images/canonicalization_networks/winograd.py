@@ -153,7 +153,7 @@ class Conv5x5Function(torch.autograd.Function):
         if ctx.fft:
             # forward pass and both gradients as FFT convolutions (2.5 instead of 4 multiplies per output; the filter spectra
             # are rebuilt by one kernel, the input spectra are kept for the filter gradient)
-            y = fftconv.conv5x5(x, fftconv.filter_spectra(bank.detach()), None, False, keep_V=keep)
+            y = fftconv.conv5x5(x, fftconv.spectra_for(bank.detach()), None, False, keep_V=keep)
         else:
             y = conv5x5(x, transform_filters(bank.detach(), m), None, False, keep_V=keep if KEEP_V_FOR_BACKWARD else None)
         ctx.save_for_backward(x, bank, *keep)     # V is kept: HBM is 288 GB, recomputing it is a 1-2 ms pass

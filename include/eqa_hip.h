@@ -337,6 +337,20 @@ int eqa_fft48k5_frequencies(void);
  * correlate = 0: FFT(filter)/2304 instead of its conjugate (a convolution: the input gradient, with bank = the filters with
  * their channel axes swapped, (Cin,Cout,5,5)) */
 int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, int correlate, void* stream);
+/* The channel contraction Mo[f] = V[f] . B[f] (complex, per stored frequency) as a hand-written batched complex GEMM on the fp32
+ * matrix cores in the 3-multiplication form (csrc/cgemm3m.hip): T1 = Ar.Br, T2 = Ai.Bi, T3 = (Ar+Ai).(Br+Bi), Cr = T1 - T2,
+ * Ci = T3 - T1 - T2 -- 25 % fewer MFMA flops than the real [M x 2Cin].[2Cin x 2Cout] product the GEMM library runs.  It is the
+ * arithmetic of the reference layer's dense conv2d (escnn_networks.py:67-91 through R2Conv) carried out in the frequency domain.
+ *   eqa_fft48k5_cgemm3m_supported  1 when Cin % 32 == 0 and Cout % 64 == 0 (other shapes: the caller's library GEMM on B).
+ *   eqa_fft48k5_spectra3m_floats   floats of B3 = F * Cin * Cout * 3.
+ *   eqa_fft48k5_filter_spectra3m   bank:(Cout,Cin,5,5) -> B3:(F, Cin/16, Cout/32, 3 [Br|Bi|Br+Bi], 2, 64, 4) in the operand
+ *                                  fragment order of the kernel (same values as eqa_fft48k5_filter_spectra, `correlate` likewise).
+ *   eqa_fft48k5_cgemm3m            V:(F, pitch(M), 2Cin) rows [Re x 16 | Im x 16] per 16 channels, B3 -> Mo:(F, pitch(M), 2Cout)
+ *                                  interleaved complex; rows >= M of a frequency are neither read nor written. */
+int eqa_fft48k5_cgemm3m_supported(int Cin, int Cout);
+int64_t eqa_fft48k5_spectra3m_floats(int Cin, int Cout);
+int eqa_fft48k5_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int correlate, void* stream);
+int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, int Cin, int Cout, void* stream);
 int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,

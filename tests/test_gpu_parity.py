@@ -1222,3 +1222,44 @@ def test_load_exported_dense_round_trip_and_fast_path(dev, group_type, N):
         other.load_exported_dense(convs[:2], norms)
     with pytest.raises(ValueError):
         other.load_exported_dense([convs[0], convs[0], convs[2]], norms)
+
+
+@pytest.mark.parametrize("M,Cin,Cout", [(36, 64, 64), (130, 32, 128), (64, 256, 256), (257, 96, 192)])
+def test_cgemm3m_matches_real_gemm_in_fp64(dev, M, Cin, Cout):
+    """The hand-written 3-multiplication complex GEMM on the fp32 MFMA (eqa_fft48k5_cgemm3m) against an fp64 evaluation of the
+    real [M x 2Cin].[2Cin x 2Cout] product the GEMM library used to run, per stored frequency: ragged row counts (rows beyond M
+    are clamped on load and never stored), one to four column tiles, 2 to 16 K-stages; the padding row of the pitched buffers
+    stays untouched.  fp32 bound: the library's own fp32 result is 2-3e-7 of max|Mo| away from fp64; Karatsuba's imaginary part
+    (a difference of three products) is allowed 8x that."""
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    lib = _lib.load()
+    assert lib.eqa_fft48k5_cgemm3m_supported(Cin, Cout) and not lib.eqa_fft48k5_cgemm3m_supported(48, 64) \
+        and not lib.eqa_fft48k5_cgemm3m_supported(64, 32)
+    g = torch.Generator().manual_seed(M + Cin)
+    bank = (torch.randn(Cout, Cin, 5, 5, generator=g) / (5.0 * Cin ** 0.5)).to(dev)
+    B = fftconv.filter_spectra(bank)                                    # (F, 2Cin, 2Cout) real form
+    B3 = fftconv.filter_spectra3m(bank)
+    V = fftconv.spectra_buffer(M, 2 * Cin, dev)
+    V.copy_(torch.randn(fftconv.F, M, 2 * Cin, generator=g).to(dev))
+    pitch = lib.eqa_fft48k5_tile_pitch(M)
+    Mo = fftconv.contract(V, B3, M)
+    assert Mo.shape == (fftconv.F, M, 2 * Cout) and Mo.stride(0) == pitch * 2 * Cout
+    want = torch.bmm(V.double(), B.double())
+    scale = want.abs().max().item()
+    err = (Mo.double() - want).abs().max().item()
+    lib_err = (torch.bmm(V, B).double() - want).abs().max().item()
+    assert err <= 2.5e-6 * scale and err <= 8 * lib_err, (err, lib_err, scale)
+    # imaginary and real parts separately (interleaved complex columns)
+    assert (Mo.double() - want)[..., 0::2].abs().max().item() <= 6e-7 * scale
+    # poison test: rows >= M of each frequency (the pitch padding) are not written
+    full = torch.full((fftconv.F, pitch, 2 * Cout), 7.0, dtype=torch.float32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.eqa_fft48k5_cgemm3m(V.data_ptr(), B3.data.data_ptr(), full.data_ptr(), M, Cin, Cout, st), "cgemm3m")
+    assert torch.equal(full[:, :M], Mo) and (full[:, M:] == 7.0).all()
+    # the convolution form (correlate = False) of the spectra as well: conj of the correlation form
+    B2 = fftconv.filter_spectra(bank, correlate=False)
+    Mo2 = fftconv.contract(V, fftconv.filter_spectra3m(bank, correlate=False), M)
+    want2 = torch.bmm(V.double(), B2.double())
+    assert (Mo2.double() - want2).abs().max().item() <= 2.5e-6 * want2.abs().max().item()

@@ -47,7 +47,11 @@ def test_discrete_onehot_ste_gradient_and_losses_on_product(dev, golden):
         d.train(mode == "train")
         a = acts.to(dev).clone().requires_grad_(True)
         oh = d.groupactivations_to_groupelementonehot(a)
-        assert torch.equal(oh.detach().cpu(), g["cases"][mode]["onehot"]), mode      # hard + soft - soft == hard bit for bit
+        want = g["cases"][mode]["onehot"]
+        if mode == "eval":
+            assert torch.equal(oh.detach().cpu(), want), mode
+        else:      # (hard + soft) - soft leaves a rounding residue of the softmax values (1 ulp of 1.x), device softmax != CPU's last bit
+            assert torch.equal(oh.detach().cpu().argmax(-1), want.argmax(-1)) and torch.allclose(oh.detach().cpu(), want, atol=2.5e-7, rtol=0)
         if mode == "train":
             (oh * torch.arange(8.0, device=dev)).sum().backward()
             assert torch.allclose(a.grad.cpu(), g["cases"][mode]["grad"], atol=2e-7, rtol=1e-6)
@@ -82,8 +86,9 @@ def test_image_group_element_rotation_sums_match_reference_onehot(dev, golden):
         can.train(mode == "train")
         el = can.groupactivations_to_groupelement(acts.clone().requires_grad_(mode == "train"))
         oh = g["cases"][mode]["onehot"]
-        assert torch.equal(el["rotation"].detach().cpu(), (oh * ang).sum(-1)), mode
-        assert torch.equal(el["reflection"].detach().cpu(), (oh * ind).sum(-1)), mode
+        # train mode: the STE one-hot carries a <= 1 ulp residue of the softmax, times an angle of up to 270
+        assert torch.allclose(el["rotation"].detach().cpu(), (oh * ang).sum(-1), atol=0.0 if mode == "eval" else 2e-4, rtol=0), mode
+        assert torch.allclose(el["reflection"].detach().cpu(), (oh * ind).sum(-1), atol=0.0 if mode == "eval" else 1e-6, rtol=0), mode
         assert torch.equal(el["group_index"].cpu().long(), oh.argmax(-1)), mode
 
 
@@ -162,7 +167,8 @@ def test_vn_layers_on_product_match_reference(dev, golden):
     idx_got = (g["pool_in"] == got.unsqueeze(-1)).all(dim=2).float().argmax(-1)     # which sample the device picked
     got_score = torch.gather(score, -1, idx_got.unsqueeze(-1)).squeeze(-1)
     assert (score.max(dim=-1).values - got_score).abs().max().item() <= 1e-5 * score.abs().max().item()
-    assert torch.equal(g["pool_in"].to(dev).mean(-1).cpu(), g["mean_pool_out"])
+    from equiadapt_amd.pointcloud.canonicalization_networks.vector_neuron_layers import mean_pool
+    assert torch.allclose(mean_pool(g["pool_in"].to(dev)).cpu(), g["mean_pool_out"], atol=1e-6, rtol=1e-6)
 
 
 def test_vnsmall_train_mode_fused_first_block_matches_reference(dev, golden):
@@ -226,6 +232,14 @@ def test_conv_network_on_product_matches_reference_golden(dev, golden):
         after = net.state_dict()
         for k_, v in c["state_after_train"].items():
             assert torch.allclose(after[k_].cpu().float(), v.float(), atol=1e-5, rtol=1e-4), (c["args"], k_)
-        for n, p in net.named_parameters():
+        grads = {n: p.grad.cpu() for n, p in net.named_parameters()}
+        for n, got in grads.items():
             want = c["grads"][n]
-            assert (p.grad.cpu() - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 1e-6, (c["args"], n)
+            if n.startswith("enc_network.") and n.endswith(".bias") and int(n.split(".")[1]) % 3 == 0:
+                # a convolution bias in front of a training-mode batch-norm: the true gradient is ZERO (the sum of the batch-norm's
+                # input gradient over a channel); both sides hold rounding noise of that sum, whose size follows the gradient scale of
+                # the layer (B = 3 samples through BatchNorm1d batch statistics make it large), not each other
+                wscale = c["grads"][n[:-4] + "weight"].abs().max().item()
+                assert got.abs().max().item() <= 1e-4 * wscale + 2e-5 and want.abs().max().item() <= 1e-4 * wscale + 2e-5, (c["args"], n, wscale)
+                continue
+            assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 2e-5, (c["args"], n)
