@@ -647,12 +647,18 @@ def stage_table(ktimes, B):
         "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
     }
     # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1154 stored frequencies;
-    # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written);
-    # flops of the complex channel contraction counted as 4 real multiply-adds per complex one (the 3-multiplication kernel does 3)
+    # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written).  The
+    # per-frequency complex channel contraction: hand-written 3-multiplication GEMM (3 real products per complex one: those are
+    # the flops counted), or with EQA_FFT_GEMM=lib the library's real GEMM (4).
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
     m_tiles, spectra = B * 4, 1154 * B * 4 * 512 * 4
+    own_gemm = fftconv.gemm3m_supported(256, 256)
     spec.update({
         "fft_input": ("hbm", px_l * 256 * 4 + spectra, "eqa_fft48k5_input: row + column FFT-48 passes (hand-written)"),
-        "fft_gemm": ("mfma", 2.0 * 1154 * m_tiles * 512 * 512, "1154 x [tiles x 256].[256 x 256] complex products (flops as 4 real products each)"),
+        "fft_gemm": ("mfma", (3.0 if own_gemm else 4.0) * 2.0 * 1154 * m_tiles * 256 * 256,
+                     "eqa_fft48k5_cgemm3m: 1154 x [tiles x 256].[256 x 256] complex products, 3-multiplication form on the fp32 MFMA (hand-written)"
+                     if own_gemm else "1154 x [tiles x 512].[512 x 512] batched GEMM, complex as real (library)"),
         "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
     })
     stages = {}

@@ -24,6 +24,9 @@
 // (Cr = T1 - T2, Ci = T3 - T1 - T2) and parked in the wave's private 32 KB of LDS (64 ds_write_b64, ~1.5 k cycles); it leaves
 // for HBM during the NEXT tile's MFMA stream, two whole 512-byte rows per ds_read_b128 + global_store_dwordx4 pair, 32 / S pairs
 // per K-stage -- LDS and store instructions issue in the shadow of the 64-cycle MFMAs.
+// (Tried and dropped: tile-major spectra (tile, 8 channels, frequency, 16 floats) so that the fused FFT kernels could run two
+// 8-channel blocks per CU on contiguous runs: correct, but forward 1.03 -> 1.48 ms, inverse 0.96 -> 1.11 ms, this kernel 3.54 ->
+// 3.64 ms -- DESIGN 3.4.)
 // Work: wave-tile = (frequency, 64 rows, 64 complex columns); the 4 waves of a block take the column tiles of one (f, row tile)
 // (they share the rows of V through L1 / L2); the frequencies are dealt to the XCDs (f mod 8, block b runs on XCD b mod 8) so that a
 // frequency's B panel (0.79 MB at 256 channels) is read from HBM once and then served by that XCD's L2 to its 16 row tiles.
@@ -51,22 +54,22 @@ struct OperandSet {                       // one K-stage of MFMA operands: 80 re
   f32x4 b[3][2][2];                       // [part r/i/s][n][b]
 };
 
-// Operand loads go through buffer descriptors: a wave-uniform descriptor (one frequency of V / of B3, rebuilt per tile by scalar
-// code) + a scalar byte offset (the K-stage, advanced by scalar adds) + a 32-bit lane offset that is constant within a tile.
-// No vector address arithmetic in the MFMA stream (a VALU instruction there costs ~6 MFMA cycles), and rows beyond the buffer
-// read as zero instead of needing a clamp.
+// Operand loads go through buffer descriptors: a wave-uniform descriptor (rebuilt per tile by scalar code) + a scalar byte offset
+// (frequency / K-stage, advanced by scalar adds) + a 32-bit lane offset that is constant within a tile.  No vector address
+// arithmetic in the MFMA stream (a VALU instruction there costs ~6 MFMA cycles), and rows beyond the buffer read as zero instead
+// of needing a clamp.
 struct StageAddr {
-  __amdgpu_buffer_rsrc_t a, b;   // V[f] (pitch rows), B3[f]
-  unsigned sa, sb;               // byte offsets of the stage: in a row of V; in B3[f] incl. the wave's column tile
+  __amdgpu_buffer_rsrc_t a, b;   // rows of V the tile reads; B3[f]
+  unsigned sa, sb;               // scalar byte offsets of the stage
 };
 
 __device__ __forceinline__ f32x4 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+// aoff0 / aoff1: byte offset of this lane's row (the two 32-row subtiles) + 16 h; boff = 16 * lane.  A row's stage is one
+// [Re x 16 | Im x 16] piece: k-block b at +32 b, Im at +64.  In the order the MFMAs consume them: all of b = 0, then b = 1.
 __device__ __forceinline__ void load_stage(OperandSet& o, const StageAddr& at, unsigned aoff0, unsigned aoff1, unsigned boff) {
-  // aoff0 / aoff1: byte offset of this lane's row (the two 32-row subtiles) + 16 h; boff = 16 * lane.
-  // In the order the MFMAs consume them: everything of k-block b = 0, then b = 1.
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     o.ar[0][b] = buf_ld(at.a, aoff0 + 32 * b, at.sa);
@@ -103,43 +106,41 @@ __device__ __forceinline__ void mma_stage(const OperandSet& o, f32x16 (&acc)[3][
 constexpr int kLdsRowFloats = 2 * kTileN;                 // one parked row: 64 complex = 128 floats = 512 bytes
 constexpr int kLdsWaveFloats = kTileM * kLdsRowFloats;    // 32 KB per wave
 
-// row pairs [p0, p1) of the parked tile -> Mo: lanes 0..31 carry row 2p, lanes 32..63 row 2p + 1, 16 bytes each
-__device__ __forceinline__ void flush_rows(const float* lds_w, float* mo_prev, int rows_left, size_t mo_row, int lane, int p0, int p1) {
-  for (int p = p0; p < p1; ++p) {
-    const int r = 2 * p + (lane >> 5);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(lds_w + r * kLdsRowFloats + (lane & 31) * 4);
-    if (r < rows_left) {
-#ifdef EQA_CGEMM_NOSTORE
-      asm volatile("" ::"v"(v));
+// Where a parked tile goes: a buffer over the tile's rows that lie inside M (rows beyond it fall outside num_records and are
+// dropped by the hardware: no branch), the lane's byte offset for row pair 0, the step to the next pair, a scalar offset.
+struct ParkedDst {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff, pair_bytes;
+  unsigned soff;
+};
+
+__device__ __forceinline__ void store_pair(const ParkedDst& d, int p, f32x4 v) {
+#ifdef EQA_CGEMM_NOSTORE      // experiment: no global stores (the value stays live through the asm)
+  asm volatile("" ::"v"(v));
 #else
-      *reinterpret_cast<f32x4*>(mo_prev + (size_t)r * mo_row + (lane & 31) * 4) = v;
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), d.rsrc, d.voff + p * d.pair_bytes, d.soff, 0);
 #endif
-    }
-  }
+}
+
+// row pairs [p0, p1) of the parked tile -> Mo: lanes 0..31 carry row 2p, lanes 32..63 row 2p + 1, 16 bytes each
+__device__ __forceinline__ void flush_rows(const float* lds_lane, const ParkedDst& d, int p0, int p1) {
+  for (int p = p0; p < p1; ++p) store_pair(d, p, *reinterpret_cast<const f32x4*>(lds_lane + p * (2 * kLdsRowFloats)));
 }
 
 // One K-stage: request the next stage's operands, send NPAIR row pairs of the parked tile on their way, 96 MFMAs -- as ONE
 // scheduling region whose instruction order is then pinned: the LDS reads first, one global load behind every third MFMA (a run of
 // 20 loads would stall the in-order wave for ~300 cycles with the matrix pipe drained), the stores further down.
-// The stores go through a buffer descriptor over the tile's rows that lie inside M (rows beyond it fall outside num_records and
-// are dropped by the hardware): no branch, so the stage stays one basic block.
 template <int NPAIR>
 __device__ __forceinline__ void run_stage(OperandSet& nxt, const OperandSet& cur, f32x16 (&acc)[3][2][2], const StageAddr& at,
-                                          unsigned aoff0, unsigned aoff1, unsigned boff, const float* lds_lane,
-                                          __amdgpu_buffer_rsrc_t mo_rsrc, int mo_voff, int mo_pair_bytes, int p0) {
+                                          unsigned aoff0, unsigned aoff1, unsigned boff, const float* lds_lane, const ParkedDst& dst,
+                                          int p0) {
   f32x4 park[NPAIR > 0 ? NPAIR : 1];
 #pragma unroll
   for (int k = 0; k < NPAIR; ++k) park[k] = *reinterpret_cast<const f32x4*>(lds_lane + (p0 + k) * (2 * kLdsRowFloats));
   load_stage(nxt, at, aoff0, aoff1, boff);
   mma_stage(cur, acc);
 #pragma unroll
-  for (int k = 0; k < NPAIR; ++k) {
-#ifdef EQA_CGEMM_NOSTORE
-    asm volatile("" ::"v"(park[k]));
-#else
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, park[k]), mo_rsrc, mo_voff + (p0 + k) * mo_pair_bytes, 0, 0);
-#endif
-  }
+  for (int k = 0; k < NPAIR; ++k) store_pair(dst, p0 + k, park[k]);
 #ifndef EQA_CGEMM_NOPIN
   __builtin_amdgcn_sched_group_barrier(0x100, NPAIR, 0);            // DS reads
 #pragma unroll
@@ -157,7 +158,8 @@ __device__ __forceinline__ void run_stage(OperandSet& nxt, const OperandSet& cur
 }
 
 // V (F, pitch, 2 Cin) rows [Re x 16 | Im x 16] per 16 channels; B3 (F, S, Cout/32, 3, 2, 64, 4); Mo (F, pitch, 2 Cout) interleaved
-template <int NPAIR>   // row pairs of the parked tile flushed per K-stage: 32 / S where S divides 32, 0: any S (unpinned flush loop)
+// complex.  NPAIR: row pairs of the parked tile flushed per K-stage: 32 / S where S divides 32, 0: any S (unpinned flush loop)
+template <int NPAIR>
 __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __restrict__ V, const float* __restrict__ B3,
                                                              float* __restrict__ Mo, int M, int pitch, int Cin, int Cout, int F,
                                                              int n_rt, int n_ct, int waves_per_xcd) {
@@ -173,16 +175,14 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
   const int i = lane & 31, h = lane >> 5;
   __shared__ __attribute__((aligned(16))) float lds_all[4 * kLdsWaveFloats];
   float* lds_w = lds_all + wave * kLdsWaveFloats;       // this wave's parking space for one finished tile
-  const size_t mo_row = (size_t)2 * Cout;               // floats per row of Mo
-  float* mo_prev = Mo;                                  // the parked tile: its first row of Mo (wave-uniform), its column tile and
-  int rows_prev = 0, ct_prev = 0;                       // the rows it has inside M
-  const size_t rowf = (size_t)2 * Cin;                  // floats per row of V
-  const size_t b_stage = (size_t)(Cout / 32) * 3 * 2 * 64 * 4;   // floats per (f, stage) of B3
+  const float* lds_lane = lds_w + h * kLdsRowFloats + i * 4;
+  const size_t rowf = (size_t)2 * Cin, mo_row = (size_t)2 * Cout;           // floats per row of V / Mo
+  const unsigned b_stage_bytes = (unsigned)(Cout / 32) * 3 * 2 * 64 * 4 * 4;                    // bytes per (f, stage) of B3
+  const unsigned a_stage = 32u * 4u;                                        // bytes from one K-stage of a row to the next
+  const unsigned boff = lane * 16;
 
   // a wave-tile u (index in this XCD's sequence): operand descriptors + scalar offsets at stage 0, the lane's row offsets, its
-  // coordinates
-  const unsigned a_stage = 32 * 4, b_stage_bytes = (unsigned)b_stage * 4;     // bytes per K-stage in a row of V / in B3[f]
-  const unsigned v_f_bytes = (unsigned)((size_t)pitch * rowf * 4), b_f_bytes = (unsigned)S * b_stage_bytes;    // < 2^32: host-checked
+  // coordinates.  All sizes are < 2^32 bytes (host-checked).
   auto locate = [&](int u, StageAddr& at, unsigned& aoff0, unsigned& aoff1, int& f, int& row0, int& ct) {
 #ifdef EQA_CGEMM_SAMETILE     // experiment (tools/micro/cgemm3m_bench.hip): every wave-tile reads tile 0 -- operands always cached
     u = 0;
@@ -192,20 +192,31 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
     const int rt = r / n_ct;
     ct = r - rt * n_ct;
     row0 = rt * kTileM;
-    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, v_f_bytes, 0x00020000);
-    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B3) + (size_t)f * S * b_stage, 0, b_f_bytes, 0x00020000);
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, (unsigned)((size_t)pitch * rowf * 4), 0x00020000);
     at.sa = 0;
-    at.sb = (unsigned)(2 * ct) * (3 * 2 * 64 * 4 * 4);
-    aoff0 = (unsigned)((size_t)(row0 + i) * rowf + 4 * h) * 4u;      // rows >= pitch fall outside the descriptor and read as 0
+    aoff0 = (unsigned)((size_t)(row0 + i) * rowf + 4 * h) * 4u;        // rows >= pitch fall outside the descriptor and read as 0
     aoff1 = aoff0 + 32 * (unsigned)rowf * 4u;
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B3) + (size_t)f * S * (b_stage_bytes / 4), 0, (unsigned)S * b_stage_bytes, 0x00020000);
+    at.sb = (unsigned)(2 * ct) * (3 * 2 * 64 * 4 * 4);
   };
-  const unsigned boff = lane * 16;
   auto at_stage = [&](const StageAddr& t, int s) { return StageAddr{t.a, t.b, t.sa + s * a_stage, t.sb + s * b_stage_bytes}; };
+  // destination of the tile (f, row0, ct) once it is parked
+  auto parked = [&](int f, int row0, int ct) {
+    const int rows = min(kTileM, M - row0);
+    ParkedDst d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo + ((size_t)f * pitch + row0) * mo_row, 0, (unsigned)(rows * mo_row * 4), 0x00020000);
+    d.voff = (h * (int)mo_row + ct * kLdsRowFloats + i * 4) * 4;
+    d.pair_bytes = 2 * (int)mo_row * 4;
+    d.soff = 0;
+    return d;
+  };
 
   StageAddr at;
   unsigned aoff0, aoff1;
   int f, row0, ct;
   locate(q, at, aoff0, aoff1, f, row0, ct);
+  ParkedDst dst = parked(f, row0, ct);
+  dst.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo, 0, 0, 0x00020000);       // nothing parked yet: an empty buffer drops the stores
   OperandSet s0, s1;
   CG_STAMP(c_begin);
 #ifdef EQA_CGEMM_CLOCK
@@ -229,29 +240,25 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
     unsigned naoff0, naoff1;
     int nf, nrow0, nct;
     locate(un, nat, naoff0, naoff1, nf, nrow0, nct);
-    const float* lds_lane = lds_w + h * kLdsRowFloats + i * 4;
-    // the parked tile's rows inside M as a buffer: base = its first row (whole row of Mo), lane offset = row h, column tile, 16 i
-    const __amdgpu_buffer_rsrc_t mo_rsrc = __builtin_amdgcn_make_buffer_rsrc(mo_prev, 0, rows_prev * (int)mo_row * 4, 0x00020000);
-    const int mo_voff = (h * (int)mo_row + ct_prev * kLdsRowFloats + i * 4) * 4, mo_pair_bytes = 2 * (int)mo_row * 4;
     for (int s = 0; s < S; s += 2) {
       // the scheduling barriers keep the next stage's loads INSIDE this stage's MFMA stream: left alone, the compiler sinks them
       // to their first use (the next stage) to save registers and every stage starts with an exposed HBM round trip
       const bool more = s + 2 < S;
       if (NPAIR > 0) {
         __builtin_amdgcn_sched_barrier(0);
-        run_stage<NPAIR>(s1, s0, acc, at_stage(at, s + 1), aoff0, aoff1, boff, lds_lane, mo_rsrc, mo_voff, mo_pair_bytes, s * NPAIR);
+        run_stage<NPAIR>(s1, s0, acc, at_stage(at, s + 1), aoff0, aoff1, boff, lds_lane, dst, s * NPAIR);
         __builtin_amdgcn_sched_barrier(0);
-        run_stage<NPAIR>(s0, s1, acc, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff, lds_lane,
-                         mo_rsrc, mo_voff, mo_pair_bytes, (s + 1) * NPAIR);
+        run_stage<NPAIR>(s0, s1, acc, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff, lds_lane, dst,
+                         (s + 1) * NPAIR);
         __builtin_amdgcn_sched_barrier(0);
       } else {
         load_stage(s1, at_stage(at, s + 1), aoff0, aoff1, boff);
-        flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, (32 * s) / S, (32 * (s + 1)) / S);
+        flush_rows(lds_lane, dst, (32 * s) / S, (32 * (s + 1)) / S);
         __builtin_amdgcn_sched_barrier(0);
         mma_stage(s0, acc);
         __builtin_amdgcn_sched_barrier(0);
         load_stage(s0, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff);
-        flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, (32 * (s + 1)) / S, (32 * (s + 2)) / S);
+        flush_rows(lds_lane, dst, (32 * (s + 1)) / S, (32 * (s + 2)) / S);
         __builtin_amdgcn_sched_barrier(0);
         mma_stage(s1, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -275,16 +282,14 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
           *reinterpret_cast<f32x2v*>(lds_w + r * kLdsRowFloats + (32 * n + i) * 2) = c;
         }
       }
-    mo_prev = Mo + ((size_t)f * pitch + row0) * mo_row;
-    rows_prev = min(kTileM, M - row0);
-    ct_prev = ct;
+    dst = parked(f, row0, ct);
     at = nat; aoff0 = naoff0; aoff1 = naoff1; f = nf; row0 = nrow0; ct = nct;
 #ifdef EQA_CGEMM_CLOCK
     CG_STAMP(c2);
     c_mma += c1 - c0; c_epi += c2 - c1; ++c_tiles;
 #endif
   }
-  flush_rows(lds_w, mo_prev + ct_prev * kLdsRowFloats, rows_prev, mo_row, lane, 0, 32);       // the wave's last tile
+  flush_rows(lds_lane, dst, 0, 32);       // the wave's last tile
 #ifdef EQA_CGEMM_CLOCK
   if (lane == 0) {
     unsigned long long* o = g_cg_clock + (size_t)(blockIdx.x * 4 + wave) * 4;
@@ -307,9 +312,12 @@ int64_t eqa_fft48k5_spectra3m_floats(int Cin, int Cout) {
 int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, int Cin, int Cout, void* stream) {
   if (!V || !B3 || !Mo || M < 0 || Cin <= 0 || Cout <= 0) return EQA_ERR_INVALID_ARG;
   if (M == 0) return EQA_OK;
-  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || M > 0x3fffff || (int64_t)64 * 2 * Cout * 4 > 0x7fffffff || ((M | 1) + 64) * 2 * (int64_t)Cin * 4 > 0xffffffffLL || (int64_t)Cin * Cout * 3 * 4 > 0xffffffffLL || (((uintptr_t)V | (uintptr_t)B3) & 15) || ((uintptr_t)Mo & 7))
-    return EQA_ERR_UNSUPPORTED;
   const int F = eqa_fft48k5_frequencies();
+  // every descriptor range and lane offset must fit 32 bits: one frequency of V / Mo, one frequency of B3
+  const int64_t fm_bytes = ((M | 1) + 64) * 2 * (int64_t)std::max(Cin, Cout) * 4;
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || M > 0x3fffff || fm_bytes > 0x7fffffffLL || (int64_t)Cin * Cout * 3 * 4 > 0x7fffffffLL ||
+      (((uintptr_t)V | (uintptr_t)B3 | (uintptr_t)Mo) & 15))
+    return EQA_ERR_UNSUPPORTED;
   const int n_rt = (int)((M + kTileM - 1) / kTileM), n_ct = Cout / kTileN;
   // persistent: one block of 4 waves per CU (the register budget admits one wave per SIMD); 32 blocks per XCD
   const int blocks = 256;

@@ -1263,3 +1263,40 @@ def test_cgemm3m_matches_real_gemm_in_fp64(dev, M, Cin, Cout):
     Mo2 = fftconv.contract(V, fftconv.filter_spectra3m(bank, correlate=False), M)
     want2 = torch.bmm(V.double(), B2.double())
     assert (Mo2.double() - want2).abs().max().item() <= 2.5e-6 * want2.abs().max().item()
+
+
+def test_fft48_convolution_3m_gemm_path_matches_conv2d(dev):
+    """The FFT convolution with the hand-written 3-multiplication complex GEMM as its contraction (eqa_fft48k5_input ->
+    eqa_fft48k5_cgemm3m -> eqa_fft48k5_output / _output_sums) against F.conv2d in fp64: exact tiles, ragged last tiles in both
+    axes, a single tile, more than 64 tiles (two row tiles of the GEMM, the second ragged), bias / ReLU on both sides, both
+    window-sum sizes."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(49)
+    assert fftconv.GEMM == "3m"
+    cases = [(2, 32, 64, 92, 92), (1, 64, 64, 60, 97), (1, 32, 64, 48, 48), (3, 32, 128, 137, 49), (1, 64, 64, 53, 50), (1, 32, 64, 50, 52),
+             (20, 32, 64, 92, 92)]
+    for (B, Cin, Cout, H, W) in cases:
+        x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cin ** 0.5)
+        b, ib = torch.randn(Cout, device=dev), torch.randn(Cin, device=dev)
+        Bm = fftconv.spectra_for(w)
+        assert isinstance(Bm, fftconv.Spectra3M)
+        for (relu, in_relu) in [(False, False), (True, True)]:
+            xin = torch.relu(x.double() + ib.double()[None, :, None, None]) if in_relu else x.double()
+            want = F.conv2d(xin, w.double(), b.double())
+            want = torch.relu(want) if relu else want
+            got = fftconv.conv5x5(x, Bm, b, relu, ib if in_relu else None, in_relu)
+            assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+            scale = want.abs().max().item()
+            assert (got.double() - want).abs().max().item() <= 5e-6 * scale, (B, Cin, Cout, H, W, relu, (got.double() - want).abs().max().item() / scale)
+            OH, OW = H - 4, W - 4
+            for k in (5, 3):
+                if min(OH, OW) < 2 * k - 1:
+                    continue
+                S = fftconv.conv5x5(x, Bm, b, relu, ib if in_relu else None, in_relu, sums_k=k)
+                Sw = torch.stack([torch.stack([want[:, :, u:u + OH - k + 1, v:v + OW - k + 1].sum((-1, -2)) for v in range(k)], -1)
+                                  for u in range(k)], -2)
+                assert S.dtype == torch.float64 and ((S - Sw).abs().max() <= 2e-6 * Sw.abs().max().clamp_min(scale)), (B, H, W, k)

@@ -238,8 +238,9 @@ def test_conv_network_on_product_matches_reference_golden(dev, golden):
             if n.startswith("enc_network.") and n.endswith(".bias") and int(n.split(".")[1]) % 3 == 0:
                 # a convolution bias in front of a training-mode batch-norm: the true gradient is ZERO (the sum of the batch-norm's
                 # input gradient over a channel); both sides hold rounding noise of that sum, whose size follows the gradient scale of
-                # the layer (B = 3 samples through BatchNorm1d batch statistics make it large), not each other
+                # the layer (B = 3 samples through BatchNorm1d batch statistics make it large), not each other: the framework's fp32
+                # batch-norm backward on the device leaves 1.6e-3 of the layer's weight-gradient scale, the CPU's 5e-7
                 wscale = c["grads"][n[:-4] + "weight"].abs().max().item()
-                assert got.abs().max().item() <= 1e-4 * wscale + 2e-5 and want.abs().max().item() <= 1e-4 * wscale + 2e-5, (c["args"], n, wscale)
+                assert got.abs().max().item() <= 5e-3 * wscale + 2e-5 and want.abs().max().item() <= 5e-3 * wscale + 2e-5, (c["args"], n, wscale)
                 continue
             assert (got - want).abs().max().item() <= 2e-3 * want.abs().max().item() + 2e-5, (c["args"], n)

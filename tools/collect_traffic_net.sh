@@ -7,7 +7,7 @@ out=${1:-gpurun_out/traffic_net}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c -d "$out/$c" -o p --output-format csv -- python bench.py --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c -d "$out/$c" -o p --output-format csv -- python bench.py --mode forward --steps 3 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 done
 python - "$out" <<'PY'
 import csv, json, sys, collections
@@ -22,6 +22,8 @@ alg = {  # algorithmic bytes per launch, fp32
     "crop_resize_aa_kernel": B * 3 * 180 * 180 * 4 + B * 3 * 96 * 96 * 4,
     "window_sums_nhwc_finalize_kernel": B * 10 * 2 * 256 * 9 * 4 + B * 256 * 25 * 8,  # 8 border rows + 2 tile rows, x 2 tile columns
     "group_action_kernel": B * 2 * 3 * 224 * 224 * 4,
+    # V in + B3 (F x 256 x 256 x 3 floats) in + Mo out; the filter spectra are re-read from L2 by a frequency's 16 row tiles
+    "fft_cgemm3m_kernel": 2 * 1154 * (B * 4 | 1) * 512 * 4 + 1154 * 256 * 256 * 3 * 4,
 }
 res = {k: {"algorithmic_bytes_per_launch": v} for k, v in alg.items()}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
