@@ -35,6 +35,7 @@ SIGNATURES = {
     "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
     "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 9 + [_vp]),
     "eqa_mask_action_nearest": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),
+    "eqa_mask_action_nearest_planes": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),
     "eqa_boxes_action": (_int, [_vp] * 5 + [_int, ctypes.c_float, _int, _vp]),
     "eqa_image_action_nearest": (_int, [_vp] * 5 + [_int] * 10 + [_vp]),
     "eqa_group_action_bwd_tiles": (_int, [_int, _int]),
@@ -86,6 +87,8 @@ SIGNATURES = {
     "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_sums": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_affine_relu_rows": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_cosine_group_activations": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_float, _vp]),
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_window_sums_nhwc_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_window_sums_nhwc": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),

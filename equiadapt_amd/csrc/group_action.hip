@@ -968,6 +968,100 @@ __global__ __launch_bounds__(kThreads) void nearest_action_tile_kernel(const T* 
   }
 }
 
+// uint8 masks, the config-5 case (96 masks of 1024 x 1024 per step): the tiled kernel above staged its source box byte by
+// byte (one 64-byte wave load per 64 pixels) and stored 4 bytes per lane -- 0.21 ms for 0.2 GB = 1 TB/s, bound by the number
+// of memory instructions.  Same tile, same per-pixel arithmetic (bit-identical results), but the box is staged in whole dwords
+// (rows start 4-byte aligned: W % 4 == 0) and a thread owns 16 consecutive pixels of one row = one 16-byte store.  The source
+// planes come either from one contiguous tensor or from a table of per-plane pointers (the masks of a batch live in one
+// tensor per sample: no concatenation pass in front of the kernel).
+constexpr int kU8Pitch = 104;  // bytes per staged row: 96 + 3 (alignment slack), rounded to a dword multiple + 1 dword
+__global__ __launch_bounds__(kThreads) void mask_action_u8_kernel(const uint8_t* __restrict__ m, const uint8_t* const* __restrict__ planes,
+                                                                 uint8_t* __restrict__ out, const int32_t* __restrict__ eidx,
+                                                                 const float* __restrict__ rtheta, const int32_t* __restrict__ flags, int E,
+                                                                 int H, int W) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[kNearBox * kU8Pitch];
+  const int p = blockIdx.z;
+  const int i0 = blockIdx.y * kNearTile, j0 = blockIdx.x * kNearTile;
+  const int e = min(max(eidx[p], 0), E - 1);
+  const float* t = rtheta + e * 6;
+  const float t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+  const bool flip = flags && (flags[e] & EQA_FLIP_SRC);
+  const uint8_t* src = planes ? planes[p] : m + (size_t)p * H * W;
+  auto frame_xy = [&](int i, int j, float& xr, float& yr) {
+    const float yb = ((float)i + 0.5f) - 0.5f * (float)H;
+    const float xb = ((float)j + 0.5f) - 0.5f * (float)W;
+    const float gx = xb * t0 + yb * t1 + t2;
+    const float gy = xb * t3 + yb * t4 + t5;
+    xr = rintf(((gx + 1.0f) * (float)W - 1.0f) / 2.0f);  // std::nearbyint: round half to even
+    yr = rintf(((gy + 1.0f) * (float)H - 1.0f) / 2.0f);
+  };
+  const int i1 = min(i0 + kNearTile, H) - 1, j1 = min(j0 + kNearTile, W) - 1;
+  float xa, ya, xb_, yb_, xc, yc, xd, yd;
+  frame_xy(i0, j0, xa, ya); frame_xy(i0, j1, xb_, yb_); frame_xy(i1, j0, xc, yc); frame_xy(i1, j1, xd, yd);
+  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - 1, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + 1;
+  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - 1, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + 1;
+  fx0 = max(fx0, 0); fx1 = min(fx1, W - 1); fy0 = max(fy0, 0); fy1 = min(fy1, H - 1);
+  if (flip) { const int a = W - 1 - fx1, b = W - 1 - fx0; fx0 = a; fx1 = b; }
+  const int sx0 = fx0 & ~3, sx1 = fx1;               // dword-aligned left edge
+  const int sy0 = fy0, sy1 = fy1;
+  const int bw = sx1 - sx0 + 1, bh = sy1 - sy0 + 1;
+  const bool staged = bw > 0 && bh > 0 && bw <= kU8Pitch - 4 && bh <= kNearBox;  // block-uniform
+  if (staged) {
+    const int nd = (bw + 3) >> 2;                     // dwords per row (the last one may reach past sx1: still inside the row, W % 4 == 0)
+    // 32 dword slots per row (nd <= 25), 8 rows per pass, all 12 passes' loads in flight before the first LDS store (a rolled
+    // load -> store loop pays one HBM round trip per pass: 0.14 instead of 0.21 ms was all the dword staging bought that way)
+    constexpr int kPasses = kNearBox * 32 / kThreads;
+    const int d = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    uint32_t w[kPasses];
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+      const int r = r0 + 8 * k;
+      const bool on = d < nd && r < bh;
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + (size_t)(sy0 + (on ? r : 0)) * W + sx0 + 4 * (on ? d : 0));
+      w[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < kPasses; ++k) {
+      const int r = r0 + 8 * k;
+      if (d < nd && r < bh) *reinterpret_cast<uint32_t*>(s_src + r * kU8Pitch + 4 * d) = w[k];
+    }
+  }
+  __syncthreads();
+  const int i = i0 + (threadIdx.x >> 2);
+  const int jb = j0 + (threadIdx.x & 3) * 16;
+  if (i >= H || jb >= W) return;
+  uint32_t w4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float xr, yr;
+    frame_xy(i, jb + k, xr, yr);
+    uint32_t val = 0u;
+    if (xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1)) {
+      const int sx = flip ? (W - 1 - (int)xr) : (int)xr, sy = (int)yr;
+      const int lx = sx - sx0, ly = sy - sy0;
+      val = (staged && (unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) ? s_src[ly * kU8Pitch + lx] : src[(size_t)sy * W + sx];
+    }
+    w4[k >> 2] |= val << (8 * (k & 3));
+  }
+  uint8_t* o = out + (size_t)p * H * W + (size_t)i * W + jb;
+  if (jb + 15 < W) {
+    *reinterpret_cast<uint4*>(o) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+  } else {
+    for (int k = 0; k < 16; ++k)
+      if (jb + k < W) o[k] = (uint8_t)(w4[k >> 2] >> (8 * (k & 3)));
+  }
+}
+
+int launch_mask_u8(const uint8_t* m, const uint8_t* const* planes, uint8_t* out, const int32_t* eidx, const float* rtheta,
+                   const int32_t* flags, int E, int n_planes, int H, int W, void* stream) {
+  if ((!m && !planes) || !out || !eidx || !rtheta || E <= 0 || n_planes < 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (n_planes > 65535 || H > 65535 * kNearTile || (W & 15) || ((uintptr_t)out & 15) || ((uintptr_t)m & 3)) return EQA_ERR_UNSUPPORTED;
+  if (n_planes == 0) return EQA_OK;
+  hipLaunchKernelGGL(mask_action_u8_kernel, dim3((W + kNearTile - 1) / kNearTile, (H + kNearTile - 1) / kNearTile, n_planes), dim3(kThreads),
+                     0, (hipStream_t)stream, m, planes, out, eidx, rtheta, flags, E, H, W);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
 template <typename T>
 int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta, const int32_t* flags, int E,
                           int n_planes, int H, int W, int pad, int OH, int OW, int top, int left, int src_mod, void* stream) {
@@ -1178,7 +1272,14 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
 
 int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
                             int num_elements, int n_masks, int H, int W, void* stream) {
+  if (!g_force_direct && m && (W & 15) == 0 && (((uintptr_t)out & 15) | ((uintptr_t)m & 3)) == 0 && n_masks <= 65535)
+    return launch_mask_u8(m, nullptr, out, eidx, rtheta, flags, num_elements, n_masks, H, W, stream);
   return launch_nearest<uint8_t>(m, out, eidx, rtheta, flags, num_elements, n_masks, H, W, 0, H, W, 0, 0, 0, stream);
+}
+
+int eqa_mask_action_nearest_planes(const uint8_t* const* planes, uint8_t* out, const int32_t* eidx, const float* rtheta,
+                                   const int32_t* flags, int num_elements, int n_masks, int H, int W, void* stream) {
+  return launch_mask_u8(nullptr, planes, out, eidx, rtheta, flags, num_elements, n_masks, H, W, stream);
 }
 
 int eqa_boxes_action(const float* boxes, const int32_t* img_of_box, const float* rotation_deg, float* flipped, float* out,

@@ -81,9 +81,16 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
 //   [168,609) c1.Wf(21x21)  [609,1050) c1.Wd  [1050,1071) c1.bn scale  [1071,1092) c1.bn shift
 //   [1092,1113) bn1 scale  [1113,1134) bn1 shift
 //   [1134,1218) c2.Wf(4x21)  [1218,1302) c2.Wd  [1302,1306) c2.bn scale  [1306,1310) c2.bn shift
+//   pooling = "max" only: [1310,1751) pool.Wd(21x21)
+// MAXPOOL (VNMaxPool, vector_neuron_layers.py:349-364): per point and channel the edge with the largest <q_c, (W_p q)_c> is kept
+// instead of the mean over the edges -- the first such edge, like torch.max; W_p mixes all 21 channels of an edge, so the edge's
+// 21 vectors stay in registers until its 21 scores exist (two waves per SIMD instead of three).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm,
-                                                                 float* __restrict__ partial, int N, int nblk) {
+template <bool MAXPOOL>
+__global__ __launch_bounds__(kVnThreads, MAXPOOL ? 2 : EQA_VN_MIN_BLOCKS) void vnsmall_fwd_kernel(const float* __restrict__ x,
+                                                                                                const float* __restrict__ prm,
+                                                                                                float* __restrict__ partial, int N,
+                                                                                                int nblk) {
   extern __shared__ __attribute__((aligned(16))) float vn_smem[];
   float4* pts = reinterpret_cast<float4*>(vn_smem);  // [Npad] (x, y, z, |p|^2): one ds_read_b128 per candidate
   __shared__ float s_part[kVnThreads / 64][12];
@@ -100,8 +107,11 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_ker
 
   // ---- conv_pos on the k edges + mean over neighbours
   V3 pooled[kVnC];
+  float best[MAXPOOL ? kVnC : 1];
 #pragma unroll
   for (int c = 0; c < kVnC; ++c) pooled[c] = v3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < (MAXPOOL ? kVnC : 1); ++c) best[c] = 0.f;
   const float* Wf = prm;
   const float* Wd = prm + 63;
   const float* bsc = prm + 126;
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_ker
     const V3 nb = v3(nb4.x, nb4.y, nb4.z);
     const V3 f0 = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);                                   // neighbour - centre
     const V3 f2 = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);  // nbr x ctr
+    V3 qe[MAXPOOL ? kVnC : 1];
 #pragma unroll
     for (int c = 0; c < kVnC; ++c) {
       const float a0 = Wf[c * 3], a1 = Wf[c * 3 + 1], a2 = Wf[c * 3 + 2];
@@ -126,12 +137,37 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vnsmall_fwd_ker
       V3 q = v3(a0 * f0.x + a1 * ctr.x + a2 * f2.x, a0 * f0.y + a1 * ctr.y + a2 * f2.y, a0 * f0.z + a1 * ctr.z + a2 * f2.z);
       const V3 d = v3(d0 * f0.x + d1 * ctr.x + d2 * f2.x, d0 * f0.y + d1 * ctr.y + d2 * f2.y, d0 * f0.z + d1 * ctr.z + d2 * f2.z);
       q = vn_relu(vn_bn(q, bsc[c], bsh[c]), d);
-      pooled[c].x += q.x; pooled[c].y += q.y; pooled[c].z += q.z;
+      if (MAXPOOL) {
+        qe[c] = q;
+      } else {
+        pooled[c].x += q.x; pooled[c].y += q.y; pooled[c].z += q.z;
+      }
+    }
+    if (MAXPOOL) {
+      const float* Wp = prm + kVnParams;
+#pragma unroll
+      for (int c = 0; c < kVnC; ++c) {
+        if (c % 3 == 0) asm volatile("" ::: "memory");     // keeps the 441 scalar weights of W_p from being hoisted out of the edge loop
+        V3 dp = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < kVnC; ++a) {
+          const float w = Wp[c * kVnC + a];
+          dp.x += w * qe[a].x; dp.y += w * qe[a].y; dp.z += w * qe[a].z;
+        }
+        const float sc = qe[c].x * dp.x + qe[c].y * dp.y + qe[c].z * dp.z;
+        const bool take = t == 0 || sc > best[c];          // strict: the first maximal edge wins, as torch.max does
+        best[c] = take ? sc : best[c];
+        pooled[c].x = take ? qe[c].x : pooled[c].x;
+        pooled[c].y = take ? qe[c].y : pooled[c].y;
+        pooled[c].z = take ? qe[c].z : pooled[c].z;
+      }
     }
   }
-  const float inv_k = 1.0f / (float)kVnK;
+  if (!MAXPOOL) {
+    const float inv_k = 1.0f / (float)kVnK;
 #pragma unroll
-  for (int c = 0; c < kVnC; ++c) { pooled[c].x *= inv_k; pooled[c].y *= inv_k; pooled[c].z *= inv_k; }
+    for (int c = 0; c < kVnC; ++c) { pooled[c].x *= inv_k; pooled[c].y *= inv_k; pooled[c].z *= inv_k; }
+  }
 
   // ---- conv1 (21->21) + its VN-BN + ReLU, then bn1; every output channel is folded into conv2's (21->4) two linear
   // maps as soon as it exists, so the 21 x 3 intermediate never has to be held in registers
@@ -274,13 +310,16 @@ int64_t eqa_vnsmall_workspace_bytes(int B, int N) {
 int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
                     void* stream) {
   if (!x || !params || !out || !workspace || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
-  if (k != kVnK || pooling != 0 || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20, mean pooling
+  if (k != kVnK || (pooling != 0 && pooling != 1) || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20; pooling 0 mean, 1 max
   const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
   if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = (N + kVnThreads - 1) / kVnThreads;
-  hipLaunchKernelGGL(vnsmall_fwd_kernel, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  if (pooling == 1)
+    hipLaunchKernelGGL(vnsmall_fwd_kernel<true>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  else
+    hipLaunchKernelGGL(vnsmall_fwd_kernel<false>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
   return launch_status();

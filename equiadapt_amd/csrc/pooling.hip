@@ -409,6 +409,45 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
   }
 }
 
+
+// ---- Optimized canonicalizer, inference tail (I8 / I10): embeddings of the G views -> (B, G) activations -------------------
+// z = relu(h * scale[d] + shift[d]) on (R, D) rows: BatchNorm1d (eval, folded) + ReLU of ConvNetwork's head
+// (custom_nonequivariant_networks.py:62-67) in one pass
+__global__ __launch_bounds__(kThreads) void affine_relu_rows_kernel(const float* __restrict__ h, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, float* __restrict__ z, size_t n_vec,
+                                                                   int Dq) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * kThreads) {
+    const int q = (int)(i % Dq);
+    const float4 v = reinterpret_cast<const float4*>(h)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    reinterpret_cast<float4*>(z)[i] = make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f),
+                                                  fmaxf(v.z * sc.z + sh.z, 0.f), fmaxf(v.w * sc.w + sh.w, 0.f));
+  }
+}
+
+// act[b][g] = cosine_similarity(ref, v[g * B + b]) = sum(ref / max(|ref|, eps) * v / max(|v|, eps)) -- torch's formula -- for the
+// element-major (G * B, V) embeddings of the orbit (discrete_group.py:475-481: cosine_similarity, reshape(G, -1).T): one wave
+// per embedding, lanes over V, wavefront-shuffle reductions; replaces ~10 element-wise launches and the transposed copy.
+__global__ __launch_bounds__(kThreads) void cosine_group_activations_kernel(const float* __restrict__ v, const float* __restrict__ ref,
+                                                                           float* __restrict__ act, int B, int G, int V, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);      // row of v: g * B + b
+  if (r >= G * B) return;
+  float rr = 0.f, vv = 0.f;
+  for (int k = lane; k < V; k += 64) {
+    const float a = ref[k], x = v[(size_t)r * V + k];
+    rr += a * a;
+    vv += x * x;
+  }
+  rr = wave_sum_f(rr);
+  vv = wave_sum_f(vv);
+  const float inv_r = 1.0f / fmaxf(sqrtf(rr), eps), inv_v = 1.0f / fmaxf(sqrtf(vv), eps);
+  float dot = 0.f;
+  for (int k = lane; k < V; k += 64) dot += (ref[k] * inv_r) * (v[(size_t)r * V + k] * inv_v);
+  dot = wave_sum_f(dot);
+  if (lane == 0) act[(size_t)(r % B) * G + r / B] = dot;
+}
+
 }  // namespace
 
 int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream, int sub) {
@@ -481,6 +520,26 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
   if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
   if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(sums_gemv_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  return launch_status();
+}
+
+int eqa_affine_relu_rows(const float* h, const float* scale, const float* shift, float* z, int64_t rows, int D, void* stream) {
+  if (!h || !scale || !shift || !z || rows < 0 || D <= 0) return EQA_ERR_INVALID_ARG;
+  if (D % 4 != 0 || (((uintptr_t)h | (uintptr_t)z | (uintptr_t)scale | (uintptr_t)shift) & 15)) return EQA_ERR_UNSUPPORTED;
+  if (rows == 0) return EQA_OK;
+  const size_t n_vec = (size_t)rows * (D / 4);
+  const unsigned blocks = (unsigned)std::min<size_t>((n_vec + kThreads - 1) / kThreads, 8192);
+  hipLaunchKernelGGL(affine_relu_rows_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, h, scale, shift, z, n_vec, D / 4);
+  return launch_status();
+}
+
+int eqa_cosine_group_activations(const float* v, const float* ref, float* act, int B, int G, int V, float eps, void* stream) {
+  if (!v || !ref || !act || B < 0 || G <= 0 || V <= 0) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if ((int64_t)B * G > 0x7fffffff) return EQA_ERR_UNSUPPORTED;
+  const int rows = B * G, per = kThreads / 64;
+  hipLaunchKernelGGL(cosine_group_activations_kernel, dim3((rows + per - 1) / per), dim3(kThreads), 0, (hipStream_t)stream, v, ref, act, B,
+                     G, V, eps);
   return launch_status();
 }
 

@@ -318,6 +318,9 @@ class OptimizedGroupEquivariantImageCanonicalization(DiscreteGroupImageCanonical
             vector_out_dummy = self.canonicalization_network(x_dummy)
             self.canonicalization_info_dict.update({"vector_out_dummy": vector_out_dummy})
 
+        if vector_out.is_cuda and vector_out.dtype == torch.float32 and not torch.is_grad_enabled():
+            # inference: cosine similarity + (G, B) -> (B, G) in one launch (the element-wise form below is ~10)
+            return ops.cosine_group_activations(vector_out, self.reference_vector.detach(), self.num_group)
         scalar_out = F.cosine_similarity(self.reference_vector.repeat(vector_out.shape[0], 1), vector_out)
         return scalar_out.reshape(self.num_group, -1).T
 

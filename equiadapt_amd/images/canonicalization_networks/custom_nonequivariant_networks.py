@@ -57,5 +57,18 @@ class ConvNetwork(nn.Module):
                     continue
                 w, b = self._folded(conv, bn)
                 h = act(torch.nn.functional.conv2d(h, w, b, conv.stride, conv.padding, conv.dilation, conv.groups))
-            return self.final_fc(h.reshape(x.shape[0], -1))
+            h = h.reshape(x.shape[0], -1)
+            bn1, lin = self.final_fc[0], self.final_fc[3]
+            if h.dtype == torch.float32 and h.shape[1] % 4 == 0 and bn1.running_mean is not None:
+                # head: BatchNorm1d (eval, folded) + [Dropout1d: identity] + ReLU in one pass, then the Linear layer
+                from equiadapt_amd import ops
+
+                key = (bn1.weight._version, bn1.bias._version, bn1.running_mean._version, bn1.running_var._version, str(h.device))
+                hit = self._fold_cache.get("head")
+                if hit is None or hit[0] != key:
+                    scale = (bn1.weight / torch.sqrt(bn1.running_var + bn1.eps)).contiguous()
+                    hit = (key, scale, (bn1.bias - bn1.running_mean * scale).contiguous())
+                    self._fold_cache["head"] = hit
+                return torch.nn.functional.linear(ops.affine_relu_rows(h.contiguous(), hit[1], hit[2]), lin.weight, lin.bias)
+            return self.final_fc(h)
         return self.final_fc(self.enc_network(x).reshape(x.shape[0], -1))

@@ -205,7 +205,10 @@ def canonicalize_masks(mask_list, group_index: torch.Tensor, num_rotations: int,
     rtheta, flags = hit
     ridx = (group_index % num_rotations).to(torch.int32)
     eidx = ridx[owner_table(counts, dev).long()]
-    out = ops.mask_action_nearest(torch.cat(list(mask_list), dim=0).contiguous(), eidx, rtheta, flags)
+    if W % 16 == 0 and len(mask_list) > 1 and all(m.data_ptr() % 4 == 0 for m in mask_list):
+        out = ops.mask_action_nearest_planes([m for m in mask_list if m.shape[0]], eidx, rtheta, flags)   # no concatenation pass
+    else:
+        out = ops.mask_action_nearest(torch.cat(list(mask_list), dim=0).contiguous(), eidx, rtheta, flags)
     return list(torch.split(out, counts, dim=0))
 
 

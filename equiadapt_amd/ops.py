@@ -307,18 +307,21 @@ def gram_schmidt(v: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def vnsmall_forward(x: torch.Tensor, params: torch.Tensor, k: int = 20) -> torch.Tensor:
-    """P1+P2 fused: (B,3,N) point clouds + packed VNSmall parameters -> (B,3,3) equivariant vectors (eqa_vnsmall_fwd)."""
+def vnsmall_forward(x: torch.Tensor, params: torch.Tensor, k: int = 20, pooling: str = "mean") -> torch.Tensor:
+    """P1+P2 fused: (B,3,N) point clouds + packed VNSmall parameters -> (B,3,3) equivariant vectors (eqa_vnsmall_fwd).
+    ``pooling`` "mean" (1310 packed floats) or "max" (1751: + the pooling layer's 21 x 21 direction map)."""
     lib = _lib.load()
     x = _need(x, "point_cloud")
     params = _need(params, "params")
     B, three, N = x.shape
-    if three != 3 or params.numel() != 1310:
-        raise ValueError("vnsmall_forward expects x:(B,3,N) and 1310 packed parameters")
+    if pooling not in ("mean", "max"):
+        raise ValueError(f"Pooling type {pooling} not supported")
+    if three != 3 or params.numel() != (1310 if pooling == "mean" else 1751):
+        raise ValueError("vnsmall_forward expects x:(B,3,N) and 1310 (mean) / 1751 (max) packed parameters")
     out = torch.empty((B, 3, 3), dtype=torch.float32, device=x.device)
     ws = torch.empty((max(lib.eqa_vnsmall_workspace_bytes(B, N), 4) // 4,), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("vnsmall_fwd"):
-        st = lib.eqa_vnsmall_fwd(x.data_ptr(), params.data_ptr(), out.data_ptr(), ws.data_ptr(), B, N, k, 0, _stream())
+        st = lib.eqa_vnsmall_fwd(x.data_ptr(), params.data_ptr(), out.data_ptr(), ws.data_ptr(), B, N, k, int(pooling == "max"), _stream())
     _lib.check(st, "eqa_vnsmall_fwd")
     return out
 
@@ -354,6 +357,27 @@ def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.T
     return out
 
 
+def mask_action_nearest_planes(mask_list, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor]) -> torch.Tensor:
+    """I6 for a LIST of per-sample (n_t, H, W) uint8 mask tensors: one launch over all planes, read through a table of plane
+    pointers (eqa_mask_action_nearest_planes) instead of a concatenated copy.  Returns one (sum n_t, H, W) tensor."""
+    lib = _lib.load()
+    eidx = _need(eidx, "eidx", torch.int32)
+    rtheta = _need(rtheta, "rtheta")
+    flags, p_flags = _opt(flags, "flags", torch.int32)
+    masks = [_need(m, "masks", torch.uint8) for m in mask_list]
+    H, W = masks[0].shape[-2:]
+    ptrs = [m.data_ptr() + k * H * W for m in masks for k in range(m.shape[0])]
+    n = len(ptrs)
+    dev = masks[0].device
+    table = torch.tensor(ptrs, dtype=torch.int64).to(dev, non_blocking=True)
+    out = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev), _timed("mask_action"):
+        st = lib.eqa_mask_action_nearest_planes(table.data_ptr(), out.data_ptr(), eidx.data_ptr(), rtheta.data_ptr(), p_flags,
+                                                rtheta.shape[0], n, H, W, _stream())
+    _lib.check(st, "eqa_mask_action_nearest_planes")
+    return out
+
+
 def boxes_action(boxes: torch.Tensor, img_of_box: torch.Tensor, rotation_deg: torch.Tensor, width: float,
                  flip_all: bool) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """I6: every (n,4) xyxy box flipped (if ``flip_all``) and rotated by its image's angle about (width/2, width/2), one
@@ -370,6 +394,33 @@ def boxes_action(boxes: torch.Tensor, img_of_box: torch.Tensor, rotation_deg: to
                                   int(flip_all), _stream())
     _lib.check(st, "eqa_boxes_action")
     return out, flipped
+
+
+def affine_relu_rows(h: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """relu(h * scale[d] + shift[d]) on (rows, D) (eqa_affine_relu_rows): eval-mode BatchNorm1d + ReLU in one pass."""
+    lib = _lib.load()
+    h, scale, shift = _need(h, "h"), _need(scale, "scale"), _need(shift, "shift")
+    rows, D = h.shape
+    z = torch.empty_like(h)
+    with torch.cuda.device(h.device):
+        st = lib.eqa_affine_relu_rows(h.data_ptr(), scale.data_ptr(), shift.data_ptr(), z.data_ptr(), rows, D, _stream())
+    _lib.check(st, "eqa_affine_relu_rows")
+    return z
+
+
+def cosine_group_activations(v: torch.Tensor, ref: torch.Tensor, num_group: int, eps: float = 1e-8) -> torch.Tensor:
+    """(G*B, V) element-major embeddings, (V) reference -> (B, G) cosine similarities (eqa_cosine_group_activations)."""
+    lib = _lib.load()
+    v, ref = _need(v, "vector_out"), _need(ref.reshape(-1), "reference_vector")
+    R, V = v.shape
+    if R % num_group or ref.numel() != V:
+        raise ValueError("cosine_group_activations expects (G*B, V) embeddings and a (V) reference vector")
+    B = R // num_group
+    act = torch.empty((B, num_group), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        st = lib.eqa_cosine_group_activations(v.data_ptr(), ref.data_ptr(), act.data_ptr(), B, num_group, V, float(eps), _stream())
+    _lib.check(st, "eqa_cosine_group_activations")
+    return act
 
 
 def bias_relu_nhwc_(x: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:

@@ -138,7 +138,8 @@ class VNSmall(nn.Module):
 
     def packed_parameters(self) -> torch.Tensor:
         """The 1310 floats the fused kernel consumes (layout: csrc/pointcloud.hip), eval-mode batch-norms folded to a
-        scale/shift of the vector norm.  Cached per parameter version."""
+        scale/shift of the vector norm; "max" pooling: + the 441 of the pooling layer's direction map.  Cached per parameter
+        version."""
         tensors = list(self.parameters()) + [b for b in self.buffers()]
         key = tuple(t._version for t in tensors) + (str(tensors[0].device),)
         hit = getattr(self, "_packed", None)
@@ -156,17 +157,19 @@ class VNSmall(nn.Module):
         parts += list(fold(self.bn1.bn1d))
         sc, sh = fold(self.conv2.batchnorm.bn1d)
         parts += [self.conv2.map_to_feat.weight.flatten(), self.conv2.map_to_dir.weight.flatten(), sc, sh]
+        if self.pooling == "max":
+            parts.append(self.pool.map_to_dir.weight.flatten())
         packed = torch.cat([p.detach().float() for p in parts]).contiguous()
-        assert packed.numel() == 1310
+        assert packed.numel() == (1751 if self.pooling == "max" else 1310)
         self._packed = (key, packed)
         return packed
 
     def forward(self, point_cloud: torch.Tensor) -> torch.Tensor:
-        if (point_cloud.is_cuda and not self.training and not torch.is_grad_enabled() and self.pooling == "mean"
+        if (point_cloud.is_cuda and not self.training and not torch.is_grad_enabled()
                 and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32):
             from equiadapt_amd import ops
 
-            return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn)
+            return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn, self.pooling)
         if (point_cloud.is_cuda and torch.is_grad_enabled() and not point_cloud.requires_grad and self.pooling == "mean"
                 and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32
                 and os.environ.get("EQA_TRAIN_FAST", "1") != "0"):

@@ -116,6 +116,11 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
  */
 int eqa_mask_action_nearest(const uint8_t* m, uint8_t* out, const int32_t* eidx, const float* rtheta, const int32_t* flags,
                             int num_elements, int n_masks, int H, int W, void* stream);
+/* The same with the source planes given one by one: planes:(n_masks) device array of device pointers to (H,W) uint8 planes, each
+ * 4-byte aligned -- the masks of a batch are one tensor per sample (discrete_group.py:217-236 loops over the samples), so no
+ * concatenation pass is needed in front of the kernel.  W % 16 == 0 and out 16-byte aligned, else EQA_ERR_UNSUPPORTED. */
+int eqa_mask_action_nearest_planes(const uint8_t* const* planes, uint8_t* out, const int32_t* eidx, const float* rtheta,
+                                   const int32_t* flags, int num_elements, int n_masks, int H, int W, void* stream);
 
 /*
  * I6 -- the boxes of a batch follow their images: flip_boxes (equiadapt/images/utils.py:97-109; applied to EVERY box when
@@ -200,6 +205,14 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
  *   eqa_window_sums_nhwc  eqa_window_sums for a (B,H,W,C) buffer; out:(B,C,k,k) fp64 as above;
  *                         workspace: eqa_window_sums_nhwc_workspace_bytes(B, C, H, k) bytes.
  */
+/* Optimized canonicalizer, inference tail:
+ *   eqa_affine_relu_rows           z:(rows,D) = relu(h * scale[d] + shift[d]): the eval-mode BatchNorm1d (folded to scale / shift) +
+ *                                  ReLU in front of ConvNetwork's Linear head (custom_nonequivariant_networks.py:62-67); D % 4 == 0.
+ *   eqa_cosine_group_activations   v:(G*B,V) element-major orbit embeddings, ref:(V) -> act:(B,G) =
+ *                                  cosine_similarity(ref, v[g*B+b]) with torch's formula (each vector divided by max(norm, eps)):
+ *                                  discrete_group.py:475-481 (cosine_similarity + reshape(G,-1).T) in one launch. */
+int eqa_affine_relu_rows(const float* h, const float* scale, const float* shift, float* z, int64_t rows, int D, void* stream);
+int eqa_cosine_group_activations(const float* v, const float* ref, float* act, int B, int G, int V, float eps, void* stream);
 int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream);
 int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k);
 int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
@@ -387,12 +400,16 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
  * mean over points in one kernel; a cloud is staged once in LDS, every intermediate lives in registers.
  * Replaces equiadapt/pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn,
  * get_graph_feature_cross) and :128-150 (VNSmall.forward) with vector_neuron_layers.py:251-273, :303-324.
- * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; k must be 20, pooling 0 (= "mean").
- * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in csrc/pointcloud.hip).
- * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  Other k / "max" pooling / training: EQA_ERR_UNSUPPORTED
- * (the host keeps an op-by-op path for those).
+ * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; k must be 20; pooling 0 = "mean",
+ * 1 = "max" (VNMaxPool, vector_neuron_layers.py:327-364: per point and channel the edge maximising <x, W_p x>, first index on
+ * ties like torch.max).
+ * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in csrc/pointcloud.hip);
+ * pooling 1: + the 441 floats of the pooling layer's map_to_dir weight (EQA_VNSMALL_PARAMS_MAX in total).
+ * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  Other k / training: EQA_ERR_UNSUPPORTED (the host keeps an op-by-op
+ * path for those).
  */
 #define EQA_VNSMALL_PARAMS 1310
+#define EQA_VNSMALL_PARAMS_MAX 1751
 int64_t eqa_vnsmall_workspace_bytes(int B, int N);
 int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
                     void* stream);

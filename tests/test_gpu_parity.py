@@ -398,6 +398,44 @@ def test_fused_vnsmall_matches_reference_golden_and_op_path(dev, golden):
     assert torch.allclose(vr, torch.bmm(v, R.transpose(1, 2)), atol=1e-5)
 
 
+def test_fused_vnsmall_max_pooling_matches_reference_golden(dev, golden):
+    """pooling="max" through the fused kernel (eqa_vnsmall_fwd, pooling 1): VNMaxPool's argmax over the 20 edges of <x, W_p x>
+    (vector_neuron_layers.py:349-364) against the reference-generated vectors, the whole canonicalizer (Gram-Schmidt, rotate,
+    losses) against the reference's, and against the op-by-op module path.  An argmax over near-ties can move on a last-bit
+    difference of a score; one moved pick changes the mean over N points by |dx| / N, hence the 2e-5 bound."""
+    import equiadapt_amd as ea
+
+    c = golden("pointcloud.pt")["max"]
+    hp = types.SimpleNamespace(n_knn=20, pooling="max")
+    net = ea.VNSmall(hp)
+    net.load_state_dict(c["state"])
+    net = net.to(dev).eval()
+    assert net.packed_parameters().numel() == 1751
+    with torch.no_grad():
+        fused = net(c["x"].to(dev)).cpu()
+    err = (fused - c["vnsmall_out"]).abs().max().item()
+    assert err <= 2e-5 * max(c["vnsmall_out"].abs().max().item(), 1.0), err
+    can = ea.EquivariantPointcloudCanonicalization(net, hp).to(dev).eval()
+    with torch.no_grad():
+        xc = can(c["x"].to(dev)).cpu()
+    R = can.canonicalization_info_dict["group_element_matrix_representation"].cpu()
+    assert torch.allclose(R, c["rotation"], atol=1e-4) and torch.allclose(xc, c["x_canonicalized"], atol=5e-4)
+    assert torch.allclose(can.get_prior_regularization_loss().cpu(), c["prior_loss"], atol=1e-4)
+    torch.manual_seed(14)
+    for (B, N) in [(3, 1024), (2, 300), (1, 20)]:
+        x = torch.randn(B, 3, N, device=dev)
+        with torch.no_grad():
+            fused = net(x)
+        with torch.enable_grad():
+            slow = net(x).detach()  # grad mode -> op-by-op torch path
+        assert (fused - slow).abs().max().item() <= 2e-5 * max(slow.abs().max().item(), 1.0), (B, N, (fused - slow).abs().max().item())
+    x = torch.randn(4, 3, 512, device=dev)
+    Rr = torch.linalg.qr(torch.randn(4, 3, 3, device=dev)).Q
+    with torch.no_grad():
+        v, vr = net(x), net(torch.bmm(Rr, x))
+    assert torch.allclose(vr, torch.bmm(v, Rr.transpose(1, 2)), atol=2e-5)
+
+
 def test_crop_resize_aa_matches_torch_interpolate(dev):
     """I1: eqa_crop_resize_aa vs torchvision semantics (CenterCrop -> F.interpolate(antialias=True)) on the CPU."""
     from equiadapt_amd import ops
@@ -438,6 +476,47 @@ def test_mask_action_nearest_bit_exact(dev, golden):
     for t, m in enumerate(masks):
         want = io.rotate_masks(io.flip_masks(m), -ang[gidx[t] % 4].item()) if m.shape[0] else m
         assert torch.equal(got[t].cpu(), want), t
+
+
+def test_mask_action_u8_dword_staged_kernel_and_plane_table_bit_exact(dev):
+    """The uint8 mask kernel with dword staging / 16-byte stores (widths that are multiples of 16) and its plane-pointer-table
+    entry point (eqa_mask_action_nearest_planes: per-sample mask tensors, no concatenation): bit-exact against the oracle's
+    torchvision restatement for every element of C8 and D4, square and non-square planes, ragged tiles, and against the
+    byte-staged kernel it replaces."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import canonicalize_masks
+
+    g = torch.Generator().manual_seed(16)
+    for (H, W) in [(64, 64), (80, 112), (144, 48), (256, 256)]:
+        m = (torch.rand(3, H, W, generator=g) * 255).to(torch.uint8)
+        for ang in (-45.0, 90.0, 135.0, -270.0, 0.0, 315.0, 180.0):
+            want = io.rotate_masks(m, ang)
+            got = ea.rotate_masks(m.to(dev), ang)
+            assert torch.equal(got.cpu(), want), (H, W, ang)
+            _lib.load().eqa_set_option(0, 1)              # the row-per-block kernel without staging
+            try:
+                old = ea.rotate_masks(m.to(dev), ang)
+            finally:
+                _lib.load().eqa_set_option(0, 0)
+            assert torch.equal(old, got), (H, W, ang)
+    for (N, flip, S) in [(8, False, 128), (4, True, 96)]:
+        masks = [(torch.rand(n, S, S, generator=g) > 0.5).to(torch.uint8) for n in (2, 0, 3, 1, 4)]
+        G = 2 * N if flip else N
+        gidx = torch.randint(0, G, (5,), generator=g)
+        calls = []
+        orig = ops.mask_action_nearest_planes
+        ops.mask_action_nearest_planes = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+        try:
+            got = canonicalize_masks([m.to(dev) for m in masks], gidx.to(dev, torch.int32), N, flip_all=flip)
+        finally:
+            ops.mask_action_nearest_planes = orig
+        assert calls, "the plane-pointer path was not taken"
+        ang = io.group_angles(N)
+        for t, m in enumerate(masks):
+            src = io.flip_masks(m) if flip else m
+            want = io.rotate_masks(src, -ang[gidx[t] % N].item()) if m.shape[0] else m
+            assert torch.equal(got[t].cpu(), want), (N, flip, t)
 
 
 def test_canonicalize_with_targets(dev):
