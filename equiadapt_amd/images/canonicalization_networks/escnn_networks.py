@@ -242,6 +242,21 @@ class ESCNNEquivariantNetwork(nn.Module):
         self._dense: Sequence = ()
         self._fold_cache: dict = {}
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        """A checkpoint of the reference's e2cnn network (escnn_networks.py:48-91) cannot be loaded by key: e2cnn stores a flat
+        coefficient vector per layer over its steerable basis (``...weights`` 1-D, ``...basisexpansion...`` / ``...filter``
+        buffers), this network stores rotated filter banks.  Say so instead of failing on a shape mismatch."""
+        own = prefix + "eqv_network."
+        for k, v in state_dict.items():
+            if k.startswith(own) and ("basisexpansion" in k or k.endswith(".filter") or k.endswith(".expanded_bias")
+                                      or (k.endswith(".weights") and getattr(v, "dim", lambda: 2)() == 1)):
+                raise RuntimeError(
+                    f"state_dict key {k!r} comes from e2cnn's steerable-basis parameterisation (the reference's ESCNNEquivariantNetwork). "
+                    "equiadapt_amd.ESCNNEquivariantNetwork parameterises its layers by rotated filter banks and cannot load it by key; "
+                    "export the trained layers on the e2cnn side (R2Conv.export() -> nn.Conv2d, InnerBatchNorm.export() -> nn.BatchNorm2d) "
+                    "and pass them to load_exported_dense(convs, norms).")
+        return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def load_exported_dense(self, convs: Sequence[nn.Conv2d], norms: Sequence[nn.BatchNorm2d]) -> None:
         """Use exported dense layers (lists in network order) instead of the filter-bank parameterisation: the bridge for
         weights trained with e2cnn, whose steerable-basis parameters cannot be loaded by key (``R2Conv.export()`` ->

@@ -303,3 +303,20 @@ def test_generated_fft48_is_current_and_correct():
         sw = gen.evaluate(z.imag + 1j * z.real)                      # inverse = forward on swapped parts, swapped back
         inv = sw.imag + 1j * sw.real
         assert np.abs(inv - np.fft.ifft(z) * 48).max() <= 4e-6 * np.abs(want).max()
+
+
+def test_escnn_network_refuses_e2cnn_checkpoints_with_a_pointer_to_the_bridge():
+    """A reference checkpoint (e2cnn steerable-basis parameters) must fail with an explanation, not with a shape mismatch."""
+    import pytest
+    import torch
+
+    import equiadapt_amd as ea
+
+    net = ea.ESCNNEquivariantNetwork((3, 32, 32), 2, 3, "rotation", 4, 2)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net.load_state_dict(sd)                                     # its own state dict loads
+    bad = dict(sd)
+    bad["eqv_network.0.weights"] = torch.zeros(24)              # e2cnn: one flat coefficient vector per layer
+    bad["eqv_network.0.basisexpansion.block_expansion_('irrep_0', 'regular').sampled_basis"] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match="load_exported_dense"):
+        net.load_state_dict(bad, strict=False)
