@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "fftconv.hip", "cgemm3m.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "fftconv.hip", "cgemm3m.hip", "smallconv.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -87,6 +87,8 @@ SIGNATURES = {
     "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_sums": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_conv_s2_supported": (_int, [_int] * 5),
+    "eqa_conv_s2": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 8 + [_vp]),
     "eqa_affine_relu_rows": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_cosine_group_activations": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_float, _vp]),
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),

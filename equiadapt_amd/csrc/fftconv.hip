@@ -500,16 +500,30 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
 #pragma unroll
       for (int i = 0; i < NV; ++i) o[i] = acc[i];
     }
-    __syncthreads();
-    if (y < kFftO) {
+    // a wave holds 64 / CH consecutive rows of the same CH channels: those are summed by wavefront shuffles first, one LDS slot
+    // per wave instead of one per row (44 -> 11 terms in the serial sum below, a quarter of the LDS traffic)
+    constexpr int kRowsPerWave = 64 / CH;
+    static_assert(kFftO % kRowsPerWave == 0 || CH > 16, "the rows of a wave are either all below 44 or all above");
 #pragma unroll
-      for (int i = 0; i < NV; ++i) lds[(y * NV + i) * CH + cl] = (valid && !border) ? acc[i] : 0.0f;
+    for (int i = 0; i < NV; ++i) {
+      float v = (valid && !border) ? acc[i] : 0.0f;
+#pragma unroll
+      for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[i] = v;
+    }
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    constexpr int kWaves = (kFftO * CH + 63) / 64;      // waves that hold output rows
+    if ((threadIdx.x & 63) < CH && wv < kWaves) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) lds[(wv * NV + i) * CH + cl] = acc[i];
     }
     __syncthreads();
     if (threadIdx.x < NV * CH) {
       const int i = threadIdx.x / CH;
       float t = 0.0f;
-      for (int r = 0; r < kFftO; ++r) t += lds[(r * NV + i) * CH + cl];
+#pragma unroll
+      for (int r = 0; r < kWaves; ++r) t += lds[(r * NV + i) * CH + cl];
       // tile rows made of border rows only (OH <= 2 NB + ...) contribute an all-zero piece: harmless
       out[(((img * nseg + 2 * NB + ty) * TX + tx) * (size_t)C + c) * NV + i] = t;
     }

@@ -4,6 +4,7 @@ Reference: equiadapt/images/canonicalization_networks/custom_nonequivariant_netw
 Small MIOpen convolutions (PyTorch-ROCm); module / parameter names match the reference's state_dict.
 The pretrained torchvision wrappers (ResNet18Network, WideResNet*) are out of scope.
 """
+import os
 from typing import List
 
 import torch
@@ -46,8 +47,58 @@ class ConvNetwork(nn.Module):
             self._fold_cache[id(conv)] = hit
         return hit[1], hit[2]
 
+    def _mfma_plan(self, x: torch.Tensor):
+        """Per layer (packed weights, bias, Cout, k, pad, planar) when EVERY convolution of the encoder fits eqa_conv_s2 (stride 2,
+        k in {3,5,7}, first layer <= 4 input planes, then multiples of 16 channels), plus the head's parameters re-indexed from
+        the reference's (C,H,W) flattening to the kernels' channels-last one; None otherwise.  Cached per parameter version."""
+        from equiadapt_amd import ops
+
+        mods = list(self.enc_network)
+        convs, bns = mods[0::3], mods[1::3]
+        if any(not isinstance(a, nn.GELU) or a.approximate != "none" for a in mods[2::3]) or any(bn.running_mean is None for bn in bns):
+            return None
+        tensors = [t for m in list(convs) + list(bns) + [self.final_fc[0], self.final_fc[3]] for t in list(m.parameters()) + list(m.buffers())]
+        key = tuple(t._version for t in tensors) + (tuple(x.shape[1:]), str(x.device))
+        hit = self._fold_cache.get("mfma")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        plan, layers, hw = None, [], tuple(x.shape[-2:])
+        ok = True
+        for i, (conv, bn) in enumerate(zip(convs, bns)):
+            k, pad = conv.kernel_size[0], conv.padding[0]
+            if (conv.kernel_size[0] != conv.kernel_size[1] or conv.stride != (2, 2) or conv.padding[0] != conv.padding[1] or conv.groups != 1
+                    or conv.dilation != (1, 1) or not ops.conv_s2_supported(conv.in_channels, conv.out_channels, k, pad, i == 0)):
+                ok = False
+                break
+            w, b = self._folded(conv, bn)
+            layers.append((ops.pack_conv_s2_weights(w, i == 0), b, conv.out_channels, k, pad, i == 0))
+            hw = ((hw[0] + 2 * pad - k) // 2 + 1, (hw[1] + 2 * pad - k) // 2 + 1)
+        bn1, lin = self.final_fc[0], self.final_fc[3]
+        if ok and bn1.running_mean is not None and min(hw) > 0:
+            C = convs[-1].out_channels
+            # feature d of the reference = c * H * W + y * W + x; the kernels produce (y, x, c): gather the head's parameters
+            idx = torch.arange(C * hw[0] * hw[1], device=x.device).view(C, hw[0], hw[1]).permute(1, 2, 0).reshape(-1)
+            scale = bn1.weight / torch.sqrt(bn1.running_var + bn1.eps)
+            shift = bn1.bias - bn1.running_mean * scale
+            plan = (layers, scale[idx].contiguous(), shift[idx].contiguous(), lin.weight[:, idx].contiguous())
+        self._fold_cache["mfma"] = (key, plan)
+        return plan
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            if x.dtype == torch.float32 and os.environ.get("EQA_CONVNET_MFMA", "1") != "0":
+                plan = self._mfma_plan(x)
+                if plan is not None:
+                    # inference: every convolution (+ folded batch-norm + GELU) on the fp32 matrix cores, channels-last from the
+                    # first layer on; head = BatchNorm1d + ReLU in one pass + the Linear layer, re-indexed to that layout
+                    from equiadapt_amd import ops
+
+                    layers, scale, shift, wlin = plan
+                    h = x.contiguous()
+                    for wp, b, cout, k, pad, planar in layers:
+                        h = ops.conv_s2(h, wp, b, True, cout, k, pad, planar)
+                    z = ops.affine_relu_rows(h.view(x.shape[0], -1), scale, shift)
+                    return torch.nn.functional.linear(z, wlin, self.final_fc[3].bias)
             # inference: eval-mode batch-norms folded into the convolutions (three fewer passes over the feature maps)
             mods = list(self.enc_network)
             h = x

@@ -396,6 +396,40 @@ def boxes_action(boxes: torch.Tensor, img_of_box: torch.Tensor, rotation_deg: to
     return out, flipped
 
 
+def conv_s2_supported(cin: int, cout: int, k: int, pad: int, planar: bool) -> bool:
+    return bool(_lib.load().eqa_conv_s2_supported(cin, cout, k, pad, int(planar)))
+
+
+def pack_conv_s2_weights(w: torch.Tensor, planar: bool) -> torch.Tensor:
+    """(Cout, Cin, K, K) filters -> the operand order of eqa_conv_s2 (layouts: include/eqa_hip.h)."""
+    Cout, Cin, K, _ = w.shape
+    if planar:
+        wp = torch.zeros(Cout, 4, K, K, dtype=w.dtype, device=w.device)
+        wp[:, :Cin] = w
+        return wp.permute(2, 3, 1, 0).reshape(K * K, 4, Cout // 16, 16).permute(0, 2, 1, 3).contiguous()
+    t = w.permute(2, 3, 1, 0).reshape(K * K, Cin // 16, 4, 4, Cout // 16, 16)      # tap, chunk, kq, s, n, j
+    return t.permute(0, 1, 4, 2, 5, 3).contiguous()                                  # tap, chunk, n, kq, j, s
+
+
+def conv_s2(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], gelu: bool, cout: int, k: int, pad: int,
+            planar: bool) -> torch.Tensor:
+    """Stride-2 k x k convolution (+ bias, + exact GELU) on the fp32 MFMA (eqa_conv_s2).  planar: x (B,Cin<=4,H,W) contiguous;
+    else x is a (B,H,W,Cin) contiguous tensor.  Returns (B,OH,OW,Cout) contiguous (channels-last data)."""
+    lib = _lib.load()
+    x, wp = _need(x, "x"), _need(wp, "wp")
+    bias, p_bias = _opt(bias, "bias", torch.float32)
+    if planar:
+        B, cin, H, W = x.shape
+    else:
+        B, H, W, cin = x.shape
+    OH, OW = (H + 2 * pad - k) // 2 + 1, (W + 2 * pad - k) // 2 + 1
+    y = torch.empty((B, OH, OW, cout), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("conv_s2"):
+        st = lib.eqa_conv_s2(x.data_ptr(), wp.data_ptr(), p_bias, int(gelu), y.data_ptr(), B, cin, H, W, cout, k, pad, int(planar), _stream())
+    _lib.check(st, "eqa_conv_s2")
+    return y
+
+
 def affine_relu_rows(h: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
     """relu(h * scale[d] + shift[d]) on (rows, D) (eqa_affine_relu_rows): eval-mode BatchNorm1d + ReLU in one pass."""
     lib = _lib.load()

@@ -205,6 +205,15 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
  *   eqa_window_sums_nhwc  eqa_window_sums for a (B,H,W,C) buffer; out:(B,C,k,k) fp64 as above;
  *                         workspace: eqa_window_sums_nhwc_workspace_bytes(B, C, H, k) bytes.
  */
+/* I10 -- the strided convolutions of ConvNetwork (custom_nonequivariant_networks.py:44-57: Conv2d(k, stride 2, padding 0 | 1) ->
+ * BatchNorm2d -> GELU) in inference, as an implicit GEMM on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; csrc/smallconv.hip).
+ * y:(B,OH,OW,Cout) channels-last = [gelu](conv(x) + bias), OH = (H + 2 pad - K) / 2 + 1; the caller folds the eval-mode batch-norm
+ * into weights and bias.  planar = 1: x:(B,Cin,H,W) with Cin <= 4 (the first layer) and wp:(K*K, Cout/16, 4, 16) =
+ * w[16 n + j][kq][u][v] (zero for kq >= Cin); planar = 0: x:(B,H,W,Cin) channels-last with Cin % 16 == 0 and
+ * wp:(K*K, Cin/16, Cout/16, 4, 16, 4) = w[16 n + j][16 c + 4 kq + s][u][v].  K in {3,5,7}; channel pairs: eqa_conv_s2_supported. */
+int eqa_conv_s2_supported(int Cin, int Cout, int K, int pad, int planar);
+int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, float* y, int B, int Cin, int H, int W, int Cout, int K,
+                int pad, int planar, void* stream);
 /* Optimized canonicalizer, inference tail:
  *   eqa_affine_relu_rows           z:(rows,D) = relu(h * scale[d] + shift[d]): the eval-mode BatchNorm1d (folded to scale / shift) +
  *                                  ReLU in front of ConvNetwork's Linear head (custom_nonequivariant_networks.py:62-67); D % 4 == 0.

@@ -1379,3 +1379,33 @@ def test_fft48_convolution_3m_gemm_path_matches_conv2d(dev):
                 Sw = torch.stack([torch.stack([want[:, :, u:u + OH - k + 1, v:v + OW - k + 1].sum((-1, -2)) for v in range(k)], -1)
                                   for u in range(k)], -2)
                 assert S.dtype == torch.float64 and ((S - Sw).abs().max() <= 2e-6 * Sw.abs().max().clamp_min(scale)), (B, H, W, k)
+
+
+def test_conv_s2_mfma_matches_conv2d(dev):
+    """eqa_conv_s2 (ConvNetwork's stride-2 convolutions as an implicit GEMM on the fp32 MFMA, bias + exact GELU in the epilogue,
+    channels-last output) against F.conv2d / F.gelu in fp64: the planar first-layer form (1-4 input planes) and the channels-last
+    form (16 / 32 / 64 channels), k = 3, 5, 7, padding 0 and 1, pixel counts that are not a multiple of the 256-pixel block."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd import ops
+
+    torch.manual_seed(50)
+    cases = [(True, 3, 16, 7, 0, 5, 128, 128), (True, 1, 16, 3, 1, 3, 30, 41), (True, 3, 32, 5, 0, 2, 64, 64), (True, 4, 16, 5, 1, 1, 21, 19),
+             (False, 16, 16, 7, 0, 5, 61, 61), (False, 16, 32, 7, 1, 3, 28, 28), (False, 32, 32, 5, 0, 2, 33, 29), (False, 32, 64, 3, 1, 2, 17, 23),
+             (False, 64, 64, 5, 1, 1, 20, 20), (False, 16, 16, 3, 0, 1, 9, 9)]
+    for (planar, Cin, Cout, K, pad, B, H, W) in cases:
+        assert ops.conv_s2_supported(Cin, Cout, K, pad, planar), (planar, Cin, Cout, K, pad)
+        x = torch.randn(B, Cin, H, W, device=dev)
+        w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
+        b = torch.randn(Cout, device=dev)
+        wp = ops.pack_conv_s2_weights(w, planar)
+        xin = x.contiguous() if planar else x.permute(0, 2, 3, 1).contiguous()
+        for gelu in (True, False):
+            got = ops.conv_s2(xin, wp, b, gelu, Cout, K, pad, planar)
+            want = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=pad)
+            want = F.gelu(want) if gelu else want
+            assert got.shape == (B, want.shape[2], want.shape[3], Cout)
+            err = (got.permute(0, 3, 1, 2).double() - want).abs().max().item()
+            assert err <= 2e-6 * max(want.abs().max().item(), 1.0), (planar, Cin, Cout, K, pad, gelu, err)
+    assert not ops.conv_s2_supported(3, 8, 5, 0, True) and not ops.conv_s2_supported(16, 16, 4, 0, False) \
+        and not ops.conv_s2_supported(16, 16, 5, 2, False) and not ops.conv_s2_supported(8, 16, 5, 0, False)
