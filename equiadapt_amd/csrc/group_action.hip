@@ -711,16 +711,24 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
         wv[j] = j < K ? wx[ox * K + j] : 0.0f;
         xo[j] = min(xs + j, W - 1);
       }
-      for (int ry = rsub; ry < nrows; ry += rows_par) {
-        const float* row = src + (size_t)(ybeg + ry) * W;
-        float xv[EQA_AA_WIDE_MIN_K];
+      // four row trips' loads in flight at a time (a trip = K loads that return together; one trip per HBM round trip made
+      // the pass latency-bound: ~10 round trips per block)
+      for (int ry = rsub; ry < nrows; ry += 4 * rows_par) {
+        float xv[4][EQA_AA_WIDE_MIN_K];
 #pragma unroll
-        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) xv[j] = j < K ? row[xo[j]] : 0.0f;
-        float acc = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+          const float* row = src + (size_t)(ybeg + min(ry + q * rows_par, nrows - 1)) * W;
 #pragma unroll
-        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
-          if (j < K) acc += wv[j] * xv[j];
-        aa_tmp[ry * OW + ox] = acc;
+          for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) xv[q][j] = j < K ? row[xo[j]] : 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float acc = 0.0f;
+#pragma unroll
+          for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
+            if (j < K) acc += wv[j] * xv[q][j];
+          if (ry + q * rows_par < nrows) aa_tmp[(ry + q * rows_par) * OW + ox] = acc;
+        }
       }
     }
   } else {
@@ -770,6 +778,8 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_wide_kernel(const flo
   const float* src = x + (size_t)plane * H * W;
   auto pos = [&](int e) { return pad_shift ? e + (e >> pad_shift) : e; };
   const bool fixed_col = (kThreads % OW) == 0 && K <= kAaMaxK;
+  // whole float4s of 16-byte aligned rows (uniform): the staging below then loads 16 bytes per lane
+  const bool vec_stage = rpi <= 8 && (xlen & 3) == 0 && (xbeg & 3) == 0 && (W & 3) == 0 && ((((uintptr_t)src) & 15) == 0);
   const int ox_fixed = threadIdx.x % OW;
   const int xs_fixed = x0[ox_fixed] - xbeg;
   float wreg[kAaMaxK];
@@ -777,10 +787,28 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_wide_kernel(const flo
   for (int j = 0; j < kAaMaxK; ++j) wreg[j] = (fixed_col && j < K) ? wx[ox_fixed * K + j] : 0.0f;
   for (int ry0 = 0; ry0 < nrows; ry0 += rpi) {
     const int nr = min(rpi, nrows - ry0);
-    for (int rr = 0; rr < nr; ++rr) {
-      const float* grow = src + (size_t)(ybeg + ry0 + rr) * W + xbeg;
-      float* lrow = rowbuf + rr * row_stride;
-      for (int e = threadIdx.x; e < xlen; e += kThreads) lrow[pos(e)] = grow[e];  // xbeg + xlen <= W
+    if (vec_stage) {
+      // 16-byte loads, one per (row, thread) and trip, ALL rows' loads in flight before the first LDS store: the rolled
+      // load -> store loop paid one HBM round trip per row and 256 floats (32 trips per iteration of 8 rows of 1024)
+      for (int e = 4 * threadIdx.x; e < xlen; e += 4 * kThreads) {
+        float4 v[8];
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+          v[rr] = *reinterpret_cast<const float4*>(src + (size_t)(ybeg + ry0 + min(rr, nr - 1)) * W + xbeg + e);
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          if (rr < nr) {
+            float* lrow = rowbuf + rr * row_stride;
+            lrow[pos(e)] = v[rr].x; lrow[pos(e + 1)] = v[rr].y; lrow[pos(e + 2)] = v[rr].z; lrow[pos(e + 3)] = v[rr].w;
+          }
+        }
+      }
+    } else {
+      for (int rr = 0; rr < nr; ++rr) {
+        const float* grow = src + (size_t)(ybeg + ry0 + rr) * W + xbeg;
+        float* lrow = rowbuf + rr * row_stride;
+        for (int e = threadIdx.x; e < xlen; e += kThreads) lrow[pos(e)] = grow[e];  // xbeg + xlen <= W
+      }
     }
     __syncthreads();
     if (fixed_col) {  // kThreads % OW == 0: the thread keeps its output column, weights and tap start live in registers
