@@ -13,6 +13,6 @@ for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     for k, v in agg.items():
-        if any(t in k for t in ("group_", "so3", "gram", "lift", "wino", "vnsmall")):
+        if any(t in k for t in ("group_", "so3", "gram", "lift", "wino", "vnsmall", "fft48", "cgemm", "conv_s2")):
             n = max(len(disp[k]), 1)
             print(k, f"dispatches={n}", {a: round(b / n) for a, b in sorted(v.items())})
