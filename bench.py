@@ -674,7 +674,7 @@ def stage_table(ktimes, B):
             a = work / (ms_k * 1e-3) / 1e12
             stages[name] = {"what": what, "ms": ms_k, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TF,
                             "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TF, "launches_timed": n_k}
-    for name in ("group_pool", "window_sums", "crop_resize"):
+    for name in ("group_pool", "window_sums", "crop_resize_aa", "sums_gemv"):
         if name in ktimes:
             stages[name] = {"ms": ktimes[name][1], "launches_timed": ktimes[name][0]}
     return stages

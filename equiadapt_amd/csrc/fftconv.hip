@@ -304,7 +304,8 @@ constexpr int kFusLds = kFftH * kFusKxPitch;                      // 38,800 floa
 
 __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                                       const float* __restrict__ in_bias, int in_relu, int H, int W,
-                                                                      int C, int TY, int TX, size_t M, unsigned nwork, int win) {
+                                                                      int C, int TY, int TX, size_t M, unsigned nwork, int win,
+                                                                      unsigned x_bytes, unsigned v_bytes) {
   extern __shared__ float lds[];
   FFT_CLOCK_BEGIN();  // forward stamps: [8] loads, [9] row transform + LDS writes, [10] barrier, [11] LDS reads + column transform, [12] stores issued
   // XCD-aware order: consecutive work items (the channel groups of one tile) on one XCD
@@ -328,8 +329,17 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     const bool row_in = gy < H && y < win;
     float re[kFftN], ore[kFftH], oim[kFftH];
     if (nvalid == kFftN && !in_bias && !in_relu) {  // uniform: a full-width tile of a plain map (the headline case) needs no per-pixel work
+      if (x_bytes) {
+        // the 48 pixels of a row are C floats apart for every lane: buffer loads with that step as a scalar offset, no vector
+        // address arithmetic (x_bytes = 0: the map does not fit a 32-bit offset)
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+        const unsigned voff = (unsigned)((size_t)(p - x) * 4);
 #pragma unroll
-      for (int j = 0; j < kFftN; ++j) re[j] = p[(size_t)j * C];
+        for (int j = 0; j < kFftN; ++j) re[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, (unsigned)(j * C * 4), 0));
+      } else {
+#pragma unroll
+        for (int j = 0; j < kFftN; ++j) re[j] = p[(size_t)j * C];
+      }
       if (!row_in) {
 #pragma unroll
         for (int j = 0; j < kFftN; ++j) re[j] = 0.0f;
@@ -370,11 +380,24 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     const size_t fpitch = (size_t)fft_fstep(kx) * M * 2 * C;
     const int nky = fft_nky(kx);
     FFT_CLOCK_USE(ore[0], 11);
+    if (v_bytes && !__any(fft_edge(kx))) {
+      // a wave without edge columns: every lane steps by the same 23 * M * 2C floats from one ky to the next -> buffer stores
+      // with that step as a scalar offset (non-temporal: aux 2)
+      const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(V, 0, v_bytes, 0x00020000);
+      const unsigned voff = (unsigned)((size_t)(o - V) * 4);
+      const unsigned step = (unsigned)((size_t)kFftInner * M * 2 * C * 4);      // (from constants: provably wave-uniform)
 #pragma unroll
-    for (int ky = 0; ky < kFftN; ++ky) {
-      if (ky < nky) {
-        __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
-        __builtin_nontemporal_store(oim[ky], o + ky * fpitch + kFusCh);
+      for (int ky = 0; ky < kFftN; ++ky) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ore[ky]), vr, voff, ky * step, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oim[ky]), vr, voff + kFusCh * 4, ky * step, 2);
+      }
+    } else {
+#pragma unroll
+      for (int ky = 0; ky < kFftN; ++ky) {
+        if (ky < nky) {
+          __builtin_nontemporal_store(ore[ky], o + ky * fpitch);
+          __builtin_nontemporal_store(oim[ky], o + ky * fpitch + kFusCh);
+        }
       }
     }
   }
@@ -386,34 +409,51 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
 // value): they are pulled out of the register array by a shift network on the bits of a -- 81 selects on 6 scalar
 // conditions instead of a compare-and-add per column and border (352).
 template <int NB>
-__device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], float b, int relu, int ncols, bool first_col, int a,
+__device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], int relu, int ncols, bool first_col, int a,
                                                float (&acc)[1 + 2 * NB]) {
-  constexpr int PAD = NB - 1, EXT = 64 + NB;
-  float w[EXT];
+  // `ore` already carries the bias (added to the row's DC bin before the transform).  relu, ncols, a are block-uniform: the
+  // common cases -- a full-width tile, the right border either outside this tile or exactly at its end -- take branches without
+  // per-column selects (the kernel is bound by its vector instruction count: profiles/r02/pmc_sq_counters.md).
+  float v[kFftO];
+  if (relu) {
 #pragma unroll
-  for (int i = 0; i < EXT; ++i) w[i] = 0.0f;
+    for (int j = 0; j < kFftO; ++j) v[j] = fmaxf(ore[j], 0.0f);
+  } else {
+#pragma unroll
+    for (int j = 0; j < kFftO; ++j) v[j] = ore[j];
+  }
+  if (ncols < kFftO) {
+#pragma unroll
+    for (int j = 0; j < kFftO; ++j) v[j] = j < ncols ? v[j] : 0.0f;
+  }
   float total = 0.0f;
 #pragma unroll
-  for (int j = 0; j < kFftO; ++j) {
-    float v = ore[j] + b;
-    v = relu ? fmaxf(v, 0.0f) : v;
-    v = j < ncols ? v : 0.0f;
-    total += v;
-    w[PAD + j] = v;
-  }
+  for (int j = 0; j < kFftO; ++j) total += v[j];
   acc[0] = total;
 #pragma unroll
-  for (int q = 0; q < NB; ++q) acc[1 + q] = first_col ? w[PAD + q] : 0.0f;
-  const int ap = a + PAD;  // offset into w of the first wanted column
-  const bool any = ap >= 0 && ap < kFftO + PAD;
+  for (int q = 0; q < NB; ++q) acc[1 + q] = first_col ? v[q] : 0.0f;
+  constexpr int PAD = NB - 1;
+  const int ap = a + PAD;  // offset of the first wanted column in the PAD-shifted array of the general case
+  if (ap < 0 || ap >= kFftO + PAD) {            // the map's right border is not in this tile
 #pragma unroll
-  for (int bit = 32; bit >= 1; bit >>= 1) {
-    const bool on = (ap & bit) != 0;
+    for (int q = 0; q < NB; ++q) acc[1 + NB + q] = 0.0f;
+  } else if (a == kFftO - NB) {                 // ... or ends exactly with it (88 = 2 x 44: the headline)
 #pragma unroll
-    for (int i = 0; i < bit + NB - 1; ++i) w[i] = on ? w[i + bit] : w[i];
+    for (int q = 0; q < NB; ++q) acc[1 + NB + q] = v[kFftO - NB + q];
+  } else {                                      // anywhere: shift network on the bits of its position
+    constexpr int EXT = 64 + NB;
+    float w[EXT];
+#pragma unroll
+    for (int i = 0; i < EXT; ++i) w[i] = (i >= PAD && i < PAD + kFftO) ? v[i - PAD] : 0.0f;
+#pragma unroll
+    for (int bit = 32; bit >= 1; bit >>= 1) {
+      const bool on = (ap & bit) != 0;
+#pragma unroll
+      for (int i = 0; i < bit + NB - 1; ++i) w[i] = on ? w[i + bit] : w[i];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) acc[1 + NB + q] = w[q];
   }
-#pragma unroll
-  for (int q = 0; q < NB; ++q) acc[1 + NB + q] = any ? w[q] : 0.0f;
 }
 
 // The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
@@ -422,7 +462,7 @@ __device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], float 
 template <int NB, int CH>
 __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                       int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
-                                                                      int TX, size_t M, unsigned nwork) {
+                                                                      int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
   extern __shared__ float lds[];
   FFT_CLOCK_BEGIN();
   constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
@@ -442,7 +482,23 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
     const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m) * (size_t)C + c;
     const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
-    fft_load_column(p, fpitch, fft_edge(kx), re, im);
+    const bool edge = fft_edge(kx);
+    if (mo_bytes && !__any(edge)) {
+      // a wave without edge columns (5 of the 7): all its lanes step through the 48 frequencies of their column by the same
+      // 23 * M * C complex numbers -> buffer loads with that step as a SCALAR offset, no vector address arithmetic at all
+      // (mo_bytes = 0: the spectra do not fit a 32-bit offset, pointer arithmetic as in the edge waves)
+      const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mo), 0, mo_bytes, 0x00020000);
+      const unsigned voff = (unsigned)((((size_t)fft_f0(kx) * M + m) * (size_t)C + c) * 8);
+      const unsigned step = (unsigned)(kFftInner * M * (size_t)C * 8);
+#pragma unroll
+      for (int ky = 0; ky < kFftN; ++ky) {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, voff, ky * step, 2));   // aux 2: non-temporal
+        re[ky] = t[0];
+        im[ky] = t[1];
+      }
+    } else {
+      fft_load_column(p, fpitch, edge, re, im);
+    }
     FFT_CLOCK_LOADS();
     fft48(im, re, oim, ore);
     float* q = lds + kx * kPitch + cl;
@@ -470,21 +526,20 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       re[k] = q[k * kPitch];
       im[k] = q[k * kPitch + CH];
     }
-    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
+    // the bias rides on the row's DC bin: the (unnormalised) inverse adds re[0] to every output
     const float b = bias ? bias[c] : 0.0f;
+    re[0] += b;
+    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
     const int x0 = kFftO * tx;
     const int ncols = min(kFftO, OW - x0);  // uniform
     if constexpr (NB == 0) {
       float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
 #pragma unroll
       for (int j = 0; j < kFftO; ++j) {
-        if (j < ncols) {
-          const float v = ore[j] + b;
-          o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
-        }
+        if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
       }
     } else {
-      fft_row_pieces<NB>(ore, b, relu, ncols, tx == 0, OW - NB - x0, acc);
+      fft_row_pieces<NB>(ore, relu, ncols, tx == 0, OW - NB - x0, acc);
     }
   }
   FFT_CLOCK(3);
@@ -753,8 +808,9 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kInvCh));
+      const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;      // bytes of Mo; 0 to the kernel = beyond 32-bit offsets
       hipLaunchKernelGGL((fft48_inv_fused_kernel<NB, kInvCh>), dim3(nwork), dim3(kFftN * kInvCh), lds_bytes, st, Mo, bias, relu, out, OH,
-                         OW, C, TY, TX, fft_pitch(M), nwork);
+                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
       *fused = 1;
       return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
     }
@@ -841,8 +897,10 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
         hipFuncSetAttribute((const void*)fft48_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
+      const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
       hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
-                         W, C, TY, TX, fft_pitch(M), nwork, win);
+                         W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
+                         vb <= 0xfffffff0ULL ? (unsigned)vb : 0u);
       return launch_status();
     }
     (void)hipGetLastError();
