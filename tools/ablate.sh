@@ -12,7 +12,7 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p build_variants
-build() { hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude $2 equiadapt_amd/csrc/*.hip -o build_variants/libeqa_$1.so; }
+build() { hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -Iinclude $2 equiadapt_amd/csrc/*.hip -o build_variants/libeqa_$1.so; }
 build base "" &
 build noload "-DEQA_ABL_NOLOAD" &
 build nostore "-DEQA_ABL_NOSTORE" &

@@ -5,6 +5,6 @@ cd "$(dirname "$0")/../.." && mkdir -p build_variants
 for v in "${@:-base}"; do
   d=""; [ "$v" != base ] && d="-DEQA_CGEMM_$v"
   # one translation unit (the harness includes the kernel source) so that the experiment's device symbols are visible to it
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -I include -I equiadapt_amd/csrc $d -DEQA_CG_INCLUDE_KERNEL \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -w -I include -I equiadapt_amd/csrc $d -DEQA_CG_INCLUDE_KERNEL \
       tools/micro/cgemm3m_bench.hip -o build_variants/cg_$v || echo "FAILED $v"
 done

@@ -1,6 +1,6 @@
 """Shader-cycle stamps of the phases of one block of the fused inverse FFT kernel (debug build only).
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DEQA_FFT_CLOCK equiadapt_amd/csrc/*.hip -o build_variants/libeqa_fftclock.so
+  hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -Iinclude -DEQA_FFT_CLOCK equiadapt_amd/csrc/*.hip -o build_variants/libeqa_fftclock.so
   EQA_LIB=$PWD/build_variants/libeqa_fftclock.so python tools/probe_fft_clock.py
 
 Thread 0 of the middle block of the grid stamps the phases of the fused inverse (loads issued and returned, column

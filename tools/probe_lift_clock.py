@@ -1,6 +1,6 @@
 """Per-wave cycle stamps of the lifting convolution (debug build only).
 
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Iinclude -DEQA_LIFT_CLOCK equiadapt_amd/csrc/*.hip -o build_variants/libeqa_clock.so
+  hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -std=c++17 -shared -fPIC -Iinclude -DEQA_LIFT_CLOCK equiadapt_amd/csrc/*.hip -o build_variants/libeqa_clock.so
   EQA_LIB=$PWD/build_variants/libeqa_clock.so python tools/probe_lift_clock.py
 
 Prints shader cycles per tile (5120 = the tile's MFMAs alone), the clock each wave saw (s_memtime / s_memrealtime), the
