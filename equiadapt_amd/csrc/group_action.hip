@@ -711,24 +711,18 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
         wv[j] = j < K ? wx[ox * K + j] : 0.0f;
         xo[j] = min(xs + j, W - 1);
       }
-      // four row trips' loads in flight at a time (a trip = K loads that return together; one trip per HBM round trip made
-      // the pass latency-bound: ~10 round trips per block)
-      for (int ry = rsub; ry < nrows; ry += 4 * rows_par) {
-        float xv[4][EQA_AA_WIDE_MIN_K];
+      // (keeping four row trips' loads in flight at once was tried: 84 -> 92 us, the extra registers cost more occupancy than the
+      // shorter dependency chain gains)
+      for (int ry = rsub; ry < nrows; ry += rows_par) {
+        const float* row = src + (size_t)(ybeg + ry) * W;
+        float xv[EQA_AA_WIDE_MIN_K];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float* row = src + (size_t)(ybeg + min(ry + q * rows_par, nrows - 1)) * W;
+        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) xv[j] = j < K ? row[xo[j]] : 0.0f;
+        float acc = 0.0f;
 #pragma unroll
-          for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j) xv[q][j] = j < K ? row[xo[j]] : 0.0f;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float acc = 0.0f;
-#pragma unroll
-          for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
-            if (j < K) acc += wv[j] * xv[q][j];
-          if (ry + q * rows_par < nrows) aa_tmp[(ry + q * rows_par) * OW + ox] = acc;
-        }
+        for (int j = 0; j < EQA_AA_WIDE_MIN_K; ++j)
+          if (j < K) acc += wv[j] * xv[j];
+        aa_tmp[ry * OW + ox] = acc;
       }
     }
   } else {

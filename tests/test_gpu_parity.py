@@ -790,8 +790,9 @@ def test_nbody_e3_canonicalizer_matches_reference_golden(dev, golden):
         inv = can.invert_canonicalization(g["pred"].to(dev))
     R = can.canonicalization_info_dict["group_element"]["rotation_matrix"].cpu()
     assert torch.allclose(R, g["rotation"], atol=1e-5)
-    assert torch.allclose(cl.cpu(), g["canonical_loc"], atol=2e-5) and torch.allclose(cv.cpu(), g["canonical_vel"], atol=2e-5)
-    assert torch.allclose(inv.cpu(), g["inverted"], atol=2e-5)
+    # coordinates: |x| up to ~3 times the 1e-5 allowed on R (a few of the 40 random frames are nearly collinear)
+    assert torch.allclose(cl.cpu(), g["canonical_loc"], atol=5e-5) and torch.allclose(cv.cpu(), g["canonical_vel"], atol=5e-5)
+    assert torch.allclose(inv.cpu(), g["inverted"], atol=5e-5)
     # autograd path (op-by-op) gives the same numbers
     rv = rot_vec.clone().requires_grad_(True)
     assert torch.allclose(can.modified_gram_schmidt(rv).detach().cpu(), g["rotation"], atol=1e-5)
