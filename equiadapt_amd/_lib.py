@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "fftconv.hip", "cgemm3m.hip", "smallconv.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "smallconv.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -55,6 +55,11 @@ SIGNATURES = {
     "eqa_vn_convpos_fwd": (_int, [_vp] * 7 + [_int, _int, _vp]),
     "eqa_vn_convpos_bwd_reduce": (_int, [_vp] * 10 + [_int, _int, _vp]),
     "eqa_vn_convpos_bwd_apply": (_int, [_vp] * 12 + [_int, _int, _vp]),
+    "eqa_vn_tail_blocks": (_int, [_int]),
+    "eqa_vn_tail_partial_floats": (_int, [_int]),
+    "eqa_vn_tail_pass": (_int, [_int] + [_vp] * 8 + [_int, _int, _vp]),
+    "eqa_vn_bn_finalize": (_int, [_vp, _int, _int, _int, ctypes.c_int64] + [_vp] * 5 + [ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "eqa_vn_bn_bwd_finalize": (_int, [_vp, _int, _int, _int, ctypes.c_int64, _vp, _vp, _vp]),
     "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_lift_conv_wgrad_supported": (_int, [_int] * 7),

@@ -210,8 +210,8 @@ int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, fl
                 int pad, int planar, void* stream) {
   if (!x || !wp || !y || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
   if (!eqa_conv_s2_supported(Cin, Cout, K, pad, planar)) return EQA_ERR_UNSUPPORTED;
+  if (H + 2 * pad < K || W + 2 * pad < K) return EQA_ERR_INVALID_ARG;  // frame smaller than the kernel (torch raises too)
   const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
-  if (OH <= 0 || OW <= 0) return EQA_ERR_INVALID_ARG;
   if (B == 0) return EQA_OK;
   const size_t xbytes = (size_t)B * Cin * H * W * 4;
   if (xbytes > 0x7fffffe0ULL || (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15)) return EQA_ERR_UNSUPPORTED;

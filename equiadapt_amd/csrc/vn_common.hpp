@@ -32,6 +32,67 @@ __device__ __forceinline__ V3 vn_relu(V3 q, const V3& d) {
   return q;
 }
 
+// Backward of one VN layer output  y = gate(u * nbn, d),  u = q / n,  n = |q| + EPS,  nbn = n * scale + shift  (scale = gamma *
+// rstd, shift = beta - mean * scale; vector_neuron_layers.py:251-273, :303-324): forward values and the gradients that do not
+// need batch-wide sums.
+struct VnGrad {
+  V3 q, u, d, g_qn, g_d;  // pre-norm vector, its direction q / n, gate direction, dL/d(normalised vector), dL/d(gate)
+  float nr, nbn, g_nbn;   // n = |q| + EPS, batch-normalised norm, dL/d(nbn)
+};
+__device__ __forceinline__ VnGrad vn_gate_grad(const V3& q, const V3& d, float scale, float shift, const V3& g_out) {
+  VnGrad r;
+  r.q = q;
+  r.nr = sqrtf(dot3(r.q, r.q)) + kVnEps;
+  const float inv_n = 1.0f / r.nr;
+  r.u = v3(r.q.x * inv_n, r.q.y * inv_n, r.q.z * inv_n);
+  r.nbn = r.nr * scale + shift;
+  const V3 qn = v3(r.u.x * r.nbn, r.u.y * r.nbn, r.u.z * r.nbn);
+  r.d = d;
+  const float dp = dot3(qn, r.d);
+  if (dp >= 0.0f) {  // kept as is
+    r.g_qn = g_out;
+    r.g_d = v3(0.f, 0.f, 0.f);
+  } else {           // out = qn - alpha d, alpha = <qn, d> / (|d|^2 + EPS)
+    const float rr = 1.0f / (dot3(r.d, r.d) + kVnEps);
+    const float alpha = dp * rr;
+    const float g_alpha = -dot3(g_out, r.d);
+    const float ga_r = g_alpha * rr;
+    r.g_qn = v3(g_out.x + ga_r * r.d.x, g_out.y + ga_r * r.d.y, g_out.z + ga_r * r.d.z);
+    r.g_d = v3(-alpha * g_out.x + ga_r * (qn.x - 2.0f * alpha * r.d.x), -alpha * g_out.y + ga_r * (qn.y - 2.0f * alpha * r.d.y),
+               -alpha * g_out.z + ga_r * (qn.z - 2.0f * alpha * r.d.z));
+  }
+  r.g_nbn = dot3(r.g_qn, r.u);
+  return r;
+}
+// The same layer without a gate (VNBatchNorm alone): y = u * nbn
+__device__ __forceinline__ VnGrad vn_norm_grad(const V3& q, float scale, float shift, const V3& g_out) {
+  VnGrad r;
+  r.q = q;
+  r.nr = sqrtf(dot3(q, q)) + kVnEps;
+  const float inv_n = 1.0f / r.nr;
+  r.u = v3(q.x * inv_n, q.y * inv_n, q.z * inv_n);
+  r.nbn = r.nr * scale + shift;
+  r.d = v3(0.f, 0.f, 0.f);
+  r.g_qn = g_out;
+  r.g_d = r.d;
+  r.g_nbn = dot3(g_out, r.u);
+  return r;
+}
+// dL/dq once the batch sums are known: through the direction u = q / n and through the norm,
+//   g_n = gamma rstd (g_nbn - m1 - nhat m2)   (m1 = sum g_nbn / M, m2 = sum g_nbn nhat / M; both 0 with running statistics)
+//   g_q = (g_u - u <g_u, q> / |q|) / n + g_n q / |q|,   g_u = g_qn * nbn
+// sc = gamma * rstd.  Idle threads (duplicates of the last point) must not pick up the batch terms -m1 - nhat m2.
+__device__ __forceinline__ V3 vn_norm_input_grad(const VnGrad& r, float sc, float mu, float rs, float m1, float m2, bool active) {
+  const float nhat = (r.nr - mu) * rs;
+  const float g_n = active ? sc * (r.g_nbn - m1 - nhat * m2) : 0.0f;
+  const float qlen = fmaxf(r.nr - kVnEps, 1e-30f);
+  const V3 g_u = v3(r.g_qn.x * r.nbn, r.g_qn.y * r.nbn, r.g_qn.z * r.nbn);
+  const float proj = dot3(g_u, r.q) / qlen;
+  const float inv_n = 1.0f / r.nr, gq = g_n / qlen;
+  return v3((g_u.x - r.u.x * proj) * inv_n + gq * r.q.x, (g_u.y - r.u.y * proj) * inv_n + gq * r.q.y,
+            (g_u.z - r.u.z * proj) * inv_n + gq * r.q.z);
+}
+
 // A cloud staged in LDS as float4 (x, y, z, |p|^2): one ds_read_b128 per kNN candidate.  x: (3, N) of one cloud.
 __device__ __forceinline__ void vn_stage_cloud(const float* __restrict__ xb, int N, int Npad, float4* pts, int tid) {
   for (int i = tid; i < Npad; i += kVnThreads) {

@@ -136,36 +136,10 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float*
   }
 }
 
-// One (edge, channel) of the block, forward values and the gradients that do not need batch-wide sums.
-struct VnGrad {
-  V3 q, u, d, g_qn, g_d;  // pre-norm vector, its direction q / n, gate direction, dL/d(normalised vector), dL/d(gate)
-  float nr, nbn, g_nbn;   // n = |q| + EPS, batch-normalised norm, dL/d(nbn)
-};
+// One (edge, channel) of the block: mix the edge features, then the shared layer gradient (vn_common.hpp)
 __device__ __forceinline__ VnGrad vn_edge_grad(const float* __restrict__ wf, const float* __restrict__ wd, const VnEdge& e,
                                                float scale, float shift, const V3& g_out) {
-  VnGrad r;
-  r.q = vn_mix(wf, e);
-  r.nr = sqrtf(dot3(r.q, r.q)) + kVnEps;
-  const float inv_n = 1.0f / r.nr;
-  r.u = v3(r.q.x * inv_n, r.q.y * inv_n, r.q.z * inv_n);
-  r.nbn = r.nr * scale + shift;
-  const V3 qn = v3(r.u.x * r.nbn, r.u.y * r.nbn, r.u.z * r.nbn);
-  r.d = vn_mix(wd, e);
-  const float dp = dot3(qn, r.d);
-  if (dp >= 0.0f) {  // kept as is
-    r.g_qn = g_out;
-    r.g_d = v3(0.f, 0.f, 0.f);
-  } else {           // out = qn - alpha d, alpha = <qn, d> / (|d|^2 + EPS)
-    const float rr = 1.0f / (dot3(r.d, r.d) + kVnEps);
-    const float alpha = dp * rr;
-    const float g_alpha = -dot3(g_out, r.d);
-    const float ga_r = g_alpha * rr;
-    r.g_qn = v3(g_out.x + ga_r * r.d.x, g_out.y + ga_r * r.d.y, g_out.z + ga_r * r.d.z);
-    r.g_d = v3(-alpha * g_out.x + ga_r * (qn.x - 2.0f * alpha * r.d.x), -alpha * g_out.y + ga_r * (qn.y - 2.0f * alpha * r.d.y),
-               -alpha * g_out.z + ga_r * (qn.z - 2.0f * alpha * r.d.z));
-  }
-  r.g_nbn = dot3(r.g_qn, r.u);
-  return r;
+  return vn_gate_grad(vn_mix(wf, e), vn_mix(wd, e), scale, shift, g_out);
 }
 
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
@@ -225,15 +199,7 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const 
     for (int t = 0; t < kVnK; ++t) {
       const VnEdge e = vn_edge(ctr, pts[nb[t]]);
       const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, e, sc, sh, g_out);
-      const float nhat = (r.nr - mu) * rs;
-      // sc = gamma * rstd; idle threads (duplicates of the last point) must not pick up the batch terms -m1 - nhat m2
-      const float g_n = active ? sc * (r.g_nbn - mm1 - nhat * mm2) : 0.0f;
-      const float qlen = fmaxf(r.nr - kVnEps, 1e-30f);
-      const V3 g_u = v3(r.g_qn.x * r.nbn, r.g_qn.y * r.nbn, r.g_qn.z * r.nbn);
-      const float proj = dot3(g_u, r.q) / qlen;
-      const float inv_n = 1.0f / r.nr, gq = g_n / qlen;
-      const V3 g_q = v3((g_u.x - r.u.x * proj) * inv_n + gq * r.q.x, (g_u.y - r.u.y * proj) * inv_n + gq * r.q.y,
-                        (g_u.z - r.u.z * proj) * inv_n + gq * r.q.z);
+      const V3 g_q = vn_norm_input_grad(r, sc, mu, rs, mm1, mm2, active);
       acc[0] += dot3(g_q, e.f0);
       acc[1] += dot3(g_q, e.f1);
       acc[2] += dot3(g_q, e.f2);

@@ -117,6 +117,82 @@ class ConvPosMeanPool(torch.autograd.Function):
         return None, dW[:, :3].contiguous(), dW[:, 3:].contiguous(), dgamma, dbeta, None, None
 
 
+class TailMean(torch.autograd.Function):
+    """mean over the points of dropout(conv2(bn1(conv1(pooled)))) with the three VN batch-norms in training mode, on the
+    recompute-everything passes of csrc/vnsmall_tail.hip (eqa_vn_tail_pass): (B, 21, 3, N) -> (B, 4, 3), with autograd
+    w.r.t. the pooled features and the ten parameters.  Statistics of the vector norms over all B*N points (fp64 across
+    blocks); running statistics and num_batches_tracked updated like nn.BatchNorm1d.  ``mask``: the dropout factors
+    (0 or 1/(1-p)) of the (B, 4, 3, N) output of conv2, or None."""
+
+    @staticmethod
+    def forward(ctx, pooled, Wf1, Wd1, Wf2, Wd2, g1, b1, g2, b2, g3, b3, bns, mask):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        B, C, _, N = pooled.shape
+        dev = pooled.device
+        pooled = pooled.detach().contiguous()
+        W = torch.cat([w.detach().reshape(-1) for w in (Wf1, Wd1, Wf2, Wd2)]).contiguous()
+        assert C == 21 and W.numel() == 1050
+        nbx = lib.eqa_vn_tail_blocks(N)
+        nblk = B * nbx
+        st = ops._stream()
+        p_mask = mask.data_ptr() if mask is not None else None
+        with torch.cuda.device(dev):
+            stat = torch.zeros((3, 128), dtype=torch.float32, device=dev)
+            part = torch.empty(nblk * 42, dtype=torch.float32, device=dev)
+            for layer, (bn, gamma, beta) in enumerate(zip(bns, (g1, g2, g3), (b1, b2, b3))):
+                _lib.check(lib.eqa_vn_tail_pass(layer, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), None, None, None,
+                                                part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
+                track = bn.track_running_stats and bn.running_mean is not None
+                _lib.check(lib.eqa_vn_bn_finalize(part.data_ptr(), nblk, lib.eqa_vn_tail_partial_floats(layer), gamma.numel(), B * N,
+                                                  gamma.detach().data_ptr(), beta.detach().data_ptr(),
+                                                  bn.running_mean.data_ptr() if track else None,
+                                                  bn.running_var.data_ptr() if track else None,
+                                                  bn.num_batches_tracked.data_ptr() if track else None,
+                                                  float(bn.momentum), float(bn.eps), stat[layer].data_ptr(), st), "eqa_vn_bn_finalize")
+            _lib.check(lib.eqa_vn_tail_pass(3, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), None, p_mask, None,
+                                            part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
+            out = part[:nblk * 12].view(B, nbx, 12).sum(1).div_(N).view(B, 4, 3)
+        ctx.save_for_backward(pooled, W, stat, mask)
+        ctx.gammas = (g1.detach(), g2.detach(), g3.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        from equiadapt_amd import _lib, ops
+
+        lib = _lib.load()
+        pooled, W, stat, mask = ctx.saved_tensors
+        B, _, _, N = pooled.shape
+        dev = pooled.device
+        gout = gout.contiguous().float()
+        nblk = B * lib.eqa_vn_tail_blocks(N)
+        st = ops._stream()
+        p_mask = mask.data_ptr() if mask is not None else None
+        with torch.cuda.device(dev):
+            red = torch.zeros((3, 64), dtype=torch.float32, device=dev)
+            grads = torch.empty((3, 64), dtype=torch.float32, device=dev)
+            part = torch.empty(nblk * 882, dtype=torch.float32, device=dev)
+            g_pooled = torch.empty_like(pooled)
+            dW2 = None
+            for pas, layer, C in ((4, 2, 4), (5, 1, 21), (6, 0, 21)):
+                _lib.check(lib.eqa_vn_tail_pass(pas, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), red.data_ptr(), p_mask,
+                                                gout.data_ptr(), part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
+                stride = lib.eqa_vn_tail_partial_floats(pas)
+                _lib.check(lib.eqa_vn_bn_bwd_finalize(part.data_ptr(), nblk, stride, C, B * N, grads[layer].data_ptr(),
+                                                      red[layer].data_ptr(), st), "eqa_vn_bn_bwd_finalize")
+                if pas == 5:
+                    dW2 = part[:nblk * stride].view(nblk, stride)[:, 42:].sum(0, dtype=torch.float64).float()
+            _lib.check(lib.eqa_vn_tail_pass(7, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), red.data_ptr(), p_mask,
+                                            gout.data_ptr(), part.data_ptr(), g_pooled.data_ptr(), B, N, st), "eqa_vn_tail_pass")
+            dW1 = part.view(nblk, 882).sum(0, dtype=torch.float64).float()
+        db = [grads[i, :c] for i, c in ((0, 21), (1, 21), (2, 4))]
+        dg = [grads[i, 32:32 + c] for i, c in ((0, 21), (1, 21), (2, 4))]
+        return (g_pooled, dW1[:441].view(21, 21), dW1[441:].view(21, 21), dW2[:84].view(4, 21), dW2[84:].view(4, 21),
+                dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
+
+
 class VNSmall(nn.Module):
     """(B, 3, N) point cloud -> (B, 3, 3): three vectors that rotate with the cloud."""
 
@@ -180,6 +256,19 @@ class VNSmall(nn.Module):
         else:
             feat = get_graph_feature_cross(point_cloud.unsqueeze(1), k=self.n_knn)
             out = self.pool(self.conv_pos(feat))
+        bns = (self.conv1.batchnorm.bn1d, self.bn1.bn1d, self.conv2.batchnorm.bn1d)
+        if (out.is_cuda and self.training and torch.is_grad_enabled() and out.dtype == torch.float32 and out.shape[1] == 21
+                and out.shape[0] <= 65535 and all(bn.training and bn.momentum is not None and bn.affine for bn in bns)
+                and os.environ.get("EQA_TRAIN_FAST", "1") != "0"):
+            # training: conv1 -> bn1 -> conv2 -> dropout -> mean in eight recompute passes (csrc/vnsmall_tail.hip)
+            mask = None
+            if self.dropout.p > 0:
+                B, _, _, N = out.shape
+                mask = nn.functional.dropout(torch.ones((B, 4, 3, N), dtype=out.dtype, device=out.device), self.dropout.p, True)
+            y = TailMean.apply(out, self.conv1.map_to_feat.weight, self.conv1.map_to_dir.weight, self.conv2.map_to_feat.weight,
+                               self.conv2.map_to_dir.weight, bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias,
+                               bns[2].weight, bns[2].bias, bns, mask)
+            return y[:, :3]
         out = self.bn1(self.conv1(out))
         out = self.dropout(self.conv2(out))
         return out.mean(dim=-1)[:, :3]

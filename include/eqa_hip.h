@@ -451,6 +451,35 @@ int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf
                              const float* gpool, float* partial, int B, int N, void* stream);
 
 /*
+ * Training passes of VNSmall's tail on the pooled features of the first block: conv1 = VNLinearLeakyReLU(21 -> 21, slope 0) ->
+ * bn1 = VNBatchNorm(21) -> conv2 = VNLinearLeakyReLU(21 -> 4, slope 0) -> dropout -> mean over the points
+ * (equivariant_networks.py:141-150; vector_neuron_layers.py:251-273, :303-324), the three batch-norms in training mode, forward
+ * and the backward w.r.t. the parameters and the pooled features.  Every pass recomputes the chain from the 63 floats of a
+ * point; nothing of size (B, 21, 3, N) is stored between the layers.  One launch per pass, per-block partials
+ * (blocks = B * eqa_vn_tail_blocks(N), eqa_vn_tail_partial_floats(pass) floats each) reduced by the finalize kernels or the caller:
+ *   pooled:(B,21,3,N)   weights:(1050) = conv1.map_to_feat (21x21) | conv1.map_to_dir (21x21) | conv2.map_to_feat (4x21) |
+ *   conv2.map_to_dir (4x21)   stat:(3,128) per batch-norm (conv1, bn1, conv2): scale[32] | shift[32] | mean[32] | rstd[32]
+ *   red:(3,64) per batch-norm: m1[32] | m2[32] (sum g / M, sum g nhat / M)   mask:(B,4,3,N) dropout factors or NULL
+ *   gout:(B,4,3) gradient of the mean over the points (rows of unused channels zero)   g_pooled:(B,21,3,N)
+ *   pass 0, 1, 2   partial = sum n, sum n^2 per channel of conv1 / bn1 / conv2 (each needs the stat of the layers before it)
+ *   pass 3         partial:(blocks, 12) = sum over the block's points of the dropped-out conv2 output (the caller divides by N)
+ *   pass 4, 5, 6   partial[0 .. 2C) = sum g, sum g nhat of conv2 / bn1 / conv1 (each needs red of the layers after it);
+ *                  pass 5 also partial[42 .. 210) = d conv2.map_to_feat | d conv2.map_to_dir
+ *   pass 7         partial:(blocks, 882) = d conv1.map_to_feat | d conv1.map_to_dir;  g_pooled written
+ *   eqa_vn_bn_finalize      partial:(nblk, stride) sums -> stat of one batch-norm over M samples; running_mean / running_var
+ *                           (may be NULL) updated with the unbiased variance and `momentum`, *num_batches_tracked += 1
+ *   eqa_vn_bn_bwd_finalize  partial:(nblk, stride) sums -> grads = d beta[32] | d gamma[32], red = m1[32] | m2[32]
+ */
+int eqa_vn_tail_blocks(int N);
+int eqa_vn_tail_partial_floats(int pass);
+int eqa_vn_tail_pass(int pass, const float* pooled, const float* weights, const float* stat, const float* red, const float* mask,
+                     const float* gout, float* partial, float* g_pooled, int B, int N, void* stream);
+int eqa_vn_bn_finalize(const float* partial, int nblk, int stride, int C, long long M, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps, float* stat,
+                       void* stream);
+int eqa_vn_bn_bwd_finalize(const float* partial, int nblk, int stride, int C, long long M, float* grads, float* red, void* stream);
+
+/*
  * P3 -- batched 3x3 classical Gram-Schmidt on rows (no epsilon, no handedness fix).
  * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
  */

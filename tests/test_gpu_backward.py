@@ -617,3 +617,58 @@ def test_fused_bn_block_wide_channels_partial_last_trip(dev):
     assert torch.allclose(bn1.weight.grad, bn2.weight.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(bn1.bias.grad, bn2.bias.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(bn1.running_mean, bn2.running_mean, atol=1e-5) and torch.allclose(bn1.running_var, bn2.running_var, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,N,p", [(4, 256, 0.0), (3, 100, 0.0), (2, 1024, 0.5)])
+def test_vnsmall_training_tail_matches_op_path(dev, B, N, p):
+    """VNSmall's tail in train() (conv1 -> bn1 -> conv2 -> dropout -> mean; eqa_vn_tail_pass) against the same modules op by op in
+    fp64 on the SAME pooled features and the same dropout mask: output, the gradient w.r.t. the pooled features, every parameter
+    gradient, running statistics and num_batches_tracked.  N = 100 leaves idle lanes in the last block."""
+    import copy
+    import types
+
+    import equiadapt_amd as ea
+    from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import TailMean
+
+    torch.manual_seed(7 + N)
+    net = ea.VNSmall(types.SimpleNamespace(n_knn=20, pooling="mean")).to(dev).train()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+                m.running_mean.uniform_(-0.1, 0.1)
+        # conv1's batch-normalised norms gamma * nhat + beta must stay away from 0: bn1 takes the norm of conv1's output, whose
+        # gradient is ~1 / |y1|; with beta around 0 a handful of the 20 k vectors land at |y1| ~ 1e-5 of the median and fp32 (this
+        # path and the op-by-op one alike, measured 2e-3 vs fp64) cannot resolve their gradients
+        net.conv1.batchnorm.bn1d.bias.uniform_(2.5, 3.5)
+    op64 = copy.deepcopy(net).double().train()
+    pooled = torch.randn(B, 21, 3, N, device=dev, requires_grad=True)
+    pooled64 = pooled.detach().double().requires_grad_(True)
+    mask = None
+    if p > 0:
+        mask = torch.nn.functional.dropout(torch.ones(B, 4, 3, N, device=dev), p, True)
+    g_up = torch.randn(B, 3, 3, device=dev)
+    bns = (net.conv1.batchnorm.bn1d, net.bn1.bn1d, net.conv2.batchnorm.bn1d)
+    y = TailMean.apply(pooled, net.conv1.map_to_feat.weight, net.conv1.map_to_dir.weight, net.conv2.map_to_feat.weight,
+                       net.conv2.map_to_dir.weight, bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias, bns[2].weight, bns[2].bias,
+                       bns, mask)[:, :3]
+    (y * g_up).sum().backward()
+    o = op64.conv2(op64.bn1(op64.conv1(pooled64)))
+    if mask is not None:
+        o = o * mask.double()
+    y64 = o.mean(-1)[:, :3]
+    (y64 * g_up.double()).sum().backward()
+    assert (y.double() - y64).abs().max().item() <= 2e-6 * max(1.0, y64.abs().max().item())
+    scale = pooled64.grad.abs().max().item()
+    assert (pooled.grad.double() - pooled64.grad).abs().max().item() <= 2e-4 * scale
+    tail = lambda n: [q for k, q in n.named_parameters() if k.split(".")[0] in ("conv1", "bn1", "conv2")]  # noqa: E731
+    for (k, p1), p2 in zip([(k, q) for k, q in net.named_parameters() if k.split(".")[0] in ("conv1", "bn1", "conv2")], tail(op64)):
+        assert p1.grad is not None, k
+        assert (p1.grad.double() - p2.grad).abs().max().item() <= 2e-4 * max(p2.grad.abs().max().item(), 1e-3), k
+    for (k, b1), b2 in zip(net.named_buffers(), op64.buffers()):
+        if k.split(".")[0] in ("conv1", "bn1", "conv2"):
+            if b1.dtype.is_floating_point:
+                assert torch.allclose(b1.double(), b2, rtol=1e-5, atol=1e-7), k
+            else:
+                assert int(b1) == int(b2) == 1, k

@@ -103,6 +103,41 @@ def test_c_abi_argument_validation(dev):
     torch.cuda.synchronize()
 
 
+def test_c_abi_argument_validation_round2_entry_points(dev):
+    """The hot-path additions (3M complex GEMM, stride-2 MFMA conv, mask planes, fused heads) reject what they cannot run."""
+    from equiadapt_amd import _lib
+
+    lib = _lib.load()
+    x = torch.zeros(4096, device=dev)
+    g = torch.zeros(4, dtype=torch.int32, device=dev)
+    u8 = torch.zeros(64, dtype=torch.uint8, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    # complex GEMM: nulls / negative M are argument errors, channel counts off the 32 x 64 wave tile are "unsupported"
+    assert lib.eqa_fft48k5_cgemm3m(None, p(x), p(x), 4, 32, 64, None) == -1
+    assert lib.eqa_fft48k5_cgemm3m(p(x), p(x), p(x), -1, 32, 64, None) == -1
+    assert lib.eqa_fft48k5_cgemm3m(p(x), p(x), p(x), 4, 24, 64, None) == -3
+    assert lib.eqa_fft48k5_cgemm3m(p(x), p(x), p(x), 4, 32, 48, None) == -3
+    assert lib.eqa_fft48k5_cgemm3m(p(x), p(x), p(x), 0, 32, 64, None) == 0          # empty batch: nothing launched
+    assert lib.eqa_fft48k5_cgemm3m_supported(256, 256) == 1 and lib.eqa_fft48k5_cgemm3m_supported(8, 8) == 0
+    # stride-2 conv: kernel sizes outside {3,5,7}, a frame smaller than the kernel, a misaligned pointer
+    assert lib.eqa_conv_s2(p(x), p(x), None, 0, p(x), 1, 16, 8, 8, 16, 4, 0, 0, None) == -3
+    assert lib.eqa_conv_s2(p(x), p(x), None, 0, p(x), 1, 16, 2, 2, 16, 3, 0, 0, None) == -1
+    assert lib.eqa_conv_s2(None, p(x), None, 0, p(x), 1, 16, 8, 8, 16, 3, 0, 0, None) == -1
+    off = ctypes.c_void_p(x.data_ptr() + 4)
+    assert lib.eqa_conv_s2(off, p(x), None, 0, p(x), 1, 16, 8, 8, 16, 3, 0, 0, None) == -3
+    assert lib.eqa_conv_s2(p(x), p(x), None, 0, p(x), 0, 16, 8, 8, 16, 3, 0, 0, None) == 0
+    # mask planes: W must be a multiple of 16 (dword staging, 16-byte stores); neither source given is an argument error
+    assert lib.eqa_mask_action_nearest_planes(p(g), p(u8), p(g), p(x), None, 1, 1, 16, 24, None) == -3
+    assert lib.eqa_mask_action_nearest_planes(None, p(u8), p(g), p(x), None, 1, 1, 16, 16, None) == -1
+    # fused BatchNorm1d + ReLU rows: D % 4, alignment; cosine activations: non-positive sizes
+    assert lib.eqa_affine_relu_rows(p(x), p(x), p(x), p(x), 2, 6, None) == -3
+    assert lib.eqa_affine_relu_rows(p(x), None, p(x), p(x), 2, 8, None) == -1
+    assert lib.eqa_affine_relu_rows(p(x), p(x), p(x), p(x), 0, 8, None) == 0
+    assert lib.eqa_cosine_group_activations(p(x), p(x), p(x), 1, 0, 8, 1e-8, None) == -1
+    assert lib.eqa_cosine_group_activations(p(x), p(x), p(x), 0, 4, 8, 1e-8, None) == 0
+    torch.cuda.synchronize()
+
+
 def test_nan_and_inf_inputs_do_not_spread(dev):
     """A NaN pixel only contaminates outputs whose bilinear footprint touches it (grid_sample semantics)."""
     from equiadapt_amd import ops
