@@ -19,11 +19,22 @@ constexpr int kMaxWinK = 8;
 constexpr int kWsMaxBorder = kMaxWinK - 1;  // k - 1 <= 7
 constexpr int kFinCh = 32;                  // channels per block of the finalize kernel
 
+// Sum over the 64 lanes of a wave, returned to every lane (wave-uniform: it comes back through a scalar register).
+// Data-parallel-primitive adds instead of __shfl_xor: the shuffles compile to ds_bpermute_b32, a six-deep chain of LDS-crossbar
+// round trips per sum; the DPP modifiers ride on the v_add itself.  Inside a row of 16 lanes: quad swaps, then the two row
+// mirrors; across rows: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3; lane 63 holds the total.
+#define EQA_DPP_ADD(v, ctrl, row_mask) \
+  (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), (row_mask), 0xf, false))
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  EQA_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  EQA_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  EQA_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+  EQA_DPP_ADD(v, 0x140, 0xf);  // row_mirror
+  EQA_DPP_ADD(v, 0x142, 0xa);  // row_bcast15 -> rows 1, 3 (masked rows add the `old` operand, 0)
+  EQA_DPP_ADD(v, 0x143, 0xc);  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef EQA_DPP_ADD
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 

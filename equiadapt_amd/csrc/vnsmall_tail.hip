@@ -11,8 +11,8 @@
 //   pass 3      sum over the block's points of dropout(conv2 output)  -> (blocks, 12) partials of the mean
 //   pass 4      sums of g, g * nhat of conv2's batch-norm             -> eqa_vn_bn_bwd_finalize -> d beta, d gamma, m1, m2
 //   pass 5      the same for bn1, and d W of conv2 (rows of the block staged in LDS, 168 dot products over the 64 points)
-//   pass 6      the same for conv1's batch-norm
-//   pass 7      d W of conv1 (882 dot products per block) and the gradient w.r.t. the pooled features
+//   pass 6      the same for conv1's batch-norm, and d W_d of conv1 (441 dot products per block)
+//   pass 7      d W_f of conv1 and the gradient w.r.t. the pooled features
 // Partials are per block and summed by the caller in a fixed order (deterministic).  C ABI: include/eqa_hip.h.
 #include "vn_common.hpp"
 
@@ -40,7 +40,7 @@ struct TailArgs {
 
 __host__ __device__ constexpr int tail_partial_floats(int pass) {
   return pass <= 1 ? 2 * kVnC : pass == 2 ? 2 * kTailC2 : pass == 3 ? 3 * kTailC2 : pass == 4 ? 2 * kTailC2
-         : pass == 5 ? 2 * kVnC + 2 * kTailW2 : pass == 6 ? 2 * kVnC : 2 * kTailW1;
+         : pass == 5 ? 2 * kVnC + 2 * kTailW2 : pass == 6 ? 2 * kVnC + kTailW1 : kTailW1;
 }
 
 __device__ __forceinline__ V3 tail_mix(const float* __restrict__ w, const V3 (&X)[kVnC]) {  // w: one output row, 21 inputs
@@ -69,26 +69,32 @@ __device__ __forceinline__ float tail_rows_dot(const float* __restrict__ G, cons
   return acc;
 }
 
+// The pointers are kernel arguments of their own (const __restrict__), not members of a struct: only then does the compiler
+// prove the weights and statistics read-only and fetch them with scalar loads (as struct members every weight was a per-lane
+// global_load inside the channel loop: pass 7 took 127 us instead of 45).
 template <int PASS>
-__global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(TailArgs A) {
-  constexpr int kRows = PASS == 5 ? 3 * (kVnC + 2 * kTailC2) : PASS == 7 ? 3 * 3 * kVnC : 1;
+__global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(const float* __restrict__ aP, const float* __restrict__ aW,
+                                                              const float* __restrict__ a_stat, const float* __restrict__ a_red,
+                                                              const float* __restrict__ a_mask, const float* __restrict__ a_gout,
+                                                              float* __restrict__ a_partial, float* __restrict__ a_gP, int N) {
+  constexpr int kRows = PASS == 5 ? 3 * (kVnC + 2 * kTailC2) : PASS >= 6 ? 3 * 2 * kVnC : 1;  // 34 KB: four blocks per CU
   __shared__ __attribute__((aligned(16))) float rows[kRows * kTailPitch];
-  const int N = A.N, b = blockIdx.y, lane = threadIdx.x;
+  const int b = blockIdx.y, lane = threadIdx.x;
   const int n = blockIdx.x * kTailThreads + lane;
   const bool active = n < N;
   const int nn = active ? n : N - 1;
-  const float* __restrict__ Wf1 = A.W;
-  const float* __restrict__ Wd1 = A.W + kTailW1;
-  const float* __restrict__ Wf2 = A.W + 2 * kTailW1;
-  const float* __restrict__ Wd2 = A.W + 2 * kTailW1 + kTailW2;
-  const float* __restrict__ st1 = A.stat;
-  const float* __restrict__ st2 = A.stat + kTailStat;
-  const float* __restrict__ st3 = A.stat + 2 * kTailStat;
-  float* __restrict__ out = A.partial + ((size_t)b * gridDim.x + blockIdx.x) * tail_partial_floats(PASS);
+  const float* __restrict__ Wf1 = aW;
+  const float* __restrict__ Wd1 = aW + kTailW1;
+  const float* __restrict__ Wf2 = aW + 2 * kTailW1;
+  const float* __restrict__ Wd2 = aW + 2 * kTailW1 + kTailW2;
+  const float* __restrict__ st1 = a_stat;
+  const float* __restrict__ st2 = a_stat + kTailStat;
+  const float* __restrict__ st3 = a_stat + 2 * kTailStat;
+  float* __restrict__ out = a_partial + ((size_t)b * gridDim.x + blockIdx.x) * tail_partial_floats(PASS);
 
   V3 X[kVnC];
   {
-    const float* p = A.P + (size_t)b * kVnC * 3 * N + nn;
+    const float* p = aP + (size_t)b * kVnC * 3 * N + nn;
 #pragma unroll
     for (int i = 0; i < kVnC; ++i) X[i] = v3(p[(size_t)(3 * i) * N], p[(size_t)(3 * i + 1) * N], p[(size_t)(3 * i + 2) * N]);
   }
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(TailArgs A) {
   float keep[3 * kTailC2];
 #pragma unroll
   for (int j = 0; j < 3 * kTailC2; ++j)
-    keep[j] = !active ? 0.f : A.mask ? A.mask[((size_t)b * 3 * kTailC2 + j) * N + nn] : 1.f;
+    keep[j] = !active ? 0.f : a_mask ? a_mask[((size_t)b * 3 * kTailC2 + j) * N + nn] : 1.f;
   if constexpr (PASS == 3) {
 #pragma unroll
     for (int o = 0; o < kTailC2; ++o) {
@@ -149,13 +155,13 @@ __global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(TailArgs A) {
   // ---- backward.  mean over N, then dropout: g_y3 = gout / N * keep
   if constexpr (PASS >= 4) {
     const float inv_N = 1.0f / (float)N;
-    const float* __restrict__ rd1 = A.red;
-    const float* __restrict__ rd2 = A.red + kTailRed;
-    const float* __restrict__ rd3 = A.red + 2 * kTailRed;
+    const float* __restrict__ rd1 = a_red;
+    const float* __restrict__ rd2 = a_red + kTailRed;
+    const float* __restrict__ rd3 = a_red + 2 * kTailRed;
     V3 gp3[kTailC2], gd3[kTailC2];
 #pragma unroll
     for (int o = 0; o < kTailC2; ++o) {
-      const float* g = A.gout + ((size_t)b * kTailC2 + o) * 3;
+      const float* g = a_gout + ((size_t)b * kTailC2 + o) * 3;
       const V3 g_y3 = v3(g[0] * inv_N * keep[3 * o], g[1] * inv_N * keep[3 * o + 1], g[2] * inv_N * keep[3 * o + 2]);
       const VnGrad r = vn_gate_grad(p3[o], d3[o], st3[o], st3[32 + o], g_y3);
       if constexpr (PASS == 4) {
@@ -204,17 +210,17 @@ __global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(TailArgs A) {
       }
       const V3 g_y1 = vn_norm_input_grad(rb, st2[c], st2[64 + c], st2[96 + c], rd2[c], rd2[32 + c], active);
       const VnGrad ra = vn_gate_grad(p1, d1, st1[c], st1[32 + c], g_y1);
-      if constexpr (PASS == 6) {
+      if constexpr (PASS == 6) {  // rows: g_d1 (63) | X (63)  (the gate's gradient needs no batch sums of this layer)
         const float s0 = wave_sum_f(ra.g_nbn), s1 = wave_sum_f(ra.g_nbn * (ra.nr - st1[64 + c]) * st1[96 + c]);
         if (lane == 0) { out[2 * c] = s0; out[2 * c + 1] = s1; }
+        float* r0 = rows + 3 * c * kTailPitch + lane;
+        r0[0] = ra.g_d.x; r0[kTailPitch] = ra.g_d.y; r0[2 * kTailPitch] = ra.g_d.z;
         continue;
       }
-      if constexpr (PASS == 7) {  // rows: g_p1 (63) | g_d1 (63) | X (63)
+      if constexpr (PASS == 7) {  // rows: g_p1 (63) | X (63)
         const V3 g_p1 = vn_norm_input_grad(ra, st1[c], st1[64 + c], st1[96 + c], rd1[c], rd1[32 + c], active);
         float* r0 = rows + 3 * c * kTailPitch + lane;
         r0[0] = g_p1.x; r0[kTailPitch] = g_p1.y; r0[2 * kTailPitch] = g_p1.z;
-        float* r1 = r0 + 3 * kVnC * kTailPitch;
-        r1[0] = ra.g_d.x; r1[kTailPitch] = ra.g_d.y; r1[2 * kTailPitch] = ra.g_d.z;
 #pragma unroll
         for (int i = 0; i < kVnC; ++i) {
           axpy3(gX[i], Wf1[c * kVnC + i], g_p1);
@@ -230,24 +236,43 @@ __global__ __launch_bounds__(kTailThreads) void vn_tail_kernel(TailArgs A) {
         o2[k] = tail_rows_dot(rows + (3 * kVnC + 3 * (mat * kTailC2 + o)) * kTailPitch, rows + 3 * c * kTailPitch);
       }
     }
-    if constexpr (PASS == 7) {
-      float* gp = A.gP + (size_t)b * kVnC * 3 * N + n;
+    if constexpr (PASS >= 6) {  // pass 6: d W_d1 (21 x 21) behind the 42 sums; pass 7: d W_f1 (21 x 21) and g_pooled
+      float* gp = a_gP + (size_t)b * kVnC * 3 * N + n;
 #pragma unroll
       for (int i = 0; i < kVnC; ++i) {
-        float* r2 = rows + (6 * kVnC + 3 * i) * kTailPitch + lane;
+        float* r2 = rows + (3 * kVnC + 3 * i) * kTailPitch + lane;
         const float f = active ? 1.f : 0.f;
         r2[0] = X[i].x * f; r2[kTailPitch] = X[i].y * f; r2[2 * kTailPitch] = X[i].z * f;
-        if (active) {
-          gp[(size_t)(3 * i) * N] = gX[i].x; gp[(size_t)(3 * i + 1) * N] = gX[i].y; gp[(size_t)(3 * i + 2) * N] = gX[i].z;
+        if constexpr (PASS == 7) {
+          if (active) {
+            gp[(size_t)(3 * i) * N] = gX[i].x; gp[(size_t)(3 * i + 1) * N] = gX[i].y; gp[(size_t)(3 * i + 2) * N] = gX[i].z;
+          }
         }
       }
       __syncthreads();
-      for (int k = lane; k < 2 * kTailW1; k += kTailThreads) {  // d W_f1 (21 x 21) | d W_d1 (21 x 21)
-        const int mat = k / kTailW1, r = k - mat * kTailW1, c = r / kVnC, i = r - c * kVnC;
-        out[k] = tail_rows_dot(rows + 3 * (mat * kVnC + c) * kTailPitch, rows + (6 * kVnC + 3 * i) * kTailPitch);
+      float* ow = PASS == 6 ? out + 2 * kVnC : out;
+      for (int k = lane; k < kTailW1; k += kTailThreads) {
+        const int c = k / kVnC, i = k - c * kVnC;
+        ow[k] = tail_rows_dot(rows + 3 * c * kTailPitch, rows + (3 * kVnC + 3 * i) * kTailPitch);
       }
     }
   }
+}
+
+// sum over the blocks j = slice, slice + 16, ... of one column of the partials; eight loads in flight (one at a time the loop
+// is a chain of L2 round trips: 18 us for 1024 blocks)
+__device__ __forceinline__ double tail_column_sum(const float* __restrict__ col, int nblk, int stride, int slice) {
+  double acc = 0.0;
+  int j = slice;
+  for (; j + 7 * 16 < nblk; j += 8 * 16) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = col[(size_t)(j + 16 * u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += (double)t[u];
+  }
+  for (; j < nblk; j += 16) acc += (double)col[(size_t)j * stride];
+  return acc;
 }
 
 // partial:(nblk, stride) block sums (sum n at 2c, sum n^2 at 2c+1) -> stat = scale | shift | mean | rstd of one batch-norm over M
@@ -259,10 +284,7 @@ __global__ __launch_bounds__(1024) void vn_bn_finalize_kernel(const float* __res
                                                              float* __restrict__ stat) {
   __shared__ double s[16][64];
   const int v = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  double acc = 0.0;
-  if (v < 2 * C)
-    for (int j = slice; j < nblk; j += 16) acc += (double)partial[(size_t)j * stride + v];
-  s[slice][v] = acc;
+  s[slice][v] = v < 2 * C ? tail_column_sum(partial + v, nblk, stride, slice) : 0.0;
   __syncthreads();
   if (threadIdx.x < C) {
     const int c = threadIdx.x;
@@ -292,10 +314,7 @@ __global__ __launch_bounds__(1024) void vn_bn_bwd_finalize_kernel(const float* _
                                                                  float* __restrict__ grads, float* __restrict__ red) {
   __shared__ double s[16][64];
   const int v = threadIdx.x & 63, slice = threadIdx.x >> 6;
-  double acc = 0.0;
-  if (v < 2 * C)
-    for (int j = slice; j < nblk; j += 16) acc += (double)partial[(size_t)j * stride + v];
-  s[slice][v] = acc;
+  s[slice][v] = v < 2 * C ? tail_column_sum(partial + v, nblk, stride, slice) : 0.0;
   __syncthreads();
   if (threadIdx.x < 2 * C) {
     double t = 0.0;
@@ -308,7 +327,8 @@ __global__ __launch_bounds__(1024) void vn_bn_bwd_finalize_kernel(const float* _
 
 template <int PASS>
 int launch_tail(const TailArgs& a, int B, hipStream_t st) {
-  hipLaunchKernelGGL(vn_tail_kernel<PASS>, dim3((a.N + kTailThreads - 1) / kTailThreads, B), dim3(kTailThreads), 0, st, a);
+  hipLaunchKernelGGL(vn_tail_kernel<PASS>, dim3((a.N + kTailThreads - 1) / kTailThreads, B), dim3(kTailThreads), 0, st, a.P, a.W, a.stat,
+                     a.red, a.mask, a.gout, a.partial, a.gP, a.N);
   return launch_status();
 }
 

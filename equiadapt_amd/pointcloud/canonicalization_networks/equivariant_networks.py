@@ -173,23 +173,24 @@ class TailMean(torch.autograd.Function):
         with torch.cuda.device(dev):
             red = torch.zeros((3, 64), dtype=torch.float32, device=dev)
             grads = torch.empty((3, 64), dtype=torch.float32, device=dev)
-            part = torch.empty(nblk * 882, dtype=torch.float32, device=dev)
+            part = torch.empty(nblk * 483, dtype=torch.float32, device=dev)
             g_pooled = torch.empty_like(pooled)
-            dW2 = None
+            dW2 = dWd1 = None
             for pas, layer, C in ((4, 2, 4), (5, 1, 21), (6, 0, 21)):
                 _lib.check(lib.eqa_vn_tail_pass(pas, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), red.data_ptr(), p_mask,
                                                 gout.data_ptr(), part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
                 stride = lib.eqa_vn_tail_partial_floats(pas)
                 _lib.check(lib.eqa_vn_bn_bwd_finalize(part.data_ptr(), nblk, stride, C, B * N, grads[layer].data_ptr(),
                                                       red[layer].data_ptr(), st), "eqa_vn_bn_bwd_finalize")
-                if pas == 5:
-                    dW2 = part[:nblk * stride].view(nblk, stride)[:, 42:].sum(0, dtype=torch.float64).float()
+                if pas != 4:   # weight-gradient partials behind the 42 sums: conv2 (168) in pass 5, conv1.map_to_dir (441) in pass 6
+                    dW = part[:nblk * stride].view(nblk, stride)[:, 42:].sum(0, dtype=torch.float64).float()
+                    dW2, dWd1 = (dW, dWd1) if pas == 5 else (dW2, dW)
             _lib.check(lib.eqa_vn_tail_pass(7, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), red.data_ptr(), p_mask,
                                             gout.data_ptr(), part.data_ptr(), g_pooled.data_ptr(), B, N, st), "eqa_vn_tail_pass")
-            dW1 = part.view(nblk, 882).sum(0, dtype=torch.float64).float()
+            dWf1 = part[:nblk * 441].view(nblk, 441).sum(0, dtype=torch.float64).float()
         db = [grads[i, :c] for i, c in ((0, 21), (1, 21), (2, 4))]
         dg = [grads[i, 32:32 + c] for i, c in ((0, 21), (1, 21), (2, 4))]
-        return (g_pooled, dW1[:441].view(21, 21), dW1[441:].view(21, 21), dW2[:84].view(4, 21), dW2[84:].view(4, 21),
+        return (g_pooled, dWf1.view(21, 21), dWd1.view(21, 21), dW2[:84].view(4, 21), dW2[84:].view(4, 21),
                 dg[0], db[0], dg[1], db[1], dg[2], db[2], None, None)
 
 

@@ -464,8 +464,9 @@ int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf
  *   pass 0, 1, 2   partial = sum n, sum n^2 per channel of conv1 / bn1 / conv2 (each needs the stat of the layers before it)
  *   pass 3         partial:(blocks, 12) = sum over the block's points of the dropped-out conv2 output (the caller divides by N)
  *   pass 4, 5, 6   partial[0 .. 2C) = sum g, sum g nhat of conv2 / bn1 / conv1 (each needs red of the layers after it);
- *                  pass 5 also partial[42 .. 210) = d conv2.map_to_feat | d conv2.map_to_dir
- *   pass 7         partial:(blocks, 882) = d conv1.map_to_feat | d conv1.map_to_dir;  g_pooled written
+ *                  pass 5 also partial[42 .. 210) = d conv2.map_to_feat | d conv2.map_to_dir,
+ *                  pass 6 also partial[42 .. 483) = d conv1.map_to_dir
+ *   pass 7         partial:(blocks, 441) = d conv1.map_to_feat;  g_pooled written
  *   eqa_vn_bn_finalize      partial:(nblk, stride) sums -> stat of one batch-norm over M samples; running_mean / running_var
  *                           (may be NULL) updated with the unbiased variance and `momentum`, *num_batches_tracked += 1
  *   eqa_vn_bn_bwd_finalize  partial:(nblk, stride) sums -> grads = d beta[32] | d gamma[32], red = m1[32] | m2[32]
