@@ -105,6 +105,7 @@ SIGNATURES = {
     "eqa_vnsmall_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_so3_rotate": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "eqa_gram_schmidt": (_int, [_vp, _vp, _int, _vp]),
+    "eqa_gram_schmidt_bwd": (_int, [_vp, _vp, _vp, _int, _vp]),
     "eqa_modified_gram_schmidt": (_int, [_vp, _vp, _int, _vp]),
     "eqa_rigid_rows": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp]),
 }

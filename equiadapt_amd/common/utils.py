@@ -5,7 +5,7 @@ from equiadapt_amd import ops
 
 
 class _GramSchmidtFn(torch.autograd.Function):
-    """Forward: eqa_gram_schmidt kernel.  Backward: analytic, re-derived from the same three steps."""
+    """Forward: eqa_gram_schmidt kernel.  Backward: eqa_gram_schmidt_bwd, the analytic derivative of the same three steps."""
 
     @staticmethod
     def forward(ctx, vectors: torch.Tensor) -> torch.Tensor:
@@ -15,17 +15,7 @@ class _GramSchmidtFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
         (vectors,) = ctx.saved_tensors
-        # 9 numbers per sample: differentiate the reference formula with autograd on the device.
-        with torch.enable_grad():
-            v = vectors.detach().requires_grad_(True)
-            e1 = v[:, 0] / torch.norm(v[:, 0], dim=1, keepdim=True)
-            u2 = v[:, 1] - torch.sum(v[:, 1] * e1, dim=1, keepdim=True) * e1
-            e2 = u2 / torch.norm(u2, dim=1, keepdim=True)
-            u3 = v[:, 2] - torch.sum(v[:, 2] * e1, dim=1, keepdim=True) * e1 - torch.sum(v[:, 2] * e2, dim=1, keepdim=True) * e2
-            e3 = u3 / torch.norm(u3, dim=1, keepdim=True)
-            out = torch.stack([e1, e2, e3], dim=1)
-            (g,) = torch.autograd.grad(out, v, grad_out)
-        return g
+        return ops.gram_schmidt_backward(vectors, grad_out)
 
 
 def gram_schmidt(vectors: torch.Tensor) -> torch.Tensor:

@@ -68,6 +68,48 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
   o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
 }
 
+// Backward of the classical Gram-Schmidt above: g:(B,3,3) = dL/d(e1,e2,e3) -> gv:(B,3,3) = dL/d(v1,v2,v3).  With e = u / |u|,
+// dL/du = (g - e <e, g>) / |u|;  u3 = v3 - <v3,e1> e1 - <v3,e2> e2 and u2 = v2 - <v2,e1> e1 feed gradients back into e1, e2:
+//   d/de of -<v,e> e against gu:  -(<v,e> gu + <gu,e> v).
+// (As 100 element-wise autograd launches on (B,3) tensors this was the largest host cost of a point-cloud training step.)
+__global__ __launch_bounds__(kThreads) void gram_schmidt_bwd_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                   float* __restrict__ gv, int B) {
+  const int b = blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  const float* p = v + (size_t)b * 9;
+  const float* q = g + (size_t)b * 9;
+  const V3 v1 = v3(p[0], p[1], p[2]), v2 = v3(p[3], p[4], p[5]), vv3 = v3(p[6], p[7], p[8]);
+  auto scaled = [](const V3& a, float s) { return v3(a.x * s, a.y * s, a.z * s); };
+  auto sub = [](const V3& a, const V3& c) { return v3(a.x - c.x, a.y - c.y, a.z - c.z); };
+  auto add = [](const V3& a, const V3& c) { return v3(a.x + c.x, a.y + c.y, a.z + c.z); };
+  // forward, keeping the lengths
+  const float n1 = sqrtf(dot3(v1, v1));
+  const V3 e1 = scaled(v1, 1.0f / n1);
+  const float c = dot3(v2, e1);
+  const V3 u2 = sub(v2, scaled(e1, c));
+  const float n2 = sqrtf(dot3(u2, u2));
+  const V3 e2 = scaled(u2, 1.0f / n2);
+  const float a1 = dot3(vv3, e1), a2 = dot3(vv3, e2);
+  const V3 u3 = sub(sub(vv3, scaled(e1, a1)), scaled(e2, a2));
+  const float n3 = sqrtf(dot3(u3, u3));
+  const V3 e3 = scaled(u3, 1.0f / n3);
+  // backward
+  V3 g1 = v3(q[0], q[1], q[2]), g2 = v3(q[3], q[4], q[5]);
+  const V3 g3 = v3(q[6], q[7], q[8]);
+  const V3 gu3 = scaled(sub(g3, scaled(e3, dot3(e3, g3))), 1.0f / n3);
+  const float s31 = dot3(gu3, e1), s32 = dot3(gu3, e2);
+  const V3 gv3 = sub(sub(gu3, scaled(e1, s31)), scaled(e2, s32));
+  g1 = sub(g1, add(scaled(gu3, a1), scaled(vv3, s31)));
+  g2 = sub(g2, add(scaled(gu3, a2), scaled(vv3, s32)));
+  const V3 gu2 = scaled(sub(g2, scaled(e2, dot3(e2, g2))), 1.0f / n2);
+  const float s21 = dot3(gu2, e1);
+  const V3 gv2 = sub(gu2, scaled(e1, s21));
+  g1 = sub(g1, add(scaled(gu2, c), scaled(v2, s21)));
+  const V3 gv1 = scaled(sub(g1, scaled(e1, dot3(e1, g1))), 1.0f / n1);
+  float* o = gv + (size_t)b * 9;
+  o[0] = gv1.x; o[1] = gv1.y; o[2] = gv1.z; o[3] = gv2.x; o[4] = gv2.y; o[5] = gv2.z; o[6] = gv3.x; o[7] = gv3.y; o[8] = gv3.z;
+}
+
 // ------------------------------------------------------------------------------------------------
 // P1 + P2: fused VNSmall forward (eval mode, mean pooling): kNN graph -> cross edge features -> VN linear / VN batch-norm
 // / direction-gated ReLU (3->21) -> mean over neighbours -> (21->21) + VN batch-norm -> (21->4) -> mean over points.
@@ -336,6 +378,14 @@ int eqa_rigid_rows(const float* x, const float* R, const float* t, float* out, i
   if (M == 0) return EQA_OK;
   if (!x || !R || !out || M < 0 || (mode != 0 && mode != 1)) return EQA_ERR_INVALID_ARG;
   hipLaunchKernelGGL(rigid_rows_kernel, dim3((M + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, x, R, t, out, M, mode);
+  return launch_status();
+}
+
+int eqa_gram_schmidt_bwd(const float* v, const float* grad_out, float* grad_v, int B, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!v || !grad_out || !grad_v || B < 0) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(gram_schmidt_bwd_kernel, dim3((B + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, v, grad_out,
+                     grad_v, B);
   return launch_status();
 }
 

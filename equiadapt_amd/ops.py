@@ -568,6 +568,20 @@ def image_action_nearest(x: torch.Tensor, eidx: torch.Tensor, rtheta: torch.Tens
     return out
 
 
+def gram_schmidt_backward(v: torch.Tensor, grad_out: torch.Tensor) -> torch.Tensor:
+    """dL/dv of `gram_schmidt` from dL/d(out), both (B,3,3) (eqa_gram_schmidt_bwd)."""
+    lib = _lib.load()
+    v = _need(v, "vectors")
+    grad_out = _need(grad_out, "grad_out")
+    if v.dim() != 3 or v.shape[1:] != (3, 3) or grad_out.shape != v.shape:
+        raise ValueError("gram_schmidt_backward expects two (B,3,3) tensors")
+    gv = torch.empty_like(v)
+    with torch.cuda.device(v.device):
+        st = lib.eqa_gram_schmidt_bwd(v.data_ptr(), grad_out.data_ptr(), gv.data_ptr(), v.shape[0], _stream())
+    _lib.check(st, "eqa_gram_schmidt_bwd")
+    return gv
+
+
 def modified_gram_schmidt(v: torch.Tensor) -> torch.Tensor:
     """(B,3,3) -> orthonormal rows by MODIFIED Gram-Schmidt (n-body canonicalizer; eqa_modified_gram_schmidt)."""
     lib = _lib.load()

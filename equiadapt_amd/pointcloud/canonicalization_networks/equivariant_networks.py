@@ -64,25 +64,39 @@ class ConvPosMeanPool(torch.autograd.Function):
             idx = torch.empty((B, N, k), dtype=torch.int32, device=dev)
             _lib.check(lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, st), "eqa_vn_knn")
             M = B * N * k
-            if bn.training or bn.running_mean is None:
+            batch_stats = bool(bn.training or bn.running_mean is None)
+            stat = torch.empty(128, dtype=torch.float32, device=dev)          # scale | shift | mean | rstd, 32 floats each
+            if batch_stats and (bn.momentum is not None or not bn.track_running_stats):
                 part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
                 _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, st),
                            "eqa_vn_convpos_stats")
-                sums = part.sum(0, dtype=torch.float64)
-                mean = sums[:, 0] / M
-                var = (sums[:, 1] / M - mean * mean).clamp_min(0.0)
-                update_running_stats(bn, mean, var * (M / max(M - 1, 1)))
-                mean, var = mean.float(), var.float()
+                track = bn.track_running_stats and bn.running_mean is not None
+                _lib.check(lib.eqa_vn_bn_finalize(part.data_ptr(), nblk, 2 * C, C, M, gamma.detach().data_ptr(), beta.detach().data_ptr(),
+                                                  bn.running_mean.data_ptr() if track else None,
+                                                  bn.running_var.data_ptr() if track else None,
+                                                  bn.num_batches_tracked.data_ptr() if track else None,
+                                                  float(bn.momentum or 0.0), float(bn.eps), stat.data_ptr(), st), "eqa_vn_bn_finalize")
             else:
-                mean, var = bn.running_mean, bn.running_var
-            rstd = torch.rsqrt(var + bn.eps)
-            scale = (gamma.detach() * rstd).contiguous()
-            shift = (beta.detach() - mean * scale).contiguous()
+                if batch_stats:                                                # cumulative moving average (momentum=None): host glue
+                    part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
+                    _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, st),
+                               "eqa_vn_convpos_stats")
+                    sums = part.sum(0, dtype=torch.float64)
+                    mean = sums[:, 0] / M
+                    var = (sums[:, 1] / M - mean * mean).clamp_min(0.0)
+                    update_running_stats(bn, mean, var * (M / max(M - 1, 1)))
+                    mean, var = mean.float(), var.float()
+                else:
+                    mean, var = bn.running_mean, bn.running_var
+                rstd = torch.rsqrt(var + bn.eps)
+                sc = gamma.detach() * rstd
+                stat[0:C], stat[32:32 + C], stat[64:64 + C], stat[96:96 + C] = sc, beta.detach() - mean * sc, mean, rstd
+            scale, shift, mean, rstd = stat[0:C], stat[32:32 + C], stat[64:64 + C], stat[96:96 + C]
             pooled = torch.empty((B, C, 3, N), dtype=torch.float32, device=dev)
             _lib.check(lib.eqa_vn_convpos_fwd(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), Wd_.data_ptr(), scale.data_ptr(),
                                               shift.data_ptr(), pooled.data_ptr(), B, N, st), "eqa_vn_convpos_fwd")
-        ctx.save_for_backward(x, idx, Wf_, Wd_, scale, shift, mean.contiguous(), rstd.contiguous())
-        ctx.batch_stats, ctx.M = bool(bn.training or bn.running_mean is None), M
+        ctx.save_for_backward(x, idx, Wf_, Wd_, stat)
+        ctx.batch_stats, ctx.M = batch_stats, M
         return pooled
 
     @staticmethod
@@ -90,9 +104,10 @@ class ConvPosMeanPool(torch.autograd.Function):
         from equiadapt_amd import _lib, ops
 
         lib = _lib.load()
-        x, idx, Wf, Wd, scale, shift, mean, rstd = ctx.saved_tensors
+        x, idx, Wf, Wd, stat = ctx.saved_tensors
         B, _, N = x.shape
         C = Wf.shape[0]
+        scale, shift, mean, rstd = stat[0:C], stat[32:32 + C], stat[64:64 + C], stat[96:96 + C]
         gpool = gpool.contiguous()
         st = ops._stream()
         nblk = B * lib.eqa_vn_blocks(N)
@@ -102,17 +117,18 @@ class ConvPosMeanPool(torch.autograd.Function):
             _lib.check(lib.eqa_vn_convpos_bwd_reduce(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
                                                      shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gpool.data_ptr(),
                                                      part.data_ptr(), B, N, st), "eqa_vn_convpos_bwd_reduce")
-            sums = part.sum(0, dtype=torch.float64)
-            dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
-            if ctx.batch_stats:
-                m1, m2 = (sums[:, 0] / ctx.M).float().contiguous(), (sums[:, 1] / ctx.M).float().contiguous()
-            else:
-                m1 = torch.zeros(C, device=dev)
-                m2 = m1
+            grads = torch.empty(64, dtype=torch.float32, device=dev)            # d beta[32] | d gamma[32]
+            red = torch.empty(64, dtype=torch.float32, device=dev)              # m1[32] | m2[32]
+            _lib.check(lib.eqa_vn_bn_bwd_finalize(part.data_ptr(), nblk, 2 * C, C, ctx.M, grads.data_ptr(), red.data_ptr(), st),
+                       "eqa_vn_bn_bwd_finalize")
+            dbeta, dgamma = grads[:C], grads[32:32 + C]
+            if not ctx.batch_stats:
+                red.zero_()
             wpart = torch.empty((nblk, C, 6), dtype=torch.float32, device=dev)
             _lib.check(lib.eqa_vn_convpos_bwd_apply(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
-                                                    shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), m1.data_ptr(), m2.data_ptr(),
-                                                    gpool.data_ptr(), wpart.data_ptr(), B, N, st), "eqa_vn_convpos_bwd_apply")
+                                                    shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), red.data_ptr(),
+                                                    red[32:].data_ptr(), gpool.data_ptr(), wpart.data_ptr(), B, N, st),
+                       "eqa_vn_convpos_bwd_apply")
             dW = wpart.sum(0, dtype=torch.float64).float()
         return None, dW[:, :3].contiguous(), dW[:, 3:].contiguous(), dgamma, dbeta, None, None
 

@@ -485,6 +485,8 @@ int eqa_vn_bn_bwd_finalize(const float* partial, int nblk, int stride, int C, lo
  * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
  */
 int eqa_gram_schmidt(const float* v, float* out, int B, void* stream);
+/* its backward (training): grad_out:(B,3,3) = dL/d out -> grad_v:(B,3,3) = dL/d v, the analytic derivative of the three steps */
+int eqa_gram_schmidt_bwd(const float* v, const float* grad_out, float* grad_v, int B, void* stream);
 
 /*
  * (f).4 -- E(3) canonicalization of n-body systems (equiadapt/nbody/canonicalization/euclidean_group.py):

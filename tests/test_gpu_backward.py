@@ -672,3 +672,33 @@ def test_vnsmall_training_tail_matches_op_path(dev, B, N, p):
                 assert torch.allclose(b1.double(), b2, rtol=1e-5, atol=1e-7), k
             else:
                 assert int(b1) == int(b2) == 1, k
+
+
+def test_gram_schmidt_backward_matches_autograd_of_the_oracle(dev):
+    """eqa_gram_schmidt_bwd (analytic) against autograd through the oracle's restatement of common/utils.py:22-51 in fp64."""
+    from oracle import pointcloud_ops as po
+    from equiadapt_amd.common.utils import gram_schmidt
+
+    torch.manual_seed(31)
+    v = torch.randn(257, 3, 3)
+    g = torch.randn(257, 3, 3)
+    v64 = v.double().requires_grad_(True)
+    (po.gram_schmidt(v64) * g.double()).sum().backward()
+    vd = v.to(dev).requires_grad_(True)
+    (gram_schmidt(vd) * g.to(dev)).sum().backward()
+    # nearly collinear inputs make the derivative ~1 / sin^2(angle) and fp32 loses it (any fp32 evaluation does): judge the
+    # samples whose second and third vectors keep at least 0.2 of their length after the projections
+    with torch.no_grad():
+        e = po.gram_schmidt(v64)
+        u2 = v64[:, 1] - (v64[:, 1] * e[:, 0]).sum(1, keepdim=True) * e[:, 0]
+        u3 = (v64[:, 2] * e[:, 2]).sum(1).abs()
+        ok = (u2.norm(dim=1) / v64[:, 1].norm(dim=1) > 0.2) & (u3 / v64[:, 2].norm(dim=1) > 0.2)
+    assert int(ok.sum()) >= 120
+    scale = v64.grad.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-3)
+    rel = (vd.grad.cpu().double() - v64.grad).abs() / scale
+    assert rel[ok].max().item() <= 2e-4
+    assert rel.median().item() <= 1e-5
+    assert vd.grad.shape == (257, 3, 3)
+    empty = torch.empty(0, 3, 3, device=dev, requires_grad=True)
+    gram_schmidt(empty).sum().backward()
+    assert empty.grad.shape == (0, 3, 3)
