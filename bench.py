@@ -421,6 +421,14 @@ def leg_configs(comm: Comm, with_cpu: bool):
             "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd", "achieved": ach, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct,
             "note": "launch-bound at this size: B*24.6 KB per launch" if B == 128 else None}}
+        if B == 128:  # the same step captured once and replayed as a hipGraph (one host call instead of ~12 launches)
+            from equiadapt_amd.graphs import GraphedCanonicalizer
+
+            gstep = GraphedCanonicalizer(can, x.shape, f.shape)
+            gstep(x, f)
+            vg, msg = run(gstep.replay, B, 50, 10)
+            c1["batches"][str(B)]["hipgraph"] = {"value": vg, "ms_per_step": msg}
+            del gstep
     c1["value"] = c1["batches"]["8192"]["value"]
     if with_cpu:
         c1["cpu_baseline"] = cpu_baseline_config("cfg1", {"sd": sd1})
@@ -442,11 +450,21 @@ def leg_configs(comm: Comm, with_cpu: bool):
         pc = torch.randn(B, 3, 1024, device=dev)
         v, ms = run(lambda: can4(pc), B, 20, 5)
         per_gpu = v / comm.world
+        if B == 64:
+            from equiadapt_amd.graphs import GraphedCanonicalizer
+
+            gstep = GraphedCanonicalizer(can4, pc.shape)
+            gstep(pc)
+            vg, msg = run(gstep.replay, B, 50, 10)
+            hipgraph4 = {"value": vg, "ms_per_step": msg}
+            del gstep
         c4["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
             "bound": "valu", "kernel": "vnsmall_fwd_kernel (eqa_vnsmall_fwd)", "achieved": per_gpu * instr_per_cloud / 1e12,
             "peak": VALU_PEAK_WAVE_INSTR_S / 1e12, "unit": "T wave-instr/s", "frac": per_gpu * instr_per_cloud / VALU_PEAK_WAVE_INSTR_S,
             "hbm_frac": per_gpu * 12324 / 1e9 / HBM_PEAK_GBS,
             "note": "1.09 M VALU wave-instructions per cloud (kNN distances 82 k of them) against 12 KB of HBM traffic: issue-bound, not HBM-bound"}}
+        if B == 64:
+            c4["batches"][str(B)]["hipgraph"] = hipgraph4
     c4["value"] = c4["batches"]["2048"]["value"]
     if with_cpu:
         c4["cpu_baseline"] = cpu_baseline_config("cfg4", {"sd": sd4})

@@ -1410,3 +1410,42 @@ def test_conv_s2_mfma_matches_conv2d(dev):
             assert err <= 2e-6 * max(want.abs().max().item(), 1.0), (planar, Cin, Cout, K, pad, gelu, err)
     assert not ops.conv_s2_supported(3, 8, 5, 0, True) and not ops.conv_s2_supported(16, 16, 4, 0, False) \
         and not ops.conv_s2_supported(16, 16, 5, 2, False) and not ops.conv_s2_supported(8, 16, 5, 0, False)
+
+
+def test_graphed_canonicalizer_matches_eager(dev):
+    """equiadapt_amd.graphs.GraphedCanonicalizer: the captured hipGraph of canonicalize + invert replays bit-identically to the
+    eager step on new data, for an image canonicalizer (with invert) and the point-cloud one (no invert defined)."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.graphs import GraphedCanonicalizer
+
+    torch.manual_seed(23)
+    net = ea.CustomEquivariantNetwork((3, 32, 32), 8, 5, "rotation", 4, 2, device="cpu")
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=32)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 32, 32)).to(dev)
+    with pytest.raises(RuntimeError, match="eval"):
+        GraphedCanonicalizer(can.train(), (16, 3, 32, 32))
+    can.eval()
+    step = GraphedCanonicalizer(can, (16, 3, 32, 32), (16, 3, 32, 32))
+    for seed in (1, 2):
+        x = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(seed)).to(dev)
+        f = torch.randn(16, 3, 32, 32, generator=torch.Generator().manual_seed(50 + seed)).to(dev)
+        y, idx, inv = step(x, f)
+        torch.cuda.synchronize()
+        y, idx, inv = y.clone(), idx.clone(), inv.clone()
+        with torch.no_grad():
+            y_e = can(x)
+            idx_e = can.canonicalization_info_dict["group_index"]
+            inv_e = can.invert_canonicalization(f, induced_rep_type="scalar")
+        assert torch.equal(y, y_e) and torch.equal(idx, idx_e) and torch.equal(inv, inv_e)
+    with pytest.raises(ValueError, match="captured for"):
+        step(torch.zeros(8, 3, 32, 32, device=dev))
+
+    hp4 = types.SimpleNamespace(n_knn=20, pooling="mean")
+    can4 = ea.EquivariantPointcloudCanonicalization(ea.VNSmall(hp4), hp4).to(dev).eval()
+    step4 = GraphedCanonicalizer(can4, (4, 3, 128))
+    pc = torch.randn(4, 3, 128, device=dev)
+    y, R, inv = step4(pc)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        y_e = can4(pc)
+    assert inv is None and torch.equal(y, y_e) and torch.equal(R, can4.canonicalization_info_dict["group_element"]["rotation"])
