@@ -479,7 +479,12 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   const int c = grp * CH + cl;
   if (threadIdx.x < kFftH * CH) {
     const int kx = threadIdx.x / CH;
-    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m) * (size_t)C + c;
+#ifdef EQA_FFT_SAMETILE  // experiment: every block reads tile 0 (L2-resident) -- the kernel without its HBM wait
+    const size_t m_ld = 0;
+#else
+    const size_t m_ld = m;
+#endif
+    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c;
     const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
     float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
     const bool edge = fft_edge(kx);
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       // 23 * M * C complex numbers -> buffer loads with that step as a SCALAR offset, no vector address arithmetic at all
       // (mo_bytes = 0: the spectra do not fit a 32-bit offset, pointer arithmetic as in the edge waves)
       const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mo), 0, mo_bytes, 0x00020000);
-      const unsigned voff = (unsigned)((((size_t)fft_f0(kx) * M + m) * (size_t)C + c) * 8);
+      const unsigned voff = (unsigned)((((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c) * 8);
       const unsigned step = (unsigned)(kFftInner * M * (size_t)C * 8);
 #pragma unroll
       for (int ky = 0; ky < kFftN; ++ky) {
@@ -581,6 +586,309 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
       for (int r = 0; r < kWaves; ++r) t += lds[(r * NV + i) * CH + cl];
       // tile rows made of border rows only (OH <= 2 NB + ...) contribute an all-zero piece: harmless
       out[(((img * nseg + 2 * NB + ty) * TX + tx) * (size_t)C + c) * NV + i] = t;
+    }
+  }
+  FFT_CLOCK(4);
+}
+
+// The fused inverse as a persistent producer / consumer pipeline.  PMC (profiles/r02/pmc_memory_path.md): the fused kernel above
+// keeps only 34 cache lines per CU in flight on average (the group action: 69, the forward transform: 75) because a block loads
+// for 43 % of its life and computes for the rest, and with 155 KB of LDS no second block can fill the gap.  Here the block's
+// waves are specialised and walk the work items together:
+//   producers (7 waves, thread (kx, c)): column transform of item i -> LDS | barrier A | issue the 48 loads of item i+1 |
+//                                       barrier B | (wait for the loads) column transform of item i+1 ...
+//   consumers (5 waves, thread (row, c), 20 rows per pass, 3 passes): barrier A | read row, transform, epilogue | ... | read last row |
+//                                       barrier B | transform, epilogue, pieces ...
+// so the loads of the next item are in flight while the consumers work on this one, and the producers' registers (they only
+// hold the incoming column) cost nothing meanwhile.  12 waves = 3 per SIMD, 168 VGPRs each (with a sixth consumer wave the limit is
+// 128 and the producer loop spills its incoming column).
+constexpr int kPipeProd = 7 * 64, kPipeCons = 5 * 64, kPipeThreads = kPipeProd + kPipeCons;
+constexpr int kPipePasses = (kFftO * 16 + kPipeCons - 1) / kPipeCons;  // 20 rows of 16 channels per pass: 3 passes (20 + 20 + 4)
+
+template <int NB, int CH>
+__global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                                     int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
+                                                                     int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
+  extern __shared__ float lds[];
+  constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
+  constexpr int NV = 1 + 2 * NB;
+  constexpr int kPassRows = kPipeCons / CH;      // 20 rows per consumer pass
+  const unsigned nblk = gridDim.x;               // a multiple of the XCD count (or < 8): virtual block v runs on XCD v % 8 = blockIdx % 8
+  const int ngrp = C / CH;
+  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd;
+  auto work_of = [&](unsigned v) {
+    const unsigned xcd = v % kXcd;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + v / kXcd;
+  };
+  if (threadIdx.x < kPipeProd) {
+    // ---------------------------------------------------------------- producers
+    // the 48 idle lanes of the seventh wave duplicate its column kx = 24 (same loads, same values to the same LDS words): the
+    // loop body stays straight-line code
+    const int kx = min((int)threadIdx.x / CH, kFftH - 1);
+    const int cl = threadIdx.x % CH;
+    const bool edge = fft_edge(kx);
+    // One load path for every lane: buffer loads (32-bit offsets: the launcher checks that the spectra fit) at
+    // base + kk * lstep, lstep = this lane's frequency step.  Edge columns store rows 0..24 only: their rows ky > 24 are the
+    // conjugates of rows 48 - ky.  Past the last item the base is out of range: no memory access, zeros.
+    const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mo), 0, mo_bytes, 0x00020000);
+    unsigned lstep = (unsigned)((size_t)fft_fstep(kx) * M * C * 8);
+    const unsigned flip = edge ? 0x80000000u : 0u;
+    const unsigned col0 = (unsigned)((size_t)fft_f0(kx) * M * C * 8) + (unsigned)cl * 8;
+    float re[kFftN], im[kFftN];
+    // lstep is made opaque at every issue: otherwise its 48 multiples are hoisted out of the item loop as loop invariants and
+    // the incoming column is spilled to make room for them
+#define EQA_PIPE_ISSUE(v_)                                                                                                    \
+  do {                                                                                                                       \
+    asm volatile("" : "+v"(lstep));                                                                                          \
+    const unsigned work_ = work_of(v_);                                                                                      \
+    const unsigned item_ = (unsigned)(((size_t)(work_ / ngrp) * C + (size_t)(work_ % ngrp) * CH) * 8);                       \
+    const unsigned base_ = (v_) < nwork ? col0 + item_ : 0xfffffff0u;                                                        \
+    _Pragma("unroll") for (int ky = 0; ky < kFftN; ++ky) {                                                                   \
+      const unsigned kk_ = ky > kFftH - 1 ? (edge ? (unsigned)(kFftN - ky) : (unsigned)ky) : (unsigned)ky;                   \
+      const unsigned off_ = (v_) < nwork ? base_ + kk_ * lstep : 0xfffffff0u;                                                \
+      const f32x2 t_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, off_, 0, 2));                      \
+      re[ky] = t_[0];                                                                                                        \
+      im[ky] = ky > kFftH - 1 ? __uint_as_float(__float_as_uint(t_[1]) ^ flip) : t_[1];                                      \
+    }                                                                                                                        \
+    /* every offset right in front of its load (left alone, the scheduler forms all 48 offsets first: 48 more registers) */  \
+    _Pragma("unroll") for (int ky = 0; ky < kFftN; ++ky) {                                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                     \
+    }                                                                                                                        \
+  } while (0)
+    unsigned v = blockIdx.x;
+    EQA_PIPE_ISSUE(v);
+    float* const q = lds + kx * kPitch + cl;
+    for (; v < nwork; v += nblk) {
+      float ore[kFftN], oim[kFftN];
+      fft48(im, re, oim, ore);
+#pragma unroll
+      for (int i = 0; i < kFftO; ++i) {  // rows 44..47: the circular wrap-around
+        q[(i * 2) * CH] = ore[i];
+        q[(i * 2 + 1) * CH] = oim[i];
+      }
+      __syncthreads();                                   // A: the item's column transforms are in LDS
+      EQA_PIPE_ISSUE(v + nblk);
+      asm volatile("" ::: "memory");                     // the loads stay on this side of the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                   // B: the consumers have read their last row
+    }
+#undef EQA_PIPE_ISSUE
+    return;
+  }
+  // ------------------------------------------------------------------ consumers
+  const int t = threadIdx.x - kPipeProd;
+  const int r = t / CH, cl = t % CH;
+  for (unsigned v = blockIdx.x; v < nwork; v += nblk) {
+    const unsigned work = work_of(v);
+    const int grp = work % ngrp;
+    const size_t m = work / ngrp;
+    const int tx = (int)(m % TX);
+    const int ty = (int)((m / TX) % TY);
+    const size_t img = m / ((size_t)TX * TY);
+    const int c = grp * CH + cl;
+    const float b = bias ? bias[c] : 0.0f;
+    const int x0 = kFftO * tx;
+    const int ncols = min(kFftO, OW - x0);  // uniform
+    const int nseg = 2 * NB + (kPipeCons / 64) * TY;   // border rows one by one, then one interior piece per (tile row, consumer wave)
+    float tot[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tot[i] = 0.0f;
+    __syncthreads();                                     // A
+#pragma unroll 1
+    for (int pass = 0; pass < kPipePasses; ++pass) {
+      const int y = pass * kPassRows + r;
+      const int gy = kFftO * ty + y;
+      const bool valid = y < kFftO && gy < OH;
+      float re[kFftH], im[kFftH], ore[kFftN];
+      if (valid) {
+        const float* q = lds + (y * 2) * CH + cl;
+#pragma unroll
+        for (int k = 0; k < kFftH; ++k) {
+          re[k] = q[k * kPitch];
+          im[k] = q[k * kPitch + CH];
+        }
+      }
+      if (pass == kPipePasses - 1) __syncthreads();      // B: LDS may be overwritten (the values are in registers)
+      if (valid) {
+        re[0] += b;  // the bias rides on the row's DC bin: the (unnormalised) inverse adds re[0] to every output
+        ifft48_c2r(re, im, ore);
+        if constexpr (NB == 0) {
+          float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
+#pragma unroll
+          for (int j = 0; j < kFftO; ++j) {
+            if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
+          }
+        } else {
+          float acc[NV];
+          fft_row_pieces<NB>(ore, relu, ncols, tx == 0, OW - NB - x0, acc);
+          if (gy < NB || gy >= OH - NB) {
+            const int seg = gy < NB ? gy : NB + (gy - (OH - NB));
+            float* o = out + (((img * nseg + seg) * TX + tx) * (size_t)C + c) * NV;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) o[i] = acc[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) tot[i] += acc[i];
+          }
+        }
+      }
+    }
+    if constexpr (NB > 0) {
+      // a wave holds 64 / CH rows of the same CH channels: summed by shuffles, one interior piece per wave and tile row
+      const int cw = t >> 6;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        float s_ = tot[i];
+#pragma unroll
+        for (int o = CH; o < 64; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+        tot[i] = s_;
+      }
+      if ((t & 63) < CH) {
+        float* o = out + (((img * nseg + 2 * NB + (kPipeCons / 64) * ty + cw) * TX + tx) * (size_t)C + c) * NV;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) o[i] = tot[i];
+      }
+    }
+  }
+}
+
+constexpr int kSplitThreads = 448;  // fft48_inv_split_kernel: 25 x 16 column threads, 22 x 16 row threads, 7 waves
+
+// The same with a tile's 44 output rows split by parity over two blocks (one decimation-in-frequency step: the even rows are a
+// 24-point inverse transform of X_k + X_{k+24}, the odd rows one of (X_k - X_{k+24}) e^{+2 pi i k/48}).  The intermediate of a
+// block is 22 rows instead of 44 -- 72 KB of LDS and 7 waves, so TWO blocks fit a CU and one block's loads and barrier waits
+// overlap the other's arithmetic; the price is that both blocks read all 48 frequencies of their columns (the second read comes
+// from the XCD's L2: the two parities are consecutive work items) and 847 instead of 819 operations per column.
+template <int NB, int CH>
+__global__ __launch_bounds__(kSplitThreads, 4) void fft48_inv_split_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
+                                                                      int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
+                                                                      int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
+  extern __shared__ float lds[];
+  FFT_CLOCK_BEGIN();
+  constexpr int kRows = kFftO / 2;             // output rows of one parity
+  constexpr int kPitch = kRows * 2 * CH + CH;  // floats per kx slab
+  const unsigned bid = blockIdx.x;
+  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
+  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kXcd;
+  const int parity = work & 1;
+  const int ngrp = C / CH;
+  const int grp = (work >> 1) % ngrp;
+  const size_t m = (work >> 1) / ngrp;
+  const int tx = (int)(m % TX);
+  const int ty = (int)((m / TX) % TY);
+  const size_t img = m / ((size_t)TX * TY);
+  const int cl = threadIdx.x % CH;
+  const int c = grp * CH + cl;
+  if (threadIdx.x < kFftH * CH) {
+    const int kx = threadIdx.x / CH;
+#ifdef EQA_FFT_SAMETILE  // experiment: every block reads tile 0 (L2-resident) -- the kernel without its HBM wait
+    const size_t m_ld = 0;
+#else
+    const size_t m_ld = m;
+#endif
+    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c;
+    const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
+    float re[kFftN], im[kFftN], ore[kFftN / 2], oim[kFftN / 2];
+    const bool edge = fft_edge(kx);
+    if (mo_bytes && !__any(edge)) {
+      // a wave without edge columns (5 of the 7): all its lanes step through the 48 frequencies of their column by the same
+      // 23 * M * C complex numbers -> buffer loads with that step as a SCALAR offset, no vector address arithmetic at all
+      // (mo_bytes = 0: the spectra do not fit a 32-bit offset, pointer arithmetic as in the edge waves)
+      const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mo), 0, mo_bytes, 0x00020000);
+      const unsigned voff = (unsigned)((((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c) * 8);
+      const unsigned step = (unsigned)(kFftInner * M * (size_t)C * 8);
+#pragma unroll
+      for (int ky = 0; ky < kFftN; ++ky) {
+        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, voff, ky * step, 0));   // cached: the other parity's block reads the same lines
+        re[ky] = t[0];
+        im[ky] = t[1];
+      }
+    } else {
+      fft_load_column(p, fpitch, edge, re, im);
+    }
+    FFT_CLOCK_LOADS();
+    if (parity) ifft48_odd(re, im, ore, oim); else ifft48_even(re, im, ore, oim);
+    float* q = lds + kx * kPitch + cl;
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {  // rows 44..47 (i = 22, 23): the circular wrap-around
+      q[(i * 2) * CH] = ore[i];
+      q[(i * 2 + 1) * CH] = oim[i];
+    }
+  }
+  FFT_CLOCK(1);
+  __syncthreads();
+  FFT_CLOCK(2);
+  const int r = threadIdx.x / CH;
+  const int y = 2 * r + parity;
+  const int gy = kFftO * ty + y;
+  const bool valid = r < kRows && gy < OH;
+  constexpr int NV = 1 + 2 * NB;
+  float acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
+  if (valid) {
+    const float* q = lds + (r * 2) * CH + cl;
+    float re[kFftH], im[kFftH], ore[kFftN];
+#pragma unroll
+    for (int k = 0; k < kFftH; ++k) {
+      re[k] = q[k * kPitch];
+      im[k] = q[k * kPitch + CH];
+    }
+    // the bias rides on the row's DC bin: the (unnormalised) inverse adds re[0] to every output
+    const float b = bias ? bias[c] : 0.0f;
+    re[0] += b;
+    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
+    const int x0 = kFftO * tx;
+    const int ncols = min(kFftO, OW - x0);  // uniform
+    if constexpr (NB == 0) {
+      float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
+#pragma unroll
+      for (int j = 0; j < kFftO; ++j) {
+        if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
+      }
+    } else {
+      fft_row_pieces<NB>(ore, relu, ncols, tx == 0, OW - NB - x0, acc);
+    }
+  }
+  FFT_CLOCK(3);
+  if (NB > 0) {
+    // Window-sum pieces.  Segments (the order window_sums_nhwc_finalize_kernel expects): the NB top rows, the NB bottom rows,
+    // then ONE per tile row for its interior rows -- those are only ever needed as a sum, which the block forms here in a
+    // fixed order (LDS is free once every thread has read its row spectrum) instead of writing 44 pieces per tile column.
+    const int nseg = 2 * NB + 2 * TY;           // one interior piece per (tile row, parity)
+    const bool border = gy < NB || gy >= OH - NB;
+    if (valid && border) {
+      const int seg = gy < NB ? gy : NB + (gy - (OH - NB));
+      float* o = out + (((img * nseg + seg) * TX + tx) * (size_t)C + c) * NV;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) o[i] = acc[i];
+    }
+    // a wave holds 64 / CH consecutive rows of the same CH channels: those are summed by wavefront shuffles first, one LDS slot
+    // per wave instead of one per row (44 -> 11 terms in the serial sum below, a quarter of the LDS traffic)
+    constexpr int kRowsPerWave = 64 / CH;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float v = (valid && !border) ? acc[i] : 0.0f;
+#pragma unroll
+      for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+      acc[i] = v;
+    }
+    __syncthreads();
+    const int wv = threadIdx.x >> 6;
+    constexpr int kWaves = (kRows * CH + 63) / 64;      // waves that hold output rows
+    if ((threadIdx.x & 63) < CH && wv < kWaves) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) lds[(wv * NV + i) * CH + cl] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < NV * CH) {
+      const int i = threadIdx.x / CH;
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < kWaves; ++r) t += lds[(r * NV + i) * CH + cl];
+      // tile rows made of border rows only (OH <= 2 NB + ...) contribute an all-zero piece: harmless
+      out[(((img * nseg + 2 * NB + 2 * ty + parity) * TX + tx) * (size_t)C + c) * NV + i] = t;
     }
   }
   FFT_CLOCK(4);
@@ -802,6 +1110,43 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   *fused = 0;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
+  // NB > 0 (window-sum pieces): the tile rows split by parity over two co-resident blocks (EQA_FFT_INV_SPLIT=0: one block per
+  // tile); the pieces buffer has OH segment slots per image, the split needs 2 NB + 2 TY
+  static const bool split_on = []() { const char* e = getenv("EQA_FFT_INV_SPLIT"); return e && e[0] == '1'; }();
+  if (NB > 0 && split_on && kInvCh == 16 && C % kInvCh == 0 && 2 * M * (C / kInvCh) <= 0x7fffffffULL && !two_pass && 2 * NB + 2 * TY <= OH) {
+    constexpr int lds_bytes = kFftH * ((kFftO / 2) * 2 * kInvCh + kInvCh) * (int)sizeof(float);
+    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_split_kernel<NB, kInvCh>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    if (lds_ok) {
+      const unsigned nwork = (unsigned)(2 * M * (C / kInvCh));
+      const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
+      hipLaunchKernelGGL((fft48_inv_split_kernel<NB, kInvCh>), dim3(nwork), dim3(kSplitThreads), lds_bytes, st, Mo, bias, relu, out, OH,
+                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
+      *fused = 2;
+      return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+    }
+    (void)hipGetLastError();
+  }
+  // persistent producer / consumer pipeline (EQA_FFT_INV_PIPE=0: one block per work item); with window-sum pieces the buffer
+  // must hold 2 NB + 6 TY segments per image (it has OH)
+  static const bool pipe_on = []() { const char* e = getenv("EQA_FFT_INV_PIPE"); return !(e && e[0] == '0'); }();
+  if (pipe_on && kInvCh == 16 && C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass &&
+      (size_t)kFftF * fft_pitch(M) * C * 8 <= 0xffffff00ULL && (NB == 0 || 2 * NB + (kPipeCons / 64) * TY <= OH)) {
+    constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
+    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_pipe_kernel<NB, kInvCh>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    static const int n_cu = []() { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    if (lds_ok) {
+      const unsigned nwork = (unsigned)(M * (C / kInvCh));
+      const unsigned blocks = nwork < (unsigned)n_cu ? nwork : (unsigned)(n_cu / kXcd * kXcd);
+      const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
+      hipLaunchKernelGGL((fft48_inv_pipe_kernel<NB, kInvCh>), dim3(blocks), dim3(kPipeThreads), lds_bytes, st, Mo, bias, relu, out, OH,
+                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
+      *fused = 3;
+      return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+    }
+    (void)hipGetLastError();
+  }
   if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass) {
     constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
     static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB, kInvCh>,
@@ -963,7 +1308,9 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   if (rc != EQA_OK) return rc;
   // fused path: 2 nb border rows + one segment per tile row, each in `sub` = TX pieces; two-pass path: one per output row
   const int sub = fused ? (OW + kFftO - 1) / kFftO : 1;
-  const int nseg = fused ? 2 * nb + (OH + kFftO - 1) / kFftO : OH;
+  // interior pieces per tile row: 1 (fused), 2 (split: one per parity), 6 (pipeline: one per consumer wave)
+  const int per_row = fused == 3 ? kPipeCons / 64 : fused;
+  const int nseg = fused ? 2 * nb + per_row * ((OH + kFftO - 1) / kFftO) : OH;
   return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, nseg * sub, st, sub);
 }
 

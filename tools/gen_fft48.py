@@ -179,6 +179,29 @@ out_r2c = build_r2c()
 lines_r2c = lines
 
 
+def build_half_inverse(parity):
+    """Rows y = 2 r + parity (r = 0..23) of the unscaled 48-point INVERSE transform x[y] = sum_k X_k e^{+2 pi i k y/48} by one
+    decimation-in-frequency step: a 24-point inverse transform of X_k + X_{k+24} (even rows) or of
+    (X_k - X_{k+24}) e^{+2 pi i k/48} (odd rows)."""
+    X = [(f"re[{k}]", f"im[{k}]") for k in range(48)]
+    Z = []
+    for k in range(24):
+        if parity == 0:
+            Z.append(cadd(X[k], X[k + 24]))
+        else:
+            Z.append(cmul_const(csub(X[k], X[k + 24]), 48 - k, 48))   # e^{+2 pi i k/48} = e^{-2 pi i (48-k)/48}
+    o = fft24([(zi, zr) for (zr, zi) in Z])            # inverse = forward with re / im swapped on the way in and out
+    return [(o[r][1], o[r][0]) for r in range(24)]
+
+
+lines = []
+out_even = build_half_inverse(0)
+lines_even = lines
+lines = []
+out_odd = build_half_inverse(1)
+lines_odd = lines
+
+
 def evaluate(z, ops=None, outs=None):
     """Run an operation list in numpy with float32 rounding after every operation (what the device does without FMA
     contraction) on the complex vector z; default: the 48-point transform."""
@@ -211,22 +234,36 @@ def evaluate(z, ops=None, outs=None):
 def render():
     o = ["// GENERATED by tools/gen_fft48.py -- do not edit.  48-point complex DFT, forward sign, natural order in and out.",
          "// %d floating-point operations, all indices static.  Inverse: call with (im, re) in and (oim, ore) out." % len(lines_fft),
-         "__device__ __forceinline__ void fft48(const float (&re)[48], const float (&im)[48], float (&ore)[48], float (&oim)[48]) {"]
-    o += [f"  const float {dst} = {expr};" for dst, expr in lines_fft]
+         "// T: float, or a 2-vector of floats (two independent transforms per lane on the packed fp32 instructions).",
+         "template <typename T>",
+         "__device__ __forceinline__ void fft48(const T (&re)[48], const T (&im)[48], T (&ore)[48], T (&oim)[48]) {"]
+    o += [f"  const T {dst} = {expr};" for dst, expr in lines_fft]
     o += [f"  ore[{k}] = {r}; oim[{k}] = {i};" for k, (r, i) in enumerate(out)]
     o += ["}", "",
           "// Real 48-point output of a Hermitian spectrum from its half re/im[0..24] (unscaled inverse; im[0], im[24] ignored):",
           "// one 24-point complex transform of Z_k = E_k + i O_k (see tools/gen_fft48.py build_c2r).  %d operations." % len(lines_c2r),
-          "__device__ __forceinline__ void ifft48_c2r(const float (&re)[25], const float (&im)[25], float (&x)[48]) {"]
-    o += [f"  const float {dst} = {expr};" for dst, expr in lines_c2r]
+          "template <typename T>",
+          "__device__ __forceinline__ void ifft48_c2r(const T (&re)[25], const T (&im)[25], T (&x)[48]) {"]
+    o += [f"  const T {dst} = {expr};" for dst, expr in lines_c2r]
     o += [f"  x[{n}] = {v};" for n, v in enumerate(out_c2r)]
     o += ["}", "",
           "// Half spectrum ore/oim[0..24] (forward sign, unscaled) of the real input re[0..47]: one 24-point complex transform of",
           "// x[2n] + i x[2n+1] and a recombination pass (see tools/gen_fft48.py build_r2c).  %d operations." % len(lines_r2c),
-          "__device__ __forceinline__ void fft48_r2c(const float (&re)[48], float (&ore)[25], float (&oim)[25]) {"]
-    o += [f"  const float {dst} = {expr};" for dst, expr in lines_r2c]
-    o += [f"  ore[{k}] = {r}; oim[{k}] = {i};" for k, (r, i) in enumerate(out_r2c)]
-    return "\n".join(o + ["}"]) + "\n"
+          "template <typename T>",
+          "__device__ __forceinline__ void fft48_r2c(const T (&re)[48], T (&ore)[25], T (&oim)[25]) {"]
+    o += [f"  const T {dst} = {expr};" for dst, expr in lines_r2c]
+    o += [f"  ore[{k}] = {r}; oim[{k}] = {'T(0.0f)' if i == '0.0f' else i};" for k, (r, i) in enumerate(out_r2c)]
+    o += ["}"]
+    for name, ls, outs, what in (("ifft48_even", lines_even, out_even, "even rows y = 2 r"), ("ifft48_odd", lines_odd, out_odd, "odd rows y = 2 r + 1")):
+        o += ["",
+              "// The %s (r = 0..23) of the unscaled 48-point inverse transform: one decimation-in-frequency step and a 24-point" % what,
+              "// inverse transform (see tools/gen_fft48.py build_half_inverse).  %d operations." % len(ls),
+              "template <typename T>",
+              "__device__ __forceinline__ void %s(const T (&re)[48], const T (&im)[48], T (&ore)[24], T (&oim)[24]) {" % name]
+        o += [f"  const T {dst} = {expr};" for dst, expr in ls]
+        o += [f"  ore[{k}] = {r}; oim[{k}] = {i};" for k, (r, i) in enumerate(outs)]
+        o += ["}"]
+    return "\n".join(o) + "\n"
 
 
 if __name__ == "__main__":
@@ -248,6 +285,13 @@ if __name__ == "__main__":
         errh = np.abs(goth[:, 0] + 1j * goth[:, 1] - wanth).max()
         print("r2c ops", len(lines_r2c), "max err vs numpy.fft.rfft:", errh, "scale", np.abs(wanth).max())
         ok = ok and errh < 1e-5 * np.abs(wanth).max()
+        zz = (rng.standard_normal(48) + 1j * rng.standard_normal(48)).astype(np.complex64).astype(np.complex128)
+        full = np.fft.ifft(zz) * 48
+        for par, ls, outs in ((0, lines_even, out_even), (1, lines_odd, out_odd)):
+            g = evaluate(zz, ls, [t for pair in outs for t in pair]).reshape(24, 2)
+            e = np.abs(g[:, 0] + 1j * g[:, 1] - full[par::2]).max()
+            print("half inverse parity", par, "ops", len(ls), "max err vs numpy.fft.ifft:", e, "scale", np.abs(full).max())
+            ok = ok and e < 1e-5 * np.abs(full).max()
         sys.exit(0 if ok else 1)
     import os
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "equiadapt_amd", "csrc", "fft48.inc")
