@@ -286,16 +286,25 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
 #ifdef EQA_FFT_CLOCK
 // Debug build: shader-cycle stamps of one block of the fused inverse (thread 0, a column-role thread): [0] loads issued and
 // returned, [1] column transform + LDS writes, [2] wait at the barrier, [3] row transform + epilogue, [4] window-sum pieces.
-__device__ unsigned long long g_fft_clock[16];  // [0..4] inverse, [8..12] forward
+__device__ unsigned long long g_fft_clock[32];  // [0..4] inverse, [8..12] forward, [16..21] pipeline producer, [24..29] consumer
 #define FFT_CLOCK_BEGIN() const bool clk_on = blockIdx.x == gridDim.x / 2 && threadIdx.x == 0; unsigned long long clk_t = __builtin_readcyclecounter()
 #define FFT_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); if (clk_on) g_fft_clock[i] = n_ - clk_t; clk_t = n_; } while (0)
 #define FFT_CLOCK_LOADS() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); FFT_CLOCK(0); } while (0)
 #define FFT_CLOCK_USE(v, i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(v) : "memory"); FFT_CLOCK(i); } while (0)
+// pipeline kernel: sums over the items of the middle block (thread 0 of the producers / of the consumers)
+#define PIPE_CLOCK_BEGIN(tid0) const bool pclk_on = blockIdx.x == gridDim.x / 2 && threadIdx.x == (tid0); unsigned long long pclk_t = __builtin_readcyclecounter(); unsigned long long pclk_s[6] = {0, 0, 0, 0, 0, 0}
+#define PIPE_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); pclk_s[i] += n_ - pclk_t; pclk_t = n_; } while (0)
+#define PIPE_CLOCK_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PIPE_CLOCK(i); } while (0)
+#define PIPE_CLOCK_END(base) do { if (pclk_on) for (int i_ = 0; i_ < 6; ++i_) g_fft_clock[(base) + i_] = pclk_s[i_]; } while (0)
 #else
 #define FFT_CLOCK_BEGIN() do { } while (0)
 #define FFT_CLOCK(i) do { } while (0)
 #define FFT_CLOCK_LOADS() do { } while (0)
 #define FFT_CLOCK_USE(v, i) do { } while (0)
+#define PIPE_CLOCK_BEGIN(tid0) do { } while (0)
+#define PIPE_CLOCK(i) do { } while (0)
+#define PIPE_CLOCK_WAIT(i) do { } while (0)
+#define PIPE_CLOCK_END(base) do { } while (0)
 #endif
 constexpr int kFusCh = 16;
 constexpr int kFusThreads = kFftN * kFusCh;                       // 768
@@ -659,7 +668,9 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
     unsigned v = blockIdx.x;
     EQA_PIPE_ISSUE(v);
     float* const q = lds + kx * kPitch + cl;
+    PIPE_CLOCK_BEGIN(0);  // producer stamps: [16] wait for the loads, [17] column transform + LDS writes, [18] wait at A, [19] issue, [20] wait at B
     for (; v < nwork; v += nblk) {
+      PIPE_CLOCK_WAIT(0);
       float ore[kFftN], oim[kFftN];
       fft48(im, re, oim, ore);
 #pragma unroll
@@ -667,18 +678,24 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
         q[(i * 2) * CH] = ore[i];
         q[(i * 2 + 1) * CH] = oim[i];
       }
+      PIPE_CLOCK(1);
       __syncthreads();                                   // A: the item's column transforms are in LDS
+      PIPE_CLOCK(2);
       EQA_PIPE_ISSUE(v + nblk);
       asm volatile("" ::: "memory");                     // the loads stay on this side of the barrier
       __builtin_amdgcn_sched_barrier(0);
+      PIPE_CLOCK(3);
       __syncthreads();                                   // B: the consumers have read their last row
+      PIPE_CLOCK(4);
     }
+    PIPE_CLOCK_END(16);
 #undef EQA_PIPE_ISSUE
     return;
   }
   // ------------------------------------------------------------------ consumers
   const int t = threadIdx.x - kPipeProd;
   const int r = t / CH, cl = t % CH;
+  PIPE_CLOCK_BEGIN(kPipeProd);  // consumer stamps: [24] wait at A, [25] passes before the last LDS read, [26] wait at B, [27] last pass + pieces
   for (unsigned v = blockIdx.x; v < nwork; v += nblk) {
     const unsigned work = work_of(v);
     const int grp = work % ngrp;
@@ -695,6 +712,7 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
 #pragma unroll
     for (int i = 0; i < NV; ++i) tot[i] = 0.0f;
     __syncthreads();                                     // A
+    PIPE_CLOCK(0);
 #pragma unroll 1
     for (int pass = 0; pass < kPipePasses; ++pass) {
       const int y = pass * kPassRows + r;
@@ -709,7 +727,11 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
           im[k] = q[k * kPitch + CH];
         }
       }
-      if (pass == kPipePasses - 1) __syncthreads();      // B: LDS may be overwritten (the values are in registers)
+      if (pass == kPipePasses - 1) {
+        PIPE_CLOCK(1);
+        __syncthreads();                                 // B: LDS may be overwritten (the values are in registers)
+        PIPE_CLOCK(2);
+      }
       if (valid) {
         re[0] += b;  // the bias rides on the row's DC bin: the (unnormalised) inverse adds re[0] to every output
         ifft48_c2r(re, im, ore);
@@ -750,7 +772,9 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
         for (int i = 0; i < NV; ++i) o[i] = tot[i];
       }
     }
+    PIPE_CLOCK(3);
   }
+  PIPE_CLOCK_END(24);
 }
 
 constexpr int kSplitThreads = 448;  // fft48_inv_split_kernel: 25 x 16 column threads, 22 x 16 row threads, 7 waves

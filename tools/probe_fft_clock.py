@@ -22,15 +22,21 @@ if not hasattr(raw, "eqa_debug_fft_clock"):
     sys.exit("this library was built without -DEQA_FFT_CLOCK")
 names = ["loads issued and returned", "column transform + LDS writes", "wait at the barrier", "row transform + epilogue",
          "window-sum pieces (2 barriers)"]
-out = (ctypes.c_ulonglong * 16)()
+out = (ctypes.c_ulonglong * 32)()
 for rep in range(3):
     for _ in range(5):
         fftconv.conv5x5(x, B, b, True, b, True, sums_k=5)
     torch.cuda.synchronize()
     assert raw.eqa_debug_fft_clock(out) == 0
     n = len(names)
-    tot = sum(out[:n])
+    tot = sum(out[:n]) or 1    # 0: the pipelined kernel ran instead (stamps [16..29])
     print("inverse: " + " | ".join(f"{n}: {v} ({100 * v / tot:.0f} %)" for n, v in zip(names, out[:n])), f"| total {tot} cycles")
     fn = ["loads issued and returned", "row transform + LDS writes", "wait at the barrier", "LDS reads + column transform", "stores issued"]
     ft = sum(out[8:13])
     print("forward: " + " | ".join(f"{n}: {v} ({100 * v / ft:.0f} %)" for n, v in zip(fn, out[8:13])), f"| total {ft} cycles")
+    pn = ["wait for the loads", "column transform + LDS writes", "wait at A", "issue next loads", "wait at B"]
+    cn = ["wait at A", "passes up to the last LDS read", "wait at B", "last pass + pieces"]
+    if sum(out[16:21]):
+        items = 64
+        print("pipeline producer (cycles per item): " + " | ".join(f"{n}: {v // items}" for n, v in zip(pn, out[16:21])), f"| total {sum(out[16:21]) // items}")
+        print("pipeline consumer (cycles per item): " + " | ".join(f"{n}: {v // items}" for n, v in zip(cn, out[24:28])), f"| total {sum(out[24:28]) // items}")
