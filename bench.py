@@ -20,6 +20,8 @@ barrier + synchronize pairs, max over ranks.
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   roofline      HBM roofline of the dominant hand-written HBM kernel (the canonicalizing transform),
                 from HIP events recorded inside the timed region;
+  roofline_dominant  the same object for the kernel the step spends most of its time in (the hand-written complex GEMM:
+                MFMA-bound), so that both the metric's kernel and the time-dominant one are priced;
   group_action  transform+invert only (random group index), the figure the "% HBM roofline" target is about;
   stages        the canonicalization network's kernels, each against the roofline that bounds it (HIP events inside the
                 timed region);
@@ -637,6 +639,22 @@ def main():
             "self_check": self_check,
         })
         line["stages"] = stage_table(ktimes, B)
+        # the kernel the step spends most of its time in, against ITS roofline (the `roofline` object above is the metric's
+        # HBM-bound transform kernel); traffic from the committed PMC profile when it is there
+        dom = max((k for k in line["stages"] if "frac" in line["stages"][k]), key=lambda k: line["stages"][k]["ms"], default=None)
+        if dom is not None:
+            d = dict(line["stages"][dom])
+            tr = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_canon_net.json")))
+                key = {"fft_gemm": "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
+                       "lift_conv": "lift_conv_mfma_kernel"}.get(dom)
+                tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
+            except (OSError, ValueError):
+                pass
+            line["roofline_dominant"] = {"stage": dom, "kernel": d.get("what"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
+                                         "unit": d["unit"], "frac": d["frac"], "avg_launch_ms": d["ms"], "share_of_step": d["ms"] / line["ms_per_step"],
+                                         "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r02/traffic_canon_net.json)"}
 
     if args.mode in ("all", "train"):
         line["train"] = leg_train_images(comm, args.train_steps, args.train_warmup, args.train_batch)

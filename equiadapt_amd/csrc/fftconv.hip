@@ -334,7 +334,13 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     const int gy = kFftO * ty + y;
     const int nvalid = min(win, W - kFftO * tx);  // uniform
     const float ib = in_bias ? in_bias[c] : 0.0f;
+#ifdef EQA_FFT_XGROUPED  // experiment (timing only, wrong values): x read as (img, channel group, y, x, 16) -- a tile row of a group is one 3 KB run
+    const float* p = x + ((((img * ngrp + grp) * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * kFusCh) + cl;
+    const int xstep = kFusCh;
+#else
     const float* p = x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
+    const int xstep = C;
+#endif
     const bool row_in = gy < H && y < win;
     float re[kFftN], ore[kFftH], oim[kFftH];
     if (nvalid == kFftN && !in_bias && !in_relu) {  // uniform: a full-width tile of a plain map (the headline case) needs no per-pixel work
@@ -344,10 +350,10 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
         const unsigned voff = (unsigned)((size_t)(p - x) * 4);
 #pragma unroll
-        for (int j = 0; j < kFftN; ++j) re[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, (unsigned)(j * C * 4), 0));
+        for (int j = 0; j < kFftN; ++j) re[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, voff, (unsigned)(j * xstep * 4), 0));
       } else {
 #pragma unroll
-        for (int j = 0; j < kFftN; ++j) re[j] = p[(size_t)j * C];
+        for (int j = 0; j < kFftN; ++j) re[j] = p[(size_t)j * xstep];
       }
       if (!row_in) {
 #pragma unroll
