@@ -314,7 +314,7 @@ constexpr int kFusLds = kFftH * kFusKxPitch;                      // 38,800 floa
 __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                                       const float* __restrict__ in_bias, int in_relu, int H, int W,
                                                                       int C, int TY, int TX, size_t M, unsigned nwork, int win,
-                                                                      unsigned x_bytes, unsigned v_bytes) {
+                                                                      unsigned x_bytes, unsigned v_bytes, int x_grouped) {
   extern __shared__ float lds[];
   FFT_CLOCK_BEGIN();  // forward stamps: [8] loads, [9] row transform + LDS writes, [10] barrier, [11] LDS reads + column transform, [12] stores issued
   // XCD-aware order: consecutive work items (the channel groups of one tile) on one XCD
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     const int gy = kFftO * ty + y;
     const int nvalid = min(win, W - kFftO * tx);  // uniform
     const float ib = in_bias ? in_bias[c] : 0.0f;
-#ifdef EQA_FFT_XGROUPED  // experiment (timing only, wrong values): x read as (img, channel group, y, x, 16) -- a tile row of a group is one 3 KB run
-    const float* p = x + ((((img * ngrp + grp) * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * kFusCh) + cl;
-    const int xstep = kFusCh;
-#else
-    const float* p = x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
-    const int xstep = C;
-#endif
+    // x_grouped: the map is stored (img, channel group of 16, y, x, 16) -- a tile row of this block's group is one 3 KB run, and
+    // the two 64-byte halves of a cache line are asked for by consecutive loads of the same lanes.  Channels-last, the other half
+    // of every line belongs to the neighbouring channel group, i.e. to another block: every line was requested twice
+    // (TCP_TCC_READ_REQ 37.7 M for 18.4 M lines, profiles/r02/pmc_memory_path.md).
+    const float* p = x_grouped ? x + ((((img * ngrp + grp) * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * kFusCh) + cl
+                               : x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
+    const int xstep = x_grouped ? kFusCh : C;
     const bool row_in = gy < H && y < win;
     float re[kFftN], ore[kFftH], oim[kFftH];
     if (nvalid == kFftN && !in_bias && !in_relu) {  // uniform: a full-width tile of a plain map (the headline case) needs no per-pixel work
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
     } else {
 #pragma unroll
       for (int j = 0; j < kFftN; ++j) {
-        float v = p[(size_t)min(j, nvalid - 1) * C] + ib;
+        float v = p[(size_t)min(j, nvalid - 1) * xstep] + ib;
         v = in_relu ? fmaxf(v, 0.0f) : v;
         re[j] = (row_in && j < nvalid) ? v : 0.0f;
       }
@@ -1263,7 +1263,7 @@ int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int cols, int C) {
 }
 
 static int fft_forward_impl(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                            int TY, int TX, int win, hipStream_t st) {
+                            int TY, int TX, int win, hipStream_t st, int x_grouped = 0) {
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
@@ -1275,11 +1275,12 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
       const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
       hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
                          W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
-                         vb <= 0xfffffff0ULL ? (unsigned)vb : 0u);
+                         vb <= 0xfffffff0ULL ? (unsigned)vb : 0u, x_grouped);
       return launch_status();
     }
     (void)hipGetLastError();
   }
+  if (x_grouped) return EQA_ERR_UNSUPPORTED;  // only the fused kernel reads the grouped layout
   const unsigned cb = (C + kThreads - 1) / kThreads;
   const int chunk = fft_chunk_images(nimg, H, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
@@ -1298,6 +1299,20 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
   if (nimg == 0) return EQA_OK;
   return fft_forward_impl(x, T, V, in_bias, in_relu, nimg, H, W, C, (int)eqa_fft48k5_tiles(H), (int)eqa_fft48k5_tiles(W), kFftN,
                           (hipStream_t)stream);
+}
+
+int eqa_fft48k5_input_grouped_supported(int C) {
+  static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
+  return C > 0 && C % kFusCh == 0 && !two_pass;
+}
+
+int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                              void* stream) {
+  if (!x || !T || !V || !fft_dims_ok(nimg, H, W, C)) return EQA_ERR_INVALID_ARG;
+  if (!eqa_fft48k5_input_grouped_supported(C)) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;
+  return fft_forward_impl(x, T, V, in_bias, in_relu, nimg, H, W, C, (int)eqa_fft48k5_tiles(H), (int)eqa_fft48k5_tiles(W), kFftN,
+                          (hipStream_t)stream, 1);
 }
 
 int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream) {

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
                                                                     float* __restrict__ y, int H, int W, int Cin, int R,
                                                                     int OH, int OW, int Cout, unsigned tiles_per_row,
                                                                     unsigned ntiles, size_t x_numel, size_t y_numel, unsigned nslices,
-                                                                    unsigned nstreams) {
+                                                                    unsigned nstreams, int grouped) {
   using Stage = LiftStage<KH>;
   __shared__ float lds_all[kThreads / 64][2][Stage::kFloats + 4];
   __shared__ float lds_tr_all[kThreads / 64][32 * kLiftTrPitch];
@@ -296,8 +296,13 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   epi.tr_w = lds_tr_all[wave] + col * kLiftTrPitch + 4 * h;
   epi.tr_r = lds_tr_all[wave] + (lane >> 4) * kLiftTrPitch + 4 * (lane & 15);
   epi.lo = relu ? 0 : (int)0x80000000;
-  epi.out_voff = ((unsigned)(lane >> 4) * Cout + slice * 64 + 4 * (lane & 15)) * 4u;
-  epi.row4 = 4u * Cout * 4u;
+  // grouped: the output goes out as (img, channel group of 16, y, x, 16) -- what the FFT convolution's input transform reads in
+  // whole cache lines.  Same store instruction: a lane's 16 bytes are 4 channels of one pixel; the four 16-lane pixel groups of
+  // an instruction now write four consecutive pixels of each of the slice's four channel groups (4 runs of 256 bytes, as before).
+  const unsigned plane16 = (unsigned)OH * (unsigned)OW * 16u;  // floats of one (image, channel group) plane
+  epi.out_voff = grouped ? ((slice * 4 + ((lane & 15) >> 2)) * plane16 + (unsigned)(lane >> 4) * 16u + 4 * (lane & 3)) * 4u
+                         : ((unsigned)(lane >> 4) * Cout + slice * 64 + 4 * (lane & 15)) * 4u;
+  epi.row4 = grouped ? 4u * 16u * 4u : 4u * Cout * 4u;
   epi.lane = lane;
   const int n_el = 31 * Cin + R;
   const int a_off = Cin * col + (R - 8) * h;  // this lane's first element inside a staged row
@@ -322,6 +327,8 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   auto out_of = [&](const LiftPos& p, int& cols_left) -> __amdgpu_buffer_rsrc_t {
     const unsigned ox0 = lift_ox0<MASKED>(p, OW);
     cols_left = OW - (int)ox0;
+    if (grouped)
+      return lift_out_rsrc(y, y_numel, (size_t)p.img * ((size_t)OH * OW * Cout) + ((size_t)p.oy * OW + ox0) * 16);
     return lift_out_rsrc(y, y_numel, (size_t)(p.img * (unsigned)OH + p.oy) * ((unsigned)OW * (unsigned)Cout) + ox0 * (unsigned)Cout);
   };
 
@@ -399,8 +406,8 @@ extern "C" {
 int eqa_debug_lift_hist(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_hist), sizeof(g_lift_hist)) == hipSuccess ? 0 : -1; }
 int eqa_debug_lift_clock(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_clock), sizeof(g_lift_clock)) == hipSuccess ? 0 : -1; }
 #endif
-int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
-                       int Cin, int KH, int KW, int Cout, void* stream) {
+static int lift_conv_launch(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
+                            int Cin, int KH, int KW, int Cout, void* stream, int grouped) {
   if (!x || !wpk || !y || nimg < 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout <= 0 || H < KH || W < KW) return EQA_ERR_INVALID_ARG;
   const int R = KW * Cin;
   if ((KH != 3 && KH != 5) || R < 9 || R > 15 || (Cout % 64) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;  // R <= 15: the bias slot
@@ -418,7 +425,7 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
   hipStream_t st = (hipStream_t)stream;
 #define EQA_LIFT_LAUNCH(KH_, MASKED_)                                                                                      \
   hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
-                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams)
+                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped)
   if (KH == 5) {
     if (OW < 32) EQA_LIFT_LAUNCH(5, true); else EQA_LIFT_LAUNCH(5, false);
   } else {
@@ -426,6 +433,17 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
   }
 #undef EQA_LIFT_LAUNCH
   return launch_status();
+}
+
+int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
+                       int Cin, int KH, int KW, int Cout, void* stream) {
+  return lift_conv_launch(x, wpk, bias, relu, y, nimg, H, W, Cin, KH, KW, Cout, stream, 0);
+}
+
+int eqa_lift_conv_grouped(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
+                          int Cin, int KH, int KW, int Cout, void* stream) {
+  if ((size_t)(H - KH + 1) * (W - KW + 1) * Cout * 4 > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;  // per-image plane offsets are 32-bit
+  return lift_conv_launch(x, wpk, bias, relu, y, nimg, H, W, Cin, KH, KW, Cout, stream, 1);
 }
 
 }  // extern "C"

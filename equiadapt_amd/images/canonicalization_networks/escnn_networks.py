@@ -384,6 +384,8 @@ class ESCNNEquivariantNetwork(nn.Module):
                 if last_before_tail:
                     return conv_then_group_pool(h, convs[-1])
                 continue
+            if isinstance(h, fftconv.GroupedMap):   # written for an FFT layer that did not take it after all
+                h = h.to_channels_last()
             use_wino = is_5x5 and winograd.applicable(h, bank.shape[1], bank.shape[0])
             if use_wino:
                 # 5x5 regular->regular layer: Winograd F(m x m, 5x5), m = 4 where the size allows.  The previous layer's
@@ -411,7 +413,15 @@ class ESCNNEquivariantNetwork(nn.Module):
             k = conv.kernel_size
             if (nhwc and conv.lifting and conv.stride == 1 and conv.padding == 0 and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
                     and ops.lift_conv_supported(bank.shape[1], k, k, bank.shape[0])):
-                # lifting layer (RGB -> regular fields): hand-written fp32-MFMA implicit GEMM, bias + ReLU in its epilogue
+                # lifting layer (RGB -> regular fields): hand-written fp32-MFMA implicit GEMM, bias + ReLU in its epilogue.
+                # If the next layer is an FFT-convolved 5x5 layer, the map goes out channel-group-major, the layout that
+                # layer's input transform reads in whole cache lines (it is consumed by nothing else).
+                nxt = convs[i + 1] if i + 1 < len(convs) - 1 else None
+                out_shape = (h.shape[0], bank.shape[0], h.shape[2] - k + 1, h.shape[3] - k + 1)
+                if (nxt is not None and not nxt.lifting and nxt.kernel_size == 5 and nxt.stride == 1 and nxt.padding == 0
+                        and fftconv.grouped_applicable(out_shape, bank.shape[0], bank.shape[0], h.device)):
+                    h = fftconv.GroupedMap(ops.lift_conv_grouped(h, self._lift_weights(conv, bank), bias, True, k, k))
+                    continue
                 h = ops.lift_conv_nhwc(h, self._lift_weights(conv, bank), bias, True, k, k)
                 if last_before_tail:
                     return conv_then_group_pool(h, convs[-1])

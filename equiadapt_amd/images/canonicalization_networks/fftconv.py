@@ -90,10 +90,44 @@ def tiles(n: int) -> int:
     return 0 if n <= 4 else (n - 4 + OUT - 1) // OUT
 
 
+class GroupedMap:
+    """An activation map in the channel-group-major layout (nimg, C/16, H, W, 16) written by `ops.lift_conv_grouped` and read by
+    `conv5x5` (eqa_fft48k5_input_grouped): `.shape` is the logical (nimg, C, H, W)."""
+
+    def __init__(self, data: torch.Tensor):
+        assert data.dim() == 5 and data.shape[-1] == 16 and data.is_contiguous()
+        self.data = data
+        self.shape = torch.Size((data.shape[0], data.shape[1] * 16, data.shape[2], data.shape[3]))
+        self.device, self.dtype, self.is_cuda = data.device, data.dtype, data.is_cuda
+
+    def data_ptr(self) -> int:
+        return self.data.data_ptr()
+
+    def to_channels_last(self) -> torch.Tensor:
+        """The same map as an ordinary channels-last (nimg, C, H, W) tensor (a copy)."""
+        n, g, h, w, _ = self.data.shape
+        return self.data.permute(0, 1, 4, 2, 3).reshape(n, g * 16, h, w).contiguous(memory_format=torch.channels_last)
+
+
+def grouped_applicable(shape, cin: int, cout: int, device, max_waste: float = 1.12) -> bool:
+    """Would `conv5x5` take a (nimg, cin, H, W) fp32 map of this shape on `device` through the FFT path AND read it in the
+    grouped layout?  (Decided before the producing layer runs, so that it can write that layout.)"""
+    if not (ENABLED and device.type == "cuda" and len(shape) == 4 and shape[1] == cin and cin % 16 == 0):
+        return False
+    if os.environ.get("EQA_FFT_GROUPED", "1") == "0" or not _lib.load().eqa_fft48k5_input_grouped_supported(cin):
+        return False
+    H, W = shape[-2:]
+    if H < 16 or W < 16 or shape[0] * tiles(H) * tiles(W) < MIN_TILES:
+        return False
+    return tiles(H) * OUT <= max_waste * (H - 4) and tiles(W) * OUT <= max_waste * (W - 4)
+
+
 def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) -> bool:
     """Channels-last fp32 device tensor, 5x5 kernel, enough tiles to amortise the filter spectra (``MIN_TILES``), and tiles
     that fit the output to within ``max_waste`` (the FFT work is per tile: 88 outputs per axis = 2 tiles exactly, 84 would
     waste 5 %, 50 would waste 43 % -> Winograd)."""
+    if isinstance(x, GroupedMap):
+        return grouped_applicable(x.shape, cin, cout, x.device, max_waste)
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         return False
     H, W = x.shape[-2:]
@@ -178,8 +212,8 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     p_bias = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(dev):
         with _timed("fft_input"):
-            _lib.check(lib.eqa_fft48k5_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st),
-                       "eqa_fft48k5_input")
+            fn = lib.eqa_fft48k5_input_grouped if isinstance(x, GroupedMap) else lib.eqa_fft48k5_input
+            _lib.check(fn(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st), "eqa_fft48k5_input")
         del T
         with _timed("fft_gemm"):
             Mo = contract(V, B, M)

@@ -525,6 +525,23 @@ def lift_conv_nhwc(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def lift_conv_grouped(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int) -> torch.Tensor:
+    """`lift_conv_nhwc` with the output in the channel-group-major layout (B, Cout/16, H-kh+1, W-kw+1, 16) that the FFT
+    convolution's input transform reads in whole cache lines (eqa_lift_conv_grouped)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("lift_conv_grouped expects a channels-last fp32 tensor on the device")
+    wpk = _need(wpk, "wpk")
+    bias, p_bias = _opt(bias, "bias", torch.float32)
+    B, Cin, H, W = x.shape
+    Cout = wpk.shape[2]
+    y = torch.empty((B, Cout // 16, H - kh + 1, W - kw + 1, 16), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("lift_conv"):
+        st = lib.eqa_lift_conv_grouped(x.data_ptr(), wpk.data_ptr(), p_bias, int(relu), y.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
+    _lib.check(st, "eqa_lift_conv_grouped")
+    return y
+
+
 def lift_conv_wgrad_supported(x: torch.Tensor, cout: int, kh: int, kw: int) -> bool:
     """Shapes eqa_lift_conv_wgrad_nhwc takes (others: the framework's convolution-weight-gradient)."""
     B, Cin, H, W = x.shape

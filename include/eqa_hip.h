@@ -280,6 +280,12 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
  */
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream);
+/* The same convolution with the output in the channel-group-major layout (nimg, Cout/16, OH, OW, 16) that
+ * eqa_fft48k5_input_grouped reads (inference: the lifting layer feeding an FFT-convolved layer).  Channels-last, the 64 bytes
+ * a 16-channel block of the input transform needs from a pixel are half a cache line whose other half belongs to another
+ * block; grouped, a tile row of a channel group is one contiguous run.  Same arguments and return codes. */
+int eqa_lift_conv_grouped(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin,
+                          int KH, int KW, int Cout, void* stream);
 
 /*
  * Training: filter gradient of the same lifting convolution (the reference: autograd through e2cnn's R2Conv,
@@ -377,6 +383,11 @@ int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                       void* stream);
+/* eqa_fft48k5_input on a map stored (nimg, C/16, H, W, 16) (eqa_lift_conv_grouped); C % 16 == 0, fused kernel only
+ * (eqa_fft48k5_input_grouped_supported(C) == 1), else EQA_ERR_UNSUPPORTED. */
+int eqa_fft48k5_input_grouped_supported(int C);
+int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
+                              void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
 /* Training, filter gradient in the frequency domain (the reference gets it from autograd through R2Conv's conv2d):

@@ -1449,3 +1449,32 @@ def test_graphed_canonicalizer_matches_eager(dev):
     with torch.no_grad():
         y_e = can4(pc)
     assert inv is None and torch.equal(y, y_e) and torch.equal(R, can4.canonicalization_info_dict["group_element"]["rotation"])
+
+
+def test_grouped_activation_layout_between_lift_and_fft(dev):
+    """The lifting convolution's channel-group-major output (eqa_lift_conv_grouped) holds exactly the channels-last result, and the
+    FFT convolution reads it (eqa_fft48k5_input_grouped) to exactly the same spectra / output -- the layout changes which bytes sit
+    next to each other, not one arithmetic operation.  Also a width whose last tile is partial (general load path)."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(41)
+    for (B, H, W) in ((8, 52, 96), (8, 64, 70)):
+        x = torch.randn(B, 3, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+        bank = torch.randn(64, 3, 5, 5, device=dev) / 8
+        bias = torch.randn(64, device=dev)
+        wpk = ops.pack_lift_weights(bank)
+        y = ops.lift_conv_nhwc(x, wpk, bias, True, 5, 5)
+        g = fftconv.GroupedMap(ops.lift_conv_grouped(x, wpk, bias, True, 5, 5))
+        assert g.shape == y.shape
+        assert torch.equal(g.to_channels_last(), y)
+        w2 = torch.randn(64, 64, 5, 5, device=dev) / 40
+        b2 = torch.randn(64, device=dev)
+        Bf = fftconv.spectra_for(w2)
+        for in_bias in (None, b2):
+            o1 = fftconv.conv5x5(y, Bf, b2, True, in_bias, in_bias is not None)
+            o2 = fftconv.conv5x5(g, Bf, b2, True, in_bias, in_bias is not None)
+            assert torch.equal(o1, o2)
+        s1 = fftconv.conv5x5(y, Bf, b2, True, sums_k=5)
+        s2 = fftconv.conv5x5(g, Bf, b2, True, sums_k=5)
+        assert torch.equal(s1, s2)
