@@ -320,7 +320,11 @@ def leg_train_images(comm: Comm, steps: int, warmup: int, batch: int):
     dev = comm.dev
     can = build_canonicalizer(dev).train()
     torch.manual_seed(0)
+    # the prediction network is unmodified torch; it is merely RUN channels-last (MIOpen's NHWC convolutions: ResNet-50 forward +
+    # backward at B=128 59.6 -> 50.1 ms on this chip; cudnn.benchmark makes no difference).  EQA_BENCH_PRED_NCHW=1: as constructed
     pred = ResNet50(num_classes=10)
+    if os.environ.get("EQA_BENCH_PRED_NCHW", "0") != "1":
+        pred = pred.to(memory_format=torch.channels_last)
     model = tr.CanonicalizedClassifier(can, pred, tr.LossWeights(task_weight=1.0, prior_weight=100.0)).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
     ddp = tr.wrap_ddp(model, dev)
@@ -342,7 +346,7 @@ def leg_train_images(comm: Comm, steps: int, warmup: int, batch: int):
     assert loss == loss, "training loss is NaN"
     res = {"images_s": batch * comm.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
            "batch_per_gpu": batch, "n_gpus": comm.world,
-           "model": "GroupEquivariantImageCanonicalization(ESCNNEquivariantNetwork C8 32ch k5 L3) + ResNet50(10 classes), fp32",
+           "model": "GroupEquivariantImageCanonicalization(ESCNNEquivariantNetwork C8 32ch k5 L3) + ResNet50(10 classes, run channels-last), fp32",
            "optimizer": type(opt).__name__ + " (reference rule: resnet + non-mnist -> SGD 0.9 / wd 5e-4)",
            "loss": "1.0 * CE + 100.0 * prior", "parameters": n_params, "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.world > 1 else 0.0,
            "collective": "DDP bucketed all-reduce over RCCL (64 MB buckets), overlapped with backward" if comm.world > 1 else "none (1 rank)",
