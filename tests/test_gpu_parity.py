@@ -1089,7 +1089,10 @@ def test_fft48_convolution_matches_conv2d(dev):
     cases = [(2, 8, 12, 92, 92), (3, 16, 8, 60, 97), (1, 4, 4, 48, 48), (2, 4, 8, 20, 33), (1, 64, 64, 92, 92), (2, 12, 4, 137, 49),
              # channel counts that are multiples of 16 take the fused kernels: ragged last tiles, the right border columns
              # of the window sums inside one tile (97), split over two (49, 50, 51) and alone in the last tile (52)
-             (2, 8, 16, 137, 49), (1, 16, 32, 60, 97), (1, 8, 16, 53, 50), (1, 16, 16, 48, 51), (1, 8, 16, 50, 52), (1, 8, 16, 30, 140)]
+             (2, 8, 16, 137, 49), (1, 16, 32, 60, 97), (1, 8, 16, 53, 50), (1, 16, 16, 48, 51), (1, 8, 16, 50, 52), (1, 8, 16, 30, 140),
+             # 100 tiles x 3 channel groups = 300 work items: the persistent inverse pipeline's blocks take one or two items, and
+             # the XCD split has a remainder (300 = 8 x 37 + 4)
+             (25, 16, 48, 92, 92)]
     for (B, Cin, Cout, H, W) in cases:
         x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, 5, 5, device=dev) / (5 * Cin ** 0.5)
