@@ -783,147 +783,6 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
   PIPE_CLOCK_END(24);
 }
 
-constexpr int kSplitThreads = 448;  // fft48_inv_split_kernel: 25 x 16 column threads, 22 x 16 row threads, 7 waves
-
-// The same with a tile's 44 output rows split by parity over two blocks (one decimation-in-frequency step: the even rows are a
-// 24-point inverse transform of X_k + X_{k+24}, the odd rows one of (X_k - X_{k+24}) e^{+2 pi i k/48}).  The intermediate of a
-// block is 22 rows instead of 44 -- 72 KB of LDS and 7 waves, so TWO blocks fit a CU and one block's loads and barrier waits
-// overlap the other's arithmetic; the price is that both blocks read all 48 frequencies of their columns (the second read comes
-// from the XCD's L2: the two parities are consecutive work items) and 847 instead of 819 operations per column.
-template <int NB, int CH>
-__global__ __launch_bounds__(kSplitThreads, 4) void fft48_inv_split_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
-                                                                      int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
-                                                                      int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
-  extern __shared__ float lds[];
-  FFT_CLOCK_BEGIN();
-  constexpr int kRows = kFftO / 2;             // output rows of one parity
-  constexpr int kPitch = kRows * 2 * CH + CH;  // floats per kx slab
-  const unsigned bid = blockIdx.x;
-  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd, xcd = bid % kXcd;
-  const unsigned work = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kXcd;
-  const int parity = work & 1;
-  const int ngrp = C / CH;
-  const int grp = (work >> 1) % ngrp;
-  const size_t m = (work >> 1) / ngrp;
-  const int tx = (int)(m % TX);
-  const int ty = (int)((m / TX) % TY);
-  const size_t img = m / ((size_t)TX * TY);
-  const int cl = threadIdx.x % CH;
-  const int c = grp * CH + cl;
-  if (threadIdx.x < kFftH * CH) {
-    const int kx = threadIdx.x / CH;
-#ifdef EQA_FFT_SAMETILE  // experiment: every block reads tile 0 (L2-resident) -- the kernel without its HBM wait
-    const size_t m_ld = 0;
-#else
-    const size_t m_ld = m;
-#endif
-    const float2* p = reinterpret_cast<const float2*>(Mo) + ((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c;
-    const size_t fpitch = (size_t)fft_fstep(kx) * M * C;
-    float re[kFftN], im[kFftN], ore[kFftN / 2], oim[kFftN / 2];
-    const bool edge = fft_edge(kx);
-    if (mo_bytes && !__any(edge)) {
-      // a wave without edge columns (5 of the 7): all its lanes step through the 48 frequencies of their column by the same
-      // 23 * M * C complex numbers -> buffer loads with that step as a SCALAR offset, no vector address arithmetic at all
-      // (mo_bytes = 0: the spectra do not fit a 32-bit offset, pointer arithmetic as in the edge waves)
-      const __amdgpu_buffer_rsrc_t mr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Mo), 0, mo_bytes, 0x00020000);
-      const unsigned voff = (unsigned)((((size_t)fft_f0(kx) * M + m_ld) * (size_t)C + c) * 8);
-      const unsigned step = (unsigned)(kFftInner * M * (size_t)C * 8);
-#pragma unroll
-      for (int ky = 0; ky < kFftN; ++ky) {
-        const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, voff, ky * step, 0));   // cached: the other parity's block reads the same lines
-        re[ky] = t[0];
-        im[ky] = t[1];
-      }
-    } else {
-      fft_load_column(p, fpitch, edge, re, im);
-    }
-    FFT_CLOCK_LOADS();
-    if (parity) ifft48_odd(re, im, ore, oim); else ifft48_even(re, im, ore, oim);
-    float* q = lds + kx * kPitch + cl;
-#pragma unroll
-    for (int i = 0; i < kRows; ++i) {  // rows 44..47 (i = 22, 23): the circular wrap-around
-      q[(i * 2) * CH] = ore[i];
-      q[(i * 2 + 1) * CH] = oim[i];
-    }
-  }
-  FFT_CLOCK(1);
-  __syncthreads();
-  FFT_CLOCK(2);
-  const int r = threadIdx.x / CH;
-  const int y = 2 * r + parity;
-  const int gy = kFftO * ty + y;
-  const bool valid = r < kRows && gy < OH;
-  constexpr int NV = 1 + 2 * NB;
-  float acc[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i] = 0.0f;
-  if (valid) {
-    const float* q = lds + (r * 2) * CH + cl;
-    float re[kFftH], im[kFftH], ore[kFftN];
-#pragma unroll
-    for (int k = 0; k < kFftH; ++k) {
-      re[k] = q[k * kPitch];
-      im[k] = q[k * kPitch + CH];
-    }
-    // the bias rides on the row's DC bin: the (unnormalised) inverse adds re[0] to every output
-    const float b = bias ? bias[c] : 0.0f;
-    re[0] += b;
-    ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
-    const int x0 = kFftO * tx;
-    const int ncols = min(kFftO, OW - x0);  // uniform
-    if constexpr (NB == 0) {
-      float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
-#pragma unroll
-      for (int j = 0; j < kFftO; ++j) {
-        if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
-      }
-    } else {
-      fft_row_pieces<NB>(ore, relu, ncols, tx == 0, OW - NB - x0, acc);
-    }
-  }
-  FFT_CLOCK(3);
-  if (NB > 0) {
-    // Window-sum pieces.  Segments (the order window_sums_nhwc_finalize_kernel expects): the NB top rows, the NB bottom rows,
-    // then ONE per tile row for its interior rows -- those are only ever needed as a sum, which the block forms here in a
-    // fixed order (LDS is free once every thread has read its row spectrum) instead of writing 44 pieces per tile column.
-    const int nseg = 2 * NB + 2 * TY;           // one interior piece per (tile row, parity)
-    const bool border = gy < NB || gy >= OH - NB;
-    if (valid && border) {
-      const int seg = gy < NB ? gy : NB + (gy - (OH - NB));
-      float* o = out + (((img * nseg + seg) * TX + tx) * (size_t)C + c) * NV;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) o[i] = acc[i];
-    }
-    // a wave holds 64 / CH consecutive rows of the same CH channels: those are summed by wavefront shuffles first, one LDS slot
-    // per wave instead of one per row (44 -> 11 terms in the serial sum below, a quarter of the LDS traffic)
-    constexpr int kRowsPerWave = 64 / CH;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      float v = (valid && !border) ? acc[i] : 0.0f;
-#pragma unroll
-      for (int o = CH; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-      acc[i] = v;
-    }
-    __syncthreads();
-    const int wv = threadIdx.x >> 6;
-    constexpr int kWaves = (kRows * CH + 63) / 64;      // waves that hold output rows
-    if ((threadIdx.x & 63) < CH && wv < kWaves) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) lds[(wv * NV + i) * CH + cl] = acc[i];
-    }
-    __syncthreads();
-    if (threadIdx.x < NV * CH) {
-      const int i = threadIdx.x / CH;
-      float t = 0.0f;
-#pragma unroll
-      for (int r = 0; r < kWaves; ++r) t += lds[(r * NV + i) * CH + cl];
-      // tile rows made of border rows only (OH <= 2 NB + ...) contribute an all-zero piece: harmless
-      out[(((img * nseg + 2 * NB + 2 * ty + parity) * TX + tx) * (size_t)C + c) * NV + i] = t;
-    }
-  }
-  FFT_CLOCK(4);
-}
-
 // Filter spectra for the batched GEMM: bank (Cout, Cin, 5, 5) -> B (F, 2 Cin, 2 Cout), B[f] = [[Br, Bi], [-Bi, Br]] with
 // Br + i Bi = conj(FFT48x48(filter))[ky][kx] / 48^2 = sum_{u,v} w[u][v] (cos t + i sin t) / 2304, t = 2 pi (ky u + kx v) / 48.
 // Rows follow the rows of V ([Re x G | Im x G] per group of G input channels), columns the rows of Mo (interleaved complex).
@@ -1140,23 +999,6 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   *fused = 0;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
-  // NB > 0 (window-sum pieces): the tile rows split by parity over two co-resident blocks (EQA_FFT_INV_SPLIT=0: one block per
-  // tile); the pieces buffer has OH segment slots per image, the split needs 2 NB + 2 TY
-  static const bool split_on = []() { const char* e = getenv("EQA_FFT_INV_SPLIT"); return e && e[0] == '1'; }();
-  if (NB > 0 && split_on && kInvCh == 16 && C % kInvCh == 0 && 2 * M * (C / kInvCh) <= 0x7fffffffULL && !two_pass && 2 * NB + 2 * TY <= OH) {
-    constexpr int lds_bytes = kFftH * ((kFftO / 2) * 2 * kInvCh + kInvCh) * (int)sizeof(float);
-    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_split_kernel<NB, kInvCh>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-    if (lds_ok) {
-      const unsigned nwork = (unsigned)(2 * M * (C / kInvCh));
-      const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
-      hipLaunchKernelGGL((fft48_inv_split_kernel<NB, kInvCh>), dim3(nwork), dim3(kSplitThreads), lds_bytes, st, Mo, bias, relu, out, OH,
-                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
-      *fused = 2;
-      return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
-    }
-    (void)hipGetLastError();
-  }
   // persistent producer / consumer pipeline (EQA_FFT_INV_PIPE=0: one block per work item); with window-sum pieces the buffer
   // must hold 2 NB + 6 TY segments per image (it has OH)
   static const bool pipe_on = []() { const char* e = getenv("EQA_FFT_INV_PIPE"); return !(e && e[0] == '0'); }();
@@ -1353,7 +1195,7 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   if (rc != EQA_OK) return rc;
   // fused path: 2 nb border rows + one segment per tile row, each in `sub` = TX pieces; two-pass path: one per output row
   const int sub = fused ? (OW + kFftO - 1) / kFftO : 1;
-  // interior pieces per tile row: 1 (fused), 2 (split: one per parity), 6 (pipeline: one per consumer wave)
+  // interior pieces per tile row: 1 (one block per item), 5 (pipeline: one per consumer wave)
   const int per_row = fused == 3 ? kPipeCons / 64 : fused;
   const int nseg = fused ? 2 * nb + per_row * ((OH + kFftO - 1) / kFftO) : OH;
   return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, nseg * sub, st, sub);

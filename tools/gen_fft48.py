@@ -254,7 +254,10 @@ def render():
     o += [f"  const T {dst} = {expr};" for dst, expr in lines_r2c]
     o += [f"  ore[{k}] = {r}; oim[{k}] = {'T(0.0f)' if i == '0.0f' else i};" for k, (r, i) in enumerate(out_r2c)]
     o += ["}"]
-    for name, ls, outs, what in (("ifft48_even", lines_even, out_even, "even rows y = 2 r"), ("ifft48_odd", lines_odd, out_odd, "odd rows y = 2 r + 1")):
+    # the half-length inverse transforms were used by an experiment (a tile's rows split by parity over two co-resident blocks:
+    # slower); `--half` emits them again
+    halves = (("ifft48_even", lines_even, out_even, "even rows y = 2 r"), ("ifft48_odd", lines_odd, out_odd, "odd rows y = 2 r + 1"))
+    for name, ls, outs, what in (halves if "--half" in sys.argv else ()):
         o += ["",
               "// The %s (r = 0..23) of the unscaled 48-point inverse transform: one decimation-in-frequency step and a 24-point" % what,
               "// inverse transform (see tools/gen_fft48.py build_half_inverse).  %d operations." % len(ls),
