@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(kThreads) void mask_action_u8_kernel(const uint8_t*
                                                                  uint8_t* __restrict__ out, const int32_t* __restrict__ eidx,
                                                                  const float* __restrict__ rtheta, const int32_t* __restrict__ flags, int E,
                                                                  int H, int W) {
-  __shared__ __attribute__((aligned(16))) uint8_t s_src[kNearBox * kU8Pitch];
+  __shared__ __attribute__((aligned(16))) uint8_t s_src[kNearBox * kU8Pitch + 8];  // + 8: the fifth dword of a row run at the very end
   const int p = blockIdx.z;
   const int i0 = blockIdx.y * kNearTile, j0 = blockIdx.x * kNearTile;
   const int e = min(max(eidx[p], 0), E - 1);
@@ -1053,17 +1053,72 @@ __global__ __launch_bounds__(kThreads) void mask_action_u8_kernel(const uint8_t*
   const int jb = j0 + (threadIdx.x & 3) * 16;
   if (i >= H || jb >= W) return;
   uint32_t w4[4] = {0u, 0u, 0u, 0u};
+  // Axis-aligned elements (every element of C4 / D4: the config-5 case) move a run of 16 output pixels onto 16 consecutive
+  // source pixels of one row or one column.  The run's two END pixels go through the reference's arithmetic; if they land 15
+  // apart along one axis, on the same line of the other, both inside the frame and the staged box, and their unrounded
+  // coordinates are within 0.25 of the integers they round to, then the 14 pixels between them round to the integers between
+  // (the coordinate is affine in the pixel index up to ~1e-4 of fp32 noise at |x| <= 2^15: an interior pixel could only round
+  // elsewhere from within that noise of a .5 tie, and a quarter pixel is far from it) -- bit-identical to evaluating all 16,
+  // at 2 coordinate evaluations instead of 16 (the kernel was bound by its ~28 vector instructions per pixel: 1.9 TB/s).
+  bool fast = false;
+  if (staged && jb + 15 < W) {
+    auto raw_xy = [&](int ii, int jj, float& fx, float& fy) {
+      const float yb = ((float)ii + 0.5f) - 0.5f * (float)H;
+      const float xb = ((float)jj + 0.5f) - 0.5f * (float)W;
+      const float gx = xb * t0 + yb * t1 + t2;
+      const float gy = xb * t3 + yb * t4 + t5;
+      fx = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+      fy = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+    };
+    float fxa, fya, fxb, fyb;
+    raw_xy(i, jb, fxa, fya);
+    raw_xy(i, jb + 15, fxb, fyb);
+    const float xra = rintf(fxa), yra = rintf(fya), xrb = rintf(fxb), yrb = rintf(fyb);
+    const bool inside = fminf(xra, xrb) >= 0.0f && fmaxf(xra, xrb) <= (float)(W - 1) && fminf(yra, yrb) >= 0.0f && fmaxf(yra, yrb) <= (float)(H - 1);
+    const bool snug = fabsf(fxa - xra) < 0.25f && fabsf(fya - yra) < 0.25f && fabsf(fxb - xrb) < 0.25f && fabsf(fyb - yrb) < 0.25f;
+    const int sxa = flip ? (W - 1 - (int)xra) : (int)xra, sxb = flip ? (W - 1 - (int)xrb) : (int)xrb;
+    const int sya = (int)yra, syb = (int)yrb;
+    const int ddx = sxb - sxa, ddy = syb - sya;
+    const bool line = (ddy == 0 && (ddx == 15 || ddx == -15)) || (ddx == 0 && (ddy == 15 || ddy == -15));
+    const int lxa = sxa - sx0, lya = sya - sy0, lxb = sxb - sx0, lyb = syb - sy0;
+    const bool boxed = (unsigned)lxa < (unsigned)bw && (unsigned)lya < (unsigned)bh && (unsigned)lxb < (unsigned)bw && (unsigned)lyb < (unsigned)bh;
+    fast = inside && snug && line && boxed;
+    if (fast) {
+      if (ddy == 0) {
+        // along a source row: the 16 bytes [lo, lo + 16) come out of 5 aligned dword reads and 4 funnel shifts; a run that walks
+        // the row backwards (flips, 180 degrees) is the same bytes in reverse order
+        const int lo = lya * kU8Pitch + min(lxa, lxb);
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(s_src + (lo & ~3));
+        const uint32_t sh = (uint32_t)(lo & 3);
+        const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4];
+        const uint32_t f0 = __builtin_amdgcn_alignbyte(d1, d0, sh), f1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        const uint32_t f2 = __builtin_amdgcn_alignbyte(d3, d2, sh), f3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        const bool rev = ddx < 0;
+        w4[0] = rev ? __builtin_bswap32(f3) : f0;
+        w4[1] = rev ? __builtin_bswap32(f2) : f1;
+        w4[2] = rev ? __builtin_bswap32(f1) : f2;
+        w4[3] = rev ? __builtin_bswap32(f0) : f3;
+      } else {
+        const int stride = (ddy / 15) * kU8Pitch;
+        const uint8_t* sp = s_src + lya * kU8Pitch + lxa;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    float xr, yr;
-    frame_xy(i, jb + k, xr, yr);
-    uint32_t val = 0u;
-    if (xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1)) {
-      const int sx = flip ? (W - 1 - (int)xr) : (int)xr, sy = (int)yr;
-      const int lx = sx - sx0, ly = sy - sy0;
-      val = (staged && (unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) ? s_src[ly * kU8Pitch + lx] : src[(size_t)sy * W + sx];
+        for (int k = 0; k < 16; ++k) w4[k >> 2] |= (uint32_t)sp[k * stride] << (8 * (k & 3));
+      }
     }
-    w4[k >> 2] |= val << (8 * (k & 3));
+  }
+  if (!fast) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      float xr, yr;
+      frame_xy(i, jb + k, xr, yr);
+      uint32_t val = 0u;
+      if (xr >= 0.0f && xr <= (float)(W - 1) && yr >= 0.0f && yr <= (float)(H - 1)) {
+        const int sx = flip ? (W - 1 - (int)xr) : (int)xr, sy = (int)yr;
+        const int lx = sx - sx0, ly = sy - sy0;
+        val = (staged && (unsigned)lx < (unsigned)bw && (unsigned)ly < (unsigned)bh) ? s_src[ly * kU8Pitch + lx] : src[(size_t)sy * W + sx];
+      }
+      w4[k >> 2] |= val << (8 * (k & 3));
+    }
   }
   uint8_t* o = out + (size_t)p * H * W + (size_t)i * W + jb;
   if (jb + 15 < W) {
