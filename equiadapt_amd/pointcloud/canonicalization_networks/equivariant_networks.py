@@ -171,7 +171,6 @@ class TailMean(torch.autograd.Function):
                                             part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
             out = part[:nblk * 12].view(B, nbx, 12).sum(1).div_(N).view(B, 4, 3)
         ctx.save_for_backward(pooled, W, stat, mask)
-        ctx.gammas = (g1.detach(), g2.detach(), g3.detach())
         return out
 
     @staticmethod
