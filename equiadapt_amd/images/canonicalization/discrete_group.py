@@ -33,6 +33,14 @@ from equiadapt_amd.images.utils import (
 )
 
 
+
+def _get(hyperparams: Any, name: str):
+    """Hyper-parameters by attribute (SimpleNamespace / dataclass / DictConfig, as the reference reads them) or by key (a plain
+    mapping: the reference's own tests build a DictConfig from one)."""
+    if isinstance(hyperparams, dict):
+        return hyperparams[name]
+    return getattr(hyperparams, name)
+
 class _CanonTransformFn(torch.autograd.Function):
     """y = crop(rotate(flip?(pad(x)), -rotation)).
 
@@ -73,7 +81,7 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
 
     def __init__(self, canonicalization_network: torch.nn.Module, canonicalization_hyperparams: Any, in_shape: tuple):
         super().__init__(canonicalization_network)
-        self.beta = canonicalization_hyperparams.beta
+        self.beta = _get(canonicalization_hyperparams, "beta")
         assert len(in_shape) == 3, "Input shape should be in the format (channels, height, width)"
         self.in_shape = tuple(int(s) for s in in_shape)
         is_grayscale = self.in_shape[0] == 1
@@ -83,11 +91,11 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
         self.crop = torch.nn.Identity() if is_grayscale else CenterCrop((self.in_shape[-2], self.in_shape[-1]))
         self.crop_canonization = (
             torch.nn.Identity() if is_grayscale else CenterCrop((
-                math.ceil(self.in_shape[-2] * canonicalization_hyperparams.input_crop_ratio),
-                math.ceil(self.in_shape[-1] * canonicalization_hyperparams.input_crop_ratio)))
+                math.ceil(self.in_shape[-2] * _get(canonicalization_hyperparams, "input_crop_ratio")),
+                math.ceil(self.in_shape[-1] * _get(canonicalization_hyperparams, "input_crop_ratio"))))
         )
         self.resize_canonization = (
-            torch.nn.Identity() if is_grayscale else Resize(size=_as_size(canonicalization_hyperparams.resize_shape))
+            torch.nn.Identity() if is_grayscale else Resize(size=_as_size(_get(canonicalization_hyperparams, "resize_shape")))
         )
         self._consts: Dict[str, torch.Tensor] = {}
 
@@ -273,19 +281,19 @@ class OptimizedGroupEquivariantImageCanonicalization(DiscreteGroupImageCanonical
 
     def __init__(self, canonicalization_network: torch.nn.Module, canonicalization_hyperparams: Any, in_shape: tuple):
         super().__init__(canonicalization_network, canonicalization_hyperparams, in_shape)
-        self.group_type = canonicalization_hyperparams.group_type
-        self.num_rotations = canonicalization_hyperparams.num_rotations
-        self.artifact_err_wt = canonicalization_hyperparams.artifact_err_wt
+        self.group_type = _get(canonicalization_hyperparams, "group_type")
+        self.num_rotations = _get(canonicalization_hyperparams, "num_rotations")
+        self.artifact_err_wt = _get(canonicalization_hyperparams, "artifact_err_wt")
         self.num_group = _num_group(self.group_type, self.num_rotations)
         self.out_vector_size = canonicalization_network.out_vector_size
-        size = canonicalization_hyperparams.resize_shape
+        size = _get(canonicalization_hyperparams, "resize_shape")
         self.group_augment_size = int(size)
         gray = self.in_shape[0] == 1
         self.group_augment_pad = 0 if gray else math.ceil(self.group_augment_size * 0.5)
         self.crop_group_augment = torch.nn.Identity() if gray else CenterCrop(self.group_augment_size)
         self.pad_group_augment = torch.nn.Identity() if gray else EdgePad(self.group_augment_pad)
         self.reference_vector = torch.nn.Parameter(
-            torch.randn(1, self.out_vector_size), requires_grad=canonicalization_hyperparams.learn_ref_vec)
+            torch.randn(1, self.out_vector_size), requires_grad=_get(canonicalization_hyperparams, "learn_ref_vec"))
         self.group_info_dict = {"num_rotations": self.num_rotations, "num_group": self.num_group}
 
     def group_augment(self, x: torch.Tensor) -> torch.Tensor:

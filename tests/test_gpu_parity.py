@@ -1481,3 +1481,26 @@ def test_grouped_activation_layout_between_lift_and_fft(dev):
         s1 = fftconv.conv5x5(y, Bf, b2, True, sums_k=5)
         s2 = fftconv.conv5x5(g, Bf, b2, True, sums_k=5)
         assert torch.equal(s1, s2)
+
+
+@pytest.mark.parametrize("induced_rep,num_channels", [("regular", 12), ("scalar", 3)])
+def test_reference_own_test_invert_canonicalization_induced_rep(dev, induced_rep, num_channels):
+    """The reference's own test of this path (tests/images/canonicalization/test_discrete_group.py:44-86) through the product: the
+    same constructor arguments (ESCNNEquivariantNetwork((3,64,64), 32, k=3, C4, 2 layers), crop 0.9, resize (32,32), beta 0.1,
+    hyper-parameters as a mapping like its DictConfig), one (1,3,64,64) image, then invert_canonicalization of a 12-channel
+    regular / 3-channel scalar map: the shape the reference asserts, and the values against the oracle for the element chosen."""
+    import equiadapt_amd as ea
+
+    torch.manual_seed(0)
+    net = ea.ESCNNEquivariantNetwork(in_shape=(3, 64, 64), out_channels=32, kernel_size=3, group_type="rotation", num_rotations=4,
+                                     num_layers=2)
+    hp = {"input_crop_ratio": 0.9, "resize_shape": (32, 32), "beta": 0.1}
+    dgic = ea.GroupEquivariantImageCanonicalization(net, hp, (3, 64, 64)).to(dev)
+    image = torch.randn((1, 3, 64, 64))
+    _ = dgic(image.to(dev))                                      # populates canonicalization_info_dict
+    canonicalized_image = torch.randn((1, num_channels, 64, 64))
+    inverted = dgic.invert_canonicalization(canonicalized_image.to(dev), **{"induced_rep_type": induced_rep})
+    assert inverted.shape == canonicalized_image.shape           # what the reference's test asserts
+    el = dgic.canonicalization_info_dict["group_element"]
+    want = io.invert_action(canonicalized_image, el["rotation"].detach().cpu(), None, 4, 4, induced_rep)
+    _close(inverted.detach().cpu(), want)
