@@ -9,6 +9,13 @@ marks = []
 with torch.no_grad():
     for i in range(400):
         y = can(x); o = can.invert_canonicalization(f, induced_rep_type="scalar")
+        # determinism: the same input gives the same activations, bit for bit, every time (a race between the producer and
+        # consumer waves of the pipelined inverse transform, or an uninitialised read, would show up here)
+        acts = can.canonicalization_info_dict["group_activations"]
+        if i == 0:
+            acts0, y0 = acts.clone(), y.clone()
+        elif i % 25 == 0:
+            assert torch.equal(acts, acts0) and torch.equal(y, y0), f"step {i}: results differ from step 0"
         if i in (20, 399):
             torch.cuda.synchronize(); marks.append((torch.cuda.memory_allocated() / 1e9, torch.cuda.memory_reserved() / 1e9))
 print("inference: allocated/reserved GB after 20 and 400 steps:", marks)
