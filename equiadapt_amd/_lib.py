@@ -84,10 +84,13 @@ SIGNATURES = {
     "eqa_fft48k5_input_grad": (_int, [_vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_grad_transform": (_int, [_vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_filter_grad": (_int, [_vp, _vp, _int, _int, _vp]),
+    "eqa_fft48k5_filter_grad3m": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m_supported": (_int, [_int, _int]),
     "eqa_fft48k5_spectra3m_floats": (ctypes.c_int64, [_int, _int]),
     "eqa_fft48k5_filter_spectra3m": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
+    "eqa_fft48k5_wgrad3m_supported": (_int, [_int, _int]),
+    "eqa_fft48k5_wgrad3m": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
     "eqa_fft48k5_group": (_int, [_int, _int]),
     "eqa_fft48k5_workspace_bytes": (ctypes.c_int64, [_int] * 4),
     "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),

@@ -298,6 +298,147 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The filter gradient's contraction (training):  D[f] (Cin x Cout, complex) = V[f]^T . conj(G[f]),  summed over the M tiles --
+// the same 3-multiplication trick with the TILES as the contraction axis:
+//     P1 = Vr^T Gr    P2 = Vi^T Gi    P3 = (Vr - Vi)^T (Gr + Gi)          Dr = P1 + P2    Di = ViGr - VrGi = P1 - P2 - P3
+// (through the GEMM library: the real [2Cin x M].[M x 2Cout] product, 4 multiplies per complex one, 4.7 ms at B = 256).
+// Wave tile = 64 input x 64 output channels of one frequency, three 2 x 2 x (32 x 32) accumulator sets (192 registers); operands
+// straight from global memory / L2 into registers, one stage (16 tiles) ahead, no LDS, no barriers.  Rows beyond M fall outside
+// the buffer descriptor and read as zero.  The K loop is M / 2 steps of 12 MFMAs (393 k cycles at M = 1024): the epilogue (128
+// 8-byte stores per lane) is noise and goes straight from the accumulators.
+// D comes out compact: D3 (F, Cin, 2, Cout) = Dr | Di per input channel, plain channel order (fft48_filter_grad_kernel<PACKED>).
+// (Writing Dr / Di into two quadrants of the library form's (F, 2Cin, 2Cout) layout and leaving the rest unwritten made every
+// line of D half-written: the reader then took 1.1 ms instead of 0.6.)
+// (First version: v_mfma_f32_16x16x4_f32 with 48 four-register accumulators and 16-byte loads -- the register allocator kept a
+// third of them in AGPRs as spill slots and shuttled them through VGPRs around every MFMA: 316 copies per 96 MFMAs, 6.4 ms.  With
+// twelve 16-register accumulators, as in the kernel above, the MFMAs take them in AGPR form.)
+constexpr int kWgSteps = 8;   // MFMA k-steps (2 tiles each) per stage: operands are requested one stage = 96 MFMAs = 6144 cycles ahead
+                              // (one step ahead, 768 cycles, is less than an L2 round trip under load: 7 ms instead of 3.5)
+struct WgOps {
+  f32x2v ar[kWgSteps], ai[kWgSteps], br[kWgSteps], bi[kWgSteps];
+};
+
+__device__ __forceinline__ f32x2v buf_ld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+__device__ __forceinline__ void wg_load(WgOps& o, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, unsigned aoff, unsigned boff,
+                                        unsigned sa, unsigned sb, unsigned step_a, unsigned step_b) {
+#pragma unroll
+  for (int k = 0; k < kWgSteps; ++k) {
+    o.ar[k] = buf_ld2(ra, aoff, sa + k * step_a);
+    o.ai[k] = buf_ld2(ra, aoff + 64, sa + k * step_a);
+    o.br[k] = buf_ld2(rb, boff, sb + k * step_b);
+    o.bi[k] = buf_ld2(rb, boff + 64, sb + k * step_b);
+  }
+}
+
+__device__ __forceinline__ void wg_mma(const WgOps& o, f32x16 (&acc)[3][2][2]) {
+#pragma unroll
+  for (int k = 0; k < kWgSteps; ++k) {
+    const f32x2v as = o.ar[k] - o.ai[k], bs = o.br[k] + o.bi[k];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        acc[0][t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ar[k][t], o.br[k][u], acc[0][t][u], 0, 0, 0);
+        acc[1][t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.ai[k][t], o.bi[k][u], acc[1][t][u], 0, 0, 0);
+        acc[2][t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[t], bs[u], acc[2][t][u], 0, 0, 0);
+      }
+  }
+}
+
+// one stage (16 tiles, 96 MFMAs): the next stage's 32 loads spread through them (one behind every third)
+__device__ __forceinline__ void wg_stage(WgOps& nxt, const WgOps& cur, f32x16 (&acc)[3][2][2], __amdgpu_buffer_rsrc_t ra,
+                                         __amdgpu_buffer_rsrc_t rb, unsigned aoff, unsigned boff, unsigned sa, unsigned sb, unsigned step_a,
+                                         unsigned step_b) {
+  wg_load(nxt, ra, rb, aoff, boff, sa, sb, step_a, step_b);
+  wg_mma(cur, acc);
+#pragma unroll
+  for (int k = 0; k < 4 * kWgSteps; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+  }
+}
+
+// v_mfma_f32_32x32x2_f32: A[i][k], B[k][j] one register each, lane l = 32 k + i -- k = 2 consecutive tiles.  A lane's 8-byte load is
+// 2 consecutive channels of its tile row; component t feeds MFMA row block t, whose 32 rows are the channels
+// {16 (i / 8) + 2 (i % 8) + t} of the wave tile's 64: a permutation the epilogue undoes when it stores.
+__global__ __launch_bounds__(256, 1) void fft_wgrad3m_kernel(const float* __restrict__ V, const float* __restrict__ G, float* __restrict__ D,
+                                                             int M, int pitch, int Cin, int Cout, int F, int n_it, int n_ot,
+                                                             int waves_per_xcd) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & (kXcd - 1);
+  const int q = (blockIdx.x >> 3) * 4 + wave;
+  const int wpf = n_it * n_ot;                          // wave tiles per frequency; neighbouring waves share the input-channel tile
+  const int nf_x = (F - xcd + kXcd - 1) / kXcd;
+  const int total = nf_x * wpf;
+  const int i = lane & 31, h = lane >> 5;
+  const size_t rowa = (size_t)2 * Cin, rowb = (size_t)2 * Cout;
+  const unsigned step_a = 2u * (unsigned)rowa * 4u, step_b = 2u * (unsigned)rowb * 4u;   // 2 tiles further
+  const int steps = (M + 1) / 2;
+  for (int u = q; u < total; u += waves_per_xcd) {
+    const int fi = u / wpf, r = u - fi * wpf;
+    const int f = xcd + kXcd * fi;
+    const int it = r / n_ot, ot = r - it * n_ot;
+#ifdef EQA_WG_SAMEF   // experiment: every wave tile reads frequency 0 -- operands always cached
+    const int fl = 0;
+#else
+    const int fl = f;
+#endif
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)fl * pitch * rowa, 0,
+                                                                        (unsigned)((size_t)M * rowa * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(G) + (size_t)fl * pitch * rowb, 0,
+                                                                        (unsigned)((size_t)M * rowb * 4), 0x00020000);
+    // this lane's 2 channels of tile row h: group i / 8 of the wave tile's four [Re x 16 | Im x 16] groups, floats 2 (i % 8) ..
+    const unsigned aoff = (unsigned)((size_t)h * rowa + (size_t)it * 128 + (i >> 3) * 32 + (i & 7) * 2) * 4u;
+    const unsigned boff = (unsigned)((size_t)h * rowb + (size_t)ot * 128 + (i >> 3) * 32 + (i & 7) * 2) * 4u;
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[p][t][v][e] = 0.f;
+    // (A third operand set -- two stages of lead -- spills; a one-dword touch of the lines of the stage after next changed
+    // nothing: the 9 % to the always-cached rate, 3.82 vs 3.49 ms at M = 1024, are not first-touch latency.)
+    WgOps s0, s1;
+    wg_load(s0, ra, rb, aoff, boff, 0, 0, step_a, step_b);
+    for (int s = 0; s < steps; s += 2 * kWgSteps) {   // steps past the last read beyond the descriptors: zeros, harmless
+      __builtin_amdgcn_sched_barrier(0);
+      wg_stage(s1, s0, acc, ra, rb, aoff, boff, (s + kWgSteps) * step_a, (s + kWgSteps) * step_b, step_a, step_b);
+      __builtin_amdgcn_sched_barrier(0);
+      wg_stage(s0, s1, acc, ra, rb, aoff, boff, (s + 2 * kWgSteps) * step_a, (s + 2 * kWgSteps) * step_b, step_a, step_b);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // accumulator register e of lane (h, j = i) in block (t, v): block row (e & 3) + 8 (e >> 2) + 4 h = input-channel position ir,
+    // channel 16 (ir / 8) + 2 (ir % 8) + t; output channel 16 (j / 8) + 2 (j % 8) + v -> 2 consecutive output channels per 8-byte store,
+    // the 32 lanes of a half wave one 256-byte run
+    float* Df = D + (size_t)f * (2 * (size_t)Cin) * Cout;           // D3[f][ci][Dr | Di][co], plain channel order
+    const size_t col = (size_t)ot * 64 + (i >> 3) * 16 + (i & 7) * 2;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ir = (e & 3) + 8 * (e >> 2) + 4 * h;
+        const size_t ci = (size_t)it * 64 + (ir >> 3) * 16 + (ir & 7) * 2 + t;
+        f32x2v dr, di;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const float p1 = acc[0][t][v][e], p2 = acc[1][t][v][e], p3 = acc[2][t][v][e];
+          dr[v] = p1 + p2;
+          di[v] = p1 - p2 - p3;
+        }
+        *reinterpret_cast<f32x2v*>(Df + (2 * ci) * Cout + col) = dr;          // 32 lanes: 256 contiguous bytes
+        *reinterpret_cast<f32x2v*>(Df + (2 * ci + 1) * Cout + col) = di;
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -333,6 +474,23 @@ int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, i
   }
 #undef EQA_CG_LAUNCH
   return launch_status();
+}
+
+int eqa_fft48k5_wgrad3m_supported(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0; }
+
+int eqa_fft48k5_wgrad3m(const float* V, const float* G, float* D, int64_t M, int Cin, int Cout, void* stream) {
+  if (!V || !G || !D || M <= 0 || Cin <= 0 || Cout <= 0) return EQA_ERR_INVALID_ARG;
+  const int F = eqa_fft48k5_frequencies();
+  const int64_t fm_bytes = ((M | 1) + 8) * 2 * (int64_t)std::max(Cin, Cout) * 4;
+  if (!eqa_fft48k5_wgrad3m_supported(Cin, Cout) || M > 0x3fffff || fm_bytes > 0x7fffffffLL ||
+      (((uintptr_t)V | (uintptr_t)G | (uintptr_t)D) & 15))
+    return EQA_ERR_UNSUPPORTED;
+  const int n_it = Cin / 64, n_ot = Cout / 64;
+  if ((int64_t)F * n_it * n_ot > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;
+  const int blocks = 256;
+  hipLaunchKernelGGL(fft_wgrad3m_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, G, D, (int)M, (int)eqa_fft48k5_tile_pitch(M),
+                     Cin, Cout, F, n_it, n_ot, (blocks / kXcd) * 4);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -918,6 +918,8 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const 
 //   dW[co][ci][u][v] = 1/48^2 sum_f wgt(f) (cos t Dr - sin t Di),  t = 2 pi (ky u + kx v) / 48,
 // wgt = 2 for the stored frequencies whose conjugate partner is not stored, 1 for the self-conjugate ones -- the correlation theorem; no
 // wrap-around because a 44-wide gradient tile shifted by up to 4 stays inside the 48-wide input tile.
+// PACKED: D3 (F, Cin, 2, Cout) as eqa_fft48k5_wgrad3m writes it -- Dr | Di per input channel, plain channel order.
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float* __restrict__ D, float* __restrict__ dbank, int Cout,
                                                                     int Cin, int Gin, int Gout) {
   __shared__ double tw_c[kFftN], tw_s[kFftN];
@@ -932,7 +934,8 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
   if (co >= Cout) return;
   const int r0 = (ci / Gin) * 2 * Gin + ci % Gin, r1 = r0 + Gin;
   const int c0 = (co / Gout) * 2 * Gout + co % Gout, c1 = c0 + Gout;
-  const size_t ld = (size_t)2 * Cout, fstride = (size_t)2 * Cin * ld;
+  const size_t ld = (size_t)2 * Cout, fstride = (size_t)2 * Cin * (PACKED ? (size_t)Cout : ld);
+  const size_t p_dr = ((size_t)2 * ci) * Cout + co, p_di = p_dr + Cout;   // PACKED
   double acc[25];
 #pragma unroll
   for (int i = 0; i < 25; ++i) acc[i] = 0.0;
@@ -945,8 +948,8 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
       const float* d = D + (size_t)(f0 + ky * fstep) * fstride;
       // weight 2 for every stored frequency whose conjugate partner is not stored; 1 for the four self-conjugate ones
       const double wgt = (edge && (ky == 0 || ky == kFftH - 1)) ? 1.0 : 2.0;
-      const double dr = wgt * ((double)d[r0 * ld + c0] + (double)d[r1 * ld + c1]);
-      const double di = wgt * ((double)d[r1 * ld + c0] - (double)d[r0 * ld + c1]);
+      const double dr = PACKED ? wgt * (double)d[p_dr] : wgt * ((double)d[r0 * ld + c0] + (double)d[r1 * ld + c1]);
+      const double di = PACKED ? wgt * (double)d[p_di] : wgt * ((double)d[r1 * ld + c0] - (double)d[r0 * ld + c1]);
 #pragma unroll
       for (int u = 0; u < 5; ++u) {
         const int t = (ky * u) % kFftN;
@@ -1167,8 +1170,16 @@ int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, in
 int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream) {
   if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (Cin > 65535) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_filter_grad_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
+  hipLaunchKernelGGL(fft48_filter_grad_kernel<false>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
                      dbank, Cout, Cin, fft_group_in(Cin), fft_group_in(Cout));
+  return launch_status();
+}
+
+int eqa_fft48k5_filter_grad3m(const float* D, float* dbank, int Cout, int Cin, void* stream) {
+  if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (Cin > 65535 || Cin % kFusCh || Cout % kFusCh) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fft48_filter_grad_kernel<true>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
+                     dbank, Cout, Cin, kFusCh, kFusCh);
   return launch_status();
 }
 

@@ -251,6 +251,12 @@ def filter_grad(V: torch.Tensor, dy: torch.Tensor, cin: int, G: Optional[torch.T
         G = grad_spectra(dy)
     dbank = torch.empty((Cout, cin, 5, 5), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        if GEMM == "3m" and lib.eqa_fft48k5_wgrad3m_supported(cin, Cout) and os.environ.get("EQA_FFT_WGRAD3M", "1") != "0":
+            # the contraction over the tiles in the 3-multiplication form on the fp32 MFMA (the library's real GEMM: 4 products)
+            D = torch.empty((F, cin, 2, Cout), dtype=torch.float32, device=dev)      # Dr | Di per input channel
+            _lib.check(lib.eqa_fft48k5_wgrad3m(V.data_ptr(), G.data_ptr(), D.data_ptr(), M, cin, Cout, st), "eqa_fft48k5_wgrad3m")
+            _lib.check(lib.eqa_fft48k5_filter_grad3m(D.data_ptr(), dbank.data_ptr(), Cout, cin, st), "eqa_fft48k5_filter_grad3m")
+            return dbank
         D = torch.bmm(V.transpose(1, 2), G)                       # (F, 2 Cin, 2 Cout)
         _lib.check(lib.eqa_fft48k5_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, st), "eqa_fft48k5_filter_grad")
     return dbank

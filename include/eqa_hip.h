@@ -379,6 +379,13 @@ int eqa_fft48k5_cgemm3m_supported(int Cin, int Cout);
 int64_t eqa_fft48k5_spectra3m_floats(int Cin, int Cout);
 int eqa_fft48k5_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int correlate, void* stream);
 int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, int Cin, int Cout, void* stream);
+/* The filter gradient's contraction (training), replacing the library's real [2Cin x M].[M x 2Cout] product (autograd through the
+ * same R2Conv): D[f] = V[f]^T . conj(G[f]) over the M tiles in the 3-multiplication form on the fp32 MFMA.  V:(F, M|1, 2Cin),
+ * G:(F, M|1, 2Cout) as eqa_fft48k5_input / _grad_transform write them; D3:(F, Cin, 2, Cout) = Dr | Di per input channel, plain
+ * channel order; Cin, Cout % 64 == 0.  eqa_fft48k5_filter_grad3m: eqa_fft48k5_filter_grad on that form. */
+int eqa_fft48k5_wgrad3m_supported(int Cin, int Cout);
+int eqa_fft48k5_wgrad3m(const float* V, const float* G, float* D, int64_t M, int Cin, int Cout, void* stream);
+int eqa_fft48k5_filter_grad3m(const float* D, float* dbank, int Cout, int Cin, void* stream);
 int eqa_fft48k5_group(int C, int side);
 int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int out_cols, int C);
 int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,

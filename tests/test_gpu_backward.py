@@ -702,3 +702,48 @@ def test_gram_schmidt_backward_matches_autograd_of_the_oracle(dev):
     empty = torch.empty(0, 3, 3, device=dev, requires_grad=True)
     gram_schmidt(empty).sum().backward()
     assert empty.grad.shape == (0, 3, 3)
+
+
+@pytest.mark.parametrize("M,Cin,Cout", [(37, 64, 128), (64, 128, 64), (130, 256, 256)])
+def test_fft_wgrad3m_matches_the_real_product(dev, M, Cin, Cout):
+    """eqa_fft48k5_wgrad3m (filter-gradient contraction over the tiles, 3-multiplication form on the fp32 MFMA) against the real
+    [2Cin x M].[M x 2Cout] product in fp64: Dr = (re,re) + (im,im), Di = (im,re) - (re,im) -- the two numbers
+    eqa_fft48k5_filter_grad takes from every channel pair -- to 2e-6 of the largest entry; the padding row of the spectra (tile
+    pitch M | 1) is poisoned with NaN to show it is never read; and the filter gradient computed from it
+    (eqa_fft48k5_filter_grad3m) equals the library path's."""
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    lib = _lib.load()
+    torch.manual_seed(M)
+    F = fftconv.F
+    pitch = M | 1
+    V = torch.randn(F, pitch, 2 * Cin, device=dev)
+    G = torch.randn(F, pitch, 2 * Cout, device=dev)
+    if pitch > M:
+        V[:, M:] = float("nan")
+        G[:, M:] = float("nan")
+    D = torch.full((F, Cin, 2, Cout), float("nan"), device=dev)
+    assert lib.eqa_fft48k5_wgrad3m_supported(Cin, Cout) == 1
+    _lib.check(lib.eqa_fft48k5_wgrad3m(V.data_ptr(), G.data_ptr(), D.data_ptr(), M, Cin, Cout, None), "eqa_fft48k5_wgrad3m")
+    fsel = torch.tensor([0, 1, 7, 500, 1103, 1104, 1153], device=dev)
+    ref = torch.bmm(V[fsel, :M].double().transpose(1, 2), G[fsel, :M].double())          # (7, 2Cin, 2Cout)
+
+    def quad(T, a, b):   # (re/im of ci, re/im of co) quadrants of the [Re x 16 | Im x 16] grouped layout
+        T = T.reshape(T.shape[0], Cin // 16, 2, 16, Cout // 16, 2, 16)
+        return T[:, :, a, :, :, b, :]
+    want_r, want_i = quad(ref, 0, 0) + quad(ref, 1, 1), quad(ref, 1, 0) - quad(ref, 0, 1)
+    assert torch.isfinite(D).all()
+    got = D[fsel].double()                                          # (7, Cin, 2, Cout), plain channel order
+    got_r = got[:, :, 0].reshape(-1, Cin // 16, 16, Cout // 16, 16)
+    got_i = got[:, :, 1].reshape(-1, Cin // 16, 16, Cout // 16, 16)
+    scale = max(want_r.abs().max().item(), want_i.abs().max().item())
+    assert (got_r - want_r).abs().max().item() <= 2e-6 * scale
+    assert (got_i - want_i).abs().max().item() <= 4e-6 * scale      # a difference of three products
+    # through eqa_fft48k5_filter_grad: the same filter gradient as from the library's 4-product form
+    db3 = torch.empty(Cout, Cin, 5, 5, device=dev)
+    db4 = torch.empty(Cout, Cin, 5, 5, device=dev)
+    D4 = torch.bmm(V[:, :M].transpose(1, 2), G[:, :M]).contiguous()
+    _lib.check(lib.eqa_fft48k5_filter_grad3m(D.data_ptr(), db3.data_ptr(), Cout, Cin, None), "eqa_fft48k5_filter_grad3m")
+    _lib.check(lib.eqa_fft48k5_filter_grad(D4.data_ptr(), db4.data_ptr(), Cout, Cin, None), "eqa_fft48k5_filter_grad")
+    assert (db3 - db4).abs().max().item() <= 5e-6 * db4.abs().max().item()
