@@ -1504,3 +1504,36 @@ def test_reference_own_test_invert_canonicalization_induced_rep(dev, induced_rep
     el = dgic.canonicalization_info_dict["group_element"]
     want = io.invert_action(canonicalized_image, el["rotation"].detach().cpu(), None, 4, 4, induced_rep)
     _close(inverted.detach().cpu(), want)
+
+
+@pytest.mark.parametrize("group_type,N,out_ch,layers,res,B", [
+    ("rotation", 4, 32, 3, 96, 8),          # C4: 128 channels, FFT layer behind a channel-group-major lifting layer
+    ("rotation", 8, 16, 4, 96, 8),          # four layers: two FFT layers in a row (plain-output inverse feeding the next transform)
+    ("roto-reflection", 4, 16, 3, 100, 8),  # D4, ragged tiles (96 -> 92 outputs: partial last tile)
+    ("rotation", 8, 32, 3, 64, 12),         # 64-pixel input: 60 -> 56 outputs, tiles do not fit -> Winograd path
+    ("rotation", 4, 8, 3, 96, 4),           # narrow network (32 channels) and too few tiles for the FFT path
+])
+def test_escnn_network_inference_paths_match_oracle_sweep(dev, group_type, N, out_ch, layers, res, B):
+    """ESCNNEquivariantNetwork.forward in eval mode -- whichever fast path its shape selects (FFT / Winograd convolutions, MFMA
+    lifting layer in either output layout, linearised tail) -- against the oracle's op-by-op restatement with the same state
+    dict: group activations to 2e-5 of their scale (escnn_networks.py:93-117)."""
+    import equiadapt_amd as ea
+    from oracle import nets as onets
+
+    torch.manual_seed(res + layers + out_ch)
+    net = ea.ESCNNEquivariantNetwork((3, res, res), out_channels=out_ch, kernel_size=5, group_type=group_type, num_rotations=N,
+                                     num_layers=layers)
+    with torch.no_grad():
+        for m in net.modules():                      # non-trivial batch-norm statistics (eval mode folds them)
+            if hasattr(m, "running_mean") and m.running_mean is not None:
+                m.running_mean.uniform_(-0.05, 0.05)
+                m.running_var.uniform_(0.8, 1.2)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(dev).eval()
+    x = torch.randn(B, 3, res, res)
+    with torch.no_grad():
+        got = net(x.to(dev)).cpu()
+        want = onets.escnn_like_network(x, sd, group_type, N, layers, out_ch)
+    assert got.shape == want.shape
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item() / scale
