@@ -49,6 +49,26 @@ __device__ __forceinline__ void vn_block_sum(float (&v)[NV], float* s_red /* [wa
   }
 }
 
+// The same in two halves for sums formed inside a loop: every wave parks its NV sums at s_red[wave][at + i] (no barrier), and after
+// the loop one barrier and a fixed-order sum over the waves writes all `total` values.
+template <int NV>
+__device__ __forceinline__ void vn_wave_part(const float (&v)[NV], float* s_red, int total, int at) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float s = wave_sum_f(v[i]);
+    if (lane == 0) s_red[wave * total + at + i] = s;
+  }
+}
+__device__ __forceinline__ void vn_block_finish(const float* s_red, int total, float* __restrict__ out) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < total; i += kVnThreads) {
+    float s = 0.f;
+    for (int w = 0; w < kVnThreads / 64; ++w) s += s_red[w * total + i];
+    out[i] = s;
+  }
+}
+
 __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
                                                                              int N) {
   extern __shared__ __attribute__((aligned(16))) float vn_smem[];
@@ -69,7 +89,14 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(c
   }
 }
 
-// common prologue of the four conv_pos passes: cloud in LDS, this thread's point and its neighbour list
+// Four lanes per point, five of its twenty edges each (kVnSplit x kVnEdges = kVnK): with one thread per point a batch of 64
+// clouds is 65 k threads = one wave per SIMD walking 20 edges x 21 channels of dependent arithmetic (the four passes took
+// 0.05 + 0.13 + 0.15 + 0.19 ms); split, there are four waves per SIMD and a quarter of the chain each.  Sums over a point's
+// edges: the block sums already cover all lanes; the forward pass adds the four lanes of a quad with two DPP quad permutes.
+constexpr int kVnSplit = 4, kVnEdges = kVnK / kVnSplit, kVnPts = kVnThreads / kVnSplit;
+static_assert(kVnSplit * kVnEdges == kVnK, "the edges divide evenly over the lanes of a point");
+
+// common prologue of the four conv_pos passes: cloud in LDS, this thread's point and its share of the neighbour list
 #define VN_PASS_PROLOGUE                                                                           \
   extern __shared__ __attribute__((aligned(16))) float vn_smem[];                                  \
   float4* pts = reinterpret_cast<float4*>(vn_smem);                                                \
@@ -77,11 +104,11 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(c
   const int Npad = (N + 3) & ~3;                                                                   \
   vn_stage_cloud(x + (size_t)b * 3 * N, N, Npad, pts, tid);                                        \
   __syncthreads();                                                                                 \
-  const int n = blockIdx.x * kVnThreads + tid;                                                     \
+  const int n = blockIdx.x * kVnPts + tid / kVnSplit, sub = tid % kVnSplit;                        \
   const bool active = n < N;                                                                       \
   const float4 c4 = pts[active ? n : N - 1];                                                       \
   const V3 ctr = v3(c4.x, c4.y, c4.z);                                                             \
-  const int32_t* nbr = idx + ((size_t)b * N + (active ? n : N - 1)) * kVnK;
+  const int32_t* nbr = idx + ((size_t)b * N + (active ? n : N - 1)) * kVnK + sub * kVnEdges;
 
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                                      const float* __restrict__ Wf, float* __restrict__ partial,
@@ -92,7 +119,7 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const floa
 #pragma unroll
   for (int i = 0; i < 2 * kVnC; ++i) acc[i] = 0.f;
 #pragma unroll 1
-  for (int t = 0; t < kVnK; ++t) {
+  for (int t = 0; t < kVnEdges; ++t) {
     asm volatile("" ::: "memory");  // keep the weights in the scalar cache, not hoisted into VGPRs (see pointcloud.hip)
     const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
 #pragma unroll
@@ -115,7 +142,7 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float*
 #pragma unroll
   for (int c = 0; c < kVnC; ++c) acc[c] = v3(0.f, 0.f, 0.f);
 #pragma unroll 1
-  for (int t = 0; t < kVnK; ++t) {
+  for (int t = 0; t < kVnEdges; ++t) {
     asm volatile("" ::: "memory");
     const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
 #pragma unroll
@@ -124,14 +151,22 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float*
       acc[c].x += q.x; acc[c].y += q.y; acc[c].z += q.z;
     }
   }
-  if (active) {
-    const float inv_k = 1.0f / (float)kVnK;
-    float* o = pooled + (size_t)b * kVnC * 3 * N + n;  // (B, 21, 3, N)
+  // the four lanes of a point: butterfly over the quad, every lane ends up with the point's sums; lane `sub` stores channels
+  // c = sub, sub + 4, ...
+  auto quad_sum = [](float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));  // [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
+    return v;
+  };
+  const float inv_k = 1.0f / (float)kVnK;
+  float* o = pooled + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);  // (B, 21, 3, N)
 #pragma unroll
-    for (int c = 0; c < kVnC; ++c) {
-      o[(size_t)(3 * c) * N] = acc[c].x * inv_k;
-      o[(size_t)(3 * c + 1) * N] = acc[c].y * inv_k;
-      o[(size_t)(3 * c + 2) * N] = acc[c].z * inv_k;
+  for (int c = 0; c < kVnC; ++c) {
+    const float sx = quad_sum(acc[c].x), sy = quad_sum(acc[c].y), sz = quad_sum(acc[c].z);
+    if (active && (c % kVnSplit) == sub) {
+      o[(size_t)(3 * c) * N] = sx * inv_k;
+      o[(size_t)(3 * c + 1) * N] = sy * inv_k;
+      o[(size_t)(3 * c + 2) * N] = sz * inv_k;
     }
   }
 }
@@ -148,13 +183,13 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const
                                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                           const float* __restrict__ gpool, float* __restrict__ partial,
                                                                           int N) {
-  __shared__ float s_red[(kVnThreads / 64) * 2];
+  __shared__ float s_red[(kVnThreads / 64) * 2 * kVnC];   // per wave, all channels: ONE barrier after the channel loop, not two per channel
   VN_PASS_PROLOGUE
   const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;  // idle threads contribute nothing
   const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
-  int nb[kVnK];
+  int nb[kVnEdges];
 #pragma unroll
-  for (int t = 0; t < kVnK; ++t) nb[t] = nbr[t];
+  for (int t = 0; t < kVnEdges; ++t) nb[t] = nbr[t];
   float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC);
   // channel by channel (the output gradient of a channel is the same for all k edges of the point): two accumulators live
 #pragma unroll 1
@@ -163,13 +198,14 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
     float acc[2] = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < kVnK; ++t) {
+    for (int t = 0; t < kVnEdges; ++t) {
       const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, vn_edge(ctr, pts[nb[t]]), sc, sh, g_out);
       acc[0] += r.g_nbn;
       acc[1] += r.g_nbn * (r.nr - mu) * rs;
     }
-    vn_block_sum<2>(acc, s_red, out + 2 * c);
+    vn_wave_part<2>(acc, s_red, 2 * kVnC, 2 * c);
   }
+  vn_block_finish(s_red, 2 * kVnC, out);
 }
 
 // dW_f[c][i] = sum <g_q, f_i>, dW_d[c][i] = sum <g_d, f_i>;  g_q = dL/dq through the direction u = q/n and through the norm:
@@ -182,13 +218,13 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const 
                                                                          const float* __restrict__ m1, const float* __restrict__ m2,
                                                                          const float* __restrict__ gpool, float* __restrict__ partial,
                                                                          int N) {
-  __shared__ float s_red[(kVnThreads / 64) * 6];
+  __shared__ float s_red[(kVnThreads / 64) * 6 * kVnC];
   VN_PASS_PROLOGUE
   const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;
   const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
-  int nb[kVnK];
+  int nb[kVnEdges];
 #pragma unroll
-  for (int t = 0; t < kVnK; ++t) nb[t] = nbr[t];
+  for (int t = 0; t < kVnEdges; ++t) nb[t] = nbr[t];
   float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (6 * kVnC);  // [c][W_f 0..2, W_d 0..2]
 #pragma unroll 1
   for (int c = 0; c < kVnC; ++c) {
@@ -196,7 +232,7 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const 
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c], mm1 = m1[c], mm2 = m2[c];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < kVnK; ++t) {
+    for (int t = 0; t < kVnEdges; ++t) {
       const VnEdge e = vn_edge(ctr, pts[nb[t]]);
       const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, e, sc, sh, g_out);
       const V3 g_q = vn_norm_input_grad(r, sc, mu, rs, mm1, mm2, active);
@@ -207,8 +243,9 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const 
       acc[4] += dot3(r.g_d, e.f1);
       acc[5] += dot3(r.g_d, e.f2);
     }
-    vn_block_sum<6>(acc, s_red, out + 6 * c);
+    vn_wave_part<6>(acc, s_red, 6 * kVnC, 6 * c);
   }
+  vn_block_finish(s_red, 6 * kVnC, out);
 }
 
 inline int vn_check(const void* x, const void* idx, int B, int N, size_t& lds, bool with_queue) {
@@ -225,14 +262,16 @@ inline int vn_check(const void* x, const void* idx, int B, int N, size_t& lds, b
 
 extern "C" {
 
-int eqa_vn_blocks(int N) { return N <= 0 ? 0 : (N + kVnThreads - 1) / kVnThreads; }
+// blocks per cloud of the four conv_pos passes (32 points per block: four lanes per point); the kNN kernel keeps one thread per point
+int eqa_vn_blocks(int N) { return N <= 0 ? 0 : (N + kVnPts - 1) / kVnPts; }
+static int vn_knn_blocks(int N) { return (N + kVnThreads - 1) / kVnThreads; }
 
 int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream) {
   if (k != kVnK) return EQA_ERR_UNSUPPORTED;
   size_t lds;
   const int rc = vn_check(x, idx, B, N, lds, true);
   if (rc != 1) return rc;
-  hipLaunchKernelGGL(vn_knn_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, N);
+  hipLaunchKernelGGL(vn_knn_kernel, dim3(vn_knn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, N);
   return launch_status();
 }
 
