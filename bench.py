@@ -240,21 +240,22 @@ class Comm:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         self.dry_run = dry_run
         self.backend = None
-        if self.world > 1:
+        if not dry_run:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback (--dry-run tests the launcher only)"
+            torch.cuda.set_device(self.local)
+        # Under a launcher (RANK set) the process group comes up even for a single rank: `torch.distributed.run
+        # --nproc-per-node 1 bench.py` is then the N-rank job with N = 1 (RCCL initialised, the training legs DDP-wrapped).
+        if self.world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
             self.backend = "gloo" if dry_run else "nccl"   # "nccl" IS RCCL on ROCm
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
-        if dry_run:
-            self.dev = torch.device("cpu")
-        else:
-            assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback (--dry-run tests the launcher only)"
-            torch.cuda.set_device(self.local)
-            self.dev = torch.device("cuda", self.local)
+        self.dev = torch.device("cpu") if dry_run else torch.device("cuda", self.local)
 
     def barrier(self):
-        if self.world > 1:
+        if self.backend is not None:
             import torch.distributed as dist
 
             dist.barrier()
@@ -298,7 +299,7 @@ class Comm:
         return self.reduce(dt, "max"), self.gather(dt)
 
     def close(self):
-        if self.world > 1:
+        if self.backend is not None:
             import torch.distributed as dist
 
             dist.destroy_process_group()
@@ -327,7 +328,7 @@ def leg_train_images(comm: Comm, steps: int, warmup: int, batch: int):
         pred = pred.to(memory_format=torch.channels_last)
     model = tr.CanonicalizedClassifier(can, pred, tr.LossWeights(task_weight=1.0, prior_weight=100.0)).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    ddp = tr.wrap_ddp(model, dev)
+    ddp = tr.wrap_ddp(model, dev, force=comm.backend is not None)
     opt, _ = tr.configure_optimizer(model, 1e-3, 1e-3, kind=None, max_epochs=200,
                                     prediction_network_architecture="resnet50", dataset_name="cifar10")
     g = torch.Generator().manual_seed(100 + comm.rank)
@@ -348,8 +349,9 @@ def leg_train_images(comm: Comm, steps: int, warmup: int, batch: int):
            "batch_per_gpu": batch, "n_gpus": comm.world,
            "model": "GroupEquivariantImageCanonicalization(ESCNNEquivariantNetwork C8 32ch k5 L3) + ResNet50(10 classes, run channels-last), fp32",
            "optimizer": type(opt).__name__ + " (reference rule: resnet + non-mnist -> SGD 0.9 / wd 5e-4)",
-           "loss": "1.0 * CE + 100.0 * prior", "parameters": n_params, "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.world > 1 else 0.0,
-           "collective": "DDP bucketed all-reduce over RCCL (64 MB buckets), overlapped with backward" if comm.world > 1 else "none (1 rank)",
+           "loss": "1.0 * CE + 100.0 * prior", "parameters": n_params, "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.backend == "nccl" else 0.0,
+           "collective": "DDP bucketed all-reduce over RCCL (64 MB buckets), overlapped with backward" if comm.backend == "nccl" else "none (1 rank, no process group)",
+           "ddp_wrapped": type(ddp).__name__ == "DistributedDataParallel",
            "per_rank_ms_per_step": [t / steps * 1e3 for t in per_rank], "final_loss": loss,
            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9, "data": "synthetic CIFAR-10-shaped (resized 224x224x3), labels uniform"}
     del ddp, model, opt, xs, ys
@@ -372,7 +374,7 @@ def leg_train_pointcloud(comm: Comm, steps: int, warmup: int, batch: int):
     can = ea.EquivariantPointcloudCanonicalization(ea.VNSmall(hp), hp)
     model = tr.CanonicalizedClassifier(can, PointNetCls(40), tr.LossWeights(task_weight=1.0, prior_weight=100.0)).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
-    ddp = tr.wrap_ddp(model, dev)
+    ddp = tr.wrap_ddp(model, dev, force=comm.backend is not None)
     opt, _ = tr.configure_pointcloud_optimizer(model, 1e-3, 1e-3, "SGD", "cosine", 250)
     g = torch.Generator().manual_seed(200 + comm.rank)
     xs = [torch.randn(batch, 3, 1024, generator=g).to(dev) for _ in range(2)]
@@ -562,7 +564,7 @@ def main():
                                    "ESCNNEquivariantNetwork(32ch,k5,3 layers, crop 0.8, resize 96) forward, "
                                    "then invert_canonicalization(scalar, 3ch); prediction network excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective in the forward path)"},
-            "rccl_ranks": world if world > 1 else 0, "backend": comm.backend}
+            "rccl_ranks": world if comm.backend == "nccl" else 0, "backend": comm.backend}
 
     if args.mode in ("all", "forward"):
         can = build_canonicalizer(dev)

@@ -17,6 +17,8 @@ SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "b
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
+ABI_VERSION = 3   # == EQA_ABI_VERSION of include/eqa_hip.h (tests/test_abi_and_host.py compares the two)
+
 _c_f = ctypes.POINTER(ctypes.c_float)
 _c_i = ctypes.POINTER(ctypes.c_int32)
 _vp = ctypes.c_void_p
@@ -163,7 +165,7 @@ def load() -> ctypes.CDLL:
                 raise EqaLibraryError(f"{SO_PATH} does not export {name}; rebuild it") from exc
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.eqa_abi_version() != 2:
+        if lib.eqa_abi_version() != ABI_VERSION:
             raise EqaLibraryError("libeqa_hip.so ABI version mismatch; rebuild it")
         _lib = lib
     return _lib

@@ -37,3 +37,12 @@ def update_running_stats(bn: torch.nn.modules.batchnorm._BatchNorm, mean: torch.
         m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
         bn.running_mean.mul_(1 - m).add_(m * mean.to(bn.running_mean.dtype))
         bn.running_var.mul_(1 - m).add_(m * var_unbiased.to(bn.running_var.dtype))
+
+
+def mark_written(*tensors: torch.Tensor) -> None:
+    """Bump the autograd version counter of buffers that a kernel has written through their raw pointers (the running
+    statistics that eqa_vn_bn_finalize updates).  An in-place torch op would do this by itself; without it, caches keyed on
+    ``_version`` (VNSmall.packed_parameters) and autograd's saved-tensor checks would not see the write."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)

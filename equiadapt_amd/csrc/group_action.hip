@@ -1236,7 +1236,7 @@ __global__ __launch_bounds__(kThreads) void boxes_action_kernel(const float* __r
 
 extern "C" {
 
-int eqa_abi_version(void) { return 2; }  // 2: eqa_crop_resize_aa gained x_begin, x_span
+int eqa_abi_version(void) { return EQA_ABI_VERSION; }
 
 int eqa_get_option(int key) { return key == 0 ? g_force_direct : EQA_ERR_INVALID_ARG; }
 

@@ -149,9 +149,14 @@ class InnerBnReluDropout(torch.autograd.Function):
         # With batch statistics the convolution bias cancels in the normalised output (zero gradient).  With running statistics
         # (frozen batch-norm under autograd) it does not: out = scale * (h + conv_bias - running_mean) + ..., so
         # d conv_bias = per-field sum of dh, as the op-by-op path and the reference propagate it.
+        # The zero is returned as a tensor, not as None: the reference and the op-by-op path leave an exact-zero .grad on the
+        # bias, which weight decay then acts on and which DistributedDataParallel needs to count the parameter as used.
         dconv_bias = None
-        if ctx.has_conv_bias and ctx.needs_input_grad[5] and not ctx.batch_stats:
-            dconv_bias = dh.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1).float()
+        if ctx.has_conv_bias and ctx.needs_input_grad[5]:
+            if ctx.batch_stats:
+                dconv_bias = torch.zeros(Fd, dtype=h.dtype, device=h.device)
+            else:
+                dconv_bias = dh.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1).float()
         return dh, dweight, dbias, None, None, dconv_bias, None, None
 
 

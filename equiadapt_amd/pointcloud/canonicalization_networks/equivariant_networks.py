@@ -10,7 +10,7 @@ from typing import Any, Optional
 import torch
 import torch.nn as nn
 
-from equiadapt_amd.common.utils import update_running_stats
+from equiadapt_amd.common.utils import mark_written, update_running_stats
 
 from equiadapt_amd.pointcloud.canonicalization_networks.vector_neuron_layers import (
     VNBatchNorm,
@@ -76,6 +76,8 @@ class ConvPosMeanPool(torch.autograd.Function):
                                                   bn.running_var.data_ptr() if track else None,
                                                   bn.num_batches_tracked.data_ptr() if track else None,
                                                   float(bn.momentum or 0.0), float(bn.eps), stat.data_ptr(), st), "eqa_vn_bn_finalize")
+                if track:
+                    mark_written(bn.running_mean, bn.running_var, bn.num_batches_tracked)
             else:
                 if batch_stats:                                                # cumulative moving average (momentum=None): host glue
                     part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
@@ -167,6 +169,8 @@ class TailMean(torch.autograd.Function):
                                                   bn.running_var.data_ptr() if track else None,
                                                   bn.num_batches_tracked.data_ptr() if track else None,
                                                   float(bn.momentum), float(bn.eps), stat[layer].data_ptr(), st), "eqa_vn_bn_finalize")
+                if track:
+                    mark_written(bn.running_mean, bn.running_var, bn.num_batches_tracked)
             _lib.check(lib.eqa_vn_tail_pass(3, pooled.data_ptr(), W.data_ptr(), stat.data_ptr(), None, p_mask, None,
                                             part.data_ptr(), None, B, N, st), "eqa_vn_tail_pass")
             out = part[:nblk * 12].view(B, nbx, 12).sum(1).div_(N).view(B, 4, 3)

@@ -26,7 +26,7 @@ int main(void) {
   const float theta[2][6] = {{1, 0, 0, 0, 1, 0}, {-1, 0, 0, 0, -1, 0}};
   const int32_t gidx[B] = {0, 1, 1, 0};
 
-  if (eqa_abi_version() != 2) { fprintf(stderr, "unexpected ABI version %d\n", eqa_abi_version()); return 3; }
+  if (eqa_abi_version() != EQA_ABI_VERSION) { fprintf(stderr, "unexpected ABI version %d\n", eqa_abi_version()); return 3; }
   float *dx, *dy, *dth;
   int32_t* dg;
   CHECK_HIP(hipMalloc((void**)&dx, n * sizeof(float)));

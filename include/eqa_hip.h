@@ -42,7 +42,12 @@ extern "C" {
 #define EQA_FLIP_SRC 1
 #define EQA_FLIP_DST 2
 
-/* library / build identification: returns the ABI version (currently 2). */
+/* ABI version of this header.  History: 1 = round-1 entry points; 2 = eqa_crop_resize_aa gained x_begin / x_span;
+ * 3 = the round-2 additions (cgemm3m / wgrad3m, conv_s2, vn_tail / vn_bn_finalize, gram_schmidt_bwd, mask planes, boxes,
+ * cosine activations, fold_edge_pad, ...) and round 3's (group_action_pair, any-k VNSmall, narrow lifting convolution,
+ * Winograd plane GEMM).  A caller compares eqa_abi_version() with the EQA_ABI_VERSION it was compiled against. */
+#define EQA_ABI_VERSION 3
+/* library / build identification: returns the EQA_ABI_VERSION the library was built from. */
 int eqa_abi_version(void);
 
 /* Debug/benchmark knobs (process-global, not part of the data path):

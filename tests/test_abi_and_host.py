@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.SO_PATH)
     for n in names:
         assert hasattr(lib, n), f"libeqa_hip.so does not export {n}"
-    assert _lib.load().eqa_abi_version() == 2
+    # the version the library reports == the header's macro == the binding's constant (bumped whenever entry points are added)
+    macro = int(re.search(r"#define\s+EQA_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "eqa_hip.h")).read()).group(1))
+    assert _lib.load().eqa_abi_version() == macro == _lib.ABI_VERSION == 3
     # argument validation happens before any device work, so it is checkable without a GPU
     assert _lib.load().eqa_set_option(99, 0) == -1
     assert _lib.load().eqa_group_pool_workspace_bytes(4, 32, 8, 7056) > 0

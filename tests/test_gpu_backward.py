@@ -457,6 +457,45 @@ def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_vnsmall_eval_after_train_forward_sees_the_new_running_statistics(dev, monkeypatch):
+    """eval -> train-mode forward WITHOUT an optimizer step (frozen canonicalizer, batch-norm recalibration) -> eval: the
+    kernels write the running statistics through raw pointers, and the fused eval kernel folds them from a cache keyed on the
+    tensors' versions -- the second eval forward must use the updated statistics, like the op-by-op path and the reference
+    (pointcloud/canonicalization_networks/equivariant_networks.py:128-150 with nn.BatchNorm in train mode)."""
+    import copy
+    import types
+
+    import equiadapt_amd as ea
+
+    torch.manual_seed(7)
+    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    net = ea.VNSmall(hp).to(dev)
+    ref = copy.deepcopy(net)
+    x = torch.randn(6, 3, 256, device=dev) * 1.7 + 0.3        # statistics well away from the initial (0, 1)
+    net.eval()
+    with torch.no_grad():
+        before = net(x)
+    versions = [b._version for b in net.buffers()]
+    net.train()
+    net(x)                                                    # grad enabled, no backward, no optimizer step
+    assert all(b._version > v for b, v in zip(net.buffers(), versions)), "the kernel's writes must bump the buffers' versions"
+    net.eval()
+    with torch.no_grad():
+        after = net(x)
+    monkeypatch.setenv("EQA_TRAIN_FAST", "0")
+    ref.train()
+    ref(x)
+    ref.eval()
+    with torch.enable_grad():                                 # op-by-op path (the fused eval kernel runs under no_grad only)
+        want = ref(x).detach()
+    monkeypatch.delenv("EQA_TRAIN_FAST")
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.allclose(b1.float(), b2.float(), rtol=1e-4, atol=1e-6), n1
+    assert not torch.allclose(before, after, atol=1e-4), "the statistics moved, so must the eval output"
+    assert torch.allclose(after, want, atol=2e-5 * max(want.abs().max().item(), 1.0))
+
+
+@pytest.mark.gpu
 def test_padded_input_gradient_frame_gather_equals_atomic_scatter(dev):
     """Edge-padded canonicalize: gather on the padded frame + fold of the pad strips / corners (default) against the atomic
     scatter (eqa_set_option(0, 1)); with reflections, 45-degree elements, odd sizes; bit-reproducible; adjoint identity."""

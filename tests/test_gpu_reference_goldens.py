@@ -253,3 +253,88 @@ def test_conv_network_on_product_matches_reference_golden(dev, golden):
                 continue
             # (the 128 x 128 case runs BatchNorm1d batch statistics over 3 samples: ill-conditioned, 6e-3 between device and CPU)
             assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 2e-5, (c["args"], n)
+
+
+def _knn_sets_agree(idx_dev, x, want, k):
+    """Neighbour sets equal the reference's, except where the reference's own k-th / (k+1)-th candidates are closer than fp32
+    can separate (evaluated in fp64): there either pick is a correct top-k."""
+    got = idx_dev.long().sort(-1).values.cpu()
+    ref = want.long().sort(-1).values
+    bad = (got != ref).any(-1)                                   # (B, N)
+    if not bad.any():
+        return True, 0
+    xd = x.double()
+    d = (xd.transpose(1, 2)[:, :, None, :] - xd.transpose(1, 2)[:, None, :, :]).pow(2).sum(-1)     # (B, N, N)
+    top = d.topk(k + 1, dim=-1, largest=False).values
+    gap = (top[..., k] - top[..., k - 1]) / top[..., k].clamp_min(1e-12)
+    return bool((gap[bad] < 1e-5).all()), int(bad.sum())
+
+
+@pytest.mark.parametrize("grp,name", [("n1024", "mean"), ("n1024", "max"), ("k16", "mean"), ("k16", "max"), ("k8", "mean"), ("k32", "max")])
+def test_vnsmall_eval_at_config4_size_and_other_k_matches_reference(dev, golden, grp, name):
+    """pointcloud_n1024.pt, generated by the unmodified reference (tests/golden/make_golden_pointcloud1024.py): BASELINE config 4
+    at its own size (B=8 x 1024 points, k=20) and neighbourhoods of 16 / 8 / 32 through the product in eval mode (the fused
+    kernel, eqa_vnsmall_fwd) -- network output, Gram-Schmidt frame, canonical cloud, losses -- and the kNN kernel's neighbour
+    sets (reference: pointcloud/canonicalization_networks/equivariant_networks.py:15-33, 128-150; continuous_group.py:51-134)."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import _lib
+
+    c = golden("pointcloud_n1024.pt")[grp][name]
+    k, B, N = c["k"], c["B"], c["N"]
+    hp = types.SimpleNamespace(n_knn=k, pooling=c["pooling"])
+    net = ea.VNSmall(hp)
+    net.load_state_dict(c["state"])
+    net = net.to(dev).eval()
+    x = c["x"].to(dev)
+    lib = _lib.load()
+    if k == 20:
+        idx = torch.empty(B, N, k, dtype=torch.int32, device=dev)
+        _lib.check(lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, None), "eqa_vn_knn")
+        torch.cuda.synchronize()
+        ok, n_bad = _knn_sets_agree(idx, c["x"], c["knn_idx"], k)
+        assert ok, f"{n_bad} points disagree outside fp32 near-ties"
+    with torch.no_grad():
+        vec = net(x).cpu()
+    # max pooling: one argmax pick moved by a last-bit score difference changes the mean over N points by |dx| / N
+    tol = (2e-6 if c["pooling"] == "mean" else 2e-5) * max(c["vnsmall_out"].abs().max().item(), 1.0)
+    assert (vec - c["vnsmall_out"]).abs().max().item() <= tol + 1e-4 * tol, (grp, name, (vec - c["vnsmall_out"]).abs().max().item())
+    can = ea.EquivariantPointcloudCanonicalization(net, hp).to(dev).eval()
+    with torch.no_grad():
+        xc = can(x).cpu()
+    R = can.canonicalization_info_dict["group_element_matrix_representation"].cpu()
+    assert (R - c["rotation"]).abs().max().item() <= 1e-4
+    assert (xc - c["x_canonicalized"]).abs().max().item() <= 5e-4
+    assert torch.allclose(can.get_prior_regularization_loss().cpu(), c["prior_loss"], atol=1e-4)
+    assert torch.allclose(can.get_identity_metric().cpu(), c["identity_metric"], atol=1e-4)
+
+
+@pytest.mark.parametrize("grp", ["n1024", "k16"])
+def test_vnsmall_training_step_at_config4_size_matches_reference(dev, golden, grp):
+    """The training-mode forward + backward (fused first block and tail, csrc/vnsmall_train.hip / vnsmall_tail.hip) at B=8 x 1024
+    points against the reference's own step: output, running statistics after the step, parameter gradients of sum(out * w).
+    A VN-ReLU gate (<q, d> >= 0) that flips on a last-bit difference moves a gradient entry by O(1/(B N)) of its scale; with
+    8192 points the bound is 1 % of each gradient's scale."""
+    import equiadapt_amd as ea
+
+    t = golden("pointcloud_n1024.pt")[grp]["mean_train"]
+    hp = types.SimpleNamespace(n_knn=t["k"], pooling="mean")
+    net = ea.VNSmall(hp)
+    net.load_state_dict(t["state"])
+    net.dropout.p = 0.0
+    net = net.to(dev).train()
+    out = net(t["x"].to(dev))
+    assert torch.allclose(out.detach().cpu(), t["vnsmall_out"], atol=1e-5, rtol=1e-4)
+    (out * t["w"].to(dev)).sum().backward()
+    after = {k: v.cpu() for k, v in net.state_dict().items()}
+    for k, v in t["state_after"].items():
+        if v.dtype.is_floating_point:
+            assert torch.allclose(after[k], v, atol=1e-6, rtol=1e-5), k
+        else:
+            assert torch.equal(after[k], v), k
+    for n, p in net.named_parameters():
+        want = t["grads"].get(n)
+        if want is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0, n
+            continue
+        g = max(want.abs().max().item(), 1e-6)
+        assert (p.grad.cpu() - want).abs().max().item() <= 1e-2 * g, (n, (p.grad.cpu() - want).abs().max().item(), g)
