@@ -392,7 +392,8 @@ def leg_train_pointcloud(comm: Comm, steps: int, warmup: int, batch: int):
     return {"clouds_s": batch * comm.world * steps / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
             "batch_per_gpu": batch, "n_gpus": comm.world, "model": "EquivariantPointcloudCanonicalization(VNSmall k=20 mean) + PointNet(40 classes), fp32",
             "optimizer": "SGD x100 lr, momentum 0.9, wd 1e-4 (reference rule)", "parameters": n_params,
-            "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.world > 1 else 0.0,
+            "allreduce_MB_per_step": n_params * 4 / 1e6 if comm.backend == "nccl" else 0.0,
+            "ddp_wrapped": type(ddp).__name__ == "DistributedDataParallel",
             "per_rank_ms_per_step": [t / steps * 1e3 for t in per_rank], "final_loss": loss,
             "data": "synthetic ModelNet40-shaped (B,3,1024) normal clouds, labels uniform"}
 
@@ -612,6 +613,16 @@ def main():
                 ops.invert_action(f, gidx, th_i, fl_i, None)
             e1.record()
             torch.cuda.synchronize()
+            ga2_ms = e0.elapsed_time(e1) / reps
+            # the same two jobs in ONE launch (eqa_group_action_pair: job 1's first blocks fill the CUs job 0's tail leaves idle)
+            for _ in range(3):
+                ops.group_action_pair(x, f, gidx, th_c, fl_c, H // 2, th_i, fl_i, None)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                ops.group_action_pair(x, f, gidx, th_c, fl_c, H // 2, th_i, fl_i, None)
+            e1.record()
+            torch.cuda.synchronize()
             ga_ms = e0.elapsed_time(e1) / reps
         del xs, fs, x, f, can
         torch.cuda.empty_cache()
@@ -641,7 +652,9 @@ def main():
             "group_action": {"images_s_per_gpu": B / (ga_ms * 1e-3), "ms": ga_ms,
                              "achieved_GBs": ga_bytes / (ga_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "eqa_canon_transform_fwd + eqa_invert_action_fwd only, seeded random index"},
+                             "two_launches_ms": ga2_ms, "two_launches_frac_hbm_peak": ga_bytes / (ga2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "canonicalize x + invert f only, seeded random index: one eqa_group_action_pair launch "
+                                     "(two_launches_*: eqa_canon_transform_fwd then eqa_invert_action_fwd, bit-identical results)"},
             "self_check": self_check,
         })
         line["stages"] = stage_table(ktimes, B)

@@ -33,6 +33,7 @@ SIGNATURES = {
     "eqa_fold_edge_pad": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_canon_transform_fwd": (_int, [_vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
     "eqa_invert_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
+    "eqa_group_action_pair": (_int, [_vp] * 4 + [_int, _int] + [_vp] * 5 + [_int, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_orbit_expand_fwd": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
     "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 9 + [_vp]),

@@ -72,15 +72,16 @@ __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
 // Thread t owns 4 consecutive pixels of tile row t/8 (float4 stores, 128 B per 8 lanes).
 // Sampling arithmetic = torch affine_grid + grid_sample(bilinear, zeros, align_corners=True) on the
 // (Hp, Wp) frame, the frame itself being the edge-replicated (pad) and optionally h-flipped source.
+// `bz` = the block's image-group index (blockIdx.z of a single job; blockIdx.z minus the first job's groups in a pair launch).
 template <int CH, bool VEC>
-__global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kernel(const ActionArgs a) {
+__device__ __forceinline__ void group_action_body(const ActionArgs& a, const int bz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = kBox * kLdsStride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: row math stays on the SALU
-  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
+  const int n = bz * kXcd + (int)(blockIdx.x & (kXcd - 1));
   if (n >= a.n_out) return;
   const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
 
@@ -350,6 +351,24 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kerne
       }
     }
   }
+}
+
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kernel(const ActionArgs a) {
+  group_action_body<CH, VEC>(a, (int)blockIdx.z);
+}
+
+// Two jobs with the same tile grid in ONE launch (eqa_group_action_pair: canonicalize x / invert f with the same group
+// index): blocks [0, zsplit) of the z axis run job 0, the rest job 1.  The dispatcher walks z last, so job 1's first blocks
+// fill the CUs that job 0's tail leaves idle -- the ~12 us drain + launch gap between two dependent-looking launches
+// (they are independent) disappears.  Each block executes exactly one of the two bodies: no register or LDS cost.
+template <int CH, bool VEC>
+__global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_pair_kernel(const ActionArgs a0, const ActionArgs a1,
+                                                                                      const int zsplit) {
+  if ((int)blockIdx.z < zsplit)
+    group_action_body<CH, VEC>(a0, (int)blockIdx.z);
+  else
+    group_action_body<CH, VEC>(a1, (int)blockIdx.z - zsplit);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -667,6 +686,48 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
   if (C % 2 == 0) return launch_action_ch<2>(a, vec, st);
   return launch_action_ch<1>(a, vec, st);
 #endif
+}
+
+template <int CH>
+int launch_pair_ch(const ActionArgs& a0, const ActionArgs& a1, bool vec, hipStream_t st) {
+  const int tiles_x = (a0.OW + kTile - 1) / kTile, tiles_y = (a0.OH + kTile - 1) / kTile;
+  const int g0 = (a0.n_out + kXcd - 1) / kXcd, g1 = (a1.n_out + kXcd - 1) / kXcd;
+  if (tiles_y > 65535 || g0 + g1 > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)(g0 + g1));
+  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + ((a0.chan_map || a1.chan_map) ? kMaxMapG * sizeof(int) : 0);
+  if (vec)
+    hipLaunchKernelGGL((group_action_pair_kernel<CH, true>), grid, dim3(kThreads), lds, st, a0, a1, g0);
+  else
+    hipLaunchKernelGGL((group_action_pair_kernel<CH, false>), grid, dim3(kThreads), lds, st, a0, a1, g0);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+inline int action_ch(int C) { return C % 3 == 0 ? 3 : (C % 2 == 0 ? 2 : 1); }
+
+// canonicalize x (edge-padded frame, crop back) and invert f (whole frame, optional regular-representation roll) for the same
+// per-image group index.  One launch when the two jobs share the tile grid, the channel staging width and the store width
+// (always the case for x, f of the same H x W with 3 | C or equal parity); two launches otherwise -- same results either way.
+int launch_pair(const float* x, float* y, const float* theta_c, const int32_t* flags_c, int pad, int C, const float* f, float* out,
+                const float* theta_i, const int32_t* flags_i, const int32_t* chan_map, int G, int Cf, const int32_t* gidx, int E,
+                int B, int H, int W, void* stream) {
+  if (B == 0) return EQA_OK;
+  if (!gidx || !y || !out) return EQA_ERR_INVALID_ARG;
+  ActionArgs a0, a1;
+  int rc = fill_action_args(a0, x, y, gidx, theta_c, flags_c, nullptr, E, 1, B, B, C, H, W, pad, H, W, pad, pad);
+  if (rc != EQA_OK) return rc;
+  rc = fill_action_args(a1, f, out, gidx, theta_i, flags_i, chan_map, E, G, B, B, Cf, H, W, 0, H, W, 0, 0);
+  if (rc != EQA_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const bool v0 = (W % 4 == 0) && (((uintptr_t)y & 15) == 0), v1 = (W % 4 == 0) && (((uintptr_t)out & 15) == 0);
+  const int ch0 = EQA_FORCE_CH ? EQA_FORCE_CH : action_ch(C), ch1 = EQA_FORCE_CH ? EQA_FORCE_CH : action_ch(Cf);
+  if (ch0 == ch1 && v0 == v1) {
+    if (ch0 == 3) return launch_pair_ch<3>(a0, a1, v0, st);
+    if (ch0 == 2) return launch_pair_ch<2>(a0, a1, v0, st);
+    return launch_pair_ch<1>(a0, a1, v0, st);
+  }
+  rc = launch_action(x, y, gidx, theta_c, flags_c, nullptr, E, 1, B, B, C, H, W, pad, H, W, pad, pad, stream);
+  if (rc != EQA_OK) return rc;
+  return launch_action(f, out, gidx, theta_i, flags_i, chan_map, E, G, B, B, Cf, H, W, 0, H, W, 0, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1287,6 +1348,13 @@ int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const
   if (B == 0) return EQA_OK;
   if (!gidx) return EQA_ERR_INVALID_ARG;
   return launch_action(f, out, gidx, theta, flags, chan_map, num_elements, G, B, B, C, H, W, 0, H, W, 0, 0, stream);
+}
+
+int eqa_group_action_pair(const float* x, float* y, const float* theta_canon, const int32_t* flags_canon, int pad, int C,
+                          const float* f, float* out, const float* theta_inv, const int32_t* flags_inv, const int32_t* chan_map,
+                          int G, int Cf, const int32_t* gidx, int num_elements, int B, int H, int W, void* stream) {
+  return launch_pair(x, y, theta_canon, flags_canon, pad, C, f, out, theta_inv, flags_inv, chan_map, G, Cf, gidx, num_elements, B, H,
+                     W, stream);
 }
 
 int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int32_t* flags, int num_elements, int B,

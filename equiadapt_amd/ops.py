@@ -209,6 +209,31 @@ def invert_action(f: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flag
     return out
 
 
+def group_action_pair(x: torch.Tensor, f: torch.Tensor, gidx: torch.Tensor, theta_canon: torch.Tensor,
+                      flags_canon: Optional[torch.Tensor], pad: int, theta_inv: torch.Tensor, flags_inv: Optional[torch.Tensor],
+                      chan_map: Optional[torch.Tensor]):
+    """I5 + I7 in one launch (eqa_group_action_pair): (canon_transform(x, ...), invert_action(f, ...)) for the same group
+    index, bit-identical to the two separate calls.  x:(B,C,H,W), f:(B,Cf,H,W)."""
+    lib = _lib.load()
+    x, f = _need(x, "x"), _need(f, "feature_map")
+    gidx = _need(gidx, "gidx", torch.int32)
+    theta_canon, theta_inv = _need(theta_canon, "theta_canon"), _need(theta_inv, "theta_inv")
+    flags_canon, p_fc = _opt(flags_canon, "flags_canon", torch.int32)
+    flags_inv, p_fi = _opt(flags_inv, "flags_inv", torch.int32)
+    chan_map, p_map = _opt(chan_map, "chan_map", torch.int32)
+    G = chan_map.shape[1] if chan_map is not None else 1
+    B, C, H, W = x.shape
+    if f.shape[0] != B or tuple(f.shape[2:]) != (H, W) or theta_canon.shape[0] != theta_inv.shape[0]:
+        raise ValueError(f"group_action_pair: x {tuple(x.shape)} and f {tuple(f.shape)} must share batch and spatial size, and the tables their element count")
+    y, out = torch.empty_like(x), torch.empty_like(f)
+    with torch.cuda.device(x.device), _timed("group_action_pair"):
+        st = lib.eqa_group_action_pair(x.data_ptr(), y.data_ptr(), theta_canon.data_ptr(), p_fc, pad, C, f.data_ptr(), out.data_ptr(),
+                                       theta_inv.data_ptr(), p_fi, p_map, G, f.shape[1], gidx.data_ptr(), theta_canon.shape[0], B, H, W,
+                                       _stream())
+    _lib.check(st, "eqa_group_action_pair")
+    return y, out
+
+
 def orbit_expand(x: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int) -> torch.Tensor:
     """I8: all E group views of every image, element-major (eqa_orbit_expand_fwd)."""
     lib = _lib.load()

@@ -80,6 +80,20 @@ int eqa_invert_action_fwd(const float* f, float* out, const int32_t* gidx, const
                           int H, int W, void* stream);
 
 /*
+ * I5 + I7 in ONE launch, for callers that hold both tensors at the same time (a pipelined loop canonicalizing batch t+1
+ * while inverting the prediction of batch t; test-time evaluation; the transform-only benchmark): y = canonicalize(x)
+ * exactly as eqa_canon_transform_fwd and out = invert(f) exactly as eqa_invert_action_fwd, same gidx:(B) for both
+ * (discrete_group.py:204-215 and images/utils.py:54-89 of the reference, called back to back).
+ * x:(B,C,H,W), f:(B,Cf,H,W); theta_canon / flags_canon and theta_inv / flags_inv: the (E,6) / (E) tables of the two
+ * actions; chan_map:(E,G) or NULL.  Bit-identical to the two separate calls; when the two jobs cannot share a tile grid
+ * (different channel staging widths) the library issues the two launches itself.
+ */
+int eqa_group_action_pair(const float* x, float* y, const float* theta_canon, const int32_t* flags_canon, int pad, int C,
+                          const float* f, float* out, const float* theta_inv, const int32_t* flags_inv,
+                          const int32_t* chan_map, int G, int Cf, const int32_t* gidx, int num_elements, int B, int H,
+                          int W, void* stream);
+
+/*
  * I8 -- orbit expansion (group_augment): for every group element e,
  *   pad(edge) -> rotate(-deg_e) -> [hflip AFTER the rotation] -> center-crop(S), concatenated
  *   element-major: y[(e*B + b)] = action_e(x[b]).   x:(B,C,S,S) -> y:(E*B,C,S,S).

