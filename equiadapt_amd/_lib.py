@@ -54,10 +54,10 @@ SIGNATURES = {
     "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_uint32, _vp]),
     "eqa_vn_blocks": (_int, [_int]),
     "eqa_vn_knn": (_int, [_vp, _vp, _int, _int, _int, _vp]),
-    "eqa_vn_convpos_stats": (_int, [_vp, _vp, _vp, _vp, _int, _int, _vp]),
-    "eqa_vn_convpos_fwd": (_int, [_vp] * 7 + [_int, _int, _vp]),
-    "eqa_vn_convpos_bwd_reduce": (_int, [_vp] * 10 + [_int, _int, _vp]),
-    "eqa_vn_convpos_bwd_apply": (_int, [_vp] * 12 + [_int, _int, _vp]),
+    "eqa_vn_convpos_stats": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),
+    "eqa_vn_convpos_fwd": (_int, [_vp] * 7 + [_int, _int, _int, _vp]),
+    "eqa_vn_convpos_bwd_reduce": (_int, [_vp] * 10 + [_int, _int, _int, _vp]),
+    "eqa_vn_convpos_bwd_apply": (_int, [_vp] * 12 + [_int, _int, _int, _vp]),
     "eqa_vn_tail_blocks": (_int, [_int]),
     "eqa_vn_tail_partial_floats": (_int, [_int]),
     "eqa_vn_tail_pass": (_int, [_int] + [_vp] * 8 + [_int, _int, _vp]),

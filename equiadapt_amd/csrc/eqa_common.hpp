@@ -36,6 +36,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 #undef EQA_DPP_ADD
 
+extern int g_vn_kernel_choice;  // pointcloud.hip; eqa_set_option key 1
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
 // pooling.hip: part (B, nseg, C, 1 + 2(k-1)) row segments -> S (B, C, k, k) fp64; used by eqa_window_sums_nhwc and by the

@@ -1299,7 +1299,7 @@ extern "C" {
 
 int eqa_abi_version(void) { return EQA_ABI_VERSION; }
 
-int eqa_get_option(int key) { return key == 0 ? g_force_direct : EQA_ERR_INVALID_ARG; }
+int eqa_get_option(int key) { return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : EQA_ERR_INVALID_ARG; }
 
 int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad) {
   if (planes <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;
@@ -1323,6 +1323,10 @@ int eqa_fold_edge_pad(const float* gframe, float* gsrc, void* workspace, int pla
 int eqa_set_option(int key, int value) {
   if (key == 0) {
     g_force_direct = value ? 1 : 0;
+    return EQA_OK;
+  }
+  if (key == 1 && value >= 0 && value <= 2) {
+    eqa::g_vn_kernel_choice = value;
     return EQA_OK;
   }
   return EQA_ERR_INVALID_ARG;

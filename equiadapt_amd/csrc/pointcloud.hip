@@ -272,6 +272,204 @@ __global__ __launch_bounds__(kVnThreads, MAXPOOL ? 2 : EQA_VN_MIN_BLOCKS) void v
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same network with FOUR LANES PER POINT (vn_common.hpp, "quad" kernels) and any k <= 4 SEG: the quad scans the candidates
+// together (distributed sorted list), each lane pushes its share of the point's edges (ranks SEG sub + t < k) through conv_pos,
+// the pooled features are combined over the quad by DPP (sum, or first-maximum for VNMaxPool), conv1 / bn1 / conv2 are split
+// over the quad by OUTPUT channel (lane `sub` takes c = sub, sub + 4, ...; those weights are lane-dependent, so they come from a
+// re-packed copy in LDS: rows padded to 24 floats for ds_read_b128, rows 21..23 zero so that the idle sixth trip of lanes 1..3
+// contributes exact zeros), and lane `sub` finishes output channel `sub`.  4 x the waves of the one-thread-per-point kernel at
+// the same total instruction count: a batch of 64 clouds fills 4 waves per SIMD instead of one.
+// LDS floats: [4 Npad] cloud | [2 * 12 * 256] queue | tail parameters:
+//   W1f [24][24] | W1d [24][24] | (s1, t1, s2, t2) [24][4] | W2T [24][8] = (W2f[0..3][c], W2d[0..3][c]) | (s3, t3) [4][2]
+// ------------------------------------------------------------------------------------------------
+constexpr int kVnTailLds = 2 * 24 * 24 + 24 * 4 + 24 * 8 + 8;   // 1448 floats
+
+template <int SEG, bool MAXPOOL>
+__global__ __launch_bounds__(kVnQThreads, MAXPOOL ? 2 : 3) void vnsmall_fwd_quad_kernel(const float* __restrict__ x,
+                                                                                         const float* __restrict__ prm,
+                                                                                         float* __restrict__ partial, int N, int k,
+                                                                                         int nblk) {
+  extern __shared__ __attribute__((aligned(16))) float vn_smem[];
+  const int b = blockIdx.y, tid = threadIdx.x, sub = tid & 3;
+  const int Npad = (N + 15) & ~15;
+  float4* pts = reinterpret_cast<float4*>(vn_smem);
+  float2* queue = reinterpret_cast<float2*>(vn_smem + 4 * Npad);
+  float* tl = vn_smem + 4 * Npad + 2 * kVnQSlots * kVnQThreads;
+  __shared__ float s_part[kVnQThreads / 64][12];
+  vn_stage_cloud_quad(x + (size_t)b * 3 * N, N, Npad, pts, tid);
+  // tail parameters, re-packed (see above)
+  for (int i = tid; i < kVnTailLds; i += kVnQThreads) {
+    float v = 0.f;
+    if (i < 2 * 576) {                       // W1f | W1d rows
+      const int m = i / 576, r = (i - m * 576) / 24, a = i % 24;
+      if (r < kVnC && a < kVnC) v = prm[(m ? 609 : 168) + r * kVnC + a];
+    } else if (i < 2 * 576 + 96) {           // (s1, t1, s2, t2)[c]
+      const int c = (i - 1152) >> 2, w = (i - 1152) & 3;
+      if (c < kVnC) v = prm[(w == 0 ? 1050 : w == 1 ? 1071 : w == 2 ? 1092 : 1113) + c];
+    } else if (i < 2 * 576 + 96 + 192) {     // W2T[c][0..3] = W2f[o][c], [4..7] = W2d[o][c]
+      const int c = (i - 1248) >> 3, w = (i - 1248) & 7;
+      if (c < kVnC) v = prm[(w < 4 ? 1134 : 1218) + (w & 3) * kVnC + c];
+    } else {                                 // (s3, t3)[o]
+      const int o = (i - 1440) >> 1, w = (i - 1440) & 1;
+      v = prm[(w ? 1306 : 1302) + o];
+    }
+    tl[i] = v;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * kVnQPts + (tid >> 2);
+  const bool active = n < N;
+  const float4 c4 = pts[active ? n : N - 1];
+  const V3 ctr = v3(c4.x, c4.y, c4.z);
+  float bv[SEG];
+  int bi[SEG];
+  vn_knn_quad<SEG>(pts, Npad, queue, ctr, c4.w, tid, bv, bi);
+
+  // ---- conv_pos on this lane's edges (ranks SEG * sub + t < k)
+  V3 pooled[kVnC];
+  float best[MAXPOOL ? kVnC : 1];
+#pragma unroll
+  for (int c = 0; c < kVnC; ++c) pooled[c] = v3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int c = 0; c < (MAXPOOL ? kVnC : 1); ++c) best[c] = -INFINITY;
+  const float* Wf = prm;
+  const float* Wd = prm + 63;
+  const float* bsc = prm + 126;
+  const float* bsh = prm + 147;
+#pragma unroll 1
+  for (int t = 0; t < SEG; ++t) {
+    if (!__any(SEG * sub + t < k)) break;   // wave-uniform
+    asm volatile("" ::: "memory");          // keep the weights in the scalar cache, not hoisted into VGPRs (see above)
+    int j = bi[0];
+#pragma unroll
+    for (int u = 1; u < SEG; ++u) j = (t == u) ? bi[u] : j;
+    const bool valid = SEG * sub + t < k;
+    const float m = valid ? 1.0f : 0.0f;
+    const float4 nb4 = pts[j];
+    const V3 nb = v3(nb4.x, nb4.y, nb4.z);
+    const V3 f0 = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);
+    const V3 f2 = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);
+    V3 qe[MAXPOOL ? kVnC : 1];
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      const float a0 = Wf[c * 3], a1 = Wf[c * 3 + 1], a2 = Wf[c * 3 + 2];
+      const float d0 = Wd[c * 3], d1 = Wd[c * 3 + 1], d2 = Wd[c * 3 + 2];
+      V3 q = v3(a0 * f0.x + a1 * ctr.x + a2 * f2.x, a0 * f0.y + a1 * ctr.y + a2 * f2.y, a0 * f0.z + a1 * ctr.z + a2 * f2.z);
+      const V3 d = v3(d0 * f0.x + d1 * ctr.x + d2 * f2.x, d0 * f0.y + d1 * ctr.y + d2 * f2.y, d0 * f0.z + d1 * ctr.z + d2 * f2.z);
+      q = vn_relu(vn_bn(q, bsc[c], bsh[c]), d);
+      if (MAXPOOL) {
+        qe[c] = q;
+      } else {
+        pooled[c].x += m * q.x; pooled[c].y += m * q.y; pooled[c].z += m * q.z;
+      }
+    }
+    if (MAXPOOL) {
+      const float* Wp = prm + kVnParams;
+#pragma unroll
+      for (int c = 0; c < kVnC; ++c) {
+        if (c % 3 == 0) asm volatile("" ::: "memory");
+        V3 dp = v3(0.f, 0.f, 0.f);
+#pragma unroll
+        for (int a = 0; a < kVnC; ++a) {
+          const float w = Wp[c * kVnC + a];
+          dp.x += w * qe[a].x; dp.y += w * qe[a].y; dp.z += w * qe[a].z;
+        }
+        const float sc = qe[c].x * dp.x + qe[c].y * dp.y + qe[c].z * dp.z;
+        const bool take = valid && sc > best[c];   // strict: the first maximal edge (lowest rank) wins, as torch.max does
+        best[c] = take ? sc : best[c];
+        pooled[c].x = take ? qe[c].x : pooled[c].x;
+        pooled[c].y = take ? qe[c].y : pooled[c].y;
+        pooled[c].z = take ? qe[c].z : pooled[c].z;
+      }
+    }
+  }
+  // ---- the point's pooled features in all four lanes
+  if (MAXPOOL) {
+    // lane `sub` holds the ranks below lane sub + 1's: on equal scores the lower lane's pick stands
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      {
+        const float os = vn_dpp_f<0xB1>(best[c]);
+        const float ox = vn_dpp_f<0xB1>(pooled[c].x), oy = vn_dpp_f<0xB1>(pooled[c].y), oz = vn_dpp_f<0xB1>(pooled[c].z);
+        const bool take = (sub & 1) ? (os >= best[c]) : (os > best[c]);
+        best[c] = take ? os : best[c];
+        pooled[c].x = take ? ox : pooled[c].x; pooled[c].y = take ? oy : pooled[c].y; pooled[c].z = take ? oz : pooled[c].z;
+      }
+      {
+        const float os = vn_dpp_f<0x4E>(best[c]);
+        const float ox = vn_dpp_f<0x4E>(pooled[c].x), oy = vn_dpp_f<0x4E>(pooled[c].y), oz = vn_dpp_f<0x4E>(pooled[c].z);
+        const bool take = (sub & 2) ? (os >= best[c]) : (os > best[c]);
+        pooled[c].x = take ? ox : pooled[c].x; pooled[c].y = take ? oy : pooled[c].y; pooled[c].z = take ? oz : pooled[c].z;
+      }
+    }
+  } else {
+    const float inv_k = 1.0f / (float)k;
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      pooled[c].x = vn_quad_sum(pooled[c].x) * inv_k;
+      pooled[c].y = vn_quad_sum(pooled[c].y) * inv_k;
+      pooled[c].z = vn_quad_sum(pooled[c].z) * inv_k;
+    }
+  }
+
+  // ---- conv1 + its VN-BN + ReLU + bn1 for the output channels c = sub, sub + 4, ..., folded into conv2's two maps
+  V3 q2[4], d2[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { q2[o] = v3(0.f, 0.f, 0.f); d2[o] = v3(0.f, 0.f, 0.f); }
+#pragma unroll 1
+  for (int ci = 0; ci < 6; ++ci) {
+    const int c = sub + 4 * ci;   // <= 23; rows 21..23 are zero
+    const float4* rf = reinterpret_cast<const float4*>(tl + c * 24);
+    const float4* rd = reinterpret_cast<const float4*>(tl + 576 + c * 24);
+    V3 q = v3(0.f, 0.f, 0.f), d = v3(0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a4 = 0; a4 < 6; ++a4) {
+      const float4 wf = rf[a4], wd = rd[a4];
+      const float wfa[4] = {wf.x, wf.y, wf.z, wf.w}, wda[4] = {wd.x, wd.y, wd.z, wd.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = a4 * 4 + u;
+        if (a < kVnC) {
+          q.x += wfa[u] * pooled[a].x; q.y += wfa[u] * pooled[a].y; q.z += wfa[u] * pooled[a].z;
+          d.x += wda[u] * pooled[a].x; d.y += wda[u] * pooled[a].y; d.z += wda[u] * pooled[a].z;
+        }
+      }
+    }
+    const float4 st = *reinterpret_cast<const float4*>(tl + 1152 + c * 4);
+    q = vn_relu(vn_bn(q, st.x, st.y), d);
+    const V3 hc = vn_bn(q, st.z, st.w);
+    const float4 w2f = *reinterpret_cast<const float4*>(tl + 1248 + c * 8), w2d = *reinterpret_cast<const float4*>(tl + 1248 + c * 8 + 4);
+    const float wfo[4] = {w2f.x, w2f.y, w2f.z, w2f.w}, wdo[4] = {w2d.x, w2d.y, w2d.z, w2d.w};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+      q2[o].x += wfo[o] * hc.x; q2[o].y += wfo[o] * hc.y; q2[o].z += wfo[o] * hc.z;
+      d2[o].x += wdo[o] * hc.x; d2[o].y += wdo[o] * hc.y; d2[o].z += wdo[o] * hc.z;
+    }
+  }
+  // ---- conv2's VN-BN + ReLU: lane `sub` finishes output channel `sub`
+  V3 qs = v3(0.f, 0.f, 0.f), ds = v3(0.f, 0.f, 0.f);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const float qx = vn_quad_sum(q2[o].x), qy = vn_quad_sum(q2[o].y), qz = vn_quad_sum(q2[o].z);
+    const float dx = vn_quad_sum(d2[o].x), dy = vn_quad_sum(d2[o].y), dz = vn_quad_sum(d2[o].z);
+    if (sub == o) { qs = v3(qx, qy, qz); ds = v3(dx, dy, dz); }
+  }
+  const V3 qo = vn_relu(vn_bn(qs, tl[1440 + 2 * sub], tl[1441 + 2 * sub]), ds);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    const bool mine = active && sub == o;
+    const float sx = wave_sum_f(mine ? qo.x : 0.f), sy = wave_sum_f(mine ? qo.y : 0.f), sz = wave_sum_f(mine ? qo.z : 0.f);
+    if ((tid & 63) == 0) { s_part[tid >> 6][o * 3] = sx; s_part[tid >> 6][o * 3 + 1] = sy; s_part[tid >> 6][o * 3 + 2] = sz; }
+  }
+  __syncthreads();
+  if (tid < 12) {
+    float acc = 0.f;
+#pragma unroll
+    for (int w = 0; w < kVnQThreads / 64; ++w) acc += s_part[w][tid];
+    partial[((size_t)b * nblk + blockIdx.x) * 12 + tid] = acc;
+  }
+}
+
 // (B, nblk, 12) partial sums -> (B,3,3): mean over the N points, first three of the four output channels
 __global__ void vnsmall_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int nblk, float inv_n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,6 +527,13 @@ __global__ __launch_bounds__(kThreads) void rigid_rows_kernel(const float* __res
 
 }  // namespace
 
+// eqa_set_option key 1: 0 = choose the VNSmall forward kernel by size (default), 1 = always one thread per point (k = 20 only),
+// 2 = always four lanes per point
+int eqa::g_vn_kernel_choice = 0;
+#ifndef EQA_VN_SINGLE_MIN_POINTS
+#define EQA_VN_SINGLE_MIN_POINTS (1LL << 62)   // B * N from which the one-thread-per-point kernel is preferred (set from measurements)
+#endif
+
 extern "C" {
 
 int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int transpose, void* stream) {
@@ -346,22 +551,41 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
 
 int64_t eqa_vnsmall_workspace_bytes(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
-  return (int64_t)B * ((N + kVnThreads - 1) / kVnThreads) * 12 * (int64_t)sizeof(float);
+  return (int64_t)B * ((N + kVnQPts - 1) / kVnQPts) * 12 * (int64_t)sizeof(float);   // the finer of the two block sizes
 }
 
 int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
                     void* stream) {
-  if (!x || !params || !out || !workspace || B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
-  if (k != kVnK || (pooling != 0 && pooling != 1) || N < kVnK) return EQA_ERR_UNSUPPORTED;  // fused path: k = 20; pooling 0 mean, 1 max
-  const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
-  if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  if (!x || !params || !out || !workspace || B < 0 || N <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
+  if (k > 32 || (pooling != 0 && pooling != 1) || N < k) return EQA_ERR_UNSUPPORTED;  // pooling 0 mean, 1 max
+  if (B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
-  const int nblk = (N + kVnThreads - 1) / kVnThreads;
-  if (pooling == 1)
-    hipLaunchKernelGGL(vnsmall_fwd_kernel<true>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
-  else
-    hipLaunchKernelGGL(vnsmall_fwd_kernel<false>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  // one thread per point: fewer, longer instruction streams -- ahead once the batch alone fills the chip (measured crossover)
+  const bool single = k == kVnK && (g_vn_kernel_choice == 1 || (g_vn_kernel_choice == 0 && (long long)B * N >= EQA_VN_SINGLE_MIN_POINTS));
+  int nblk;
+  if (single) {
+    const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
+    if (lds > 96 * 1024) return EQA_ERR_UNSUPPORTED;
+    nblk = (N + kVnThreads - 1) / kVnThreads;
+    if (pooling == 1)
+      hipLaunchKernelGGL(vnsmall_fwd_kernel<true>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+    else
+      hipLaunchKernelGGL(vnsmall_fwd_kernel<false>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
+  } else {
+    const size_t lds = ((size_t)4 * ((N + 15) & ~15) + 2 * kVnQSlots * kVnQThreads + kVnTailLds) * sizeof(float);
+    if (lds > 128 * 1024) return EQA_ERR_UNSUPPORTED;
+    nblk = (N + kVnQPts - 1) / kVnQPts;
+    const dim3 grid(nblk, B), blk(kVnQThreads);
+    float* ws = (float*)workspace;
+    if (k <= 20) {
+      if (pooling == 1) hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<5, true>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+      else hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<5, false>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+    } else {
+      if (pooling == 1) hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<8, true>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+      else hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<8, false>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+    }
+  }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
   return launch_status();

@@ -168,4 +168,118 @@ __device__ __forceinline__ void vn_knn(const float4* pts, int Npad, float2* queu
   drain();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Four lanes per point ("quad" kernels).  One thread per point leaves a batch of 64 clouds with one wave per SIMD, each wave a
+// single dependent instruction stream (215 k clouds/s at B = 64 against 555 k at B = 2048).  Here the four lanes of a DPP quad share
+// a point: lane q scans the candidates j = q (mod 4) and the point's sorted neighbour list is DISTRIBUTED over the quad -- lane q
+// holds ranks [SEG q, SEG q + SEG) -- so an insertion is a SEG-step chain per lane instead of a 4 SEG-step one, the threshold
+// (the list's last entry, lane 3) is exact for all four scanners, there is no merge step, and at the end every lane already
+// owns its share of the point's edges.  SEG = 5 serves k <= 20, SEG = 8 serves k <= 32; a runtime k < 4 SEG uses the ranks < k.
+//
+// Insertion of a candidate (v, j) that all four lanes see (vector_neuron kNN = k largest scores, strict '>': on equal scores the
+// entry inserted first stays in front):  with pv = the OLD last entry of the previous lane's segment (+inf for lane 0),
+//   v > pv : the candidate lands before this lane's segment, whose entries all move down by one: the incoming element is pv;
+//   else   : the incoming element is the candidate itself, placed in front of the first entry it beats (if any).
+// From the insertion point on every entry moves down (a sticky swap flag), so what leaves a segment is always its old last entry,
+// which is exactly what the next lane takes in.  (Emulated against a stable sort in tools/knn_quad_model.py.)
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kVnQThreads = 256;                  // 64 points per block
+constexpr int kVnQPts = kVnQThreads / 4;
+constexpr int kVnQSlots = 12;                     // pending candidates per lane (LDS, 8 bytes each)
+
+template <int CTRL>
+__device__ __forceinline__ float vn_dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int vn_dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int kQuadPrev = 0x90;  // quad_perm [0,0,1,2]: lane q reads lane q - 1 (lane 0 itself)
+// sum over the four lanes of a quad, returned to all of them
+__device__ __forceinline__ float vn_quad_sum(float v) {
+  v += vn_dpp_f<0xB1>(v);  // [1,0,3,2]
+  v += vn_dpp_f<0x4E>(v);  // [2,3,0,1]
+  return v;
+}
+
+// cloud -> LDS as float4 (x, y, z, |p|^2), padded with never-selected points to a multiple of 16
+__device__ __forceinline__ void vn_stage_cloud_quad(const float* __restrict__ xb, int N, int Npad, float4* pts, int tid) {
+  for (int i = tid; i < Npad; i += kVnQThreads) {
+    if (i < N) {
+      const float a = xb[i], c = xb[N + i], d = xb[2 * (size_t)N + i];
+      pts[i] = make_float4(a, c, d, a * a + c * c + d * d);
+    } else {
+      pts[i] = make_float4(0.f, 0.f, 0.f, INFINITY);
+    }
+  }
+}
+
+// The point's 4 SEG nearest neighbours, distributed: on return lane `sub` of the quad holds ranks [SEG sub, SEG sub + SEG) in
+// (bv, bi), best first.  queue: LDS, [kVnQSlots][kVnQThreads] float2, this BLOCK's base.
+template <int SEG>
+__device__ __forceinline__ void vn_knn_quad(const float4* pts, int Npad, float2* queue, const V3& ctr, float cn, int tid,
+                                            float (&bv)[SEG], int (&bi)[SEG]) {
+  const int sub = tid & 3;
+#pragma unroll
+  for (int t = 0; t < SEG; ++t) { bv[t] = -INFINITY; bi[t] = 0; }
+  auto score = [&](const float4& p) {
+    const float inner = -2.0f * (ctr.x * p.x + ctr.y * p.y + ctr.z * p.z);
+    return (-p.w - inner) - cn;
+  };
+  auto insert = [&](float v, int j) {   // v, j uniform over the quad; v = -inf: no candidate
+    float pv = vn_dpp_f<kQuadPrev>(bv[SEG - 1]);
+    const int pi = vn_dpp_i<kQuadPrev>(bi[SEG - 1]);
+    pv = sub == 0 ? INFINITY : pv;
+    bool sw = v > pv;
+    float cv = sw ? pv : v;
+    int ci = sw ? pi : j;
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+      sw = sw || (cv > bv[t]);
+      const float tv = bv[t];
+      const int ti = bi[t];
+      bv[t] = sw ? cv : tv;
+      bi[t] = sw ? ci : ti;
+      cv = sw ? tv : cv;
+      ci = sw ? ti : ci;
+    }
+  };
+  float thr = -INFINITY;   // the list's last entry (lane 3's last): a candidate must beat it
+  int cnt = 0;
+  float2* const myq = queue + tid;
+  const float2* const quadq = queue + (tid & ~3);
+  auto drain = [&]() {
+#pragma unroll 1
+    for (int s = 0; s < kVnQSlots; ++s) {
+      if (!__any(s < cnt)) break;   // wave-uniform
+      const float2 e0 = quadq[s * kVnQThreads], e1 = quadq[s * kVnQThreads + 1], e2 = quadq[s * kVnQThreads + 2],
+                   e3 = quadq[s * kVnQThreads + 3];
+      const int c0 = vn_dpp_i<0x00>(cnt), c1 = vn_dpp_i<0x55>(cnt), c2 = vn_dpp_i<0xAA>(cnt), c3 = vn_dpp_i<0xFF>(cnt);
+      insert(s < c0 ? e0.x : -INFINITY, __float_as_int(e0.y));
+      insert(s < c1 ? e1.x : -INFINITY, __float_as_int(e1.y));
+      insert(s < c2 ? e2.x : -INFINITY, __float_as_int(e2.y));
+      insert(s < c3 ? e3.x : -INFINITY, __float_as_int(e3.y));
+    }
+    cnt = 0;
+    thr = vn_dpp_f<0xFF>(bv[SEG - 1]);
+  };
+  auto offer = [&](float v, int j) {
+    if (v > thr) {
+      myq[cnt * kVnQThreads] = make_float2(v, __int_as_float(j));
+      ++cnt;
+    }
+  };
+  for (int j0 = 0; j0 < Npad; j0 += 16) {
+    const int j = j0 + sub;
+    const float4 p0 = pts[j], p1 = pts[j + 4], p2 = pts[j + 8], p3 = pts[j + 12];
+    offer(score(p0), j);
+    offer(score(p1), j + 4);
+    offer(score(p2), j + 8);
+    offer(score(p3), j + 12);
+    if (__any(cnt > kVnQSlots - 4)) drain();  // wave-uniform
+  }
+  drain();
+}
+
 }  // namespace

@@ -69,23 +69,27 @@ __device__ __forceinline__ void vn_block_finish(const float* s_red, int total, f
   }
 }
 
-__global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(const float* __restrict__ x, int32_t* __restrict__ idx,
-                                                                             int N) {
+// Four lanes per point (vn_common.hpp): the quad's distributed sorted list IS the neighbour list, lane `sub` stores the ranks
+// [SEG sub, SEG sub + SEG) below k.  (One thread per point this was the largest kernel of a training step at B = 64: 157 us.)
+template <int SEG>
+__global__ __launch_bounds__(kVnQThreads, 4) void vn_knn_kernel(const float* __restrict__ x, int32_t* __restrict__ idx, int N, int k) {
   extern __shared__ __attribute__((aligned(16))) float vn_smem[];
   float4* pts = reinterpret_cast<float4*>(vn_smem);
-  const int b = blockIdx.y, tid = threadIdx.x;
-  const int Npad = (N + 3) & ~3;
-  vn_stage_cloud(x + (size_t)b * 3 * N, N, Npad, pts, tid);
+  const int b = blockIdx.y, tid = threadIdx.x, sub = tid & 3;
+  const int Npad = (N + 15) & ~15;
+  vn_stage_cloud_quad(x + (size_t)b * 3 * N, N, Npad, pts, tid);
   __syncthreads();
-  const int n = blockIdx.x * kVnThreads + tid;
+  const int n = blockIdx.x * kVnQPts + (tid >> 2);
   const bool active = n < N;
   const float4 c4 = pts[active ? n : N - 1];
-  int bi[kVnK];
-  vn_knn(pts, Npad, reinterpret_cast<float2*>(vn_smem + 4 * Npad) + tid, v3(c4.x, c4.y, c4.z), c4.w, bi);
+  float bv[SEG];
+  int bi[SEG];
+  vn_knn_quad<SEG>(pts, Npad, reinterpret_cast<float2*>(vn_smem + 4 * Npad), v3(c4.x, c4.y, c4.z), c4.w, tid, bv, bi);
   if (active) {
-    int32_t* o = idx + ((size_t)b * N + n) * kVnK;
+    int32_t* o = idx + ((size_t)b * N + n) * k;
 #pragma unroll
-    for (int t = 0; t < kVnK; ++t) o[t] = bi[t];
+    for (int t = 0; t < SEG; ++t)
+      if (SEG * sub + t < k) o[SEG * sub + t] = bi[t];
   }
 }
 
@@ -93,8 +97,9 @@ __global__ __launch_bounds__(kVnThreads, EQA_VN_MIN_BLOCKS) void vn_knn_kernel(c
 // clouds is 65 k threads = one wave per SIMD walking 20 edges x 21 channels of dependent arithmetic (the four passes took
 // 0.05 + 0.13 + 0.15 + 0.19 ms); split, there are four waves per SIMD and a quarter of the chain each.  Sums over a point's
 // edges: the block sums already cover all lanes; the forward pass adds the four lanes of a quad with two DPP quad permutes.
-constexpr int kVnSplit = 4, kVnEdges = kVnK / kVnSplit, kVnPts = kVnThreads / kVnSplit;
-static_assert(kVnSplit * kVnEdges == kVnK, "the edges divide evenly over the lanes of a point");
+// Any k <= 32: lane `sub` takes the edges [E sub, min(E sub + E, k)), E = ceil(k / 4); the kernels are instantiated for E <= 5
+// (k <= 20; k = 20 is E = 5 exactly, every lane busy) and E <= 8 (k <= 32).
+constexpr int kVnSplit = 4, kVnPts = kVnThreads / kVnSplit;
 
 // common prologue of the four conv_pos passes: cloud in LDS, this thread's point and its share of the neighbour list
 #define VN_PASS_PROLOGUE                                                                           \
@@ -108,24 +113,28 @@ static_assert(kVnSplit * kVnEdges == kVnK, "the edges divide evenly over the lan
   const bool active = n < N;                                                                       \
   const float4 c4 = pts[active ? n : N - 1];                                                       \
   const V3 ctr = v3(c4.x, c4.y, c4.z);                                                             \
-  const int32_t* nbr = idx + ((size_t)b * N + (active ? n : N - 1)) * kVnK + sub * kVnEdges;
+  const int edges = (k + kVnSplit - 1) / kVnSplit;                                                 \
+  const int cnt = min(max(k - sub * edges, 0), edges);                                             \
+  const int32_t* nbr = idx + ((size_t)b * N + (active ? n : N - 1)) * k + min(sub * edges, k - 1);
 
+template <int EMAX>
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                                      const float* __restrict__ Wf, float* __restrict__ partial,
-                                                                     int N) {
+                                                                     int N, int k) {
   __shared__ float s_red[(kVnThreads / 64) * 2 * kVnC];
   VN_PASS_PROLOGUE
   float acc[2 * kVnC];
 #pragma unroll
   for (int i = 0; i < 2 * kVnC; ++i) acc[i] = 0.f;
 #pragma unroll 1
-  for (int t = 0; t < kVnEdges; ++t) {
+  for (int t = 0; t < edges; ++t) {
     asm volatile("" ::: "memory");  // keep the weights in the scalar cache, not hoisted into VGPRs (see pointcloud.hip)
-    const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
+    const bool live = active && t < cnt;
+    const VnEdge e = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
 #pragma unroll
     for (int c = 0; c < kVnC; ++c) {
       const V3 q = vn_mix(Wf + 3 * c, e);
-      const float nr = active ? sqrtf(dot3(q, q)) + kVnEps : 0.f;
+      const float nr = live ? sqrtf(dot3(q, q)) + kVnEps : 0.f;
       acc[2 * c] += nr;
       acc[2 * c + 1] += nr * nr;
     }
@@ -133,22 +142,24 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const floa
   vn_block_sum<2 * kVnC>(acc, s_red, partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC));
 }
 
+template <int EMAX>
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                                    const float* __restrict__ Wf, const float* __restrict__ Wd,
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                   float* __restrict__ pooled, int N) {
+                                                                   float* __restrict__ pooled, int N, int k) {
   VN_PASS_PROLOGUE
   V3 acc[kVnC];
 #pragma unroll
   for (int c = 0; c < kVnC; ++c) acc[c] = v3(0.f, 0.f, 0.f);
 #pragma unroll 1
-  for (int t = 0; t < kVnEdges; ++t) {
+  for (int t = 0; t < edges; ++t) {
     asm volatile("" ::: "memory");
-    const VnEdge e = vn_edge(ctr, pts[nbr[t]]);
+    const float m = t < cnt ? 1.0f : 0.0f;   // (k = 20: every lane has its five edges and m == 1 throughout)
+    const VnEdge e = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
 #pragma unroll
     for (int c = 0; c < kVnC; ++c) {
       const V3 q = vn_relu(vn_bn(vn_mix(Wf + 3 * c, e), scale[c], shift[c]), vn_mix(Wd + 3 * c, e));
-      acc[c].x += q.x; acc[c].y += q.y; acc[c].z += q.z;
+      acc[c].x += m * q.x; acc[c].y += m * q.y; acc[c].z += m * q.z;
     }
   }
   // the four lanes of a point: butterfly over the quad, every lane ends up with the point's sums; lane `sub` stores channels
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float*
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));  // [2,3,0,1]
     return v;
   };
-  const float inv_k = 1.0f / (float)kVnK;
+  const float inv_k = 1.0f / (float)k;
   float* o = pooled + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);  // (B, 21, 3, N)
 #pragma unroll
   for (int c = 0; c < kVnC; ++c) {
@@ -177,19 +188,20 @@ __device__ __forceinline__ VnGrad vn_edge_grad(const float* __restrict__ wf, con
   return vn_gate_grad(vn_mix(wf, e), vn_mix(wd, e), scale, shift, g_out);
 }
 
+template <int EMAX>
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                                           const float* __restrict__ Wf, const float* __restrict__ Wd,
                                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                           const float* __restrict__ gpool, float* __restrict__ partial,
-                                                                          int N) {
+                                                                          int N, int k) {
   __shared__ float s_red[(kVnThreads / 64) * 2 * kVnC];   // per wave, all channels: ONE barrier after the channel loop, not two per channel
   VN_PASS_PROLOGUE
-  const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;  // idle threads contribute nothing
+  const float inv_k = active ? 1.0f / (float)k : 0.0f;  // idle threads contribute nothing
   const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
-  int nb[kVnEdges];
+  int nb[EMAX];
 #pragma unroll
-  for (int t = 0; t < kVnEdges; ++t) nb[t] = nbr[t];
+  for (int t = 0; t < EMAX; ++t) nb[t] = nbr[t < cnt ? t : 0];
   float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC);
   // channel by channel (the output gradient of a channel is the same for all k edges of the point): two accumulators live
 #pragma unroll 1
@@ -198,10 +210,12 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
     float acc[2] = {0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < kVnEdges; ++t) {
-      const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, vn_edge(ctr, pts[nb[t]]), sc, sh, g_out);
-      acc[0] += r.g_nbn;
-      acc[1] += r.g_nbn * (r.nr - mu) * rs;
+    for (int t = 0; t < EMAX; ++t) {
+      if (t < cnt) {   // (k = 20, EMAX = 5: always true)
+        const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, vn_edge(ctr, pts[nb[t]]), sc, sh, g_out);
+        acc[0] += r.g_nbn;
+        acc[1] += r.g_nbn * (r.nr - mu) * rs;
+      }
     }
     vn_wave_part<2>(acc, s_red, 2 * kVnC, 2 * c);
   }
@@ -211,20 +225,21 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_reduce_kernel(const
 // dW_f[c][i] = sum <g_q, f_i>, dW_d[c][i] = sum <g_d, f_i>;  g_q = dL/dq through the direction u = q/n and through the norm:
 //   g_n = gamma rstd (g_nbn - m1 - nhat m2)   (m1 = sum g_nbn / M, m2 = sum g_nbn nhat / M; both 0 with running statistics)
 //   g_q = (g_u - u <g_u, q> / |q|) / n + g_n q / |q|,   g_u = g_qn * nbn
+template <int EMAX>
 __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
                                                                          const float* __restrict__ Wf, const float* __restrict__ Wd,
                                                                          const float* __restrict__ scale, const float* __restrict__ shift,
                                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                          const float* __restrict__ m1, const float* __restrict__ m2,
                                                                          const float* __restrict__ gpool, float* __restrict__ partial,
-                                                                         int N) {
+                                                                         int N, int k) {
   __shared__ float s_red[(kVnThreads / 64) * 6 * kVnC];
   VN_PASS_PROLOGUE
-  const float inv_k = active ? 1.0f / (float)kVnK : 0.0f;
+  const float inv_k = active ? 1.0f / (float)k : 0.0f;
   const float* gp = gpool + (size_t)b * kVnC * 3 * N + (active ? n : N - 1);
-  int nb[kVnEdges];
+  int nb[EMAX];
 #pragma unroll
-  for (int t = 0; t < kVnEdges; ++t) nb[t] = nbr[t];
+  for (int t = 0; t < EMAX; ++t) nb[t] = nbr[t < cnt ? t : 0];
   float* out = partial + ((size_t)b * gridDim.x + blockIdx.x) * (6 * kVnC);  // [c][W_f 0..2, W_d 0..2]
 #pragma unroll 1
   for (int c = 0; c < kVnC; ++c) {
@@ -232,27 +247,29 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_bwd_apply_kernel(const 
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c], mm1 = m1[c], mm2 = m2[c];
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < kVnEdges; ++t) {
-      const VnEdge e = vn_edge(ctr, pts[nb[t]]);
-      const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, e, sc, sh, g_out);
-      const V3 g_q = vn_norm_input_grad(r, sc, mu, rs, mm1, mm2, active);
-      acc[0] += dot3(g_q, e.f0);
-      acc[1] += dot3(g_q, e.f1);
-      acc[2] += dot3(g_q, e.f2);
-      acc[3] += dot3(r.g_d, e.f0);
-      acc[4] += dot3(r.g_d, e.f1);
-      acc[5] += dot3(r.g_d, e.f2);
+    for (int t = 0; t < EMAX; ++t) {
+      if (t < cnt) {
+        const VnEdge e = vn_edge(ctr, pts[nb[t]]);
+        const VnGrad r = vn_edge_grad(Wf + 3 * c, Wd + 3 * c, e, sc, sh, g_out);
+        const V3 g_q = vn_norm_input_grad(r, sc, mu, rs, mm1, mm2, active);
+        acc[0] += dot3(g_q, e.f0);
+        acc[1] += dot3(g_q, e.f1);
+        acc[2] += dot3(g_q, e.f2);
+        acc[3] += dot3(r.g_d, e.f0);
+        acc[4] += dot3(r.g_d, e.f1);
+        acc[5] += dot3(r.g_d, e.f2);
+      }
     }
     vn_wave_part<6>(acc, s_red, 6 * kVnC, 6 * c);
   }
   vn_block_finish(s_red, 6 * kVnC, out);
 }
 
-inline int vn_check(const void* x, const void* idx, int B, int N, size_t& lds, bool with_queue) {
-  if (B < 0 || N <= 0) return EQA_ERR_INVALID_ARG;
-  if (N < kVnK) return EQA_ERR_UNSUPPORTED;
-  lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (with_queue ? (size_t)kVnThreads * kVnQueue * sizeof(float2) : 0);
-  if (lds > 96 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+inline int vn_check(const void* x, const void* idx, int B, int N, int k, size_t& lds, bool knn) {
+  if (B < 0 || N <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
+  if (N < k || k > 32) return EQA_ERR_UNSUPPORTED;
+  lds = knn ? ((size_t)4 * ((N + 15) & ~15) + 2 * kVnQSlots * kVnQThreads) * sizeof(float) : (size_t)4 * ((N + 3) & ~3) * sizeof(float);
+  if (lds > 128 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   if (!x || !idx) return EQA_ERR_INVALID_ARG;
   return 1;  // go
@@ -264,58 +281,66 @@ extern "C" {
 
 // blocks per cloud of the four conv_pos passes (32 points per block: four lanes per point); the kNN kernel keeps one thread per point
 int eqa_vn_blocks(int N) { return N <= 0 ? 0 : (N + kVnPts - 1) / kVnPts; }
-static int vn_knn_blocks(int N) { return (N + kVnThreads - 1) / kVnThreads; }
+static int vn_knn_blocks(int N) { return (N + kVnQPts - 1) / kVnQPts; }
 
 int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream) {
-  if (k != kVnK) return EQA_ERR_UNSUPPORTED;
   size_t lds;
-  const int rc = vn_check(x, idx, B, N, lds, true);
+  const int rc = vn_check(x, idx, B, N, k, lds, true);
   if (rc != 1) return rc;
-  hipLaunchKernelGGL(vn_knn_kernel, dim3(vn_knn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, N);
+  const dim3 grid(vn_knn_blocks(N), B);
+  if (k <= 20)
+    hipLaunchKernelGGL(vn_knn_kernel<5>, grid, dim3(kVnQThreads), lds, (hipStream_t)stream, x, idx, N, k);
+  else
+    hipLaunchKernelGGL(vn_knn_kernel<8>, grid, dim3(kVnQThreads), lds, (hipStream_t)stream, x, idx, N, k);
   return launch_status();
 }
 
-int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, void* stream) {
+#define VN_LAUNCH_E(kernel, ...)                                                                                          \
+  do {                                                                                                                    \
+    if (k <= 20)                                                                                                          \
+      hipLaunchKernelGGL(kernel<5>, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, __VA_ARGS__);  \
+    else                                                                                                                  \
+      hipLaunchKernelGGL(kernel<8>, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, __VA_ARGS__);  \
+  } while (0)
+
+int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, int k, void* stream) {
   size_t lds;
-  const int rc = vn_check(x, idx, B, N, lds, false);
+  const int rc = vn_check(x, idx, B, N, k, lds, false);
   if (rc != 1) return rc;
   if (!Wf || !partial) return EQA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(vn_convpos_stats_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, partial, N);
+  VN_LAUNCH_E(vn_convpos_stats_kernel, x, idx, Wf, partial, N, k);
   return launch_status();
 }
 
 int eqa_vn_convpos_fwd(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale, const float* shift,
-                       float* pooled, int B, int N, void* stream) {
+                       float* pooled, int B, int N, int k, void* stream) {
   size_t lds;
-  const int rc = vn_check(x, idx, B, N, lds, false);
+  const int rc = vn_check(x, idx, B, N, k, lds, false);
   if (rc != 1) return rc;
   if (!Wf || !Wd || !scale || !shift || !pooled) return EQA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(vn_convpos_fwd_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd, scale,
-                     shift, pooled, N);
+  VN_LAUNCH_E(vn_convpos_fwd_kernel, x, idx, Wf, Wd, scale, shift, pooled, N, k);
   return launch_status();
 }
 
 int eqa_vn_convpos_bwd_reduce(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
                               const float* shift, const float* mean, const float* rstd, const float* gpool, float* partial, int B,
-                              int N, void* stream) {
+                              int N, int k, void* stream) {
   size_t lds;
-  const int rc = vn_check(x, idx, B, N, lds, false);
+  const int rc = vn_check(x, idx, B, N, k, lds, false);
   if (rc != 1) return rc;
   if (!Wf || !Wd || !scale || !shift || !mean || !rstd || !gpool || !partial) return EQA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(vn_convpos_bwd_reduce_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd,
-                     scale, shift, mean, rstd, gpool, partial, N);
+  VN_LAUNCH_E(vn_convpos_bwd_reduce_kernel, x, idx, Wf, Wd, scale, shift, mean, rstd, gpool, partial, N, k);
   return launch_status();
 }
 
 int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
                              const float* shift, const float* mean, const float* rstd, const float* m1, const float* m2,
-                             const float* gpool, float* partial, int B, int N, void* stream) {
+                             const float* gpool, float* partial, int B, int N, int k, void* stream) {
   size_t lds;
-  const int rc = vn_check(x, idx, B, N, lds, false);
+  const int rc = vn_check(x, idx, B, N, k, lds, false);
   if (rc != 1) return rc;
   if (!Wf || !Wd || !scale || !shift || !mean || !rstd || !m1 || !m2 || !gpool || !partial) return EQA_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(vn_convpos_bwd_apply_kernel, dim3(eqa_vn_blocks(N), B), dim3(kVnThreads), lds, (hipStream_t)stream, x, idx, Wf, Wd,
-                     scale, shift, mean, rstd, m1, m2, gpool, partial, N);
+  VN_LAUNCH_E(vn_convpos_bwd_apply_kernel, x, idx, Wf, Wd, scale, shift, mean, rstd, m1, m2, gpool, partial, N, k);
   return launch_status();
 }
 

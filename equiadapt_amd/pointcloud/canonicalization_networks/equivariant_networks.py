@@ -68,7 +68,7 @@ class ConvPosMeanPool(torch.autograd.Function):
             stat = torch.empty(128, dtype=torch.float32, device=dev)          # scale | shift | mean | rstd, 32 floats each
             if batch_stats and (bn.momentum is not None or not bn.track_running_stats):
                 part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
-                _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, st),
+                _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, k, st),
                            "eqa_vn_convpos_stats")
                 track = bn.track_running_stats and bn.running_mean is not None
                 _lib.check(lib.eqa_vn_bn_finalize(part.data_ptr(), nblk, 2 * C, C, M, gamma.detach().data_ptr(), beta.detach().data_ptr(),
@@ -81,7 +81,7 @@ class ConvPosMeanPool(torch.autograd.Function):
             else:
                 if batch_stats:                                                # cumulative moving average (momentum=None): host glue
                     part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
-                    _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, st),
+                    _lib.check(lib.eqa_vn_convpos_stats(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), part.data_ptr(), B, N, k, st),
                                "eqa_vn_convpos_stats")
                     sums = part.sum(0, dtype=torch.float64)
                     mean = sums[:, 0] / M
@@ -96,9 +96,9 @@ class ConvPosMeanPool(torch.autograd.Function):
             scale, shift, mean, rstd = stat[0:C], stat[32:32 + C], stat[64:64 + C], stat[96:96 + C]
             pooled = torch.empty((B, C, 3, N), dtype=torch.float32, device=dev)
             _lib.check(lib.eqa_vn_convpos_fwd(x.data_ptr(), idx.data_ptr(), Wf_.data_ptr(), Wd_.data_ptr(), scale.data_ptr(),
-                                              shift.data_ptr(), pooled.data_ptr(), B, N, st), "eqa_vn_convpos_fwd")
+                                              shift.data_ptr(), pooled.data_ptr(), B, N, k, st), "eqa_vn_convpos_fwd")
         ctx.save_for_backward(x, idx, Wf_, Wd_, stat)
-        ctx.batch_stats, ctx.M = batch_stats, M
+        ctx.batch_stats, ctx.M, ctx.k = batch_stats, M, k
         return pooled
 
     @staticmethod
@@ -108,7 +108,7 @@ class ConvPosMeanPool(torch.autograd.Function):
         lib = _lib.load()
         x, idx, Wf, Wd, stat = ctx.saved_tensors
         B, _, N = x.shape
-        C = Wf.shape[0]
+        C, k = Wf.shape[0], ctx.k
         scale, shift, mean, rstd = stat[0:C], stat[32:32 + C], stat[64:64 + C], stat[96:96 + C]
         gpool = gpool.contiguous()
         st = ops._stream()
@@ -118,7 +118,7 @@ class ConvPosMeanPool(torch.autograd.Function):
             part = torch.empty((nblk, C, 2), dtype=torch.float32, device=dev)
             _lib.check(lib.eqa_vn_convpos_bwd_reduce(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
                                                      shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gpool.data_ptr(),
-                                                     part.data_ptr(), B, N, st), "eqa_vn_convpos_bwd_reduce")
+                                                     part.data_ptr(), B, N, k, st), "eqa_vn_convpos_bwd_reduce")
             grads = torch.empty(64, dtype=torch.float32, device=dev)            # d beta[32] | d gamma[32]
             red = torch.empty(64, dtype=torch.float32, device=dev)              # m1[32] | m2[32]
             _lib.check(lib.eqa_vn_bn_bwd_finalize(part.data_ptr(), nblk, 2 * C, C, ctx.M, grads.data_ptr(), red.data_ptr(), st),
@@ -129,7 +129,7 @@ class ConvPosMeanPool(torch.autograd.Function):
             wpart = torch.empty((nblk, C, 6), dtype=torch.float32, device=dev)
             _lib.check(lib.eqa_vn_convpos_bwd_apply(x.data_ptr(), idx.data_ptr(), Wf.data_ptr(), Wd.data_ptr(), scale.data_ptr(),
                                                     shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), red.data_ptr(),
-                                                    red[32:].data_ptr(), gpool.data_ptr(), wpart.data_ptr(), B, N, st),
+                                                    red[32:].data_ptr(), gpool.data_ptr(), wpart.data_ptr(), B, N, k, st),
                        "eqa_vn_convpos_bwd_apply")
             dW = wpart.sum(0, dtype=torch.float64).float()
         return None, dW[:, :3].contiguous(), dW[:, 3:].contiguous(), dgamma, dbeta, None, None
@@ -262,12 +262,12 @@ class VNSmall(nn.Module):
 
     def forward(self, point_cloud: torch.Tensor) -> torch.Tensor:
         if (point_cloud.is_cuda and not self.training and not torch.is_grad_enabled()
-                and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32):
+                and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32):
             from equiadapt_amd import ops
 
             return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn, self.pooling)
         if (point_cloud.is_cuda and torch.is_grad_enabled() and not point_cloud.requires_grad and self.pooling == "mean"
-                and self.n_knn == 20 and 20 <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32
+                and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32
                 and os.environ.get("EQA_TRAIN_FAST", "1") != "0"):
             # training: the (B, 21, 3, N, k) edge tensors of the first block are never materialised (csrc/vnsmall_train.hip)
             cp = self.conv_pos

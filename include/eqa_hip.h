@@ -51,7 +51,8 @@ extern "C" {
 int eqa_abi_version(void);
 
 /* Debug/benchmark knobs (process-global, not part of the data path):
- *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels. */
+ *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels.
+ *   key 1: VNSmall forward kernel: 0 = chosen by size (default), 1 = one thread per point (k = 20 only), 2 = four lanes per point. */
 int eqa_set_option(int key, int value);
 int eqa_get_option(int key);
 
@@ -446,13 +447,13 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
  * mean over points in one kernel; a cloud is staged once in LDS, every intermediate lives in registers.
  * Replaces equiadapt/pointcloud/canonicalization_networks/equivariant_networks.py:15-76 (knn,
  * get_graph_feature_cross) and :128-150 (VNSmall.forward) with vector_neuron_layers.py:251-273, :303-324.
- * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; k must be 20; pooling 0 = "mean",
+ * x:(B,3,N); out:(B,3,3) = mean over points of the first 3 output vector channels; 1 <= k <= 32 (and k <= N); pooling 0 = "mean",
  * 1 = "max" (VNMaxPool, vector_neuron_layers.py:327-364: per point and channel the edge maximising <x, W_p x>, first index on
  * ties like torch.max).
  * params: EQA_VNSMALL_PARAMS floats, batch-norms folded to scale/shift of the vector norm (layout in csrc/pointcloud.hip);
  * pooling 1: + the 441 floats of the pooling layer's map_to_dir weight (EQA_VNSMALL_PARAMS_MAX in total).
- * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  Other k / training: EQA_ERR_UNSUPPORTED (the host keeps an op-by-op
- * path for those).
+ * workspace: eqa_vnsmall_workspace_bytes(B, N) bytes.  k > 32: EQA_ERR_UNSUPPORTED (the host keeps an op-by-op path).
+ * Two kernels: four lanes per point (any k; the default) and one thread per point (k = 20; eqa_set_option key 1).
  */
 #define EQA_VNSMALL_PARAMS 1310
 #define EQA_VNSMALL_PARAMS_MAX 1751
@@ -462,13 +463,13 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
 
 /*
  * Training passes of VNSmall's first block (kNN graph -> cross edge features -> VNLinearLeakyReLU(3 -> 21, slope 0) with
- * training-mode VN batch-norm -> mean over the k = 20 neighbours; equivariant_networks.py:15-76, :128-140,
+ * training-mode VN batch-norm -> mean over the k <= 32 neighbours; equivariant_networks.py:15-76, :128-140,
  * vector_neuron_layers.py:251-273, :303-324), forward and the autograd backward w.r.t. the parameters.  Nothing of size
  * (B, 21, 3, N, k) is materialised: every pass re-derives the edge features from the cloud and the neighbour indices.
- * x:(B,3,N); idx:(B,N,20) int32; Wf, Wd:(21,3) = conv_pos.map_to_feat / map_to_dir weights; per-channel (21) vectors:
+ * x:(B,3,N); idx:(B,N,k) int32; Wf, Wd:(21,3) = conv_pos.map_to_feat / map_to_dir weights; per-channel (21) vectors:
  * scale = gamma*rstd, shift = beta - mean*scale, mean, rstd of n = |W_f f| + 1e-6 over all B*N*k edges.
  * Partials are per block, blocks = B * eqa_vn_blocks(N), summed by the caller (fixed order: deterministic).
- *   eqa_vn_knn                 idx <- the 20 nearest neighbours of every point (self included), best first
+ *   eqa_vn_knn                 idx <- the k nearest neighbours of every point (self included), best first
  *   eqa_vn_convpos_stats       partial:(blocks, 21, 2) = sum n, sum n^2
  *   eqa_vn_convpos_fwd         pooled:(B, 21, 3, N)
  *   eqa_vn_convpos_bwd_reduce  partial:(blocks, 21, 2) = sum g, sum g*nhat   (g = dL/d BN output; = d beta, d gamma)
@@ -477,15 +478,15 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
  */
 int eqa_vn_blocks(int N);
 int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream);
-int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, void* stream);
+int eqa_vn_convpos_stats(const float* x, const int32_t* idx, const float* Wf, float* partial, int B, int N, int k, void* stream);
 int eqa_vn_convpos_fwd(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale, const float* shift,
-                       float* pooled, int B, int N, void* stream);
+                       float* pooled, int B, int N, int k, void* stream);
 int eqa_vn_convpos_bwd_reduce(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
                               const float* shift, const float* mean, const float* rstd, const float* gpool, float* partial, int B,
-                              int N, void* stream);
+                              int N, int k, void* stream);
 int eqa_vn_convpos_bwd_apply(const float* x, const int32_t* idx, const float* Wf, const float* Wd, const float* scale,
                              const float* shift, const float* mean, const float* rstd, const float* m1, const float* m2,
-                             const float* gpool, float* partial, int B, int N, void* stream);
+                             const float* gpool, float* partial, int B, int N, int k, void* stream);
 
 /*
  * Training passes of VNSmall's tail on the pooled features of the first block: conv1 = VNLinearLeakyReLU(21 -> 21, slope 0) ->

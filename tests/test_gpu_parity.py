@@ -1575,3 +1575,43 @@ def test_group_action_pair_is_bit_identical_to_the_two_launches(dev, group_type,
         rf = (gidx >= N).float() if refl else None
         assert (y2.cpu() - io.canonicalize_images(x, rot, rf, (C, H, W))).abs().max().item() <= 1e-3
         assert (o2.cpu() - io.invert_action(f, rot, rf, N, G, rep)).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("pooling", ["mean", "max"])
+def test_fused_vnsmall_any_k_and_both_kernels_match_the_op_path(dev, pooling):
+    """eqa_vnsmall_fwd for neighbourhood sizes 1..32 (four lanes per point, distributed sorted list; k <= 20 and k <= 32
+    instantiations), ragged cloud sizes (N not a multiple of the 64 points of a block or of the 16-candidate scan step, N == k), and
+    the one-thread-per-point kernel (k = 20, eqa_set_option key 1) -- each against the op-by-op module path of the same network
+    (equivariant_networks.py:15-76, 128-150)."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import _lib
+
+    lib = _lib.load()
+    torch.manual_seed(40)
+    tol = 3e-6 if pooling == "mean" else 2e-5
+    for k, B, N in [(1, 2, 40), (3, 2, 70), (8, 3, 300), (16, 2, 513), (19, 2, 64), (20, 3, 1024), (20, 1, 20), (21, 2, 100), (27, 2, 1000),
+                    (32, 2, 32), (32, 2, 777)]:
+        net = ea.VNSmall(types.SimpleNamespace(n_knn=k, pooling=pooling))
+        for m in net.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.running_mean.normal_(0.5, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.data.uniform_(0.5, 1.5)
+                m.bias.data.normal_(0, 0.2)
+        net = net.to(dev).eval()
+        x = torch.randn(B, 3, N, device=dev)
+        with torch.enable_grad():
+            slow = net(x).detach()                     # grad mode -> op-by-op torch path
+        scale = max(slow.abs().max().item(), 1.0)
+        with torch.no_grad():
+            quad = net(x)
+        assert (quad - slow).abs().max().item() <= tol * scale, (k, B, N, (quad - slow).abs().max().item())
+        if k == 20:
+            assert lib.eqa_set_option(1, 1) == 0 and lib.eqa_get_option(1) == 1
+            try:
+                with torch.no_grad():
+                    single = net(x)
+            finally:
+                assert lib.eqa_set_option(1, 0) == 0
+            assert (single - slow).abs().max().item() <= tol * scale, (k, B, N)
+    assert lib.eqa_set_option(1, 3) == -1

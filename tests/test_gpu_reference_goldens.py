@@ -287,12 +287,14 @@ def test_vnsmall_eval_at_config4_size_and_other_k_matches_reference(dev, golden,
     net = net.to(dev).eval()
     x = c["x"].to(dev)
     lib = _lib.load()
-    if k == 20:
-        idx = torch.empty(B, N, k, dtype=torch.int32, device=dev)
-        _lib.check(lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, None), "eqa_vn_knn")
-        torch.cuda.synchronize()
-        ok, n_bad = _knn_sets_agree(idx, c["x"], c["knn_idx"], k)
-        assert ok, f"{n_bad} points disagree outside fp32 near-ties"
+    idx = torch.empty(B, N, k, dtype=torch.int32, device=dev)
+    _lib.check(lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, None), "eqa_vn_knn")
+    torch.cuda.synchronize()
+    ok, n_bad = _knn_sets_agree(idx, c["x"], c["knn_idx"], k)
+    assert ok, f"{n_bad} points disagree outside fp32 near-ties"
+    # best first, like torch.topk: the reference's own ORDER wherever its consecutive scores are distinct in fp32
+    same_order = (idx.long().cpu() == c["knn_idx"].long()).float().mean().item()
+    assert same_order >= 0.999, same_order
     with torch.no_grad():
         vec = net(x).cpu()
     # max pooling: one argmax pick moved by a last-bit score difference changes the mean over N points by |dx| / N
@@ -336,7 +338,10 @@ def test_vnsmall_training_step_at_config4_size_matches_reference(dev, golden, gr
     net.dropout.p = 0.0
     net = net.to(dev).train()
     out = net(t["x"].to(dev))
-    assert torch.allclose(out.detach().cpu(), t["vnsmall_out"], atol=1e-5, rtol=1e-4)
+    # the output is a mean over the points of O(1) vectors that largely cancel (|out| ~ 0.03): the error scale is the summands',
+    # and one VN-ReLU gate flipped by a last-bit difference moves the mean by O(1 / N)
+    err = (out.detach().cpu() - t["vnsmall_out"]).abs().max().item()
+    assert err <= 5e-5, err
     (out * t["w"].to(dev)).sum().backward()
     after = {k: v.cpu() for k, v in net.state_dict().items()}
     for k, v in t["state_after"].items():
