@@ -127,22 +127,50 @@ class EqaLibraryError(RuntimeError):
     pass
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/*.hip -> csrc/libeqa_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
-    newest_src = max(os.path.getmtime(p) for p in SOURCES + HEADERS + [os.path.join(INCLUDE, "eqa_hip.h")])
-    if not force and os.path.exists(SO_PATH) and os.path.getmtime(SO_PATH) >= newest_src:
-        return SO_PATH
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile csrc/*.hip -> csrc/libeqa_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+    Each translation unit is compiled to its own object (in parallel, re-compiled only when it or a header changed) and the
+    objects are linked; ``extra_flags`` / ``out`` build a variant (tools/ablate.sh, A/B runs through ``EQA_LIB``)."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    out = out or SO_PATH
+    hdr_time = max(os.path.getmtime(p) for p in HEADERS + [os.path.join(INCLUDE, "eqa_hip.h")])
+    newest_src = max(hdr_time, max(os.path.getmtime(p) for p in SOURCES))
+    if not force and not extra_flags and os.path.exists(out) and os.path.getmtime(out) >= newest_src:
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -fno-slp-vectorize: left on, the SLP vectoriser packs adjacent fp32 adds / multiplies of the straight-line FFT and resampling
     # code into v_pk_*_f32 pairs and pays for them with register moves (956 v_mov in the fused inverse transform); measured
     # without it: inverse transform + window sums 0.90 -> 0.80 ms, fused VNSmall +5 %, group action 0.649 -> 0.671 of HBM peak
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-shared", "-fPIC", "-I", INCLUDE, *SOURCES, "-o", SO_PATH]
-    if verbose:
-        print(" ".join(cmd))
+    flags = ["--offload-arch=gfx950", "-O3", "-fno-slp-vectorize", "-std=c++17", "-fPIC", "-I", INCLUDE, *extra_flags]
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+
+    def compile_one(src):
+        obj = os.path.join(objdir, f"{os.path.splitext(os.path.basename(src))[0]}.{tag}.o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(src)):
+            return obj, None
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, (None if res.returncode == 0 else f"{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, SOURCES))
+    errors = [e for _, e in results if e]
+    if errors:
+        raise EqaLibraryError("hipcc failed:\n" + "\n".join(errors))
+    tmp = out + f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[o for o, _ in results], "-o", tmp]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
-        raise EqaLibraryError(f"hipcc failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
-    return SO_PATH
+        raise EqaLibraryError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
+    os.replace(tmp, out)
+    return out
 
 
 def load() -> ctypes.CDLL:

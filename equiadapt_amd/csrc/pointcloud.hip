@@ -286,7 +286,7 @@ __global__ __launch_bounds__(kVnThreads, MAXPOOL ? 2 : EQA_VN_MIN_BLOCKS) void v
 constexpr int kVnTailLds = 2 * 24 * 24 + 24 * 4 + 24 * 8 + 8;   // 1448 floats
 
 template <int SEG, bool MAXPOOL>
-__global__ __launch_bounds__(kVnQThreads, MAXPOOL ? 2 : 3) void vnsmall_fwd_quad_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kVnQThreads, MAXPOOL ? 2 : EQA_VN_QUAD_WAVES) void vnsmall_fwd_quad_kernel(const float* __restrict__ x,
                                                                                          const float* __restrict__ prm,
                                                                                          float* __restrict__ partial, int N, int k,
                                                                                          int nblk) {
@@ -336,6 +336,38 @@ __global__ __launch_bounds__(kVnQThreads, MAXPOOL ? 2 : 3) void vnsmall_fwd_quad
   const float* Wd = prm + 63;
   const float* bsc = prm + 126;
   const float* bsh = prm + 147;
+  if (!MAXPOOL) {
+    // mean pooling: channel-outer, edge-inner.  The lane's SEG edges are set up once (6 registers each); a channel's 8 scalars are
+    // then loaded once for all of them (edge-outer: once per edge, with a scalar-cache wait per channel), the SEG dependent
+    // root / reciprocal chains of a channel are independent of each other, and only one accumulator triple is live at a time.
+    V3 f0[SEG], f2[SEG];
+    float m[SEG];
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+      const float4 nb4 = pts[bi[t]];
+      const V3 nb = v3(nb4.x, nb4.y, nb4.z);
+      f0[t] = v3(nb.x - ctr.x, nb.y - ctr.y, nb.z - ctr.z);                                               // neighbour - centre
+      f2[t] = v3(nb.y * ctr.z - nb.z * ctr.y, nb.z * ctr.x - nb.x * ctr.z, nb.x * ctr.y - nb.y * ctr.x);  // neighbour x centre
+      m[t] = SEG * sub + t < k ? 1.0f : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < kVnC; ++c) {
+      asm volatile("" ::: "memory");   // one channel at a time: without it the scheduler interleaves all 21 and spills
+      const float a0 = Wf[c * 3], a1 = Wf[c * 3 + 1], a2 = Wf[c * 3 + 2];
+      const float d0 = Wd[c * 3], d1 = Wd[c * 3 + 1], d2 = Wd[c * 3 + 2];
+      const float sc = bsc[c], sh = bsh[c];
+      const V3 qc = v3(a1 * ctr.x, a1 * ctr.y, a1 * ctr.z), dc = v3(d1 * ctr.x, d1 * ctr.y, d1 * ctr.z);  // the centre's share: same for all edges
+      V3 acc = v3(0.f, 0.f, 0.f);
+#pragma unroll
+      for (int t = 0; t < SEG; ++t) {
+        V3 q = v3(a0 * f0[t].x + qc.x + a2 * f2[t].x, a0 * f0[t].y + qc.y + a2 * f2[t].y, a0 * f0[t].z + qc.z + a2 * f2[t].z);
+        const V3 d = v3(d0 * f0[t].x + dc.x + d2 * f2[t].x, d0 * f0[t].y + dc.y + d2 * f2[t].y, d0 * f0[t].z + dc.z + d2 * f2[t].z);
+        q = vn_relu_sel(vn_bn(q, sc, sh), d);
+        acc.x += m[t] * q.x; acc.y += m[t] * q.y; acc.z += m[t] * q.z;
+      }
+      pooled[c] = acc;
+    }
+  } else {
 #pragma unroll 1
   for (int t = 0; t < SEG; ++t) {
     if (!__any(SEG * sub + t < k)) break;   // wave-uniform
@@ -382,6 +414,7 @@ __global__ __launch_bounds__(kVnQThreads, MAXPOOL ? 2 : 3) void vnsmall_fwd_quad
         pooled[c].z = take ? qe[c].z : pooled[c].z;
       }
     }
+  }
   }
   // ---- the point's pooled features in all four lanes
   if (MAXPOOL) {

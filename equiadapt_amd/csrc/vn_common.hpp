@@ -17,19 +17,37 @@ struct V3 {
 __device__ __forceinline__ V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 __device__ __forceinline__ float dot3(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
+// Square root and reciprocal of the VN layers.  The correctly rounded forms (sqrtf, IEEE division) expand to ~10 instructions
+// each and made up a third of the per-(edge, channel) work of conv_pos (76 VALU instructions, two divisions and a root); the
+// hardware's v_sqrt_f32 / v_rcp_f32 are one instruction and 1 ulp: the layer outputs move by ~1e-7 relative, two orders below
+// the 1e-5 point-cloud tolerance and below the fp32 noise of the reference's own evaluation (6e-5 at 8 x 1024
+// points in training mode, tools/diag/vn_train_noise.py).  -DEQA_VN_IEEE_MATH=1 restores the correctly rounded forms.
+#ifndef EQA_VN_IEEE_MATH
+#define EQA_VN_IEEE_MATH 0
+#endif
+__device__ __forceinline__ float vn_sqrt(float x) { return EQA_VN_IEEE_MATH ? sqrtf(x) : __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float vn_rcp(float x) { return EQA_VN_IEEE_MATH ? 1.0f / x : __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float vn_div(float a, float b) { return EQA_VN_IEEE_MATH ? a / b : a * __builtin_amdgcn_rcpf(b); }
+
 // VN batch-norm (eval): q * BN(|q| + EPS) / (|q| + EPS);  then direction-gated ReLU with slope 0
 __device__ __forceinline__ V3 vn_bn(V3 q, float scale, float shift) {
-  const float n = sqrtf(dot3(q, q)) + kVnEps;
-  const float r = (n * scale + shift) / n;
+  const float n = vn_sqrt(dot3(q, q)) + kVnEps;
+  const float r = vn_div(n * scale + shift, n);
   return v3(q.x * r, q.y * r, q.z * r);
 }
 __device__ __forceinline__ V3 vn_relu(V3 q, const V3& d) {
   const float dp = dot3(q, d);
   if (dp < 0.0f) {
-    const float t = dp / (dot3(d, d) + kVnEps);
+    const float t = vn_div(dp, dot3(d, d) + kVnEps);
     q.x -= t * d.x; q.y -= t * d.y; q.z -= t * d.z;
   }
   return q;
+}
+// the same without a branch (straight-line code for the unrolled edge loops: some lane of a wave takes the branch anyway)
+__device__ __forceinline__ V3 vn_relu_sel(V3 q, const V3& d) {
+  const float dp = dot3(q, d);
+  const float t = dp < 0.0f ? vn_div(dp, dot3(d, d) + kVnEps) : 0.0f;
+  return v3(q.x - t * d.x, q.y - t * d.y, q.z - t * d.z);
 }
 
 // Backward of one VN layer output  y = gate(u * nbn, d),  u = q / n,  n = |q| + EPS,  nbn = n * scale + shift  (scale = gamma *
@@ -42,8 +60,8 @@ struct VnGrad {
 __device__ __forceinline__ VnGrad vn_gate_grad(const V3& q, const V3& d, float scale, float shift, const V3& g_out) {
   VnGrad r;
   r.q = q;
-  r.nr = sqrtf(dot3(r.q, r.q)) + kVnEps;
-  const float inv_n = 1.0f / r.nr;
+  r.nr = vn_sqrt(dot3(r.q, r.q)) + kVnEps;
+  const float inv_n = vn_rcp(r.nr);
   r.u = v3(r.q.x * inv_n, r.q.y * inv_n, r.q.z * inv_n);
   r.nbn = r.nr * scale + shift;
   const V3 qn = v3(r.u.x * r.nbn, r.u.y * r.nbn, r.u.z * r.nbn);
@@ -53,7 +71,7 @@ __device__ __forceinline__ VnGrad vn_gate_grad(const V3& q, const V3& d, float s
     r.g_qn = g_out;
     r.g_d = v3(0.f, 0.f, 0.f);
   } else {           // out = qn - alpha d, alpha = <qn, d> / (|d|^2 + EPS)
-    const float rr = 1.0f / (dot3(r.d, r.d) + kVnEps);
+    const float rr = vn_rcp(dot3(r.d, r.d) + kVnEps);
     const float alpha = dp * rr;
     const float g_alpha = -dot3(g_out, r.d);
     const float ga_r = g_alpha * rr;
@@ -68,8 +86,8 @@ __device__ __forceinline__ VnGrad vn_gate_grad(const V3& q, const V3& d, float s
 __device__ __forceinline__ VnGrad vn_norm_grad(const V3& q, float scale, float shift, const V3& g_out) {
   VnGrad r;
   r.q = q;
-  r.nr = sqrtf(dot3(q, q)) + kVnEps;
-  const float inv_n = 1.0f / r.nr;
+  r.nr = vn_sqrt(dot3(q, q)) + kVnEps;
+  const float inv_n = vn_rcp(r.nr);
   r.u = v3(q.x * inv_n, q.y * inv_n, q.z * inv_n);
   r.nbn = r.nr * scale + shift;
   r.d = v3(0.f, 0.f, 0.f);
@@ -87,8 +105,9 @@ __device__ __forceinline__ V3 vn_norm_input_grad(const VnGrad& r, float sc, floa
   const float g_n = active ? sc * (r.g_nbn - m1 - nhat * m2) : 0.0f;
   const float qlen = fmaxf(r.nr - kVnEps, 1e-30f);
   const V3 g_u = v3(r.g_qn.x * r.nbn, r.g_qn.y * r.nbn, r.g_qn.z * r.nbn);
-  const float proj = dot3(g_u, r.q) / qlen;
-  const float inv_n = 1.0f / r.nr, gq = g_n / qlen;
+  const float inv_q = vn_rcp(qlen);
+  const float proj = dot3(g_u, r.q) * inv_q;
+  const float inv_n = vn_rcp(r.nr), gq = g_n * inv_q;
   return v3((g_u.x - r.u.x * proj) * inv_n + gq * r.q.x, (g_u.y - r.u.y * proj) * inv_n + gq * r.q.y,
             (g_u.z - r.u.z * proj) * inv_n + gq * r.q.z);
 }
@@ -180,12 +199,21 @@ __device__ __forceinline__ void vn_knn(const float4* pts, int Npad, float2* queu
 // entry inserted first stays in front):  with pv = the OLD last entry of the previous lane's segment (+inf for lane 0),
 //   v > pv : the candidate lands before this lane's segment, whose entries all move down by one: the incoming element is pv;
 //   else   : the incoming element is the candidate itself, placed in front of the first entry it beats (if any).
-// From the insertion point on every entry moves down (a sticky swap flag), so what leaves a segment is always its old last entry,
-// which is exactly what the next lane takes in.  (Emulated against a stable sort in tools/knn_quad_model.py.)
+// From the insertion point on every entry moves down, so what leaves a segment is always its old last entry, which is exactly
+// what the next lane takes in.  (Emulated against a stable sort in tools/knn_quad_model.py.)
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kVnQThreads = 256;                  // 64 points per block
 constexpr int kVnQPts = kVnQThreads / 4;
-constexpr int kVnQSlots = 12;                     // pending candidates per lane (LDS, 8 bytes each)
+#ifndef EQA_VN_QSLOTS
+#define EQA_VN_QSLOTS 12
+#endif
+#ifndef EQA_VN_QUAD_WAVES
+#define EQA_VN_QUAD_WAVES 3   // waves per SIMD the mean-pooling kernel's register allocation must allow
+#endif
+#ifndef EQA_VN_DRAIN_SKIP
+#define EQA_VN_DRAIN_SKIP 0   // 1: skip a quad lane's insertion round when no lane of the wave has an entry in it
+#endif
+constexpr int kVnQSlots = EQA_VN_QSLOTS;          // pending candidates per lane (LDS, 8 bytes each)
 
 template <int CTRL>
 __device__ __forceinline__ float vn_dpp_f(float v) {
@@ -231,19 +259,24 @@ __device__ __forceinline__ void vn_knn_quad(const float4* pts, int Npad, float2*
     float pv = vn_dpp_f<kQuadPrev>(bv[SEG - 1]);
     const int pi = vn_dpp_i<kQuadPrev>(bi[SEG - 1]);
     pv = sub == 0 ? INFINITY : pv;
-    bool sw = v > pv;
-    float cv = sw ? pv : v;
-    int ci = sw ? pi : j;
+    const bool take = v > pv;
+    const float cv = take ? pv : v;
+    const int ci = take ? pi : j;
+    // g[t]: the incoming element goes in front of entry t.  The segment is sorted, so g is monotone (the "sticky" flag of the
+    // serial chain for free) and every entry's new value is a two-level select of OLD values: entry t keeps itself, takes the
+    // incoming element (g[t] and not g[t-1]) or takes entry t-1 -- SEG independent selects instead of a SEG-deep chain.
+    bool g[SEG];
 #pragma unroll
-    for (int t = 0; t < SEG; ++t) {
-      sw = sw || (cv > bv[t]);
-      const float tv = bv[t];
-      const int ti = bi[t];
-      bv[t] = sw ? cv : tv;
-      bi[t] = sw ? ci : ti;
-      cv = sw ? tv : cv;
-      ci = sw ? ti : ci;
+    for (int t = 0; t < SEG; ++t) g[t] = take | (cv > bv[t]);   // '|', not '||': no control flow
+#pragma unroll
+    for (int t = SEG - 1; t >= 1; --t) {
+      const float uv = g[t - 1] ? bv[t - 1] : cv;
+      const int ui = g[t - 1] ? bi[t - 1] : ci;
+      bv[t] = g[t] ? uv : bv[t];
+      bi[t] = g[t] ? ui : bi[t];
     }
+    bv[0] = g[0] ? cv : bv[0];
+    bi[0] = g[0] ? ci : bi[0];
   };
   float thr = -INFINITY;   // the list's last entry (lane 3's last): a candidate must beat it
   int cnt = 0;
@@ -256,10 +289,17 @@ __device__ __forceinline__ void vn_knn_quad(const float4* pts, int Npad, float2*
       const float2 e0 = quadq[s * kVnQThreads], e1 = quadq[s * kVnQThreads + 1], e2 = quadq[s * kVnQThreads + 2],
                    e3 = quadq[s * kVnQThreads + 3];
       const int c0 = vn_dpp_i<0x00>(cnt), c1 = vn_dpp_i<0x55>(cnt), c2 = vn_dpp_i<0xAA>(cnt), c3 = vn_dpp_i<0xFF>(cnt);
+#if EQA_VN_DRAIN_SKIP
+      if (__any(s < c0)) insert(s < c0 ? e0.x : -INFINITY, __float_as_int(e0.y));
+      if (__any(s < c1)) insert(s < c1 ? e1.x : -INFINITY, __float_as_int(e1.y));
+      if (__any(s < c2)) insert(s < c2 ? e2.x : -INFINITY, __float_as_int(e2.y));
+      if (__any(s < c3)) insert(s < c3 ? e3.x : -INFINITY, __float_as_int(e3.y));
+#else
       insert(s < c0 ? e0.x : -INFINITY, __float_as_int(e0.y));
       insert(s < c1 ? e1.x : -INFINITY, __float_as_int(e1.y));
       insert(s < c2 ? e2.x : -INFINITY, __float_as_int(e2.y));
       insert(s < c3 ? e3.x : -INFINITY, __float_as_int(e3.y));
+#endif
     }
     cnt = 0;
     thr = vn_dpp_f<0xFF>(bv[SEG - 1]);

@@ -11,13 +11,14 @@ def insert(S, I, v, j, SEG):
     pv = [np.inf] + [S[q - 1][SEG - 1] for q in range(1, 4)]
     pi = [0] + [I[q - 1][SEG - 1] for q in range(1, 4)]
     for q in range(4):
-        sw = v > pv[q]                      # the candidate lands before this segment: everything moves down, pv comes in
-        cv, ci = (pv[q], pi[q]) if sw else (v, j)
-        for t in range(SEG):
-            sw = sw or (cv > S[q][t])       # sticky: from the insertion point on every entry moves down
-            if sw:
-                S[q][t], cv = cv, S[q][t]
-                I[q][t], ci = ci, I[q][t]
+        take = v > pv[q]                    # the candidate lands before this segment: everything moves down, pv comes in
+        cv, ci = (pv[q], pi[q]) if take else (v, j)
+        g = [take or (cv > S[q][t]) for t in range(SEG)]   # monotone: the segment is sorted
+        for t in range(SEG - 1, 0, -1):     # every new entry is a select of OLD values
+            if g[t]:
+                S[q][t], I[q][t] = (S[q][t - 1], I[q][t - 1]) if g[t - 1] else (cv, ci)
+        if g[0]:
+            S[q][0], I[q][0] = cv, ci
 
 
 def main():
