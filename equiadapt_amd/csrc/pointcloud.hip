@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void rigid_rows_kernel(const float* __res
 // 2 = always four lanes per point
 int eqa::g_vn_kernel_choice = 0;
 #ifndef EQA_VN_SINGLE_MIN_POINTS
-#define EQA_VN_SINGLE_MIN_POINTS (1LL << 62)   // B * N from which the one-thread-per-point kernel is preferred (set from measurements)
+#define EQA_VN_SINGLE_MIN_POINTS (1LL << 20)   // B * N from which the one-thread-per-point kernel is preferred for max pooling
 #endif
 
 extern "C" {
@@ -594,8 +594,11 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   hipStream_t st = (hipStream_t)stream;
-  // one thread per point: fewer, longer instruction streams -- ahead once the batch alone fills the chip (measured crossover)
-  const bool single = k == kVnK && (g_vn_kernel_choice == 1 || (g_vn_kernel_choice == 0 && (long long)B * N >= EQA_VN_SINGLE_MIN_POINTS));
+  // one thread per point: fewer, longer instruction streams.  Mean pooling: the quad kernel is ahead at every batch size (B = 64:
+  // 137 vs 250 us, B = 2048: 3.11 vs 3.21 ms); max pooling (two waves per SIMD either way): ahead only once the batch alone fills
+  // the chip (B = 2048: 5.2 vs 6.0 ms; B = 256: 0.91 vs 0.84)
+  const bool single = k == kVnK && (g_vn_kernel_choice == 1 ||
+                                    (g_vn_kernel_choice == 0 && pooling == 1 && (long long)B * N >= EQA_VN_SINGLE_MIN_POINTS));
   int nblk;
   if (single) {
     const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);

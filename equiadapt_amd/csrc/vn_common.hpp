@@ -204,14 +204,16 @@ __device__ __forceinline__ void vn_knn(const float4* pts, int Npad, float2* queu
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kVnQThreads = 256;                  // 64 points per block
 constexpr int kVnQPts = kVnQThreads / 4;
+// Measured (tools/kbench_vn.py, B = 64 / 2048 clouds of 1024 points, mean pooling, us): 12 slots + 3 waves per SIMD 146 / 3339;
+// 8 slots (37.8 KB of LDS per block: four blocks per CU) + 4 waves 137 / 3107; skipping empty insertion rounds: kNN kernel 82 -> 73.
 #ifndef EQA_VN_QSLOTS
-#define EQA_VN_QSLOTS 12
+#define EQA_VN_QSLOTS 8
 #endif
 #ifndef EQA_VN_QUAD_WAVES
-#define EQA_VN_QUAD_WAVES 3   // waves per SIMD the mean-pooling kernel's register allocation must allow
+#define EQA_VN_QUAD_WAVES 4   // waves per SIMD the mean-pooling kernel's register allocation must allow
 #endif
 #ifndef EQA_VN_DRAIN_SKIP
-#define EQA_VN_DRAIN_SKIP 0   // 1: skip a quad lane's insertion round when no lane of the wave has an entry in it
+#define EQA_VN_DRAIN_SKIP 1   // 1: skip a quad lane's insertion round when no lane of the wave has an entry in it
 #endif
 constexpr int kVnQSlots = EQA_VN_QSLOTS;          // pending candidates per lane (LDS, 8 bytes each)
 

@@ -123,21 +123,29 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_stats_kernel(const floa
                                                                      int N, int k) {
   __shared__ float s_red[(kVnThreads / 64) * 2 * kVnC];
   VN_PASS_PROLOGUE
+  // channel-outer, edge-inner (as the fused eval kernel): the lane's edges are set up once, a channel's three weights are loaded
+  // once for all of them, and the EMAX norm chains of a channel are independent
+  VnEdge e[EMAX];
+  float live[EMAX];
+#pragma unroll
+  for (int t = 0; t < EMAX; ++t) {
+    e[t] = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
+    live[t] = active && t < cnt ? 1.0f : 0.0f;
+  }
   float acc[2 * kVnC];
 #pragma unroll
-  for (int i = 0; i < 2 * kVnC; ++i) acc[i] = 0.f;
-#pragma unroll 1
-  for (int t = 0; t < edges; ++t) {
-    asm volatile("" ::: "memory");  // keep the weights in the scalar cache, not hoisted into VGPRs (see pointcloud.hip)
-    const bool live = active && t < cnt;
-    const VnEdge e = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
+  for (int c = 0; c < kVnC; ++c) {
+    asm volatile("" ::: "memory");  // one channel at a time (see pointcloud.hip)
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int c = 0; c < kVnC; ++c) {
-      const V3 q = vn_mix(Wf + 3 * c, e);
-      const float nr = live ? sqrtf(dot3(q, q)) + kVnEps : 0.f;
-      acc[2 * c] += nr;
-      acc[2 * c + 1] += nr * nr;
+    for (int t = 0; t < EMAX; ++t) {
+      const V3 q = vn_mix(Wf + 3 * c, e[t]);
+      const float nr = live[t] * (vn_sqrt(dot3(q, q)) + kVnEps);
+      s0 += nr;
+      s1 += nr * nr;
     }
+    acc[2 * c] = s0;
+    acc[2 * c + 1] = s1;
   }
   vn_block_sum<2 * kVnC>(acc, s_red, partial + ((size_t)b * gridDim.x + blockIdx.x) * (2 * kVnC));
 }
@@ -148,19 +156,25 @@ __global__ __launch_bounds__(kVnThreads) void vn_convpos_fwd_kernel(const float*
                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
                                                                    float* __restrict__ pooled, int N, int k) {
   VN_PASS_PROLOGUE
+  VnEdge e[EMAX];
+  float m[EMAX];
+#pragma unroll
+  for (int t = 0; t < EMAX; ++t) {
+    e[t] = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
+    m[t] = t < cnt ? 1.0f : 0.0f;   // (k = 20: every lane has its five edges and m == 1 throughout)
+  }
   V3 acc[kVnC];
 #pragma unroll
-  for (int c = 0; c < kVnC; ++c) acc[c] = v3(0.f, 0.f, 0.f);
-#pragma unroll 1
-  for (int t = 0; t < edges; ++t) {
-    asm volatile("" ::: "memory");
-    const float m = t < cnt ? 1.0f : 0.0f;   // (k = 20: every lane has its five edges and m == 1 throughout)
-    const VnEdge e = vn_edge(ctr, pts[nbr[t < cnt ? t : 0]]);
+  for (int c = 0; c < kVnC; ++c) {
+    asm volatile("" ::: "memory");  // one channel at a time
+    const float sc = scale[c], sh = shift[c];
+    V3 a = v3(0.f, 0.f, 0.f);
 #pragma unroll
-    for (int c = 0; c < kVnC; ++c) {
-      const V3 q = vn_relu(vn_bn(vn_mix(Wf + 3 * c, e), scale[c], shift[c]), vn_mix(Wd + 3 * c, e));
-      acc[c].x += m * q.x; acc[c].y += m * q.y; acc[c].z += m * q.z;
+    for (int t = 0; t < EMAX; ++t) {
+      const V3 q = vn_relu_sel(vn_bn(vn_mix(Wf + 3 * c, e[t]), sc, sh), vn_mix(Wd + 3 * c, e[t]));
+      a.x += m[t] * q.x; a.y += m[t] * q.y; a.z += m[t] * q.z;
     }
+    acc[c] = a;
   }
   // the four lanes of a point: butterfly over the quad, every lane ends up with the point's sums; lane `sub` stores channels
   // c = sub, sub + 4, ...

@@ -387,9 +387,11 @@ def test_input_gradient_gather_equals_atomic_scatter(dev):
 
 
 @pytest.mark.gpu
-def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
+@pytest.mark.parametrize("k", [20, 16, 27, 3])
+def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch, k):
     """VNSmall in train(): the recompute kernels of the first block (eqa_vn_*) vs the op-by-op path with the same weights:
-    output vectors, every parameter gradient, the batch-norm running statistics; and the kNN kernel vs torch.topk."""
+    output vectors, every parameter gradient, the batch-norm running statistics; and the kNN kernel vs torch.topk.
+    k = 20: five edges per lane; 16 / 3: partly idle lanes of the k <= 20 instantiation; 27: the k <= 32 instantiation."""
     import copy
     import types
 
@@ -398,7 +400,7 @@ def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
     from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import knn
 
     torch.manual_seed(101)
-    hp = types.SimpleNamespace(n_knn=20, pooling="mean")
+    hp = types.SimpleNamespace(n_knn=k, pooling="mean")
     net = ea.VNSmall(hp).to(dev)
     net.dropout.p = 0.0
     with torch.no_grad():
@@ -410,9 +412,9 @@ def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
     x = torch.randn(5, 3, 200, device=dev)
     # kNN: same neighbour SETS as topk on the reference's score matrix (order within the list is irrelevant for the mean)
     lib = _lib.load()
-    idx = torch.empty(5, 200, 20, dtype=torch.int32, device=dev)
-    assert lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), 5, 200, 20, None) == 0
-    want = knn(x, 20)
+    idx = torch.empty(5, 200, k, dtype=torch.int32, device=dev)
+    assert lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), 5, 200, k, None) == 0
+    want = knn(x, k)
     assert torch.equal(idx.long().sort(-1).values, want.sort(-1).values)
     # the block itself, with a FIXED upstream gradient, against the op-by-op block evaluated in fp64
     from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import ConvPosMeanPool, get_graph_feature_cross
@@ -422,9 +424,9 @@ def test_vnsmall_training_fast_path_matches_op_path(dev, monkeypatch):
         fast, op64 = copy.deepcopy(net).train(training), copy.deepcopy(net).double().train(training)
         cp = fast.conv_pos
         o1 = ConvPosMeanPool.apply(x, cp.map_to_feat.weight, cp.map_to_dir.weight, cp.batchnorm.bn2d.weight, cp.batchnorm.bn2d.bias,
-                                   cp.batchnorm.bn2d, 20)
+                                   cp.batchnorm.bn2d, k)
         (o1 * g_up).sum().backward()
-        o2 = op64.conv_pos(get_graph_feature_cross(x.double().unsqueeze(1), 20, want)).mean(-1)
+        o2 = op64.conv_pos(get_graph_feature_cross(x.double().unsqueeze(1), k, want)).mean(-1)
         (o2 * g_up.double()).sum().backward()
         assert (o1.double() - o2).abs().max().item() <= 1e-5
         for p1, p2 in zip(fast.conv_pos.parameters(), op64.conv_pos.parameters()):

@@ -1592,7 +1592,11 @@ def test_fused_vnsmall_any_k_and_both_kernels_match_the_op_path(dev, pooling):
     for k, B, N in [(1, 2, 40), (3, 2, 70), (8, 3, 300), (16, 2, 513), (19, 2, 64), (20, 3, 1024), (20, 1, 20), (21, 2, 100), (27, 2, 1000),
                     (32, 2, 32), (32, 2, 777)]:
         net = ea.VNSmall(types.SimpleNamespace(n_knn=k, pooling=pooling))
-        for m in net.modules():
+        # k = 1: the only neighbour is the point itself, the edge feature is [0, x, 0], every channel's q and gate direction d are
+        # parallel, and a closed gate leaves q - <q, d>/|d|^2 d = rounding noise of size 1e-8 -- which a batch-norm SHIFT then
+        # divides by |q| + 1e-6: the network amplifies last-bit differences to 1e-2.  Only with the initial statistics (shift 0) is
+        # that configuration a meaningful comparison.
+        for m in (net.modules() if k > 1 else ()):
             if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
                 m.running_mean.normal_(0.5, 0.2)
                 m.running_var.uniform_(0.5, 1.5)
