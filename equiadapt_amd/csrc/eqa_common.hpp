@@ -20,6 +20,9 @@ constexpr int kWsMaxBorder = kMaxWinK - 1;  // k - 1 <= 7
 constexpr int kFinCh = 32;                  // channels per block of the finalize kernel
 
 // Sum over the 64 lanes of a wave, returned to every lane (wave-uniform: it comes back through a scalar register).
+// PRECONDITION: all 64 lanes active (EXEC all ones) -- the total is read from lane 63 after the row broadcasts, and an inactive
+// lane would contribute a stale register; every call site is wave-uniform control flow (no early return, no divergent branch
+// around it).  The row_bcast15 / row_bcast31 controls exist on gfx9 / CDNA only, which is the one target of this library.
 // Data-parallel-primitive adds instead of __shfl_xor: the shuffles compile to ds_bpermute_b32, a six-deep chain of LDS-crossbar
 // round trips per sum; the DPP modifiers ride on the v_add itself.  Inside a row of 16 lanes: quad swaps, then the two row
 // mirrors; across rows: row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3; lane 63 holds the total.

@@ -102,8 +102,9 @@ template <bool MASKED>
 __device__ __forceinline__ unsigned lift_ox0(const LiftPos& p, int OW) {
   // with OW >= 32 the last tile of a row starts at OW - 32 and overlaps its neighbour (the shared pixels are computed twice
   // from the same operands in the same order and stored twice with the same value), so every tile has 32 valid pixels and
-  // the stores need no predicate; MASKED (OW < 32): one partial tile per row
-  return MASKED ? 0u : min(p.tx * 32u, (unsigned)OW - 32u);
+  // the stores need no predicate; MASKED (OW < 32, or a channel count off the 64-multiples): tiles at multiples of 32, the
+  // last one of a row partial, every store predicated
+  return MASKED ? p.tx * 32u : min(p.tx * 32u, (unsigned)OW - 32u);
 }
 
 template <int KH>
@@ -282,15 +283,17 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   if (lane < 2) lds[lane][Stage::kFloats] = 1.0f;
   const int h = lane >> 5, col = lane & 31;
   const int ch0 = slice * 64 + col;
+  // Cout off the 64-multiples (MASKED launches only): the channels past Cout of the last slice get weight 0 and are never stored
+  const bool in0 = ch0 < Cout, in1 = ch0 + 32 < Cout;
   float b0[KH * 8], b1[KH * 8];
 #pragma unroll
   for (int s = 0; s < KH * 8; ++s) {
-    b0[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0];
-    b1[s] = wpk[(size_t)(s * 2 + h) * Cout + ch0 + 32];
+    b0[s] = in0 ? wpk[(size_t)(s * 2 + h) * Cout + ch0] : 0.0f;
+    b1[s] = in1 ? wpk[(size_t)(s * 2 + h) * Cout + ch0 + 32] : 0.0f;
   }
   if (h == 1) {  // the spare slot (see lift_read_row): weight = bias, input = 1.0
-    b0[0] = bias ? bias[ch0] : 0.0f;
-    b1[0] = bias ? bias[ch0 + 32] : 0.0f;
+    b0[0] = bias && in0 ? bias[ch0] : 0.0f;
+    b1[0] = bias && in1 ? bias[ch0 + 32] : 0.0f;
   }
   LiftEpi epi;
   epi.tr_w = lds_tr_all[wave] + col * kLiftTrPitch + 4 * h;
@@ -303,7 +306,8 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   epi.out_voff = grouped ? ((slice * 4 + ((lane & 15) >> 2)) * plane16 + (unsigned)(lane >> 4) * 16u + 4 * (lane & 3)) * 4u
                          : ((unsigned)(lane >> 4) * Cout + slice * 64 + 4 * (lane & 15)) * 4u;
   epi.row4 = grouped ? 4u * 16u * 4u : 4u * Cout * 4u;
-  epi.lane = lane;
+  // a lane whose four channels lie past Cout fails every store predicate of the MASKED form (pixel index beyond any row)
+  epi.lane = (int)(slice * 64 + 4 * (lane & 15)) < Cout ? lane : (1 << 20);
   const int n_el = 31 * Cin + R;
   const int a_off = Cin * col + (R - 8) * h;  // this lane's first element inside a staged row
   const int a_q0 = h ? Stage::kFloats : a_off;
@@ -410,7 +414,9 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
                             int Cin, int KH, int KW, int Cout, void* stream, int grouped) {
   if (!x || !wpk || !y || nimg < 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout <= 0 || H < KH || W < KW) return EQA_ERR_INVALID_ARG;
   const int R = KW * Cin;
-  if ((KH != 3 && KH != 5) || R < 9 || R > 15 || (Cout % 64) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;  // R <= 15: the bias slot
+  if ((KH != 3 && KH != 5) || R < 9 || R > 15 || (Cout % 16) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;  // R <= 15: the bias slot
+  const bool narrow = (Cout % 64) != 0;   // 16 / 32 / 48 channels in the last slice: predicated stores (the MASKED form)
+  if (narrow && grouped) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
   const int OH = H - KH + 1, OW = W - KW + 1;
   const unsigned tiles_per_row = (unsigned)(OW + 31) / 32;
@@ -418,7 +424,7 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   if (ntiles > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   const size_t x_numel = (size_t)nimg * H * W * Cin, y_numel = (size_t)nimg * OH * OW * Cout;
   // persistent waves (the weights live in registers), 2 per SIMD: `nstreams` tile streams x `nslices` 64-channel slices
-  const unsigned nslices = (unsigned)Cout / 64;
+  const unsigned nslices = ((unsigned)Cout + 63) / 64;
   const unsigned nstreams = (unsigned)std::min<size_t>(ntiles, std::max(1u, (unsigned)EQA_LIFT_WAVES / nslices));
   const unsigned waves = nslices * nstreams, per_block = kThreads / 64;
   const dim3 grid((waves + per_block - 1) / per_block);
@@ -427,9 +433,9 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
                      OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped)
   if (KH == 5) {
-    if (OW < 32) EQA_LIFT_LAUNCH(5, true); else EQA_LIFT_LAUNCH(5, false);
+    if (OW < 32 || narrow) EQA_LIFT_LAUNCH(5, true); else EQA_LIFT_LAUNCH(5, false);
   } else {
-    if (OW < 32) EQA_LIFT_LAUNCH(3, true); else EQA_LIFT_LAUNCH(3, false);
+    if (OW < 32 || narrow) EQA_LIFT_LAUNCH(3, true); else EQA_LIFT_LAUNCH(3, false);
   }
 #undef EQA_LIFT_LAUNCH
   return launch_status();

@@ -42,6 +42,11 @@ class CustomEquivariantNetwork(nn.Module):
             # inference: the last convolution feeds only the group mean, which is linear -> window sums, no conv
             if len(self.eqv_network) == 1:
                 return conv_then_group_pool(x, last)
+            lift = self.eqv_network[0]
+            if len(self.eqv_network) == 3 and lift.mfma_lifting_ok(x):
+                # two layers (the CIFAR-shaped configuration): the lifting convolution on the hand-written fp32-MFMA kernel,
+                # channels-last, straight into the window sums of the linearised 1x1 group convolution
+                return conv_then_group_pool(lift.lift_nhwc(x), last, relu=True)
             h = self.eqv_network[:-2](x)                      # everything before the final [ReLU, 1x1 group conv]
             return conv_then_group_pool(h.flatten(1, 2), last, relu=True)
         return group_pool(self.eqv_network(x))

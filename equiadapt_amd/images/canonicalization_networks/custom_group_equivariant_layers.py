@@ -136,8 +136,32 @@ class _GroupConvBase(nn.Module):
     def supports_linear_tail(self) -> bool:
         return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
 
+    def mfma_lifting_ok(self, x: torch.Tensor) -> bool:
+        """Inference on the hand-written fp32-MFMA lifting convolution (eqa_lift_conv_nhwc) instead of the framework's
+        convolution: a Z2 -> G lifting layer with stride 1, no padding, on a shape the kernel takes (kernel rows of 9..15 floats,
+        k in {3, 5}, O * |G| a multiple of 16)."""
+        return (self.lifting and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self.stride == 1
+                and self.padding == 0 and x.dim() == 4 and x.shape[-2] >= self.kernel_size and x.shape[-1] >= self.kernel_size
+                and ops.lift_conv_supported(self.in_channels, self.kernel_size, self.kernel_size, self.out_channels * self.num_group_elements))
+
+    def lift_nhwc(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
+        """[relu](lifting convolution + bias) as a channels-last (B, O*|G|, H', W') tensor (channel = field * |G| + element): the
+        layout the window-sum kernels read, without the 5-D reshape of ``forward``."""
+        w, b = self.weights, self.bias
+        key = (w._version, -1 if b is None else b._version, str(w.device))
+        hit = getattr(self, "_cached_lift", None)
+        if hit is None or hit[0] != key:
+            wpk = ops.pack_lift_weights(self.expanded_weights().detach())
+            be = None if b is None else b.detach().repeat_interleave(self.num_group_elements).contiguous()
+            hit = (key, wpk, be)
+            self._cached_lift = hit
+        return ops.lift_conv_nhwc(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2], relu, self.kernel_size, self.kernel_size)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]
+        if self.mfma_lifting_ok(x):
+            y = self.lift_nhwc(x)
+            return y.reshape(B, self.out_channels, self.num_group_elements, y.shape[2], y.shape[3])   # (contiguous 5-D copy)
         if not self.lifting:
             x = x.flatten(1, 2)
         x = F.conv2d(x, self.expanded_weights(), stride=self.stride, padding=self.padding)

@@ -12,6 +12,8 @@ from torch import nn
 
 
 class ConvNetwork(nn.Module):
+    _mfma_chunk_override = None   # tests set this to run the inference fast path in small batch chunks
+
     def __init__(self, in_shape: tuple, out_channels: int, kernel_size: int, num_layers: int = 2,
                  out_vector_size: int = 128):
         super().__init__()
@@ -64,6 +66,7 @@ class ConvNetwork(nn.Module):
             return hit[1]
         plan, layers, hw = None, [], tuple(x.shape[-2:])
         ok = True
+        per_sample = [x.shape[1] * hw[0] * hw[1] * 4]      # bytes of every activation per sample (eqa_conv_s2 addresses < 2^31 bytes)
         for i, (conv, bn) in enumerate(zip(convs, bns)):
             k, pad = conv.kernel_size[0], conv.padding[0]
             if (conv.kernel_size[0] != conv.kernel_size[1] or conv.stride != (2, 2) or conv.padding[0] != conv.padding[1] or conv.groups != 1
@@ -73,6 +76,7 @@ class ConvNetwork(nn.Module):
             w, b = self._folded(conv, bn)
             layers.append((ops.pack_conv_s2_weights(w, i == 0), b, conv.out_channels, k, pad, i == 0))
             hw = ((hw[0] + 2 * pad - k) // 2 + 1, (hw[1] + 2 * pad - k) // 2 + 1)
+            per_sample.append(conv.out_channels * max(hw[0], 0) * max(hw[1], 0) * 4)
         bn1, lin = self.final_fc[0], self.final_fc[3]
         if ok and bn1.running_mean is not None and min(hw) > 0:
             C = convs[-1].out_channels
@@ -80,7 +84,11 @@ class ConvNetwork(nn.Module):
             idx = torch.arange(C * hw[0] * hw[1], device=x.device).view(C, hw[0], hw[1]).permute(1, 2, 0).reshape(-1)
             scale = bn1.weight / torch.sqrt(bn1.running_var + bn1.eps)
             shift = bn1.bias - bn1.running_mean * scale
-            plan = (layers, scale[idx].contiguous(), shift[idx].contiguous(), lin.weight[:, idx].contiguous())
+            # largest batch one eqa_conv_s2 call takes (every activation below 2^31 bytes); larger batches run in chunks, which
+            # needs every per-sample activation to be a multiple of 16 bytes (the kernels' 16-byte loads start at the chunk's base)
+            max_batch = (2 ** 31 - 64) // max(per_sample)
+            chunkable = all(b % 16 == 0 for b in per_sample)
+            plan = (layers, scale[idx].contiguous(), shift[idx].contiguous(), lin.weight[:, idx].contiguous(), max_batch, chunkable)
         self._fold_cache["mfma"] = (key, plan)
         return plan
 
@@ -88,16 +96,24 @@ class ConvNetwork(nn.Module):
         if not self.training and not torch.is_grad_enabled() and x.is_cuda:
             if x.dtype == torch.float32 and os.environ.get("EQA_CONVNET_MFMA", "1") != "0":
                 plan = self._mfma_plan(x)
-                if plan is not None:
+                if plan is not None and (x.shape[0] <= plan[4] or plan[5]) and plan[4] >= 1:
                     # inference: every convolution (+ folded batch-norm + GELU) on the fp32 matrix cores, channels-last from the
-                    # first layer on; head = BatchNorm1d + ReLU in one pass + the Linear layer, re-indexed to that layout
+                    # first layer on; head = BatchNorm1d + ReLU in one pass + the Linear layer, re-indexed to that layout.
+                    # (The optimised canonicalizer feeds G * B views at once: batches beyond the kernels' 2 GiB addressing run in
+                    # chunks; shapes that can neither fit nor be chunked fall through to the folded conv2d path below.)
                     from equiadapt_amd import ops
 
-                    layers, scale, shift, wlin = plan
-                    h = x.contiguous()
-                    for wp, b, cout, k, pad, planar in layers:
-                        h = ops.conv_s2(h, wp, b, True, cout, k, pad, planar)
-                    z = ops.affine_relu_rows(h.view(x.shape[0], -1), scale, shift)
+                    layers, scale, shift, wlin, max_batch, chunkable = plan
+                    if chunkable and self._mfma_chunk_override:       # tests: exercise the chunked form at a small size
+                        max_batch = min(max_batch, int(self._mfma_chunk_override))
+                    xc = x.contiguous()
+                    outs = []
+                    for lo in range(0, x.shape[0], max_batch):
+                        h = xc[lo:lo + max_batch]
+                        for wp, b, cout, k, pad, planar in layers:
+                            h = ops.conv_s2(h, wp, b, True, cout, k, pad, planar)
+                        outs.append(h.view(h.shape[0], -1))
+                    z = ops.affine_relu_rows(outs[0] if len(outs) == 1 else torch.cat(outs), scale, shift)
                     return torch.nn.functional.linear(z, wlin, self.final_fc[3].bias)
             # inference: eval-mode batch-norms folded into the convolutions (three fewer passes over the feature maps)
             mods = list(self.enc_network)

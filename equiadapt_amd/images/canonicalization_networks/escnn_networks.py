@@ -524,8 +524,12 @@ class ESCNNEquivariantNetwork(nn.Module):
             return self._forward_training(x)
         if not self.training and not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32:
             convs, norms = self._layers()
-            hw = x.shape[-2] - (self.kernel_size - 1) * (len(convs) - 1)
-            if (convs[-1].supports_linear_tail() and 0 < hw and hw * hw <= 12288 and all(n.running_mean is not None for n in norms)
+            shrink = (self.kernel_size - 1) * (len(convs) - 1)
+            oh, ow = x.shape[-2] - shrink, x.shape[-1] - shrink
+            # (the exported dense layers are not registered submodules, so .eval() does not reach them: a norm left in training
+            # mode must take the module path with its batch statistics, not the folded running statistics)
+            if (convs[-1].supports_linear_tail() and 0 < oh and 0 < ow and oh * ow <= 12288
+                    and all(n.running_mean is not None and not n.training for n in norms)
                     and all(c.stride == 1 and c.padding == 0 and c.kernel_size == self.kernel_size for c in convs)):
                 return self._forward_inference(x)
         if self._dense:

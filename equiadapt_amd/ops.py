@@ -516,7 +516,7 @@ def window_sums_gemv(S: torch.Tensor, weff: torch.Tensor, scale: float, shift) -
 
 def lift_conv_supported(cin: int, kh: int, kw: int, cout: int) -> bool:
     """Shapes eqa_lift_conv_nhwc takes (others: the framework's convolution)."""
-    return kh in (3, 5) and 9 <= kw * cin <= 15 and cout % 64 == 0
+    return kh in (3, 5) and 9 <= kw * cin <= 15 and cout % 16 == 0
 
 
 def pack_lift_weights(bank: torch.Tensor) -> torch.Tensor:

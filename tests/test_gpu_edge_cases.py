@@ -99,7 +99,10 @@ def test_c_abi_argument_validation(dev):
     assert lib.eqa_invert_action_fwd(p(x), p(x), p(g), p(th), None, p(g), 1, 4, 1, 1, 4, 4, None) == -1
     assert lib.eqa_group_argmax(p(x), p(g), 1, 100, None) == -3          # more than one wave of orientations
     assert lib.eqa_window_sums(p(x), None, None, 0, p(x), 1, 1, 4, 4, 9, None) == -1
-    assert lib.eqa_vnsmall_fwd(p(x), p(x), p(x), p(x), 1, 64, 8, 0, None) == -3   # fused path is k = 20 only
+    assert lib.eqa_vnsmall_fwd(p(x), p(x), p(x), p(x), 1, 64, 33, 0, None) == -3   # fused path: k <= 32 ...
+    assert lib.eqa_vnsmall_fwd(p(x), p(x), p(x), p(x), 1, 7, 8, 0, None) == -3     # ... and at least k points
+    assert lib.eqa_vnsmall_fwd(p(x), p(x), p(x), p(x), 1, 64, 0, 0, None) == -1
+    assert lib.eqa_vn_knn(p(x), p(g), 1, 64, 33, None) == -3
     torch.cuda.synchronize()
 
 
@@ -252,3 +255,34 @@ def test_c_abi_from_plain_c(tmp_path):
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
     assert "max |error|" in run.stdout
+
+
+def test_conv_network_fast_path_in_batch_chunks(dev):
+    """ConvNetwork's inference fast path addresses each activation with 31 bits (eqa_conv_s2): the optimised canonicalizer's G * B
+    views can exceed that (224 x 224 x 32 channels: ~1.4 k images), so larger batches run in chunks -- same result bit for bit --
+    and shapes that can neither fit nor be chunked (per-sample activations off the 16-byte grid) take the folded conv2d path
+    instead of raising (custom_nonequivariant_networks.py:19-80 of the reference accepts any batch)."""
+    import equiadapt_amd as ea
+
+    torch.manual_seed(3)
+    net = ea.ConvNetwork((3, 64, 64), out_channels=16, kernel_size=5, num_layers=3, out_vector_size=32).to(dev).eval()
+    x = torch.randn(8, 3, 64, 64, device=dev)
+    with torch.no_grad():
+        whole = net(x)
+        net._mfma_chunk_override = 3          # chunks of 3, 3, 2
+        try:
+            chunked = net(x)
+        finally:
+            net._mfma_chunk_override = None
+    assert torch.equal(whole, chunked)
+    plan = net._mfma_plan(x)
+    assert plan is not None and plan[4] == (2 ** 31 - 64) // (16 * 30 * 30 * 4) and plan[5]
+    # 31 x 31 x 3 inputs: 11532 bytes per sample, not a multiple of 16 -> not chunkable; still one call while the batch fits
+    net2 = ea.ConvNetwork((3, 31, 31), out_channels=16, kernel_size=3, num_layers=2, out_vector_size=8).to(dev).eval()
+    x2 = torch.randn(5, 3, 31, 31, device=dev)
+    with torch.no_grad():
+        fast = net2(x2)
+    with torch.enable_grad():
+        slow = net2(x2).detach()
+    assert not net2._mfma_plan(x2)[5]
+    assert torch.allclose(fast, slow, atol=2e-5 * max(slow.abs().max().item(), 1.0))

@@ -808,7 +808,10 @@ def test_lift_conv_mfma_matches_conv2d(dev):
     torch.manual_seed(31)
     for (B, Cin, K, Cout, H, W) in [(3, 3, 5, 256, 20, 24), (2, 3, 3, 64, 9, 11), (5, 2, 5, 128, 13, 13), (1, 4, 3, 64, 40, 7),
                                     (2, 5, 3, 192, 12, 12), (64, 3, 5, 64, 33, 33), (1, 3, 5, 64, 5, 5), (7, 3, 5, 128, 6, 70),
-                                    (300, 3, 3, 64, 10, 37)]:   # incl. streams of 1, 2, 3 tiles per wave and partial tiles
+                                    (300, 3, 3, 64, 10, 37),
+                                    # channel counts off the 64-multiples (predicated stores, several tiles per row)
+                                    (128, 3, 5, 32, 32, 32), (3, 3, 5, 16, 20, 75), (2, 3, 3, 48, 40, 40), (4, 3, 5, 80, 12, 100),
+                                    (1, 3, 5, 32, 5, 5)]:   # incl. streams of 1, 2, 3 tiles per wave and partial tiles
         assert ops.lift_conv_supported(Cin, K, K, Cout)
         x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
@@ -834,7 +837,7 @@ def test_lift_conv_mfma_matches_conv2d(dev):
     assert torch.isfinite(got[0, :, :7, :]).all() and torch.isfinite(got[0, :, :, :7]).all() and not torch.isfinite(got[0, :, 7, 7]).all()
     # unsupported shapes are refused, not approximated
     lib = _lib.load()
-    assert not ops.lift_conv_supported(1, 5, 5, 64) and not ops.lift_conv_supported(3, 5, 5, 32) and not ops.lift_conv_supported(3, 7, 7, 64)
+    assert not ops.lift_conv_supported(1, 5, 5, 64) and not ops.lift_conv_supported(3, 5, 5, 24) and not ops.lift_conv_supported(3, 7, 7, 64)
     assert not ops.lift_conv_supported(4, 3, 4, 64)      # R = 16: no spare k-slot for the bias
     assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 1, 5, 5, 64, None) == -3
     assert lib.eqa_lift_conv_nhwc(x.data_ptr(), w.data_ptr(), None, 0, got.data_ptr(), 1, 12, 12, 4, 3, 4, 64, None) == -3
@@ -1619,3 +1622,38 @@ def test_fused_vnsmall_any_k_and_both_kernels_match_the_op_path(dev, pooling):
                 assert lib.eqa_set_option(1, 0) == 0
             assert (single - slow).abs().max().item() <= tol * scale, (k, B, N)
     assert lib.eqa_set_option(1, 3) == -1
+
+
+@pytest.mark.parametrize("group_type,N", [("rotation", 4), ("roto-reflection", 4), ("rotation", 8)])
+def test_custom_network_lifting_conv_on_the_mfma_kernel(dev, group_type, N, monkeypatch):
+    """CustomEquivariantNetwork's one convolution (the Z2 -> G lifting layer, custom_group_equivariant_layers.py:92-111 /
+    :190-226 of the reference) on the hand-written fp32-MFMA kernel in inference: the CIFAR-shaped configuration (3 -> 8 fields,
+    k = 5, two layers) against the oracle network, and the layer alone against the framework's convolution."""
+    import torch.nn.functional as F
+
+    import equiadapt_amd as ea
+    from equiadapt_amd import ops
+    from oracle import nets as onets
+
+    torch.manual_seed(17)
+    O = 8 if group_type == "rotation" else 4                 # O * |G| = 32 or 64 channels
+    net = ea.CustomEquivariantNetwork((3, 32, 32), O, 5, group_type, N, 2, device="cpu").to(dev).eval()
+    with torch.no_grad():
+        net.eqv_network[0].bias.normal_(0, 0.1)
+    x = torch.randn(9, 3, 32, 32, device=dev)
+    lift = net.eqv_network[0]
+    assert lift.mfma_lifting_ok(x) is False                   # grad mode: the module path
+    with torch.no_grad():
+        assert lift.mfma_lifting_ok(x)
+        calls = []
+        orig = ops.lift_conv_nhwc
+        monkeypatch.setattr(ops, "lift_conv_nhwc", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+        fast = net(x)
+        y5 = lift(x)                                          # the layer alone, 5-D as the reference returns it
+        assert len(calls) == 2, "the inference paths must run the hand-written kernel"
+    want5 = F.conv2d(x.double(), lift.expanded_weights().double()).reshape(9, O, lift.num_group_elements, 28, 28) \
+        + lift.bias.double()[None, :, None, None, None]
+    assert (y5.double() - want5).abs().max().item() <= 2e-6 * want5.abs().max().item()
+    sd = {k: v.cpu() for k, v in net.state_dict().items()}
+    want = onets.custom_equivariant_network(x.cpu(), sd, group_type, N, 2)
+    assert torch.allclose(fast.cpu(), want, atol=2e-5, rtol=1e-3)
