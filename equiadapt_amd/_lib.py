@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "smallconv.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "smallconv.hip", "planegemm.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "eqa_lift_conv_wgrad_supported": (_int, [_int] * 7),
     "eqa_lift_conv_wgrad_workspace_bytes": (ctypes.c_int64, [_int] * 7),
     "eqa_lift_conv_wgrad_nhwc": (_int, [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp]),
+    "eqa_plane_gemm_supported": (_int, [_int, _int]),
+    "eqa_plane_gemm": (_int, [_vp, _vp, _vp, ctypes.c_longlong, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f2k5_output": (_int, [_vp, _vp, _int, _vp, _int, _int, _int, _int, _vp]),
     "eqa_winograd_f4k5_input": (_int, [_vp, _vp, _vp, _int, _int, _int, _int, _int, _vp]),

@@ -5,7 +5,8 @@ N*N per m x m output tile:  m = 2, points {0, 1, -1, 2, -2, inf}: 36/4 = 9 per o
 {0, 1, -1, 2, -2, 1/2, -1/2, inf}: 64/16 = 4 per output.  Pipeline (channels-last, fp32 throughout), P = N*N:
 
     x (B,H,W,Cin) --eqa_winograd_f{m}k5_input-->  V (tiles, P, Cin)
-    V[:, a] @ U[a]  (strided-batched fp32 GEMM, library)        ->  M (tiles, P, Cout)
+    V[:, a] @ U[a]  (eqa_plane_gemm: hand-written batched fp32-MFMA GEMM; channel counts off the 32-multiples: the
+                     framework's strided-batched GEMM)               ->  M (tiles, P, Cout)
     M --eqa_winograd_f{m}k5_output--> y (B,H-4,W-4,Cout) = [relu](A^T M A + bias)
 
 U = G g G^T is computed once per weight version in fp64 (G carries the non-dyadic fractions; B^T and A^T are exact in
@@ -21,7 +22,7 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
-from equiadapt_amd import _lib
+from equiadapt_amd import _lib, ops
 from equiadapt_amd.ops import _timed
 
 # interpolation points (the last, implicit one is infinity)
@@ -29,6 +30,22 @@ POINTS = {2: (0, 1, -1, 2, -2), 4: (0, 1, -1, 2, -2, Fraction(1, 2), Fraction(-1
 
 CHUNK_IMAGES = int(os.environ.get("EQA_WINOGRAD_CHUNK", "64"))
 KEEP_V_FOR_BACKWARD = os.environ.get("EQA_WINOGRAD_KEEP_V", "1") != "0"
+PLANE_GEMM = os.environ.get("EQA_WINOGRAD_GEMM", "own") != "lib"   # "lib": the framework's strided-batched GEMM (A/B runs)
+
+_packed_cache: dict = {}
+
+
+def _packed_filters(U: torch.Tensor) -> torch.Tensor:
+    """U in the operand-fragment order of eqa_plane_gemm, cached per (storage, version): inference passes the same cached U every
+    call; training builds a new U per step and pays one 64 x Cin x Cout copy for it."""
+    key = (U.data_ptr(), U._version, tuple(U.shape), str(U.device))
+    hit = _packed_cache.get(key)
+    if hit is None:
+        if len(_packed_cache) >= 16:
+            _packed_cache.clear()
+        hit = (U, ops.pack_plane_gemm_weights(U))      # (keeps U alive so that its address cannot be reused under this key)
+        _packed_cache[key] = hit
+    return hit[1]
 
 
 def _polymul(a: Sequence[Fraction], b: Sequence[Fraction]) -> List[Fraction]:
@@ -221,6 +238,7 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
                          dtype=torch.float32, device=x.device)
     p_bias = bias.data_ptr() if bias is not None else None
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
+    Upk = _packed_filters(U) if PLANE_GEMM and ops.plane_gemm_supported(Cin, Cout) else None
     with torch.cuda.device(x.device):
         for b0 in range(0, B, chunk):
             n = min(chunk, B - b0)
@@ -233,7 +251,10 @@ def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu
             _lib.check(st, f"eqa_winograd_f{m}k5_input")
             # plane a is the strided matrix V[:, a, :] (row stride P*Cin): no copy, the library takes lda / batch stride
             with _timed("winograd_gemm"):
-                torch.bmm(V[:t].permute(1, 0, 2), U, out=M[:t].permute(1, 0, 2))
+                if Upk is not None:
+                    ops.plane_gemm(V, Upk, M, t)      # hand-written fp32-MFMA batched GEMM (csrc/planegemm.hip)
+                else:
+                    torch.bmm(V[:t].permute(1, 0, 2), U, out=M[:t].permute(1, 0, 2))
             if sums_k:
                 with _timed("winograd_output_sums"):
                     st = f_sums(M.data_ptr(), p_bias, int(relu), S.data_ptr() + b0 * Cout * sums_k * sums_k * 8,

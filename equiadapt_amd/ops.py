@@ -514,6 +514,29 @@ def window_sums_gemv(S: torch.Tensor, weff: torch.Tensor, scale: float, shift) -
     return act
 
 
+def plane_gemm_supported(cin: int, cout: int) -> bool:
+    return bool(_lib.load().eqa_plane_gemm_supported(cin, cout))
+
+
+def pack_plane_gemm_weights(U: torch.Tensor) -> torch.Tensor:
+    """(P, Cin, Cout) Winograd-domain filters -> the MFMA operand-fragment order of eqa_plane_gemm:
+    Upk[p][s][n][b][32 h + i][t] = U[p][16 s + 8 b + 4 h + t][32 n + i]."""
+    P, Cin, Cout = U.shape
+    t = U.float().reshape(P, Cin // 16, 2, 2, 4, Cout // 32, 32)        # p, s, b, h, t, n, i
+    return t.permute(0, 1, 5, 2, 3, 6, 4).contiguous()                   # p, s, n, b, h, i, t
+
+
+def plane_gemm(V: torch.Tensor, Upk: torch.Tensor, M: torch.Tensor, tiles: int) -> None:
+    """M[:tiles, a] = V[:tiles, a] . U[a] for every plane a (eqa_plane_gemm); V:(T,P,Cin), M:(T,P,Cout) contiguous."""
+    lib = _lib.load()
+    V, Upk, M = _need(V, "V"), _need(Upk, "Upk"), _need(M, "M")
+    P, Cin = V.shape[1], V.shape[2]
+    Cout = M.shape[2]
+    with torch.cuda.device(V.device):
+        st = lib.eqa_plane_gemm(V.data_ptr(), Upk.data_ptr(), M.data_ptr(), tiles, P, Cin, Cout, _stream())
+    _lib.check(st, "eqa_plane_gemm")
+
+
 def lift_conv_supported(cin: int, kh: int, kw: int, cout: int) -> bool:
     """Shapes eqa_lift_conv_nhwc takes (others: the framework's convolution)."""
     return kh in (3, 5) and 9 <= kw * cin <= 15 and cout % 16 == 0

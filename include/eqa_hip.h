@@ -325,11 +325,20 @@ int eqa_lift_conv_wgrad_nhwc(const float* x, const float* dy, void* workspace, f
  *   eqa_winograd_f{m}k5_input   x:(nimg,H,W,C) -> V:(nimg*TY*TX, P, C), TY = (H-4)/m, TX = (W-4)/m   (B^T d B), with
  *                               d = in_relu ? max(x + in_bias[c], 0) : x + in_bias[c]  (in_bias NULL = 0): the previous
  *                               layer's bias / folded batch-norm / ReLU applied while loading
- *   [ strided-batched fp32 GEMM by the caller:  M[:,a] = V[:,a] (tiles x Cin, lda P*Cin) . U[a] (Cin x Cout), a < P ]
+ *   eqa_plane_gemm              M[:,a] = V[:,a] (tiles x Cin, row stride P*Cin) . U[a] (Cin x Cout), a < P: the per-plane
+ *                               channel contraction on the fp32 MFMA (declared below; channel counts it does not take: a
+ *                               strided-batched GEMM by the caller)
  *   eqa_winograd_f{m}k5_output  M:(nimg*TY*TX, P, C) -> y:(nimg,OH,OW,C) = [relu](A^T M A + bias[c]),  m | OH, OW
  * Cook-Toom points {0, 1, -1, 2, -2, [1/2, -1/2,] inf}; matrices in csrc/winograd.hip and
  * images/canonicalization_networks/winograd.py (U = G g G^T in fp64).  EQA_ERR_UNSUPPORTED when m does not divide H-4, W-4.
  */
+/* The per-plane channel contraction of the Winograd convolution (escnn_networks.py:67-91 at shapes the FFT tiles do not fit).
+ * V:(T,P,Cin), M:(T,P,Cout) as above; Upk: U:(P,Cin,Cout) re-ordered into MFMA operand fragments,
+ *   Upk[p][s][n][b][32 h + i][t] = U[p][16 s + 8 b + 4 h + t][32 n + i]     (P, Cin/16, Cout/32, 2, 64, 4)
+ * eqa_plane_gemm_supported: Cin % 32 == 0 and Cout % 32 == 0.  Pointers 16-byte aligned. */
+int eqa_plane_gemm_supported(int Cin, int Cout);
+int eqa_plane_gemm(const float* V, const float* Upk, float* M, long long T, int P, int Cin, int Cout, void* stream);
+
 int eqa_winograd_f2k5_input(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                             void* stream);
 int eqa_winograd_f2k5_output(const float* M, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,

@@ -55,7 +55,13 @@ def main():
     ms = timeit(lambda: _lib.check(f_in(x.data_ptr(), V.data_ptr(), bias.data_ptr(), 1, n, H, H, C, st), "in"), args.reps)
     print(f"input transform   {ms*1e3:8.1f} us  {(gb_v + gb_x)/ms*1e3:7.0f} GB/s  (write {gb_v:.2f} GB + read {gb_x:.2f} GB)")
     ms = timeit(lambda: torch.bmm(Vb, U, out=Mb), args.reps)
-    print(f"batched GEMM      {ms*1e3:8.1f} us  {2*P*t*C*C/ms/1e9:7.1f} TFLOP/s")
+    print(f"batched GEMM (library)  {ms*1e3:8.1f} us  {2*P*t*C*C/ms/1e9:7.1f} TFLOP/s")
+    from equiadapt_amd import ops
+    if ops.plane_gemm_supported(C, C):
+        Upk = ops.pack_plane_gemm_weights(U)
+        V3, M3 = V.view(t, P, C), M.view(t, P, C)
+        ms = timeit(lambda: ops.plane_gemm(V3, Upk, M3, t), args.reps)
+        print(f"eqa_plane_gemm          {ms*1e3:8.1f} us  {2*P*t*C*C/ms/1e9:7.1f} TFLOP/s")
     ms = timeit(lambda: _lib.check(f_out(M.data_ptr(), bias.data_ptr(), 1, y.data_ptr(), n, OH, OH, C, st), "out"), args.reps)
     print(f"output transform  {ms*1e3:8.1f} us  {(gb_v + y.numel()*4/1e9)/ms*1e3:7.0f} GB/s")
     ms = timeit(lambda: _lib.check(f_sums(M.data_ptr(), bias.data_ptr(), 1, S.data_ptr(), ws.data_ptr(), n, OH, OH, C, 5, st), "sums"), args.reps)
