@@ -452,9 +452,10 @@ def leg_configs(comm: Comm, with_cpu: bool):
     can4 = ea.EquivariantPointcloudCanonicalization(vn, hp4).to(dev).eval()
     c4 = {"workload": "configs[3] shape: ModelNet40 (B,3,1024), SO(3): VNSmall(k=20, mean) -> Gram-Schmidt -> rotate "
                       "(the reference defines no invert for clouds)", "unit": "clouds/s", "batches": {}}
-    # VALU-bound: measured 68k VALU wave-instructions per 64 points (PMC SQ_INSTS_VALU) -> 1.09 M per cloud, of which
-    # the kNN distance evaluations are the irreducible 1024 x 1024 x ~5 = 82 k; HBM traffic is 12 KB in + 36 B out per cloud.
-    instr_per_cloud = 16 * 68.0e3
+    # VALU-bound: measured 68.4 M VALU wave-instructions per launch of 64 clouds (PMC SQ_INSTS_VALU, profiles/r03/pmc_vnsmall_quad.txt:
+    # the four-lanes-per-point kernel issues as many as round 2's one-thread-per-point kernel did, on 4 x the waves) -> 1.07 M per
+    # cloud, of which the kNN distance evaluations are the irreducible 1024 x 1024 x ~5 = 82 k; HBM traffic 12 KB in + 36 B out per cloud.
+    instr_per_cloud = 68.4e6 / 64
     for B in (64, 2048):
         pc = torch.randn(B, 3, 1024, device=dev)
         v, ms = run(lambda: can4(pc), B, 20, 5)
@@ -468,10 +469,10 @@ def leg_configs(comm: Comm, with_cpu: bool):
             hipgraph4 = {"value": vg, "ms_per_step": msg}
             del gstep
         c4["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
-            "bound": "valu", "kernel": "vnsmall_fwd_kernel (eqa_vnsmall_fwd)", "achieved": per_gpu * instr_per_cloud / 1e12,
+            "bound": "valu", "kernel": "vnsmall_fwd_quad_kernel<5,false> (eqa_vnsmall_fwd)", "achieved": per_gpu * instr_per_cloud / 1e12,
             "peak": VALU_PEAK_WAVE_INSTR_S / 1e12, "unit": "T wave-instr/s", "frac": per_gpu * instr_per_cloud / VALU_PEAK_WAVE_INSTR_S,
             "hbm_frac": per_gpu * 12324 / 1e9 / HBM_PEAK_GBS,
-            "note": "1.09 M VALU wave-instructions per cloud (kNN distances 82 k of them) against 12 KB of HBM traffic: issue-bound, not HBM-bound"}}
+            "note": "1.07 M VALU wave-instructions per cloud (kNN distances 82 k of them) against 12 KB of HBM traffic: issue-bound, not HBM-bound"}}
         if B == 64:
             c4["batches"][str(B)]["hipgraph"] = hipgraph4
     c4["value"] = c4["batches"]["2048"]["value"]
@@ -509,8 +510,16 @@ def leg_configs(comm: Comm, with_cpu: bool):
         c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
             "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct},
-            "mask_kernel": {"kernel": "nearest_action_tile_kernel via eqa_mask_action_nearest (2 B / mask pixel)", "achieved": ach_m,
+            "mask_kernel": {"kernel": "mask_action_u8_kernel via eqa_mask_action_nearest_planes (2 B / mask pixel)", "achieved": ach_m,
                             "unit": "GB/s", "frac": ach_m / HBM_PEAK_GBS, "avg_launch_ms": ms_mk}}
+        if B == 4:   # BASELINE's own batch: the whole step (image, masks, boxes, invert) captured once and replayed as a hipGraph
+            from equiadapt_amd.graphs import GraphedCanonicalizer
+
+            gstep = GraphedCanonicalizer(can5, x.shape, pred.shape, targets_like=[{"boxes": b, "masks": m} for b, m in zip(boxes, masks)])
+            gstep(x, pred)
+            vg, msg = run(gstep.replay, B, 30, 5)
+            c5["batches"][str(B)]["hipgraph"] = {"value": vg, "ms_per_step": msg}
+            del gstep
     c5["value"] = c5["batches"]["32"]["value"]
     if with_cpu:
         c5["cpu_baseline"] = cpu_baseline_config("cfg5", {})

@@ -197,12 +197,12 @@ __device__ __forceinline__ void lift_epi_store(int j, const f32x4& t, const Lift
     __builtin_amdgcn_raw_buffer_store_b128(v, out, (int)e.out_voff, (int)(j * e.row4), 0);
 }
 
-template <bool MASKED>
+template <bool MASKED, bool HALF = false>
 __device__ __forceinline__ void lift_epi_all(const LiftEpi& e, const f32x16& p0, const f32x16& p1, __amdgpu_buffer_rsrc_t out, int left) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     lift_epi_write(g, p0, e.tr_w);
-    lift_epi_write(g, p1, e.tr_w + 32);
+    if (!HALF) lift_epi_write(g, p1, e.tr_w + 32);
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) lift_epi_store<MASKED>(j, *reinterpret_cast<const f32x4*>(e.tr_r + 4 * j * kLiftTrPitch), e, out, left);
@@ -210,7 +210,8 @@ __device__ __forceinline__ void lift_epi_all(const LiftEpi& e, const f32x16& p0,
 
 // One tile's MFMA stream.  Between the MFMAs: row ky of the NEXT tile moves LDS -> a[ky] as soon as the 16 MFMAs reading
 // a[ky] have issued, and (EPI) the previous tile's accumulators p0 / p1 are clamped and stored in 8 groups.
-template <int KH, bool EPI, bool MASKED>
+// HALF: the wave's slice has at most 32 channels (Cout <= 32): the second N-tile's MFMAs, half of the stream, are not issued.
+template <int KH, bool EPI, bool MASKED, bool HALF = false>
 __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float (&b1)[KH * 8], float (&a)[KH][8],
                                           const float* __restrict__ lds_next, int a_off, int a_q0, f32x16& acc0, f32x16& acc1,
                                           const f32x16& p0, const f32x16& p1, const LiftEpi& e,
@@ -231,7 +232,7 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
     for (int q = 0; q < 8; ++q) {
       const int s = ky * 8 + q;
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a[ky][q], s == 0 ? zero : acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a[ky][q], s == 0 ? zero : acc1, 0, 0, 0);
+      if (!HALF) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a[ky][q], s == 0 ? zero : acc1, 0, 0, 0);
     }
     lift_read_row<KH>(lds_next, ky, a_off, a_q0, a);
     if (EPI) {
@@ -239,7 +240,7 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           lift_epi_write(g, p0, e.tr_w);
-          lift_epi_write(g, p1, e.tr_w + 32);
+          if (!HALF) lift_epi_write(g, p1, e.tr_w + 32);
         }
       } else {        // ... and out: bias, ReLU, store
 #pragma unroll
@@ -255,7 +256,7 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
   // ds_read_b32: 128; every VALU: +6 wherever it sits (the matrix core and the vector ALU share the issue port) -- hence
   // no bias add, no accumulator copies and an integer max as the ReLU: 32 VALU instructions per tile.
 #pragma unroll
-  for (int m = 0; m < KH * 16; ++m) {
+  for (int m = 0; m < KH * (HALF ? 8 : 16); ++m) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
     __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);  // one LDS instruction (two writes behind one MFMA cost 40 cycles)
     __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);  // one VALU (each costs ~6 cycles of matrix time wherever it sits)
@@ -264,7 +265,7 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
   }
 }
 
-template <int KH, bool MASKED>
+template <int KH, bool MASKED, bool HALF = false>
 __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                                     const float* __restrict__ bias, int relu,
                                                                     float* __restrict__ y, int H, int W, int Cin, int R,
@@ -360,13 +361,13 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   __amdgpu_buffer_rsrc_t po = out_of(pA, left);  // where tile 0 goes (stored during step 1)
   lift_stage_store<KH>(lds[1], lane, G1);
   lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
-  lift_tile<KH, false, MASKED>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, e0, e1, epi, po, 0);
+  lift_tile<KH, false, MASKED, HALF>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, e0, e1, epi, po, 0);
   // the first trip of the loop must not inherit a shorter queue than the later ones: the compiler takes the minimum over
   // both ways in when it counts how many loads and stores may still be in flight at the LDS writes
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   for (unsigned i = 1;; i += 2) {
     if (i >= count) {
-      lift_epi_all<MASKED>(epi, e0, e1, po, left);
+      lift_epi_all<MASKED, HALF>(epi, e0, e1, po, left);
       lift_stage_pin<KH>(G0);  // a use on the way out as well: otherwise the compiler sinks the loads below the exit test,
       lift_stage_pin<KH>(G1);  // in front of their first use one or two steps later
       LIFT_CLOCK_END();
@@ -379,12 +380,12 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
     lift_stage_store<KH>(lds[0], lane, G0);
     lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G0);
     __amdgpu_buffer_rsrc_t pn = out_of(pA, left_next);  // tile i: scalar work inside the stream, not in front of it
-    lift_tile<KH, true, MASKED>(b0, b1, a, lds[0], a_off, a_q0, o0, o1, e0, e1, epi, po, left);
+    lift_tile<KH, true, MASKED, HALF>(b0, b1, a, lds[0], a_off, a_q0, o0, o1, e0, e1, epi, po, left);
     po = pn;
     left = left_next;
 
     if (i + 1 >= count) {
-      lift_epi_all<MASKED>(epi, o0, o1, po, left);
+      lift_epi_all<MASKED, HALF>(epi, o0, o1, po, left);
       lift_stage_pin<KH>(G0);
       lift_stage_pin<KH>(G1);
       LIFT_CLOCK_END();
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
     lift_stage_store<KH>(lds[1], lane, G1);
     lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
     pn = out_of(pA, left_next);  // tile i + 1
-    lift_tile<KH, true, MASKED>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, o0, o1, epi, po, left);
+    lift_tile<KH, true, MASKED, HALF>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, o0, o1, epi, po, left);
     po = pn;
     left = left_next;
   }
@@ -429,13 +430,13 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   const unsigned waves = nslices * nstreams, per_block = kThreads / 64;
   const dim3 grid((waves + per_block - 1) / per_block);
   hipStream_t st = (hipStream_t)stream;
-#define EQA_LIFT_LAUNCH(KH_, MASKED_)                                                                                      \
-  hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
+#define EQA_LIFT_LAUNCH(KH_, MASKED_, HALF_)                                                                                      \
+  hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_, HALF_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
                      OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped)
   if (KH == 5) {
-    if (OW < 32 || narrow) EQA_LIFT_LAUNCH(5, true); else EQA_LIFT_LAUNCH(5, false);
+    if (Cout <= 32) EQA_LIFT_LAUNCH(5, true, true); else if (OW < 32 || narrow) EQA_LIFT_LAUNCH(5, true, false); else EQA_LIFT_LAUNCH(5, false, false);
   } else {
-    if (OW < 32 || narrow) EQA_LIFT_LAUNCH(3, true); else EQA_LIFT_LAUNCH(3, false);
+    if (Cout <= 32) EQA_LIFT_LAUNCH(3, true, true); else if (OW < 32 || narrow) EQA_LIFT_LAUNCH(3, true, false); else EQA_LIFT_LAUNCH(3, false, false);
   }
 #undef EQA_LIFT_LAUNCH
   return launch_status();

@@ -382,6 +382,9 @@ def mask_action_nearest(masks: torch.Tensor, eidx: torch.Tensor, rtheta: torch.T
     return out
 
 
+_plane_tables: dict = {}
+
+
 def mask_action_nearest_planes(mask_list, eidx: torch.Tensor, rtheta: torch.Tensor, flags: Optional[torch.Tensor]) -> torch.Tensor:
     """I6 for a LIST of per-sample (n_t, H, W) uint8 mask tensors: one launch over all planes, read through a table of plane
     pointers (eqa_mask_action_nearest_planes) instead of a concatenated copy.  Returns one (sum n_t, H, W) tensor."""
@@ -391,10 +394,18 @@ def mask_action_nearest_planes(mask_list, eidx: torch.Tensor, rtheta: torch.Tens
     flags, p_flags = _opt(flags, "flags", torch.int32)
     masks = [_need(m, "masks", torch.uint8) for m in mask_list]
     H, W = masks[0].shape[-2:]
-    ptrs = [m.data_ptr() + k * H * W for m in masks for k in range(m.shape[0])]
+    ptrs = tuple(m.data_ptr() + k * H * W for m in masks for k in range(m.shape[0]))
     n = len(ptrs)
     dev = masks[0].device
-    table = torch.tensor(ptrs, dtype=torch.int64).to(dev, non_blocking=True)
+    # the pointer table is uploaded once per set of mask tensors: a loop that re-uses its target buffers (and a captured
+    # hipGraph, which must not contain a pageable host-to-device copy) finds it on the device
+    key = (ptrs, str(dev))
+    table = _plane_tables.get(key)
+    if table is None:
+        if len(_plane_tables) >= 64:
+            _plane_tables.clear()
+        table = torch.tensor(ptrs, dtype=torch.int64).to(dev)
+        _plane_tables[key] = table
     out = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev), _timed("mask_action"):
         st = lib.eqa_mask_action_nearest_planes(table.data_ptr(), out.data_ptr(), eidx.data_ptr(), rtheta.data_ptr(), p_flags,

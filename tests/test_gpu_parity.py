@@ -1459,6 +1459,47 @@ def test_graphed_canonicalizer_matches_eager(dev):
     assert inv is None and torch.equal(y, y_e) and torch.equal(R, can4.canonicalization_info_dict["group_element"]["rotation"])
 
 
+def test_graphed_canonicalizer_with_targets_matches_eager(dev):
+    """The COCO-shaped step (optimised D4 canonicalizer + ConvNetwork, uint8 masks and boxes as targets, scalar invert) captured as
+    one hipGraph: image, masks, boxes and the inverted output replay bit-identically to the eager step on new data
+    (reference: discrete_group.py:190-259 with the targets branch :217-236)."""
+    import equiadapt_amd as ea
+    from equiadapt_amd.graphs import GraphedCanonicalizer
+
+    torch.manual_seed(29)
+    net = ea.ConvNetwork((3, 32, 32), out_channels=16, kernel_size=3, num_layers=2, out_vector_size=16)
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=32, group_type="roto-reflection", num_rotations=4,
+                               artifact_err_wt=0.0, learn_ref_vec=False)
+    can = ea.OptimizedGroupEquivariantImageCanonicalization(net, hp, (3, 64, 64)).to(dev).eval()
+    B = 5
+
+    def make(seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, 3, 64, 64, generator=g).to(dev)
+        f = torch.randn(B, 1, 64, 64, generator=g).to(dev)
+        t = [{"boxes": (torch.rand(2, 4, generator=g) * 30 + torch.tensor([0.0, 0.0, 30.0, 30.0])).to(dev),
+              "masks": (torch.rand(2, 64, 64, generator=g) > 0.5).to(torch.uint8).to(dev)} for _ in range(B)]
+        return x, f, t
+
+    x, f, t = make(0)
+    step = GraphedCanonicalizer(can, x.shape, f.shape, targets_like=t)
+    for seed in (1, 2):
+        x, f, t = make(seed)
+        boxes_before = [d["boxes"].clone() for d in t]
+        y, idx, inv = step(x, f, t)
+        torch.cuda.synchronize()
+        got = (y.clone(), idx.clone(), inv.clone(), [{k: v.clone() for k, v in d.items()} for d in step.targets])
+        assert all(torch.equal(a, d["boxes"]) for a, d in zip(boxes_before, t)), "the caller's boxes are copied, not flipped in place"
+        with torch.no_grad():
+            y_e, t_e = can(x, [{k: v.clone() for k, v in d.items()} for d in t])
+            inv_e = can.invert_canonicalization(f, induced_rep_type="scalar")
+        assert torch.equal(got[0], y_e) and torch.equal(got[1], can.canonicalization_info_dict["group_index"]) and torch.equal(got[2], inv_e)
+        for a, b in zip(got[3], t_e):
+            assert torch.equal(a["masks"], b["masks"]) and torch.equal(a["boxes"], b["boxes"])
+    with pytest.raises(ValueError, match="target"):
+        step(x, f, [{"boxes": d["boxes"][:1], "masks": d["masks"]} for d in t])
+
+
 def test_grouped_activation_layout_between_lift_and_fft(dev):
     """The lifting convolution's channel-group-major output (eqa_lift_conv_grouped) holds exactly the channels-last result, and the
     FFT convolution reads it (eqa_fft48k5_input_grouped) to exactly the same spectra / output -- the layout changes which bytes sit

@@ -8,7 +8,7 @@ net5 = ea.ConvNetwork((3, 128, 128), out_channels=16, kernel_size=7, num_layers=
 hp5 = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=128, group_type="roto-reflection", num_rotations=4,
                             artifact_err_wt=0.0, learn_ref_vec=False)
 can5 = ea.OptimizedGroupEquivariantImageCanonicalization(net5, hp5, (3, 1024, 1024)).to(dev).eval()
-B = 32
+B = int(os.environ.get("B", "32"))
 x = torch.randn(B, 3, 1024, 1024, device=dev); pred = torch.randn(B, 1, 1024, 1024, device=dev)
 masks = [(torch.rand(3, 1024, 1024, device=dev) > 0.5).to(torch.uint8) for _ in range(B)]
 boxes = [torch.tensor([[10.0, 20.0, 200.0, 300.0]] * 3, device=dev) for _ in range(B)]
