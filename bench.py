@@ -644,7 +644,7 @@ def main():
         # correction; tools/collect_traffic.sh).  Counters cannot be collected inside this process, so the committed
         # measurement of the same kernel / shape is reported; null when it does not match this run's shape.
         traffic, tsrc = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "traffic_group_action.json")
             if os.path.exists(tpath) and B == 256:
                 traffic, tsrc = json.load(open(tpath)).get("traffic_bytes_per_launch"), f"profiles/{rnd}/traffic_group_action.json"
@@ -674,7 +674,7 @@ def main():
             d = dict(line["stages"][dom])
             tr = None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r02", "traffic_canon_net.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic_canon_net.json")))
                 key = {"fft_gemm": "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
                        "lift_conv": "lift_conv_mfma_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
@@ -682,7 +682,7 @@ def main():
                 pass
             line["roofline_dominant"] = {"stage": dom, "kernel": d.get("what"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                                          "unit": d["unit"], "frac": d["frac"], "avg_launch_ms": d["ms"], "share_of_step": d["ms"] / line["ms_per_step"],
-                                         "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r02/traffic_canon_net.json)"}
+                                         "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r03/traffic_canon_net.json)"}
 
     if args.mode in ("all", "train"):
         line["train"] = leg_train_images(comm, args.train_steps, args.train_warmup, args.train_batch)
