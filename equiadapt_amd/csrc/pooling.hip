@@ -232,9 +232,14 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int Q = C >> 2;  // channel quads
+  // fewer than 64 channel quads (C = 32: 8): a wave instruction covers P = 64 / Q pixels instead of leaving 64 - Q lanes idle
+  // (the CIFAR-shaped configuration ran this kernel at 0.95 TB/s with 8 of 64 lanes loading); the P pixel groups of a lane's
+  // quad are added up by a butterfly before the totals leave the wave
+  const int P = (Q < 64 && (64 % Q) == 0) ? 64 / Q : 1;
+  const int psub = P > 1 ? lane / Q : 0;
   const float4* xb = reinterpret_cast<const float4*>(x + (size_t)b * H * W * C);
   for (int q0 = 0; q0 < Q; q0 += 64) {
-    const int q = q0 + lane;
+    const int q = P > 1 ? lane % Q : q0 + lane;
     const bool on = q < Q;
     const int qq = on ? q : Q - 1;
     const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[qq] : make_float4(1.f, 1.f, 1.f, 1.f);
@@ -251,9 +256,10 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
     for (int y = y0; y < y1; ++y) {
       // the 4 waves take pixels x = wave, wave+4, ...: each load instruction reads one pixel's channels, contiguous
       float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
-      int xc = wave;
-      for (; xc + 4 < W; xc += 8) {
-        const float4 a = ld(y, xc), c2 = ld(y, xc + 4);
+      const int xs = 4 * P;   // pixels covered by the block's four waves per step
+      int xc = wave * P + psub;
+      for (; xc + xs < W; xc += 2 * xs) {
+        const float4 a = ld(y, xc), c2 = ld(y, xc + xs);
         t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
         t1.x += c2.x; t1.y += c2.y; t1.z += c2.z; t1.w += c2.w;
       }
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
       // border columns (static j, wave-uniform owner): re-read from L1
 #pragma unroll
       for (int j = 0; j < kWsMaxBorder; ++j) {
-        if (j < nb) {
+        if (j < nb && psub == 0) {   // (one pixel: the lanes of pixel group 0 own it)
           if ((j & 3) == wave) { const float4 a = ld(y, j); acc[1 + j].x += a.x; acc[1 + j].y += a.y; acc[1 + j].z += a.z; acc[1 + j].w += a.w; }
           const int xr = W - nb + j;
           if ((xr & 3) == wave) {
@@ -277,17 +283,24 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
       float* o = part + ((((size_t)b * nseg + s) * Q + q) * 4) * nval + i;
       o[0] = v.x; o[nval] = v.y; o[2 * nval] = v.z; o[3 * nval] = v.w;
     };
+    if (P > 1) {   // totals of the P pixel groups -> the lanes of group 0 (fixed order: deterministic)
+      for (int off = 32; off >= Q; off >>= 1) {
+        acc[0].x += __shfl_down(acc[0].x, off); acc[0].y += __shfl_down(acc[0].y, off);
+        acc[0].z += __shfl_down(acc[0].z, off); acc[0].w += __shfl_down(acc[0].w, off);
+      }
+    }
+    const bool owner = on && psub == 0;
     __syncthreads();
     s_tot[wave][lane] = acc[0];
 #pragma unroll
     for (int j = 0; j < kWsMaxBorder; ++j) {
-      if (j < nb && on) {
+      if (j < nb && owner) {
         if ((j & 3) == wave) put(1 + j, acc[1 + j]);
         if (((W - nb + j) & 3) == wave) put(1 + nb + j, acc[1 + kWsMaxBorder + j]);
       }
     }
     __syncthreads();
-    if (wave == 0 && on) {
+    if (wave == 0 && owner) {
       const float4 a = s_tot[0][lane], b2 = s_tot[1][lane], c2 = s_tot[2][lane], d = s_tot[3][lane];
       put(0, make_float4((a.x + b2.x) + (c2.x + d.x), (a.y + b2.y) + (c2.y + d.y), (a.z + b2.z) + (c2.z + d.z), (a.w + b2.w) + (c2.w + d.w)));
     }

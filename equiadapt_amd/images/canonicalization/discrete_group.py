@@ -174,6 +174,10 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
             from equiadapt_amd.images.transforms import resized_output_size
 
             out_hw = resized_output_size(crop.size, resize.size)
+            if tuple(out_hw) == tuple(x.shape[-2:]) == tuple(crop.size):
+                # crop ratio 1 and a resize to the size the image already has (the CIFAR-shaped configuration): CenterCrop returns
+                # the image and torchvision's resize returns its input when the size matches -- no kernel at all
+                return x
             if out_hw[0] <= crop.size[0] and out_hw[1] <= crop.size[1]:  # down-sampling (the reference's use)
                 key = (tuple(x.shape[-2:]), crop.size, out_hw, str(x.device))
                 tabs = self._consts.get(key)

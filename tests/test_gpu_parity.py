@@ -339,6 +339,25 @@ def test_window_sums_matches_unfold(dev):
         assert torch.allclose(got, want, atol=1e-6 * H * W, rtol=1e-9)
 
 
+def test_window_sums_channels_last_few_channels(dev):
+    """eqa_window_sums_nhwc with fewer than 64 channel quads: a wave instruction covers several pixels (C = 8, 16, 32, 64, 128), the
+    general path (C = 48: 12 quads do not divide 64; C = 512: two trips), k = 1 (the 1 x 1 tail of the CIFAR-shaped network),
+    3 and 5, widths that do not divide the pixel step -- against fp64 unfold sums."""
+    from equiadapt_amd import ops
+
+    torch.manual_seed(13)
+    for (B, C, H, W, k) in [(3, 32, 28, 28, 1), (2, 8, 30, 37, 3), (2, 16, 12, 9, 5), (1, 64, 20, 21, 5), (2, 128, 11, 50, 3), (2, 48, 14, 14, 3),
+                            (1, 512, 10, 12, 1), (5, 32, 9, 200, 5)]:
+        x = torch.randn(B, C, H, W).to(dev).contiguous(memory_format=torch.channels_last)
+        scale, shift = (torch.rand(C) + 0.5).to(dev), (torch.randn(C) * 0.3).to(dev)
+        assert not x.is_contiguous() or C == 1
+        got = ops.window_sums(x, k, scale, shift, relu=True).cpu()
+        a = torch.relu(x.double().cpu() * scale.double().cpu()[None, :, None, None] + shift.double().cpu()[None, :, None, None])
+        OH, OW = H - k + 1, W - k + 1
+        want = torch.stack([torch.stack([a[:, :, u:u + OH, v:v + OW].sum(dim=(2, 3)) for v in range(k)], -1) for u in range(k)], -2)
+        assert torch.allclose(got, want, atol=2e-6 * H * W, rtol=1e-9), (B, C, H, W, k)
+
+
 @pytest.mark.parametrize("group_type", ["rotation", "roto-reflection"])
 def test_linear_tail_fast_path_equals_conv_path(dev, group_type):
     """Inference fast path (window sums instead of the last conv, BN folded) vs the plain module path and the oracle."""
