@@ -52,6 +52,9 @@ SIGNATURES = {
     "eqa_bn_relu_dropout_nhwc": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, ctypes.c_float, ctypes.c_uint32, _vp]),
     "eqa_bn_bwd_reduce_nhwc": (_int, [_vp] * 5 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_uint32, _vp]),
     "eqa_bn_bwd_apply_nhwc": (_int, [_vp] * 8 + [ctypes.c_float, _vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_uint32, _vp]),
+    "eqa_window_sums_nhwc_act": (_int, [_vp, _vp, _vp, _int, ctypes.c_float, ctypes.c_uint32, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_bn_bwd_reduce_nhwc_wsgrad": (_int, [_vp] * 4 + [ctypes.c_float, _vp] + [_int] * 5 + [_vp, _vp, ctypes.c_uint32, _vp]),
+    "eqa_bn_bwd_apply_nhwc_wsgrad": (_int, [_vp] * 7 + [ctypes.c_float, _vp] + [_int] * 5 + [_vp, _vp, ctypes.c_uint32, _vp]),
     "eqa_vn_blocks": (_int, [_int]),
     "eqa_vn_knn": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "eqa_vn_convpos_stats": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _vp]),

@@ -11,11 +11,7 @@ namespace {
 
 constexpr int kBnPixPerBlock = 256;  // pixels per block of the two reductions: (N / 256) x C x 2 fp64 partials
 
-// counter-based hash for the dropout mask (one draw per element, reproducible from (seed, element index))
-__device__ __forceinline__ uint32_t mix32(uint32_t h) {
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-  return h;
-}
+// (the dropout mask's counter-based hash, mix32 / dropout_keep_quad: eqa_common.hpp)
 
 // partial[(blk * C + c) * 2 + {0, 1}] = sum, sum of squares over the block's pixels (fp32 inside a block of <= 256 pixels,
 // fp64 across blocks by the caller: deterministic)
@@ -81,19 +77,36 @@ __device__ __forceinline__ void bn_live_quad(const float4& v, const float4& sc, 
                                              uint32_t seed, bool (&live)[4]) {
   const float o[4] = {fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
                       fmaxf(v.w * sc.w + sh.w, 0.f)};
-  const uint32_t base = mix32((uint32_t)i * 0x9E3779B1u + seed) ^ (uint32_t)(i >> 32);
+  bool keep[4];
+  dropout_keep_quad(i, drop_threshold, seed, keep);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) live[k] = o[k] > 0.f && (!drop_threshold || mix32(base + (uint32_t)k * 0x632BE5ABu) >= drop_threshold);
+  for (int k = 0; k < 4; ++k) live[k] = o[k] > 0.f && keep[k];
+}
+
+// The gradient of a hidden block whose output feeds only the window sums of the linearised last layer (pooling.hip) depends on a
+// pixel only through the CLASS of its row and of its column (border index < nb, interior, bottom / right border): TABLE mode reads
+// gy[b][y][x][c] = table[b][cls(y)][cls(x)][c] from the (B, 2nb+1, 2nb+1, C) table instead of an expanded (B, H, W, C) map that
+// one kernel would write and two would read (2.2 GB each way at the headline shape).
+struct WsGradGeom {
+  int H, W, nb;   // map size, k - 1
+};
+__device__ __forceinline__ int ws_cls(int i, int n, int nb) { return i < nb ? i : (i >= n - nb ? i - (n - nb) + nb + 1 : nb); }
+__device__ __forceinline__ size_t ws_table_quad(size_t p, int q, int Q, const WsGradGeom& g) {   // pixel index -> quad index in the table
+  const unsigned hw = (unsigned)g.H * (unsigned)g.W;
+  const unsigned b = (unsigned)(p / hw), r = (unsigned)(p - (size_t)b * hw);
+  const unsigned y = r / (unsigned)g.W, x = r - y * (unsigned)g.W;
+  const unsigned T = 2 * g.nb + 1;
+  return ((size_t)(b * T + ws_cls((int)y, g.H, g.nb)) * T + ws_cls((int)x, g.W, g.nb)) * Q + q;
 }
 
 // g = gy * (y > 0 ? inv_keep : 0)  (gradient at the batch-norm output);  partial sums of g and g * xhat per channel
-template <bool RECOMPUTE>
+template <bool RECOMPUTE, bool TABLE = false>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                      const float* __restrict__ x, const float* __restrict__ mean,
                                                                      const float* __restrict__ rstd, float inv_keep,
                                                                      double* __restrict__ partial, size_t npix, int C,
                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                     uint32_t drop_threshold, uint32_t seed) {
+                                                                     uint32_t drop_threshold, uint32_t seed, WsGradGeom geom) {
   __shared__ float4 s_red[2][kThreads];
   const int Q = C >> 2;
   const int lanes = min(Q, kThreads);
@@ -110,7 +123,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
     if (r0 < rows && has_q) {
       for (size_t p = p0 + r0; p < p1; p += rows) {
         const size_t i = p * Q + q;
-        const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(gy)[TABLE ? ws_table_quad(p, q, Q, geom) : i];
         const float4 x4 = reinterpret_cast<const float4*>(x)[i];
         bool live[4];
         if (RECOMPUTE) {
@@ -146,17 +159,17 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_nhwc_kernel(const floa
 // dx = a[c] * (g - b[c] - xhat * d[c]),  xhat = (x - mean[c]) * rstd[c],  g as above.
 // (a = gamma * rstd, b = sum(g) / n, d = sum(g xhat) / n per FIELD, expanded to channels by the caller; with running
 // statistics -- eval mode under autograd -- b = d = 0.)
-template <bool RECOMPUTE>
+template <bool RECOMPUTE, bool TABLE = false>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_nhwc_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                                     const float* __restrict__ x, const float* __restrict__ mean,
                                                                     const float* __restrict__ rstd, const float* __restrict__ a,
                                                                     const float* __restrict__ b, const float* __restrict__ d,
                                                                     float inv_keep, float* __restrict__ dx, size_t nquad, int Q,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                    uint32_t drop_threshold, uint32_t seed) {
+                                                                    uint32_t drop_threshold, uint32_t seed, WsGradGeom geom) {
   for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
     const int q = (int)(i % Q);
-    const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+    const float4 g4 = reinterpret_cast<const float4*>(gy)[TABLE ? ws_table_quad(i / Q, q, Q, geom) : i];
     const float4 x4 = reinterpret_cast<const float4*>(x)[i];
     bool live[4];
     if (RECOMPUTE) {
@@ -178,9 +191,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_nhwc_kernel(const float
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-inline uint32_t drop_threshold(float drop_p) {
-  return drop_p > 0.0f ? (uint32_t)std::min<double>((double)drop_p * 4294967296.0, 4294967295.0) : 0u;
-}
+inline uint32_t drop_threshold(float drop_p) { return dropout_threshold(drop_p); }
 inline unsigned stream_blocks(size_t nquad) { return (unsigned)std::min<size_t>((nquad + kThreads - 1) / kThreads, 256 * 32); }
 
 }  // namespace
@@ -225,10 +236,10 @@ int eqa_bn_bwd_reduce_nhwc(const float* gy, const float* y, const float* x, cons
   const float inv_keep = 1.0f / (1.0f - drop_p);
   if (y)
     hipLaunchKernelGGL(bn_bwd_reduce_nhwc_kernel<false>, grid, dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean, rstd, inv_keep,
-                       partial, (size_t)n_pixels, C, scale, shift, 0u, seed);
+                       partial, (size_t)n_pixels, C, scale, shift, 0u, seed, WsGradGeom{0, 0, 0});
   else
     hipLaunchKernelGGL(bn_bwd_reduce_nhwc_kernel<true>, grid, dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean, rstd, inv_keep,
-                       partial, (size_t)n_pixels, C, scale, shift, drop_threshold(drop_p), seed);
+                       partial, (size_t)n_pixels, C, scale, shift, drop_threshold(drop_p), seed, WsGradGeom{0, 0, 0});
   return launch_status();
 }
 
@@ -245,10 +256,47 @@ int eqa_bn_bwd_apply_nhwc(const float* gy, const float* y, const float* x, const
   const float inv_keep = 1.0f / (1.0f - drop_p);
   if (y)
     hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel<false>, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean,
-                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, 0u, seed);
+                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, 0u, seed, WsGradGeom{0, 0, 0});
   else
     hipLaunchKernelGGL(bn_bwd_apply_nhwc_kernel<true>, dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, gy, y, x, mean,
-                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, drop_threshold(drop_p), seed);
+                       rstd, a, b, d, inv_keep, dx, nquad, C >> 2, scale, shift, drop_threshold(drop_p), seed, WsGradGeom{0, 0, 0});
+  return launch_status();
+}
+
+// The two backward passes of a hidden block whose output feeds only the window sums (eqa_window_sums_nhwc_act): the upstream
+// gradient is the (B, 2k-1, 2k-1, C) class table of the window sums' backward, read in place of an expanded (B, H, W, C) map;
+// "kept and positive" is recomputed from x, scale, shift and the seed.  x:(B,H,W,C).
+int eqa_bn_bwd_reduce_nhwc_wsgrad(const float* table, const float* x, const float* mean, const float* rstd, float drop_p,
+                                  double* partial, int B, int H, int W, int C, int k, const float* scale, const float* shift,
+                                  uint32_t seed, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || !(drop_p >= 0.0f && drop_p < 1.0f)) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (!table || !x || !mean || !rstd || !partial || !scale || !shift) return EQA_ERR_INVALID_ARG;
+  if (H < 2 * k - 1 || W < 2 * k - 1) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || !aligned16(table) || !aligned16(x) || !aligned16(mean) || !aligned16(rstd) || !aligned16(scale) || !aligned16(shift) ||
+      (size_t)B * H * W > 0x7fffffffULL)
+    return EQA_ERR_UNSUPPORTED;
+  const int64_t npix = (int64_t)B * H * W;
+  hipLaunchKernelGGL((bn_bwd_reduce_nhwc_kernel<true, true>), dim3((unsigned)eqa_bn_partial_blocks(npix)), dim3(kThreads), 0,
+                     (hipStream_t)stream, table, (const float*)nullptr, x, mean, rstd, 1.0f / (1.0f - drop_p), partial, (size_t)npix, C, scale,
+                     shift, drop_threshold(drop_p), seed, WsGradGeom{H, W, k - 1});
+  return launch_status();
+}
+
+int eqa_bn_bwd_apply_nhwc_wsgrad(const float* table, const float* x, const float* mean, const float* rstd, const float* a,
+                                 const float* b, const float* d, float drop_p, float* dx, int B, int H, int W, int C, int k,
+                                 const float* scale, const float* shift, uint32_t seed, void* stream) {
+  if (B < 0 || H <= 0 || W <= 0 || C <= 0 || k <= 0 || !(drop_p >= 0.0f && drop_p < 1.0f)) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (!table || !x || !mean || !rstd || !a || !b || !d || !dx || !scale || !shift) return EQA_ERR_INVALID_ARG;
+  if (H < 2 * k - 1 || W < 2 * k - 1) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || !aligned16(table) || !aligned16(x) || !aligned16(dx) || !aligned16(mean) || !aligned16(rstd) || !aligned16(a) ||
+      !aligned16(b) || !aligned16(d) || !aligned16(scale) || !aligned16(shift) || (size_t)B * H * W > 0x7fffffffULL)
+    return EQA_ERR_UNSUPPORTED;
+  const size_t nquad = (size_t)B * H * W * (C >> 2);
+  hipLaunchKernelGGL((bn_bwd_apply_nhwc_kernel<true, true>), dim3(stream_blocks(nquad)), dim3(kThreads), 0, (hipStream_t)stream, table,
+                     (const float*)nullptr, x, mean, rstd, a, b, d, 1.0f / (1.0f - drop_p), dx, nquad, C >> 2, scale, shift,
+                     drop_threshold(drop_p), seed, WsGradGeom{H, W, k - 1});
   return launch_status();
 }
 

@@ -41,6 +41,22 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 
 extern int g_vn_kernel_choice;  // pointcloud.hip; eqa_set_option key 1
 
+// Counter-based hash for the dropout mask of the canonicalization network's hidden blocks (one draw per element, reproducible from
+// (seed, element index)): shared by batchnorm.hip (which writes / recomputes the mask) and pooling.hip (the window sums that
+// consume a hidden block without its output ever being written).  i = index of the channel QUAD in the channels-last map.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+__device__ __forceinline__ void dropout_keep_quad(size_t i, uint32_t drop_threshold, uint32_t seed, bool (&keep)[4]) {
+  const uint32_t base = mix32((uint32_t)i * 0x9E3779B1u + seed) ^ (uint32_t)(i >> 32);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) keep[k] = !drop_threshold || mix32(base + (uint32_t)k * 0x632BE5ABu) >= drop_threshold;
+}
+inline uint32_t dropout_threshold(float drop_p) {
+  return drop_p > 0.0f ? (uint32_t)std::min<double>((double)drop_p * 4294967296.0, 4294967295.0) : 0u;
+}
+
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
 
 // pooling.hip: part (B, nseg, C, 1 + 2(k-1)) row segments -> S (B, C, k, k) fp64; used by eqa_window_sums_nhwc and by the

@@ -219,10 +219,14 @@ __device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands,
   y1 = lo + (int)(((long long)rows * (band + 1)) / nbands);
 }
 
+// drop_threshold != 0: act also carries the dropout of a training-mode hidden block (mask = the hash batchnorm.hip uses, on the
+// element's quad index in the (B, H, W, C / 4) map; kept elements x inv_keep) -- the block's output is consumed here without ever
+// being written (eqa_window_sums_nhwc_act).
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                            const float* __restrict__ shift, int relu,
                                                                            float* __restrict__ part, int C, int H, int W, int k,
-                                                                           int nbands) {
+                                                                           int nbands, uint32_t drop_threshold, float inv_keep,
+                                                                           uint32_t seed) {
   __shared__ float4 s_tot[4][64];  // only the totals need a cross-wave sum; a border column has ONE owner wave
   const int s = blockIdx.x, b = blockIdx.y;
   const int nseg = gridDim.x;
@@ -245,9 +249,16 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
     const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[qq] : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 sh = shift ? reinterpret_cast<const float4*>(shift)[qq] : make_float4(0.f, 0.f, 0.f, 0.f);
     auto ld = [&](int y, int xc) {
-      float4 v = xb[((size_t)y * W + xc) * Q + qq];
+      const size_t e = ((size_t)y * W + xc) * Q + qq;
+      float4 v = xb[e];
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
       if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (drop_threshold) {   // uniform
+        bool keep[4];
+        dropout_keep_quad((size_t)b * H * W * Q + e, drop_threshold, seed, keep);
+        v.x = keep[0] ? v.x * inv_keep : 0.f; v.y = keep[1] ? v.y * inv_keep : 0.f;
+        v.z = keep[2] ? v.z * inv_keep : 0.f; v.w = keep[3] ? v.w * inv_keep : 0.f;
+      }
       return v;
     };
     float4 acc[1 + 2 * kWsMaxBorder];
@@ -588,8 +599,22 @@ int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k) {
   return (int64_t)B * nseg * C * (1 + 2 * (k - 1)) * (int64_t)sizeof(float);
 }
 
+static int window_sums_nhwc_impl(const float* x, const float* scale, const float* shift, int relu, float drop_p, uint32_t seed, double* out,
+                                 void* workspace, int B, int C, int H, int W, int k, void* stream);
+
 int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
                          int B, int C, int H, int W, int k, void* stream) {
+  return window_sums_nhwc_impl(x, scale, shift, relu, 0.0f, 0u, out, workspace, B, C, H, W, k, stream);
+}
+
+int eqa_window_sums_nhwc_act(const float* x, const float* scale, const float* shift, int relu, float drop_p, uint32_t seed, double* out,
+                             void* workspace, int B, int C, int H, int W, int k, void* stream) {
+  if (!(drop_p >= 0.0f && drop_p < 1.0f)) return EQA_ERR_INVALID_ARG;
+  return window_sums_nhwc_impl(x, scale, shift, relu, drop_p, seed, out, workspace, B, C, H, W, k, stream);
+}
+
+static int window_sums_nhwc_impl(const float* x, const float* scale, const float* shift, int relu, float drop_p, uint32_t seed, double* out,
+                                 void* workspace, int B, int C, int H, int W, int k, void* stream) {
   if (!x || !out || !workspace || B < 0 || C <= 0 || H <= 0 || W <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
   // needs disjoint top / bottom (left / right) border sets and at least one interior row
   if (k > kMaxWinK || C % 4 != 0 || H < 2 * (k - 1) + 1 || W < 2 * (k - 1) + 1 || B > 65535) return EQA_ERR_UNSUPPORTED;
@@ -599,7 +624,7 @@ int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift,
   const int nbands = ws_nhwc_bands(H, k);
   const int nseg = 2 * (k - 1) + nbands;
   hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
-                     (float*)workspace, C, H, W, k, nbands);
+                     (float*)workspace, C, H, W, k, nbands, dropout_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, st,
                      (const float*)workspace, out, B, C, k, nseg, 1);

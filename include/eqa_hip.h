@@ -279,6 +279,25 @@ int eqa_bn_bwd_reduce_nhwc(const float* gy, const float* y, const float* x, cons
 int eqa_bn_bwd_apply_nhwc(const float* gy, const float* y, const float* x, const float* mean, const float* rstd, const float* a,
                           const float* b, const float* d, float drop_p, float* dx, int64_t n_pixels, int C, const float* scale,
                           const float* shift, uint32_t seed, void* stream);
+/*
+ * The LAST hidden block (the one in front of the linearised final convolution, escnn_networks.py:67-91 + :106-115) without its
+ * output ever being written, in training:
+ *   eqa_window_sums_nhwc_act        eqa_window_sums_nhwc of dropout(relu(scale[c] * x + shift[c])) with the dropout mask of
+ *                                   eqa_bn_relu_dropout_nhwc (same hash of (seed, element index)) applied on the fly;
+ *   eqa_bn_bwd_reduce_nhwc_wsgrad,  the two backward passes of the block with the upstream gradient given as the window sums'
+ *   eqa_bn_bwd_apply_nhwc_wsgrad    (B, 2k-1, 2k-1, C) class table (gy[b][y][x][c] = table[b][cls(y)][cls(x)][c]; classes: the
+ *                                   k-1 top / left border indices, the interior, the k-1 bottom / right ones) instead of an
+ *                                   expanded (B, H, W, C) map; "kept and positive" recomputed from x, scale, shift, seed.
+ * x:(B,H,W,C) channels-last, C % 4 == 0; partial / a / b / d as in the plain forms.
+ */
+int eqa_window_sums_nhwc_act(const float* x, const float* scale, const float* shift, int relu, float drop_p, uint32_t seed, double* out,
+                             void* workspace, int B, int C, int H, int W, int k, void* stream);
+int eqa_bn_bwd_reduce_nhwc_wsgrad(const float* table, const float* x, const float* mean, const float* rstd, float drop_p,
+                                  double* partial, int B, int H, int W, int C, int k, const float* scale, const float* shift,
+                                  uint32_t seed, void* stream);
+int eqa_bn_bwd_apply_nhwc_wsgrad(const float* table, const float* x, const float* mean, const float* rstd, const float* a,
+                                 const float* b, const float* d, float drop_p, float* dx, int B, int H, int W, int C, int k,
+                                 const float* scale, const float* shift, uint32_t seed, void* stream);
 
 /*
  * The GEMV after the window sums (last convolution + mean over channels and positions, escnn_networks.py:115,

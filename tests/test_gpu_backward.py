@@ -788,3 +788,40 @@ def test_fft_wgrad3m_matches_the_real_product(dev, M, Cin, Cout):
     _lib.check(lib.eqa_fft48k5_filter_grad3m(D.data_ptr(), db3.data_ptr(), Cout, Cin, None), "eqa_fft48k5_filter_grad3m")
     _lib.check(lib.eqa_fft48k5_filter_grad(D4.data_ptr(), db4.data_ptr(), Cout, Cin, None), "eqa_fft48k5_filter_grad")
     assert (db3 - db4).abs().max().item() <= 5e-6 * db4.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group_type,N,size", [("rotation", 8, 96), ("roto-reflection", 4, 40), ("rotation", 4, 30)])
+def test_fused_last_block_into_window_sums_is_bit_identical(dev, group_type, N, size, monkeypatch):
+    """The last hidden block consumed by the window sums without being written (InnerBnReluDropoutWindowSums: affine + ReLU +
+    dropout mask applied while eqa_window_sums_nhwc_act loads h; backward from the (2k-1)^2 class table) against the two-stage form
+    (InnerBnReluDropout writes the block's output, WindowSumsFunction reads it; its backward expands the table to a map): same
+    statistics, same mask, same per-element arithmetic and summation order -- activations, every parameter gradient and the
+    running statistics must agree bit for bit, with dropout ACTIVE (p = 0.5, seeds from torch's CPU generator)."""
+    import copy
+
+    import equiadapt_amd as ea
+
+    torch.manual_seed(5)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", True)    # the framework's filter-gradient solvers (small shapes) must not use atomics
+    net = ea.ESCNNEquivariantNetwork((3, size, size), 8, 5, group_type, N, 3).to(dev).train()
+    ref = copy.deepcopy(net)
+    ref2 = copy.deepcopy(net)
+    x = torch.randn(6, 3, size, size, device=dev)
+    w = torch.randn(6, net.num_group_elements, device=dev)
+    outs = []
+    for model, fused in ((net, "1"), (ref, "0"), (ref2, "0")):
+        monkeypatch.setenv("EQA_TRAIN_FUSED_TAIL", fused)
+        torch.manual_seed(99)                       # the dropout seeds
+        a = model(x)
+        (a * w).sum().backward()
+        outs.append(a.detach())
+    monkeypatch.delenv("EQA_TRAIN_FUSED_TAIL")
+    assert torch.equal(outs[0], outs[1])
+    for (n1, p1), (n2, p2), (n3, p3) in zip(net.named_parameters(), ref.named_parameters(), ref2.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), n1
+        if p1.grad is not None:
+            assert torch.equal(p2.grad, p3.grad), f"{n1}: the two-stage form is not reproducible run to run"
+            assert torch.equal(p1.grad, p2.grad), (n1, (p1.grad - p2.grad).abs().max().item(), p2.grad.abs().max().item())
+    for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert torch.equal(b1, b2), n1
