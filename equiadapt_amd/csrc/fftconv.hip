@@ -419,6 +419,146 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
   FFT_CLOCK(12);
 }
 
+// The fused forward transform as a persistent producer / consumer pipeline (round 3; the mirror image of fft48_inv_pipe_kernel
+// further down).  Counters on the one-block-per-item kernel above (profiles/r03/pmc_memory_path.md): 52 cache lines per CU in flight,
+// but each waits 1,538 cycles, twice a streaming kernel's latency -- the kernel's 2.5 GB of reads queue behind its own 2.5 GB of
+// writes, which a block issues in one burst at the end of its life while no other block of the CU is loading.  Here the block's
+// waves are specialised and walk the work items together:
+//   row waves (6, thread (row ry, channel): rows ry and ry + 24):  (wait for the 96 loads of item i) two real-input transforms ->
+//        LDS | barrier A | issue the 96 loads of item i+1 | barrier B
+//   column waves (6, thread (column, channel)):  barrier A | read the column from LDS | barrier B | transform, 96 stores
+// so an item's stores and the next item's loads are in the memory system at the same time, and the column waves' arithmetic
+// overlaps the row waves'.  24 x 16 column tasks for 25 columns: the two purely real columns kx = 0 and kx = 24 (spectra of real
+// rows at the DC and Nyquist bins) ride in ONE complex transform, z = c0 + i c24, and are separated afterwards:
+//   C0[k] = (Z[k] + conj(Z[-k])) / 2,   C24[k] = (Z[k] - conj(Z[-k])) / 2i        (k = 0..24: the rows the edge columns store).
+// 12 waves = 3 per SIMD, 162 VGPRs, no scratch.  Only for full-width tiles of a plain channel-group-major map (the headline case).
+// MEASURED (B = 256, inside the step): 1.066 ms against the one-block-per-item kernel's 0.957 -- correct (same tests) but SLOWER,
+// so it is opt-in (EQA_FFT_FWD_PIPE=1) and the kernel above stays the default.  Why: an item's stores and the next item's loads
+// do overlap now, but with ONE LDS buffer the chain load(i+1) -> row transforms -> A -> column read -> B is serial, and during
+// the row transforms (6 waves: ~7 k cycles) plus the column read nothing new is requested: ~35 k cycles per item against 31 k.
+// Hiding that needs the NEXT item's rows in flight while this item's are transformed: 2 x 96 loaded registers per row thread,
+// which 168 do not hold next to the transform (the inverse pipeline holds ONE incoming column per producer).  Also measured:
+// issuing the loads after B instead of before (1.08 ms), priority for the row waves (1.16 ms).
+constexpr int kFwdRowT = 6 * 64, kFwdColT = 6 * 64, kFwdPipeThreads = kFwdRowT + kFwdColT;
+
+__global__ __launch_bounds__(kFwdPipeThreads) void fft48_fwd_pipe_kernel(const float* __restrict__ x, float* __restrict__ V, int H, int W,
+                                                                        int C, int TY, int TX, size_t M, unsigned nwork, int win,
+                                                                        unsigned x_bytes, unsigned v_bytes) {
+  extern __shared__ float lds[];
+  const unsigned nblk = gridDim.x;               // a multiple of the XCD count (or < 8): virtual block v runs on XCD v % 8
+  const int ngrp = C / kFusCh;
+  const unsigned q8 = nwork / kXcd, r8 = nwork % kXcd;
+  auto work_of = [&](unsigned v) {
+    const unsigned xcd = v % kXcd;
+    return (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + v / kXcd;
+  };
+  if (threadIdx.x < kFwdRowT) {
+    // ---------------------------------------------------------------- row waves
+    const int ry = threadIdx.x / kFusCh, cl = threadIdx.x % kFusCh;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+    float r0[kFftN], r1[kFftN];
+    // item -> byte offsets of this thread's two rows (out of range = zero row: rows beyond the map or beyond the tile's window;
+    // 0xffffe000 + the largest scalar offset does not wrap, and the launcher keeps the map below it)
+#define EQA_FWD_ISSUE(v_)                                                                                                     \
+  do {                                                                                                                        \
+    const unsigned work_ = work_of(v_);                                                                                       \
+    const unsigned grp_ = work_ % ngrp, m_ = work_ / ngrp;                                                                    \
+    const unsigned tx_ = m_ % TX, ty_ = (m_ / TX) % TY, img_ = m_ / (TX * TY);                                                \
+    const int gy0_ = kFftO * (int)ty_ + ry, gy1_ = gy0_ + 24;                                                                 \
+    const bool in0_ = (v_) < nwork && gy0_ < H && ry < win, in1_ = (v_) < nwork && gy1_ < H && ry + 24 < win;                 \
+    const size_t plane_ = ((size_t)img_ * ngrp + grp_) * H;                                                                   \
+    const unsigned o0_ = in0_ ? (unsigned)((((plane_ + gy0_) * W + (size_t)kFftO * tx_) * kFusCh + cl) * 4) : 0xffffe000u;   \
+    const unsigned o1_ = in1_ ? (unsigned)((((plane_ + gy1_) * W + (size_t)kFftO * tx_) * kFusCh + cl) * 4) : 0xffffe000u;   \
+    _Pragma("unroll") for (int j = 0; j < kFftN; ++j) {                                                                      \
+      r0[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o0_, (unsigned)(j * kFusCh * 4), 0));        \
+      r1[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o1_, (unsigned)(j * kFusCh * 4), 0));        \
+    }                                                                                                                         \
+  } while (0)
+    unsigned v = blockIdx.x;
+    EQA_FWD_ISSUE(v);
+    float* const o0 = lds + (ry * 2) * kFusCh + cl;
+    float* const o1 = lds + ((ry + 24) * 2) * kFusCh + cl;
+    for (; v < nwork; v += nblk) {
+      float ore[kFftH], oim[kFftH];
+      fft48_r2c(r0, ore, oim);
+#pragma unroll
+      for (int k = 0; k < kFftH; ++k) {
+        o0[k * kFusKxPitch] = ore[k];
+        o0[k * kFusKxPitch + kFusCh] = oim[k];
+      }
+      fft48_r2c(r1, ore, oim);
+#pragma unroll
+      for (int k = 0; k < kFftH; ++k) {
+        o1[k * kFusKxPitch] = ore[k];
+        o1[k * kFusKxPitch + kFusCh] = oim[k];
+      }
+      __syncthreads();                                   // A: the item's row spectra are in LDS
+      EQA_FWD_ISSUE(v + nblk);
+      asm volatile("" ::: "memory");                     // the loads stay on this side of the barrier
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                   // B: the column waves have read their columns
+    }
+#undef EQA_FWD_ISSUE
+    return;
+  }
+  // ------------------------------------------------------------------ column waves
+  const int t = threadIdx.x - kFwdRowT;
+  const int kc = t / kFusCh, cl = t % kFusCh;
+  const bool packed = kc == kFftInner;                   // the last column task: kx = 0 and kx = 24 in one transform
+  const int kx = packed ? 0 : kc + 1;
+  const float* const qre = lds + kx * kFusKxPitch + cl;
+  // imaginary parts: the column's own (interior columns); the REAL parts of column 24 (packed task)
+  const float* const qim = packed ? lds + (kFftH - 1) * kFusKxPitch + cl : qre + kFusCh;
+  const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(V, 0, v_bytes, 0x00020000);
+  const unsigned step_in = (unsigned)((size_t)kFftInner * M * 2 * C * 4);       // interior columns: 23 frequencies per ky
+  const unsigned step_ed = (unsigned)((size_t)2 * M * 2 * C * 4);               // edge columns: 2 per ky
+  for (unsigned v = blockIdx.x; v < nwork; v += nblk) {
+    const unsigned work = work_of(v);
+    const unsigned grp = work % ngrp, m = work / ngrp;
+    float re[kFftN], im[kFftN], ore[kFftN], oim[kFftN];
+    __syncthreads();                                     // A
+#pragma unroll
+    for (int i = 0; i < kFftN; ++i) {
+      re[i] = qre[(i * 2) * kFusCh];
+      im[i] = qim[(i * 2) * kFusCh];
+    }
+    __syncthreads();                                     // B: LDS may be overwritten (the column is in registers)
+    fft48(re, im, ore, oim);
+    // [Re x 16 | Im x 16] per channel group and (frequency, tile): Re at +0, Im at +64 bytes
+    const unsigned col = (unsigned)(((size_t)m * 2 * C + grp * 2 * kFusCh + cl) * 4);
+    if (!__any(packed)) {                                // wave-uniform: waves without the packed task
+      const unsigned voff = (unsigned)((size_t)(kx - 1) * M * 2 * C * 4) + col;
+#pragma unroll
+      for (int ky = 0; ky < kFftN; ++ky) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ore[ky]), vr, voff, ky * step_in, 2);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oim[ky]), vr, voff + kFusCh * 4, ky * step_in, 2);
+      }
+    } else {
+      if (!packed) {
+        const unsigned voff = (unsigned)((size_t)(kx - 1) * M * 2 * C * 4) + col;
+#pragma unroll
+        for (int ky = 0; ky < kFftN; ++ky) {
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ore[ky]), vr, voff, ky * step_in, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, oim[ky]), vr, voff + kFusCh * 4, ky * step_in, 2);
+        }
+      } else {
+        // frequencies 1104 + 2 ky (kx = 0) and 1104 + 2 ky + 1 (kx = 24), ky = 0..24
+        const unsigned v0 = (unsigned)((size_t)(kFftN * kFftInner) * M * 2 * C * 4) + col;
+        const unsigned v24 = v0 + (unsigned)((size_t)M * 2 * C * 4);
+#pragma unroll
+        for (int ky = 0; ky < kFftH; ++ky) {
+          const int kn = (kFftN - ky) % kFftN;
+          const float a = ore[ky], b = oim[ky], c2 = ore[kn], d = oim[kn];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (a + c2)), vr, v0, ky * step_ed, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (b - d)), vr, v0 + kFusCh * 4, ky * step_ed, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (b + d)), vr, v24, ky * step_ed, 2);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, 0.5f * (c2 - a)), vr, v24 + kFusCh * 4, ky * step_ed, 2);
+        }
+      }
+    }
+  }
+}
+
 // Window-sum pieces of one output row of a tile: [sum of the 44 columns, the NB leftmost columns of the map, the NB
 // rightmost].  The leftmost columns live in tile column 0 at j = 0..NB-1.  The rightmost start at j = a (uniform, any
 // value): they are pulled out of the register array by a shift network on the bits of a -- 81 selects on 6 scalar
@@ -1118,6 +1258,19 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
       const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
+      // the pipelined form: a plain channel-group-major map, every tile full-width, 32-bit offsets, enough items to keep 256 blocks busy
+      const char* pipe_env = getenv("EQA_FFT_FWD_PIPE");      // "1": opt in to the pipelined form (read per call: tests toggle it)
+      const bool pipe_off = !(pipe_env != nullptr && pipe_env[0] == '1');
+      static const bool pipe_lds_ok =
+          hipFuncSetAttribute((const void*)fft48_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
+      const bool full_width = W >= kFftN && (W - kFftN) % kFftO == 0 && TX == (W - kFftN) / kFftO + 1;
+      if (!pipe_off && pipe_lds_ok && x_grouped && !in_bias && !in_relu && full_width && xb <= 0xffffe000ULL && vb <= 0xfffffff0ULL &&
+          nwork >= 2048 && (size_t)nimg * (C / kFusCh) * H <= 0x7fffffffULL) {
+        const unsigned nblk = 256;   // one persistent block per CU
+        hipLaunchKernelGGL(fft48_fwd_pipe_kernel, dim3(nblk), dim3(kFwdPipeThreads), kFusLds * sizeof(float), st, x, V, H, W, C, TY, TX,
+                           fft_pitch(M), nwork, win, (unsigned)xb, (unsigned)vb);
+        return launch_status();
+      }
       hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
                          W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
                          vb <= 0xfffffff0ULL ? (unsigned)vb : 0u, x_grouped);

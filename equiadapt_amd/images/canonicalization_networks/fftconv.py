@@ -12,7 +12,7 @@ from typing import Optional
 
 import torch
 
-from equiadapt_amd import _lib
+from equiadapt_amd import _lib, ops
 from equiadapt_amd.ops import _timed
 
 N, NH, OUT = 48, 25, 44
@@ -116,6 +116,8 @@ def grouped_applicable(shape, cin: int, cout: int, device, max_waste: float = 1.
         return False
     if os.environ.get("EQA_FFT_GROUPED", "1") == "0" or not _lib.load().eqa_fft48k5_input_grouped_supported(cin):
         return False
+    if not gemm3m_supported(cin, cout) and ops.plane_gemm_supported(cin, cout):   # see `applicable`
+        return False
     H, W = shape[-2:]
     if H < 16 or W < 16 or shape[0] * tiles(H) * tiles(W) < MIN_TILES:
         return False
@@ -132,6 +134,10 @@ def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) ->
         return False
     H, W = x.shape[-2:]
     if H < 16 or W < 16 or x.shape[1] != cin:
+        return False
+    if not gemm3m_supported(cin, cout) and ops.plane_gemm_supported(cin, cout):
+        # (e.g. 32 output channels: the complex GEMM wants 64-column tiles, the Winograd planes' GEMM takes 32 -- the path whose
+        # contraction is hand-written wins over the one that would call the library)
         return False
     oh, ow = H - 4, W - 4
     if x.shape[0] * tiles(H) * tiles(W) < MIN_TILES:

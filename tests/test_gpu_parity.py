@@ -1740,3 +1740,33 @@ def test_plane_gemm_matches_the_batched_product(dev):
     assert not ops.plane_gemm_supported(48, 64) and not ops.plane_gemm_supported(64, 48)
     lib = _lib.load()
     assert lib.eqa_plane_gemm(V.data_ptr(), U.data_ptr(), M.data_ptr(), 10, 36, 48, 64, None) == -3
+
+
+def test_fft_forward_pipeline_matches_the_one_block_per_item_kernel(dev, monkeypatch):
+    """fft48_fwd_pipe_kernel (EQA_FFT_FWD_PIPE=1: persistent row / column waves, the two real edge columns packed into one complex
+    transform) against the default fft48_fwd_fused_kernel on the same channel-group-major map: the convolution's output within 1e-6 of its
+    scale (the packed edge columns round differently), and both within the FFT path's 2e-6 of an fp64 convolution."""
+    import torch.nn.functional as F
+
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(44)
+    B, C = 64, 128
+    x = torch.randn(B, 3, 96, 96, device=dev).contiguous(memory_format=torch.channels_last)
+    bank = torch.randn(C, 3, 5, 5, device=dev) / 8
+    g = fftconv.GroupedMap(ops.lift_conv_grouped(x, ops.pack_lift_weights(bank), None, True, 5, 5))
+    assert fftconv.applicable(g, C, C)
+    w2 = torch.randn(C, C, 5, 5, device=dev) / 60
+    b2 = torch.randn(C, device=dev)
+    Bf = fftconv.spectra_for(w2)
+    o_item = fftconv.conv5x5(g, Bf, b2, True)
+    monkeypatch.setenv("EQA_FFT_FWD_PIPE", "1")          # opt-in: measured slower than the default kernel (csrc/fftconv.hip)
+    o_pipe = fftconv.conv5x5(g, Bf, b2, True)
+    monkeypatch.delenv("EQA_FFT_FWD_PIPE")
+    scale = o_item.abs().max().item()
+    assert (o_pipe - o_item).abs().max().item() <= 1e-6 * scale
+    assert not torch.equal(o_pipe, o_item), "the two kernels round the edge columns differently: identical output means the pipeline did not run"
+    y = g.to_channels_last()[:4]
+    want = torch.relu(F.conv2d(y.double(), w2.double(), b2.double()))
+    assert (o_pipe[:4].double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
