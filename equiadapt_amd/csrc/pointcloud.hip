@@ -602,7 +602,7 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
   int nblk;
   if (single) {
     const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
-    if (lds > 96 * 1024) return EQA_ERR_UNSUPPORTED;
+    if (lds > 64 * 1024) return EQA_ERR_UNSUPPORTED;   // (the default dynamic-LDS limit of a launch; larger clouds: the quad kernel)
     nblk = (N + kVnThreads - 1) / kVnThreads;
     if (pooling == 1)
       hipLaunchKernelGGL(vnsmall_fwd_kernel<true>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
@@ -614,13 +614,20 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
     nblk = (N + kVnQPts - 1) / kVnQPts;
     const dim3 grid(nblk, B), blk(kVnQThreads);
     float* ws = (float*)workspace;
+    // clouds beyond ~2,500 points need more dynamic LDS than the default 64 KB limit of a launch
+#define EQA_VN_QUAD_LAUNCH(SEG_, MAX_)                                                                                              \
+  do {                                                                                                                             \
+    static const bool big_ok = hipFuncSetAttribute((const void*)vnsmall_fwd_quad_kernel<SEG_, MAX_>,                               \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;           \
+    if (lds > 64 * 1024 && !big_ok) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }                                        \
+    hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<SEG_, MAX_>), grid, blk, lds, st, x, params, ws, N, k, nblk);                       \
+  } while (0)
     if (k <= 20) {
-      if (pooling == 1) hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<5, true>), grid, blk, lds, st, x, params, ws, N, k, nblk);
-      else hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<5, false>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+      if (pooling == 1) EQA_VN_QUAD_LAUNCH(5, true); else EQA_VN_QUAD_LAUNCH(5, false);
     } else {
-      if (pooling == 1) hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<8, true>), grid, blk, lds, st, x, params, ws, N, k, nblk);
-      else hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<8, false>), grid, blk, lds, st, x, params, ws, N, k, nblk);
+      if (pooling == 1) EQA_VN_QUAD_LAUNCH(8, true); else EQA_VN_QUAD_LAUNCH(8, false);
     }
+#undef EQA_VN_QUAD_LAUNCH
   }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);

@@ -283,7 +283,8 @@ inline int vn_check(const void* x, const void* idx, int B, int N, int k, size_t&
   if (B < 0 || N <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
   if (N < k || k > 32) return EQA_ERR_UNSUPPORTED;
   lds = knn ? ((size_t)4 * ((N + 15) & ~15) + 2 * kVnQSlots * kVnQThreads) * sizeof(float) : (size_t)4 * ((N + 3) & ~3) * sizeof(float);
-  if (lds > 128 * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
+  // the kNN kernel raises its dynamic-LDS limit (eqa_vn_knn); the four passes hold only the cloud and stay inside the default 64 KB
+  if (lds > (knn ? 128 : 64) * 1024 || B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
   if (!x || !idx) return EQA_ERR_INVALID_ARG;
   return 1;  // go
@@ -302,6 +303,9 @@ int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream) 
   const int rc = vn_check(x, idx, B, N, k, lds, true);
   if (rc != 1) return rc;
   const dim3 grid(vn_knn_blocks(N), B);
+  static const bool big5 = hipFuncSetAttribute((const void*)vn_knn_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+  static const bool big8 = hipFuncSetAttribute((const void*)vn_knn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
+  if (lds > 64 * 1024 && !(k <= 20 ? big5 : big8)) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }
   if (k <= 20)
     hipLaunchKernelGGL(vn_knn_kernel<5>, grid, dim3(kVnQThreads), lds, (hipStream_t)stream, x, idx, N, k);
   else

@@ -267,7 +267,7 @@ class VNSmall(nn.Module):
 
             return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn, self.pooling)
         if (point_cloud.is_cuda and torch.is_grad_enabled() and not point_cloud.requires_grad and self.pooling == "mean"
-                and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32
+                and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 4096 and point_cloud.dtype == torch.float32
                 and os.environ.get("EQA_TRAIN_FAST", "1") != "0"):
             # training: the (B, 21, 3, N, k) edge tensors of the first block are never materialised (csrc/vnsmall_train.hip)
             cp = self.conv_pos

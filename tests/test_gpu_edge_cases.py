@@ -286,3 +286,26 @@ def test_conv_network_fast_path_in_batch_chunks(dev):
         slow = net2(x2).detach()
     assert not net2._mfma_plan(x2)[5]
     assert torch.allclose(fast, slow, atol=2e-5 * max(slow.abs().max().item(), 1.0))
+
+
+def test_vnsmall_large_clouds(dev):
+    """Clouds beyond the default 64 KB of dynamic LDS per launch (the fused kernel stages a cloud as 16 bytes per point): 4096 and
+    6144 points in eval mode (the quad kernel raises its limit), 4096 in training (the largest the four first-block passes hold);
+    one point more than 6144 takes the op-by-op path instead of raising."""
+    import equiadapt_amd as ea
+
+    torch.manual_seed(8)
+    net = ea.VNSmall(types.SimpleNamespace(n_knn=20, pooling="mean")).to(dev).eval()
+    for N in (4096, 6144, 6145):
+        x = torch.randn(1, 3, N, device=dev)
+        with torch.no_grad():
+            fast = net(x)
+        if N <= 6144:
+            with torch.enable_grad():
+                slow = net(x).detach()          # with autograd: the training kernels (N <= 4096) / the op-by-op path, running statistics
+            assert torch.allclose(fast, slow, atol=3e-6, rtol=1e-4), N
+        assert torch.isfinite(fast).all()
+    net.train()
+    out = net(torch.randn(2, 3, 4096, device=dev))
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
