@@ -94,3 +94,34 @@ class GroupInference(VanillaInference):
         metrics["test/acc"] = (preds == y).float().mean()
         metrics.update(self._class_metrics(preds, y, clamp=False))
         return metrics
+
+
+def invert_detection_outputs(canonicalizer: torch.nn.Module, outputs, image_width: int):
+    """Map a detection / segmentation network's per-image outputs (dicts with "boxes", "labels", "scores", "masks") from the
+    canonical frame back to the input's, as the reference's segmentation ``GroupInference.forward`` does
+    (examples/images/segmentation/inference_utils.py:86-117): boxes rotated by the image's +rotation angle about
+    (W/2, W/2) and re-sorted (images/utils.py:161-187), then h-flipped where the image's element carries a reflection
+    (:97-109); labels, scores and masks are passed through unchanged (the reference does not transform the masks there).
+    All boxes of the batch go through ONE launch (``eqa_boxes_action``) and the reflection indicator stays on the device: the
+    reference loops over the samples and reads ``if reflection`` on the host once per image."""
+    info = getattr(canonicalizer, "canonicalization_info_dict", None)
+    if not info:
+        return outputs                                  # identity canonicalization: outputs are already in the input's frame
+    element = info["group_element"]
+    rotation = element["rotation"].detach()
+    reflection = element.get("reflection")
+    box_list = [o["boxes"] for o in outputs]
+    counts = [int(b.shape[0]) for b in box_list]
+    if sum(counts) == 0:
+        return [dict(boxes=o["boxes"], labels=o["labels"], scores=o["scores"], masks=o["masks"]) for o in outputs]
+    from equiadapt_amd.images.utils import owner_table
+
+    all_boxes = torch.cat(list(box_list), dim=0).contiguous().float()
+    owner = owner_table(counts, all_boxes.device)
+    rotated, _ = ops.boxes_action(all_boxes, owner, rotation.float().contiguous(), image_width, False)
+    if reflection is not None:
+        flipped = rotated.clone()
+        flipped[:, 0] = image_width - rotated[:, 2]
+        flipped[:, 2] = image_width - rotated[:, 0]
+        rotated = torch.where((reflection.detach()[owner.long()] != 0)[:, None], flipped, rotated)
+    return [dict(boxes=b, labels=o["labels"], scores=o["scores"], masks=o["masks"]) for b, o in zip(rotated.split(counts), outputs)]

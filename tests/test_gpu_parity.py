@@ -1770,3 +1770,33 @@ def test_fft_forward_pipeline_matches_the_one_block_per_item_kernel(dev, monkeyp
     y = g.to_channels_last()[:4]
     want = torch.relu(F.conv2d(y.double(), w2.double(), b2.double()))
     assert (o_pipe[:4].double() - want).abs().max().item() <= 2e-6 * want.abs().max().item()
+
+
+def test_invert_detection_outputs_matches_the_reference_loop(dev):
+    """inference.invert_detection_outputs: the box inversion of the reference's segmentation GroupInference.forward
+    (examples/images/segmentation/inference_utils.py:86-117: rotate_boxes(+degree) then flip_boxes where the element reflects; labels /
+    scores / masks passed through) for a whole batch in one launch, against the oracle's per-sample loop."""
+    from equiadapt_amd.inference import invert_detection_outputs
+
+    torch.manual_seed(71)
+    B, W = 9, 200
+    rot = torch.tensor([0.0, 90.0, 180.0, 270.0, 45.0, 315.0, 90.0, 0.0, 180.0])
+    refl = torch.tensor([0.0, 1.0, 0.0, 1.0, 1.0, 0.0, 0.0, 1.0, 1.0])
+    outs = []
+    for i in range(B):
+        n = [3, 0, 1, 5, 2, 4, 1, 2, 3][i]
+        xy = torch.rand(n, 2) * 100
+        boxes = torch.cat([xy, xy + torch.rand(n, 2) * 90 + 1], dim=1)
+        outs.append({"boxes": boxes, "labels": torch.arange(n), "scores": torch.rand(n), "masks": (torch.rand(n, 8, 8) > 0.5)})
+    for with_reflection in (True, False):
+        can = types.SimpleNamespace(canonicalization_info_dict={"group_element": {"rotation": rot.to(dev), **({"reflection": refl.to(dev)} if with_reflection else {})}})
+        got = invert_detection_outputs(can, [{k: v.to(dev) for k, v in o.items()} for o in outs], W)
+        for i, (g, o) in enumerate(zip(got, outs)):
+            want = io.rotate_boxes(o["boxes"].clone(), rot[i], W)
+            if with_reflection and refl[i]:
+                want = io.flip_boxes(want, W)
+            assert g["boxes"].shape == want.shape
+            assert torch.allclose(g["boxes"].cpu(), want, atol=2e-4), (with_reflection, i)
+            assert torch.equal(g["labels"].cpu(), o["labels"]) and torch.equal(g["masks"].cpu(), o["masks"]) and torch.equal(g["scores"].cpu(), o["scores"])
+    ident = types.SimpleNamespace(canonicalization_info_dict={})
+    assert invert_detection_outputs(ident, outs, W) is outs
