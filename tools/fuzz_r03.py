@@ -1,0 +1,157 @@
+"""Randomised shapes through round 3's kernels against torch references: python tools/fuzz_r03.py [--seconds 60]
+  * eqa_vn_knn / eqa_vnsmall_fwd (four lanes per point): random B, N, k, pooling; neighbour sets vs topk, output vs the op path;
+    determinism (same input twice -> same bits)
+  * eqa_plane_gemm: random T, P in {36, 64}, channel counts on the 32-multiples vs the fp64 product
+  * eqa_lift_conv_nhwc: random sizes, channel counts on the 16-multiples vs F.conv2d in fp64
+  * eqa_group_action_pair vs the two separate launches (bit-equal)"""
+import argparse
+import os
+import random
+import sys
+import time
+import types
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import equiadapt_amd as ea  # noqa: E402
+from equiadapt_amd import _lib, ops  # noqa: E402
+from equiadapt_amd.images.utils import device_tables  # noqa: E402
+from equiadapt_amd.pointcloud.canonicalization_networks.equivariant_networks import get_graph_feature_cross, knn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dump", default=None, help="where to save the inputs of a failing VNSmall case")
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    rng = random.Random(args.seed)
+    torch.manual_seed(args.seed)
+    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0}
+    worst = {}
+    t_end = time.time() + args.seconds
+    while time.time() < t_end:
+        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair"])
+        if what in ("knn", "vnsmall"):
+            k = rng.randint(1, 32)
+            N = rng.choice([k, k + 1, rng.randint(k, 200), rng.randint(k, 1500), 1024])
+            B = rng.randint(1, 9)
+            x = torch.randn(B, 3, N, device=dev) * rng.choice([0.3, 1.0, 5.0]) + rng.choice([0.0, 2.0])
+            if what == "knn":
+                idx = torch.empty(B, N, k, dtype=torch.int32, device=dev)
+                assert lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, None) == 0
+                torch.cuda.synchronize()
+                want = knn(x, k)
+                srt = idx.long().sort(-1).values
+                assert (srt >= 0).all() and (srt < N).all() and (srt[..., 1:] != srt[..., :-1]).all(), ("knn indices", B, N, k)
+                bad = (srt != want.sort(-1).values).any(-1)
+                if bad.any():      # only candidates within the fp32 rounding of the squared distances may differ from topk's choice
+                    assert N > k, ("knn with N == k must return every point", B, N, k)
+                    xd = x.double().transpose(1, 2)
+                    d = (xd[:, :, None, :] - xd[:, None, :, :]).pow(2).sum(-1)
+                    kth = d.topk(k, dim=-1, largest=False).values[..., -1]
+                    chosen = d.gather(-1, idx.long()).max(-1).values
+                    slack = 1e-5 * xd.pow(2).sum(-1).max().item()      # |x|^2 + |y|^2 - 2<x, y> in fp32: ~ eps |x|^2 absolute
+                    assert (chosen[bad] <= kth[bad] + slack).all(), ("knn", B, N, k, int(bad.sum()), (chosen - kth)[bad].max().item(), slack)
+            else:
+                pooling = rng.choice(["mean", "max"])
+                net = ea.VNSmall(types.SimpleNamespace(n_knn=k, pooling=pooling))
+                for m in (net.modules() if k > 1 else ()):
+                    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                        m.running_mean.normal_(0.5, 0.2)
+                        m.running_var.uniform_(0.5, 1.5)
+                        m.weight.data.uniform_(0.5, 1.5)
+                        m.bias.data.normal_(0, 0.2)
+                net = net.to(dev).eval()
+                with torch.no_grad():
+                    a, a2 = net(x), net(x)
+                # the op-by-op torch path in fp32 and in fp64, both on the KERNEL's neighbour lists (eqa_vn_knn, checked by the
+                # "knn" leg: with |x|^2 cancellation in the reference's score formula, near-equidistant candidates are a rounding
+                # matter, and one different neighbour moves the output by O(1 / N)); fp64 = the truth both are measured against --
+                # the gates' |q| + 1e-6 divisions amplify rounding for some clouds, the op path is then as far off as the kernel
+                idx = torch.empty(B, N, k, dtype=torch.int32, device=dev)
+                assert lib.eqa_vn_knn(x.data_ptr(), idx.data_ptr(), B, N, k, None) == 0
+
+                def op_path(n, xx):
+                    out = n.pool(n.conv_pos(get_graph_feature_cross(xx.unsqueeze(1), k, idx.long())))
+                    return n.conv2(n.bn1(n.conv1(out))).mean(dim=-1)[:, :3]
+
+                with torch.no_grad():
+                    s = op_path(net, x)
+                    nd = net.double()
+                    truth = op_path(nd, x.double())
+                    # conditioning, per cloud: the fp64 output's move under a 1e-6 relative perturbation of the points (a cloud
+                    # with a near-zero |q| in front of a batch-norm's q / (|q| + 1e-6) moves 100x more than its neighbours)
+                    sens = (op_path(nd, x.double() * (1 + 1e-6 * torch.randn_like(x, dtype=torch.float64))) - truth).abs().amax((1, 2))
+                    net.float()
+                scale = max(truth.abs().max().item(), 1.0)
+                tol = (1e-5 if pooling == "mean" else 3e-5) * scale    # one-instruction sqrt / rcp (1 ulp) in the kernel
+                e_k_c, e_op_c = (a.double() - truth).abs().amax((1, 2)), (s.double() - truth).abs().amax((1, 2))
+                allow = torch.maximum(torch.maximum(16 * e_op_c, 20 * sens), torch.full_like(sens, tol))
+                e_k, e_op = e_k_c.max().item(), e_op_c.max().item()
+                ok = bool((e_k_c <= allow).all())
+                if not ok and args.dump:
+                    torch.save({"x": x.cpu(), "state": {n_: t.cpu() for n_, t in net.state_dict().items()}, "k": k, "pooling": pooling,
+                                "kernel": a.cpu(), "op32": s.cpu(), "op64": truth.cpu(), "idx": idx.cpu()}, args.dump)
+                if not ok and pooling == "max" and k > 1:
+                    # an arg-max over the k neighbours whose two best scores are closer than fp32 resolves: the kernel and the op
+                    # path may then pool different neighbours (a step of O(1 / N) in the output); count those clouds, don't judge them
+                    with torch.no_grad():
+                        nd = net.double()
+                        h = nd.conv_pos(get_graph_feature_cross(x.double().unsqueeze(1), k, idx.long()))
+                        d = nd.pool.map_to_dir(h.transpose(1, -1)).transpose(1, -1)
+                        top = (h * d).sum(2).topk(2, dim=-1).values       # gap of the two best scores over the size of the
+                        size = (h * d).abs().sum(2).amax(-1)               # products they are sums of (scores cancel)
+                        margin = ((top[..., 0] - top[..., 1]) / size.clamp_min(1e-30)).min().item()
+                        net.float()
+                    assert margin < 1e-5, ("vnsmall", B, N, k, pooling, e_k, e_op, margin)
+                    counts["vnsmall: arg-max tie, not judged"] = counts.get("vnsmall: arg-max tie, not judged", 0) + 1
+                elif k > 1:        # k = 1 is degenerate (parallel q and gate direction: rounding noise divided by |q| + 1e-6)
+                    assert ok, ("vnsmall", B, N, k, pooling, e_k, e_op)
+                    worst["vnsmall"] = max(worst.get("vnsmall", 0.0), (e_k_c / allow).max().item())
+        elif what == "plane_gemm":
+            T, P = rng.randint(1, 700), rng.choice([36, 64])
+            Cin, Cout = 32 * rng.randint(1, 8), 32 * rng.randint(1, 8)
+            V = torch.randn(T + 2, P, Cin, device=dev)
+            U = torch.randn(P, Cin, Cout, device=dev) / Cin ** 0.5
+            M = torch.full((T + 2, P, Cout), 3.0, device=dev)
+            ops.plane_gemm(V, ops.pack_plane_gemm_weights(U), M, T)
+            want = torch.einsum("tpk,pkn->tpn", V[:T].double(), U.double())
+            assert (M[:T].double() - want).abs().max().item() <= 5e-6 * want.abs().max().item(), ("plane_gemm", T, P, Cin, Cout)
+            assert (M[T:] == 3.0).all()
+        elif what == "lift":
+            K, Cin = rng.choice([(5, 3), (3, 3), (5, 2), (3, 4), (3, 5)])
+            Cout = 16 * rng.randint(1, 12)
+            H, W, B = rng.randint(K, 70), rng.randint(K, 110), rng.randint(1, 6)
+            x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
+            b = torch.randn(Cout, device=dev)
+            got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), b, True, K, K)
+            want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
+            assert (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-3), ("lift", B, Cin, K, Cout, H, W)
+        else:
+            N, refl = rng.choice([(4, False), (8, False), (4, True)])
+            G = 2 * N if refl else N
+            C, Cf = rng.choice([(3, 3), (3, 6), (2, 2 * G), (1, 1), (3, G)])
+            H = W = rng.randint(8, 90)
+            B = rng.randint(1, 20)
+            pad = 0 if C == 1 else (W + 1) // 2
+            x, f = torch.randn(B, C, H, W, device=dev), torch.randn(B, Cf, H, W, device=dev)
+            gidx = torch.randint(0, G, (B,), dtype=torch.int32, device=dev)
+            th_c, fl_c = device_tables("canonicalize", N, refl, (H + 2 * pad, W + 2 * pad), dev)
+            th_i, fl_i, cmap = device_tables("invert", N, refl, (H, W), dev)
+            cm = cmap if Cf % G == 0 and rng.random() < 0.5 else None
+            y1, o1 = ops.canon_transform(x, gidx, th_c, fl_c, pad), ops.invert_action(f, gidx, th_i, fl_i, cm)
+            y2, o2 = ops.group_action_pair(x, f, gidx, th_c, fl_c, pad, th_i, fl_i, cm)
+            assert torch.equal(y1, y2) and torch.equal(o1, o2), ("pair", N, refl, C, Cf, H, B)
+        counts[what] += 1
+    torch.cuda.synchronize()
+    print("fuzz ok:", counts, "worst error / allowance:", worst)
+
+
+if __name__ == "__main__":
+    main()
