@@ -69,6 +69,8 @@ SIGNATURES = {
     "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_lift_conv_grouped": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
+    "eqa_lift_conv_stats_rows": (_int, [_int] * 7),
+    "eqa_lift_conv_nhwc_stats": (_int, [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp]),
     "eqa_lift_conv_wgrad_supported": (_int, [_int] * 7),
     "eqa_lift_conv_wgrad_workspace_bytes": (ctypes.c_int64, [_int] * 7),
     "eqa_lift_conv_wgrad_nhwc": (_int, [_vp, _vp, _vp, _vp] + [_int] * 7 + [_vp]),
@@ -105,6 +107,8 @@ SIGNATURES = {
     "eqa_fft48k5_input_grouped": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_input_grouped_supported": (_int, [_int]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
+    "eqa_fft48k5_output_stats_rows": (ctypes.c_int64, [_int] * 4),
+    "eqa_fft48k5_output_stats": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_sums": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_conv_s2_supported": (_int, [_int] * 5),
     "eqa_conv_s2": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 8 + [_vp]),

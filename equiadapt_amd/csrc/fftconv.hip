@@ -760,10 +760,16 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
 constexpr int kPipeProd = 7 * 64, kPipeCons = 5 * 64, kPipeThreads = kPipeProd + kPipeCons;
 constexpr int kPipePasses = (kFftO * 16 + kPipeCons - 1) / kPipeCons;  // 20 rows of 16 channels per pass: 3 passes (20 + 20 + 4)
 
-template <int NB, int CH>
+// STATS (NB == 0, training: an InnerBatchNorm follows): every consumer thread also sums the values (and their squares) it stores
+// for its channel; per item, a consumer wave's 4 rows are folded by shuffles and its 16 lanes write one fp64 partial row
+//   stats[((tile * 5 + consumer wave) * C + c) * 2 + {0, 1}]
+// -- the statistics pass over the finished map (eqa_bn_stats_nhwc, 0.45 ms at the headline shape) is not needed.
+template <int NB, int CH, bool STATS = false>
 __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                      int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
-                                                                     int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
+                                                                     int TX, size_t M, unsigned nwork, unsigned mo_bytes,
+                                                                     double* __restrict__ stats) {
+  static_assert(!STATS || NB == 0, "statistics are taken of the full map");
   extern __shared__ float lds[];
   constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
   constexpr int NV = 1 + 2 * NB;
@@ -857,6 +863,7 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
     float tot[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) tot[i] = 0.0f;
+    float st_s = 0.0f, st_q = 0.0f;                      // STATS: this thread's (<= 3 rows x 44) stored values, summed
     __syncthreads();                                     // A
     PIPE_CLOCK(0);
 #pragma unroll 1
@@ -885,7 +892,14 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
           float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
 #pragma unroll
           for (int j = 0; j < kFftO; ++j) {
-            if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
+            if (j < ncols) {
+              const float w = relu ? fmaxf(ore[j], 0.0f) : ore[j];
+              o[(size_t)j * C] = w;
+              if (STATS) {
+                st_s += w;
+                st_q = fmaf(w, w, st_q);
+              }
+            }
           }
         } else {
           float acc[NV];
@@ -900,6 +914,18 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
             for (int i = 0; i < NV; ++i) tot[i] += acc[i];
           }
         }
+      }
+    }
+    if constexpr (STATS) {
+#pragma unroll
+      for (int o = CH; o < 64; o <<= 1) {
+        st_s += __shfl_xor(st_s, o, 64);
+        st_q += __shfl_xor(st_q, o, 64);
+      }
+      if ((t & 63) < CH) {
+        double* o = stats + ((m * (kPipeCons / 64) + (size_t)(t >> 6)) * C + c) * 2;
+        o[0] = (double)st_s;
+        o[1] = (double)st_q;
       }
     }
     if constexpr (NB > 0) {
@@ -1134,11 +1160,14 @@ static int fft_chunk_images(int nimg, int rows, int TX, int C) {
   return (int)(n < (size_t)nimg ? n : (size_t)nimg);
 }
 
+// stats != nullptr (NB == 0 only): the pipeline's STATS form, or EQA_ERR_UNSUPPORTED where the pipeline does not apply;
+// stats_rows != nullptr: no launch, *stats_rows = the partial rows that form writes (0: it does not apply)
 template <int NB>
 static int fft_output_impl(const float* Mo, float* T2, const float* bias, int relu, float* out, int nimg, int OH, int OW, int C,
-                           hipStream_t st, int* fused) {
+                           hipStream_t st, int* fused, double* stats = nullptr, int64_t* stats_rows = nullptr) {
   const int TY = (OH + kFftO - 1) / kFftO, TX = (OW + kFftO - 1) / kFftO;
   const size_t M = (size_t)nimg * TY * TX;
+  if (stats_rows) *stats_rows = 0;
   if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   *fused = 0;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
@@ -1155,13 +1184,26 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
       const unsigned nwork = (unsigned)(M * (C / kInvCh));
       const unsigned blocks = nwork < (unsigned)n_cu ? nwork : (unsigned)(n_cu / kXcd * kXcd);
       const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
+      if constexpr (NB == 0) {
+        if (stats || stats_rows) {
+          static const bool lds_ok_s = hipFuncSetAttribute((const void*)fft48_inv_pipe_kernel<0, kInvCh, true>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+          if (!lds_ok_s) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }
+          if (stats_rows) { *stats_rows = (int64_t)M * (kPipeCons / 64); return EQA_OK; }
+          hipLaunchKernelGGL((fft48_inv_pipe_kernel<0, kInvCh, true>), dim3(blocks), dim3(kPipeThreads), lds_bytes, st, Mo, bias, relu, out,
+                             OH, OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u, stats);
+          *fused = 3;
+          return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+        }
+      }
       hipLaunchKernelGGL((fft48_inv_pipe_kernel<NB, kInvCh>), dim3(blocks), dim3(kPipeThreads), lds_bytes, st, Mo, bias, relu, out, OH,
-                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
+                         OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u, (double*)nullptr);
       *fused = 3;
       return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
     }
     (void)hipGetLastError();
   }
+  if (stats || stats_rows) return EQA_ERR_UNSUPPORTED;
   if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass) {
     constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
     static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB, kInvCh>,
@@ -1342,6 +1384,22 @@ int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, 
   if (nimg == 0) return EQA_OK;
   int fused = 0;
   const int rc = fft_output_impl<0>(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream, &fused);
+  return rc != EQA_OK ? rc : launch_status();
+}
+
+int64_t eqa_fft48k5_output_stats_rows(int nimg, int OH, int OW, int C) {
+  if (nimg <= 0 || OH <= 0 || OW <= 0 || C <= 0) return 0;
+  int fused = 0;
+  int64_t rows = 0;
+  const int rc = fft_output_impl<0>(nullptr, nullptr, nullptr, 0, nullptr, nimg, OH, OW, C, nullptr, &fused, nullptr, &rows);
+  return rc == EQA_OK ? rows : 0;
+}
+
+int eqa_fft48k5_output_stats(const float* Mo, float* T2, float* y, double* partial, int nimg, int OH, int OW, int C, void* stream) {
+  if (!Mo || !T2 || !y || !partial || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  int fused = 0;
+  const int rc = fft_output_impl<0>(Mo, T2, nullptr, 0, y, nimg, OH, OW, C, (hipStream_t)stream, &fused, partial);
   return rc != EQA_OK ? rc : launch_status();
 }
 

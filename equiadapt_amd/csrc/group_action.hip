@@ -131,6 +131,15 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   bool live[4];        // false: all four neighbours are off the frame -> exact zero
   float w00[4], w01[4], w10[4], w11[4];
   auto pixel_setup = [&](int pi, int pj) {
+#ifdef EQA_ABL_CHEAPSETUP  // ablation (tools/ablate.sh): what the kernel costs without the per-pixel coordinate arithmetic (wrong pixels)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      lidx[k] = min(pi - i0, bh - 2) * (CH * kLdsStride) + min(pj - j0 + k, bw - 2);
+      gx0[k] = 0; gy0[k] = 0; live[k] = true;
+      w00[k] = 0.25f; w01[k] = 0.25f; w10[k] = 0.25f; w11[k] = t0;
+    }
+    return;
+#endif
     const float yn = lin_m1_p1(a.top + pi, a.Hp, a.step_y);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -184,11 +184,30 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lift_out_rsrc(float* __restric
   return __builtin_amdgcn_make_buffer_rsrc(y + base, 0, (int)((left >> 32) ? 0xffffffffu : (unsigned)left), 0x00020000);
 }
 
-template <bool MASKED>
-__device__ __forceinline__ void lift_epi_store(int j, const f32x4& t, const LiftEpi& e, __amdgpu_buffer_rsrc_t out, int cols_left) {
+// STATS (training: the batch-norm that follows wants per-channel sum and sum of squares of this very map): a lane sees 4 channels
+// of 8 pixels per tile on their way out, always the same 4 channels -- so it keeps their running sums, packed two channels per
+// register pair: 2 v_pk_add_f32 + 2 v_pk_fma_f32 per store IN PLACE of the integer max of the ReLU (no activation in front of a
+// batch-norm), i.e. the same 32 vector instructions per tile as the plain kernel.  fp32 over the ~2,200 values a lane sees, fp64
+// across lanes / waves (lift_stats_flush, then the caller's sum over the partial rows).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct LiftStats {
+  f32x2 s01, s23, q01, q23;
+};
+
+template <bool MASKED, bool STATS = false>
+__device__ __forceinline__ void lift_epi_store(int j, const f32x4& t, const LiftEpi& e, __amdgpu_buffer_rsrc_t out, int cols_left,
+                                               LiftStats& st) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   const i32x4 lo4 = {e.lo, e.lo, e.lo, e.lo};
-  const u32x4 v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, t), lo4));
+  u32x4 v;
+  if (STATS) {
+    const f32x2 a = {t[0], t[1]}, b = {t[2], t[3]};
+    st.s01 += a; st.s23 += b;
+    st.q01 = a * a + st.q01; st.q23 = b * b + st.q23;
+    v = __builtin_bit_cast(u32x4, t);
+  } else {
+    v = __builtin_bit_cast(u32x4, __builtin_elementwise_max(__builtin_bit_cast(i32x4, t), lo4));
+  }
 #ifdef EQA_LABL_NOSTORE
   if (v[0] == 12345u)
 #else
@@ -197,25 +216,46 @@ __device__ __forceinline__ void lift_epi_store(int j, const f32x4& t, const Lift
     __builtin_amdgcn_raw_buffer_store_b128(v, out, (int)e.out_voff, (int)(j * e.row4), 0);
 }
 
-template <bool MASKED, bool HALF = false>
-__device__ __forceinline__ void lift_epi_all(const LiftEpi& e, const f32x16& p0, const f32x16& p1, __amdgpu_buffer_rsrc_t out, int left) {
+template <bool MASKED, bool HALF = false, bool STATS = false>
+__device__ __forceinline__ void lift_epi_all(const LiftEpi& e, const f32x16& p0, const f32x16& p1, __amdgpu_buffer_rsrc_t out, int left,
+                                             LiftStats& st) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     lift_epi_write(g, p0, e.tr_w);
     if (!HALF) lift_epi_write(g, p1, e.tr_w + 32);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) lift_epi_store<MASKED>(j, *reinterpret_cast<const f32x4*>(e.tr_r + 4 * j * kLiftTrPitch), e, out, left);
+  for (int j = 0; j < 8; ++j)
+    lift_epi_store<MASKED, STATS>(j, *reinterpret_cast<const f32x4*>(e.tr_r + 4 * j * kLiftTrPitch), e, out, left, st);
+}
+
+// The wave's sums -> stats[(stream * Cout + channel) * 2 + {0, 1}] (fp64): the four 16-lane groups of a wave carry the same 64
+// channels (different pixels), so two xor-shuffles fold them and lanes 0..15 write 4 channels each.
+__device__ __forceinline__ void lift_stats_flush(const LiftStats& st, double* __restrict__ stats, unsigned stream, unsigned slice,
+                                                 int Cout, int lane) {
+  float v[8] = {st.s01[0], st.q01[0], st.s01[1], st.q01[1], st.s23[0], st.q23[0], st.s23[1], st.q23[1]};
+  double d[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    d[i] = (double)v[i];
+    d[i] += __shfl_xor(d[i], 16);
+    d[i] += __shfl_xor(d[i], 32);
+  }
+  if (lane < 16) {
+    double* o = stats + ((size_t)stream * Cout + slice * 64 + 4 * lane) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = d[i];
+  }
 }
 
 // One tile's MFMA stream.  Between the MFMAs: row ky of the NEXT tile moves LDS -> a[ky] as soon as the 16 MFMAs reading
 // a[ky] have issued, and (EPI) the previous tile's accumulators p0 / p1 are clamped and stored in 8 groups.
 // HALF: the wave's slice has at most 32 channels (Cout <= 32): the second N-tile's MFMAs, half of the stream, are not issued.
-template <int KH, bool EPI, bool MASKED, bool HALF = false>
+template <int KH, bool EPI, bool MASKED, bool HALF = false, bool STATS = false>
 __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float (&b1)[KH * 8], float (&a)[KH][8],
                                           const float* __restrict__ lds_next, int a_off, int a_q0, f32x16& acc0, f32x16& acc1,
                                           const f32x16& p0, const f32x16& p1, const LiftEpi& e,
-                                          __amdgpu_buffer_rsrc_t out, int p_left) {
+                                          __amdgpu_buffer_rsrc_t out, int p_left, LiftStats& st) {
   f32x16 zero;
 #pragma unroll
   for (int i = 0; i < 16; ++i) zero[i] = 0.0f;
@@ -244,7 +284,7 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
         }
       } else {        // ... and out: bias, ReLU, store
 #pragma unroll
-        for (int n = 0; n < NG; ++n) lift_epi_store<MASKED>(NG * (ky - 1) + n, t[n], e, out, p_left);
+        for (int n = 0; n < NG; ++n) lift_epi_store<MASKED, STATS>(NG * (ky - 1) + n, t[n], e, out, p_left, st);
       }
     }
   }
@@ -265,13 +305,13 @@ __device__ __forceinline__ void lift_tile(const float (&b0)[KH * 8], const float
   }
 }
 
-template <int KH, bool MASKED, bool HALF = false>
+template <int KH, bool MASKED, bool HALF = false, bool STATS = false>
 __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
                                                                     const float* __restrict__ bias, int relu,
                                                                     float* __restrict__ y, int H, int W, int Cin, int R,
                                                                     int OH, int OW, int Cout, unsigned tiles_per_row,
                                                                     unsigned ntiles, size_t x_numel, size_t y_numel, unsigned nslices,
-                                                                    unsigned nstreams, int grouped) {
+                                                                    unsigned nstreams, int grouped, double* __restrict__ stats) {
   using Stage = LiftStage<KH>;
   __shared__ float lds_all[kThreads / 64][2][Stage::kFloats + 4];
   __shared__ float lds_tr_all[kThreads / 64][32 * kLiftTrPitch];
@@ -321,6 +361,8 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
 #else
 #define LIFT_CLOCK_END() do { } while (0)
 #endif
+  LiftStats lst;
+  lst.s01 = lst.s23 = lst.q01 = lst.q23 = f32x2{0.0f, 0.0f};
   Stage g;
   lift_stage_init<KH>(g, lane, W, Cin, n_el);
   LiftPos pA, pB, pC;  // tiles i, i+1, i+2 of the stream
@@ -361,15 +403,16 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   __amdgpu_buffer_rsrc_t po = out_of(pA, left);  // where tile 0 goes (stored during step 1)
   lift_stage_store<KH>(lds[1], lane, G1);
   lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
-  lift_tile<KH, false, MASKED, HALF>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, e0, e1, epi, po, 0);
+  lift_tile<KH, false, MASKED, HALF, STATS>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, e0, e1, epi, po, 0, lst);
   // the first trip of the loop must not inherit a shorter queue than the later ones: the compiler takes the minimum over
   // both ways in when it counts how many loads and stores may still be in flight at the LDS writes
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   for (unsigned i = 1;; i += 2) {
     if (i >= count) {
-      lift_epi_all<MASKED, HALF>(epi, e0, e1, po, left);
+      lift_epi_all<MASKED, HALF, STATS>(epi, e0, e1, po, left, lst);
       lift_stage_pin<KH>(G0);  // a use on the way out as well: otherwise the compiler sinks the loads below the exit test,
       lift_stage_pin<KH>(G1);  // in front of their first use one or two steps later
+      if (STATS) lift_stats_flush(lst, stats, stream, slice, Cout, lane);
       LIFT_CLOCK_END();
       return;
     }
@@ -380,14 +423,15 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
     lift_stage_store<KH>(lds[0], lane, G0);
     lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G0);
     __amdgpu_buffer_rsrc_t pn = out_of(pA, left_next);  // tile i: scalar work inside the stream, not in front of it
-    lift_tile<KH, true, MASKED, HALF>(b0, b1, a, lds[0], a_off, a_q0, o0, o1, e0, e1, epi, po, left);
+    lift_tile<KH, true, MASKED, HALF, STATS>(b0, b1, a, lds[0], a_off, a_q0, o0, o1, e0, e1, epi, po, left, lst);
     po = pn;
     left = left_next;
 
     if (i + 1 >= count) {
-      lift_epi_all<MASKED, HALF>(epi, o0, o1, po, left);
+      lift_epi_all<MASKED, HALF, STATS>(epi, o0, o1, po, left, lst);
       lift_stage_pin<KH>(G0);
       lift_stage_pin<KH>(G1);
+      if (STATS) lift_stats_flush(lst, stats, stream, slice, Cout, lane);
       LIFT_CLOCK_END();
       return;
     }
@@ -398,11 +442,34 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
     lift_stage_store<KH>(lds[1], lane, G1);
     lift_stage_load<KH>(x, x_numel, pD, lift_ox0<MASKED>(pD, OW), H, W, Cin, G1);
     pn = out_of(pA, left_next);  // tile i + 1
-    lift_tile<KH, true, MASKED, HALF>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, o0, o1, epi, po, left);
+    lift_tile<KH, true, MASKED, HALF, STATS>(b0, b1, a, lds[1], a_off, a_q0, e0, e1, o0, o1, epi, po, left, lst);
     po = pn;
     left = left_next;
   }
 }
+
+// The unmasked kernel computes the pixels [x0, x1) of every output row twice (the last tile of a row starts at OW - 32 and
+// overlaps its neighbour), so its running sums count them twice: this pass writes MINUS their sums into the partial rows behind
+// the kernel's.  One block per group of output rows, thread = channel (coalesced over the channels-last map), fp64.
+__global__ __launch_bounds__(kThreads) void lift_stats_dup_kernel(const float* __restrict__ y, double* __restrict__ rows, size_t nrows,
+                                                                  int OW, int C, int x0, int x1) {
+  for (int c = threadIdx.x; c < C; c += kThreads) {
+    double s = 0.0, q = 0.0;
+    for (size_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+      const float* p = y + (r * OW + x0) * C + c;
+      for (int xx = x0; xx < x1; ++xx, p += C) {
+        const double v = (double)*p;
+        s += v;
+        q += v * v;
+      }
+    }
+    double* o = rows + ((size_t)blockIdx.x * C + c) * 2;
+    o[0] = -s;
+    o[1] = -q;
+  }
+}
+
+constexpr unsigned kLiftDupBlocks = 512;
 
 }  // namespace
 
@@ -411,8 +478,12 @@ extern "C" {
 int eqa_debug_lift_hist(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_hist), sizeof(g_lift_hist)) == hipSuccess ? 0 : -1; }
 int eqa_debug_lift_clock(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lift_clock), sizeof(g_lift_clock)) == hipSuccess ? 0 : -1; }
 #endif
+// stats != nullptr: the STATS form (unmasked, >= 64-channel slices, no bias / activation); `rows_only` returns the number of
+// partial rows that form writes instead of launching anything
 static int lift_conv_launch(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
-                            int Cin, int KH, int KW, int Cout, void* stream, int grouped) {
+                            int Cin, int KH, int KW, int Cout, void* stream, int grouped, double* stats = nullptr,
+                            bool rows_only = false) {
+  if (rows_only) { x = wpk = reinterpret_cast<const float*>(16); y = reinterpret_cast<float*>(16); }
   if (!x || !wpk || !y || nimg < 0 || Cin <= 0 || KH <= 0 || KW <= 0 || Cout <= 0 || H < KH || W < KW) return EQA_ERR_INVALID_ARG;
   const int R = KW * Cin;
   if ((KH != 3 && KH != 5) || R < 9 || R > 15 || (Cout % 16) != 0 || 31 * Cin + R > kLiftRow) return EQA_ERR_UNSUPPORTED;  // R <= 15: the bias slot
@@ -430,9 +501,26 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   const unsigned waves = nslices * nstreams, per_block = kThreads / 64;
   const dim3 grid((waves + per_block - 1) / per_block);
   hipStream_t st = (hipStream_t)stream;
+  if (stats || rows_only) {
+    if (narrow || OW < 32 || grouped || bias || relu) return rows_only ? 0 : EQA_ERR_UNSUPPORTED;
+    const int x0 = OW - 32, x1 = 32 * ((int)tiles_per_row - 1);  // the columns the last tile of a row shares with its neighbour
+    const size_t nrows = (size_t)nimg * OH;
+    const unsigned dup_blocks = x1 > x0 ? (unsigned)std::min<size_t>(nrows, kLiftDupBlocks) : 0u;
+    if (rows_only) return (int)(nstreams + dup_blocks);
+    if (KH == 5)
+      hipLaunchKernelGGL((lift_conv_mfma_kernel<5, false, false, true>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R,
+                         OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped, stats);
+    else
+      hipLaunchKernelGGL((lift_conv_mfma_kernel<3, false, false, true>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R,
+                         OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped, stats);
+    if (dup_blocks)
+      hipLaunchKernelGGL(lift_stats_dup_kernel, dim3(dup_blocks), dim3(kThreads), 0, st, y, stats + (size_t)nstreams * Cout * 2, nrows, OW,
+                         Cout, x0, x1);
+    return launch_status();
+  }
 #define EQA_LIFT_LAUNCH(KH_, MASKED_, HALF_)                                                                                      \
   hipLaunchKernelGGL((lift_conv_mfma_kernel<KH_, MASKED_, HALF_>), grid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, R, \
-                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped)
+                     OH, OW, Cout, tiles_per_row, (unsigned)ntiles, x_numel, y_numel, nslices, nstreams, grouped, (double*)nullptr)
   if (KH == 5) {
     if (Cout <= 32) EQA_LIFT_LAUNCH(5, true, true); else if (OW < 32 || narrow) EQA_LIFT_LAUNCH(5, true, false); else EQA_LIFT_LAUNCH(5, false, false);
   } else {
@@ -445,6 +533,17 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream) {
   return lift_conv_launch(x, wpk, bias, relu, y, nimg, H, W, Cin, KH, KW, Cout, stream, 0);
+}
+
+int eqa_lift_conv_stats_rows(int nimg, int H, int W, int Cin, int KH, int KW, int Cout) {
+  const int r = lift_conv_launch(nullptr, nullptr, nullptr, 0, nullptr, nimg, H, W, Cin, KH, KW, Cout, nullptr, 0, nullptr, true);
+  return r < 0 ? 0 : r;
+}
+
+int eqa_lift_conv_nhwc_stats(const float* x, const float* wpk, float* y, double* partial, int nimg, int H, int W, int Cin, int KH, int KW,
+                             int Cout, void* stream) {
+  if (!partial) return EQA_ERR_INVALID_ARG;
+  return lift_conv_launch(x, wpk, nullptr, 0, y, nimg, H, W, Cin, KH, KW, Cout, stream, 0, partial);
 }
 
 int eqa_lift_conv_grouped(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,

@@ -47,13 +47,20 @@ class LiftConvFunction(torch.autograd.Function):
     needs no gradient in the canonicalizer; if asked for, it is the framework's."""
 
     @staticmethod
-    def forward(ctx, x, bank):
+    def forward(ctx, x, bank, with_stats=False):
+        """with_stats: also return the fp64 partial sums (rows, Cout, 2) of the output's per-channel sum / sum of squares, taken in the
+        kernel's epilogue (eqa_lift_conv_nhwc_stats) -- the batch-norm behind the layer then skips its own pass over the map."""
         ctx.save_for_backward(x, bank)
         k = bank.shape[-1]
-        return ops.lift_conv_nhwc(x, ops.pack_lift_weights(bank.detach()), None, False, bank.shape[-2], k)
+        wpk = ops.pack_lift_weights(bank.detach())
+        if with_stats:
+            y, part = ops.lift_conv_nhwc_stats(x, wpk, bank.shape[-2], k)
+            ctx.mark_non_differentiable(part)
+            return y, part
+        return ops.lift_conv_nhwc(x, wpk, None, False, bank.shape[-2], k)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *_):
         x, bank = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = torch.nn.grad.conv2d_input(x.shape, bank, dy) if ctx.needs_input_grad[0] else None
@@ -64,7 +71,7 @@ class LiftConvFunction(torch.autograd.Function):
                 dbank = ops.lift_conv_wgrad_nhwc(x, dy, kh, kw)            # fp32 MFMA, 0.8 ms where MIOpen's solvers take 3.1
             else:
                 dbank = torch.nn.grad.conv2d_weight(x, bank.shape, dy)
-        return dx, dbank
+        return dx, dbank, None
 
 
 class InnerBnReluDropout(torch.autograd.Function):
@@ -76,7 +83,9 @@ class InnerBnReluDropout(torch.autograd.Function):
     instead of reading y (one map less per pass)."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training):
+    def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training, part=None):
+        """part: (rows, C, 2) fp64 partial sums of h's per-channel sum / sum of squares when the kernel that produced h took them
+        on the way out (LiftConvFunction with_stats, the FFT convolution's inverse transform); None: one pass over h here."""
         from equiadapt_amd import _lib, ops
 
         lib = _lib.load()
@@ -86,9 +95,10 @@ class InnerBnReluDropout(torch.autograd.Function):
         st = ops._stream()
         with torch.cuda.device(h.device):
             if bn.training or bn.running_mean is None:
-                nblk = lib.eqa_bn_partial_blocks(npix)
-                part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
-                _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
+                if part is None:
+                    nblk = lib.eqa_bn_partial_blocks(npix)
+                    part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
+                    _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
                 sums = part.sum(0).view(Fd, E, 2).sum(1)                         # (fields, 2) fp64
                 n = npix * E
                 mean = sums[:, 0] / n
@@ -157,7 +167,7 @@ class InnerBnReluDropout(torch.autograd.Function):
                 dconv_bias = torch.zeros(Fd, dtype=h.dtype, device=h.device)
             else:
                 dconv_bias = dh.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1).float()
-        return dh, dweight, dbias, None, None, dconv_bias, None, None
+        return dh, dweight, dbias, None, None, dconv_bias, None, None, None
 
 
 def _window_grad_table(dS: torch.Tensor, H: int, W: int, k: int) -> torch.Tensor:
@@ -182,7 +192,7 @@ class InnerBnReluDropoutWindowSums(torch.autograd.Function):
     (-2.0 ms of the 29.7 ms training step).  Same statistics, same mask, same arithmetic per element."""
 
     @staticmethod
-    def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training, k):
+    def forward(ctx, h, weight, bias, bn, E, conv_bias, p, drop_training, k, part=None):
         from equiadapt_amd import _lib, ops
 
         lib = _lib.load()
@@ -193,9 +203,10 @@ class InnerBnReluDropoutWindowSums(torch.autograd.Function):
         with torch.cuda.device(h.device):
             batch_stats = bool(bn.training or bn.running_mean is None)
             if batch_stats:
-                nblk = lib.eqa_bn_partial_blocks(npix)
-                part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
-                _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
+                if part is None:                                                 # (else: taken by the producer of h, see InnerBnReluDropout)
+                    nblk = lib.eqa_bn_partial_blocks(npix)
+                    part = torch.empty((nblk, C, 2), dtype=torch.float64, device=h.device)
+                    _lib.check(lib.eqa_bn_stats_nhwc(h.data_ptr(), part.data_ptr(), npix, C, st), "eqa_bn_stats_nhwc")
                 sums = part.sum(0).view(Fd, E, 2).sum(1)
                 n = npix * E
                 mean = sums[:, 0] / n
@@ -259,7 +270,7 @@ class InnerBnReluDropoutWindowSums(torch.autograd.Function):
                 dconv_bias = torch.zeros(Fd, dtype=h.dtype, device=h.device)
             else:
                 dconv_bias = dh.sum(dim=(0, 2, 3), dtype=torch.float64).view(Fd, E).sum(1).float()
-        return dh, dweight, dbias, None, None, dconv_bias, None, None, None
+        return dh, dweight, dbias, None, None, dconv_bias, None, None, None, None
 
 
 class _DenseConv(nn.Module):
@@ -582,13 +593,23 @@ class ESCNNEquivariantNetwork(nn.Module):
         h = x.contiguous(memory_format=torch.channels_last)
         tail = convs[-1]
         S = None
+        epilogue_stats = os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and os.environ.get("EQA_TRAIN_EPILOGUE_STATS", "1") != "0"
         for li, (conv, bn, drop) in enumerate(zip(convs[:-1], norms, drops)):
             bank = conv.expanded_weights()
+            part = None          # fp64 partial sums of the block's batch statistics, when the convolution kernel took them
             if not conv.lifting and conv.kernel_size == 5 and winograd.applicable(h, bank.shape[1], bank.shape[0]):
-                h = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h))
+                if (epilogue_stats and (bn.training or bn.running_mean is None) and winograd.Conv5x5Function.stats_supported(h, bank)):
+                    h, part = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h), True)
+                else:
+                    h = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h))
             elif (conv.lifting and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
                   and ops.lift_conv_supported(bank.shape[1], conv.kernel_size, conv.kernel_size, bank.shape[0])):
-                h = LiftConvFunction.apply(h, bank)
+                # batch statistics of the norm behind the layer: taken in the convolution's epilogue where the kernel has that form
+                if (epilogue_stats and (bn.training or bn.running_mean is None)
+                        and ops.lift_conv_stats_supported(h.shape, conv.kernel_size, conv.kernel_size, bank.shape[0])):
+                    h, part = LiftConvFunction.apply(h, bank, True)
+                else:
+                    h = LiftConvFunction.apply(h, bank)
             else:
                 h = F.conv2d(h, bank.contiguous(memory_format=torch.channels_last))
             fused = os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and h.is_contiguous(memory_format=torch.channels_last)
@@ -596,9 +617,9 @@ class ESCNNEquivariantNetwork(nn.Module):
             if (fused and li == len(convs) - 2 and os.environ.get("EQA_TRAIN_FUSED_TAIL", "1") != "0" and kt <= 8
                     and h.shape[-2] > 2 * (kt - 1) and h.shape[-1] > 2 * (kt - 1) and h.shape[0] <= 65535):
                 # the last hidden block goes straight into the window sums of the linearised final layer: its output is never written
-                S = InnerBnReluDropoutWindowSums.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training, kt)
+                S = InnerBnReluDropoutWindowSums.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training, kt, part)
             elif fused:
-                h = InnerBnReluDropout.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training)
+                h = InnerBnReluDropout.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training, part)
             else:  # op-by-op form of the same block (kept as the reference for the fused kernels' test)
                 h = self._inner_bn(h, bn, E, conv.bias)
                 h = F.dropout(torch.relu(h), drop.p, drop.training)

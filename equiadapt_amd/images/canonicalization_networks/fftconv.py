@@ -192,13 +192,20 @@ def spectra_buffer(M: int, width: int, device) -> torch.Tensor:
     return torch.empty((F, pitch, width), dtype=torch.float32, device=device)[:, :M]
 
 
+def output_stats_supported(nimg: int, OH: int, OW: int, cout: int) -> bool:
+    """The inverse transform can take the batch-norm statistics of its output on the way out (eqa_fft48k5_output_stats)."""
+    return _lib.load().eqa_fft48k5_output_stats_rows(nimg, OH, OW, cout) > 0
+
+
 def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,
             in_bias: Optional[torch.Tensor] = None, in_relu: bool = False, sums_k: int = 0,
-            keep_V: Optional[list] = None) -> torch.Tensor:
+            keep_V: Optional[list] = None, stats: Optional[list] = None) -> torch.Tensor:
     """x: channels-last (nimg,Cin,H,W) -> channels-last (nimg,Cout,H-4,W-4) = [relu](conv2d(act(x), g) + bias) with
     B = spectra_for(g) (either form) and act(x) = [relu](x + in_bias[c]) applied while loading; ``sums_k`` > 0: return instead the
     (nimg, Cout, sums_k, sums_k) fp64 window sums of that output (the linearised last layer consumes only those).
-    ``keep_V``: a list that receives the input spectra V (training: the filter gradient reuses them)."""
+    ``keep_V``: a list that receives the input spectra V (training: the filter gradient reuses them).  ``stats``: a list that
+    receives the (rows, Cout, 2) fp64 partial sums of the output's per-channel sum / sum of squares, taken by the inverse
+    transform (training, no bias / activation; the caller checks ``output_stats_supported``)."""
     lib = _lib.load()
     nimg, Cin, H, W = x.shape
     if isinstance(B, Spectra3M):
@@ -235,6 +242,14 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
                                                        nimg, OH, OW, Cout, sums_k, st), "eqa_fft48k5_output_sums")
             return S
         y = torch.empty((nimg, Cout, OH, OW), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        if stats is not None:
+            assert bias is None and not relu
+            part = torch.empty((lib.eqa_fft48k5_output_stats_rows(nimg, OH, OW, Cout), Cout, 2), dtype=torch.float64, device=dev)
+            with _timed("fft_output"):
+                _lib.check(lib.eqa_fft48k5_output_stats(Mo.data_ptr(), T2.data_ptr(), y.data_ptr(), part.data_ptr(), nimg, OH, OW, Cout, st),
+                           "eqa_fft48k5_output_stats")
+            stats.append(part)
+            return y
         with _timed("fft_output"):
             _lib.check(lib.eqa_fft48k5_output(Mo.data_ptr(), T2.data_ptr(), p_bias, int(relu), y.data_ptr(), nimg, OH, OW, Cout, st),
                        "eqa_fft48k5_output")

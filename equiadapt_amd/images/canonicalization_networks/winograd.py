@@ -162,23 +162,37 @@ class Conv5x5Function(torch.autograd.Function):
     dbank = G^T dU G with dU from `filter_grad`.  Training counterpart of the inference path in escnn_networks.py."""
 
     @staticmethod
-    def forward(ctx, x, bank, m):
+    def forward(ctx, x, bank, m, with_stats=False):
+        """with_stats (the caller has checked ``stats_supported``): also return the fp64 partial sums (rows, Cout, 2) of the
+        output's per-channel sum / sum of squares, taken by the FFT convolution's inverse transform on the way out."""
         from equiadapt_amd.images.canonicalization_networks import fftconv
 
         keep: list = []
+        stats: list = []
         ctx.fft = fftconv.TRAIN_FORWARD and fftconv.applicable(x, bank.shape[1], bank.shape[0])
         if ctx.fft:
             # forward pass and both gradients as FFT convolutions (2.5 instead of 4 multiplies per output; the filter spectra
             # are rebuilt by one kernel, the input spectra are kept for the filter gradient)
-            y = fftconv.conv5x5(x, fftconv.spectra_for(bank.detach()), None, False, keep_V=keep)
+            y = fftconv.conv5x5(x, fftconv.spectra_for(bank.detach()), None, False, keep_V=keep, stats=stats if with_stats else None)
         else:
+            assert not with_stats
             y = conv5x5(x, transform_filters(bank.detach(), m), None, False, keep_V=keep if KEEP_V_FOR_BACKWARD else None)
         ctx.save_for_backward(x, bank, *keep)     # V is kept: HBM is 288 GB, recomputing it is a 1-2 ms pass
         ctx.m = m
+        if with_stats:
+            ctx.mark_non_differentiable(stats[0])
+            return y, stats[0]
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def stats_supported(x, bank) -> bool:
+        from equiadapt_amd.images.canonicalization_networks import fftconv
+
+        return bool(fftconv.TRAIN_FORWARD and fftconv.applicable(x, bank.shape[1], bank.shape[0])
+                    and fftconv.output_stats_supported(x.shape[0], x.shape[2] - 4, x.shape[3] - 4, bank.shape[0]))
+
+    @staticmethod
+    def backward(ctx, dy, *_):
         x, bank, *keep = ctx.saved_tensors
         m = ctx.m
         dy = dy.contiguous(memory_format=torch.channels_last)
@@ -192,7 +206,7 @@ class Conv5x5Function(torch.autograd.Function):
                 dx = fftconv.input_grad(dy, bank, G)
             if ctx.needs_input_grad[1]:
                 dbank = fftconv.filter_grad(keep[0], dy, bank.shape[1], G).to(bank.dtype)
-            return dx, dbank, None
+            return dx, dbank, None, None
         if ctx.needs_input_grad[0]:
             bank_t = bank.detach().flip(-1, -2).transpose(0, 1).contiguous()       # (Cin, Cout, 5, 5)
             dx = conv5x5(dy, transform_filters(bank_t, m), None, False, pad=4)   # zero padding inside the input transform
@@ -201,7 +215,7 @@ class Conv5x5Function(torch.autograd.Function):
             G = g_matrix(m).to(dy.device)
             dU = filter_grad(x, dy, m, keep[0] if keep else None).double().view(n, n, bank.shape[1], bank.shape[0])
             dbank = torch.einsum("ak,bl,abio->oikl", G, G, dU).to(bank.dtype)
-        return dx, dbank, None
+        return dx, dbank, None, None
 
 
 def conv5x5(x: torch.Tensor, U: torch.Tensor, bias: Optional[torch.Tensor], relu: bool,

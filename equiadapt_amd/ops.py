@@ -584,6 +584,33 @@ def lift_conv_nhwc(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def lift_conv_stats_supported(x_shape, kh: int, kw: int, cout: int) -> bool:
+    """Shapes eqa_lift_conv_nhwc_stats takes (x_shape: (B, Cin, H, W))."""
+    B, Cin, H, W = x_shape
+    return _lib.load().eqa_lift_conv_stats_rows(B, H, W, Cin, kh, kw, cout) > 0
+
+
+def lift_conv_nhwc_stats(x: torch.Tensor, wpk: torch.Tensor, kh: int, kw: int):
+    """`lift_conv_nhwc` without bias / activation that also returns the fp64 partial sums (rows, Cout, 2) of the output's
+    per-channel sum and sum of squares (eqa_lift_conv_nhwc_stats) -- what the batch-norm behind the lifting layer needs, taken
+    from the values on their way out of the kernel.  None as the second result: this shape has no such form."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("lift_conv_nhwc_stats expects a channels-last fp32 tensor on the device")
+    wpk = _need(wpk, "wpk")
+    B, Cin, H, W = x.shape
+    Cout = wpk.shape[2]
+    rows = lib.eqa_lift_conv_stats_rows(B, H, W, Cin, kh, kw, Cout)
+    if rows <= 0:
+        return lift_conv_nhwc(x, wpk, None, False, kh, kw), None
+    y = torch.empty((B, Cout, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    part = torch.empty((rows, Cout, 2), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device), _timed("lift_conv"):
+        st = lib.eqa_lift_conv_nhwc_stats(x.data_ptr(), wpk.data_ptr(), y.data_ptr(), part.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
+    _lib.check(st, "eqa_lift_conv_nhwc_stats")
+    return y, part
+
+
 def lift_conv_grouped(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int) -> torch.Tensor:
     """`lift_conv_nhwc` with the output in the channel-group-major layout (B, Cout/16, H-kh+1, W-kw+1, 16) that the FFT
     convolution's input transform reads in whole cache lines (eqa_lift_conv_grouped)."""

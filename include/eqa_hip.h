@@ -325,6 +325,16 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
  * block; grouped, a tile row of a channel group is one contiguous run.  Same arguments and return codes. */
 int eqa_lift_conv_grouped(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin,
                           int KH, int KW, int Cout, void* stream);
+/* Training: the lifting convolution of escnn_networks.py:60-66 feeds an InnerBatchNorm (escnn_networks.py:67-70) whose batch
+ * statistics are per-channel sums over this very map.  This form (no bias, no activation) also leaves
+ *   sum over rows r of partial[(r * Cout + c) * 2 + {0, 1}]  =  sum, sum of squares of y[.., c] over all pixels      (fp64)
+ * -- the kernel's waves keep running sums of the values they store (in place of the ReLU's instructions), one partial row per
+ * tile stream, followed by rows that take the twice-computed seam pixels of the tiling out again -- so that eqa_bn_stats_nhwc's
+ * pass over the map is not needed.  rows = eqa_lift_conv_stats_rows(...) (0: this shape has no such form -- Cout % 64 != 0 or
+ * output rows shorter than 32 pixels: use eqa_lift_conv_nhwc + eqa_bn_stats_nhwc); partial: rows * Cout * 2 doubles. */
+int eqa_lift_conv_stats_rows(int nimg, int H, int W, int Cin, int KH, int KW, int Cout);
+int eqa_lift_conv_nhwc_stats(const float* x, const float* wpk, float* y, double* partial, int nimg, int H, int W, int Cin, int KH,
+                             int KW, int Cout, void* stream);
 
 /*
  * Training: filter gradient of the same lifting convolution (the reference: autograd through e2cnn's R2Conv,
@@ -445,6 +455,12 @@ int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* i
                               void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
+/* Training: eqa_fft48k5_output without bias / activation that also leaves the fp64 partial sums of the InnerBatchNorm behind the
+ * layer (escnn_networks.py:67-91): sum over rows r of partial[(r * C + c) * 2 + {0, 1}] = sum, sum of squares of y[.., c], taken
+ * from the values the inverse transform's consumer waves store.  rows = eqa_fft48k5_output_stats_rows(...) (0: the pipelined
+ * inverse does not take this shape -- use eqa_fft48k5_output + eqa_bn_stats_nhwc); partial: rows * C * 2 doubles. */
+int64_t eqa_fft48k5_output_stats_rows(int nimg, int OH, int OW, int C);
+int eqa_fft48k5_output_stats(const float* Mo, float* T2, float* y, double* partial, int nimg, int OH, int OW, int C, void* stream);
 /* Training, filter gradient in the frequency domain (the reference gets it from autograd through R2Conv's conv2d):
  *   eqa_fft48k5_grad_transform  dy:(nimg,OH,OW,C) -> G:(F, M, 2C): spectra of the DISJOINT 44 x 44 output-gradient tiles,
  *                               zero-padded to 48 x 48, same row layout as V; T: eqa_fft48k5_workspace_bytes(nimg, OH, OW, C).

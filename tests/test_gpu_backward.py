@@ -825,3 +825,111 @@ def test_fused_last_block_into_window_sums_is_bit_identical(dev, group_type, N, 
             assert torch.equal(p1.grad, p2.grad), (n1, (p1.grad - p2.grad).abs().max().item(), p2.grad.abs().max().item())
     for (n1, b1), (n2, b2) in zip(net.named_buffers(), ref.named_buffers()):
         assert torch.equal(b1, b2), n1
+
+
+@pytest.mark.parametrize("B,HW,k,cout", [(5, (96, 96), 5, 256), (3, (68, 100), 5, 128), (4, (40, 51), 3, 64), (2, (36, 36), 5, 192)])
+def test_lift_conv_epilogue_statistics_match_the_stats_pass(dev, B, HW, k, cout):
+    """eqa_lift_conv_nhwc_stats: the lifting convolution of the training step (escnn_networks.py:60-66 of the reference, feeding the
+    InnerBatchNorm of :67-70) with the batch-norm's per-channel sum / sum of squares taken in the kernel's epilogue: the map is
+    bit-identical to eqa_lift_conv_nhwc's, the partial rows add up to what eqa_bn_stats_nhwc's pass over the map gives (fp32 running
+    sums per lane vs fp32 per 256 pixels: 1e-5 of the sum of squares), including the rows that take the seam pixels of the
+    92 -> 3 x 32 tiling out again (OW = 92, 96, 49, 32: 4, 0, 15 and 0 twice-computed columns)."""
+    from equiadapt_amd import _lib, ops
+
+    lib = _lib.load()
+    torch.manual_seed(B + k)
+    H, W = HW
+    x = (torch.randn(B, 3, H, W, device=dev) + 0.3).contiguous(memory_format=torch.channels_last)
+    bank = torch.randn(cout, 3, k, k, device=dev) / (k * 3 ** 0.5)
+    wpk = ops.pack_lift_weights(bank)
+    assert ops.lift_conv_stats_supported(x.shape, k, k, cout)
+    y, part = ops.lift_conv_nhwc_stats(x, wpk, k, k)
+    want_y = ops.lift_conv_nhwc(x, wpk, None, False, k, k)
+    assert torch.equal(y, want_y)
+    npix = B * (H - k + 1) * (W - k + 1)
+    ref = torch.empty((lib.eqa_bn_partial_blocks(npix), cout, 2), dtype=torch.float64, device=dev)
+    _lib.check(lib.eqa_bn_stats_nhwc(y.data_ptr(), ref.data_ptr(), npix, cout, None), "eqa_bn_stats_nhwc")
+    torch.cuda.synchronize()
+    got, want = part.sum(0), ref.sum(0)
+    exact = y.permute(0, 2, 3, 1).reshape(-1, cout).double()
+    truth = torch.stack([exact.sum(0), (exact * exact).sum(0)], dim=1)
+    scale = truth[:, 1].max().item()
+    assert (got - truth).abs().max().item() <= 1e-5 * scale, (got - truth).abs().max().item() / scale
+    assert (want - truth).abs().max().item() <= 1e-5 * scale
+    # shapes without that form: narrow channel counts, rows shorter than a tile
+    assert not ops.lift_conv_stats_supported((2, 3, 32, 32), 5, 5, 32)
+    assert not ops.lift_conv_stats_supported((2, 3, 40, 30), 5, 5, 64)
+    y2, none = ops.lift_conv_nhwc_stats(x[:, :, :, :30].contiguous(memory_format=torch.channels_last), wpk, k, k)
+    assert none is None and y2.shape[-1] == 30 - k + 1
+
+
+def test_training_step_with_epilogue_statistics_matches_the_separate_pass(dev, monkeypatch):
+    """The canonicalization network's training forward / backward with the first block's batch statistics taken in the lifting
+    convolution's epilogue (default) against the same step with eqa_bn_stats_nhwc's own pass (EQA_TRAIN_EPILOGUE_STATS=0): same
+    dropout seeds, so activations and running statistics agree to the rounding of the statistics (1e-5), gradients to 1e-4 of the step's gradient scale.  The
+    hidden layer's statistics come from the FFT convolution's inverse transform (eqa_fft48k5_output_stats) the same way."""
+    import equiadapt_amd as ea
+
+    def run(flag):
+        monkeypatch.setenv("EQA_TRAIN_EPILOGUE_STATS", flag)
+        torch.manual_seed(3)
+        net = ea.ESCNNEquivariantNetwork((3, 100, 100), 64 // 4, 5, "rotation", 4, 4).to(dev).train()
+        x = torch.randn(12, 3, 100, 100, device=dev)
+        torch.manual_seed(11)                     # the dropout seeds come from torch's CPU generator
+        out = net(x)
+        out.square().sum().backward()
+        norms = [m for m in net.modules() if hasattr(m, "running_mean") and m.running_mean is not None]
+        return out.detach(), [p.grad.clone() for p in net.parameters()], [m.running_var.clone() for m in norms]
+
+    calls = []
+    from equiadapt_amd import ops
+    orig = ops.lift_conv_nhwc_stats
+    monkeypatch.setattr(ops, "lift_conv_nhwc_stats", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+    fcalls = []
+    forig = fftconv.conv5x5
+    monkeypatch.setattr(fftconv, "conv5x5", lambda *a, **k: (fcalls.append(k.get("stats") is not None), forig(*a, **k))[1])
+    o1, g1, v1 = run("1")
+    assert calls, "the default training step must take the statistics in the convolution's epilogue"
+    assert any(fcalls), "... and the hidden layer's in the FFT convolution's inverse transform"
+    n = len(calls)
+    o0, g0, v0 = run("0")
+    assert len(calls) == n
+    assert (o1 - o0).abs().max().item() <= 2e-5 * o0.abs().max().item()
+    for a, b in zip(v1, v0):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item()
+    # Gradients: the late layers agree to 1e-6 of their own size.  The early layers' gradients are what is left after the batch-norm
+    # backward passes subtracted the mean and the x-hat-correlated part of an upstream gradient 300x larger (|g| 1e-3 against 0.3-0.6
+    # for the last block here), so a 1e-6 difference in the statistics shows as 1e-3 of THEIR size -- measured, and the same for either
+    # form against an fp64 evaluation (tools/diag/epilogue_stats_noise.py).  The bound is therefore on the step's gradient scale.
+    scale = max(b.abs().max().item() for b in g0)
+    for a, b in zip(g1, g0):
+        assert (a - b).abs().max().item() <= 1e-4 * scale
+    assert (g1[-1] - g0[-1]).abs().max().item() <= 1e-5 * g0[-1].abs().max().item()
+
+
+@pytest.mark.parametrize("B,HW,cin,cout", [(8, (92, 92), 64, 64), (10, (84, 88), 32, 64), (40, (48, 47), 32, 64)])
+def test_fft_conv_output_statistics_match_the_stats_pass(dev, B, HW, cin, cout):
+    """eqa_fft48k5_output_stats: the FFT convolution's inverse transform (the hidden regular -> regular layer of
+    escnn_networks.py:67-91 in training) also leaves the per-channel sum / sum of squares of its output for the InnerBatchNorm behind
+    it: the map is bit-identical to eqa_fft48k5_output's, the partial rows add up to the statistics of the map (full tiles, partial
+    border tiles in both directions, a single tile)."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(B)
+    H, W = HW
+    x = (torch.randn(B, cin, H, W, device=dev) + 0.2).contiguous(memory_format=torch.channels_last)
+    bank = torch.randn(cout, cin, 5, 5, device=dev) / (5 * cin ** 0.5)
+    if not fftconv.applicable(x, cin, cout):
+        pytest.skip("no FFT path for this shape")
+    assert fftconv.output_stats_supported(B, H - 4, W - 4, cout)
+    spectra = fftconv.spectra_for(bank)
+    stats = []
+    y = fftconv.conv5x5(x, spectra, None, False, stats=stats)
+    want_y = fftconv.conv5x5(x, spectra, None, False)
+    torch.cuda.synchronize()
+    assert torch.equal(y, want_y)
+    exact = y.permute(0, 2, 3, 1).reshape(-1, cout).double()
+    truth = torch.stack([exact.sum(0), (exact * exact).sum(0)], dim=1)
+    got = stats[0].sum(0)
+    assert (got - truth).abs().max().item() <= 1e-5 * truth[:, 1].max().item()

@@ -46,6 +46,24 @@ def main():
         ms = timeit(lambda: ops.invert_action(x, gidx, th_i, fl_i, None), args.reps)
         print(f"invert scalar    {name:12s}       {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s  {B/ms*1e3:10.0f} img/s")
     gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
+    # the same launches over a ring of buffer pairs larger than the 256 MB Infinity Cache: source and destination come from /
+    # go to HBM, as inside the real step (where GBs of network traffic lie between the producer of x and this kernel)
+    ring = max(2, int(1.3e9 // nbytes))
+    xs, ys = [torch.randn_like(x) for _ in range(ring)], [torch.empty_like(x) for _ in range(ring)]
+    it = [0]
+
+    def cold(fn):
+        def run():
+            it[0] = (it[0] + 1) % ring
+            fn(xs[it[0]], ys[it[0]])
+        return run
+    ms = timeit(cold(lambda a, b: b.copy_(a)), args.reps)
+    print(f"cache-cold ring of {ring}: torch copy_     {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    ms = timeit(cold(lambda a, b: ops.canon_transform(a, gidx, th_c, fl_c, S // 2)), args.reps)
+    print(f"cache-cold ring: canon_transform random {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    ms = timeit(cold(lambda a, b: ops.invert_action(a, gidx, th_i, fl_i, None)), args.reps)
+    print(f"cache-cold ring: invert scalar random   {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    del xs, ys
     f8 = torch.randn(B, 8, S, S, device=dev)
     ms = timeit(lambda: ops.invert_action(f8, gidx, th_i, fl_i, cm_i), args.reps)
     print(f"invert regular C=8 random            {ms*1e3:8.1f} us  {2*f8.numel()*4/ms/1e6:8.1f} GB/s")
