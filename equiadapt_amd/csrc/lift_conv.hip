@@ -453,14 +453,26 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
 // the kernel's.  One block per group of output rows, thread = channel (coalesced over the channels-last map), fp64.
 __global__ __launch_bounds__(kThreads) void lift_stats_dup_kernel(const float* __restrict__ y, double* __restrict__ rows, size_t nrows,
                                                                   int OW, int C, int x0, int x1) {
+  // the block's (row, seam pixel) pairs as one index space, eight independent loads in flight per thread
+  const unsigned npx = (unsigned)(x1 - x0);
+  const size_t my_rows = (nrows - blockIdx.x + gridDim.x - 1) / gridDim.x;
+  const size_t n_items = my_rows * npx;
   for (int c = threadIdx.x; c < C; c += kThreads) {
     double s = 0.0, q = 0.0;
-    for (size_t r = blockIdx.x; r < nrows; r += gridDim.x) {
-      const float* p = y + (r * OW + x0) * C + c;
-      for (int xx = x0; xx < x1; ++xx, p += C) {
-        const double v = (double)*p;
-        s += v;
-        q += v * v;
+    for (size_t i0 = 0; i0 < n_items; i0 += 8) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t i = i0 + k;
+        const size_t r = blockIdx.x + (i / npx) * gridDim.x;
+        const unsigned px = (unsigned)x0 + (unsigned)(i % npx);
+        v[k] = i < n_items ? y[(r * OW + px) * C + c] : 0.0f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const double d = (double)v[k];
+        s += d;
+        q += d * d;
       }
     }
     double* o = rows + ((size_t)blockIdx.x * C + c) * 2;
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(kThreads) void lift_stats_dup_kernel(const float* _
   }
 }
 
-constexpr unsigned kLiftDupBlocks = 512;
+constexpr unsigned kLiftDupBlocks = 1024;
 
 }  // namespace
 
