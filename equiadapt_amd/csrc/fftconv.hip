@@ -798,25 +798,29 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
     float re[kFftN], im[kFftN];
     // lstep is made opaque at every issue: otherwise its 48 multiples are hoisted out of the item loop as loop invariants and
     // the incoming column is spilled to make room for them
-#define EQA_PIPE_ISSUE(v_)                                                                                                    \
+#ifndef EQA_PIPE_EARLY
+#define EQA_PIPE_EARLY 16   // loads of the next item issued BEFORE barrier A (see the loop below)
+#endif
+#define EQA_PIPE_ISSUE_RANGE(v_, K0_, K1_)                                                                                    \
   do {                                                                                                                       \
     asm volatile("" : "+v"(lstep));                                                                                          \
     const unsigned work_ = work_of(v_);                                                                                      \
     const unsigned item_ = (unsigned)(((size_t)(work_ / ngrp) * C + (size_t)(work_ % ngrp) * CH) * 8);                       \
     const unsigned base_ = (v_) < nwork ? col0 + item_ : 0xfffffff0u;                                                        \
-    _Pragma("unroll") for (int ky = 0; ky < kFftN; ++ky) {                                                                   \
+    _Pragma("unroll") for (int ky = (K0_); ky < (K1_); ++ky) {                                                               \
       const unsigned kk_ = ky > kFftH - 1 ? (edge ? (unsigned)(kFftN - ky) : (unsigned)ky) : (unsigned)ky;                   \
       const unsigned off_ = (v_) < nwork ? base_ + kk_ * lstep : 0xfffffff0u;                                                \
       const f32x2 t_ = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(mr, off_, 0, 2));                      \
       re[ky] = t_[0];                                                                                                        \
       im[ky] = ky > kFftH - 1 ? __uint_as_float(__float_as_uint(t_[1]) ^ flip) : t_[1];                                      \
     }                                                                                                                        \
-    /* every offset right in front of its load (left alone, the scheduler forms all 48 offsets first: 48 more registers) */  \
-    _Pragma("unroll") for (int ky = 0; ky < kFftN; ++ky) {                                                                   \
+    /* every offset right in front of its load (left alone, the scheduler forms all the offsets first: as many more registers) */ \
+    _Pragma("unroll") for (int ky = (K0_); ky < (K1_); ++ky) {                                                               \
       __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                                                                     \
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                                                                     \
     }                                                                                                                        \
   } while (0)
+#define EQA_PIPE_ISSUE(v_) EQA_PIPE_ISSUE_RANGE(v_, 0, kFftN)
     unsigned v = blockIdx.x;
     EQA_PIPE_ISSUE(v);
     float* const q = lds + kx * kPitch + cl;
@@ -831,9 +835,17 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
         q[(i * 2 + 1) * CH] = oim[i];
       }
       PIPE_CLOCK(1);
+      // The column's registers are free as soon as its transform is in LDS, and the producers used to wait ~2.4 k cycles at A for
+      // the consumers' epilogue of the previous item with nothing in flight: the first EQA_PIPE_EARLY loads of the next item go out
+      // in that window (more would delay the producers' arrival at A -- the memory pipe throttles the issue -- and the consumers
+      // with it), the rest behind A as before.
+      __builtin_amdgcn_sched_barrier(0);
+      EQA_PIPE_ISSUE_RANGE(v + nblk, 0, EQA_PIPE_EARLY);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
       __syncthreads();                                   // A: the item's column transforms are in LDS
       PIPE_CLOCK(2);
-      EQA_PIPE_ISSUE(v + nblk);
+      EQA_PIPE_ISSUE_RANGE(v + nblk, EQA_PIPE_EARLY, kFftN);
       asm volatile("" ::: "memory");                     // the loads stay on this side of the barrier
       __builtin_amdgcn_sched_barrier(0);
       PIPE_CLOCK(3);
@@ -842,11 +854,13 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
     }
     PIPE_CLOCK_END(16);
 #undef EQA_PIPE_ISSUE
+#undef EQA_PIPE_ISSUE_RANGE
     return;
   }
   // ------------------------------------------------------------------ consumers
   const int t = threadIdx.x - kPipeProd;
   const int r = t / CH, cl = t % CH;
+  const unsigned cons_wave = __builtin_amdgcn_readfirstlane((unsigned)t >> 6);   // wave-uniform: lives in a scalar register
   PIPE_CLOCK_BEGIN(kPipeProd);  // consumer stamps: [24] wait at A, [25] passes before the last LDS read, [26] wait at B, [27] last pass + pieces
   for (unsigned v = blockIdx.x; v < nwork; v += nblk) {
     const unsigned work = work_of(v);
@@ -923,7 +937,7 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
         st_q += __shfl_xor(st_q, o, 64);
       }
       if ((t & 63) < CH) {
-        double* o = stats + ((m * (kPipeCons / 64) + (size_t)(t >> 6)) * C + c) * 2;
+        double* o = stats + ((m * (kPipeCons / 64) + cons_wave) * C + c) * 2;
         o[0] = (double)st_s;
         o[1] = (double)st_q;
       }

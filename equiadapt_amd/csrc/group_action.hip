@@ -849,9 +849,33 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_wide_kernel(const flo
   float wreg[kAaMaxK];
 #pragma unroll
   for (int j = 0; j < kAaMaxK; ++j) wreg[j] = (fixed_col && j < K) ? wx[ox_fixed * K + j] : 0.0f;
+  // Rows no wider than one float4 per thread (1024 floats: config 5): the NEXT iteration's rows are requested before this
+  // iteration's taps are taken, so the HBM round trip of an iteration hides behind the previous one's LDS work (round 3; a block
+  // runs ~10 iterations and only two blocks fit a CU, so each exposed round trip was paid in full: 171 -> see DESIGN 3.7).
+  const bool prefetch = vec_stage && xlen <= 4 * kThreads;
+  const int e_pf = 4 * threadIdx.x;
+  float4 pf[8];
+  auto pf_load = [&](int ry0) {
+    const int nr = min(rpi, nrows - ry0);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+      pf[rr] = *reinterpret_cast<const float4*>(src + (size_t)(ybeg + ry0 + min(rr, nr - 1)) * W + xbeg + min(e_pf, xlen - 4));
+  };
+  if (prefetch && nrows > 0) pf_load(0);
   for (int ry0 = 0; ry0 < nrows; ry0 += rpi) {
     const int nr = min(rpi, nrows - ry0);
-    if (vec_stage) {
+    if (prefetch) {
+      if (e_pf < xlen) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+          if (rr < nr) {
+            float* lrow = rowbuf + rr * row_stride;
+            lrow[pos(e_pf)] = pf[rr].x; lrow[pos(e_pf + 1)] = pf[rr].y; lrow[pos(e_pf + 2)] = pf[rr].z; lrow[pos(e_pf + 3)] = pf[rr].w;
+          }
+        }
+      }
+      if (ry0 + rpi < nrows) pf_load(ry0 + rpi);
+    } else if (vec_stage) {
       // 16-byte loads, one per (row, thread) and trip, ALL rows' loads in flight before the first LDS store: the rolled
       // load -> store loop paid one HBM round trip per row and 256 floats (32 trips per iteration of 8 rows of 1024)
       for (int e = 4 * threadIdx.x; e < xlen; e += 4 * kThreads) {
