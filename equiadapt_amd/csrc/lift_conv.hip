@@ -108,10 +108,17 @@ __device__ __forceinline__ unsigned lift_ox0(const LiftPos& p, int OW) {
 }
 
 template <int KH>
+__device__ __forceinline__ void lift_stage_load_at(const float* __restrict__ x, size_t x_numel, size_t base, LiftStage<KH>& g);
+
+template <int KH>
 __device__ __forceinline__ void lift_stage_load(const float* __restrict__ x, size_t x_numel, const LiftPos& p, unsigned ox0,
                                                 int H, int W, int Cin, LiftStage<KH>& g) {
   // uniform: one 32 x 32 -> 64 bit product (input row x row length), not a chain of 64-bit multiplies
-  const size_t base = (size_t)(p.img * (unsigned)H + p.oy) * ((unsigned)W * (unsigned)Cin) + ox0 * (unsigned)Cin;
+  lift_stage_load_at<KH>(x, x_numel, (size_t)(p.img * (unsigned)H + p.oy) * ((unsigned)W * (unsigned)Cin) + ox0 * (unsigned)Cin, g);
+}
+
+template <int KH>
+__device__ __forceinline__ void lift_stage_load_at(const float* __restrict__ x, size_t x_numel, size_t base, LiftStage<KH>& g) {
   const size_t left = (x_numel - base) * sizeof(float);
   // a partial tile (OW < 32) and the last rows of the last image reach past the end of x: the range check returns 0 for
   // those dwords, and they only ever land on pixels that are not stored
@@ -448,6 +455,271 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// DENSE form: 5 x 5 filters over 3 channels (R = 15), Cout % 64 == 0, output rows of >= 32 pixels -- the headline shape.  Two
+// changes to the kernel above remove 9 % of its MFMAs:
+//  * K = 76 instead of 80.  A filter row's 15 elements go to the two k-halves of the MFMA as j = q | q + 8 (q = 0..6): 7 steps per
+//    row instead of 8 with an idle slot; the five left-over elements j = 7 pair up ACROSS rows: (row 0 | row 1), (row 2 | row 3),
+//    (row 4 | the constant 1.0 whose weight is the bias).  38 steps.  The lanes of half 1 then read those three operands one staged
+//    row further down -- a second per-lane LDS address, not a select in the stream.  The packed weights keep the layout of
+//    include/eqa_hip.h; the wave only picks its registers from other slots of it.
+//  * Tiles are 32 consecutive pixels of the image's FLATTENED output map, not of one output row: 92-pixel rows needed three
+//    tiles (96 pixels computed, the seam stored twice); flattened, only the last tile of an image overlaps its neighbour.  A tile
+//    that runs over the end of an output row finds the pixels of the next row (KW - 1) * Cin floats further into the same
+//    contiguous piece of the input, so the staged segment is that much longer and the lanes behind the row end add the gap to
+//    their LDS address: one compare + three selects per tile.  (OW >= 32: at most one row end per tile.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kDenseSteps = 38;
+
+struct DensePlace {   // wave-uniform
+  size_t in_base;     // first input element of the tile
+  unsigned p0;        // first output pixel (flattened, within the image)
+  unsigned nb;        // pixels of the tile in front of the end of the output row (>= 32: the tile stays in its row)
+};
+
+__device__ __forceinline__ DensePlace dense_place(const LiftPos& p, unsigned P, unsigned OW, unsigned magic, int H, int W, int Cin) {
+  DensePlace d;
+  d.p0 = min(p.tx * 32u, P - 32u);
+  const unsigned oy0 = __umulhi(d.p0, magic);   // = p0 / OW: magic = ceil(2^32 / OW), exact while OH * OW * OW < 2^32 (host-checked)
+  const unsigned ox0 = d.p0 - oy0 * OW;
+  d.nb = OW - ox0;
+  d.in_base = (size_t)(p.img * (unsigned)H + oy0) * ((unsigned)W * (unsigned)Cin) + ox0 * (unsigned)Cin;
+  return d;
+}
+
+struct DenseLane {   // loop constants: the lane's LDS addresses in stage buffer 0 for a tile that stays in its output row
+  const float *a, *b, *last;   // rows at j = 0 | 8;  the j = 7 pairs (row 0 | 1), (row 2 | 3);  (row 4 | row 4 again, weight 0)
+};
+__device__ __forceinline__ void dense_fill(const DenseLane& l, int d, float (&a)[5][7], float (&a7)[3]) {
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) a[ky][q] = l.a[d + ky * kLiftRow + q];
+  a7[0] = l.b[d];
+  a7[1] = l.b[d + 2 * kLiftRow];
+  a7[2] = l.last[d];
+}
+
+// d: the refilled tile's stage buffer offset + (for the lanes behind the end of its output row) the row gap, in floats
+template <bool EPI, bool STATS>
+__device__ __forceinline__ void dense_tile(const float (&b0)[kDenseSteps], const float (&b1)[kDenseSteps], float (&a)[5][7], float (&a7)[3],
+                                           const DenseLane& l, int d, const f32x16& c0, const f32x16& c1, f32x16& acc0, f32x16& acc1,
+                                           const f32x16& p0, const f32x16& p1, const LiftEpi& e, __amdgpu_buffer_rsrc_t out,
+                                           LiftStats& st) {
+#pragma unroll
+  for (int ky = 0; ky < 5; ++ky) {
+    f32x4 t[2];
+    if (EPI && ky > 0) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) t[n] = *reinterpret_cast<const f32x4*>(e.tr_r + 4 * (2 * (ky - 1) + n) * kLiftTrPitch);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      const int s = ky * 7 + q;
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a[ky][q], s == 0 ? c0 : acc0, 0, 0, 0);   // c0 / c1: the bias
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a[ky][q], s == 0 ? c1 : acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) a[ky][q] = l.a[d + ky * kLiftRow + q];
+    if (EPI) {
+      if (ky == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          lift_epi_write(g, p0, e.tr_w);
+          lift_epi_write(g, p1, e.tr_w + 32);
+        }
+      } else {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) lift_epi_store<false, STATS>(2 * (ky - 1) + n, t[n], e, out, 0, st);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[35 + k], a7[k], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[35 + k], a7[k], acc1, 0, 0, 0);
+  }
+  a7[0] = l.b[d];
+  a7[1] = l.b[d + 2 * kLiftRow];
+  a7[2] = l.last[d];
+}
+
+// the pinned order of one step's region: behind every MFMA at most one LDS instruction, one VALU, two SALU, one VMEM (lift_tile)
+__device__ __forceinline__ void dense_pin() {
+#pragma unroll
+  for (int m = 0; m < 2 * kDenseSteps; ++m) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x080, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);
+    __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+  }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kThreads, 1) void lift_conv_dense_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                      const float* __restrict__ bias, int relu, float* __restrict__ y,
+                                                                      int H, int W, int Cin, int OH, int OW, int Cout,
+                                                                      unsigned tiles_per_img, unsigned ntiles, size_t x_numel,
+                                                                      size_t y_numel, unsigned nslices, unsigned nstreams, int grouped,
+                                                                      unsigned magic, double* __restrict__ stats) {
+  constexpr int KH = 5;
+  using Stage = LiftStage<KH>;
+  constexpr int kBuf = Stage::kFloats + 4;
+  __shared__ float lds_all[kThreads / 64][2][kBuf];
+  __shared__ float lds_tr_all[kThreads / 64][32 * kLiftTrPitch];
+  const int lane = threadIdx.x & 63;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned gw = blockIdx.x * (kThreads / 64) + wave;
+  if (gw >= nslices * nstreams) return;
+  const unsigned slice = gw % nslices, stream = gw / nslices;
+  float (&lds)[2][kBuf] = lds_all[wave];
+  const int h = lane >> 5, col = lane & 31;
+  const int ch0 = slice * 64 + col;
+  // the wave's weights, picked from the packed layout (ops.pack_lift_weights / include/eqa_hip.h): element j of row ky sits at
+  // [(ky * 8 + j) * 2 + 0] for j <= 7 and at [(ky * 8 + j - 7) * 2 + 1] for j >= 8
+  float b0[kDenseSteps], b1[kDenseSteps];
+#pragma unroll
+  for (int s = 0; s < 35; ++s) {
+    const int ky = s / 7, q = s % 7;
+    const size_t idx = h ? (size_t)((ky * 8 + q + 1) * 2 + 1) : (size_t)((ky * 8 + q) * 2);
+    b0[s] = wpk[idx * Cout + ch0];
+    b1[s] = wpk[idx * Cout + ch0 + 32];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int ky = 2 * k + h;   // 5: the spare k-slot -- weight 0 (its operand is row 4's element again: finite whenever the pixel's own
+    const size_t idx = (size_t)((min(ky, 4) * 8 + 7) * 2);   // receptive field is)
+    b0[35 + k] = ky < 5 ? wpk[idx * Cout + ch0] : 0.0f;
+    b1[35 + k] = ky < 5 ? wpk[idx * Cout + ch0 + 32] : 0.0f;
+  }
+  // the bias is the C operand of a tile's first MFMA: register r of lane (h, pixel) is channel (r & 3) + 8 (r >> 2) + 4 h
+  f32x16 c0, c1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ch = slice * 64 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    c0[r] = bias ? bias[ch] : 0.0f;
+    c1[r] = bias ? bias[ch + 32] : 0.0f;
+  }
+  LiftEpi epi;
+  epi.tr_w = lds_tr_all[wave] + col * kLiftTrPitch + 4 * h;
+  epi.tr_r = lds_tr_all[wave] + (lane >> 4) * kLiftTrPitch + 4 * (lane & 15);
+  epi.lo = relu ? 0 : (int)0x80000000;
+  const unsigned P = (unsigned)OH * (unsigned)OW;
+  epi.out_voff = grouped ? ((slice * 4 + ((lane & 15) >> 2)) * (P * 16u) + (unsigned)(lane >> 4) * 16u + 4 * (lane & 3)) * 4u
+                         : ((unsigned)(lane >> 4) * Cout + slice * 64 + 4 * (lane & 15)) * 4u;
+  epi.row4 = grouped ? 4u * 16u * 4u : 4u * Cout * 4u;
+  epi.lane = lane;
+  const int gap = (W - OW) * Cin;
+  const int n_el = 31 * Cin + gap + 15;
+  DenseLane dl;
+  dl.a = &lds[0][0] + Cin * col + 8 * h;
+  dl.b = &lds[0][0] + Cin * col + 7 + kLiftRow * h;
+  dl.last = &lds[0][0] + Cin * col + 7 + 4 * kLiftRow;
+  auto offset_of = [&](unsigned nb, int buf) { return ((unsigned)col >= nb ? gap : 0) + buf * kBuf; };
+  const unsigned count = (ntiles - stream + nstreams - 1) / nstreams;
+
+  LiftStats lst;
+  lst.s01 = lst.s23 = lst.q01 = lst.q23 = f32x2{0.0f, 0.0f};
+  Stage g;
+  lift_stage_init<KH>(g, lane, W, Cin, n_el);
+  LiftPos pA, pB, pC, pD, pE;   // tiles i .. i + 4 of the stream
+  LiftStep step;
+  lift_pos_init(stream, nstreams, tiles_per_img, 1u, pA, step);   // (tile of the image, 0, image)
+  pB = lift_pos_next(pA, step, tiles_per_img, 1u, 1 < count);
+  pC = lift_pos_next(pB, step, tiles_per_img, 1u, 2 < count);
+  pD = lift_pos_next(pC, step, tiles_per_img, 1u, 3 < count);
+  auto place = [&](const LiftPos& p) { return dense_place(p, P, (unsigned)OW, magic, H, W, Cin); };
+  // (no branch on `grouped` below: a branch ends the scheduling region, and what sits outside the region of a tile's MFMAs runs
+  // with the matrix pipe drained)
+  const unsigned pix_stride = grouped ? 16u : (unsigned)Cout;
+  const size_t img_stride = (size_t)P * Cout;
+  auto out_of = [&](const LiftPos& p) -> __amdgpu_buffer_rsrc_t {
+    const unsigned p0 = min(p.tx * 32u, P - 32u);
+    return lift_out_rsrc(y, y_numel, (size_t)p.img * img_stride + (size_t)(p0 * pix_stride));
+  };
+  auto in_of = [&](const LiftPos& p) -> __amdgpu_buffer_rsrc_t {
+    const size_t base = place(p).in_base;
+    const size_t left = (x_numel - base) * sizeof(float);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + base), 0, (int)((left >> 32) ? 0xffffffffu : (unsigned)left), 0x00020000);
+  };
+  auto load = [&](Stage& G, __amdgpu_buffer_rsrc_t r) {
+#pragma unroll
+    for (int k = 0; k < Stage::kIters; ++k) G.v[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)G.voff[k], 0, 0));
+  };
+
+  Stage G0, G1;
+  G0 = g;
+  G1 = g;
+  float a[5][7], a7[3];
+  load(G0, in_of(pA));
+  lift_stage_store<KH>(lds[0], lane, G0);
+  dense_fill(dl, offset_of(place(pA).nb, 0), a, a7);
+  load(G1, in_of(pB));  // tile 1
+  load(G0, in_of(pC));  // tile 2
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Step i = { tile i+1: registers -> stage buffer (i+1) & 1;  tile i+3: HBM -> the same registers;  the MFMA stream of tile i,
+  // a[] refilling from that buffer, the stores of tile i-1;  AND the scalar work that places step i+1's tiles (its load descriptor,
+  // its store descriptor, the lanes' LDS offset of its refill) } -- one scheduling region: nothing a step's memory instructions
+  // need is computed in that step, so the ~70 scalar instructions spread through the MFMA shadows instead of sitting in front.
+  f32x16 e0, e1, o0, o1;
+  __amdgpu_buffer_rsrc_t po = out_of(pA);                 // where the tile stored during the NEXT step goes
+  __amdgpu_buffer_rsrc_t r_in = in_of(pD);                // this step's load
+  int d = offset_of(place(pB).nb, 1);                     // this step's refill (tile 1, buffer 1)
+  {
+    lift_stage_store<KH>(lds[1], lane, G1);
+    load(G1, r_in);
+    dense_tile<false, STATS>(b0, b1, a, a7, dl, d, c0, c1, e0, e1, e0, e1, epi, po, lst);
+    pE = lift_pos_next(pD, step, tiles_per_img, 1u, 4 < count);
+    r_in = in_of(pE);
+    d = offset_of(place(pC).nb, 0);
+    dense_pin();
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see lift_conv_mfma_kernel
+  for (unsigned i = 1;; i += 2) {
+    if (i >= count) {
+      lift_epi_all<false, false, STATS>(epi, e0, e1, po, 0, lst);
+      lift_stage_pin<KH>(G0);
+      lift_stage_pin<KH>(G1);
+      if (STATS) lift_stats_flush(lst, stats, stream, slice, Cout, lane);
+      return;
+    }
+    {  // tile i (odd) -> o, stores tile i-1 (e) to po; positions: pB = tile i, pC = i+1, pD = i+2, pE = i+3
+      const __amdgpu_buffer_rsrc_t pn = out_of(pB);
+      lift_stage_store<KH>(lds[0], lane, G0);
+      load(G0, r_in);
+      dense_tile<true, STATS>(b0, b1, a, a7, dl, d, c0, c1, o0, o1, e0, e1, epi, po, lst);
+      pA = pB; pB = pC; pC = pD; pD = pE;
+      pE = lift_pos_next(pD, step, tiles_per_img, 1u, i + 4 < count);
+      r_in = in_of(pE);
+      d = offset_of(place(pC).nb, 1);
+      po = pn;
+      dense_pin();
+    }
+    if (i + 1 >= count) {
+      lift_epi_all<false, false, STATS>(epi, o0, o1, po, 0, lst);
+      lift_stage_pin<KH>(G0);
+      lift_stage_pin<KH>(G1);
+      if (STATS) lift_stats_flush(lst, stats, stream, slice, Cout, lane);
+      return;
+    }
+    {
+      const __amdgpu_buffer_rsrc_t pn = out_of(pB);
+      lift_stage_store<KH>(lds[1], lane, G1);
+      load(G1, r_in);
+      dense_tile<true, STATS>(b0, b1, a, a7, dl, d, c0, c1, e0, e1, o0, o1, epi, po, lst);
+      pA = pB; pB = pC; pC = pD; pD = pE;
+      pE = lift_pos_next(pD, step, tiles_per_img, 1u, i + 5 < count);
+      r_in = in_of(pE);
+      d = offset_of(place(pC).nb, 0);
+      po = pn;
+      dense_pin();
+    }
+  }
+}
+
 // The unmasked kernel computes the pixels [x0, x1) of every output row twice (the last tile of a row starts at OW - 32 and
 // overlaps its neighbour), so its running sums count them twice: this pass writes MINUS their sums into the partial rows behind
 // the kernel's.  One block per group of output rows, thread = channel (coalesced over the channels-last map), fp64.
@@ -513,6 +785,32 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   const unsigned waves = nslices * nstreams, per_block = kThreads / 64;
   const dim3 grid((waves + per_block - 1) / per_block);
   hipStream_t st = (hipStream_t)stream;
+  // the DENSE form (K = 76, flattened tiles): 5 x 5 over 3 channels, whole 64-channel slices, rows of >= 32 pixels
+  static const bool dense_off = [] { const char* e = getenv("EQA_LIFT_DENSE"); return e && e[0] == '0'; }();
+  const uint64_t P = (uint64_t)OH * OW;
+  const bool dense = !dense_off && KH == 5 && R == 15 && !narrow && OW >= 32 && (31 + KW - 1) * Cin + R <= kLiftRow &&
+                     P * OW < 0x100000000ULL && (size_t)nimg * ((P + 31) / 32) <= 0x7fffffffULL;
+  if (dense) {
+    if ((stats || rows_only) && (grouped || bias || relu)) return rows_only ? 0 : EQA_ERR_UNSUPPORTED;
+    const unsigned tpi = (unsigned)((P + 31) / 32);
+    const unsigned nt = (unsigned)nimg * tpi;
+    const unsigned ns = (unsigned)std::min<size_t>(nt, std::max(1u, (unsigned)EQA_LIFT_WAVES / nslices));
+    const dim3 dgrid((nslices * ns + per_block - 1) / per_block);
+    const unsigned magic = 0xffffffffu / (unsigned)OW + 1u;   // ceil(2^32 / OW)
+    const int x0 = (int)P - 32, x1 = 32 * ((int)tpi - 1);     // the pixels the last tile of an image shares with its neighbour
+    const unsigned dup_blocks = (stats || rows_only) && x1 > x0 ? (unsigned)std::min<size_t>((size_t)nimg, kLiftDupBlocks) : 0u;
+    if (rows_only) return (int)(ns + dup_blocks);
+    if (stats)
+      hipLaunchKernelGGL((lift_conv_dense_kernel<true>), dgrid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, OH, OW, Cout, tpi, nt,
+                         x_numel, y_numel, nslices, ns, grouped, magic, stats);
+    else
+      hipLaunchKernelGGL((lift_conv_dense_kernel<false>), dgrid, dim3(kThreads), 0, st, x, wpk, bias, relu, y, H, W, Cin, OH, OW, Cout, tpi, nt,
+                         x_numel, y_numel, nslices, ns, grouped, magic, (double*)nullptr);
+    if (dup_blocks)   // the flattened map as one "row" per image
+      hipLaunchKernelGGL(lift_stats_dup_kernel, dim3(dup_blocks), dim3(kThreads), 0, st, y, stats + (size_t)ns * Cout * 2, (size_t)nimg, (int)P,
+                         Cout, x0, x1);
+    return launch_status();
+  }
   if (stats || rows_only) {
     if (narrow || OW < 32 || grouped || bias || relu) return rows_only ? 0 : EQA_ERR_UNSUPPORTED;
     const int x0 = OW - 32, x1 = 32 * ((int)tiles_per_row - 1);  // the columns the last tile of a row shares with its neighbour

@@ -830,7 +830,11 @@ def test_lift_conv_mfma_matches_conv2d(dev):
                                     (300, 3, 3, 64, 10, 37),
                                     # channel counts off the 64-multiples (predicated stores, several tiles per row)
                                     (128, 3, 5, 32, 32, 32), (3, 3, 5, 16, 20, 75), (2, 3, 3, 48, 40, 40), (4, 3, 5, 80, 12, 100),
-                                    (1, 3, 5, 32, 5, 5)]:   # incl. streams of 1, 2, 3 tiles per wave and partial tiles
+                                    (1, 3, 5, 32, 5, 5),   # incl. streams of 1, 2, 3 tiles per wave and partial tiles
+                                    # the dense form (K = 76, tiles over the flattened map): one tile, tiles that run over a row
+                                    # end at every position, an overlapping last tile, the headline shape, many images
+                                    (1, 3, 5, 64, 5, 36), (3, 3, 5, 128, 9, 37), (2, 3, 5, 64, 96, 96), (2, 3, 5, 256, 37, 67),
+                                    (300, 3, 5, 64, 8, 40), (1, 3, 5, 64, 6, 36)]:
         assert ops.lift_conv_supported(Cin, K, K, Cout)
         x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
         w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
@@ -848,6 +852,17 @@ def test_lift_conv_mfma_matches_conv2d(dev):
     w = torch.randn(64, 3, 5, 5, device=dev)
     got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), None, False, 5, 5)
     assert torch.allclose(got.double(), F.conv2d(x.double(), w.double()), atol=1e-4)
+    for hw in [(5, 36), (6, 37), (7, 41)]:   # ... and the dense form's longer segments (exact-size buffers)
+        x = torch.randn(1, 3, *hw, device=dev).contiguous(memory_format=torch.channels_last)
+        got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), None, False, 5, 5)
+        assert torch.allclose(got.double(), F.conv2d(x.double(), w.double()), atol=1e-4), hw
+    x = torch.randn(2, 3, 9, 40, device=dev).contiguous(memory_format=torch.channels_last)
+    x[1, 2, 3, 37] = float("inf")            # confined to its receptive fields in the dense form too (row-crossing tiles)
+    got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), None, False, 5, 5)
+    bad = ~torch.isfinite(got).all(dim=1)
+    want_bad = torch.zeros_like(bad)
+    want_bad[1, 0:4, 33:36] = True
+    assert torch.equal(bad, want_bad)
     # non-finite pixels stay confined to the outputs whose receptive field contains them (zero-weight duplicates are
     # always elements of the same receptive field)
     x = torch.randn(1, 3, 12, 12, device=dev).contiguous(memory_format=torch.channels_last)
