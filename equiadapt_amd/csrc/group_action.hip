@@ -822,6 +822,118 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
   }
 }
 
+// Narrow filters over 16-byte aligned rows (the headline's 224 -> crop 180 -> 96, K = 5), round 3.  The kernel above gathers its K
+// taps from global memory (two input rows per trip, one dependent round trip per trip) and chains table load -> address -> data
+// load: ~11 us per block whatever its size, 1.65 TB/s.  Here a block keeps ONE band of kAaBand output rows and walks over planes
+// (the tables of a band are the same for every plane: loaded once), stages the band's input rows in LDS with 16-byte loads of the
+// aligned column window -- the NEXT plane's rows are requested (registers) before this plane's two passes run from LDS, so the
+// HBM round trip hides behind the LDS work -- and writes the band.
+
+template <int K, int BAND, int NL>   // K: taps per output index; BAND: output rows per block; NL: 16-byte loads per thread and plane (a template argument: no branch per tap, and the wait counts stay exact)
+__global__ __launch_bounds__(kThreads, 4) void crop_resize_aa_staged_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                        const float* __restrict__ wx, const int32_t* __restrict__ x0,
+                                                                        const float* __restrict__ wy, const int32_t* __restrict__ y0,
+                                                                        int planes, int H, int W, int OH, int OW, int cap_rows,
+                                                                        int xb, int xl) {
+  extern __shared__ __attribute__((aligned(16))) float aa_tmp[];  // rows [cap_rows][xl], the horizontal pass [cap_rows][OW], tables
+  float* rows = aa_tmp;
+  float* tmp = aa_tmp + (size_t)cap_rows * xl;
+  float* tabw = tmp + (size_t)cap_rows * OW;                              // [BAND][K] vertical weights of the band
+  int* taby = reinterpret_cast<int*>(tabw + BAND * K);  // [BAND] first input row of each output row
+  const int r0 = blockIdx.x * BAND, r1 = min(r0 + BAND, OH);
+  const int nband = r1 - r0;
+  const int rows_par = kThreads / OW;
+  const int ox = rows_par >= 1 ? threadIdx.x % OW : 0, rsub = rows_par >= 1 ? threadIdx.x / OW : 0;
+  const int xs_g = x0[ox];
+  float wv[K];
+  int xo[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    wv[j] = wx[ox * K + j];
+    xo[j] = min(xs_g - xb + j, xl - 1);
+  }
+  if ((int)threadIdx.x < nband * K) tabw[threadIdx.x] = wy[r0 * K + threadIdx.x];
+  const int ybeg = y0[r0];
+  if ((int)threadIdx.x < nband) taby[threadIdx.x] = y0[r0 + threadIdx.x] - ybeg;
+  const int yend = min(y0[r1 - 1] + K, H);
+  const int nrows = min(yend - ybeg, cap_rows);
+  const int nq = xl >> 2;
+  const int tq = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const bool prefetch = nq <= 64 && nrows <= 4 * NL;   // uniform: one 16-byte load per (thread, row group member)
+  const size_t plane_sz = (size_t)H * W;
+  const float* src0 = x + (size_t)ybeg * W + xb;
+  typedef float aa_f4 __attribute__((ext_vector_type(4)));
+  aa_f4 v[NL];
+  // (a macro, not a lambda: called from two places the lambda is not inlined and v[] goes to scratch)
+#define EQA_AA_PF_LOAD(plane_)                                                                                          \
+  do {                                                                                                                  \
+    const float* src_ = src0 + (size_t)(plane_) * plane_sz;                                                             \
+    _Pragma("unroll") for (int k = 0; k < NL; ++k)                                                           \
+      v[k] = *reinterpret_cast<const aa_f4*>(src_ + (size_t)min(tr + 4 * k, nrows - 1) * W + 4 * min(tq, nq - 1));     \
+  } while (0)
+  // the tables have arrived before the first row is requested: from here on only row loads are ever outstanding, and the waits
+  // the compiler places inside the passes are for those it names (a pending table load made them vmcnt(0): the prefetch drained)
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  if (prefetch) EQA_AA_PF_LOAD(blockIdx.y);
+  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+    if (prefetch) {
+      if (tq < nq) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k)
+          if (tr + 4 * k < nrows) *reinterpret_cast<aa_f4*>(rows + (tr + 4 * k) * xl + 4 * tq) = v[k];
+      }
+      if (plane + (int)gridDim.y < planes) EQA_AA_PF_LOAD(plane + gridDim.y);
+    } else {
+      const float* src = src0 + (size_t)plane * plane_sz;
+      for (int q = tq; q < nq; q += 64)
+        for (int rb = tr; rb < nrows; rb += 4) *reinterpret_cast<aa_f4*>(rows + rb * xl + 4 * q) = *reinterpret_cast<const aa_f4*>(src + (size_t)rb * W + 4 * q);
+    }
+    __syncthreads();
+    // horizontal pass (fp32 intermediates, as torch's kernel): a thread keeps one output column -- tap starts and weights in registers
+    if (rows_par >= 1) {
+      if (rsub < rows_par) {
+        for (int ry0 = rsub; ry0 < nrows; ry0 += 4 * rows_par) {   // four rows' taps in flight at once (LDS latency, not bandwidth)
+          float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* row = rows + min(ry0 + u * rows_par, nrows - 1) * xl;
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+              acc[u] += wv[j] * row[xo[j]];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (ry0 + u * rows_par < nrows) tmp[(ry0 + u * rows_par) * OW + ox] = acc[u];
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < nrows * OW; idx += kThreads) {
+        const int ry = idx / OW, oxx = idx - ry * OW;
+        const float* row = rows + ry * xl;
+        const int xs = x0[oxx] - xb;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+          acc += wx[oxx * K + j] * row[min(xs + j, xl - 1)];
+        tmp[ry * OW + oxx] = acc;
+      }
+    }
+    __syncthreads();
+    float* dst = y + (size_t)plane * OH * OW;
+    for (int idx = threadIdx.x; idx < nband * OW; idx += kThreads) {
+      const int r = idx / OW, oxx = idx - r * OW;
+      const int ys = taby[r];
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < K; ++j)
+        acc += tabw[r * K + j] * tmp[min(ys + j, nrows - 1) * OW + oxx];
+      dst[(size_t)(r0 + r) * OW + oxx] = acc;
+    }
+    __syncthreads();   // the next plane's horizontal pass overwrites tmp
+  }
+#undef EQA_AA_PF_LOAD
+}
+
 // Wide filters (K > 8, i.e. down-sampling by more than ~3.5x: config 5 resizes 1024 -> 128 with 17 taps): the K strided
 // global loads per intermediate value of the kernel above become the bottleneck (0.73 ms for 32 x 3 x 1024^2, 9x its HBM
 // time).  Here every needed input row segment is first staged into LDS with coalesced loads, `rpi` rows per iteration,
@@ -1444,6 +1556,42 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
     if (rpi >= 1) {
       hipLaunchKernelGGL(crop_resize_aa_wide_kernel, grid, dim3(kThreads), lds2, (hipStream_t)stream, x, y, wx, x0, wy, y0, H, W, OH,
                          OW, K, max_rows, x_begin, x_span, pad_shift, row_stride, rpi);
+      return launch_status();
+    }
+  }
+  // narrow filters over aligned rows: the LDS-staged form (whole band requested at once)
+  static const bool staged_off = [] { const char* e = getenv("EQA_AA_STAGED"); return e && e[0] == '0'; }();
+  if (!staged_off && K <= EQA_AA_WIDE_MIN_K && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0 && x_span > 0 && x_begin >= 0 &&
+      x_begin + x_span <= W) {
+    const int xb = x_begin & ~3, xl = std::min(W, (x_begin + x_span + 3) & ~3) - xb;
+    static const int band_env = [] { const char* e = getenv("EQA_AA_BAND"); return e ? atoi(e) : 8; }();
+    const int band = band_env == 16 ? 16 : 8;
+    const int cap_rows = (band / kAaBand) * max_rows;   // a band of 16 rows = two of the 8-row bands `max_rows` was taken over
+    const size_t lds3 = ((size_t)cap_rows * (xl + OW) + band * (EQA_AA_WIDE_MIN_K + 1)) * sizeof(float);
+    if (lds3 <= 64 * 1024 && band * K <= kThreads) {
+      // persistent over planes: about 8 resident blocks per CU in all, each walking planes with a stride of gridDim.y
+      static const int per_cu = [] { const char* e = getenv("EQA_AA_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 8; }();
+      const int nbands = (OH + band - 1) / band;
+      const int groups = std::max(1, std::min(planes, (256 * per_cu + nbands - 1) / nbands));
+      const bool few = cap_rows <= 20;   // 5 loads per thread cover the band's rows (else 10: up to 40 rows)
+#define EQA_AA_STAGED(K_)                                                                                                              \
+  case K_:                                                                                                                             \
+    if (band == 16)                                                                                                                    \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 16, 10>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
+                         y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
+    else if (few)                                                                                                                      \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 5>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x,  \
+                         y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 10>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
+                         y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
+    break
+      switch (K) {
+        EQA_AA_STAGED(1); EQA_AA_STAGED(2); EQA_AA_STAGED(3); EQA_AA_STAGED(4); EQA_AA_STAGED(5); EQA_AA_STAGED(6); EQA_AA_STAGED(7);
+        EQA_AA_STAGED(8);
+        default: return EQA_ERR_UNSUPPORTED;
+      }
+#undef EQA_AA_STAGED
       return launch_status();
     }
   }

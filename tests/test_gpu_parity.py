@@ -463,7 +463,10 @@ def test_crop_resize_aa_matches_torch_interpolate(dev):
     torch.manual_seed(14)
     # the last three use the wide-filter (LDS row staging) kernel: 8x, 6x (even stride, padded rows) and 5x (odd stride)
     for (H, W, ratio, size) in [(224, 224, 0.8, 96), (64, 64, 0.9, 32), (50, 70, 0.8, (24, 40)), (33, 33, 1.0, 17),
-                                (1024, 1024, 1.0, 128), (400, 300, 0.9, (60, 45)), (320, 320, 1.0, 64)]:
+                                (1024, 1024, 1.0, 128), (400, 300, 0.9, (60, 45)), (320, 320, 1.0, 64),
+                                # narrow filters over 16-byte aligned rows: the LDS-staged band kernel (incl. up-sampling, output
+                                # rows wider than a block, a window that starts off the 16-byte grid)
+                                (96, 100, 0.75, 40), (256, 256, 1.0, (300, 300)), (64, 512, 1.0, (32, 300)), (180, 184, 0.95, (90, 77))]:
         x = torch.randn(3, 3, H, W)
         want = io.pre_canonicalization_transform(x, (3, H, W), ratio, size)
         import math
