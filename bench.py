@@ -676,7 +676,7 @@ def main():
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic_canon_net.json")))
                 key = {"fft_gemm": "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
-                       "lift_conv": "lift_conv_mfma_kernel"}.get(dom)
+                       "lift_conv": "lift_conv_dense_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
             except (OSError, ValueError):
                 pass
@@ -709,6 +709,8 @@ def stage_table(ktimes, B):
         "winograd_gemm": ("mfma", 2.0 * 64 * tiles * 256 * 256, "64 x [tiles x 256].[256 x 256] strided-batched GEMM (library)"),
         "winograd_output_sums": ("hbm", v_bytes, "eqa_winograd_f4k5_output_sums incl. finalize (hand-written)"),
         "lift_conv": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift_conv_nhwc (hand-written fp32 MFMA)"),
+        # centre crop 224 -> 180 + antialiased resize -> 96: the crop window in, the resized planes out
+        "crop_resize_aa": ("hbm", B * 3 * (180 * 180 + 96 * 96) * 4, "eqa_crop_resize_aa (hand-written)"),
     }
     # the same layer as an overlap-save FFT convolution (default): 2 x 2 tiles of 48 x 48 per image, 1154 stored frequencies;
     # algorithmic bytes = activation in + spectra out (input), spectra in (output; the map itself is never written).  The
@@ -739,7 +741,7 @@ def stage_table(ktimes, B):
             stages[name] = {"what": what, "ms": ms_k, "bound": "mfma", "achieved": a, "peak": MFMA_F32_PEAK_TF,
                             "unit": "TFLOP/s", "frac": a / MFMA_F32_PEAK_TF, "launches_timed": n_k}
     for name in ("group_pool", "window_sums", "crop_resize_aa", "sums_gemv"):
-        if name in ktimes:
+        if name in ktimes and name not in stages:
             stages[name] = {"ms": ktimes[name][1], "launches_timed": ktimes[name][0]}
     return stages
 

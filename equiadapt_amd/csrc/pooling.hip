@@ -342,11 +342,30 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
     const float* q = base + e;
     double acc = 0.0;
     int s = 0;
-    for (; s < 2 * nb; ++s) {  // border-row segments are needed individually as well
-      float v = q[(size_t)(s * sub) * seg_stride];
-      for (int t = 1; t < sub; ++t) v += q[(size_t)(s * sub + t) * seg_stride];
-      s_brd[s][e] = v;
-      acc += (double)v;
+    if (sub <= 2) {
+      // border-row segments are needed individually as well.  All their pieces are requested before the first is used (the
+      // rolled form paid one round trip per piece, 16 in a row at k = 5: most of the kernel's 39 us for 85 MB)
+      float v[2 * kWsMaxBorder][2];
+#pragma unroll
+      for (int i = 0; i < 2 * kWsMaxBorder; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) v[i][t] = (i < 2 * nb && t < sub) ? q[(size_t)(i * sub + t) * seg_stride] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 2 * kWsMaxBorder; ++i) {
+        if (i < 2 * nb) {
+          const float w = sub == 2 ? v[i][0] + v[i][1] : v[i][0];
+          s_brd[i][e] = w;
+          acc += (double)w;
+        }
+      }
+      s = 2 * nb;
+    } else {
+      for (; s < 2 * nb; ++s) {
+        float v = q[(size_t)(s * sub) * seg_stride];
+        for (int t = 1; t < sub; ++t) v += q[(size_t)(s * sub + t) * seg_stride];
+        s_brd[s][e] = v;
+        acc += (double)v;
+      }
     }
     s *= sub;
     for (; s + 8 <= nseg; s += 8) {

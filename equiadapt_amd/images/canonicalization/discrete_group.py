@@ -167,9 +167,10 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
     def transformations_before_canonicalization_network_forward(self, x: torch.Tensor) -> torch.Tensor:
         """Centre crop by ``input_crop_ratio`` then resize to ``resize_shape`` (reference :174-188).
 
-        On the device, without autograd, crop + antialiased resize run as one kernel (``eqa_crop_resize_aa``)."""
+        On the device, where no gradient with respect to the image is wanted (inference, and training on images that do not
+        require grad), crop + antialiased resize run as one kernel (``eqa_crop_resize_aa``)."""
         crop, resize = self.crop_canonization, self.resize_canonization
-        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and isinstance(resize, Resize)
+        if (x.is_cuda and x.dtype == torch.float32 and not (torch.is_grad_enabled() and x.requires_grad) and isinstance(resize, Resize)
                 and resize.antialias):
             from equiadapt_amd.images.transforms import resized_output_size
 

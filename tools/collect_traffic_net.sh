@@ -21,7 +21,9 @@ alg = {  # algorithmic bytes per launch, fp32
     # the pipelined form writes one interior piece per consumer wave: 8 border rows + 5 x 2 tile rows, x 2 tile columns
     "fft48_inv_pipe_kernel": 1154 * B * 4 * 512 * 4 + B * 18 * 2 * 256 * 9 * 4,
     "lift_conv_mfma_kernel": B * 96 * 96 * 3 * 4 + B * 92 * 92 * 256 * 4,
+    "lift_conv_dense_kernel": B * 96 * 96 * 3 * 4 + B * 92 * 92 * 256 * 4,
     "crop_resize_aa_kernel": B * 3 * 180 * 180 * 4 + B * 3 * 96 * 96 * 4,
+    "crop_resize_aa_staged_kernel": B * 3 * 180 * 180 * 4 + B * 3 * 96 * 96 * 4,
     "window_sums_nhwc_finalize_kernel": B * 18 * 2 * 256 * 9 * 4 + B * 256 * 25 * 8,  # 8 border rows + 5 x 2 interior pieces, x 2 tile columns
     "group_action_kernel": B * 2 * 3 * 224 * 224 * 4,
     # V in + B3 (F x 256 x 256 x 3 floats) in + Mo out; the filter spectra are re-read from L2 by a frequency's 16 row tiles

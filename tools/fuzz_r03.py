@@ -3,6 +3,7 @@
     determinism (same input twice -> same bits)
   * eqa_plane_gemm: random T, P in {36, 64}, channel counts on the 32-multiples vs the fp64 product
   * eqa_lift_conv_nhwc: random sizes, channel counts on the 16-multiples vs F.conv2d in fp64
+  * eqa_crop_resize_aa: random sizes / crop ratios / output sizes vs the oracle (CenterCrop + antialiased interpolate)
   * eqa_group_action_pair vs the two separate launches (bit-equal)"""
 import argparse
 import os
@@ -31,11 +32,11 @@ def main():
     dev = torch.device("cuda:0")
     rng = random.Random(args.seed)
     torch.manual_seed(args.seed)
-    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0}
+    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0, "aa": 0}
     worst = {}
     t_end = time.time() + args.seconds
     while time.time() < t_end:
-        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair"])
+        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair", "aa"])
         if what in ("knn", "vnsmall"):
             k = rng.randint(1, 32)
             N = rng.choice([k, k + 1, rng.randint(k, 200), rng.randint(k, 1500), 1024])
@@ -100,15 +101,40 @@ def main():
                 if not ok and pooling == "max" and k > 1:
                     # an arg-max over the k neighbours whose two best scores are closer than fp32 resolves: the kernel and the op
                     # path may then pool different neighbours (a step of O(1 / N) in the output); count those clouds, don't judge them
+                    # (the fp32 scores themselves are only good to ~1e-5 .. 1e-3 of the size of the products they sum at the worst points
+                    # of a cloud -- tools/diag/vn_fuzz_case.py prints it -- so the tie test is: ONE flip at one of the closest sites
+                    # explains the kernel's output to within the allowance, and that site's gap is below 2e-4)
                     with torch.no_grad():
                         nd = net.double()
                         h = nd.conv_pos(get_graph_feature_cross(x.double().unsqueeze(1), k, idx.long()))
                         d = nd.pool.map_to_dir(h.transpose(1, -1)).transpose(1, -1)
-                        top = (h * d).sum(2).topk(2, dim=-1).values       # gap of the two best scores over the size of the
-                        size = (h * d).abs().sum(2).amax(-1)               # products they are sums of (scores cancel)
-                        margin = ((top[..., 0] - top[..., 1]) / size.clamp_min(1e-30)).min().item()
+                        score = (h * d).sum(2)
+                        top = score.topk(2, dim=-1)
+                        size = (h * d).abs().sum(2).amax(-1)               # gap of the two best scores over the size of the products
+                        gaps = (top.values[..., 0] - top.values[..., 1]) / size.clamp_min(1e-30)   # they are sums of (scores cancel)
+                        margin = gaps.min().item()
+
+                        def pooled_tail(choice):
+                            ix = choice[:, :, None, :, None].expand(-1, -1, 3, -1, 1)
+                            return nd.conv2(nd.bn1(nd.conv1(torch.gather(h, 4, ix).squeeze(-1)))).mean(dim=-1)[:, :3]
+
+                        best, explained = top.indices[..., 0], False
+                        bad_clouds = (e_k_c > allow).nonzero().flatten().tolist()
+                        explained_clouds = 0
+                        for bc in bad_clouds:
+                            order = gaps[bc].flatten().argsort()[:8]
+                            for o in order.tolist():
+                                c_, n_ = o // N, o % N
+                                if gaps[bc, c_, n_].item() >= 2e-4:
+                                    break
+                                ch = best.clone()
+                                ch[bc, c_, n_] = top.indices[bc, c_, n_, 1]
+                                if (a[bc].double() - pooled_tail(ch)[bc]).abs().max().item() <= allow[bc].item():
+                                    explained_clouds += 1
+                                    break
+                        explained = explained_clouds == len(bad_clouds)
                         net.float()
-                    assert margin < 1e-5, ("vnsmall", B, N, k, pooling, e_k, e_op, margin)
+                    assert explained or margin < 1e-5, ("vnsmall", B, N, k, pooling, e_k, e_op, margin)
                     counts["vnsmall: arg-max tie, not judged"] = counts.get("vnsmall: arg-max tie, not judged", 0) + 1
                 elif k > 1:        # k = 1 is degenerate (parallel q and gate direction: rounding noise divided by |q| + 1e-6)
                     assert ok, ("vnsmall", B, N, k, pooling, e_k, e_op)
@@ -124,8 +150,8 @@ def main():
             assert (M[:T].double() - want).abs().max().item() <= 5e-6 * want.abs().max().item(), ("plane_gemm", T, P, Cin, Cout)
             assert (M[T:] == 3.0).all()
         elif what == "lift":
-            K, Cin = rng.choice([(5, 3), (3, 3), (5, 2), (3, 4), (3, 5)])
-            Cout = 16 * rng.randint(1, 12)
+            K, Cin = rng.choice([(5, 3), (5, 3), (5, 3), (3, 3), (5, 2), (3, 4), (3, 5)])
+            Cout = rng.choice([64, 128, 192]) if rng.random() < 0.5 else 16 * rng.randint(1, 12)   # half of them: whole 64-channel slices (the dense form)
             H, W, B = rng.randint(K, 70), rng.randint(K, 110), rng.randint(1, 6)
             x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
             w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
@@ -133,6 +159,23 @@ def main():
             got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), b, True, K, K)
             want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
             assert (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-3), ("lift", B, Cin, K, Cout, H, W)
+        elif what == "aa":
+            # eqa_crop_resize_aa (narrow filters over aligned rows take the LDS-staged persistent kernel) vs the oracle's
+            # CenterCrop + antialiased F.interpolate
+            import math
+            from equiadapt_amd.images import geometry
+            from oracle import image_ops as io
+            H, W = rng.randint(12, 260), 4 * rng.randint(3, 65) + rng.choice([0, 0, 0, 1, 2])
+            ratio = rng.choice([1.0, 0.9, 0.8, 0.75])
+            size = rng.randint(6, 200)
+            B = rng.randint(1, 3)
+            x = torch.randn(B, 3, H, W)
+            want = io.pre_canonicalization_transform(x, (3, H, W), ratio, size)
+            crop = (math.ceil(H * ratio), math.ceil(W * ratio))
+            out_hw = io.tv_resize_output_size(crop, size)
+            tabs = tuple(v.to(dev) if isinstance(v, torch.Tensor) else v for v in geometry.aa_resize_tables((H, W), crop, out_hw))
+            got = ops.crop_resize_aa(x.to(dev), tabs, out_hw).cpu()
+            assert got.shape == want.shape and (got - want).abs().max().item() <= 3e-6, ("aa", B, H, W, ratio, size)
         else:
             N, refl = rng.choice([(4, False), (8, False), (4, True)])
             G = 2 * N if refl else N
