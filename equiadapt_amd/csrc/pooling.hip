@@ -324,10 +324,11 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
 // thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see DESIGN.md).  Fixed order, deterministic.
 // Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
 constexpr int kFinVals = 1 + 2 * kWsMaxBorder;
+constexpr int kFinThreads = 320;   // k = 5: a block's run is 32 channels x 9 values = 288 elements -- one trip of 320 threads, not two of 256
 
 // `sub` > 1: every segment arrives in `sub` pieces (one per tile column of the producer), laid out as consecutive segments;
 // the pieces of a border row are added up first (in fp32, as a single producer thread would have).
-__global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
+__global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
                                                                             int B, int C, int k, int nseg, int sub) {
   __shared__ double s_tot[kFinCh * kFinVals];
   __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
   const int run = nch * nval;  // contiguous elements of this block in one (image, segment) row
   const float* base = part + ((size_t)b * nseg * C + c0) * nval;
   const size_t seg_stride = (size_t)C * nval;
-  for (int e = threadIdx.x; e < run; e += kThreads) {
+  for (int e = threadIdx.x; e < run; e += blockDim.x) {
     const float* q = base + e;
     double acc = 0.0;
     int s = 0;
@@ -375,7 +376,14 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += (double)v[j];
     }
-    for (; s < nseg; ++s) acc += (double)q[(size_t)s * seg_stride];
+    if (s < nseg) {   // the last < 8 pieces: requested together as well (same order of additions)
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = s + j < nseg ? q[(size_t)(s + j) * seg_stride] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s + j < nseg) acc += (double)v[j];
+    }
     s_tot[e] = acc;
   }
   __syncthreads();
@@ -384,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
   // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
   // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
   const int kk = k * k;
-  for (int it = threadIdx.x; it < nch * kk; it += kThreads) {
+  for (int it = threadIdx.x; it < nch * kk; it += blockDim.x) {
     const int cl = it / kk, uv = it - cl * kk;
     const int u = uv / k, v = uv - u * k;
     auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
@@ -405,9 +413,10 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_finalize_kernel(con
 // One block per image, fixed-order tree reduction (deterministic).  rocBLAS' dgemm takes 0.2 ms for this 256 x 6400 x 8 shape.
 constexpr int kGemvMaxE = 16;
 
-__global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __restrict__ S, const double* __restrict__ Wm,
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void sums_gemv_kernel(const double* __restrict__ S, const double* __restrict__ Wm,
                                                             float* __restrict__ act, int K, int E, double scale, double shift) {
-  __shared__ double s_red[kThreads / 64][kGemvMaxE];
+  __shared__ double s_red[THREADS / 64][kGemvMaxE];
   const int b = blockIdx.x;
   const double* sb = S + (size_t)b * K;
   double acc[kGemvMaxE];
@@ -416,13 +425,13 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
   // five columns per trip: their (1 + E) x 5 loads are in flight together (one column per trip was latency-bound: 84 us for
   // 13 MB of S and a weight matrix that sits in L2)
   int j = threadIdx.x;
-  for (; j + 4 * kThreads < K; j += 5 * kThreads) {
+  for (; j + 4 * THREADS < K; j += 5 * THREADS) {
     double s[5], w[5][kGemvMaxE];
 #pragma unroll
     for (int u = 0; u < 5; ++u) {
-      s[u] = sb[j + u * kThreads];
+      s[u] = sb[j + u * THREADS];
 #pragma unroll
-      for (int e = 0; e < kGemvMaxE; ++e) w[u][e] = e < E ? Wm[(size_t)e * K + j + u * kThreads] : 0.0;
+      for (int e = 0; e < kGemvMaxE; ++e) w[u][e] = e < E ? Wm[(size_t)e * K + j + u * THREADS] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 5; ++u)
@@ -430,7 +439,7 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
       for (int e = 0; e < kGemvMaxE; ++e)
         if (e < E) acc[e] += s[u] * w[u][e];
   }
-  for (; j < K; j += kThreads) {
+  for (; j < K; j += THREADS) {
     const double s = sb[j];
 #pragma unroll
     for (int e = 0; e < kGemvMaxE; ++e)
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(kThreads) void sums_gemv_kernel(const double* __res
   __syncthreads();
   if (threadIdx.x < E) {
     double v = 0.0;
-    for (int w = 0; w < kThreads / 64; ++w) v += s_red[w][threadIdx.x];
+    for (int w = 0; w < THREADS / 64; ++w) v += s_red[w][threadIdx.x];
     act[(size_t)b * E + threadIdx.x] = (float)(v * scale + shift);
   }
 }
@@ -496,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void cosine_group_activations_kernel(cons
 int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream, int sub) {
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   // nseg counts the pieces: rows (or row groups) x sub
-  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, stream, part, S, B, C,
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kFinThreads), 0, stream, part, S, B, C,
                      k, nseg, sub);
   return launch_status();
 }
@@ -562,7 +571,8 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
   if (B == 0) return EQA_OK;
   if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
   if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(sums_gemv_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  // (1024 threads per image -- one trip instead of five -- was measured: 74 us against 20, the fp64 operand sets spill)
+  hipLaunchKernelGGL(sums_gemv_kernel<kThreads>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
   return launch_status();
 }
 
@@ -645,7 +655,7 @@ static int window_sums_nhwc_impl(const float* x, const float* scale, const float
   hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
                      (float*)workspace, C, H, W, k, nbands, dropout_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
-  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kThreads), 0, st,
+  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kFinThreads), 0, st,
                      (const float*)workspace, out, B, C, k, nseg, 1);
   return launch_status();
 }
