@@ -789,7 +789,7 @@ static int lift_conv_launch(const float* x, const float* wpk, const float* bias,
   static const bool dense_off = [] { const char* e = getenv("EQA_LIFT_DENSE"); return e && e[0] == '0'; }();
   const uint64_t P = (uint64_t)OH * OW;
   const bool dense = !dense_off && KH == 5 && R == 15 && !narrow && OW >= 32 && (31 + KW - 1) * Cin + R <= kLiftRow &&
-                     P * OW < 0x100000000ULL && (size_t)nimg * ((P + 31) / 32) <= 0x7fffffffULL;
+                     P * OW < 0x100000000ULL && P * (uint64_t)Cout < 0x100000000ULL && (size_t)nimg * ((P + 31) / 32) <= 0x7fffffffULL;
   if (dense) {
     if ((stats || rows_only) && (grouped || bias || relu)) return rows_only ? 0 : EQA_ERR_UNSUPPORTED;
     const unsigned tpi = (unsigned)((P + 31) / 32);

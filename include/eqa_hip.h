@@ -316,6 +316,9 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
  * wpk: weights packed (KH*8, 2, Cout):  wpk[(ky*8+q)*2 + h][co] = w[co][ci][ky][kx],  j = (R-8)*h + q, kx = j / Cin,
  * ci = j % Cin, and 0 where h == 1 and q < 16-R  (the two 8-element halves of a filter row overlap; the kernel uses the
  * first of those zero slots to add the bias on the matrix core).
+ * 5 x 5 filters over 3 channels with whole 64-channel slices and output rows of >= 32 pixels run a denser form of the kernel
+ * (38 k-steps instead of 40, tiles over the flattened output map): same packed layout, same results to the rounding of the
+ * summation order.
  */
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream);
