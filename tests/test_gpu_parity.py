@@ -1537,6 +1537,39 @@ def test_graphed_canonicalizer_with_targets_matches_eager(dev):
         step(x, f, [{"boxes": d["boxes"][:1], "masks": d["masks"]} for d in t])
 
 
+def test_lift_conv_dense_forms_agree_on_random_shapes(dev):
+    """The dense form of the lifting convolution (5 x 5 over RGB, 64-channel slices, rows >= 32 pixels: K = 76, tiles over the flattened
+    map) in its three outputs -- channels-last, channel-group-major, training form with running sums -- on random shapes whose tiles
+    cross row ends at every offset: the three hold the same bits, the values match F.conv2d in fp64, the sums match the map."""
+    import random
+
+    import torch.nn.functional as F
+
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    rng = random.Random(5)
+    torch.manual_seed(5)
+    for _ in range(12):
+        B, H, W = rng.randint(1, 9), rng.randint(5, 60), rng.randint(36, 130)
+        Cout = rng.choice([64, 128, 256])
+        x = (torch.randn(B, 3, H, W, device=dev) + 0.2).contiguous(memory_format=torch.channels_last)
+        bank = torch.randn(Cout, 3, 5, 5, device=dev) / 8
+        bias = torch.randn(Cout, device=dev)
+        wpk = ops.pack_lift_weights(bank)
+        y = ops.lift_conv_nhwc(x, wpk, bias, True, 5, 5)
+        want = torch.relu(F.conv2d(x.double(), bank.double(), bias.double()))
+        assert (y.double() - want).abs().max().item() <= 2e-6 * want.abs().max().item(), (B, H, W, Cout)
+        g = fftconv.GroupedMap(ops.lift_conv_grouped(x, wpk, bias, True, 5, 5))
+        assert torch.equal(g.to_channels_last(), y), (B, H, W, Cout)
+        assert ops.lift_conv_stats_supported(x.shape, 5, 5, Cout)
+        y2, part = ops.lift_conv_nhwc_stats(x, wpk, 5, 5)
+        assert torch.equal(y2, ops.lift_conv_nhwc(x, wpk, None, False, 5, 5)), (B, H, W, Cout)
+        exact = y2.permute(0, 2, 3, 1).reshape(-1, Cout).double()
+        truth = torch.stack([exact.sum(0), (exact * exact).sum(0)], dim=1)
+        assert (part.sum(0) - truth).abs().max().item() <= 1e-5 * truth[:, 1].max().item(), (B, H, W, Cout)
+
+
 def test_grouped_activation_layout_between_lift_and_fft(dev):
     """The lifting convolution's channel-group-major output (eqa_lift_conv_grouped) holds exactly the channels-last result, and the
     FFT convolution reads it (eqa_fft48k5_input_grouped) to exactly the same spectra / output -- the layout changes which bytes sit
