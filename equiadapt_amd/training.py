@@ -136,8 +136,10 @@ def wrap_ddp(model: torch.nn.Module, device: Optional[torch.device] = None, buck
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return model   # (`force`: wrap a single process too, to exercise DDP's hooks on one GPU)
     ids = [device.index] if device is not None and device.type == "cuda" else None
+    # gradient_as_bucket_view: the gradients ARE the bucket slices -- no copy into the buckets before each all-reduce (and half
+    # the gradient memory); train_step clears them with set_to_none=True, which DDP re-points at the buckets
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
-                                                     find_unused_parameters=find_unused)
+                                                     find_unused_parameters=find_unused, gradient_as_bucket_view=True)
 
 
 def reduce_metrics(metrics: Dict[str, torch.Tensor]) -> Dict[str, float]:
