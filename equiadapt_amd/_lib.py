@@ -106,7 +106,6 @@ SIGNATURES = {
     "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_input_grouped": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_input_grouped_supported": (_int, [_int]),
-    "eqa_fft48k5_input_grouped_at": (_int, [_vp, _vp, _vp] + [_int] * 5 + [ctypes.c_int64, ctypes.c_int64, _vp]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_stats_rows": (ctypes.c_int64, [_int] * 4),
     "eqa_fft48k5_output_stats": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),

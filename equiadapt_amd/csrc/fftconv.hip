@@ -1303,31 +1303,24 @@ int64_t eqa_fft48k5_workspace_bytes(int nimg, int rows, int cols, int C) {
   return (int64_t)fft_chunk_images(nimg, rows, TX, C) * rows * TX * kFftH * 2 * C * (int64_t)sizeof(float);
 }
 
-// tile0 / M_total (M_total > 0): the images are a slice of a larger batch -- their tiles are rows [tile0, tile0 + M) of a V
-// that holds M_total tiles per frequency (eqa_fft48k5_input_grouped_at; fused kernel only)
 static int fft_forward_impl(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                            int TY, int TX, int win, hipStream_t st, int x_grouped = 0, size_t tile0 = 0, size_t M_total = 0) {
+                            int TY, int TX, int win, hipStream_t st, int x_grouped = 0) {
   const size_t M = (size_t)nimg * TY * TX;
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
-  const bool slice = M_total > 0;
-  if (slice && tile0 + M > M_total) return EQA_ERR_INVALID_ARG;
-  const size_t Mp = slice ? M_total : M;            // tiles per frequency of V
-  V += tile0 * 2 * (size_t)C;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
   if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
     static const bool lds_ok =
         hipFuncSetAttribute((const void*)fft48_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
-      const size_t xb = (size_t)nimg * H * W * C * 4;                                                       // 0 = beyond 32-bit offsets
-      const size_t vb = (size_t)kFftF * fft_pitch(Mp) * 2 * C * 4 - tile0 * 2 * (size_t)C * 4;           // from the slice's first row
+      const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
       // the pipelined form: a plain channel-group-major map, every tile full-width, 32-bit offsets, enough items to keep 256 blocks busy
       const char* pipe_env = getenv("EQA_FFT_FWD_PIPE");      // "1": opt in to the pipelined form (read per call: tests toggle it)
       const bool pipe_off = !(pipe_env != nullptr && pipe_env[0] == '1');
       static const bool pipe_lds_ok =
           hipFuncSetAttribute((const void*)fft48_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
       const bool full_width = W >= kFftN && (W - kFftN) % kFftO == 0 && TX == (W - kFftN) / kFftO + 1;
-      if (!slice && !pipe_off && pipe_lds_ok && x_grouped && !in_bias && !in_relu && full_width && xb <= 0xffffe000ULL && vb <= 0xfffffff0ULL &&
+      if (!pipe_off && pipe_lds_ok && x_grouped && !in_bias && !in_relu && full_width && xb <= 0xffffe000ULL && vb <= 0xfffffff0ULL &&
           nwork >= 2048 && (size_t)nimg * (C / kFusCh) * H <= 0x7fffffffULL) {
         const unsigned nblk = 256;   // one persistent block per CU
         hipLaunchKernelGGL(fft48_fwd_pipe_kernel, dim3(nblk), dim3(kFwdPipeThreads), kFusLds * sizeof(float), st, x, V, H, W, C, TY, TX,
@@ -1335,13 +1328,13 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
         return launch_status();
       }
       hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
-                         W, C, TY, TX, fft_pitch(Mp), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
+                         W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
                          vb <= 0xfffffff0ULL ? (unsigned)vb : 0u, x_grouped);
       return launch_status();
     }
     (void)hipGetLastError();
   }
-  if (x_grouped || slice) return EQA_ERR_UNSUPPORTED;  // only the fused kernel reads the grouped layout / writes a slice
+  if (x_grouped) return EQA_ERR_UNSUPPORTED;  // only the fused kernel reads the grouped layout
   const unsigned cb = (C + kThreads - 1) / kThreads;
   const int chunk = fft_chunk_images(nimg, H, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
@@ -1374,15 +1367,6 @@ int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* i
   if (nimg == 0) return EQA_OK;
   return fft_forward_impl(x, T, V, in_bias, in_relu, nimg, H, W, C, (int)eqa_fft48k5_tiles(H), (int)eqa_fft48k5_tiles(W), kFftN,
                           (hipStream_t)stream, 1);
-}
-
-int eqa_fft48k5_input_grouped_at(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                                 int64_t tile0, int64_t M_total, void* stream) {
-  if (!x || !V || !fft_dims_ok(nimg, H, W, C) || tile0 < 0 || M_total <= 0) return EQA_ERR_INVALID_ARG;
-  if (!eqa_fft48k5_input_grouped_supported(C)) return EQA_ERR_UNSUPPORTED;
-  if (nimg == 0) return EQA_OK;
-  return fft_forward_impl(x, nullptr, V, in_bias, in_relu, nimg, H, W, C, (int)eqa_fft48k5_tiles(H), (int)eqa_fft48k5_tiles(W), kFftN,
-                          (hipStream_t)stream, 1, (size_t)tile0, (size_t)M_total);
 }
 
 int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, void* stream) {

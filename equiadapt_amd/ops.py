@@ -611,11 +611,9 @@ def lift_conv_nhwc_stats(x: torch.Tensor, wpk: torch.Tensor, kh: int, kw: int):
     return y, part
 
 
-def lift_conv_grouped(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def lift_conv_grouped(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int) -> torch.Tensor:
     """`lift_conv_nhwc` with the output in the channel-group-major layout (B, Cout/16, H-kh+1, W-kw+1, 16) that the FFT
-    convolution's input transform reads in whole cache lines (eqa_lift_conv_grouped).  ``out``: a buffer of at least that
-    many elements to write into (a chunked caller re-uses one)."""
+    convolution's input transform reads in whole cache lines (eqa_lift_conv_grouped)."""
     lib = _lib.load()
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
         raise RuntimeError("lift_conv_grouped expects a channels-last fp32 tensor on the device")
@@ -623,13 +621,7 @@ def lift_conv_grouped(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.T
     bias, p_bias = _opt(bias, "bias", torch.float32)
     B, Cin, H, W = x.shape
     Cout = wpk.shape[2]
-    shape = (B, Cout // 16, H - kh + 1, W - kw + 1, 16)
-    if out is None:
-        y = torch.empty(shape, dtype=torch.float32, device=x.device)
-    else:
-        n = B * Cout * (H - kh + 1) * (W - kw + 1)
-        assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and out.numel() >= n
-        y = out.view(-1)[:n].view(shape)
+    y = torch.empty((B, Cout // 16, H - kh + 1, W - kw + 1, 16), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device), _timed("lift_conv"):
         st = lib.eqa_lift_conv_grouped(x.data_ptr(), wpk.data_ptr(), p_bias, int(relu), y.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
     _lib.check(st, "eqa_lift_conv_grouped")

@@ -456,11 +456,6 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
 int eqa_fft48k5_input_grouped_supported(int C);
 int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                               void* stream);
-/* The same for a SLICE of a batch: x holds `nimg` images whose tiles are rows [tile0, tile0 + nimg * tiles(H) * tiles(W)) of a V
- * laid out for M_total tiles per frequency -- the lifting layer and this transform can then walk a large batch in chunks whose
- * activation (escnn_networks.py:60-70: the map between the first two blocks) stays in one re-used, cache-resident buffer. */
-int eqa_fft48k5_input_grouped_at(const float* x, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
-                                 int64_t tile0, int64_t M_total, void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
 /* Training: eqa_fft48k5_output without bias / activation that also leaves the fp64 partial sums of the InnerBatchNorm behind the
