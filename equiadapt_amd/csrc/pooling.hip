@@ -328,8 +328,10 @@ constexpr int kFinThreads = 320;   // k = 5: a block's run is 32 channels x 9 va
 
 // `sub` > 1: every segment arrives in `sub` pieces (one per tile column of the producer), laid out as consecutive segments;
 // the pieces of a border row are added up first (in fp32, as a single producer thread would have).
+template <int KW>   // the window size as a template argument (0: any): the assembly below then unrolls into independent LDS reads
 __global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
-                                                                            int B, int C, int k, int nseg, int sub) {
+                                                                            int B, int C, int k_rt, int nseg, int sub) {
+  const int k = KW ? KW : k_rt;
   __shared__ double s_tot[kFinCh * kFinVals];
   __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
   const int b = blockIdx.y;
@@ -391,19 +393,51 @@ __global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(
   // block's 256 threads idle through ~1100 conditional fp64 adds: 110 of the kernel's 124 us).
   // window (u, v) keeps rows [u, H-nb+u) and columns [v, W-nb+v): it excludes top border rows r < u, bottom border rows
   // r >= u (of the nb bottom rows), left border columns j < v and right border columns j >= v
+  // (Every block reaches this point at about the same time -- the grid is one wave of blocks and the loads above are bandwidth-bound
+  // -- so nothing overlaps the assembly: as a rolled chain of 24 dependent LDS reads + fp64 adds per window it was 16 of the
+  // kernel's 36 us.  With k known the reads of a window are independent instructions; the additions keep their order.)
   const int kk = k * k;
+#ifdef EQA_FIN_NOPHASE2   // experiment: how much of the kernel is the window assembly
+  if (threadIdx.x < nch * kk && s_tot[0] == 12345.0) out[0] = 1.0;
+  if (true) return;
+#endif
   for (int it = threadIdx.x; it < nch * kk; it += blockDim.x) {
     const int cl = it / kk, uv = it - cl * kk;
     const int u = uv / k, v = uv - u * k;
-    auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
-    double a = s_tot[cl * nval];
-    for (int r = 0; r < nb; ++r) a -= r < u ? P(r, 0) : P(nb + r, 0);
-    for (int j = 0; j < nb; ++j) {
-      const int i = j < v ? 1 + j : 1 + nb + j;  // the excluded column of this pair: left border j < v, right border j >= v
-      a -= s_tot[cl * nval + i];
-      for (int r = 0; r < nb; ++r) a += r < u ? P(r, i) : P(nb + r, i);  // excluded rows x excluded columns were subtracted twice
+    if constexpr (KW > 0) {
+      constexpr int NB = KW - 1;
+      float p0[NB], pc[NB][NB];
+      double tc[NB];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) p0[r] = s_brd[r < u ? r : NB + r][cl * nval];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int i = j < v ? 1 + j : 1 + NB + j;
+        tc[j] = s_tot[cl * nval + i];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) pc[j][r] = s_brd[r < u ? r : NB + r][cl * nval + i];
+      }
+      double a = s_tot[cl * nval];
+#pragma unroll
+      for (int r = 0; r < NB; ++r) a -= (double)p0[r];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        a -= tc[j];
+#pragma unroll
+        for (int r = 0; r < NB; ++r) a += (double)pc[j][r];
+      }
+      out[((size_t)b * C + c0) * kk + it] = a;
+    } else {
+      auto P = [&](int s, int i) { return (double)s_brd[s][cl * nval + i]; };
+      double a = s_tot[cl * nval];
+      for (int r = 0; r < nb; ++r) a -= r < u ? P(r, 0) : P(nb + r, 0);
+      for (int j = 0; j < nb; ++j) {
+        const int i = j < v ? 1 + j : 1 + nb + j;  // the excluded column of this pair: left border j < v, right border j >= v
+        a -= s_tot[cl * nval + i];
+        for (int r = 0; r < nb; ++r) a += r < u ? P(r, i) : P(nb + r, i);  // excluded rows x excluded columns were subtracted twice
+      }
+      out[((size_t)b * C + c0) * kk + it] = a;
     }
-    out[((size_t)b * C + c0) * kk + it] = a;
   }
 }
 
@@ -505,8 +539,13 @@ __global__ __launch_bounds__(kThreads) void cosine_group_activations_kernel(cons
 int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, int C, int k, int nseg, hipStream_t stream, int sub) {
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   // nseg counts the pieces: rows (or row groups) x sub
-  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kFinThreads), 0, stream, part, S, B, C,
-                     k, nseg, sub);
+  const dim3 fgrid((C + kFinCh - 1) / kFinCh, B);
+  if (k == 5)
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<5>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
+  else if (k == 3)
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<3>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
+  else
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<0>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
   return launch_status();
 }
 
@@ -655,9 +694,7 @@ static int window_sums_nhwc_impl(const float* x, const float* scale, const float
   hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
                      (float*)workspace, C, H, W, k, nbands, dropout_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
-  hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel, dim3((C + kFinCh - 1) / kFinCh, B), dim3(kFinThreads), 0, st,
-                     (const float*)workspace, out, B, C, k, nseg, 1);
-  return launch_status();
+  return eqa::launch_window_sums_nhwc_finalize((const float*)workspace, out, B, C, k, nseg, st, 1);
 }
 
 }  // extern "C"
