@@ -447,7 +447,7 @@ __global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(
 // One block per image, fixed-order tree reduction (deterministic).  rocBLAS' dgemm takes 0.2 ms for this 256 x 6400 x 8 shape.
 constexpr int kGemvMaxE = 16;
 
-template <int THREADS>
+template <int THREADS, int EMAX, int COLS>   // EMAX >= E; COLS columns per thread and trip
 __global__ __launch_bounds__(THREADS) void sums_gemv_kernel(const double* __restrict__ S, const double* __restrict__ Wm,
                                                             float* __restrict__ act, int K, int E, double scale, double shift) {
   __shared__ double s_red[THREADS / 64][kGemvMaxE];
@@ -456,28 +456,24 @@ __global__ __launch_bounds__(THREADS) void sums_gemv_kernel(const double* __rest
   double acc[kGemvMaxE];
 #pragma unroll
   for (int e = 0; e < kGemvMaxE; ++e) acc[e] = 0.0;
-  // five columns per trip: their (1 + E) x 5 loads are in flight together (one column per trip was latency-bound: 84 us for
-  // 13 MB of S and a weight matrix that sits in L2)
-  int j = threadIdx.x;
-  for (; j + 4 * THREADS < K; j += 5 * THREADS) {
-    double s[5], w[5][kGemvMaxE];
+  // COLS columns per trip: their (1 + E) x COLS loads are in flight together (one column per trip was latency-bound: 84 us for
+  // 13 MB of S and a weight matrix that sits in L2; five per trip with a one-column tail loop: 20 us at K = 6400 = 25 columns
+  // per thread; nine per trip for E <= 8, the tail inside the predicated batch: three trips).  A thread adds its columns in
+  // ascending order whatever the batching: same bits.
+  for (int j = threadIdx.x; j < K; j += COLS * THREADS) {
+    double s[COLS], w[COLS][EMAX];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
-      s[u] = sb[j + u * THREADS];
+    for (int u = 0; u < COLS; ++u) {
+      const bool in = j + u * THREADS < K;
+      s[u] = in ? sb[j + u * THREADS] : 0.0;
 #pragma unroll
-      for (int e = 0; e < kGemvMaxE; ++e) w[u][e] = e < E ? Wm[(size_t)e * K + j + u * THREADS] : 0.0;
+      for (int e = 0; e < EMAX; ++e) w[u][e] = (in && e < E) ? Wm[(size_t)e * K + j + u * THREADS] : 0.0;
     }
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < COLS; ++u)
 #pragma unroll
-      for (int e = 0; e < kGemvMaxE; ++e)
-        if (e < E) acc[e] += s[u] * w[u][e];
-  }
-  for (; j < K; j += THREADS) {
-    const double s = sb[j];
-#pragma unroll
-    for (int e = 0; e < kGemvMaxE; ++e)
-      if (e < E) acc[e] += s * Wm[(size_t)e * K + j];
+      for (int e = 0; e < EMAX; ++e)
+        if (e < E && j + u * THREADS < K) acc[e] += s[u] * w[u][e];
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -611,7 +607,11 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
   if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
   if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
   // (1024 threads per image -- one trip instead of five -- was measured: 74 us against 20, the fp64 operand sets spill)
-  hipLaunchKernelGGL(sums_gemv_kernel<kThreads>, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  if (E <= 8)
+    hipLaunchKernelGGL((sums_gemv_kernel<kThreads, 8, 9>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  else
+    hipLaunchKernelGGL((sums_gemv_kernel<kThreads, kGemvMaxE, 5>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale,
+                       shift);
   return launch_status();
 }
 
