@@ -3,7 +3,7 @@
     determinism (same input twice -> same bits)
   * eqa_plane_gemm: random T, P in {36, 64}, channel counts on the 32-multiples vs the fp64 product
   * eqa_lift_conv_nhwc: random sizes, channel counts on the 16-multiples vs F.conv2d in fp64
-  * eqa_crop_resize_aa: random sizes / crop ratios / output sizes vs the oracle (CenterCrop + antialiased interpolate)
+  * eqa_crop_resize_aa: random sizes / crop ratios / output sizes vs torch on the CPU (centre crop + antialiased interpolate)
   * eqa_group_action_pair vs the two separate launches (bit-equal)"""
 import argparse
 import os
@@ -160,19 +160,21 @@ def main():
             want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
             assert (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-3), ("lift", B, Cin, K, Cout, H, W)
         elif what == "aa":
-            # eqa_crop_resize_aa (narrow filters over aligned rows take the LDS-staged persistent kernel) vs the oracle's
-            # CenterCrop + antialiased F.interpolate
+            # eqa_crop_resize_aa (narrow filters over aligned rows take the LDS-staged persistent kernel) vs torch on the CPU:
+            # centre crop (torchvision's offset rule) + F.interpolate(bilinear, antialias=True), what the reference's transform does
             import math
             from equiadapt_amd.images import geometry
-            from oracle import image_ops as io
+            from equiadapt_amd.images.transforms import resized_output_size
             H, W = rng.randint(12, 260), 4 * rng.randint(3, 65) + rng.choice([0, 0, 0, 1, 2])
             ratio = rng.choice([1.0, 0.9, 0.8, 0.75])
             size = rng.randint(6, 200)
             B = rng.randint(1, 3)
             x = torch.randn(B, 3, H, W)
-            want = io.pre_canonicalization_transform(x, (3, H, W), ratio, size)
             crop = (math.ceil(H * ratio), math.ceil(W * ratio))
-            out_hw = io.tv_resize_output_size(crop, size)
+            out_hw = tuple(resized_output_size(crop, size))
+            top, left = geometry.center_crop_offset(H, crop[0]), geometry.center_crop_offset(W, crop[1])
+            want = F.interpolate(x[:, :, top:top + crop[0], left:left + crop[1]], size=list(out_hw), mode="bilinear", align_corners=False,
+                                 antialias=True)
             tabs = tuple(v.to(dev) if isinstance(v, torch.Tensor) else v for v in geometry.aa_resize_tables((H, W), crop, out_hw))
             got = ops.crop_resize_aa(x.to(dev), tabs, out_hw).cpu()
             assert got.shape == want.shape and (got - want).abs().max().item() <= 3e-6, ("aa", B, H, W, ratio, size)

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from equiadapt_amd import ops
 from equiadapt_amd.images import geometry
-from oracle import image_ops as io
+from equiadapt_amd.images.transforms import resized_output_size
 
 dev = torch.device("cuda")
 for B in (256, 1024):
     H = W = 224
     crop = (math.ceil(H * 0.8), math.ceil(W * 0.8))
-    out_hw = io.tv_resize_output_size(crop, 96)
+    out_hw = tuple(resized_output_size(crop, 96))
     tabs = tuple(v.to(dev) if isinstance(v, torch.Tensor) else v for v in geometry.aa_resize_tables((H, W), crop, out_hw))
     x = torch.randn(B, 3, H, W, device=dev)
     for _ in range(5):
