@@ -378,12 +378,14 @@ __global__ __launch_bounds__(kThreads, EQA_LIFT_OCC) void lift_conv_mfma_kernel(
   pB = lift_pos_next(pA, step, tiles_per_row, (unsigned)OH, 1 < count);
   pC = lift_pos_next(pB, step, tiles_per_row, (unsigned)OH, 2 < count);
 
+  // both layouts as one expression: (image, pixel of the image) x (stride of an image, stride of a pixel) -- a branch on `grouped`
+  // here ends the scheduling region of the tile's MFMAs, and the scalar work in front of it then runs with the matrix pipe drained
+  const unsigned pix_stride = grouped ? 16u : (unsigned)Cout;
+  const size_t img_stride = (size_t)OH * OW * Cout;
   auto out_of = [&](const LiftPos& p, int& cols_left) -> __amdgpu_buffer_rsrc_t {
     const unsigned ox0 = lift_ox0<MASKED>(p, OW);
     cols_left = OW - (int)ox0;
-    if (grouped)
-      return lift_out_rsrc(y, y_numel, (size_t)p.img * ((size_t)OH * OW * Cout) + ((size_t)p.oy * OW + ox0) * 16);
-    return lift_out_rsrc(y, y_numel, (size_t)(p.img * (unsigned)OH + p.oy) * ((unsigned)OW * (unsigned)Cout) + ox0 * (unsigned)Cout);
+    return lift_out_rsrc(y, y_numel, (size_t)p.img * img_stride + (size_t)((p.oy * (unsigned)OW + ox0) * pix_stride));
   };
 
   // Tiles i+2 and i+3 of the stream are on their way from HBM while tile i is in the MFMA pipe (register sets G0 / G1;

@@ -536,12 +536,14 @@ int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, i
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   // nseg counts the pieces: rows (or row groups) x sub
   const dim3 fgrid((C + kFinCh - 1) / kFinCh, B);
+  // a block's run is <= 32 channels x (2k - 1) values: 320 threads take k = 5's 288 in one trip, smaller runs keep 256 (more blocks per CU)
+  const dim3 fblock(std::min(C, kFinCh) * (2 * k - 1) > kThreads ? kFinThreads : kThreads);
   if (k == 5)
-    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<5>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<5>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
   else if (k == 3)
-    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<3>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<3>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
   else
-    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<0>, fgrid, dim3(kFinThreads), 0, stream, part, S, B, C, k, nseg, sub);
+    hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<0>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
   return launch_status();
 }
 
@@ -607,8 +609,15 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
   if (!S || !Wm || !act) return EQA_ERR_INVALID_ARG;
   if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
   // (1024 threads per image -- one trip instead of five -- was measured: 74 us against 20, the fp64 operand sets spill)
-  if (E <= 8)
+  // columns per thread and trip: as many as a thread has, up to nine (a batch wider than the row wastes predicated instructions,
+  // which shows where the grid is many waves of blocks: the CIFAR-shaped batch of 8192 images with K = 800)
+  const int per_thread = (K + kThreads - 1) / kThreads;
+  if (E <= 8 && per_thread > 5)
     hipLaunchKernelGGL((sums_gemv_kernel<kThreads, 8, 9>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  else if (E <= 8 && per_thread > 2)
+    hipLaunchKernelGGL((sums_gemv_kernel<kThreads, 8, 5>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
+  else if (E <= 8)
+    hipLaunchKernelGGL((sums_gemv_kernel<kThreads, 8, 2>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale, shift);
   else
     hipLaunchKernelGGL((sums_gemv_kernel<kThreads, kGemvMaxE, 5>), dim3(B), dim3(kThreads), 0, (hipStream_t)stream, S, Wm, act, K, E, scale,
                        shift);
