@@ -48,10 +48,15 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
+// ALWAYS: the caller knows drop_threshold != 0 -- no (uniform, but scheduling-region-splitting) branch per element
+template <bool ALWAYS = false>
 __device__ __forceinline__ void dropout_keep_quad(size_t i, uint32_t drop_threshold, uint32_t seed, bool (&keep)[4]) {
   const uint32_t base = mix32((uint32_t)i * 0x9E3779B1u + seed) ^ (uint32_t)(i >> 32);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) keep[k] = !drop_threshold || mix32(base + (uint32_t)k * 0x632BE5ABu) >= drop_threshold;
+  for (int k = 0; k < 4; ++k) {
+    const bool kept = mix32(base + (uint32_t)k * 0x632BE5ABu) >= drop_threshold;
+    keep[k] = ALWAYS ? kept : (!drop_threshold || kept);
+  }
 }
 inline uint32_t dropout_threshold(float drop_p) {
   return drop_p > 0.0f ? (uint32_t)std::min<double>((double)drop_p * 4294967296.0, 4294967295.0) : 0u;

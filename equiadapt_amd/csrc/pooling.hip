@@ -222,8 +222,11 @@ __device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands,
 // drop_threshold != 0: act also carries the dropout of a training-mode hidden block (mask = the hash batchnorm.hip uses, on the
 // element's quad index in the (B, H, W, C / 4) map; kept elements x inv_keep) -- the block's output is consumed here without ever
 // being written (eqa_window_sums_nhwc_act).
+// RELU / DROP are template arguments: as run-time flags they were (uniform) branches inside the load-and-activate step, and the
+// wait-count pass then put s_waitcnt vmcnt(0) behind EVERY load -- one load in flight per wave, 2.7-3.0 TB/s (seen in the ISA only).
+template <bool RELU, bool DROP>
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                                           const float* __restrict__ shift, int relu,
+                                                                           const float* __restrict__ shift, int /*relu*/,
                                                                            float* __restrict__ part, int C, int H, int W, int k,
                                                                            int nbands, uint32_t drop_threshold, float inv_keep,
                                                                            uint32_t seed) {
@@ -248,19 +251,25 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
     const int qq = on ? q : Q - 1;
     const float4 sc = scale ? reinterpret_cast<const float4*>(scale)[qq] : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 sh = shift ? reinterpret_cast<const float4*>(shift)[qq] : make_float4(0.f, 0.f, 0.f, 0.f);
-    auto ld = [&](int y, int xc) {
-      const size_t e = ((size_t)y * W + xc) * Q + qq;
-      float4 v = xb[e];
+    // Load and activation are two steps so that a trip can request all its pixels before it touches the first: `raw` issues the
+    // load, `act` makes the value opaque (left alone, the compiler sinks the load of a component under the dropout mask's select:
+    // a dword load inside an exec-masked branch, waited for on the spot) and applies affine map, ReLU and dropout mask.
+    typedef float ws_f4 __attribute__((ext_vector_type(4)));
+    auto raw = [&](int y, int xc) { return reinterpret_cast<const ws_f4*>(xb)[((size_t)y * W + xc) * Q + qq]; };
+    auto act = [&](ws_f4 r, int y, int xc) {
+      asm volatile("" : "+v"(r));
+      float4 v = make_float4(r[0], r[1], r[2], r[3]);
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
-      if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (drop_threshold) {   // uniform
+      if constexpr (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if constexpr (DROP) {
         bool keep[4];
-        dropout_keep_quad((size_t)b * H * W * Q + e, drop_threshold, seed, keep);
+        dropout_keep_quad<true>((size_t)b * H * W * Q + ((size_t)y * W + xc) * Q + qq, drop_threshold, seed, keep);
         v.x = keep[0] ? v.x * inv_keep : 0.f; v.y = keep[1] ? v.y * inv_keep : 0.f;
         v.z = keep[2] ? v.z * inv_keep : 0.f; v.w = keep[3] ? v.w * inv_keep : 0.f;
       }
       return v;
     };
+    auto ld = [&](int y, int xc) { return act(raw(y, xc), y, xc); };
     float4 acc[1 + 2 * kWsMaxBorder];
 #pragma unroll
     for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -272,20 +281,31 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
       // Five rows' loads go out together; the sums are taken row by row in the same order.
       const int xc = wave * P + psub;
       for (; y < y1; y += 5) {   // ~10 rows per band: two trips
-        float4 r[5];
+        ws_f4 rr[5];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) r[u] = (xc < W && y + u < y1) ? ld(y + u, xc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int u = 0; u < 5; ++u) rr[u] = raw(min(y + u, y1 - 1), min(xc, W - 1));
 #pragma unroll
-        for (int u = 0; u < 5; ++u)
-          if (xc < W && y + u < y1) { acc[0].x += r[u].x; acc[0].y += r[u].y; acc[0].z += r[u].z; acc[0].w += r[u].w; }
+        for (int u = 0; u < 5; ++u) {
+          const float4 r = act(rr[u], y + u, xc);
+          if (xc < W && y + u < y1) { acc[0].x += r.x; acc[0].y += r.y; acc[0].z += r.z; acc[0].w += r.w; }
+        }
       }
     }
     for (; y < y1; ++y) {
       // the 4 waves take pixels x = wave, wave+4, ...: each load instruction reads one pixel's channels, contiguous
       float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0;
       int xc = wave * P + psub;
+      for (; xc + 3 * xs < W; xc += 4 * xs) {   // four pixels requested together; the additions in the order of two trips of the loop below
+        const ws_f4 r0 = raw(y, xc), r1 = raw(y, xc + xs), r2 = raw(y, xc + 2 * xs), r3 = raw(y, xc + 3 * xs);
+        const float4 a = act(r0, y, xc), c2 = act(r1, y, xc + xs), a2 = act(r2, y, xc + 2 * xs), c3 = act(r3, y, xc + 3 * xs);
+        t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
+        t1.x += c2.x; t1.y += c2.y; t1.z += c2.z; t1.w += c2.w;
+        t0.x += a2.x; t0.y += a2.y; t0.z += a2.z; t0.w += a2.w;
+        t1.x += c3.x; t1.y += c3.y; t1.z += c3.z; t1.w += c3.w;
+      }
       for (; xc + xs < W; xc += 2 * xs) {
-        const float4 a = ld(y, xc), c2 = ld(y, xc + xs);
+        const ws_f4 r0 = raw(y, xc), r1 = raw(y, xc + xs);
+        const float4 a = act(r0, y, xc), c2 = act(r1, y, xc + xs);
         t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
         t1.x += c2.x; t1.y += c2.y; t1.z += c2.z; t1.w += c2.w;
       }
@@ -715,8 +735,15 @@ static int window_sums_nhwc_impl(const float* x, const float* scale, const float
   hipStream_t st = (hipStream_t)stream;
   const int nbands = ws_nhwc_bands(H, k);
   const int nseg = 2 * (k - 1) + nbands;
-  hipLaunchKernelGGL(window_sums_nhwc_segment_kernel, dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,
-                     (float*)workspace, C, H, W, k, nbands, dropout_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+  const uint32_t thr = dropout_threshold(drop_p);
+#define EQA_WS_SEG(R_, D_)                                                                                                     \
+  hipLaunchKernelGGL((window_sums_nhwc_segment_kernel<R_, D_>), dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,    \
+                     (float*)workspace, C, H, W, k, nbands, thr, 1.0f / (1.0f - drop_p), seed)
+  if (relu && thr) EQA_WS_SEG(true, true);
+  else if (relu) EQA_WS_SEG(true, false);
+  else if (thr) EQA_WS_SEG(false, true);
+  else EQA_WS_SEG(false, false);
+#undef EQA_WS_SEG
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   return eqa::launch_window_sums_nhwc_finalize((const float*)workspace, out, B, C, k, nseg, st, 1);
 }
