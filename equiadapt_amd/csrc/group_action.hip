@@ -470,18 +470,37 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
     const int cs = a.chan_map ? (c / a.G) * a.G + a.chan_map[e * a.G + c % a.G] : c;
     const float* pl = src_img + (unsigned)cs * src_plane;
     const float* go = gout_img + (unsigned)c * dst_plane + (unsigned)(i * a.OW + jb);
+    // (ANGLE without INPUT -- the training step's angle gradient -- requests a channel's 16 neighbours and 4 gradient values
+    // together: the offsets are clamped into the plane, so the loads need no predicate, only the values a select; as conditional
+    // loads behind `if (!live) continue` every one of them was waited for on the spot: 174 us per 256 images)
+    float nbv[4][4], gv[4];
+    if (ANGLE && !INPUT) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        gv[k] = gout_img[(unsigned)c * dst_plane + (live[k] ? (unsigned)(i * a.OW + jb + k) : 0u)];   // (a dead pixel reads the plane's first value)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) nbv[k][t] = pl[off[k][t]];
+      }
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (!live[k]) continue;
-      const float g = go[k];
+      if (!(ANGLE && !INPUT) && !live[k]) continue;
+      const float g = (ANGLE && !INPUT) ? (live[k] ? gv[k] : 0.0f) : go[k];
       const float wx0 = 1.0f - wx1[k], wy0 = 1.0f - wy1[k];
       if (ANGLE) {
-        const float nw = in[k][0] ? pl[off[k][0]] : 0.0f, ne = in[k][1] ? pl[off[k][1]] : 0.0f;
-        const float sw = in[k][2] ? pl[off[k][2]] : 0.0f, se = in[k][3] ? pl[off[k][3]] : 0.0f;
+        float nw, ne, sw, se;
+        if (!INPUT) {
+          nw = in[k][0] ? nbv[k][0] : 0.0f; ne = in[k][1] ? nbv[k][1] : 0.0f;
+          sw = in[k][2] ? nbv[k][2] : 0.0f; se = in[k][3] ? nbv[k][3] : 0.0f;
+        } else {
+          nw = in[k][0] ? pl[off[k][0]] : 0.0f; ne = in[k][1] ? pl[off[k][1]] : 0.0f;
+          sw = in[k][2] ? pl[off[k][2]] : 0.0f; se = in[k][3] ? pl[off[k][3]] : 0.0f;
+        }
         const float dix = wy0 * (ne - nw) + wy1[k] * (se - sw);
         const float diy = wx0 * (sw - nw) + wx1[k] * (se - ne);
-        if (GRAD == 1) sum += g * (dix * armx[k] + diy * army[k]);
-        else { sx[k] += g * dix; sy[k] += g * diy; }
+        // (a dead pixel contributes nothing -- a select, not g = 0: a non-finite neighbour must not turn 0 * inf into NaN)
+        if (GRAD == 1) sum += live[k] ? g * (dix * armx[k] + diy * army[k]) : 0.0f;
+        else { sx[k] += live[k] ? g * dix : 0.0f; sy[k] += live[k] ? g * diy : 0.0f; }
       }
       if (INPUT) {
         float* gp = a.gsrc + img_off + (size_t)cs * src_plane;
