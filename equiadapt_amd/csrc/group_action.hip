@@ -849,7 +849,8 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_kernel(const float* _
 // HBM round trip hides behind the LDS work -- and writes the band.
 
 template <int K, int BAND, int NL>   // K: taps per output index; BAND: output rows per block; NL: 16-byte loads per thread and plane (a template argument: no branch per tap, and the wait counts stay exact)
-__global__ __launch_bounds__(kThreads, 4) void crop_resize_aa_staged_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(kThreads, (NL > 5 && K > 5) ? 2 : 4) void crop_resize_aa_staged_kernel(   // (wide prefetch + many taps: 128 registers spill)
+    const float* __restrict__ x, float* __restrict__ y,
                                                                         const float* __restrict__ wx, const int32_t* __restrict__ x0,
                                                                         const float* __restrict__ wy, const int32_t* __restrict__ y0,
                                                                         int planes, int H, int W, int OH, int OW, int cap_rows,
