@@ -10,7 +10,10 @@ import os as _os
 # MIOpen's one-time algorithm search (first convolution of each shape in a process) also times its *naive reference*
 # solver; for the channels-last 256->256 5x5 layer of the canonicalization network that is 16 runs of 6.7 s (measured,
 # profiles/r01).  Excluding that debug solver keeps the real search (1.6 s) and the same winner.  Overridable.
-_os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+# The same debug solver is timed by the backward-data and weight-gradient searches of a training step (100 ms per trial x 184
+# trials in profiles/r03/rocprofv3_kernel_stats_train_images_leg.md: ~20 s of warm-up per rank).
+for _k in ("FWD", "BWD", "WRW"):
+    _os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
 
 from equiadapt_amd.common.basecanonicalization import (  # noqa: E402,F401
     BaseCanonicalization,
@@ -33,6 +36,14 @@ from equiadapt_amd.images.canonicalization_networks import (  # noqa: F401
     ConvNetwork,
     CustomEquivariantNetwork,
     ESCNNEquivariantNetwork,
+    RotationEquivariantConv,
+    RotationEquivariantConvLift,
+    RotoReflectionEquivariantConv,
+    RotoReflectionEquivariantConvLift,
+    custom_equivariant_networks,
+    custom_group_equivariant_layers,
+    custom_nonequivariant_networks,
+    escnn_networks,
 )
 from equiadapt_amd.images.utils import (  # noqa: F401
     flip_boxes,
@@ -48,6 +59,30 @@ from equiadapt_amd.pointcloud.canonicalization.continuous_group import (  # noqa
     ContinuousGroupPointcloudCanonicalization,
     EquivariantPointcloudCanonicalization,
 )
-from equiadapt_amd.pointcloud.canonicalization_networks import VNSmall  # noqa: F401
+from equiadapt_amd.pointcloud.canonicalization_networks import (  # noqa: F401
+    VNBatchNorm,
+    VNLinearLeakyReLU,
+    VNMaxPool,
+    VNSmall,
+    equivariant_networks,
+    get_graph_feature_cross,
+)
+from equiadapt_amd.common import basecanonicalization  # noqa: E402,F401  (the submodule, as equiadapt/__init__.py:7 re-exports it)
+
+# equiadapt/__init__.py:52-96 (__all__), minus the names SURVEY section 8 puts off the hot path (tests/test_abi_and_host.py lists
+# them with the reason): switching `import equiadapt` to `import equiadapt_amd as equiadapt` keeps every on-path name resolvable.
+__all__ = [
+    "BaseCanonicalization", "ContinuousGroupCanonicalization", "ContinuousGroupImageCanonicalization",
+    "ContinuousGroupPointcloudCanonicalization", "ConvNetwork", "CustomEquivariantNetwork", "DiscreteGroupCanonicalization",
+    "DiscreteGroupImageCanonicalization", "ESCNNEquivariantNetwork", "EquivariantPointcloudCanonicalization",
+    "GroupEquivariantImageCanonicalization", "IdentityCanonicalization", "OptimizedGroupEquivariantImageCanonicalization",
+    "OptimizedSteerableImageCanonicalization", "RotationEquivariantConv", "RotationEquivariantConvLift",
+    "RotoReflectionEquivariantConv", "RotoReflectionEquivariantConvLift", "SteerableImageCanonicalization", "VNBatchNorm",
+    "VNLinearLeakyReLU", "VNMaxPool", "VNSmall", "basecanonicalization", "custom_equivariant_networks",
+    "custom_group_equivariant_layers", "custom_nonequivariant_networks", "equivariant_networks", "escnn_networks",
+    "get_action_on_image_features", "get_graph_feature_cross", "gram_schmidt",
+    # not in the reference's __all__, part of this package's surface
+    "EuclideanGroupNBody", "flip_boxes", "flip_masks", "roll_by_gather", "rotate_boxes", "rotate_masks", "rotate_points",
+]
 
 __version__ = "0.1.0"

@@ -65,10 +65,37 @@ __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
 #define EQA_FORCE_CH 0
 #endif
 
+// Which (image, tile) does this block work on?  Full groups of 8 images: image n = 8 * bz + xcd, tile (blockIdx.x >> 3, blockIdx.y)
+// -- an image per XCD.  The last, ragged group (r = n_out - 8 * bz < 8 images; the whole job when n_out < 8: config 5 runs B = 4)
+// would leave 8 - r XCDs without work that way, so its r * tiles work items are dealt to the 8 XCDs in contiguous runs instead
+// (an XCD still sees neighbouring tiles of one image: the overlapping source windows keep hitting in its L2); the 8 * tiles blocks
+// of the group's grid slice beyond those exit at once.  Same tile, same arithmetic: results are bit-identical either way.
+// The two scalar divisions are paid by the blocks of a ragged group only.
+__device__ __forceinline__ bool block_tile(const int n_out, const int bz, int& n, int& tx, int& ty) {
+  const int xcd = (int)(blockIdx.x & (kXcd - 1));
+  tx = (int)(blockIdx.x >> 3);
+  ty = (int)blockIdx.y;
+  const int first = bz * kXcd, r = n_out - first;
+  if (r >= kXcd) {
+    n = first + xcd;
+    return true;
+  }
+  const int tiles_x = (int)(gridDim.x >> 3), tiles = tiles_x * (int)gridDim.y;
+  const int per = (r * tiles + kXcd - 1) >> 3;
+  const int slot = ty * tiles_x + tx;
+  const int w = xcd * per + slot;
+  if (slot >= per || w >= r * tiles) return false;
+  const int img = w / tiles, t = w - img * tiles;
+  ty = t / tiles_x;
+  tx = t - ty * tiles_x;
+  n = first + img;
+  return true;
+}
+
 // One block = one 32x32 output tile of one output image, all channels, CH channels per LDS stage.
 //   grid = (8 * tiles_x, tiles_y, ceil(n_out / 8)):  blockIdx.x & 7 is the XCD the dispatcher deals the block
 //   to, so each XCD works on whole images (n = 8*z + xcd) and the overlapping source windows of neighbouring
-//   tiles hit in that XCD's private L2.  No integer division anywhere in the kernel.
+//   tiles hit in that XCD's private L2 (block_tile above; a ragged last group is split by tiles instead).
 // Thread t owns 4 consecutive pixels of tile row t/8 (float4 stores, 128 B per 8 lanes).
 // Sampling arithmetic = torch affine_grid + grid_sample(bilinear, zeros, align_corners=True) on the
 // (Hp, Wp) frame, the frame itself being the edge-replicated (pad) and optionally h-flipped source.
@@ -81,9 +108,9 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: row math stays on the SALU
-  const int n = bz * kXcd + (int)(blockIdx.x & (kXcd - 1));
-  if (n >= a.n_out) return;
-  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
+  int n, tile_x, tile_y;
+  if (!block_tile(a.n_out, bz, n, tile_x, tile_y)) return;
+  const int j0 = tile_x * kTile, i0 = tile_y * kTile;
 
   int e, b;
   if (a.gidx) {
@@ -399,9 +426,9 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
   constexpr int NS = GRAD == 2 ? 6 : 1;
   __shared__ float s_red[4][NS];
   const int tid = threadIdx.x;
-  const int n = (int)blockIdx.z * kXcd + (int)(blockIdx.x & (kXcd - 1));
-  if (n >= a.n_out) return;
-  const int j0 = (int)(blockIdx.x >> 3) * kTile, i0 = (int)blockIdx.y * kTile;
+  int n, tile_x, tile_y;
+  if (!block_tile(a.n_out, (int)blockIdx.z, n, tile_x, tile_y)) return;
+  const int j0 = tile_x * kTile, i0 = tile_y * kTile;
   int e, b;
   if (a.gidx) {
     e = a.gidx[n];
@@ -534,7 +561,7 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
     __syncthreads();
     if (tid < NS) {
       const int tiles_x = (int)(gridDim.x >> 3);
-      const size_t t = ((size_t)n * gridDim.y + blockIdx.y) * tiles_x + (blockIdx.x >> 3);
+      const size_t t = ((size_t)n * gridDim.y + tile_y) * tiles_x + tile_x;
       a.partial[t * NS + tid] = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
     }
   }

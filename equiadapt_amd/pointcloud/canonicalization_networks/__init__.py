@@ -9,3 +9,4 @@ from equiadapt_amd.pointcloud.canonicalization_networks.vector_neuron_layers imp
     VNMaxPool,
     mean_pool,
 )
+from equiadapt_amd.pointcloud.canonicalization_networks import equivariant_networks  # noqa: E402,F401

@@ -56,6 +56,79 @@ def test_tiny_and_ragged_shapes(dev, shape):
     assert (got - want).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("B", [1, 4, 7, 9, 12, 17])
+@pytest.mark.parametrize("hw", [(40, 72), (224, 224)])
+def test_ragged_batches_tile_split_across_xcds_is_bit_identical(dev, B, hw):
+    """A last group of fewer than 8 images is dealt to the 8 XCDs tile by tile (group_action.hip: block_tile) instead of image
+    by image.  Every image of a ragged batch must come out bit-identical to the same image inside a batch of full groups
+    (where it is computed image-per-XCD), for every entry point that shares the mapping: canonicalize, invert (regular
+    representation), the pair launch, the orbit, and both backward modes; and B = 4 at 1024 x 1024 (config 5) against the oracle."""
+    import math
+
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    H, W = hw
+    torch.manual_seed(B * 131 + H)
+    full = 24                                             # three full groups
+    xf = torch.randn(full, 3, H, W, device=dev)
+    ff = torch.randn(full, 8, H, W, device=dev)
+    gf = torch.randint(0, 8, (full,), device=dev, dtype=torch.int32)
+    pad = math.ceil(W * 0.5)
+    th, fl = device_tables("canonicalize", 8, False, (H + 2 * pad, W + 2 * pad), dev)
+    thi, fli, cm = device_tables("invert", 8, False, (H, W), dev)
+    y_full = ops.canon_transform(xf, gf, th, fl, pad)
+    i_full = ops.invert_action(ff, gf, thi, fli, cm)
+    x, f, g = xf[:B].contiguous(), ff[:B].contiguous(), gf[:B].contiguous()
+    y = ops.canon_transform(x, g, th, fl, pad)
+    inv = ops.invert_action(f, g, thi, fli, cm)
+    assert torch.equal(y, y_full[:B]) and torch.equal(inv, i_full[:B])
+    yp, ip = ops.group_action_pair(x, f, g, th, fl, pad, thi, fli, cm)
+    assert torch.equal(yp, y) and torch.equal(ip, inv)
+    # orbit: n_out = 4 * B output images, element-major
+    tho, flo = device_tables("canonicalize", 4, False, (H + 2 * pad, W + 2 * pad), dev)
+    if True:
+        sq = x[..., : min(H, W), : min(H, W)].contiguous()
+        sqf = xf[..., : min(H, W), : min(H, W)].contiguous()
+        S = sq.shape[-1]
+        padq = math.ceil(S * 0.5)
+        thq, flq = device_tables("canonicalize", 4, False, (S + 2 * padq, S + 2 * padq), dev)
+        o = ops.orbit_expand(sq, thq, flq, padq).view(4, B, 3, S, S)
+        o_full = ops.orbit_expand(sqf, thq, flq, padq).view(4, full, 3, S, S)
+        assert torch.equal(o, o_full[:, :B])
+    # backward: angle partials and the atomic-free input gradient of the un-padded action
+    go = torch.randn(full, 3, H, W, device=dev)
+    gs_full, ga_full = ops.group_action_bwd(xf, go, gf, thi, fli, None, 0, (0, 0), True, True)
+    gs, ga = ops.group_action_bwd(x, go[:B].contiguous(), g, thi, fli, None, 0, (0, 0), True, True)
+    assert torch.equal(gs, gs_full[:B]) and torch.equal(ga, ga_full[:B])
+    _, gt_full = ops.group_action_bwd(xf, go, gf, th, fl, None, pad, (pad, pad), False, True)
+    _, gt = ops.group_action_bwd(x, go[:B].contiguous(), g, th, fl, None, pad, (pad, pad), False, True)
+    assert torch.equal(gt, gt_full[:B])
+
+
+def test_config5_batch_of_four_at_1024_matches_oracle(dev):
+    """BASELINE configs[4] at its own batch: 4 images of 1024 x 1024 are one ragged group -- every XCD works on half an image."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.images.utils import device_tables
+
+    torch.manual_seed(5)
+    x = torch.randn(4, 3, 1024, 1024)
+    gidx = torch.tensor([1, 6, 3, 4])                      # D4: 90 deg, flip + 180, 270, flip
+    ang = torch.cat([io.group_angles(4), io.group_angles(4)])[gidx]
+    refl = (gidx >= 4).float()
+    th, fl = device_tables("canonicalize", 4, True, (2048, 2048), dev)
+    got = ops.canon_transform(x.to(dev), gidx.to(dev, torch.int32), th, fl, 512).cpu()
+    want = io.canonicalize_images(x, ang, refl, (3, 1024, 1024))
+    # white noise on a 2048-pixel frame: one ulp of a normalised coordinate is 1.2e-4 px, times a pixel difference of up to ~6
+    err = (got - want).abs().max().item()
+    assert err <= 1.5e-3, err
+    thi, fli, _ = device_tables("invert", 4, True, (1024, 1024), dev)
+    got = ops.invert_action(x[:, :1].contiguous().to(dev), gidx.to(dev, torch.int32), thi, fli, None).cpu()
+    want = io.invert_action(x[:, :1], ang, refl, 4, 8, "scalar")
+    err = (got - want).abs().max().item()
+    assert err <= 1e-3, err
+
+
 def test_out_of_range_index_is_clamped_not_a_fault(dev):
     from equiadapt_amd import ops
     from equiadapt_amd.images.utils import device_tables
