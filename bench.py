@@ -54,6 +54,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# MIOpen's find mode also times its naive reference solvers for the backward-data / weight-gradient convolutions of the training
+# legs (100 ms per trial, ~20 s of warm-up per rank); nothing here asks for deterministic algorithms, so they can be left out
+# (equiadapt_amd/__init__.py explains why the package itself only excludes the forward one)
+for _k in ("BWD", "WRW"):
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured-achievable
 MFMA_F32_PEAK_TF = 157.3  # dense fp32-input MFMA (v_mfma_f32_32x32x2_f32), same guide

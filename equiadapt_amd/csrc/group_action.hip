@@ -242,6 +242,35 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   // stage_wait() below is the s_waitcnt.  M0 (compiler-reserved) is saved once before the row loop and restored
   // after it; every statement that reads M0 writes it first (cdna guide 5.7).
   const bool lane_dma = col_ok && col_inside;
+  // Which window pixels does the tile actually sample?  The window is the bounding BOX of the tile's pre-image; for an element
+  // that is not a multiple of 90 degrees the pre-image is a rotated square and fills about half of it (45 degrees: 1250 of the
+  // 47 x 47 = 2209 pixels).  Requesting the rest costs L2 -> LDS traffic and cache-line requests for nothing: the copy model
+  // (tools/micro/pc_tile.hip, profiles/r04/pc_tile.txt) moves 47-wide windows at 4.81 TB/s and the same windows with the lanes
+  // outside the 45-degree diamond switched off at 5.43.  A frame pixel p is a neighbour of some output pixel o of the tile iff o's
+  // sample point lies within one pixel of p; the sampling map is affine, o = M (p - b), so p is wanted iff M (p - b) lies in the
+  // tile's rectangle grown by the pre-image of that unit square (the row L1 norms of M) -- plus a quarter pixel of slack, three
+  // orders of magnitude above the rounding difference between this evaluation and the per-pixel one below.  Per lane (window
+  // column) the two coordinates are affine in the row: two adds and two compares per DMA row.
+  float mask_uj = 0.0f, mask_ui = 0.0f, mask_dj = 0.0f, mask_di = 0.0f, mask_hj = __builtin_inff(), mask_hi = __builtin_inff();
+#ifndef EQA_ABL_NOMASK
+  {
+    const float a00 = a.half_w * t0 * a.step_x, a01 = a.half_w * t1 * a.step_y, b0 = a.half_w * ((t2 - t0 - t1) + 1.0f);
+    const float a10 = a.half_h * t3 * a.step_x, a11 = a.half_h * t4 * a.step_y, b1 = a.half_h * ((t5 - t3 - t4) + 1.0f);
+    const float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) > 1e-12f) {  // (uniform) a singular map keeps every lane
+      const float rdet = 1.0f / det;
+      const float m00 = a11 * rdet, m01 = -a01 * rdet, m10 = -a10 * rdet, m11 = a00 * rdet;
+      const float jfa = (float)frame_x(j0), jfb = (float)frame_x(j1);
+      const float px = (float)col_fx - b0, py = (float)y_lo - b1;
+      mask_uj = (m00 * px + m01 * py) - 0.5f * (jfa + jfb);
+      mask_ui = (m10 * px + m11 * py) - ((float)a.top + 0.5f * (float)(i0 + i1));
+      mask_dj = m01;
+      mask_di = m11;
+      mask_hj = 0.5f * fabsf(jfb - jfa) + fabsf(m00) + fabsf(m01) + 0.25f;
+      mask_hi = 0.5f * (float)(i1 - i0) + fabsf(m10) + fabsf(m11) + 0.25f;
+    }
+  }
+#endif
   const bool any_zero = (x_lo < 0) || (y_lo < 0) || (x_hi > a.Wp - 1) || (y_hi > a.Hp - 1);
   // LDS layout [window row][channel][column]: one M0 write per row serves all CH channels, each DMA adding its
   // channel's row offset through the instruction's immediate (which shifts the global address too, so the plane
@@ -256,11 +285,15 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
       const char* p2 = reinterpret_cast<const char*>(planes[CH > 2 ? 2 : 0]) - 2 * kRowB;
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+      const int y_first = ya + ((wave - ya) & 3);
+      float vj = mask_uj + mask_dj * (float)y_first, vi = mask_ui + mask_di * (float)y_first;
+      const float sj = 4.0f * mask_dj, si = 4.0f * mask_di;
 #pragma unroll 1
-      for (int y = ya + ((wave - ya) & 3); y < EQA_ABL_YB(yb); y += 4) {
+      for (int y = y_first; y < EQA_ABL_YB(yb); y += 4, vj += sj, vi += si) {
         const int fy = y_lo + y;
         const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
         const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * (CH * kLdsStride));
+        if (!(fabsf(vj) <= mask_hj && fabsf(vi) <= mask_hi)) continue;   // this lane's pixel of the row is outside the tile's pre-image
         if (CH == 1) {
           asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]"
                        :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0) : "memory");

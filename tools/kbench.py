@@ -63,6 +63,13 @@ def main():
     print(f"cache-cold ring: canon_transform random {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
     ms = timeit(cold(lambda a, b: ops.invert_action(a, gidx, th_i, fl_i, None)), args.reps)
     print(f"cache-cold ring: invert scalar random   {ms*1e3:8.1f} us  {nbytes/ms/1e6:8.1f} GB/s")
+    for name, g in [("all 0 deg", torch.zeros(B)), ("all 45 deg", torch.ones(B)), ("all 90 deg", torch.full((B,), 2))]:
+        gk = g.to(dev, torch.int32)
+        ms = timeit(cold(lambda a, b: ops.canon_transform(a, gk, th_c, fl_c, S // 2)), args.reps)
+        ms2 = timeit(cold(lambda a, b: ops.invert_action(a, gk, th_i, fl_i, None)), args.reps)
+        print(f"cache-cold ring: {name:10s} canon {ms*1e3:6.1f} us {nbytes/ms/1e6:7.1f} GB/s   invert {ms2*1e3:6.1f} us {nbytes/ms2/1e6:7.1f} GB/s")
+    ms = timeit(cold(lambda a, b: ops.group_action_pair(a, a, gidx, th_c, fl_c, S // 2, th_i, fl_i, None)), args.reps)
+    print(f"cache-cold ring: pair launch random     {ms*1e3:8.1f} us  {2*nbytes/ms/1e6:8.1f} GB/s")
     del xs, ys
     f8 = torch.randn(B, 8, S, S, device=dev)
     ms = timeit(lambda: ops.invert_action(f8, gidx, th_i, fl_i, cm_i), args.reps)

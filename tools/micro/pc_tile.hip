@@ -51,7 +51,7 @@ __device__ __forceinline__ void dma_rows(const float* plane0, int x_lo, int y_lo
   asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
 }
 
-template <int NCH, bool NT>
+template <int NCH, int NT>
 __device__ __forceinline__ void gather_store(const float* lds, int dx, int dy, float* dst_plane0, int ty, int tx, int tid, int WB) {
   const int r = tid >> 3, q = tid & 7;
   const int row0 = min(r + dy, WB - 2);
@@ -64,14 +64,18 @@ __device__ __forceinline__ void gather_store(const float* lds, int dx, int dy, f
       v[k] = lds[idx] * 0.4f + lds[idx + 1] * 0.3f + lds[idx + NCH * LS] * 0.2f + lds[idx + NCH * LS + 1] * 0.1f;
     }
     f32x4* o = reinterpret_cast<f32x4*>(dst_plane0 + (size_t)c * S * S + (size_t)(ty * T + r) * S + tx * T + 4 * q);
-    if (NT) __builtin_nontemporal_store(v, o); else *o = v;
+    if (NT == 1) __builtin_nontemporal_store(v, o);
+    else if (NT == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(v) : "memory");
+    else if (NT == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(o), "v"(v) : "memory");
+    else if (NT == 4) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(o), "v"(v) : "memory");
+    else *o = v;
   }
 }
 
 // base with (MASK) only the lanes of the 45-degree diamond |x - 23| + |y - 23| <= 24 of the 47 x 47 box requesting data (the rotated tile's
 // preimage + its neighbour ring), and / or (CHAIN) the product's dependent start-up loads in front of the DMA: group index of the image
 // -> its row of the element table -> window position
-template <bool MASK, bool CHAIN>
+template <bool MASK, bool CHAIN, int SLEEP = 0>
 __global__ __launch_bounds__(256) void base_tile_v(const float* __restrict__ s, float* __restrict__ d, int B, int WB,
                                                    const int* __restrict__ gidx, const float* __restrict__ theta) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void base_tile_v(const float* __restrict__ s, 
   if (n >= B) return;
   const int tx = blockIdx.x >> 3, ty = blockIdx.y;
   int x_lo = min(max(tx * T - (WB - 33) / 2, 0), S - WB), y_lo = min(max(ty * T - (WB - 33) / 2, 0), S - WB);
+  if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);   // a prologue of SLEEP x 64 cycles in front of the DMA issue
   if (CHAIN) {
     const int e = gidx[n];
     const float* th = theta + e * 6;
@@ -114,7 +119,42 @@ __global__ __launch_bounds__(256) void base_tile_v(const float* __restrict__ s, 
   gather_store<3, false>(smem, tx * T - x_lo, ty * T - y_lo, d + (size_t)n * C * S * S, ty, tx, threadIdx.x, WB);
 }
 
-template <bool NT>
+template <int NT, int LDF>   // LDF: DMA flavour 1 nt, 2 sc1, 3 sc0 sc1
+__global__ __launch_bounds__(256) void base_tile_ld(const float* __restrict__ s, float* __restrict__ d, int B, int WB) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int n = blockIdx.z * 8 + (blockIdx.x & 7);
+  if (n >= B) return;
+  const int tx = blockIdx.x >> 3, ty = blockIdx.y;
+  const int x_lo = min(max(tx * T - (WB - 33) / 2, 0), S - WB), y_lo = min(max(ty * T - (WB - 33) / 2, 0), S - WB);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  {
+    const unsigned col = (unsigned)(x_lo + min(lane, WB - 1)) * 4u;
+    const float* plane0 = s + (size_t)n * C * S * S;
+    const char* p0 = reinterpret_cast<const char*>(plane0);
+    const char* p1 = reinterpret_cast<const char*>(plane0 + S * S) - LS * 4;
+    const char* p2 = reinterpret_cast<const char*>(plane0 + 2 * S * S) - 2 * LS * 4;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+    if (lane < LS) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        const int y = min(wave + k * 4, WB - 1);
+        const unsigned voff = (unsigned)((y_lo + y) * S) * 4u + col;
+        const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(smem + y * (3 * LS));
+#define DMA3(FL) asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]" FL "\n\tglobal_load_lds_dword %[v], %[p1] offset:%[o1]" FL "\n\t" \
+                       "global_load_lds_dword %[v], %[p2] offset:%[o2]" FL ::[v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0), [p1] "s"(p1), [p2] "s"(p2), \
+                       [o1] "i"(LS * 4), [o2] "i"(2 * LS * 4) : "memory")
+        if (LDF == 1) DMA3(" nt"); else if (LDF == 2) DMA3(" sc1"); else DMA3(" sc0 sc1");
+      }
+    }
+    asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  gather_store<3, NT>(smem, tx * T - x_lo, ty * T - y_lo, d + (size_t)n * C * S * S, ty, tx, threadIdx.x, WB);
+}
+
+template <int NT>
 __global__ __launch_bounds__(256) void base_tile(const float* __restrict__ s, float* __restrict__ d, int B, int WB) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = blockIdx.z * 8 + (blockIdx.x & 7);
@@ -301,13 +341,51 @@ int main(int argc, char** argv) {
     free(h);
   }
   g_s = s; g_d = d; g_ref = ref;
+  if (argc > 2 && argv[2][0] == 'r') {
+    // ring of 4 buffer pairs of B images (beyond the 256 MB Infinity Cache when B = 256), one launch per pair, cycled: what a launch
+    // of the product costs inside the real step, including whatever the kernel boundary costs (end-of-kernel write-back of the
+    // dirty L2 lines, ramp, tail)
+    float *rs[4], *rd[4];
+    for (int i = 0; i < 4; ++i) { (void)hipMalloc(&rs[i], bytes); (void)hipMalloc(&rd[i], bytes); (void)hipMemcpy(rs[i], s, bytes, hipMemcpyDeviceToDevice); }
+    const dim3 grid(8 * 7, 7, g_B / 8);
+    const size_t lds3 = (size_t)3 * kPlaneLds * 4;
+    for (int WB : {33, 47}) {
+      int it = 0;
+#define RING(NTV, what) { const float us = time_us([&] { it = (it + 1) & 3; base_tile<NTV><<<grid, 256, lds3>>>(rs[it], rd[it], g_B, WB); }, 40); if (check(what)) report(what, WB, us); }
+      RING(0, "ring: base, plain stores");
+      RING(1, "ring: base, nt stores");
+      RING(2, "ring: base, sc1 stores (write-through)");
+      RING(3, "ring: base, sc0 sc1 stores");
+      RING(4, "ring: base, sc1 nt stores");
+      RING(0, "ring: base, plain stores (again)");
+#define RINGL(NTV, LDF, what) { const float us = time_us([&] { it = (it + 1) & 3; base_tile_ld<NTV, LDF><<<grid, 256, lds3>>>(rs[it], rd[it], g_B, WB); }, 40); if (check(what)) report(what, WB, us); }
+      RINGL(0, 1, "ring: base, nt DMA loads, plain stores");
+      RINGL(1, 1, "ring: base, nt DMA loads, nt stores");
+      RINGL(4, 1, "ring: base, nt DMA loads, sc1 nt stores");
+      RINGL(0, 2, "ring: base, sc1 DMA loads, plain stores");
+      RINGL(0, 3, "ring: base, sc0 sc1 DMA loads, plain stores");
+      RING(0, "ring: base, plain stores (third)");
+      {
+        static int* gi = nullptr; static float* th = nullptr;
+        if (!gi) { (void)hipMalloc(&gi, g_B * 4); (void)hipMalloc(&th, 64 * 4); (void)hipMemset(gi, 0, g_B * 4); (void)hipMemset(th, 0, 64 * 4); }
+#define RINGS(SL, what) { const float us = time_us([&] { it = (it + 1) & 3; base_tile_v<false, true, SL><<<grid, 256, lds3>>>(rs[it], rd[it], g_B, WB, gi, th); }, 40); if (check(what)) report(what, WB, us); }
+        RINGS(0, "ring: base + chain, no sleep");
+        RINGS(4, "ring: base + chain + 256-cycle prologue");
+        RINGS(8, "ring: base + chain + 512-cycle prologue");
+        RINGS(16, "ring: base + chain + 1024-cycle prologue");
+        RINGS(32, "ring: base + chain + 2048-cycle prologue");
+        RINGS(64, "ring: base + chain + 4096-cycle prologue");
+      }
+    }
+    return 0;
+  }
   for (int WB : {33, 47}) {
     const dim3 grid(8 * 7, 7, g_B / 8);
     const size_t lds3 = (size_t)3 * kPlaneLds * 4;
-    float us = time_us([&] { base_tile<false><<<grid, 256, lds3>>>(s, d, g_B, WB); });
+    float us = time_us([&] { base_tile<0><<<grid, 256, lds3>>>(s, d, g_B, WB); });
     if (check("base")) report("base: block per tile, 3 planes, stage-barrier-gather-store", WB, us);
     (void)hipMemcpy(ref, d, (size_t)64 * C * S * S * 4, hipMemcpyDeviceToDevice);
-    us = time_us([&] { base_tile<true><<<grid, 256, lds3>>>(s, d, g_B, WB); });
+    us = time_us([&] { base_tile<1><<<grid, 256, lds3>>>(s, d, g_B, WB); });
     if (check("base nt")) report("base, nt store", WB, us);
     {
       static int* gi = nullptr; static float* th = nullptr;
