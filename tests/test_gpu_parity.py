@@ -22,7 +22,22 @@ pytestmark = pytest.mark.gpu
 from oracle import image_ops as io  # noqa: E402
 from oracle import pointcloud_ops as po  # noqa: E402
 
-PIX_MAX, PIX_RMS, SMOOTH_MAX = 1e-3, 1e-4, 5e-5
+# Pixel tolerances on unit-variance white noise: 2 x the error measured at the headline's 448-pixel frame (1.4e-4 max / 1.2e-5 rms,
+# profiles/r03/bench_n1.json self_check; the fp32 reference itself is 4e-4 / 4e-5 away from exact arithmetic there -- one ulp of a
+# normalised coordinate is 3e-5 px, times a white-noise gradient).  The error grows with the frame (ulp of the coordinate x frame
+# size): tests on larger frames scale the bound by frame / 448 (`_pix_tol`).  BASELINE.md's "1e-5 abs" is met on smooth images
+# (SMOOTH_MAX); on white noise no fp32 implementation, the reference included, is that close to another one.
+PIX_MAX, PIX_RMS, SMOOTH_MAX = 2.8e-4, 2.4e-5, 5e-5
+
+
+# Distance to EXACT arithmetic (rot90, fp64 resampling) rather than to the oracle: the fp32 reference itself is 4e-4 away from it on
+# white noise at a 448-pixel frame, and the product may be 1.5 x as far (the rule test_canonicalize_headline_shape_error_budget enforces)
+EXACT_MAX = 6e-4
+
+
+def _pix_tol(frame: int):
+    k = max(1.0, frame / 448.0)
+    return PIX_MAX * k, PIX_RMS * k
 
 
 @pytest.fixture(scope="module")
@@ -204,7 +219,7 @@ def test_c4_is_rot90_and_identity_element(dev):
         y = ops.canon_transform(x, gidx, theta, flags, 112)
         # canonicalize rotates by -angle: element k undoes a +k*90 deg rotation == rot90(k=-k)
         # white noise: the reference's own cos(90 deg) = -4.4e-8 and grid rounding move samples by ~3e-5 px
-        assert (y - torch.rot90(x, -k, (-2, -1))).abs().max().item() <= PIX_MAX
+        assert (y - torch.rot90(x, -k, (-2, -1))).abs().max().item() <= EXACT_MAX
     # invert(canonicalize(x)) == x on the inscribed disc (C8, scalar features)
     th_c, fl_c = device_tables("canonicalize", 8, False, (448, 448), dev)
     th_i, fl_i, _ = device_tables("invert", 8, False, (224, 224), dev)
@@ -1284,6 +1299,125 @@ def test_bench_configuration_full_width_against_oracle(dev, group_type, N):
     assert chk["invert_max_err"] <= PIX_MAX and chk["invert_rms_err"] <= PIX_RMS, chk
     # the random-init bench network separates the orientations of white noise only weakly: the check above must not be vacuous
     assert chk["n_clear_margin"] >= 4, chk
+
+
+def test_headline_whole_batch_of_256_against_oracle(dev):
+    """BASELINE configs[1] at its own batch: the 256 images bench.py times (same seeds, same canonicalizer), every one of them
+    through the CPU oracle -- activations, group index (100 % above the tie margin; the tie rate itself is bounded so the check
+    cannot go vacuous), canonicalized and inverted pixels max + RMS.  This is bench.py's ``self_check`` as a test."""
+    import bench
+
+    can = bench.build_canonicalizer(dev)
+    B = 256
+    x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(0))
+    f = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(1000))
+    with torch.no_grad():
+        y = can(x.to(dev))
+        acts = can.canonicalization_info_dict["group_activations"].cpu()
+        gidx = can.canonicalization_info_dict["group_index"].cpu().long()
+        inv = can.invert_canonicalization(f.to(dev), induced_rep_type="scalar")
+    chk = bench.oracle_check(can, x, f, y, inv, acts, gidx)
+    assert chk["images"] == 256
+    assert chk["acts_max_err"] <= 2e-5 * chk["acts_scale"], chk
+    assert chk["index_match"] == 1.0, chk
+    assert chk["tie_rate"] <= 0.25 and chk["n_clear_margin"] >= 192, chk
+    assert chk["canonicalize_max_err"] <= PIX_MAX and chk["canonicalize_rms_err"] <= PIX_RMS, chk
+    assert chk["invert_max_err"] <= PIX_MAX and chk["invert_rms_err"] <= PIX_RMS, chk
+    # (the randomly initialised network prefers the right-angle elements on white noise -- its 45-degree banks are bilinear
+    # re-samplings of the filters and respond more weakly; the 45-degree pixels are covered by test_canonicalize_headline_shape_error_budget)
+    assert len(set(gidx.tolist())) >= 3, sorted(set(gidx.tolist()))
+
+
+def _c4_regular_dense_layers(fields: int, k: int, layers: int, gen: torch.Generator):
+    """A C4 regular-representation G-CNN in the EXPORTED dense form (what e2cnn's ``R2Conv.export()`` / ``InnerBatchNorm.export()``
+    hand over: plain Conv2d over fields x |G| channels, channel index = field * 4 + element; plain BatchNorm2d with every
+    per-field quantity repeated 4 times), built here from the group's regular representation with exact quarter turns --
+    independently of the product's filter-bank code:
+        lifting   W[(o, r), c]      = rot90^r( w[o, c] )
+        regular   W[(o, r), (i, s)] = rot90^r( w[o, i, (s - r) mod 4] )
+    so that rotating the input by a quarter turn rotates every output plane and shifts the element axis by one."""
+    import torch.nn as nn
+
+    convs, norms = [], []
+    cin = 3
+    for layer in range(layers):
+        if layer == 0:
+            w = torch.randn(fields, 3, k, k, generator=gen) * (1.0 / (3 * k * k)) ** 0.5
+            W = torch.stack([torch.rot90(w, r, (-2, -1)) for r in range(4)], dim=1).reshape(fields * 4, 3, k, k)
+        else:
+            w = torch.randn(fields, fields, 4, k, k, generator=gen) * (1.0 / (fields * 4 * k * k)) ** 0.5
+            W = torch.empty(fields, 4, fields, 4, k, k)
+            for r in range(4):
+                for s_ in range(4):
+                    W[:, r, :, s_] = torch.rot90(w[:, :, (s_ - r) % 4], r, (-2, -1))
+            W = W.reshape(fields * 4, fields * 4, k, k)
+        cv = nn.Conv2d(cin, fields * 4, k, bias=True)
+        with torch.no_grad():
+            cv.weight.copy_(W)
+            cv.bias.copy_((torch.randn(fields, generator=gen) * 0.1).repeat_interleave(4))
+        convs.append(cv)
+        cin = fields * 4
+        if layer < layers - 1:
+            bn = nn.BatchNorm2d(fields * 4)
+            with torch.no_grad():
+                bn.weight.copy_((torch.rand(fields, generator=gen) + 0.5).repeat_interleave(4))
+                bn.bias.copy_((torch.randn(fields, generator=gen) * 0.2).repeat_interleave(4))
+                bn.running_mean.copy_((torch.randn(fields, generator=gen) * 0.2).repeat_interleave(4))
+                bn.running_var.copy_((torch.rand(fields, generator=gen) + 0.5).repeat_interleave(4))
+            norms.append(bn.eval())
+    return convs, norms
+
+
+@pytest.mark.parametrize("fields,size", [(16, 96), (8, 60)])
+def test_load_exported_dense_with_an_independently_built_regular_bank(dev, fields, size):
+    """The bridge for e2cnn-trained weights (reference network: escnn_networks.py:48-91) fed with weights it did NOT export
+    itself: a dense C4 regular-representation network built in this test from exact quarter turns + cyclic channel shifts.
+    (1) the dense network is what it claims to be -- rotating the input by 90 degrees shifts its pooled activations by one
+    element (plain torch, fp64); (2) the product loaded with those layers reproduces the plain-torch fp64 evaluation through
+    its inference fast path (FFT / Winograd convolution, MFMA lifting layer, linearised last layer) and through its module
+    path; (3) a canonicalizer built on it picks the element the dense network's own argmax picks."""
+    import copy
+
+    import equiadapt_amd as ea
+
+    gen = torch.Generator().manual_seed(1234 + fields)
+    k, layers, G = 5, 3, 4
+    convs, norms = _c4_regular_dense_layers(fields, k, layers, gen)
+
+    def dense_forward(x64):
+        h = x64
+        for i, cv in enumerate(convs):
+            h = torch.nn.functional.conv2d(h, cv.weight.double(), cv.bias.double())
+            if i < len(norms):
+                bn = norms[i]
+                h = (h - bn.running_mean.double()[None, :, None, None]) / torch.sqrt(bn.running_var.double()[None, :, None, None] + bn.eps)
+                h = torch.relu(h * bn.weight.double()[None, :, None, None] + bn.bias.double()[None, :, None, None])
+        return h.reshape(h.shape[0], fields, G, h.shape[-2], h.shape[-1]).mean(dim=(1, 3, 4))
+
+    x = torch.randn(9, 3, size, size, generator=gen)
+    with torch.no_grad():
+        want = dense_forward(x.double())
+        turned = dense_forward(torch.rot90(x, 1, (-2, -1)).double())
+    assert (turned - torch.roll(want, 1, dims=1)).abs().max().item() <= 1e-12 * want.abs().max().item() + 1e-13, \
+        "the test's own dense bank is not C4-equivariant"
+    net = ea.ESCNNEquivariantNetwork((3, size, size), fields, k, "rotation", 4, layers).to(dev).eval()
+    net.load_exported_dense([copy.deepcopy(c).to(dev) for c in convs], [copy.deepcopy(n).to(dev).eval() for n in norms])
+    with torch.no_grad():
+        fast = net(x.to(dev)).cpu().double()
+    with torch.enable_grad():
+        mod = net(x.to(dev)).detach().cpu().double()
+    scale = want.abs().max().item()
+    assert (fast - want).abs().max().item() <= 2e-5 * scale, ((fast - want).abs().max().item(), scale)
+    assert (mod - want).abs().max().item() <= 2e-5 * scale
+    top2 = want.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4 * scale
+    assert int(clear.sum()) >= 5
+    assert torch.equal(fast.argmax(-1)[clear], want.argmax(-1)[clear])
+    hp = types.SimpleNamespace(beta=1.0, input_crop_ratio=1.0, resize_shape=size)
+    can = ea.GroupEquivariantImageCanonicalization(net, hp, (3, size, size)).to(dev).eval()
+    with torch.no_grad():
+        can(x.to(dev))
+    assert torch.equal(can.canonicalization_info_dict["group_index"].cpu().long()[clear], want.argmax(-1)[clear])
 
 
 @pytest.mark.parametrize("group_type,N", [("rotation", 8), ("roto-reflection", 4)])
