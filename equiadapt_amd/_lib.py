@@ -144,6 +144,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     import hashlib
     from concurrent.futures import ThreadPoolExecutor
 
+    if extra_flags and not out:
+        raise ValueError("a variant build (extra_flags) needs its own `out`: it must not replace the product library")
     out = out or SO_PATH
     hdr_time = max(os.path.getmtime(p) for p in HEADERS + [os.path.join(INCLUDE, "eqa_hip.h")])
     newest_src = max(hdr_time, max(os.path.getmtime(p) for p in SOURCES))
@@ -162,11 +164,19 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
         obj = os.path.join(objdir, f"{os.path.splitext(os.path.basename(src))[0]}.{tag}.o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(hdr_time, os.path.getmtime(src)):
             return obj, None
-        cmd = [hipcc, *flags, "-c", src, "-o", obj]
+        # compile to a private name and rename: several processes building the same stale tree (torchrun ranks, pytest-xdist) never
+        # see a half-written object, and an interrupted compile leaves no truncated file that passes the freshness check
+        tmp_obj = f"{obj}.tmp{os.getpid()}"
+        cmd = [hipcc, *flags, "-c", src, "-o", tmp_obj]
         if verbose:
             print(" ".join(cmd))
         res = subprocess.run(cmd, capture_output=True, text=True)
-        return obj, (None if res.returncode == 0 else f"{' '.join(cmd)}\n{res.stdout}\n{res.stderr}")
+        if res.returncode != 0:
+            if os.path.exists(tmp_obj):
+                os.remove(tmp_obj)
+            return obj, f"{' '.join(cmd)}\n{res.stdout}\n{res.stderr}"
+        os.replace(tmp_obj, obj)
+        return obj, None
 
     with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as pool:
         results = list(pool.map(compile_one, SOURCES))

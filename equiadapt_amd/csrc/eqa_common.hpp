@@ -5,7 +5,10 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <type_traits>
+#include <utility>
 
 #include "eqa_hip.h"
 
@@ -63,6 +66,24 @@ inline uint32_t dropout_threshold(float drop_p) {
 }
 
 inline int launch_status() { return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH; }
+
+// Kernels that need more dynamic LDS than a launch's default 64 KB: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the
+// CURRENT device only, so the answer is cached per (kernel, device ordinal) -- a function-local `static const bool` would set it on
+// the device of the first call and leave every other GPU of the process with launch failures.
+inline bool allow_dynamic_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, bool> seen;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lock(mu);
+  const auto key = std::make_pair(kernel, dev);
+  const auto it = seen.find(key);
+  if (it != seen.end()) return it->second;
+  const bool ok = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  seen[key] = ok;
+  return ok;
+}
 
 // pooling.hip: part (B, nseg, C, 1 + 2(k-1)) row segments -> S (B, C, k, k) fp64; used by eqa_window_sums_nhwc and by the
 // Winograd output transform fused with the window sums

@@ -1213,8 +1213,7 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   if (pipe_on && kInvCh == 16 && C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass &&
       (size_t)kFftF * fft_pitch(M) * C * 8 <= 0xffffff00ULL && (NB == 0 || 2 * NB + (kPipeCons / 64) * TY <= OH)) {
     constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
-    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_pipe_kernel<NB, kInvCh>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    const bool lds_ok = allow_dynamic_lds((const void*)fft48_inv_pipe_kernel<NB, kInvCh>, lds_bytes);
     static const int n_cu = []() { int n = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kInvCh));
@@ -1222,9 +1221,7 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
       const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
       if constexpr (NB == 0) {
         if (stats || stats_rows) {
-          static const bool lds_ok_s = hipFuncSetAttribute((const void*)fft48_inv_pipe_kernel<0, kInvCh, true>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-          if (!lds_ok_s) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }
+          if (!allow_dynamic_lds((const void*)fft48_inv_pipe_kernel<0, kInvCh, true>, lds_bytes)) return EQA_ERR_UNSUPPORTED;
           if (stats_rows) { *stats_rows = (int64_t)M * (kPipeCons / 64); return EQA_OK; }
           hipLaunchKernelGGL((fft48_inv_pipe_kernel<0, kInvCh, true>), dim3(blocks), dim3(kPipeThreads), lds_bytes, st, Mo, bias, relu, out,
                              OH, OW, C, TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u, stats);
@@ -1242,8 +1239,7 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   if (stats || stats_rows) return EQA_ERR_UNSUPPORTED;
   if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass) {
     constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
-    static const bool lds_ok = hipFuncSetAttribute((const void*)fft48_inv_fused_kernel<NB, kInvCh>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+    const bool lds_ok = allow_dynamic_lds((const void*)fft48_inv_fused_kernel<NB, kInvCh>, lds_bytes);
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kInvCh));
       const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;      // bytes of Mo; 0 to the kernel = beyond 32-bit offsets
@@ -1331,16 +1327,14 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
   if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
-    static const bool lds_ok =
-        hipFuncSetAttribute((const void*)fft48_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
+    const bool lds_ok = allow_dynamic_lds((const void*)fft48_fwd_fused_kernel, kFusLds * 4);
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
       const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
       // the pipelined form: a plain channel-group-major map, every tile full-width, 32-bit offsets, enough items to keep 256 blocks busy
       const char* pipe_env = getenv("EQA_FFT_FWD_PIPE");      // "1": opt in to the pipelined form (read per call: tests toggle it)
       const bool pipe_off = !(pipe_env != nullptr && pipe_env[0] == '1');
-      static const bool pipe_lds_ok =
-          hipFuncSetAttribute((const void*)fft48_fwd_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFusLds * 4) == hipSuccess;
+      const bool pipe_lds_ok = allow_dynamic_lds((const void*)fft48_fwd_pipe_kernel, kFusLds * 4);
       const bool full_width = W >= kFftN && (W - kFftN) % kFftO == 0 && TX == (W - kFftN) / kFftO + 1;
       if (!pipe_off && pipe_lds_ok && x_grouped && !in_bias && !in_relu && full_width && xb <= 0xffffe000ULL && vb <= 0xfffffff0ULL &&
           nwork >= 2048 && (size_t)nimg * (C / kFusCh) * H <= 0x7fffffffULL) {

@@ -597,12 +597,15 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
   // one thread per point: fewer, longer instruction streams.  Mean pooling: the quad kernel is ahead at every batch size (B = 64:
   // 137 vs 250 us, B = 2048: 3.11 vs 3.21 ms); max pooling (two waves per SIMD either way): ahead only once the batch alone fills
   // the chip (B = 2048: 5.2 vs 6.0 ms; B = 256: 0.91 vs 0.84)
-  const bool single = k == kVnK && (g_vn_kernel_choice == 1 ||
-                                    (g_vn_kernel_choice == 0 && pooling == 1 && (long long)B * N >= EQA_VN_SINGLE_MIN_POINTS));
+  // (its LDS -- 16 B per point + the 12 KB queue -- must fit the default 64 KB of a launch: clouds beyond 3,328 points always take
+  // the quad kernel, whatever the batch; only the FORCED choice reports them as unsupported)
+  const size_t lds_single = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
+  if (g_vn_kernel_choice == 1 && k == kVnK && lds_single > 64 * 1024) return EQA_ERR_UNSUPPORTED;
+  const bool single = k == kVnK && lds_single <= 64 * 1024 &&
+                      (g_vn_kernel_choice == 1 || (g_vn_kernel_choice == 0 && pooling == 1 && (long long)B * N >= EQA_VN_SINGLE_MIN_POINTS));
   int nblk;
   if (single) {
-    const size_t lds = (size_t)4 * ((N + 3) & ~3) * sizeof(float) + (size_t)kVnThreads * kVnQueue * sizeof(float2);
-    if (lds > 64 * 1024) return EQA_ERR_UNSUPPORTED;   // (the default dynamic-LDS limit of a launch; larger clouds: the quad kernel)
+    const size_t lds = lds_single;
     nblk = (N + kVnThreads - 1) / kVnThreads;
     if (pooling == 1)
       hipLaunchKernelGGL(vnsmall_fwd_kernel<true>, dim3(nblk, B), dim3(kVnThreads), lds, st, x, params, (float*)workspace, N, nblk);
@@ -617,9 +620,8 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
     // clouds beyond ~2,500 points need more dynamic LDS than the default 64 KB limit of a launch
 #define EQA_VN_QUAD_LAUNCH(SEG_, MAX_)                                                                                              \
   do {                                                                                                                             \
-    static const bool big_ok = hipFuncSetAttribute((const void*)vnsmall_fwd_quad_kernel<SEG_, MAX_>,                               \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;           \
-    if (lds > 64 * 1024 && !big_ok) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }                                        \
+    if (lds > 64 * 1024 && !allow_dynamic_lds((const void*)vnsmall_fwd_quad_kernel<SEG_, MAX_>, 128 * 1024))                       \
+      return EQA_ERR_UNSUPPORTED;                                                                                                  \
     hipLaunchKernelGGL((vnsmall_fwd_quad_kernel<SEG_, MAX_>), grid, blk, lds, st, x, params, ws, N, k, nblk);                       \
   } while (0)
     if (k <= 20) {

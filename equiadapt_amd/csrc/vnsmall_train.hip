@@ -303,9 +303,8 @@ int eqa_vn_knn(const float* x, int32_t* idx, int B, int N, int k, void* stream) 
   const int rc = vn_check(x, idx, B, N, k, lds, true);
   if (rc != 1) return rc;
   const dim3 grid(vn_knn_blocks(N), B);
-  static const bool big5 = hipFuncSetAttribute((const void*)vn_knn_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-  static const bool big8 = hipFuncSetAttribute((const void*)vn_knn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess;
-  if (lds > 64 * 1024 && !(k <= 20 ? big5 : big8)) { (void)hipGetLastError(); return EQA_ERR_UNSUPPORTED; }
+  if (lds > 64 * 1024 && !allow_dynamic_lds(k <= 20 ? (const void*)vn_knn_kernel<5> : (const void*)vn_knn_kernel<8>, 128 * 1024))
+    return EQA_ERR_UNSUPPORTED;
   if (k <= 20)
     hipLaunchKernelGGL(vn_knn_kernel<5>, grid, dim3(kVnQThreads), lds, (hipStream_t)stream, x, idx, N, k);
   else

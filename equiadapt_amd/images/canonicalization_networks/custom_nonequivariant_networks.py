@@ -95,7 +95,7 @@ class ConvNetwork(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training and not torch.is_grad_enabled() and x.is_cuda:
             if x.dtype == torch.float32 and os.environ.get("EQA_CONVNET_MFMA", "1") != "0":
-                plan = self._mfma_plan(x)
+                plan = self._mfma_plan(x) if x.shape[0] > 0 else None     # (an empty batch takes the folded conv2d path below)
                 if plan is not None and (x.shape[0] <= plan[4] or plan[5]) and plan[4] >= 1:
                     # inference: every convolution (+ folded batch-norm + GELU) on the fp32 matrix cores, channels-last from the
                     # first layer on; head = BatchNorm1d + ReLU in one pass + the Linear layer, re-indexed to that layout.

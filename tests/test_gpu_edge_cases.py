@@ -382,3 +382,33 @@ def test_vnsmall_large_clouds(dev):
     out = net(torch.randn(2, 3, 4096, device=dev))
     out.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_vnsmall_max_pooling_large_batch_of_large_clouds_takes_the_quad_kernel(dev):
+    """B * N >= 2^20 with max pooling prefers the one-thread-per-point kernel, whose LDS (16 B per point + a 12 KB queue) stops
+    fitting a launch at N > 3,328: such clouds must fall through to the four-lanes-per-point kernel instead of failing
+    (B = 256 x N = 4096, eval with pooling = "max"), and give what the quad kernel gives when it is chosen explicitly."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import _lib
+
+    hp = types.SimpleNamespace(n_knn=20, pooling="max")
+    torch.manual_seed(3)
+    net = ea.VNSmall(hp).to(dev).eval()
+    x = torch.randn(256, 3, 4096, device=dev)
+    with torch.no_grad():
+        auto = net(x)
+        _lib.load().eqa_set_option(1, 2)            # always four lanes per point
+        try:
+            quad = net(x)
+        finally:
+            _lib.load().eqa_set_option(1, 0)
+    assert auto.shape == (256, 3, 3) and torch.isfinite(auto).all()
+    assert torch.equal(auto, quad)
+    # the forced one-thread-per-point choice still reports what it cannot do
+    _lib.load().eqa_set_option(1, 1)
+    try:
+        with pytest.raises(_lib.EqaLibraryError):
+            with torch.no_grad():
+                net(x)
+    finally:
+        _lib.load().eqa_set_option(1, 0)
