@@ -35,6 +35,8 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   train_pointcloud  the same for ModelNet40-shaped batches (VNSmall canonicalizer + a PointNet classifier, B=64 per GPU);
   configs       the other BASELINE configs on every rank (cfg1 CIFAR-10 32x32 C4, cfg4 ModelNet40 SO(3), cfg5 COCO-shape D4
                 with masks), whole-job units/s, the dominant kernel's roofline fraction, and (N=1) the CPU oracle;
+  tutorial      the two training loops of the reference's tutorial notebook, the only throughput read-outs the reference repository
+                holds (BASELINE.md section 1), beside their 1,860-1,885 / 1,920-1,965 img/s (tools/bench_tutorial.py);
   cpu_baseline  the CPU oracle (reference op order) on this host, bounded sample, rank 0 / N=1 only.
 
 `--dry-run` exercises ONLY the launcher logic (self-spawn, rendezvous, barrier, max-over-ranks, the JSON line) on CPU
@@ -787,6 +789,15 @@ def main():
                          "ms_per_step": line["train"]["ms_per_step"], "steps": args.train_steps, "warmup": args.train_warmup})
     if args.mode == "all":
         line["configs"] = leg_configs(comm, with_cpu=(world == 1 and not args.no_cpu_baseline))
+        # the two training loops whose tqdm read-outs are the only throughput numbers in the reference repository (BASELINE.md
+        # section 1: CIFAR-10 at 64 x 64, B = 512, C4; hardware unstated) -- per rank, no collective (the notebook is single-GPU)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_tutorial
+
+        line["tutorial"] = {leg: bench_tutorial.run_leg(leg, dev, 512, 20, 5, barrier=comm.barrier) for leg in ("prior", "optimized")}
+        line["tutorial"]["note"] = ("understanding_discrete_canonicalization.ipynb cells 17+21 (ESCNN k=9, 16 ch, 3 layers, prior loss) and "
+                                    "26+30 (Optimized + ConvNetwork k=5, artifact_err_wt=1000): canonicalize -> loss -> backward -> Adam step "
+                                    "-> identity metric, synthetic CIFAR-shaped batches; images_s per rank")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.mode in ("all", "forward"):
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_reps)

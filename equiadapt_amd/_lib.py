@@ -110,6 +110,16 @@ SIGNATURES = {
     "eqa_fft48k5_output_stats_rows": (ctypes.c_int64, [_int] * 4),
     "eqa_fft48k5_output_stats": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_sums": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48_supported": (_int, [_int]),
+    "eqa_fft48_tiles": (ctypes.c_int64, [_int, _int]),
+    "eqa_fft48_workspace_bytes": (ctypes.c_int64, [_int] * 5),
+    "eqa_fft48_filter_spectra": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_fft48_filter_spectra3m": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_fft48_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 6 + [_vp]),
+    "eqa_fft48_grad_transform": (_int, [_vp, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48_input_grad": (_int, [_vp, _vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_fft48_filter_grad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_conv_s2_supported": (_int, [_int] * 5),
     "eqa_conv_s2": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 8 + [_vp]),
     "eqa_affine_relu_rows": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, _vp]),

@@ -18,8 +18,9 @@ constexpr int kThreads = 256;  // block size of every kernel that does not say o
 constexpr int kXcd = 8;        // MI355X: 8 XCDs, block b runs on XCD b % 8, each XCD has a private L2
 
 // window sums (pooling.hip) and the Winograd output transform that emits them directly (winograd.hip)
-constexpr int kMaxWinK = 8;
-constexpr int kWsMaxBorder = kMaxWinK - 1;  // k - 1 <= 7
+constexpr int kMaxWinK = 10;                // (9: the reference tutorial's ESCNN canonicalizer, kernel_size = 9)
+constexpr int kWsMaxBorder = kMaxWinK - 1;  // k - 1 <= 9: register arrays of the kernels instantiated for 8 < k <= 10
+constexpr int kWsSmallBorder = 7;           // ... and of the instantiation every k <= 8 keeps (its register / LDS budget unchanged)
 constexpr int kFinCh = 32;                  // channels per block of the finalize kernel
 
 // Sum over the 64 lanes of a wave, returned to every lane (wave-uniform: it comes back through a scalar register).

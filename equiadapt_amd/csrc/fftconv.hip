@@ -72,6 +72,10 @@ __device__ __forceinline__ void fft_load_column(const float2* __restrict__ p, si
   }
 }
 
+// (The two-pass kernels below take the tile's output size O = 49 - kernel size as a template argument: 44 for the 5 x 5 layers
+// -- where they are the fallback of the fused kernels further down -- and 46 / 42 / 40 for 3 x 3 / 7 x 7 / 9 x 9, which run
+// through them only: eqa_fft48_* entry points, round 4.)
+template <int O>
 __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* __restrict__ x, float* __restrict__ T,
                                                                  const float* __restrict__ in_bias, int in_relu, int H, int W,
                                                                  int C, int TX, int win) {
@@ -80,8 +84,8 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* _
   const int xt = blockIdx.x % TX;
   const size_t row = blockIdx.x / TX;  // img * H + y
   const float ib = in_bias ? in_bias[c] : 0.0f;
-  const float* p = x + (row * W + (size_t)kFftO * xt) * C + c;
-  const int nvalid = min(win, W - kFftO * xt);  // uniform; win = 48: activation tiles (overlap 4), 44: gradient tiles (disjoint)
+  const float* p = x + (row * W + (size_t)O * xt) * C + c;
+  const int nvalid = min(win, W - O * xt);  // uniform; win = 48: activation tiles (overlap 4), 44: gradient tiles (disjoint)
   float re[kFftN], ore[kFftH], oim[kFftH];
 #pragma unroll
   for (int j = 0; j < kFftN; ++j) {
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_fwd_kernel(const float* _
   }
 }
 
+template <int O>
 __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* __restrict__ T, float* __restrict__ V, int H, int C,
                                                                  int TY, int TX, size_t M, size_t m0, int G, int win) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
   const int tx = (int)(m % TX);
   const int ty = (int)((m / TX) % TY);
   const size_t img = m / ((size_t)TX * TY);
-  const int y0 = kFftO * ty;
+  const int y0 = O * ty;
   const int nvalid = min(win, H - y0);  // uniform
   const size_t pitch = (size_t)TX * kFftH * 2 * C;  // one image row of T
   const float* p = T + ((img * H + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_fwd_kernel(const float* _
 }
 
 // FULL (overlap-add, the input gradient): all 48 rows are results, stored tile by tile: T2 (nimg, TY, 48, TX, 25, 2, C)
-template <bool FULL>
+template <bool FULL, int O>
 __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* __restrict__ Mo, float* __restrict__ T2, int OH, int C,
                                                                  int TY, int TX, size_t M, size_t m0) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
@@ -161,11 +166,11 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
     }
     return;
   }
-  const int y0 = kFftO * ty;
-  const int nrows = min(kFftO, OH - y0);  // uniform; rows 44..47 of the tile are the circular wrap-around
+  const int y0 = O * ty;
+  const int nrows = min(O, OH - y0);  // uniform; rows 44..47 of the tile are the circular wrap-around
   float* o = T2 + ((img * OH + y0) * TX + tx) * (size_t)kFftH * 2 * C + (size_t)(2 * kx) * C + c;
 #pragma unroll
-  for (int i = 0; i < kFftO; ++i) {
+  for (int i = 0; i < O; ++i) {
     if (i < nrows) {
       o[i * pitch] = ore[i];
       o[i * pitch + C] = oim[i];
@@ -178,6 +183,7 @@ __global__ __launch_bounds__(kThreads) void fft48_cols_inv_kernel(const float* _
 // by 4.  Thread = (image, input row y, channel): the row spectra of the (at most two) tile rows that reach y are added before
 // the row transform (it is linear), the 4 overlapping columns of consecutive tile columns are carried in registers: every
 // input-gradient element is written once, in a fixed order.
+template <int O>
 __global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const float* __restrict__ T2, float* __restrict__ dx, int H, int W,
                                                                      int C, int TY, int TX) {
   const int c = blockIdx.y * kThreads + threadIdx.x;
@@ -185,12 +191,14 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const floa
   const size_t row = blockIdx.x;  // img * H + y
   const int y = (int)(row % H);
   const size_t img = row / H;
-  const int t1 = min(y / kFftO, TY - 1), i1 = y - kFftO * t1;  // i1 <= 47 because H <= 44 TY + 4
-  const bool two = i1 < kFftN - kFftO && t1 > 0;               // rows 44..47 of the tile row above reach y as well
+  const int t1 = min(y / O, TY - 1), i1 = y - O * t1;  // i1 <= 47 because H <= 44 TY + 4
+  const bool two = i1 < kFftN - O && t1 > 0;               // rows 44..47 of the tile row above reach y as well
   const size_t pitch = (size_t)TX * kFftH * 2 * C;
   const float* p1 = T2 + ((img * TY + t1) * kFftN + i1) * pitch + c;
-  const float* p0 = two ? T2 + ((img * TY + t1 - 1) * kFftN + i1 + kFftO) * pitch + c : p1;
-  float carry[kFftN - kFftO] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const float* p0 = two ? T2 + ((img * TY + t1 - 1) * kFftN + i1 + O) * pitch + c : p1;
+  float carry[kFftN - O];
+#pragma unroll
+  for (int j = 0; j < kFftN - O; ++j) carry[j] = 0.0f;
   float* o = dx + row * (size_t)W * C + c;
   for (int tx = 0; tx < TX; ++tx) {
     float re[kFftH], im[kFftH], ore[kFftN];
@@ -202,21 +210,21 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_add_kernel(const floa
       im[k] = two ? b + b0 : b;
     }
     ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
-    const int x0 = kFftO * tx;
+    const int x0 = O * tx;
 #pragma unroll
-    for (int j = 0; j < kFftN - kFftO; ++j) ore[j] += carry[j];
+    for (int j = 0; j < kFftN - O; ++j) ore[j] += carry[j];
     const bool last = tx == TX - 1;  // uniform
 #pragma unroll
     for (int j = 0; j < kFftN; ++j) {
-      if ((j < kFftO || last) && x0 + j < W) o[(size_t)(x0 + j) * C] = ore[j];
+      if ((j < O || last) && x0 + j < W) o[(size_t)(x0 + j) * C] = ore[j];
     }
 #pragma unroll
-    for (int j = 0; j < kFftN - kFftO; ++j) carry[j] = ore[kFftO + j];
+    for (int j = 0; j < kFftN - O; ++j) carry[j] = ore[O + j];
   }
 }
 
 // NB = k_next - 1 border columns on each side are needed one by one for the window sums; 0: plain output
-template <int NB>
+template <int NB, int O>
 __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* __restrict__ T2, const float* __restrict__ bias, int relu,
                                                                  float* __restrict__ out, int OH, int OW, int C, int TX,
                                                                  size_t img0) {
@@ -239,12 +247,12 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
       im[k] = p[(size_t)(2 * k + 1) * C];
     }
     ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum
-    const int x0 = kFftO * tx;
-    const int ncols = min(kFftO, OW - x0);  // uniform
+    const int x0 = O * tx;
+    const int ncols = min(O, OW - x0);  // uniform
     if (NB == 0) {
       float* o = out + ((img * OH + y) * OW + x0) * (size_t)C + c;
 #pragma unroll
-      for (int j = 0; j < kFftO; ++j) {
+      for (int j = 0; j < O; ++j) {
         if (j < ncols) {
           const float v = ore[j] + b;
           o[(size_t)j * C] = relu ? fmaxf(v, 0.0f) : v;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void fft48_rows_inv_kernel(const float* _
     } else {
       float tot = 0.0f;
 #pragma unroll
-      for (int j = 0; j < kFftO; ++j) {
+      for (int j = 0; j < O; ++j) {
         float v = ore[j] + b;
         v = relu ? fmaxf(v, 0.0f) : v;
         v = j < ncols ? v : 0.0f;
@@ -970,6 +978,7 @@ __global__ __launch_bounds__(kPipeThreads) void fft48_inv_pipe_kernel(const floa
 // 48-entry table): 0.3 ms for 256 x 256 filters, against 13.6 ms for the same through torch.fft + concatenations -- cheap
 // enough to run every training step.
 // `sgn` = +1: the correlation form above (forward pass); -1: FFT(filter) itself, for the convolution of the input gradient.
+template <int KS>
 __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const float* __restrict__ bank, float* __restrict__ B, int Cout,
                                                                        int Cin, int G, float sgn) {
   __shared__ double tw_c[kFftN], tw_s[kFftN];
@@ -982,9 +991,9 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
   const int co = blockIdx.y * kThreads + threadIdx.x;
   const int ci = blockIdx.x;
   if (co >= Cout) return;
-  double w[25];
+  double w[KS * KS];
 #pragma unroll
-  for (int i = 0; i < 25; ++i) w[i] = bank[((size_t)co * Cin + ci) * 25 + i];
+  for (int i = 0; i < KS * KS; ++i) w[i] = bank[((size_t)co * Cin + ci) * (KS * KS) + i];
   const int r0 = (ci / G) * 2 * G + ci % G, r1 = r0 + G;
   const size_t fstride = (size_t)2 * Cin * 2 * Cout;
   float2* o0 = reinterpret_cast<float2*>(B + (size_t)r0 * 2 * Cout) + co;
@@ -993,23 +1002,23 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
   // separable: S_u(kx) = sum_v w[u][v] e^{i t kx v} once per kx, then sum_u e^{i t ky u} S_u for the 48 ky
   // (25 x (50 + 48 x 20) multiply-adds per filter instead of 1200 x 50 in the direct form, and a fifth of the table look-ups)
   for (int kx = 0; kx < kFftH; ++kx) {
-    double sr[5], si[5];
+    double sr[KS], si[KS];
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
+    for (int u = 0; u < KS; ++u) {
       sr[u] = 0.0;
       si[u] = 0.0;
 #pragma unroll
-      for (int v = 0; v < 5; ++v) {
+      for (int v = 0; v < KS; ++v) {
         const int t = (kx * v) % kFftN;
-        sr[u] += w[u * 5 + v] * tw_c[t];
-        si[u] += w[u * 5 + v] * tw_s[t];
+        sr[u] += w[u * KS + v] * tw_c[t];
+        si[u] += w[u * KS + v] * tw_s[t];
       }
     }
     const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
     for (int ky = 0; ky < nky; ++ky) {
       double br = 0.0, bi = 0.0;
 #pragma unroll
-      for (int u = 0; u < 5; ++u) {
+      for (int u = 0; u < KS; ++u) {
         const int t = (ky * u) % kFftN;
         const double c = tw_c[t], sn = tw_s[t];
         br += c * sr[u] - sn * si[u];
@@ -1029,6 +1038,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra_kernel(const fl
 // channel, 4 consecutive input channels = t) for one kx: three 16-byte stores per frequency, fully coalesced over the lanes.
 // Br + Bi is the correctly rounded sum of the two STORED floats (fp64 add of the rounded values), so that
 // Ci = (Ar + Ai)(Br + Bi) - Ar Br - Ai Bi cancels against exactly the Br, Bi the other two products see.
+template <int KS>
 __global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const float* __restrict__ bank, float* __restrict__ B3, int Cout,
                                                                          int Cin, float sgn) {
   __shared__ double tw_c[kFftN], tw_s[kFftN];
@@ -1044,18 +1054,18 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const 
   if (co >= Cout) return;
   constexpr double inv = 1.0 / (kFftN * kFftN);
   // S_u(kx) = sum_v w[u][v] e^{i t kx v} for the 4 filters of this thread
-  double sr[4][5], si[4][5];
+  double sr[4][KS], si[4][KS];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    const float* w = bank + ((size_t)co * Cin + 4 * cq + c) * 25;
+    const float* w = bank + ((size_t)co * Cin + 4 * cq + c) * (KS * KS);
 #pragma unroll
-    for (int u = 0; u < 5; ++u) {
+    for (int u = 0; u < KS; ++u) {
       sr[c][u] = 0.0;
       si[c][u] = 0.0;
 #pragma unroll
-      for (int v = 0; v < 5; ++v) {
+      for (int v = 0; v < KS; ++v) {
         const int t = (kx * v) % kFftN;
-        const double wv = w[u * 5 + v];
+        const double wv = w[u * KS + v];
         sr[c][u] += wv * tw_c[t];
         si[c][u] += wv * tw_s[t];
       }
@@ -1075,7 +1085,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const 
     for (int c = 0; c < 4; ++c) {
       double br = 0.0, bi = 0.0;
 #pragma unroll
-      for (int u = 0; u < 5; ++u) {
+      for (int u = 0; u < KS; ++u) {
         const int t = (ky * u) % kFftN;
         const double cs = tw_c[t], sn = tw_s[t];
         br += cs * sr[c][u] - sn * si[c][u];
@@ -1099,7 +1109,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_spectra3m_kernel(const 
 // wgt = 2 for the stored frequencies whose conjugate partner is not stored, 1 for the self-conjugate ones -- the correlation theorem; no
 // wrap-around because a 44-wide gradient tile shifted by up to 4 stays inside the 48-wide input tile.
 // PACKED: D3 (F, Cin, 2, Cout) as eqa_fft48k5_wgrad3m writes it -- Dr | Di per input channel, plain channel order.
-template <bool PACKED>
+template <bool PACKED, int KS>
 __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float* __restrict__ D, float* __restrict__ dbank, int Cout,
                                                                     int Cin, int Gin, int Gout) {
   __shared__ double tw_c[kFftN], tw_s[kFftN];
@@ -1116,14 +1126,16 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
   const int c0 = (co / Gout) * 2 * Gout + co % Gout, c1 = c0 + Gout;
   const size_t ld = (size_t)2 * Cout, fstride = (size_t)2 * Cin * (PACKED ? (size_t)Cout : ld);
   const size_t p_dr = ((size_t)2 * ci) * Cout + co, p_di = p_dr + Cout;   // PACKED
-  double acc[25];
+  double acc[KS * KS];
 #pragma unroll
-  for (int i = 0; i < 25; ++i) acc[i] = 0.0;
+  for (int i = 0; i < KS * KS; ++i) acc[i] = 0.0;
   // separable, like the spectra kernel: A_u(kx) = sum_ky e^{i t ky u} D(ky, kx), then dW[u][v] += Re(e^{i t kx v} A_u(kx))
   for (int kx = 0; kx < kFftH; ++kx) {
     const bool edge = fft_edge(kx);
     const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
-    double ar[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, ai[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double ar[KS], ai[KS];
+#pragma unroll
+    for (int u = 0; u < KS; ++u) { ar[u] = 0.0; ai[u] = 0.0; }
     // one block per CU and one thread per filter: the loop is a chain of round trips unless several frequencies are requested
     // together (0.56 ms for 1.26 GB at one ky per trip).  Eight per trip; the sums run over ky in the same order.
     constexpr int kKyBatch = 8;
@@ -1151,7 +1163,7 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
           const double dr = PACKED ? wgt * (double)q[b][0] : wgt * ((double)q[b][0] + (double)q[b][1]);
           const double di = PACKED ? wgt * (double)q[b][1] : wgt * ((double)q[b][PACKED ? 0 : 2] - (double)q[b][PACKED ? 1 : 3]);
 #pragma unroll
-          for (int u = 0; u < 5; ++u) {
+          for (int u = 0; u < KS; ++u) {
             const int t = (ky * u) % kFftN;
             const double c = tw_c[t], sn = tw_s[t];
             ar[u] += c * dr - sn * di;
@@ -1161,17 +1173,17 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
       }
     }
 #pragma unroll
-    for (int u = 0; u < 5; ++u)
+    for (int u = 0; u < KS; ++u)
 #pragma unroll
-      for (int v = 0; v < 5; ++v) {
+      for (int v = 0; v < KS; ++v) {
         const int t = (kx * v) % kFftN;
-        acc[u * 5 + v] += tw_c[t] * ar[u] - tw_s[t] * ai[u];
+        acc[u * KS + v] += tw_c[t] * ar[u] - tw_s[t] * ai[u];
       }
   }
   constexpr double inv = 1.0 / (kFftN * kFftN);
-  float* o = dbank + ((size_t)co * Cin + ci) * 25;
+  float* o = dbank + ((size_t)co * Cin + ci) * (KS * KS);
 #pragma unroll
-  for (int i = 0; i < 25; ++i) o[i] = (float)(acc[i] * inv);
+  for (int i = 0; i < KS * KS; ++i) o[i] = (float)(acc[i] * inv);
 }
 
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
@@ -1254,9 +1266,9 @@ static int fft_output_impl(const float* Mo, float* T2, const float* bias, int re
   const int chunk = fft_chunk_images(nimg, OH, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
     const int n = std::min(chunk, nimg - i0);
-    hipLaunchKernelGGL((fft48_cols_inv_kernel<false>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2, OH, C,
+    hipLaunchKernelGGL((fft48_cols_inv_kernel<false, kFftO>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2, OH, C,
                        TY, TX, fft_pitch(M), (size_t)i0 * TY * TX);
-    hipLaunchKernelGGL((fft48_rows_inv_kernel<NB>), dim3((unsigned)((size_t)n * OH), cb), dim3(kThreads), 0, st, T2, bias, relu, out, OH,
+    hipLaunchKernelGGL((fft48_rows_inv_kernel<NB, kFftO>), dim3((unsigned)((size_t)n * OH), cb), dim3(kThreads), 0, st, T2, bias, relu, out, OH,
                        OW, C, TX, (size_t)i0);
   }
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
@@ -1281,7 +1293,7 @@ int64_t eqa_fft48k5_tile_pitch(int64_t tiles) { return tiles <= 0 ? 0 : (int64_t
 int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, int correlate, void* stream) {
   if (!bank || !B || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (((uintptr_t)B & 7) || Cin > 65535) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_filter_spectra_kernel, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, bank,
+  hipLaunchKernelGGL(fft48_filter_spectra_kernel<5>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, bank,
                      B, Cout, Cin, fft_group_in(Cin), correlate ? 1.0f : -1.0f);
   return launch_status();
 }
@@ -1289,7 +1301,7 @@ int eqa_fft48k5_filter_spectra(const float* bank, float* B, int Cout, int Cin, i
 int eqa_fft48k5_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int correlate, void* stream) {
   if (!bank || !B3 || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (((uintptr_t)B3 & 15) || Cin % 32 || Cout % 64 || Cin / 4 > 65535) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_filter_spectra3m_kernel, dim3(Cin / 4, (Cout + kThreads - 1) / kThreads, kFftH), dim3(kThreads), 0,
+  hipLaunchKernelGGL(fft48_filter_spectra3m_kernel<5>, dim3(Cin / 4, (Cout + kThreads - 1) / kThreads, kFftH), dim3(kThreads), 0,
                      (hipStream_t)stream, bank, B3, Cout, Cin, correlate ? 1.0f : -1.0f);
   return launch_status();
 }
@@ -1307,9 +1319,9 @@ int eqa_fft48k5_input_grad(const float* Cg, float* T2, float* dx, int nimg, int 
   const int chunk = fft_chunk_images(nimg, TY * kFftN, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
     const int n = std::min(chunk, nimg - i0);
-    hipLaunchKernelGGL((fft48_cols_inv_kernel<true>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Cg, T2, OH,
+    hipLaunchKernelGGL((fft48_cols_inv_kernel<true, kFftO>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Cg, T2, OH,
                        C, TY, TX, fft_pitch(M), (size_t)i0 * TY * TX);
-    hipLaunchKernelGGL(fft48_rows_inv_add_kernel, dim3((unsigned)((size_t)n * H), cb), dim3(kThreads), 0, st, T2,
+    hipLaunchKernelGGL(fft48_rows_inv_add_kernel<kFftO>, dim3((unsigned)((size_t)n * H), cb), dim3(kThreads), 0, st, T2,
                        dx + (size_t)i0 * H * W * C, H, W, C, TY, TX);
   }
   return launch_status();
@@ -1355,9 +1367,9 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
   const int chunk = fft_chunk_images(nimg, H, TX, C);
   for (int i0 = 0; i0 < nimg; i0 += chunk) {
     const int n = std::min(chunk, nimg - i0);
-    hipLaunchKernelGGL(fft48_rows_fwd_kernel, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(fft48_rows_fwd_kernel<kFftO>, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
                        x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX, win);
-    hipLaunchKernelGGL(fft48_cols_fwd_kernel, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
+    hipLaunchKernelGGL(fft48_cols_fwd_kernel<kFftO>, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
                        TY, TX, fft_pitch(M), (size_t)i0 * TY * TX, fft_group_in(C), win);
   }
   return launch_status();
@@ -1395,7 +1407,7 @@ int eqa_fft48k5_grad_transform(const float* dy, float* T, float* G, int nimg, in
 int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, void* stream) {
   if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (Cin > 65535) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_filter_grad_kernel<false>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
+  hipLaunchKernelGGL((fft48_filter_grad_kernel<false, 5>), dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
                      dbank, Cout, Cin, fft_group_in(Cin), fft_group_in(Cout));
   return launch_status();
 }
@@ -1403,7 +1415,7 @@ int eqa_fft48k5_filter_grad(const float* D, float* dbank, int Cout, int Cin, voi
 int eqa_fft48k5_filter_grad3m(const float* D, float* dbank, int Cout, int Cin, void* stream) {
   if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
   if (Cin > 65535 || Cin % kFusCh || Cout % kFusCh) return EQA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fft48_filter_grad_kernel<true>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
+  hipLaunchKernelGGL((fft48_filter_grad_kernel<true, 5>), dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, (hipStream_t)stream, D,
                      dbank, Cout, Cin, kFusCh, kFusCh);
   return launch_status();
 }
@@ -1451,6 +1463,165 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
   const int per_row = fused == 3 ? kPipeCons / 64 : fused;
   const int nseg = fused ? 2 * nb + per_row * ((OH + kFftO - 1) / kFftO) : OH;
   return eqa::launch_window_sums_nhwc_finalize(part, S, nimg, C, k_next, nseg * sub, st, sub);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Any odd kernel size 3 .. 9 (round 4): the same overlap-save scheme with 48 x 48 tiles of O = 49 - k outputs, through the two-pass
+// kernels (one thread per channel; no fused / pipelined forms, no window-sum epilogue: the caller runs eqa_window_sums_nhwc on the
+// map).  The reference's kernel_size is a free constructor argument (escnn_networks.py:19-44): its tutorial trains k = 9, its own test
+// k = 3.  The multiply count per output falls with k^2: 1154 x 3 real products per 40 x 40 outputs and channel pair at k = 9 against
+// 81 in the direct form (37x fewer; tiles that fit the map badly give some of it back).  The per-frequency channel contraction is
+// k-independent: eqa_fft48k5_cgemm3m / _wgrad3m / torch.bmm on buffers of eqa_fft48k5_tile_pitch rows, as for k = 5.
+// ------------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int KS>
+struct FftK {
+  static constexpr int O = kFftN + 1 - KS;
+
+  static int forward(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C, int TY, int TX,
+                     int win, hipStream_t st) {
+    const size_t M = (size_t)nimg * TY * TX;
+    if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+    const unsigned cb = (C + kThreads - 1) / kThreads;
+    const int chunk = fft_chunk_images(nimg, H, TX, C);
+    for (int i0 = 0; i0 < nimg; i0 += chunk) {
+      const int n = std::min(chunk, nimg - i0);
+      hipLaunchKernelGGL(fft48_rows_fwd_kernel<O>, dim3((unsigned)((size_t)n * H * TX), cb), dim3(kThreads), 0, st,
+                         x + (size_t)i0 * H * W * C, T, in_bias, in_relu, H, W, C, TX, win);
+      hipLaunchKernelGGL(fft48_cols_fwd_kernel<O>, dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, T, V, H, C,
+                         TY, TX, fft_pitch(M), (size_t)i0 * TY * TX, fft_group_in(C), win);
+    }
+    return launch_status();
+  }
+
+  static int output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C, hipStream_t st) {
+    const int TY = (OH + O - 1) / O, TX = (OW + O - 1) / O;
+    const size_t M = (size_t)nimg * TY * TX;
+    if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+    const unsigned cb = (C + kThreads - 1) / kThreads;
+    const int chunk = fft_chunk_images(nimg, OH, TX, C);
+    for (int i0 = 0; i0 < nimg; i0 += chunk) {
+      const int n = std::min(chunk, nimg - i0);
+      hipLaunchKernelGGL((fft48_cols_inv_kernel<false, O>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Mo, T2,
+                         OH, C, TY, TX, fft_pitch(M), (size_t)i0 * TY * TX);
+      hipLaunchKernelGGL((fft48_rows_inv_kernel<0, O>), dim3((unsigned)((size_t)n * OH), cb), dim3(kThreads), 0, st, T2, bias, relu, y, OH,
+                         OW, C, TX, (size_t)i0);
+    }
+    return launch_status();
+  }
+
+  static int input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, hipStream_t st) {
+    const int OH = H - (KS - 1), OW = W - (KS - 1);
+    const int TY = (OH + O - 1) / O, TX = (OW + O - 1) / O;
+    const size_t M = (size_t)nimg * TY * TX;
+    if ((size_t)nimg * H > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+    const unsigned cb = (C + kThreads - 1) / kThreads;
+    const int chunk = fft_chunk_images(nimg, TY * kFftN, TX, C);
+    for (int i0 = 0; i0 < nimg; i0 += chunk) {
+      const int n = std::min(chunk, nimg - i0);
+      hipLaunchKernelGGL((fft48_cols_inv_kernel<true, O>), dim3((unsigned)((size_t)n * TY * TX * kFftH), cb), dim3(kThreads), 0, st, Cg, T2,
+                         OH, C, TY, TX, fft_pitch(M), (size_t)i0 * TY * TX);
+      hipLaunchKernelGGL(fft48_rows_inv_add_kernel<O>, dim3((unsigned)((size_t)n * H), cb), dim3(kThreads), 0, st, T2,
+                         dx + (size_t)i0 * H * W * C, H, W, C, TY, TX);
+    }
+    return launch_status();
+  }
+
+  static int spectra(const float* bank, float* B, int Cout, int Cin, float sgn, hipStream_t st) {
+    hipLaunchKernelGGL(fft48_filter_spectra_kernel<KS>, dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, st, bank, B, Cout,
+                       Cin, fft_group_in(Cin), sgn);
+    return launch_status();
+  }
+  static int spectra3m(const float* bank, float* B3, int Cout, int Cin, float sgn, hipStream_t st) {
+    hipLaunchKernelGGL(fft48_filter_spectra3m_kernel<KS>, dim3(Cin / 4, (Cout + kThreads - 1) / kThreads, kFftH), dim3(kThreads), 0, st, bank,
+                       B3, Cout, Cin, sgn);
+    return launch_status();
+  }
+  static int filter_grad(const float* D, float* dbank, int Cout, int Cin, bool packed, hipStream_t st) {
+    if (packed)
+      hipLaunchKernelGGL((fft48_filter_grad_kernel<true, KS>), dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, st, D, dbank,
+                         Cout, Cin, kFusCh, kFusCh);
+    else
+      hipLaunchKernelGGL((fft48_filter_grad_kernel<false, KS>), dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, st, D, dbank,
+                         Cout, Cin, fft_group_in(Cin), fft_group_in(Cout));
+    return launch_status();
+  }
+};
+
+inline bool fft_ksize_ok(int k) { return k == 3 || k == 5 || k == 7 || k == 9; }
+inline int fft_tiles_k(int n, int k) { return n < k ? 0 : (n - (k - 1) + (kFftN + 1 - k) - 1) / (kFftN + 1 - k); }
+
+#define EQA_FFT_K(ksize, expr)                 \
+  switch (ksize) {                             \
+    case 3: { using K_ = FftK<3>; return expr; } \
+    case 5: { using K_ = FftK<5>; return expr; } \
+    case 7: { using K_ = FftK<7>; return expr; } \
+    case 9: { using K_ = FftK<9>; return expr; } \
+    default: return EQA_ERR_UNSUPPORTED;       \
+  }
+
+}  // namespace
+
+extern "C" {
+
+int eqa_fft48_supported(int ksize) { return fft_ksize_ok(ksize) ? 1 : 0; }
+
+int64_t eqa_fft48_tiles(int n, int ksize) { return fft_ksize_ok(ksize) ? fft_tiles_k(n, ksize) : 0; }
+
+int64_t eqa_fft48_workspace_bytes(int nimg, int rows, int cols, int C, int ksize) {
+  if (nimg <= 0 || rows <= 0 || cols <= 0 || C <= 0 || !fft_ksize_ok(ksize)) return 0;
+  const int O = kFftN + 1 - ksize;
+  const int TX = (cols + O - 1) / O;     // callers pass the OUTPUT width (input width - (k - 1)) for either direction
+  return (int64_t)fft_chunk_images(nimg, rows, TX, C) * rows * TX * kFftH * 2 * C * (int64_t)sizeof(float);
+}
+
+int eqa_fft48_filter_spectra(const float* bank, float* B, int Cout, int Cin, int ksize, int correlate, void* stream) {
+  if (!bank || !B || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)B & 7) || Cin > 65535) return EQA_ERR_UNSUPPORTED;
+  EQA_FFT_K(ksize, K_::spectra(bank, B, Cout, Cin, correlate ? 1.0f : -1.0f, (hipStream_t)stream));
+}
+
+int eqa_fft48_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int ksize, int correlate, void* stream) {
+  if (!bank || !B3 || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)B3 & 15) || Cin % 32 || Cout % 64 || Cin / 4 > 65535) return EQA_ERR_UNSUPPORTED;
+  EQA_FFT_K(ksize, K_::spectra3m(bank, B3, Cout, Cin, correlate ? 1.0f : -1.0f, (hipStream_t)stream));
+}
+
+int eqa_fft48_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C, int ksize,
+                    void* stream) {
+  if (!x || !T || !V || nimg < 0 || C <= 0 || !fft_ksize_ok(ksize) || H < ksize || W < ksize) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  EQA_FFT_K(ksize, K_::forward(x, T, V, in_bias, in_relu, nimg, H, W, C, fft_tiles_k(H, ksize), fft_tiles_k(W, ksize), kFftN,
+                               (hipStream_t)stream));
+}
+
+int eqa_fft48_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, int ksize, void* stream) {
+  if (!dy || !T || !G || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0 || !fft_ksize_ok(ksize)) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  EQA_FFT_K(ksize, K_::forward(dy, T, G, nullptr, 0, nimg, OH, OW, C, (OH + K_::O - 1) / K_::O, (OW + K_::O - 1) / K_::O, K_::O,
+                               (hipStream_t)stream));
+}
+
+int eqa_fft48_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C, int ksize,
+                     void* stream) {
+  if (!Mo || !T2 || !y || nimg < 0 || OH <= 0 || OW <= 0 || C <= 0 || !fft_ksize_ok(ksize)) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  EQA_FFT_K(ksize, K_::output(Mo, T2, bias, relu, y, nimg, OH, OW, C, (hipStream_t)stream));
+}
+
+int eqa_fft48_input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, int ksize, void* stream) {
+  if (!Cg || !T2 || !dx || nimg < 0 || C <= 0 || !fft_ksize_ok(ksize) || H < ksize || W < ksize) return EQA_ERR_INVALID_ARG;
+  if (nimg == 0) return EQA_OK;
+  EQA_FFT_K(ksize, K_::input_grad(Cg, T2, dx, nimg, H, W, C, (hipStream_t)stream));
+}
+
+int eqa_fft48_filter_grad(const float* D, float* dbank, int Cout, int Cin, int ksize, int packed, void* stream) {
+  if (!D || !dbank || Cout <= 0 || Cin <= 0) return EQA_ERR_INVALID_ARG;
+  if (Cin > 65535 || (packed && (Cin % kFusCh || Cout % kFusCh))) return EQA_ERR_UNSUPPORTED;
+  EQA_FFT_K(ksize, K_::filter_grad(D, dbank, Cout, Cin, packed != 0, (hipStream_t)stream));
 }
 
 }  // extern "C"

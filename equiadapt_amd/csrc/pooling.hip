@@ -224,7 +224,7 @@ __device__ __forceinline__ void ws_segment_rows(int s, int H, int k, int nbands,
 // being written (eqa_window_sums_nhwc_act).
 // RELU / DROP are template arguments: as run-time flags they were (uniform) branches inside the load-and-activate step, and the
 // wait-count pass then put s_waitcnt vmcnt(0) behind EVERY load -- one load in flight per wave, 2.7-3.0 TB/s (seen in the ISA only).
-template <bool RELU, bool DROP>
+template <bool RELU, bool DROP, int MAXB = kWsSmallBorder>   // MAXB: border columns held in registers (k - 1 <= MAXB)
 __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                                            const float* __restrict__ shift, int /*relu*/,
                                                                            float* __restrict__ part, int C, int H, int W, int k,
@@ -270,9 +270,9 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
       return v;
     };
     auto ld = [&](int y, int xc) { return act(raw(y, xc), y, xc); };
-    float4 acc[1 + 2 * kWsMaxBorder];
+    float4 acc[1 + 2 * MAXB];
 #pragma unroll
-    for (int i = 0; i < 1 + 2 * kWsMaxBorder; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < 1 + 2 * MAXB; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int xs = 4 * P;   // pixels covered by the block's four waves per step
     int y = y0;
     if (W <= xs && nb == 0) {
@@ -313,14 +313,14 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
       acc[0].x += t0.x + t1.x; acc[0].y += t0.y + t1.y; acc[0].z += t0.z + t1.z; acc[0].w += t0.w + t1.w;
       // border columns (static j, wave-uniform owner): re-read from L1
 #pragma unroll
-      for (int j = 0; j < kWsMaxBorder; ++j) {
+      for (int j = 0; j < MAXB; ++j) {
         if (j < nb && psub == 0) {   // (one pixel: the lanes of pixel group 0 own it)
           if ((j & 3) == wave) { const float4 a = ld(y, j); acc[1 + j].x += a.x; acc[1 + j].y += a.y; acc[1 + j].z += a.z; acc[1 + j].w += a.w; }
           const int xr = W - nb + j;
           if ((xr & 3) == wave) {
             const float4 a = ld(y, xr);
-            acc[1 + kWsMaxBorder + j].x += a.x; acc[1 + kWsMaxBorder + j].y += a.y;
-            acc[1 + kWsMaxBorder + j].z += a.z; acc[1 + kWsMaxBorder + j].w += a.w;
+            acc[1 + MAXB + j].x += a.x; acc[1 + MAXB + j].y += a.y;
+            acc[1 + MAXB + j].z += a.z; acc[1 + MAXB + j].w += a.w;
           }
         }
       }
@@ -339,10 +339,10 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
     __syncthreads();
     s_tot[wave][lane] = acc[0];
 #pragma unroll
-    for (int j = 0; j < kWsMaxBorder; ++j) {
+    for (int j = 0; j < MAXB; ++j) {
       if (j < nb && owner) {
         if ((j & 3) == wave) put(1 + j, acc[1 + j]);
-        if (((W - nb + j) & 3) == wave) put(1 + nb + j, acc[1 + kWsMaxBorder + j]);
+        if (((W - nb + j) & 3) == wave) put(1 + nb + j, acc[1 + MAXB + j]);
       }
     }
     __syncthreads();
@@ -358,17 +358,17 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
 // value t % nval) and walks the segment axis: every load instruction is a contiguous row (the first version gave each
 // thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see DESIGN.md).  Fixed order, deterministic.
 // Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
-constexpr int kFinVals = 1 + 2 * kWsMaxBorder;
 constexpr int kFinThreads = 320;   // k = 5: a block's run is 32 channels x 9 values = 288 elements -- one trip of 320 threads, not two of 256
 
 // `sub` > 1: every segment arrives in `sub` pieces (one per tile column of the producer), laid out as consecutive segments;
 // the pieces of a border row are added up first (in fp32, as a single producer thread would have).
-template <int KW>   // the window size as a template argument (0: any): the assembly below then unrolls into independent LDS reads
+template <int KW, int MAXB = kWsSmallBorder>   // the window size as a template argument (0: any): the assembly below then unrolls into independent LDS reads
 __global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(const float* __restrict__ part, double* __restrict__ out,
                                                                             int B, int C, int k_rt, int nseg, int sub) {
+  constexpr int kFinVals = 1 + 2 * MAXB;
   const int k = KW ? KW : k_rt;
   __shared__ double s_tot[kFinCh * kFinVals];
-  __shared__ float s_brd[2 * kWsMaxBorder][kFinCh * kFinVals];
+  __shared__ float s_brd[2 * MAXB][kFinCh * kFinVals];
   const int b = blockIdx.y;
   const int c0 = blockIdx.x * kFinCh;
   const int nch = min(kFinCh, C - c0);
@@ -383,13 +383,13 @@ __global__ __launch_bounds__(kFinThreads) void window_sums_nhwc_finalize_kernel(
     if (sub <= 2) {
       // border-row segments are needed individually as well.  All their pieces are requested before the first is used (the
       // rolled form paid one round trip per piece, 16 in a row at k = 5: most of the kernel's 39 us for 85 MB)
-      float v[2 * kWsMaxBorder][2];
+      float v[2 * MAXB][2];
 #pragma unroll
-      for (int i = 0; i < 2 * kWsMaxBorder; ++i)
+      for (int i = 0; i < 2 * MAXB; ++i)
 #pragma unroll
         for (int t = 0; t < 2; ++t) v[i][t] = (i < 2 * nb && t < sub) ? q[(size_t)(i * sub + t) * seg_stride] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < 2 * kWsMaxBorder; ++i) {
+      for (int i = 0; i < 2 * MAXB; ++i) {
         if (i < 2 * nb) {
           const float w = sub == 2 ? v[i][0] + v[i][1] : v[i][0];
           s_brd[i][e] = w;
@@ -577,8 +577,10 @@ int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, i
     hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<5>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
   else if (k == 3)
     hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<3>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
-  else
+  else if (k - 1 <= kWsSmallBorder)
     hipLaunchKernelGGL(window_sums_nhwc_finalize_kernel<0>, fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
+  else
+    hipLaunchKernelGGL((window_sums_nhwc_finalize_kernel<0, kWsMaxBorder>), fgrid, fblock, 0, stream, part, S, B, C, k, nseg, sub);
   return launch_status();
 }
 
@@ -737,8 +739,14 @@ static int window_sums_nhwc_impl(const float* x, const float* scale, const float
   const int nseg = 2 * (k - 1) + nbands;
   const uint32_t thr = dropout_threshold(drop_p);
 #define EQA_WS_SEG(R_, D_)                                                                                                     \
-  hipLaunchKernelGGL((window_sums_nhwc_segment_kernel<R_, D_>), dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu,    \
-                     (float*)workspace, C, H, W, k, nbands, thr, 1.0f / (1.0f - drop_p), seed)
+  do {                                                                                                                         \
+    if (k - 1 <= kWsSmallBorder)                                                                                               \
+      hipLaunchKernelGGL((window_sums_nhwc_segment_kernel<R_, D_>), dim3(nseg, B), dim3(kThreads), 0, st, x, scale, shift, relu, \
+                         (float*)workspace, C, H, W, k, nbands, thr, 1.0f / (1.0f - drop_p), seed);                            \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((window_sums_nhwc_segment_kernel<R_, D_, kWsMaxBorder>), dim3(nseg, B), dim3(kThreads), 0, st, x, scale, \
+                         shift, relu, (float*)workspace, C, H, W, k, nbands, thr, 1.0f / (1.0f - drop_p), seed);               \
+  } while (0)
   if (relu && thr) EQA_WS_SEG(true, true);
   else if (relu) EQA_WS_SEG(true, false);
   else if (thr) EQA_WS_SEG(false, true);

@@ -134,7 +134,7 @@ class _GroupConvBase(nn.Module):
         return hit
 
     def supports_linear_tail(self) -> bool:
-        return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
+        return self.stride == 1 and self.padding == 0 and self.kernel_size <= ops.MAX_WINDOW_K
 
     def mfma_lifting_ok(self, x: torch.Tensor) -> bool:
         """Inference on the hand-written fp32-MFMA lifting convolution (eqa_lift_conv_nhwc) instead of the framework's

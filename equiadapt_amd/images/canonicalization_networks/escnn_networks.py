@@ -323,7 +323,7 @@ class _DenseConv(nn.Module):
         return hit
 
     def supports_linear_tail(self) -> bool:
-        return self.stride == 1 and self.padding == 0 and self.kernel_size <= 8
+        return self.stride == 1 and self.padding == 0 and self.kernel_size <= ops.MAX_WINDOW_K
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.conv(x)
@@ -461,7 +461,7 @@ class ESCNNEquivariantNetwork(nn.Module):
         hit = self._fold_cache.get(("fft", id(conv)))
         key = self._fold_cache[id(conv)][0]
         if hit is None or hit[0] != key:
-            hit = (key, fftconv.spectra_for(bank))
+            hit = (key, fftconv.spectra_for_k(bank))
             self._fold_cache[("fft", id(conv))] = hit
         return hit[1]
 
@@ -504,6 +504,17 @@ class ESCNNEquivariantNetwork(nn.Module):
                 continue
             if isinstance(h, fftconv.GroupedMap):   # written for an FFT layer that did not take it after all
                 h = h.to_channels_last()
+            if (nhwc and not conv.lifting and conv.kernel_size != 5 and conv.stride == 1 and conv.padding == 0
+                    and h.is_contiguous(memory_format=torch.channels_last)
+                    and fftconv.applicable_k(h.shape, bank.shape[1], bank.shape[0], conv.kernel_size, h.device)):
+                # regular -> regular layer of another kernel size (the reference's tutorial network: k = 9): the same overlap-save
+                # FFT convolution with 49 - k outputs per tile (eqa_fft48_*); previous layer's bias + ReLU on the input loads,
+                # this layer's on the way out; the linearised tail reads the map through the window-sum kernel
+                h = fftconv.conv_kxk(h, self._fft_filters(conv, bank), conv.kernel_size, bias, True, pending, pending is not None)
+                pending = None
+                if last_before_tail:
+                    return conv_then_group_pool(h, convs[-1])
+                continue
             use_wino = is_5x5 and winograd.applicable(h, bank.shape[1], bank.shape[0])
             if use_wino:
                 # 5x5 regular->regular layer: Winograd F(m x m, 5x5), m = 4 where the size allows.  The previous layer's
@@ -602,6 +613,11 @@ class ESCNNEquivariantNetwork(nn.Module):
                     h, part = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h), True)
                 else:
                     h = winograd.Conv5x5Function.apply(h, bank, winograd.tile_for(h))
+            elif (not conv.lifting and conv.kernel_size != 5
+                  and fftconv.applicable_k(h.shape, bank.shape[1], bank.shape[0], conv.kernel_size, h.device,
+                                           h.is_contiguous(memory_format=torch.channels_last))):
+                # kernel sizes Winograd F(m, 5) does not cover (the tutorial's k = 9): forward and both gradients as FFT convolutions
+                h = fftconv.ConvKxKFunction.apply(h, bank)
             elif (conv.lifting and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
                   and ops.lift_conv_supported(bank.shape[1], conv.kernel_size, conv.kernel_size, bank.shape[0])):
                 # batch statistics of the norm behind the layer: taken in the convolution's epilogue where the kernel has that form
@@ -614,7 +630,7 @@ class ESCNNEquivariantNetwork(nn.Module):
                 h = F.conv2d(h, bank.contiguous(memory_format=torch.channels_last))
             fused = os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and h.is_contiguous(memory_format=torch.channels_last)
             kt = tail.kernel_size
-            if (fused and li == len(convs) - 2 and os.environ.get("EQA_TRAIN_FUSED_TAIL", "1") != "0" and kt <= 8
+            if (fused and li == len(convs) - 2 and os.environ.get("EQA_TRAIN_FUSED_TAIL", "1") != "0" and kt <= ops.MAX_WINDOW_K
                     and h.shape[-2] > 2 * (kt - 1) and h.shape[-1] > 2 * (kt - 1) and h.shape[0] <= 65535):
                 # the last hidden block goes straight into the window sums of the linearised final layer: its output is never written
                 S = InnerBnReluDropoutWindowSums.apply(h, bn.weight, bn.bias, bn, E, conv.bias, drop.p, drop.training, kt, part)

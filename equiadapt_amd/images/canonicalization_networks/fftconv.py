@@ -316,3 +316,171 @@ def grad_spectra(dy: torch.Tensor) -> torch.Tensor:
         _lib.check(lib.eqa_fft48k5_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout,
                                                   torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_grad_transform")
     return G
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Kernel sizes other than 5 (round 4): the same scheme with O = 49 - k outputs per tile, through eqa_fft48_* (two-pass kernels).
+# The reference's kernel_size is a free constructor argument (escnn_networks.py:19-44): its tutorial trains k = 9, its test k = 3.
+# k = 5 keeps the functions above (fused / pipelined transforms).
+# ----------------------------------------------------------------------------------------------------------------------------------
+KSIZES = (3, 5, 7, 9)
+
+
+def tiles_k(n: int, k: int) -> int:
+    o = N + 1 - k
+    return 0 if n < k else (n - (k - 1) + o - 1) // o
+
+
+def applicable_k(x_shape, cin: int, cout: int, k: int, device, channels_last: bool = True) -> bool:
+    """Should a (nimg, cin, H, W) fp32 channels-last map on `device` take the FFT path for a k x k stride-1 convolution?
+    k = 5: the tuned rule above (`applicable`).  Otherwise a cost model -- the FFT path moves ~2.2 x its spectra (two-pass
+    transforms) at ~4 TB/s and contracts 1154 x 3 real products per tile and channel pair at ~100 TFLOP/s; the library's
+    direct convolution runs its OH x OW x k^2 products at ~110 TFLOP/s -- with a 1.3 x margin in favour of the library."""
+    if not (ENABLED and k in KSIZES and k != 5 and device.type == "cuda" and channels_last and len(x_shape) == 4 and x_shape[1] == cin):
+        return False
+    if os.environ.get("EQA_FFT_ANYK", "1") == "0":
+        return False
+    nimg, _, H, W = x_shape
+    if H < max(16, k) or W < max(16, k) or nimg * tiles_k(H, k) * tiles_k(W, k) < 8:
+        return False
+    oh, ow = H - k + 1, W - k + 1
+    t = tiles_k(H, k) * tiles_k(W, k)
+    fft_us = t * (F * 8 * (cin + cout) * 2.2 / 4.0e6 + F * 6 * cin * cout / 100e6)
+    direct_us = oh * ow * k * k * 2 * cin * cout / 110e6
+    return fft_us * 1.3 < direct_us
+
+
+def spectra_for_k(bank: torch.Tensor, correlate: bool = True):
+    """`spectra_for` for a (Cout, Cin, k, k) device bank of any supported k."""
+    k = bank.shape[-1]
+    if k == 5:
+        return spectra_for(bank, correlate)
+    lib = _lib.load()
+    Cout, Cin = bank.shape[:2]
+    assert bank.is_cuda and bank.dtype == torch.float32 and bank.shape[-2] == k and lib.eqa_fft48_supported(k)
+    st = torch.cuda.current_stream().cuda_stream
+    with torch.cuda.device(bank.device):
+        if gemm3m_supported(Cin, Cout):
+            B3 = torch.empty(lib.eqa_fft48k5_spectra3m_floats(Cin, Cout), dtype=torch.float32, device=bank.device)
+            _lib.check(lib.eqa_fft48_filter_spectra3m(bank.contiguous().data_ptr(), B3.data_ptr(), Cout, Cin, k, int(correlate), st),
+                       "eqa_fft48_filter_spectra3m")
+            return Spectra3M(B3, Cin, Cout)
+        B = torch.empty((F, 2 * Cin, 2 * Cout), dtype=torch.float32, device=bank.device)
+        _lib.check(lib.eqa_fft48_filter_spectra(bank.contiguous().data_ptr(), B.data_ptr(), Cout, Cin, k, int(correlate), st),
+                   "eqa_fft48_filter_spectra")
+        return B
+
+
+def conv_kxk(x: torch.Tensor, B, k: int, bias: Optional[torch.Tensor], relu: bool, in_bias: Optional[torch.Tensor] = None,
+             in_relu: bool = False, keep_V: Optional[list] = None) -> torch.Tensor:
+    """`conv5x5` for any supported k (no window-sum / statistics epilogues off k = 5): channels-last (nimg, Cin, H, W) ->
+    channels-last (nimg, Cout, H-k+1, W-k+1) = [relu](conv2d(act(x), g) + bias), B = spectra_for_k(g)."""
+    if k == 5:
+        return conv5x5(x, B, bias, relu, in_bias, in_relu, keep_V=keep_V)
+    lib = _lib.load()
+    nimg, Cin, H, W = x.shape
+    Cout = B.cout if isinstance(B, Spectra3M) else B.shape[2] // 2
+    OH, OW = H - k + 1, W - k + 1
+    M = nimg * tiles_k(H, k) * tiles_k(W, k)
+    dev = x.device
+    st = torch.cuda.current_stream().cuda_stream
+    T = torch.empty(max(lib.eqa_fft48_workspace_bytes(nimg, H, OW, Cin, k), 4) // 4, dtype=torch.float32, device=dev)
+    V = spectra_buffer(M, 2 * Cin, dev)
+    with torch.cuda.device(dev):
+        with _timed("fft_input"):
+            _lib.check(lib.eqa_fft48_input(x.data_ptr(), T.data_ptr(), V.data_ptr(), in_bias.data_ptr() if in_bias is not None else None,
+                                           int(in_relu), nimg, H, W, Cin, k, st), "eqa_fft48_input")
+        del T
+        with _timed("fft_gemm"):
+            Mo = contract(V, B, M)
+        if keep_V is not None:
+            keep_V.append(V)
+        del V
+        T2 = torch.empty(max(lib.eqa_fft48_workspace_bytes(nimg, OH, OW, Cout, k), 4) // 4, dtype=torch.float32, device=dev)
+        y = torch.empty((nimg, Cout, OH, OW), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        with _timed("fft_output"):
+            _lib.check(lib.eqa_fft48_output(Mo.data_ptr(), T2.data_ptr(), bias.data_ptr() if bias is not None else None, int(relu),
+                                            y.data_ptr(), nimg, OH, OW, Cout, k, st), "eqa_fft48_output")
+    return y
+
+
+def grad_spectra_k(dy: torch.Tensor, k: int) -> torch.Tensor:
+    if k == 5:
+        return grad_spectra(dy)
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    M = nimg * tiles_k(OH + k - 1, k) * tiles_k(OW + k - 1, k)
+    T = torch.empty(max(lib.eqa_fft48_workspace_bytes(nimg, OH, OW, Cout, k), 4) // 4, dtype=torch.float32, device=dy.device)
+    G = spectra_buffer(M, 2 * Cout, dy.device)
+    with torch.cuda.device(dy.device):
+        _lib.check(lib.eqa_fft48_grad_transform(dy.data_ptr(), T.data_ptr(), G.data_ptr(), nimg, OH, OW, Cout, k,
+                                                torch.cuda.current_stream().cuda_stream), "eqa_fft48_grad_transform")
+    return G
+
+
+def filter_grad_k(V: torch.Tensor, dy: torch.Tensor, cin: int, k: int, G: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if k == 5:
+        return filter_grad(V, dy, cin, G)
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    dev = dy.device
+    M = V.shape[1]
+    assert V.shape == (F, M, 2 * cin) and M == nimg * tiles_k(OH + k - 1, k) * tiles_k(OW + k - 1, k)
+    st = torch.cuda.current_stream().cuda_stream
+    if G is None:
+        G = grad_spectra_k(dy, k)
+    dbank = torch.empty((Cout, cin, k, k), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if GEMM == "3m" and lib.eqa_fft48k5_wgrad3m_supported(cin, Cout) and os.environ.get("EQA_FFT_WGRAD3M", "1") != "0":
+            D = torch.empty((F, cin, 2, Cout), dtype=torch.float32, device=dev)
+            _lib.check(lib.eqa_fft48k5_wgrad3m(V.data_ptr(), G.data_ptr(), D.data_ptr(), M, cin, Cout, st), "eqa_fft48k5_wgrad3m")
+            _lib.check(lib.eqa_fft48_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, k, 1, st), "eqa_fft48_filter_grad")
+            return dbank
+        D = torch.bmm(V.transpose(1, 2), G)
+        _lib.check(lib.eqa_fft48_filter_grad(D.data_ptr(), dbank.data_ptr(), Cout, cin, k, 0, st), "eqa_fft48_filter_grad")
+    return dbank
+
+
+def input_grad_k(dy: torch.Tensor, bank: torch.Tensor, G: Optional[torch.Tensor] = None) -> torch.Tensor:
+    k = bank.shape[-1]
+    if k == 5:
+        return input_grad(dy, bank, G)
+    lib = _lib.load()
+    nimg, Cout, OH, OW = dy.shape
+    Cin = bank.shape[1]
+    dev = dy.device
+    if G is None:
+        G = grad_spectra_k(dy, k)
+    B2 = spectra_for_k(bank.detach().permute(1, 0, 2, 3).contiguous(), correlate=False)
+    st = torch.cuda.current_stream().cuda_stream
+    H, W = OH + k - 1, OW + k - 1
+    dx = torch.empty((nimg, Cin, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    with torch.cuda.device(dev):
+        Cg = contract(G, B2, G.shape[1])
+        T2 = torch.empty(max(lib.eqa_fft48_workspace_bytes(nimg, N * tiles_k(H, k), OW, Cin, k), 4) // 4, dtype=torch.float32, device=dev)
+        _lib.check(lib.eqa_fft48_input_grad(Cg.data_ptr(), T2.data_ptr(), dx.data_ptr(), nimg, H, W, Cin, k, st), "eqa_fft48_input_grad")
+    return dx
+
+
+class ConvKxKFunction(torch.autograd.Function):
+    """y = conv2d(x, bank) (k x k, stride 1, no padding, channels-last) as an FFT convolution with both gradients in the frequency
+    domain (one transform of the output gradient's disjoint tiles serves both) -- `winograd.Conv5x5Function`'s FFT branch for
+    the kernel sizes Winograd F(m, 5) does not cover."""
+
+    @staticmethod
+    def forward(ctx, x, bank):
+        keep: list = []
+        k = bank.shape[-1]
+        y = conv_kxk(x, spectra_for_k(bank.detach()), k, None, False, keep_V=keep)
+        ctx.save_for_backward(bank, *keep)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        bank, V = ctx.saved_tensors
+        k = bank.shape[-1]
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        G = grad_spectra_k(dy, k)
+        dx = input_grad_k(dy, bank, G) if ctx.needs_input_grad[0] else None
+        dbank = filter_grad_k(V, dy, bank.shape[1], k, G).to(bank.dtype) if ctx.needs_input_grad[1] else None
+        return dx, dbank

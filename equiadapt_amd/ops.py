@@ -10,6 +10,9 @@ import torch
 from equiadapt_amd import _lib
 
 
+MAX_WINDOW_K = 10   # == kMaxWinK (csrc/eqa_common.hpp): the largest window the window-sum kernels take (the linearised last layer)
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 

@@ -479,6 +479,35 @@ int eqa_fft48k5_input_grad(const float* Cg, float* T2, float* dx, int nimg, int 
 int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int relu, double* S, void* workspace, int nimg,
                             int OH, int OW, int C, int k_next, void* stream);
 
+/*
+ * I2a / I2b for the kernel sizes other than 5 (round 4).  The reference's kernel_size is a free constructor argument
+ * (escnn_networks.py:19-44, custom_equivariant_networks.py:25-62): its tutorial trains ESCNNEquivariantNetwork with k = 9
+ * (tutorials/images/understanding_discrete_canonicalization.ipynb cell 17), its own test builds k = 3
+ * (tests/images/canonicalization/test_discrete_group.py:31-38).  Same overlap-save scheme as eqa_fft48k5_*, with
+ * O = 49 - ksize outputs per 48 x 48 tile (46 / 44 / 42 / 40 for ksize 3 / 5 / 7 / 9; tiles per axis eqa_fft48_tiles(n, ksize) =
+ * ceil((n - ksize + 1) / O)), the same stored frequencies, buffer pitch (eqa_fft48k5_tile_pitch) and row layouts, so the
+ * k-independent contractions (eqa_fft48k5_cgemm3m, eqa_fft48k5_wgrad3m, or the caller's batched GEMM) apply unchanged.
+ * Two-pass kernels (one thread per channel); arguments as their eqa_fft48k5_* namesakes plus `ksize`:
+ *   eqa_fft48_supported        1 for ksize in {3, 5, 7, 9}
+ *   eqa_fft48_workspace_bytes  T / T2 sizes (out_cols = the OUTPUT width of the convolution, as for k = 5)
+ *   eqa_fft48_filter_spectra / _filter_spectra3m   bank:(Cout,Cin,ksize,ksize) -> B / B3
+ *   eqa_fft48_input            x:(nimg,H,W,C) -> V            eqa_fft48_output       Mo -> y:(nimg,OH,OW,C) = [relu](ifft + bias)
+ *   eqa_fft48_grad_transform   dy -> G (disjoint O x O tiles)  eqa_fft48_input_grad   Cg -> dx:(nimg,OH+ksize-1,OW+ksize-1,C)
+ *   eqa_fft48_filter_grad      D -> dbank:(Cout,Cin,ksize,ksize); packed = 1: D in the eqa_fft48k5_wgrad3m form
+ */
+int eqa_fft48_supported(int ksize);
+int64_t eqa_fft48_tiles(int n, int ksize);
+int64_t eqa_fft48_workspace_bytes(int nimg, int rows, int out_cols, int C, int ksize);
+int eqa_fft48_filter_spectra(const float* bank, float* B, int Cout, int Cin, int ksize, int correlate, void* stream);
+int eqa_fft48_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int ksize, int correlate, void* stream);
+int eqa_fft48_input(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C, int ksize,
+                    void* stream);
+int eqa_fft48_grad_transform(const float* dy, float* T, float* G, int nimg, int OH, int OW, int C, int ksize, void* stream);
+int eqa_fft48_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C, int ksize,
+                     void* stream);
+int eqa_fft48_input_grad(const float* Cg, float* T2, float* dx, int nimg, int H, int W, int C, int ksize, void* stream);
+int eqa_fft48_filter_grad(const float* D, float* dbank, int Cout, int Cin, int ksize, int packed, void* stream);
+
 /* I4 alone: gidx[b] = argmax_g act[b,g] (first index on ties); act:(B,G). */
 int eqa_group_argmax(const float* act, int32_t* gidx, int B, int G, void* stream);
 

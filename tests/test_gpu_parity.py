@@ -341,7 +341,7 @@ def test_window_sums_matches_unfold(dev):
     from equiadapt_amd import ops
 
     torch.manual_seed(11)
-    for (B, C, H, W, k) in [(3, 5, 20, 24, 5), (2, 8, 88, 88, 5), (4, 3, 9, 9, 1), (1, 2, 17, 13, 3)]:
+    for (B, C, H, W, k) in [(3, 5, 20, 24, 5), (2, 8, 88, 88, 5), (4, 3, 9, 9, 1), (1, 2, 17, 13, 3), (2, 4, 30, 26, 9), (1, 3, 19, 40, 10), (2, 6, 15, 15, 8)]:
         x = torch.randn(B, C, H, W)
         scale, shift = torch.rand(C) + 0.5, torch.randn(C) * 0.3
         got = ops.window_sums(x.to(dev), k, scale.to(dev), shift.to(dev), relu=True).cpu()
@@ -362,7 +362,8 @@ def test_window_sums_channels_last_few_channels(dev):
 
     torch.manual_seed(13)
     for (B, C, H, W, k) in [(3, 32, 28, 28, 1), (2, 8, 30, 37, 3), (2, 16, 12, 9, 5), (1, 64, 20, 21, 5), (2, 128, 11, 50, 3), (2, 48, 14, 14, 3),
-                            (1, 512, 10, 12, 1), (5, 32, 9, 200, 5)]:
+                            (1, 512, 10, 12, 1), (5, 32, 9, 200, 5), (3, 64, 48, 48, 9), (2, 16, 17, 23, 9), (2, 32, 40, 19, 10),
+                            (2, 24, 30, 30, 7), (1, 8, 15, 16, 8)]:
         x = torch.randn(B, C, H, W).to(dev).contiguous(memory_format=torch.channels_last)
         scale, shift = (torch.rand(C) + 0.5).to(dev), (torch.randn(C) * 0.3).to(dev)
         assert not x.is_contiguous() or C == 1
@@ -1787,6 +1788,100 @@ def test_escnn_network_inference_paths_match_oracle_sweep(dev, group_type, N, ou
     assert got.shape == want.shape
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("k,nimg,cin,cout,hw", [(9, 6, 64, 64, (56, 56)), (9, 3, 32, 64, (60, 97)), (7, 4, 64, 128, (54, 48)), (3, 5, 64, 64, (50, 93)),
+                                                 (3, 2, 24, 40, (20, 31)), (7, 2, 16, 16, (90, 17)), (9, 2, 8, 12, (48, 49))])
+def test_fft_convolution_any_kernel_size_matches_conv2d_with_gradients(dev, k, nimg, cin, cout, hw):
+    """eqa_fft48_* (kernel sizes 3 / 7 / 9: 46 / 42 / 40 outputs per 48 x 48 tile): forward, input gradient and filter gradient of
+    y = conv2d(x, bank) against an fp64 convolution + autograd -- channel counts with (64 / 64, 64 / 128, 32 / 64) and without
+    (24 / 40, 16 / 16, 8 / 12) the hand-written complex GEMM, maps that one tile covers, that need partial last tiles, and whose
+    tile grid is wider than high; previous layer's bias + ReLU on the loads and this layer's on the way out (inference form).
+    Reference arithmetic: the dense conv2d of R2Conv for any kernel_size (escnn_networks.py:19-91)."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    torch.manual_seed(k * 100 + cin)
+    H, W = hw
+    x = torch.randn(nimg, cin, H, W)
+    bank = torch.randn(cout, cin, k, k) * (1.0 / (cin * k * k)) ** 0.5
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = bank.to(dev).requires_grad_(True)
+    y = fftconv.ConvKxKFunction.apply(xd, bd)
+    x64, b64 = x.double().requires_grad_(True), bank.double().requires_grad_(True)
+    y64 = torch.nn.functional.conv2d(x64, b64)
+    assert y.shape == y64.shape
+    sy = y64.abs().max().item()
+    assert (y.detach().cpu().double() - y64.detach()).abs().max().item() <= 2e-6 * sy
+    g = torch.randn(y64.shape)
+    y.backward(g.to(dev))
+    y64.backward(g.double())
+    assert (xd.grad.cpu().double() - x64.grad).abs().max().item() <= 4e-6 * x64.grad.abs().max().item()
+    assert (bd.grad.cpu().double() - b64.grad).abs().max().item() <= 1e-5 * b64.grad.abs().max().item()
+    # inference form: act(x) = relu(x + in_bias) on the loads, bias + ReLU on the output
+    ib, ob = torch.randn(cin) * 0.3, torch.randn(cout) * 0.3
+    with torch.no_grad():
+        got = fftconv.conv_kxk(xd.detach(), fftconv.spectra_for_k(bd.detach()), k, ob.to(dev), True, ib.to(dev), True).cpu().double()
+        want = torch.relu(torch.nn.functional.conv2d(torch.relu(x.double() + ib.double()[None, :, None, None]), bank.double())
+                          + ob.double()[None, :, None, None])
+    assert (got - want).abs().max().item() <= 3e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("group_type,N,out_ch,k,layers,res,B", [
+    ("rotation", 4, 16, 9, 3, 64, 16),         # the reference tutorial's canonicalization network (cell 17): FFT hidden layer, k = 9 window-sum tail
+    ("rotation", 4, 16, 7, 3, 64, 8),
+    ("rotation", 8, 32, 3, 3, 96, 8),          # k = 3 at 256 channels: the cost model picks the FFT path
+    ("rotation", 4, 8, 3, 3, 40, 4),           # the reference's own test configuration (tests/images/canonicalization/test_discrete_group.py:31-38): library path
+    ("roto-reflection", 4, 8, 9, 2, 48, 8),    # two layers: lifting layer straight into the k = 9 tail
+])
+def test_escnn_network_other_kernel_sizes_match_oracle(dev, group_type, N, out_ch, k, layers, res, B):
+    """ESCNNEquivariantNetwork with kernel sizes other than 5 (the constructor argument is free in the reference,
+    escnn_networks.py:19-44): eval-mode activations against the oracle's op-by-op restatement, and the training step's
+    activations + parameter gradients through the fast path against the module path (autograd through conv2d)."""
+    import copy
+
+    import equiadapt_amd as ea
+    from oracle import nets as onets
+
+    torch.manual_seed(res + k)
+    net = ea.ESCNNEquivariantNetwork((3, res, res), out_channels=out_ch, kernel_size=k, group_type=group_type, num_rotations=N, num_layers=layers)
+    with torch.no_grad():
+        for m in net.modules():
+            if hasattr(m, "running_mean") and m.running_mean is not None:
+                m.running_mean.uniform_(-0.05, 0.05)
+                m.running_var.uniform_(0.8, 1.2)
+    sd = {kk: v.detach().clone() for kk, v in net.state_dict().items()}
+    net = net.to(dev).eval()
+    x = torch.randn(B, 3, res, res)
+    with torch.no_grad():
+        got = net(x.to(dev)).cpu()
+        want = onets.escnn_like_network(x, sd, group_type, N, layers, out_ch)
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item() / scale
+    # training: fast path vs module path, dropout off so that the two draw no different masks
+    fast, slow = copy.deepcopy(net).train(), copy.deepcopy(net).train()
+    for m in list(fast.modules()) + list(slow.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    wgt = torch.randn(B, net.num_group_elements, device=dev)
+    a_fast = fast(x.to(dev))
+    (a_fast * wgt).sum().backward()
+    import os
+    os.environ["EQA_TRAIN_FAST"] = "0"
+    try:
+        a_slow = slow(x.to(dev))
+        (a_slow * wgt).sum().backward()
+    finally:
+        del os.environ["EQA_TRAIN_FAST"]
+    assert (a_fast - a_slow).abs().max().item() <= 5e-5 * a_slow.abs().max().item()
+    gscale = max(p.grad.abs().max().item() for p in slow.parameters() if p.grad is not None)
+    for (n1, p1), (_, p2) in zip(fast.named_parameters(), slow.named_parameters()):
+        if p2.grad is None:
+            continue
+        assert p1.grad is not None, n1
+        # (a hidden layer's convolution bias cancels inside the batch-norm behind it: the module path leaves rounding noise there,
+        # the fast path an exact zero -- hence the floor relative to the largest gradient of the network)
+        assert (p1.grad - p2.grad).abs().max().item() <= 2e-3 * max(p2.grad.abs().max().item(), 1e-2 * gscale), \
+            (n1, (p1.grad - p2.grad).abs().max().item(), p2.grad.abs().max().item())
 
 
 @pytest.mark.parametrize("group_type,N,C,Cf,rep,hw", [("rotation", 8, 3, 3, "scalar", (224, 224)), ("rotation", 8, 3, 8, "regular", (64, 64)),
