@@ -100,7 +100,11 @@ __device__ __forceinline__ bool block_tile(const int n_out, const int bz, int& n
 // Sampling arithmetic = torch affine_grid + grid_sample(bilinear, zeros, align_corners=True) on the
 // (Hp, Wp) frame, the frame itself being the edge-replicated (pad) and optionally h-flipped source.
 // `bz` = the block's image-group index (blockIdx.z of a single job; blockIdx.z minus the first job's groups in a pair launch).
-template <int CH, bool VEC>
+// MODE 0: the action itself (dst).  MODE 1: its derivative with respect to the rotation angle contracted with an output gradient
+// (a.gout), one partial sum per (output image, tile) in a.partial -- the training step's angle gradient, with the same staged window
+// (the derivative samples the same four neighbours the forward blends): round 3's group_action_bwd_kernel<1, false> gathered them
+// from global memory, 119-169 us per 256 images; it remains the fallback for forced-direct runs and the reference of the tests.
+template <int CH, bool VEC, int MODE = 0>
 __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int bz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int kPlane = kBox * kLdsStride;
@@ -187,10 +191,20 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
       // (pixels of a partial tile beyond OW/OH are computed but never stored: keep their reads in the window)
       const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
       lidx[k] = ly * (CH * kLdsStride) + lx;
-      w00[k] = wy0 * wx0;  // nw
-      w01[k] = wy0 * wx1;  // ne
-      w10[k] = wy1 * wx0;  // sw
-      w11[k] = wy1 * wx1;  // se
+      if (MODE == 0) {
+        w00[k] = wy0 * wx0;  // nw
+        w01[k] = wy0 * wx1;  // ne
+        w10[k] = wy1 * wx0;  // sw
+        w11[k] = wy1 * wx1;  // se
+      } else {
+        // the angle derivative needs the fractional parts themselves and the lever arm of the sample point about the frame
+        // centre (ds/dphi = (-(s_y - c_y), s_x - c_x) per radian; see group_action_bwd_kernel)
+        live[k] = live[k] && (pi < a.OH) && (pj + k < a.OW);
+        w00[k] = wx1;
+        w01[k] = wy1;
+        w10[k] = -(iy - a.half_h);
+        w11[k] = ix - a.half_w;
+      }
     }
   };
 
@@ -337,8 +351,72 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
     pixel_setup(pi, pj);
   }
 
+  float angle_sum = 0.0f;   // MODE 1
   for (int c0 = 0; c0 < a.C; c0 += CH) {
     float acc[CH][4];
+    if (MODE == 1) {
+      const float* const gout_img = a.gout + (size_t)n * ((size_t)a.C * dst_plane);
+      if (!use_lds) {
+        // window too large for LDS (never for a rotation) or forced: everything from global memory, pixel by pixel in ROLLED loops
+        // with the coordinates recomputed per pixel -- slow and rare, and it must not inflate the staged path's register budget
+        if (c0 > 0) stage_planes(c0, planes);
+#pragma unroll 1
+        for (int cc = 0; cc < CH; ++cc) {
+          if (c0 + cc >= a.C) break;
+          const float* pl = cc == 0 ? planes[0] : (cc == 1 ? planes[CH > 1 ? 1 : 0] : planes[CH > 2 ? 2 : 0]);
+#pragma unroll 1
+          for (int k = 0; k < 4; ++k) {
+            const float yn = lin_m1_p1(a.top + i, a.Hp, a.step_y), xn = lin_m1_p1(frame_x(jb + k), a.Wp, a.step_x);
+            const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w, iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+            const float xf = floorf(ix), yf = floorf(iy);
+            const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1)), yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+            const bool lv = xin && yin && row_ok && (jb + k < a.OW);
+            const int gx = xin ? (int)xf : -1, gy = yin ? (int)yf : -1;
+            bool in00, in01, in10, in11;
+            const int o00 = src_offset(gy, gx, in00), o01 = src_offset(gy, gx + 1, in01);
+            const int o10 = src_offset(gy + 1, gx, in10), o11 = src_offset(gy + 1, gx + 1, in11);
+            const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
+            const float g = gout_img[(unsigned)(c0 + cc) * dst_plane + (lv ? (unsigned)(i * a.OW + jb + k) : 0u)];
+            const float nw = in00 ? v00 : 0.0f, ne = in01 ? v01 : 0.0f, sw = in10 ? v10 : 0.0f, se = in11 ? v11 : 0.0f;
+            const float wx1 = ix - xf, wy1 = iy - yf, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+            const float dix = wy0 * (ne - nw) + wy1 * (se - sw), diy = wx0 * (sw - nw) + wx1 * (se - ne);
+            angle_sum += lv ? g * (dix * (-(iy - a.half_h)) + diy * (ix - a.half_w)) : 0.0f;
+          }
+        }
+        continue;
+      }
+      // the output gradient of this stage's channels (a dead pixel reads the plane's first value), requested before the wait
+      // for the window so that both are in flight together; same order of additions as group_action_bwd_kernel<1, false>
+      float gv[CH][4];
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const unsigned cpl = (unsigned)min(c0 + cc, a.C - 1) * dst_plane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gv[cc][k] = gout_img[cpl + (live[k] ? (unsigned)(i * a.OW + jb + k) : 0u)];
+      }
+      if (c0 > 0) {
+        stage_planes(c0, planes);
+        __syncthreads();
+        stage_issue(planes);
+      }
+      stage_wait();
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const float* s = smem + cc * kLdsStride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
+          const float sw = s[lidx[k] + CH * kLdsStride], se = s[lidx[k] + CH * kLdsStride + 1];
+          const float wx1 = w00[k], wy1 = w01[k];
+          const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+          const float dix = wy0 * (ne - nw) + wy1 * (se - sw);
+          const float diy = wx0 * (sw - nw) + wx1 * (se - ne);
+          // (a dead pixel contributes nothing -- a select, not g = 0: a non-finite neighbour must not turn 0 * inf into NaN)
+          if (c0 + cc < a.C) angle_sum += live[k] ? gv[cc][k] * (dix * w10[k] + diy * w11[k]) : 0.0f;
+        }
+      }
+      continue;
+    }
     if (use_lds) {
       if (c0 > 0) {
         stage_planes(c0, planes);
@@ -420,11 +498,26 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
       }
     }
   }
+  if (MODE == 1) {
+    __shared__ float s_red[kThreads / 64];
+    const float w = wave_sum_f(angle_sum);
+    if (lane == 0) s_red[wave] = w;
+    __syncthreads();
+    if (tid == 0) {
+      const int tiles_x = (int)(gridDim.x >> 3);
+      a.partial[((size_t)n * gridDim.y + tile_y) * tiles_x + tile_x] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+  }
 }
 
 template <int CH, bool VEC>
 __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_kernel(const ActionArgs a) {
   group_action_body<CH, VEC>(a, (int)blockIdx.z);
+}
+
+template <int CH>
+__global__ __launch_bounds__(kThreads) void group_action_angle_kernel(const ActionArgs a) {
+  group_action_body<CH, false, 1>(a, (int)blockIdx.z);
 }
 
 // Two jobs with the same tile grid in ONE launch (eqa_group_action_pair: canonicalize x / invert f with the same group
@@ -920,8 +1013,13 @@ __global__ __launch_bounds__(kThreads, (NL > 5 && K > 5) ? 2 : 4) void crop_resi
   float* tmp = aa_tmp + (size_t)cap_rows * xl;
   float* tabw = tmp + (size_t)cap_rows * OW;                              // [BAND][K] vertical weights of the band
   int* taby = reinterpret_cast<int*>(tabw + BAND * K);  // [BAND] first input row of each output row
-  const int r0 = blockIdx.x * BAND, r1 = min(r0 + BAND, OH);
+  // grid (8, bands, plane groups): blockIdx.x is the XCD the dispatcher deals the block to (x is the fastest grid axis and 8 wide),
+  // so the bands of one plane -- whose input rows overlap by K - 1 and share the cache lines at the window's edges -- are worked on
+  // by blocks of ONE XCD at about the same time and meet in its L2 (round 3: band b of every plane on XCD b % 8, the overlap rows
+  // fetched from HBM twice: 1.38 x the algorithmic bytes)
+  const int r0 = blockIdx.y * BAND, r1 = min(r0 + BAND, OH);
   const int nband = r1 - r0;
+  const int plane0 = (int)(blockIdx.z * kXcd + blockIdx.x), plane_step = (int)(gridDim.z * kXcd);
   const int rows_par = kThreads / OW;
   const int ox = rows_par >= 1 ? threadIdx.x % OW : 0, rsub = rows_par >= 1 ? threadIdx.x / OW : 0;
   const int xs_g = x0[ox];
@@ -954,15 +1052,15 @@ __global__ __launch_bounds__(kThreads, (NL > 5 && K > 5) ? 2 : 4) void crop_resi
   // the tables have arrived before the first row is requested: from here on only row loads are ever outstanding, and the waits
   // the compiler places inside the passes are for those it names (a pending table load made them vmcnt(0): the prefetch drained)
   __builtin_amdgcn_s_waitcnt(0x0070);
-  if (prefetch) EQA_AA_PF_LOAD(blockIdx.y);
-  for (int plane = blockIdx.y; plane < planes; plane += gridDim.y) {
+  if (prefetch && plane0 < planes) EQA_AA_PF_LOAD(plane0);
+  for (int plane = plane0; plane < planes; plane += plane_step) {
     if (prefetch) {
       if (tq < nq) {
 #pragma unroll
         for (int k = 0; k < NL; ++k)
           if (tr + 4 * k < nrows) *reinterpret_cast<aa_f4*>(rows + (tr + 4 * k) * xl + 4 * tq) = v[k];
       }
-      if (plane + (int)gridDim.y < planes) EQA_AA_PF_LOAD(plane + gridDim.y);
+      if (plane + plane_step < planes) EQA_AA_PF_LOAD(plane + plane_step);
     } else {
       const float* src = src0 + (size_t)plane * plane_sz;
       for (int q = tq; q < nq; q += 64)
@@ -1443,6 +1541,21 @@ int launch_nearest(const T* m, T* out, const int32_t* eidx, const float* rtheta,
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
+// dL/d(angle) partials alone: the LDS-staged form (the forward's window, gathered for the derivative), or with eqa_set_option(0, 1)
+// round 3's direct-gather kernel
+int launch_angle_grad(const ActionArgs& a, const dim3& grid, hipStream_t st) {
+  if (a.force_direct) {
+    hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
+    return launch_status();
+  }
+  const int ch = action_ch(a.C);
+  const size_t lds = (size_t)ch * kBox * kLdsStride * sizeof(float) + (a.chan_map ? kMaxMapG * sizeof(int) : 0);
+  if (ch == 3) hipLaunchKernelGGL(group_action_angle_kernel<3>, grid, dim3(kThreads), lds, st, a);
+  else if (ch == 2) hipLaunchKernelGGL(group_action_angle_kernel<2>, grid, dim3(kThreads), lds, st, a);
+  else hipLaunchKernelGGL(group_action_angle_kernel<1>, grid, dim3(kThreads), lds, st, a);
+  return launch_status();
+}
+
 int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, const int32_t* gidx, const float* theta,
                       const int32_t* flags, const int32_t* chan_map, float* grad_src, float* partial, int num_elements, int G,
                       int n_out, int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream) {
@@ -1471,10 +1584,8 @@ int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, co
       hipLaunchKernelGGL((group_action_bwd_gather_kernel<false>), ggrid, dim3(kThreads), 0, st, a);
     if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
     if (!partial) return EQA_OK;
-    if (grad_mode == 1)
-      hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
-    else
-      hipLaunchKernelGGL((group_action_bwd_kernel<2, false>), grid, dim3(kThreads), 0, st, a);
+    if (grad_mode == 1) return launch_angle_grad(a, grid, st);
+    hipLaunchKernelGGL((group_action_bwd_kernel<2, false>), grid, dim3(kThreads), 0, st, a);
     return launch_status();
   }
   if (!partial)
@@ -1482,7 +1593,7 @@ int launch_action_bwd(int grad_mode, const float* src, const float* grad_out, co
   else if (grad_mode == 1 && grad_src)
     hipLaunchKernelGGL((group_action_bwd_kernel<1, true>), grid, dim3(kThreads), 0, st, a);
   else if (grad_mode == 1)
-    hipLaunchKernelGGL((group_action_bwd_kernel<1, false>), grid, dim3(kThreads), 0, st, a);
+    return launch_angle_grad(a, grid, st);
   else if (grad_src)
     hipLaunchKernelGGL((group_action_bwd_kernel<2, true>), grid, dim3(kThreads), 0, st, a);
   else
@@ -1644,26 +1755,31 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
   if (!staged_off && K <= EQA_AA_WIDE_MIN_K && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0 && x_span > 0 && x_begin >= 0 &&
       x_begin + x_span <= W) {
     const int xb = x_begin & ~3, xl = std::min(W, (x_begin + x_span + 3) & ~3) - xb;
-    static const int band_env = [] { const char* e = getenv("EQA_AA_BAND"); return e ? atoi(e) : 8; }();
-    const int band = band_env == 16 ? 16 : 8;
+    // 16 output rows per block where the map has at least four such bands: 4 of 34 staged rows are shared with the next band instead of
+    // 4 of 19 (with the bands of a plane on one XCD -- round 4 -- 35.9 us per 256 x 3 planes of 224 -> 180 -> 96 against 39-40 for
+    // bands of 8; before that mapping the larger band was the slower one).  EQA_AA_BAND=8 / 16 forces either.
+    static const int band_env = [] { const char* e = getenv("EQA_AA_BAND"); return e ? atoi(e) : 0; }();
+    int band = band_env == 16 ? 16 : (band_env == 8 ? 8 : (OH >= 64 ? 16 : 8));
+    auto staged_lds = [&](int bnd) { return ((size_t)(bnd / kAaBand) * max_rows * (xl + OW) + bnd * (EQA_AA_WIDE_MIN_K + 1)) * sizeof(float); };
+    if (band == 16 && band_env != 16 && (staged_lds(16) > 64 * 1024 || 16 * K > kThreads)) band = 8;   // the smaller band may still fit
     const int cap_rows = (band / kAaBand) * max_rows;   // a band of 16 rows = two of the 8-row bands `max_rows` was taken over
-    const size_t lds3 = ((size_t)cap_rows * (xl + OW) + band * (EQA_AA_WIDE_MIN_K + 1)) * sizeof(float);
+    const size_t lds3 = staged_lds(band);
     if (lds3 <= 64 * 1024 && band * K <= kThreads) {
       // persistent over planes: about 8 resident blocks per CU in all, each walking planes with a stride of gridDim.y
-      static const int per_cu = [] { const char* e = getenv("EQA_AA_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 8; }();
+      static const int per_cu = [] { const char* e = getenv("EQA_AA_BLOCKS_PER_CU"); return e ? std::max(1, atoi(e)) : 12; }();
       const int nbands = (OH + band - 1) / band;
-      const int groups = std::max(1, std::min(planes, (256 * per_cu + nbands - 1) / nbands));
+      const int groups = std::max(1, (std::min(planes, (256 * per_cu + nbands - 1) / nbands) + kXcd - 1) / kXcd);   // plane groups of 8 (one plane per XCD)
       const bool few = cap_rows <= 20;   // 5 loads per thread cover the band's rows (else 10: up to 40 rows)
 #define EQA_AA_STAGED(K_)                                                                                                              \
   case K_:                                                                                                                             \
     if (band == 16)                                                                                                                    \
-      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 16, 10>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 16, 10>), dim3(kXcd, nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
                          y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
     else if (few)                                                                                                                      \
-      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 5>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x,  \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 5>), dim3(kXcd, nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x,  \
                          y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
     else                                                                                                                               \
-      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 10>), dim3(nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
+      hipLaunchKernelGGL((crop_resize_aa_staged_kernel<K_, 8, 10>), dim3(kXcd, nbands, groups), dim3(kThreads), lds3, (hipStream_t)stream, x, \
                          y, wx, x0, wy, y0, planes, H, W, OH, OW, cap_rows, xb, xl);                                                   \
     break
       switch (K) {

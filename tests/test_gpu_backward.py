@@ -933,3 +933,41 @@ def test_fft_conv_output_statistics_match_the_stats_pass(dev, B, HW, cin, cout):
     truth = torch.stack([exact.sum(0), (exact * exact).sum(0)], dim=1)
     got = stats[0].sum(0)
     assert (got - truth).abs().max().item() <= 1e-5 * truth[:, 1].max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("group_type,N,C,hw,pad", [("rotation", 8, 3, (224, 224), True), ("roto-reflection", 4, 8, (40, 56), False),
+                                                   ("rotation", 8, 5, (33, 47), True), ("rotation", 4, 2, (64, 64), False)])
+def test_angle_gradient_staged_kernel_equals_the_direct_gather(dev, group_type, N, C, hw, pad):
+    """dL/d(angle) of the group action (what autograd derives through kornia's rotate in discrete_group.py:213 / images/utils.py:57)
+    from the LDS-staged kernel (round 4: the forward's window, its four neighbours gathered for the derivative) against round 3's
+    direct-gather kernel (eqa_set_option(0, 1)): same per-pixel expression, same order of additions -- equal to the last bits of a
+    tile's sum (fma contraction may differ between the two kernels) -- for the edge-padded canonicalizing transform, the un-padded
+    invert action with the regular-representation channel map, channel counts that leave a partial last stage, ragged tiles."""
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import device_tables
+
+    H, W = hw
+    G = N if group_type == "rotation" else 2 * N
+    refl = group_type != "rotation"
+    torch.manual_seed(C + H)
+    B = 2 * G + 3
+    x = torch.randn(B, C, H, W, device=dev)
+    go = torch.randn(B, C, H, W, device=dev)
+    gidx = (torch.arange(B, device=dev) % G).to(torch.int32)
+    if pad:
+        p = math.ceil(W * 0.5)
+        th, fl = device_tables("canonicalize", N, refl, (H + 2 * p, W + 2 * p), dev)
+        args = (x, go, gidx, th, fl, None, p, (p, p), False, True)
+    else:
+        th, fl, cm = device_tables("invert", N, refl, (H, W), dev)
+        args = (x, go, gidx, th, fl, cm if C % G == 0 else None, 0, (0, 0), False, True)
+    _, staged = ops.group_action_bwd(*args)
+    lib = _lib.load()
+    lib.eqa_set_option(0, 1)
+    try:
+        _, direct = ops.group_action_bwd(*args)
+    finally:
+        lib.eqa_set_option(0, 0)
+    scale = direct.abs().max().item()
+    assert (staged - direct).abs().max().item() <= 2e-6 * scale, ((staged - direct).abs().max().item(), scale)
