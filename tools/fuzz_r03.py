@@ -35,6 +35,10 @@ def main():
     counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0, "aa": 0}
     worst = {}
     t_end = time.time() + args.seconds
+    guard = None
+    if os.environ.get("EQA_GUARD", "0") == "1":
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import conftest as guard    # installs the guarded torch.empty / zeros / ... at import
     while time.time() < t_end:
         what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair", "aa"])
         if what in ("knn", "vnsmall"):
@@ -194,8 +198,13 @@ def main():
             y2, o2 = ops.group_action_pair(x, f, gidx, th_c, fl_c, pad, th_i, fl_i, cm)
             assert torch.equal(y1, y2) and torch.equal(o1, o2), ("pair", N, refl, C, Cf, H, B)
         counts[what] += 1
+        if guard is not None:     # EQA_GUARD=1: every buffer the case allocated sits between poisoned bands (tests/conftest.py)
+            bad = guard._guard_check(what)
+            assert not bad, ("guard bands overwritten", what, bad)
     torch.cuda.synchronize()
     print("fuzz ok:", counts, "worst error / allowance:", worst)
+    if guard is not None:
+        print("[guard bands]", guard._guard_stats)
 
 
 if __name__ == "__main__":
