@@ -36,6 +36,7 @@ SIGNATURES = {
     "eqa_group_action_pair": (_int, [_vp] * 4 + [_int, _int] + [_vp] * 5 + [_int, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_orbit_expand_fwd": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_group_action_fwd": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 12 + [_vp]),
+    "eqa_group_action_fwd_hint": (_int, [_vp, _vp, _vp, _vp, _vp, _vp] + [_int] * 13 + [_vp]),
     "eqa_crop_resize_aa": (_int, [_vp] * 6 + [_int] * 9 + [_vp]),
     "eqa_mask_action_nearest": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),
     "eqa_mask_action_nearest_planes": (_int, [_vp] * 5 + [_int] * 4 + [_vp]),

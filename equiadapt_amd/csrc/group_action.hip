@@ -28,6 +28,7 @@ struct ActionArgs {
   int OH, OW, top, left;
   float half_w, half_h, step_x, step_y;
   int force_direct;
+  int lds_rows;       // window rows the launch reserved LDS for (kBox unless the caller bounds the window: eqa_group_action_fwd_hint)
   // backward only
   const float* gout;  // dL/d(output), shape of dst
   float* gsrc;        // dL/d(source), shape of src, pre-zeroed (nullable)
@@ -107,7 +108,6 @@ __device__ __forceinline__ bool block_tile(const int n_out, const int bz, int& n
 template <int CH, bool VEC, int MODE = 0>
 __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int bz) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  constexpr int kPlane = kBox * kLdsStride;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   const int x_hi = max((int)floorf(fmn(maxx_f, (float)(a.Wp - 1))) + 1, x_lo + 1);
   const int y_hi = max((int)floorf(fmn(maxy_f, (float)(a.Hp - 1))) + 1, y_lo + 1);
   const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
-  const bool use_lds = (bw <= kBox) && (bh <= kBox) && !a.force_direct;
+  const bool use_lds = (bw <= kBox) && (bh <= a.lds_rows) && !a.force_direct;
 
   // ---- per-thread output pixels
   const int r = tid >> 3, q = tid & 7;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   };
 
   // the element's channel-map row (regular features) goes to LDS once
-  int* s_cmap = reinterpret_cast<int*>(smem + CH * kPlane);
+  int* s_cmap = reinterpret_cast<int*>(smem + CH * a.lds_rows * kLdsStride);
   const bool has_cmap = a.chan_map != nullptr;
   if (has_cmap) {
     if (tid < a.G) s_cmap[tid] = a.chan_map[e * a.G + tid];
@@ -814,7 +814,7 @@ int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   const int groups = (a.n_out + kXcd - 1) / kXcd;
   if (tiles_y > 65535 || groups > 65535) return EQA_ERR_UNSUPPORTED;
   const dim3 grid((unsigned)(kXcd * tiles_x), (unsigned)tiles_y, (unsigned)groups);
-  const size_t lds = (size_t)CH * kBox * kLdsStride * sizeof(float) + (a.chan_map ? kMaxMapG * sizeof(int) : 0);
+  const size_t lds = (size_t)CH * a.lds_rows * kLdsStride * sizeof(float) + (a.chan_map ? kMaxMapG * sizeof(int) : 0);
   if (vec)
     hipLaunchKernelGGL((group_action_kernel<CH, true>), grid, dim3(kThreads), lds, st, a);
   else
@@ -846,18 +846,22 @@ int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t*
   a.step_x = 2.0f / (float)(Wp - 1);
   a.step_y = 2.0f / (float)(Hp - 1);
   a.force_direct = g_force_direct;
+  a.lds_rows = kBox;
   a.gout = nullptr; a.gsrc = nullptr; a.partial = nullptr;
   return EQA_OK;
 }
 
 int launch_action(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
                   const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W, int pad, int OH,
-                  int OW, int top, int left, void* stream) {
+                  int OW, int top, int left, void* stream, int max_window = 0) {
   if (!dst && n_out != 0) return EQA_ERR_INVALID_ARG;
   ActionArgs a;
   const int rc = fill_action_args(a, src, dst, gidx, theta, flags, chan_map, E, G, n_out, B, C, H, W, pad, OH, OW, top, left);
   if (rc != EQA_OK) return rc;
   if (n_out == 0) return EQA_OK;
+  // the caller's bound on a tile's source window (right-angle elements: 35 rows instead of 47 -> 19.7 KB of LDS per block at three
+  // channels, 8 blocks per CU instead of 6); a window that turns out larger takes the direct path: slow, never wrong
+  if (max_window > 0) a.lds_rows = std::min(std::max(max_window, 2), kBox);
   const bool vec = (OW % 4 == 0) && (((uintptr_t)dst & 15) == 0);
   hipStream_t st = (hipStream_t)stream;
 #if EQA_FORCE_CH
@@ -1673,6 +1677,14 @@ int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, cons
                          int pad, int OH, int OW, int top, int left, void* stream) {
   return launch_action(src, dst, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad, OH, OW, top,
                        left, stream);
+}
+
+int eqa_group_action_fwd_hint(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                              const int32_t* chan_map, int num_elements, int G, int n_out, int B, int C, int H, int W,
+                              int pad, int OH, int OW, int top, int left, int max_window, void* stream) {
+  if (max_window < 0) return EQA_ERR_INVALID_ARG;
+  return launch_action(src, dst, gidx, theta, flags, chan_map, num_elements, G, n_out, B, C, H, W, pad, OH, OW, top, left, stream,
+                       max_window);
 }
 
 int eqa_canon_transform_fwd(const float* x, float* y, const int32_t* gidx, const float* theta, const int32_t* flags,

@@ -23,6 +23,10 @@ def device_tables(kind: str, num_rotations: int, reflections: bool, frame_hw: Tu
         build = {"canonicalize": geometry.canonicalize_tables, "invert": geometry.invert_tables,
                  "orbit": geometry.orbit_tables}[kind]
         hit = tuple(t.to(device) for t in build(num_rotations, reflections, tuple(frame_hw)))
+        if num_rotations in (1, 2, 4):
+            # every element is a multiple of 90 degrees: a 32 x 32 output tile samples a window of at most 35 x 35 source pixels
+            # (ops passes the bound on: eqa_group_action_fwd_hint reserves less LDS per block, more blocks per CU)
+            hit[0].eqa_max_window = 35
         _device_tables[key] = hit
     return hit
 

@@ -186,9 +186,14 @@ def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, fl
     flags, p_flags = _opt(flags, "flags", torch.int32)
     B, C, H, W = x.shape
     y = torch.empty_like(x)
+    hint = int(getattr(theta, "eqa_max_window", 0))     # set by images.utils.device_tables for right-angle groups
     with torch.cuda.device(x.device), _timed("canon_transform"):
-        st = lib.eqa_canon_transform_fwd(x.data_ptr(), y.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags,
-                                         theta.shape[0], B, C, H, W, pad, _stream())
+        if hint > 0 and B > 0:
+            st = lib.eqa_group_action_fwd_hint(x.data_ptr(), y.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, None,
+                                               theta.shape[0], 1, B, B, C, H, W, pad, H, W, pad, pad, hint, _stream())
+        else:
+            st = lib.eqa_canon_transform_fwd(x.data_ptr(), y.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags,
+                                             theta.shape[0], B, C, H, W, pad, _stream())
     _lib.check(st, "eqa_canon_transform_fwd")
     return y
 
@@ -205,9 +210,14 @@ def invert_action(f: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flag
     G = chan_map.shape[1] if chan_map is not None else 1
     B, C, H, W = f.shape
     out = torch.empty_like(f)
+    hint = int(getattr(theta, "eqa_max_window", 0))
     with torch.cuda.device(f.device), _timed("invert_action"):
-        st = lib.eqa_invert_action_fwd(f.data_ptr(), out.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, p_map,
-                                       theta.shape[0], G, B, C, H, W, _stream())
+        if hint > 0 and B > 0:
+            st = lib.eqa_group_action_fwd_hint(f.data_ptr(), out.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, p_map,
+                                               theta.shape[0], G, B, B, C, H, W, 0, H, W, 0, 0, hint, _stream())
+        else:
+            st = lib.eqa_invert_action_fwd(f.data_ptr(), out.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, p_map,
+                                           theta.shape[0], G, B, C, H, W, _stream())
     _lib.check(st, "eqa_invert_action_fwd")
     return out
 

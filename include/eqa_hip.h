@@ -114,6 +114,14 @@ int eqa_orbit_expand_fwd(const float* x, float* y, const float* theta, const int
 int eqa_group_action_fwd(const float* src, float* dst, const int32_t* gidx, const float* theta,
                          const int32_t* flags, const int32_t* chan_map, int num_elements, int G, int n_out,
                          int B, int C, int H, int W, int pad, int OH, int OW, int top, int left, void* stream);
+/* eqa_group_action_fwd with the caller's bound on the source window of a 32 x 32 output tile, in pixels (0: unknown = 47, what an
+ * arbitrary rotation needs).  The elements of C4 / D4 (multiples of 90 degrees -- the reference's num_rotations = 4 configurations,
+ * discrete_group.py:110-112) need 35: the launch then reserves 35 instead of 47 window rows of LDS per block and two more blocks fit
+ * a CU.  A tile whose window exceeds the bound is sampled straight from global memory (same arithmetic, slower): the hint can cost
+ * time, never correctness. */
+int eqa_group_action_fwd_hint(const float* src, float* dst, const int32_t* gidx, const float* theta, const int32_t* flags,
+                              const int32_t* chan_map, int num_elements, int G, int n_out, int B, int C, int H, int W,
+                              int pad, int OH, int OW, int top, int left, int max_window, void* stream);
 
 /*
  * I1 -- centre crop + antialiased bilinear resize of the canonicalization network's input

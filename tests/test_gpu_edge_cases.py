@@ -412,3 +412,51 @@ def test_vnsmall_max_pooling_large_batch_of_large_clouds_takes_the_quad_kernel(d
                 net(x)
     finally:
         _lib.load().eqa_set_option(1, 0)
+
+
+def test_window_hint_changes_the_lds_reservation_not_the_result(dev):
+    """eqa_group_action_fwd_hint: right-angle groups (num_rotations 1 / 2 / 4, discrete_group.py:110-112) reserve 35 window rows of
+    LDS per block instead of 47.  Same tiles, same arithmetic: bit-identical to the plain entry point for C4 / D4 (canonicalize with
+    its edge padding, invert with the regular-representation roll, ragged tiles); and a bound that is too small for the table it
+    is given (C8 with the right-angle bound) still gives the right pixels -- the oversized windows are sampled from global memory."""
+    import math
+
+    from equiadapt_amd import _lib, ops
+    from equiadapt_amd.images.utils import device_tables
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    torch.manual_seed(21)
+    for refl in (False, True):
+        G = 8 if refl else 4
+        for (C, H, W) in ((3, 224, 224), (2, 50, 70), (8, 64, 64)):
+            x = torch.randn(9, C, H, W, device=dev)
+            gidx = (torch.arange(9, device=dev) % G).to(torch.int32)
+            pad = math.ceil(W * 0.5)
+            th, fl = device_tables("canonicalize", 4, refl, (H + 2 * pad, W + 2 * pad), dev)
+            assert getattr(th, "eqa_max_window", 0) == 35
+            y = ops.canon_transform(x, gidx, th, fl, pad)                       # takes the hint
+            y0 = torch.empty_like(x)
+            assert lib.eqa_canon_transform_fwd(x.data_ptr(), y0.data_ptr(), gidx.data_ptr(), th.data_ptr(), fl.data_ptr(), G, 9, C, H, W,
+                                               pad, st) == 0
+            assert torch.equal(y, y0)
+            thi, fli, cm = device_tables("invert", 4, refl, (H, W), dev)
+            use_map = cm if C % G == 0 else None
+            out = ops.invert_action(x, gidx, thi, fli, use_map)
+            out0 = torch.empty_like(x)
+            assert lib.eqa_invert_action_fwd(x.data_ptr(), out0.data_ptr(), gidx.data_ptr(), thi.data_ptr(), fli.data_ptr(),
+                                             use_map.data_ptr() if use_map is not None else None, G, G if use_map is not None else 1,
+                                             9, C, H, W, st) == 0
+            assert torch.equal(out, out0)
+    # a bound too small for the table: C8 with 35 rows -- the 45-degree tiles fall back to the direct path
+    x = torch.randn(8, 3, 96, 96, device=dev)
+    gidx = torch.arange(8, device=dev, dtype=torch.int32)
+    th8, fl8 = device_tables("canonicalize", 8, False, (192, 192), dev)
+    assert not hasattr(th8, "eqa_max_window")
+    want = ops.canon_transform(x, gidx, th8, fl8, 48)
+    got = torch.empty_like(x)
+    assert lib.eqa_group_action_fwd_hint(x.data_ptr(), got.data_ptr(), gidx.data_ptr(), th8.data_ptr(), fl8.data_ptr(), None, 8, 1, 8, 8, 3,
+                                         96, 96, 48, 96, 96, 48, 48, 35, st) == 0
+    assert (got - want).abs().max().item() <= 2e-6
+    assert lib.eqa_group_action_fwd_hint(x.data_ptr(), got.data_ptr(), gidx.data_ptr(), th8.data_ptr(), fl8.data_ptr(), None, 8, 1, 8, 8, 3,
+                                         96, 96, 48, 96, 96, 48, 48, -1, st) == -1
