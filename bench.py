@@ -592,11 +592,41 @@ def leg_configs(comm: Comm, with_cpu: bool):
         n_mk, ms_mk = ks.get("mask_action", (0, float("nan")))
         ach = B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct * 1e-3) / 1e9
         ach_m = B * 3 * 2 * 1024 * 1024 / (ms_mk * 1e-3) / 1e9
+        # The per-launch HIP-event bracket carries a fixed cost (an EMPTY bracket measures ~4.8 us on this runtime, a 256 MB fill
+        # 2 us more than back to back: tools/event_overhead.py) that is negligible for the headline's 58 us kernel and a fifth of
+        # these launches at B = 4.  The same two kernels launched 30 times between one pair of events, same tensors:
+        from equiadapt_amd.images import geometry
+        from equiadapt_amd.images.utils import device_tables
+        g5 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        th5, fl5 = device_tables("canonicalize", 4, True, (2048, 2048), dev)
+        mcat = torch.cat(masks, dim=0).contiguous()
+        e5 = (g5 % 4).repeat_interleave(3)
+        rth5 = geometry.mask_rotation_table((-geometry.group_angles(4)).tolist(), (1024, 1024)).to(dev)
+        mfl5 = torch.full((4,), geometry.FLIP_SRC, dtype=torch.int32, device=dev)
+
+        def b2b(fn, reps=30):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        with torch.no_grad():
+            ms_ct_b2b = b2b(lambda: ops.canon_transform(x, g5, th5, fl5, 512))
+            ms_mk_b2b = b2b(lambda: ops.mask_action_nearest(mcat, e5, rth5, mfl5))
+        del mcat
         c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
             "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct},
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct,
+            "back_to_back_ms": ms_ct_b2b, "frac_back_to_back": B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "mask_kernel": {"kernel": "mask_action_u8_kernel via eqa_mask_action_nearest_planes (2 B / mask pixel)", "achieved": ach_m,
-                            "unit": "GB/s", "frac": ach_m / HBM_PEAK_GBS, "avg_launch_ms": ms_mk}}
+                            "unit": "GB/s", "frac": ach_m / HBM_PEAK_GBS, "avg_launch_ms": ms_mk,
+                            "back_to_back_ms": ms_mk_b2b, "frac_back_to_back": B * 3 * 2 * 1024 * 1024 / (ms_mk_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "back_to_back_*: the same kernel 30 times between one pair of events (masks concatenated); "
+                                    "frac / avg_launch_ms: one HIP-event bracket per launch inside the timed step"}}
         if B == 4:   # BASELINE's own batch: the whole step (image, masks, boxes, invert) captured once and replayed as a hipGraph
             from equiadapt_amd.graphs import GraphedCanonicalizer
 

@@ -1186,6 +1186,77 @@ __global__ __launch_bounds__(kThreads) void fft48_filter_grad_kernel(const float
   for (int i = 0; i < KS * KS; ++i) o[i] = (float)(acc[i] * inv);
 }
 
+// The same reduction with one thread per (ci, co, filter ROW u = blockIdx.z): KS x the blocks and 1 / KS of the accumulators.  With
+// few channels the kernel above is a handful of blocks of long serial threads (64 x 64 channels at k = 9: 64 blocks, 81 fp64
+// accumulators per thread, 0.52 ms -- 5 % of the reference tutorial's training step); the KS rows re-read D from L2.  Same sums
+// in the same order per element, so both forms give identical filters.
+template <bool PACKED, int KS>
+__global__ __launch_bounds__(kThreads) void fft48_filter_grad_rows_kernel(const float* __restrict__ D, float* __restrict__ dbank, int Cout,
+                                                                         int Cin, int Gin, int Gout) {
+  __shared__ double tw_c[kFftN], tw_s[kFftN];
+  if (threadIdx.x < kFftN) {
+    const double t = 6.283185307179586476925286766559 * threadIdx.x / kFftN;
+    tw_c[threadIdx.x] = cos(t);
+    tw_s[threadIdx.x] = sin(t);
+  }
+  __syncthreads();
+  const int co = blockIdx.y * kThreads + threadIdx.x;
+  const int ci = blockIdx.x;
+  const int u = blockIdx.z;
+  if (co >= Cout) return;
+  const int r0 = (ci / Gin) * 2 * Gin + ci % Gin, r1 = r0 + Gin;
+  const int c0 = (co / Gout) * 2 * Gout + co % Gout, c1 = c0 + Gout;
+  const size_t ld = (size_t)2 * Cout, fstride = (size_t)2 * Cin * (PACKED ? (size_t)Cout : ld);
+  const size_t p_dr = ((size_t)2 * ci) * Cout + co, p_di = p_dr + Cout;
+  double acc[KS];
+#pragma unroll
+  for (int v = 0; v < KS; ++v) acc[v] = 0.0;
+  for (int kx = 0; kx < kFftH; ++kx) {
+    const bool edge = fft_edge(kx);
+    const int nky = fft_nky(kx), f0 = fft_f0(kx), fstep = fft_fstep(kx);
+    double ar = 0.0, ai = 0.0;
+    constexpr int kKyBatch = 8;
+    for (int ky0 = 0; ky0 < nky; ky0 += kKyBatch) {
+      float q[kKyBatch][PACKED ? 2 : 4];
+#pragma unroll
+      for (int b = 0; b < kKyBatch; ++b) {
+        const float* d = D + (size_t)(f0 + min(ky0 + b, nky - 1) * fstep) * fstride;
+        if (PACKED) {
+          q[b][0] = d[p_dr];
+          q[b][1] = d[p_di];
+        } else {
+          q[b][0] = d[r0 * ld + c0];
+          q[b][1] = d[r1 * ld + c1];
+          q[b][PACKED ? 0 : 2] = d[r1 * ld + c0];
+          q[b][PACKED ? 1 : 3] = d[r0 * ld + c1];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < kKyBatch; ++b) {
+        const int ky = ky0 + b;
+        if (ky < nky) {
+          const double wgt = (edge && (ky == 0 || ky == kFftH - 1)) ? 1.0 : 2.0;
+          const double dr = PACKED ? wgt * (double)q[b][0] : wgt * ((double)q[b][0] + (double)q[b][1]);
+          const double di = PACKED ? wgt * (double)q[b][1] : wgt * ((double)q[b][PACKED ? 0 : 2] - (double)q[b][PACKED ? 1 : 3]);
+          const int t = (ky * u) % kFftN;
+          const double c = tw_c[t], sn = tw_s[t];
+          ar += c * dr - sn * di;
+          ai += c * di + sn * dr;
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < KS; ++v) {
+      const int t = (kx * v) % kFftN;
+      acc[v] += tw_c[t] * ar - tw_s[t] * ai;
+    }
+  }
+  constexpr double inv = 1.0 / (kFftN * kFftN);
+  float* o = dbank + ((size_t)co * Cin + ci) * (KS * KS) + u * KS;
+#pragma unroll
+  for (int v = 0; v < KS; ++v) o[v] = (float)(acc[v] * inv);
+}
+
 int fft_dims_ok(int nimg, int H, int W, int C) { return nimg >= 0 && H >= 5 && W >= 5 && C > 0; }
 
 #ifndef EQA_FFT_INV_CH
@@ -1541,6 +1612,16 @@ struct FftK {
     return launch_status();
   }
   static int filter_grad(const float* D, float* dbank, int Cout, int Cin, bool packed, hipStream_t st) {
+    // fewer than ~2 blocks per CU in the one-thread-per-filter form: one thread per filter ROW instead
+    if ((size_t)Cin * ((Cout + kThreads - 1) / kThreads) < 512) {
+      const dim3 grid(Cin, (Cout + kThreads - 1) / kThreads, KS);
+      if (packed)
+        hipLaunchKernelGGL((fft48_filter_grad_rows_kernel<true, KS>), grid, dim3(kThreads), 0, st, D, dbank, Cout, Cin, kFusCh, kFusCh);
+      else
+        hipLaunchKernelGGL((fft48_filter_grad_rows_kernel<false, KS>), grid, dim3(kThreads), 0, st, D, dbank, Cout, Cin, fft_group_in(Cin),
+                           fft_group_in(Cout));
+      return launch_status();
+    }
     if (packed)
       hipLaunchKernelGGL((fft48_filter_grad_kernel<true, KS>), dim3(Cin, (Cout + kThreads - 1) / kThreads), dim3(kThreads), 0, st, D, dbank,
                          Cout, Cin, kFusCh, kFusCh);

@@ -4,7 +4,11 @@
   * eqa_plane_gemm: random T, P in {36, 64}, channel counts on the 32-multiples vs the fp64 product
   * eqa_lift_conv_nhwc: random sizes, channel counts on the 16-multiples vs F.conv2d in fp64
   * eqa_crop_resize_aa: random sizes / crop ratios / output sizes vs torch on the CPU (centre crop + antialiased interpolate)
-  * eqa_group_action_pair vs the two separate launches (bit-equal)"""
+  * eqa_group_action_pair vs the two separate launches (bit-equal)
+Round 4 cases:
+  * "action": canon_transform / invert_action (incl. the right-angle window hint, ragged image groups, the DMA lane mask) against
+    the direct-gather path (eqa_set_option(0, 1)); the LDS-staged angle gradient against round 3's direct kernel
+  * "fftk": eqa_fft48_* (k = 3 / 7 / 9) forward, input gradient and filter gradient against fp64 conv2d + autograd"""
 import argparse
 import os
 import random
@@ -32,7 +36,7 @@ def main():
     dev = torch.device("cuda:0")
     rng = random.Random(args.seed)
     torch.manual_seed(args.seed)
-    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0, "aa": 0}
+    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0, "aa": 0, "action": 0, "fftk": 0}
     worst = {}
     t_end = time.time() + args.seconds
     guard = None
@@ -40,7 +44,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
         import conftest as guard    # installs the guarded torch.empty / zeros / ... at import
     while time.time() < t_end:
-        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair", "aa"])
+        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair", "aa", "action", "fftk"])
         if what in ("knn", "vnsmall"):
             k = rng.randint(1, 32)
             N = rng.choice([k, k + 1, rng.randint(k, 200), rng.randint(k, 1500), 1024])
@@ -163,6 +167,45 @@ def main():
             got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), b, True, K, K)
             want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
             assert (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-3), ("lift", B, Cin, K, Cout, H, W)
+        elif what == "action":
+            N, refl = rng.choice([(4, False), (8, False), (4, True), (8, True), (2, False)])
+            G = 2 * N if refl else N
+            C = rng.choice([1, 2, 3, 4, 5, 6])
+            H, W = rng.randint(2, 140), rng.randint(2, 140)
+            B = rng.randint(1, 19)
+            pad = rng.choice([0, (W + 1) // 2])
+            x = torch.randn(B, C, H, W, device=dev)
+            gidx = torch.randint(0, G, (B,), dtype=torch.int32, device=dev)
+            th, fl = device_tables("canonicalize", N, refl, (H + 2 * pad, W + 2 * pad), dev)
+            y = ops.canon_transform(x, gidx, th, fl, pad)
+            go = torch.randn_like(x)
+            _, ga = ops.group_action_bwd(x, go, gidx, th, fl, None, pad, (pad, pad), False, True)
+            lib.eqa_set_option(0, 1)
+            try:
+                y_d = ops.canon_transform(x, gidx, th, fl, pad)
+                _, ga_d = ops.group_action_bwd(x, go, gidx, th, fl, None, pad, (pad, pad), False, True)
+            finally:
+                lib.eqa_set_option(0, 0)
+            assert (y - y_d).abs().max().item() <= 4e-6, ("action fwd", N, refl, C, H, W, B, pad)
+            assert (ga - ga_d).abs().max().item() <= 1e-5 * max(ga_d.abs().max().item(), 1e-3), ("action angle grad", N, refl, C, H, W, B, pad)
+        elif what == "fftk":
+            from equiadapt_amd.images.canonicalization_networks import fftconv
+            k = rng.choice([3, 7, 9])
+            cin, cout = rng.choice([(64, 64), (32, 64), (64, 128), (16, 16), (24, 40), (8, 12), (3, 32)])
+            H, W, B = rng.randint(k, 110), rng.randint(k, 110), rng.randint(1, 4)
+            x = torch.randn(B, cin, H, W)
+            bank = torch.randn(cout, cin, k, k) / (cin * k * k) ** 0.5
+            xd = x.to(dev).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            bd = bank.to(dev).requires_grad_(True)
+            yk = fftconv.ConvKxKFunction.apply(xd, bd)
+            x64, b64 = x.double().requires_grad_(True), bank.double().requires_grad_(True)
+            y64 = F.conv2d(x64, b64)
+            g = torch.randn(y64.shape)
+            yk.backward(g.to(dev))
+            y64.backward(g.double())
+            assert (yk.detach().cpu().double() - y64.detach()).abs().max().item() <= 3e-6 * max(y64.abs().max().item(), 1e-3), ("fftk fwd", k, cin, cout, H, W, B)
+            assert (xd.grad.cpu().double() - x64.grad).abs().max().item() <= 6e-6 * max(x64.grad.abs().max().item(), 1e-3), ("fftk dx", k, cin, cout, H, W, B)
+            assert (bd.grad.cpu().double() - b64.grad).abs().max().item() <= 2e-5 * max(b64.grad.abs().max().item(), 1e-3), ("fftk dw", k, cin, cout, H, W, B)
         elif what == "aa":
             # eqa_crop_resize_aa (narrow filters over aligned rows take the LDS-staged persistent kernel) vs torch on the CPU:
             # centre crop (torchvision's offset rule) + F.interpolate(bilinear, antialias=True), what the reference's transform does
