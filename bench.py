@@ -618,15 +618,18 @@ def leg_configs(comm: Comm, with_cpu: bool):
             ms_ct_b2b = b2b(lambda: ops.canon_transform(x, g5, th5, fl5, 512))
             ms_mk_b2b = b2b(lambda: ops.mask_action_nearest(mcat, e5, rth5, mfl5))
         del mcat
+        ach_b, ach_mb = B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct_b2b * 1e-3) / 1e9, B * 3 * 2 * 1024 * 1024 / (ms_mk_b2b * 1e-3) / 1e9
+        how = ("avg_launch_ms / achieved / frac: the kernel launched 30 times between ONE pair of HIP events on the same tensors -- the duration "
+               "rocprofv3's kernel trace reports (profiles/r04/rocprofv3_kernel_stats_cfg5_b4.md: mask kernel 12.5 us); "
+               "per_launch_event_*: one event bracket per launch inside the timed step, which adds the bracket's own ~2-5 us "
+               "(tools/event_overhead.py) to these 12-27 us launches")
         c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
-            "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "avg_launch_ms": ms_ct,
-            "back_to_back_ms": ms_ct_b2b, "frac_back_to_back": B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "mask_kernel": {"kernel": "mask_action_u8_kernel via eqa_mask_action_nearest_planes (2 B / mask pixel)", "achieved": ach_m,
-                            "unit": "GB/s", "frac": ach_m / HBM_PEAK_GBS, "avg_launch_ms": ms_mk,
-                            "back_to_back_ms": ms_mk_b2b, "frac_back_to_back": B * 3 * 2 * 1024 * 1024 / (ms_mk_b2b * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "note": "back_to_back_*: the same kernel 30 times between one pair of events (masks concatenated); "
-                                    "frac / avg_launch_ms: one HIP-event bracket per launch inside the timed step"}}
+            "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach_b,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "avg_launch_ms": ms_ct_b2b,
+            "per_launch_event_ms": ms_ct, "per_launch_event_frac": ach / HBM_PEAK_GBS, "how": how},
+            "mask_kernel": {"kernel": "mask_action_u8_kernel via eqa_mask_action_nearest (2 B / mask pixel)", "achieved": ach_mb,
+                            "unit": "GB/s", "frac": ach_mb / HBM_PEAK_GBS, "avg_launch_ms": ms_mk_b2b,
+                            "per_launch_event_ms": ms_mk, "per_launch_event_frac": ach_m / HBM_PEAK_GBS}}
         if B == 4:   # BASELINE's own batch: the whole step (image, masks, boxes, invert) captured once and replayed as a hipGraph
             from equiadapt_amd.graphs import GraphedCanonicalizer
 
