@@ -138,4 +138,20 @@ class ConvNetwork(nn.Module):
                     self._fold_cache["head"] = hit
                 return torch.nn.functional.linear(ops.affine_relu_rows(h.contiguous(), hit[1], hit[2]), lin.weight, lin.bias)
             return self.final_fc(h)
+        mode = os.environ.get("EQA_CONVNET_TRAIN_MODE", "cl_native")
+        if x.is_cuda and x.dim() == 4 and mode != "plain":
+            # training (or autograd on): the reference's modules, run channels-last (MIOpen's fp32 convolutions are NHWC kernels)
+            # with the batch-norms taken by ATen's channels-last kernels instead of MIOpen's.  Measured on the reference tutorial's
+            # second loop (B = 512 x 4 views of 64 x 64, profiles/r04): as constructed (NCHW, MIOpen batch-norm: 0.4 TB/s,
+            # 45 % of the step) 8.1 ms per step; channels-last with MIOpen's batch-norm 12.3; ATen's NCHW batch-norm 14.5;
+            # channels-last + ATen's batch-norm 5.3 ms.  Same arithmetic and autograd formulas; the flattening in front of the
+            # head follows the logical (C, H, W) order whatever the memory format.  EQA_CONVNET_TRAIN_MODE=plain: as constructed.
+            h = x.contiguous(memory_format=torch.channels_last) if mode.startswith("cl") else x
+            for m in self.enc_network:
+                if isinstance(m, nn.BatchNorm2d) and mode.endswith("native"):
+                    with torch.backends.cudnn.flags(enabled=False):      # (the convolutions stay with MIOpen)
+                        h = m(h)
+                else:
+                    h = m(h)
+            return self.final_fc(h.reshape(x.shape[0], -1))
         return self.final_fc(self.enc_network(x).reshape(x.shape[0], -1))
