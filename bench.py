@@ -488,6 +488,13 @@ def leg_configs(comm: Comm, with_cpu: bool):
 
     def run(step, units, reps, warm, kt=None):
         with torch.no_grad():
+            # these legs follow host-side work (model construction, the CPU oracle of the previous leg) and their steps are 0.06-1 ms:
+            # `warm` steps alone would be timed on a chip still coming back to its running clocks (the first launches after an idle
+            # stretch run ~12 % slow), so the untimed part lasts at least 60 ms
+            t_warm = time.perf_counter() + 0.06
+            while time.perf_counter() < t_warm:
+                step()
+                torch.cuda.synchronize()
             dt, _ = comm.timed(step, reps, warm, kt)
         return units * comm.world * reps / dt, dt / reps * 1e3
 
@@ -721,22 +728,14 @@ def main():
             elapsed, per_rank = comm.timed(step, args.steps, args.warmup, kt)
             ktimes = kt.summary()
 
-            # self check: every image of rank 0's batch 0 against the CPU oracle (seed 0 / seed 1000 as generated above)
-            self_check = None
-            if rank == 0 and not args.no_cpu_baseline:
-                n = B if args.check_images <= 0 else min(args.check_images, B)   # default: the WHOLE timed batch (256 images ~ 10 s of CPU oracle)
-                y = can(xs[0])
-                acts = can.canonicalization_info_dict["group_activations"]
-                gidx = can.canonicalization_info_dict["group_index"]
-                inv = can.invert_canonicalization(fs[0], induced_rep_type="scalar")
-                self_check = oracle_check(can, xs[0][:n], fs[0][:n], y[:n], inv[:n], acts[:n], gidx[:n])
-
             # group-action-only leg: the two resampling kernels back to back with a seeded random index
             x, f = xs[0], fs[0]
             gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
             th_c, fl_c = device_tables("canonicalize", 8, False, (2 * H, 2 * W), dev)
             th_i, fl_i, _ = device_tables("invert", 8, False, (H, W), dev)
-            for _ in range(3):
+            # (20 untimed rounds first: the chip needs a few ms of work to come back to its running clocks -- this leg follows host-side
+            # work, and the first launches after an idle stretch run ~12 % slow)
+            for _ in range(20):
                 ops.canon_transform(x, gidx, th_c, fl_c, H // 2)
                 ops.invert_action(f, gidx, th_i, fl_i, None)
             torch.cuda.synchronize()
@@ -750,7 +749,7 @@ def main():
             torch.cuda.synchronize()
             ga2_ms = e0.elapsed_time(e1) / reps
             # the same two jobs in ONE launch (eqa_group_action_pair: job 1's first blocks fill the CUs job 0's tail leaves idle)
-            for _ in range(3):
+            for _ in range(10):
                 ops.group_action_pair(x, f, gidx, th_c, fl_c, H // 2, th_i, fl_i, None)
             torch.cuda.synchronize()
             e0.record()
@@ -759,6 +758,16 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ga_ms = e0.elapsed_time(e1) / reps
+            # self check: every image of rank 0's batch 0 against the CPU oracle (seed 0 / seed 1000 as generated above)
+            self_check = None
+            if rank == 0 and not args.no_cpu_baseline:
+                n = B if args.check_images <= 0 else min(args.check_images, B)   # default: the WHOLE timed batch (256 images ~ 10 s of CPU oracle)
+                y = can(xs[0])
+                acts = can.canonicalization_info_dict["group_activations"]
+                gidx = can.canonicalization_info_dict["group_index"]
+                inv = can.invert_canonicalization(fs[0], induced_rep_type="scalar")
+                self_check = oracle_check(can, xs[0][:n], fs[0][:n], y[:n], inv[:n], acts[:n], gidx[:n])
+
         del xs, fs, x, f, can
         torch.cuda.empty_cache()
 

@@ -132,6 +132,7 @@ SIGNATURES = {
     "eqa_group_argmax": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_vnsmall_workspace_bytes": (ctypes.c_int64, [_int, _int]),
     "eqa_vnsmall_fwd": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _vp]),
+    "eqa_vnsmall_canonicalize": (_int, [_vp] * 6 + [_int] * 4 + [_vp]),
     "eqa_so3_rotate": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp]),
     "eqa_gram_schmidt": (_int, [_vp, _vp, _int, _vp]),
     "eqa_gram_schmidt_bwd": (_int, [_vp, _vp, _vp, _int, _vp]),

@@ -45,10 +45,16 @@ __global__ __launch_bounds__(kThreads) void so3_rotate_kernel(const float* __res
   }
 }
 
+// classical Gram-Schmidt of the three rows of p -> o (both 9 floats; used by gram_schmidt_kernel and by the fused tail below)
+__device__ __forceinline__ void gram_schmidt_rows(const float* p, float* o);
+
 __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
   const int b = blockIdx.x * kThreads + threadIdx.x;
   if (b >= B) return;
-  const float* p = v + (size_t)b * 9;
+  gram_schmidt_rows(v + (size_t)b * 9, out + (size_t)b * 9);
+}
+
+__device__ __forceinline__ void gram_schmidt_rows(const float* p, float* o) {
   float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
   // e1 = a / |a|   (torch.norm: sqrt of the sum of squares; division, not rsqrt, to stay on the reference's rounding)
   float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
@@ -64,7 +70,6 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
   c2 = c2 - d1 * a2 - d2 * b2;
   n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
   c0 /= n; c1 /= n; c2 /= n;
-  float* o = out + (size_t)b * 9;
   o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
 }
 
@@ -513,6 +518,56 @@ __global__ void vnsmall_finalize_kernel(const float* __restrict__ partial, float
   out[i] = acc * inv_n;
 }
 
+// The whole tail of the eval-mode point-cloud canonicalizer in ONE launch per batch (one block per cloud): the partial sums of the
+// fused VNSmall kernel -> the network's (3, 3) output vectors (vnsmall_finalize_kernel's sums) -> their Gram-Schmidt frame
+// (gram_schmidt_kernel's arithmetic; equiadapt/common/utils.py:22-51) -> the canonical cloud y = R x (so3_rotate_kernel's;
+// pointcloud/canonicalization/continuous_group.py:74-79).  As three launches behind the network kernel these cost three kernel
+// boundaries of a 0.12 ms step (ModelNet40-shaped batches of 64 clouds).
+__global__ __launch_bounds__(kThreads) void vnsmall_canon_tail_kernel(const float* __restrict__ partial, const float* __restrict__ x,
+                                                                     float* __restrict__ vec, float* __restrict__ R,
+                                                                     float* __restrict__ y, int N, int nblk, float inv_n) {
+  __shared__ float s_v[9], s_r[9];
+  const int b = blockIdx.x;
+  if (threadIdx.x < 9) {
+    float acc = 0.f;
+    for (int k = 0; k < nblk; ++k) acc += partial[((size_t)b * nblk + k) * 12 + threadIdx.x];
+    acc *= inv_n;
+    s_v[threadIdx.x] = acc;
+    vec[(size_t)b * 9 + threadIdx.x] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) gram_schmidt_rows(s_v, s_r);
+  __syncthreads();
+  float m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = s_r[k];
+  if (threadIdx.x < 9) R[(size_t)b * 9 + threadIdx.x] = m[threadIdx.x];
+  const float* xb = x + (size_t)b * 3 * N;
+  float* yb = y + (size_t)b * 3 * N;
+  if ((N & 3) == 0 && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0)) {
+    for (int k = threadIdx.x; k < (N >> 2); k += kThreads) {
+      const float4 p0 = reinterpret_cast<const float4*>(xb)[k];
+      const float4 p1 = reinterpret_cast<const float4*>(xb + N)[k];
+      const float4 p2 = reinterpret_cast<const float4*>(xb + 2 * (size_t)N)[k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        float4 o;
+        o.x = m[r * 3] * p0.x + m[r * 3 + 1] * p1.x + m[r * 3 + 2] * p2.x;
+        o.y = m[r * 3] * p0.y + m[r * 3 + 1] * p1.y + m[r * 3 + 2] * p2.y;
+        o.z = m[r * 3] * p0.z + m[r * 3 + 1] * p1.z + m[r * 3 + 2] * p2.z;
+        o.w = m[r * 3] * p0.w + m[r * 3 + 1] * p1.w + m[r * 3 + 2] * p2.w;
+        reinterpret_cast<float4*>(yb + (size_t)r * N)[k] = o;
+      }
+    }
+  } else {
+    for (int k = threadIdx.x; k < N; k += kThreads) {
+      const float p0 = xb[k], p1 = xb[N + k], p2 = xb[2 * (size_t)N + k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) yb[(size_t)r * N + k] = m[r * 3] * p0 + m[r * 3 + 1] * p1 + m[r * 3 + 2] * p2;
+    }
+  }
+}
+
 // (f).4 -- n-body E(3) canonicalization: modified Gram-Schmidt and the per-row rigid action
 // (nbody/canonicalization/euclidean_group.py:87-157).  Tiny tensors (nodes x 3): one thread per row.
 __global__ __launch_bounds__(kThreads) void modified_gram_schmidt_kernel(const float* __restrict__ v, float* __restrict__ out, int B) {
@@ -587,9 +642,33 @@ int64_t eqa_vnsmall_workspace_bytes(int B, int N) {
   return (int64_t)B * ((N + kVnQPts - 1) / kVnQPts) * 12 * (int64_t)sizeof(float);   // the finer of the two block sizes
 }
 
+static int vnsmall_main(const float* x, const float* params, void* workspace, int B, int N, int k, int pooling, void* stream, int* nblk_out);
+
 int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
                     void* stream) {
-  if (!x || !params || !out || !workspace || B < 0 || N <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
+  if (!out) return EQA_ERR_INVALID_ARG;
+  int nblk = 0;
+  const int rc = vnsmall_main(x, params, workspace, B, N, k, pooling, stream, &nblk);
+  if (rc != EQA_OK || B == 0) return rc;
+  hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, B,
+                     nblk, 1.0f / (float)N);
+  return launch_status();
+}
+
+int eqa_vnsmall_canonicalize(const float* x, const float* params, float* vectors, float* R, float* y, void* workspace, int B, int N, int k,
+                             int pooling, void* stream) {
+  if (B == 0 && N > 0) return EQA_OK;     // (empty tensors have null data pointers)
+  if (!vectors || !R || !y) return EQA_ERR_INVALID_ARG;
+  int nblk = 0;
+  const int rc = vnsmall_main(x, params, workspace, B, N, k, pooling, stream, &nblk);
+  if (rc != EQA_OK || B == 0) return rc;
+  hipLaunchKernelGGL(vnsmall_canon_tail_kernel, dim3(B), dim3(kThreads), 0, (hipStream_t)stream, (const float*)workspace, x, vectors, R, y,
+                     N, nblk, 1.0f / (float)N);
+  return launch_status();
+}
+
+static int vnsmall_main(const float* x, const float* params, void* workspace, int B, int N, int k, int pooling, void* stream, int* nblk_out) {
+  if (!x || !params || !workspace || B < 0 || N <= 0 || k <= 0) return EQA_ERR_INVALID_ARG;
   if (k > 32 || (pooling != 0 && pooling != 1) || N < k) return EQA_ERR_UNSUPPORTED;  // pooling 0 mean, 1 max
   if (B > 65535) return EQA_ERR_UNSUPPORTED;
   if (B == 0) return EQA_OK;
@@ -632,8 +711,8 @@ int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* works
 #undef EQA_VN_QUAD_LAUNCH
   }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
-  hipLaunchKernelGGL(vnsmall_finalize_kernel, dim3((B * 9 + 255) / 256), dim3(256), 0, st, (const float*)workspace, out, B, nblk, 1.0f / (float)N);
-  return launch_status();
+  *nblk_out = nblk;
+  return EQA_OK;
 }
 
 int eqa_modified_gram_schmidt(const float* v, float* out, int B, void* stream) {

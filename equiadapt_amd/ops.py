@@ -364,6 +364,28 @@ def vnsmall_forward(x: torch.Tensor, params: torch.Tensor, k: int = 20, pooling:
     return out
 
 
+def vnsmall_canonicalize(x: torch.Tensor, params: torch.Tensor, k: int = 20, pooling: str = "mean"):
+    """P1-P4 in two launches (eqa_vnsmall_canonicalize): (B,3,N) clouds -> (network output vectors (B,3,3), their Gram-Schmidt
+    frame R (B,3,3), canonical clouds R x (B,3,N))."""
+    lib = _lib.load()
+    x = _need(x, "point_cloud")
+    params = _need(params, "params")
+    B, three, N = x.shape
+    if pooling not in ("mean", "max"):
+        raise ValueError(f"Pooling type {pooling} not supported")
+    if three != 3 or params.numel() != (1310 if pooling == "mean" else 1751):
+        raise ValueError("vnsmall_canonicalize expects x:(B,3,N) and 1310 (mean) / 1751 (max) packed parameters")
+    vec = torch.empty((B, 3, 3), dtype=torch.float32, device=x.device)
+    R = torch.empty((B, 3, 3), dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    ws = torch.empty((max(lib.eqa_vnsmall_workspace_bytes(B, N), 4) // 4,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("vnsmall_fwd"):
+        st = lib.eqa_vnsmall_canonicalize(x.data_ptr(), params.data_ptr(), vec.data_ptr(), R.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                          B, N, k, int(pooling == "max"), _stream())
+    _lib.check(st, "eqa_vnsmall_canonicalize")
+    return vec, R, y
+
+
 def crop_resize_aa(x: torch.Tensor, tables, out_hw: Tuple[int, int]) -> torch.Tensor:
     """I1: centre crop + antialiased bilinear resize in one kernel (eqa_crop_resize_aa).  ``tables`` from
     ``geometry.aa_resize_tables`` already moved to x.device."""

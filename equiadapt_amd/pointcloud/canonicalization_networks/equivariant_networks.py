@@ -260,9 +260,13 @@ class VNSmall(nn.Module):
         self._packed = (key, packed)
         return packed
 
+    def fused_inference_applies(self, point_cloud: torch.Tensor) -> bool:
+        """eval mode without autograd on the device, at a size the fused kernel takes (eqa_vnsmall_fwd / _canonicalize)."""
+        return bool(point_cloud.is_cuda and not self.training and not torch.is_grad_enabled() and point_cloud.dim() == 3
+                    and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32)
+
     def forward(self, point_cloud: torch.Tensor) -> torch.Tensor:
-        if (point_cloud.is_cuda and not self.training and not torch.is_grad_enabled()
-                and 1 <= self.n_knn <= 32 and self.n_knn <= point_cloud.shape[-1] <= 6144 and point_cloud.dtype == torch.float32):
+        if self.fused_inference_applies(point_cloud):
             from equiadapt_amd import ops
 
             return ops.vnsmall_forward(point_cloud, self.packed_parameters(), self.n_knn, self.pooling)

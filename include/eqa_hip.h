@@ -544,6 +544,12 @@ int eqa_so3_rotate(const float* x, const float* R, float* y, int B, int N, int t
 int64_t eqa_vnsmall_workspace_bytes(int B, int N);
 int eqa_vnsmall_fwd(const float* x, const float* params, float* out, void* workspace, int B, int N, int k, int pooling,
                     void* stream);
+/* The eval-mode point-cloud canonicalizer in two launches: eqa_vnsmall_fwd's network kernel, then ONE kernel per batch that finishes
+ * the network output (vectors:(B,3,3)), orthonormalises it (R:(B,3,3), eqa_gram_schmidt's arithmetic -- common/utils.py:22-51) and
+ * writes the canonical cloud y:(B,3,N) = R x (eqa_so3_rotate's -- pointcloud/canonicalization/continuous_group.py:51-81, :107-134).
+ * Same arguments and limits as eqa_vnsmall_fwd otherwise; replaces three launches behind the network kernel. */
+int eqa_vnsmall_canonicalize(const float* x, const float* params, float* vectors, float* R, float* y, void* workspace, int B, int N,
+                             int k, int pooling, void* stream);
 
 /*
  * Training passes of VNSmall's first block (kNN graph -> cross edge features -> VNLinearLeakyReLU(3 -> 21, slope 0) with

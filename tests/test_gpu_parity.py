@@ -2080,3 +2080,30 @@ def test_invert_detection_outputs_matches_the_reference_loop(dev):
             assert torch.equal(g["labels"].cpu(), o["labels"]) and torch.equal(g["masks"].cpu(), o["masks"]) and torch.equal(g["scores"].cpu(), o["scores"])
     ident = types.SimpleNamespace(canonicalization_info_dict={})
     assert invert_detection_outputs(ident, outs, W) is outs
+
+
+@pytest.mark.parametrize("pooling,k,B,N", [("mean", 20, 64, 1024), ("max", 20, 5, 1000), ("mean", 8, 3, 333), ("mean", 32, 2, 4096)])
+def test_fused_pointcloud_canonicalize_equals_the_three_kernels(dev, pooling, k, B, N):
+    """eqa_vnsmall_canonicalize (network kernel + ONE tail kernel: output vectors, Gram-Schmidt frame, rotated cloud) against
+    eqa_vnsmall_fwd -> eqa_gram_schmidt -> eqa_so3_rotate on the same clouds, and through the canonicalizer class (same info dict)."""
+    import equiadapt_amd as ea
+    from equiadapt_amd import ops
+
+    torch.manual_seed(N + k)
+    hp = types.SimpleNamespace(n_knn=k, pooling=pooling)
+    net = ea.VNSmall(hp).to(dev).eval()
+    x = torch.randn(B, 3, N, device=dev)
+    prm = net.packed_parameters()
+    with torch.no_grad():
+        vec0 = ops.vnsmall_forward(x, prm, k, pooling)
+        R0 = ops.gram_schmidt(vec0)
+        y0 = ops.so3_rotate(x, R0)
+        vec, R, y = ops.vnsmall_canonicalize(x, prm, k, pooling)
+        assert torch.equal(vec, vec0)
+        assert (R - R0).abs().max().item() <= 1e-6 and (y - y0).abs().max().item() <= 1e-5
+        can = ea.EquivariantPointcloudCanonicalization(net, hp).to(dev).eval()
+        yc = can(x)
+        assert torch.equal(yc, y)
+        assert torch.equal(can.canonicalization_info_dict["group_element_matrix_representation"], R)
+        assert can.canonicalization_info_dict["group_element"]["rotation"] is can.canonicalization_info_dict["group_element_matrix_representation"]
+    assert ops.vnsmall_canonicalize(torch.empty(0, 3, N, device=dev), prm, k, pooling)[2].shape == (0, 3, N)
