@@ -319,6 +319,7 @@ constexpr int kFusThreads = kFftN * kFusCh;                       // 768
 constexpr int kFusKxPitch = kFftN * 2 * kFusCh + kFusCh;          // floats per kx slab (+16: slabs start 16 banks apart)
 constexpr int kFusLds = kFftH * kFusKxPitch;                      // 38,800 floats = 155,200 bytes
 
+template <int O = kFftO>   // outputs per tile = the tile stride (44: 5 x 5 filters; 46 / 42 / 40: eqa_fft48_* for 3 / 7 / 9)
 __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ V,
                                                                       const float* __restrict__ in_bias, int in_relu, int H, int W,
                                                                       int C, int TY, int TX, size_t M, unsigned nwork, int win,
@@ -339,15 +340,15 @@ __global__ __launch_bounds__(kFusThreads) void fft48_fwd_fused_kernel(const floa
   const int c = grp * kFusCh + cl;
   {
     const int y = threadIdx.x / kFusCh;  // 0..47
-    const int gy = kFftO * ty + y;
-    const int nvalid = min(win, W - kFftO * tx);  // uniform
+    const int gy = O * ty + y;
+    const int nvalid = min(win, W - O * tx);  // uniform
     const float ib = in_bias ? in_bias[c] : 0.0f;
     // x_grouped: the map is stored (img, channel group of 16, y, x, 16) -- a tile row of this block's group is one 3 KB run, and
     // the two 64-byte halves of a cache line are asked for by consecutive loads of the same lanes.  Channels-last, the other half
     // of every line belongs to the neighbouring channel group, i.e. to another block: every line was requested twice
     // (TCP_TCC_READ_REQ 37.7 M for 18.4 M lines, profiles/r02/pmc_memory_path.md).
-    const float* p = x_grouped ? x + ((((img * ngrp + grp) * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * kFusCh) + cl
-                               : x + ((img * H + min(gy, H - 1)) * W + (size_t)kFftO * tx) * C + c;
+    const float* p = x_grouped ? x + ((((img * ngrp + grp) * H + min(gy, H - 1)) * W + (size_t)O * tx) * kFusCh) + cl
+                               : x + ((img * H + min(gy, H - 1)) * W + (size_t)O * tx) * C + c;
     const int xstep = x_grouped ? kFusCh : C;
     const bool row_in = gy < H && y < win;
     float re[kFftN], ore[kFftH], oim[kFftH];
@@ -622,10 +623,11 @@ __device__ __forceinline__ void fft_row_pieces(const float (&ore)[kFftN], int re
 // The inverse counterpart: column pass (thread (kx, c)), LDS, row pass (thread (y, c), y < 44) and the epilogue; Mo is read
 // as interleaved complex with 8-byte loads (128 bytes per (frequency, tile) row and block).  NB > 0: the window-sum pieces of this tile's 44 output columns go to segment (row, tile column); the pieces of a
 // row are put together by window_sums_nhwc_finalize_kernel (sub = TX).
-template <int NB, int CH>
+template <int NB, int CH, int O = kFftO>   // O: outputs per tile (window-sum pieces, NB > 0: 44 only)
 __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float* __restrict__ Mo, const float* __restrict__ bias,
                                                                       int relu, float* __restrict__ out, int OH, int OW, int C, int TY,
                                                                       int TX, size_t M, unsigned nwork, unsigned mo_bytes) {
+  static_assert(NB == 0 || O == kFftO, "the window-sum epilogue is written for 44-output tiles");
   extern __shared__ float lds[];
   FFT_CLOCK_BEGIN();
   constexpr int kPitch = kFftN * 2 * CH + CH;  // floats per kx slab
@@ -671,7 +673,7 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
     fft48(im, re, oim, ore);
     float* q = lds + kx * kPitch + cl;
 #pragma unroll
-    for (int i = 0; i < kFftO; ++i) {  // rows 44..47: the circular wrap-around
+    for (int i = 0; i < O; ++i) {  // rows O..47: the circular wrap-around
       q[(i * 2) * CH] = ore[i];
       q[(i * 2 + 1) * CH] = oim[i];
     }
@@ -680,8 +682,8 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
   __syncthreads();
   FFT_CLOCK(2);
   const int y = threadIdx.x / CH;
-  const int gy = kFftO * ty + y;
-  const bool valid = y < kFftO && gy < OH;
+  const int gy = O * ty + y;
+  const bool valid = y < O && gy < OH;
   constexpr int NV = 1 + 2 * NB;
   float acc[NV];
 #pragma unroll
@@ -698,12 +700,12 @@ __global__ __launch_bounds__(kFftN * CH) void fft48_inv_fused_kernel(const float
     const float b = bias ? bias[c] : 0.0f;
     re[0] += b;
     ifft48_c2r(re, im, ore);  // real output from the stored half of the spectrum (468 operations; the complex transform: 819)
-    const int x0 = kFftO * tx;
-    const int ncols = min(kFftO, OW - x0);  // uniform
+    const int x0 = O * tx;
+    const int ncols = min(O, OW - x0);  // uniform
     if constexpr (NB == 0) {
       float* o = out + ((img * OH + gy) * OW + x0) * (size_t)C + c;
 #pragma unroll
-      for (int j = 0; j < kFftO; ++j) {
+      for (int j = 0; j < O; ++j) {
         if (j < ncols) o[(size_t)j * C] = relu ? fmaxf(ore[j], 0.0f) : ore[j];
       }
     } else {
@@ -1410,7 +1412,7 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
   if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
   static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;  // ablation switch: the unfused passes
   if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass) {
-    const bool lds_ok = allow_dynamic_lds((const void*)fft48_fwd_fused_kernel, kFusLds * 4);
+    const bool lds_ok = allow_dynamic_lds((const void*)fft48_fwd_fused_kernel<kFftO>, kFusLds * 4);
     if (lds_ok) {
       const unsigned nwork = (unsigned)(M * (C / kFusCh));
       const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;     // 0 = beyond 32-bit offsets
@@ -1426,7 +1428,7 @@ static int fft_forward_impl(const float* x, float* T, float* V, const float* in_
                            fft_pitch(M), nwork, win, (unsigned)xb, (unsigned)vb);
         return launch_status();
       }
-      hipLaunchKernelGGL(fft48_fwd_fused_kernel, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
+      hipLaunchKernelGGL(fft48_fwd_fused_kernel<kFftO>, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
                          W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
                          vb <= 0xfffffff0ULL ? (unsigned)vb : 0u, x_grouped);
       return launch_status();
@@ -1556,6 +1558,17 @@ struct FftK {
                      int win, hipStream_t st) {
     const size_t M = (size_t)nimg * TY * TX;
     if ((size_t)nimg * H * TX > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+    static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
+    if (C % kFusCh == 0 && M * (C / kFusCh) <= 0x7fffffffULL && !two_pass &&
+        allow_dynamic_lds((const void*)fft48_fwd_fused_kernel<O>, kFusLds * 4)) {
+      // row pass, LDS, column pass in one block per (tile, 16 channels): the spectra are written once and nothing is read back
+      const unsigned nwork = (unsigned)(M * (C / kFusCh));
+      const size_t xb = (size_t)nimg * H * W * C * 4, vb = (size_t)kFftF * fft_pitch(M) * 2 * C * 4;
+      hipLaunchKernelGGL(fft48_fwd_fused_kernel<O>, dim3(nwork), dim3(kFusThreads), kFusLds * sizeof(float), st, x, V, in_bias, in_relu, H,
+                         W, C, TY, TX, fft_pitch(M), nwork, win, xb <= 0xfffffff0ULL ? (unsigned)xb : 0u,
+                         vb <= 0xfffffff0ULL ? (unsigned)vb : 0u, 0);
+      return launch_status();
+    }
     const unsigned cb = (C + kThreads - 1) / kThreads;
     const int chunk = fft_chunk_images(nimg, H, TX, C);
     for (int i0 = 0; i0 < nimg; i0 += chunk) {
@@ -1572,6 +1585,16 @@ struct FftK {
     const int TY = (OH + O - 1) / O, TX = (OW + O - 1) / O;
     const size_t M = (size_t)nimg * TY * TX;
     if ((size_t)nimg * OH > 0x7fffffffULL || M * kFftH > 0x7fffffffULL) return EQA_ERR_UNSUPPORTED;
+    static const bool two_pass = getenv("EQA_FFT_TWO_PASS") != nullptr;
+    constexpr int lds_bytes = kFftH * (kFftN * 2 * kInvCh + kInvCh) * (int)sizeof(float);
+    if (C % kInvCh == 0 && M * (C / kInvCh) <= 0x7fffffffULL && !two_pass &&
+        allow_dynamic_lds((const void*)fft48_inv_fused_kernel<0, kInvCh, O>, lds_bytes)) {
+      const unsigned nwork = (unsigned)(M * (C / kInvCh));
+      const size_t mo_total = (size_t)kFftF * fft_pitch(M) * C * 8;
+      hipLaunchKernelGGL((fft48_inv_fused_kernel<0, kInvCh, O>), dim3(nwork), dim3(kFftN * kInvCh), lds_bytes, st, Mo, bias, relu, y, OH, OW, C,
+                         TY, TX, fft_pitch(M), nwork, mo_total <= 0xfffffff0ULL ? (unsigned)mo_total : 0u);
+      return launch_status();
+    }
     const unsigned cb = (C + kThreads - 1) / kThreads;
     const int chunk = fft_chunk_images(nimg, OH, TX, C);
     for (int i0 = 0; i0 < nimg; i0 += chunk) {

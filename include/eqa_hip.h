@@ -495,7 +495,8 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
  * O = 49 - ksize outputs per 48 x 48 tile (46 / 44 / 42 / 40 for ksize 3 / 5 / 7 / 9; tiles per axis eqa_fft48_tiles(n, ksize) =
  * ceil((n - ksize + 1) / O)), the same stored frequencies, buffer pitch (eqa_fft48k5_tile_pitch) and row layouts, so the
  * k-independent contractions (eqa_fft48k5_cgemm3m, eqa_fft48k5_wgrad3m, or the caller's batched GEMM) apply unchanged.
- * Two-pass kernels (one thread per channel); arguments as their eqa_fft48k5_* namesakes plus `ksize`:
+ * The forward, gradient and output transforms run fused (row pass -> LDS -> column pass in one block) where C % 16 == 0, as two
+ * passes otherwise; arguments as their eqa_fft48k5_* namesakes plus `ksize`:
  *   eqa_fft48_supported        1 for ksize in {3, 5, 7, 9}
  *   eqa_fft48_workspace_bytes  T / T2 sizes (out_cols = the OUTPUT width of the convolution, as for k = 5)
  *   eqa_fft48_filter_spectra / _filter_spectra3m   bank:(Cout,Cin,ksize,ksize) -> B / B3
