@@ -1541,9 +1541,9 @@ int eqa_fft48k5_output_sums(const float* Mo, float* T2, const float* bias, int r
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Any odd kernel size 3 .. 9 (round 4): the same overlap-save scheme with 48 x 48 tiles of O = 49 - k outputs, through the two-pass
-// kernels (one thread per channel; no fused / pipelined forms, no window-sum epilogue: the caller runs eqa_window_sums_nhwc on the
-// map).  The reference's kernel_size is a free constructor argument (escnn_networks.py:19-44): its tutorial trains k = 9, its own test
+// Any odd kernel size 3 .. 9 (round 4): the same overlap-save scheme with 48 x 48 tiles of O = 49 - k outputs.  The forward, gradient
+// and output transforms use the fused kernels instantiated for O where C % 16 == 0 (two-pass kernels otherwise and for the input
+// gradient); no pipelined inverse and no window-sum epilogue off k = 5: the caller runs eqa_window_sums_nhwc on the map.  The reference's kernel_size is a free constructor argument (escnn_networks.py:19-44): its tutorial trains k = 9, its own test
 // k = 3.  The multiply count per output falls with k^2: 1154 x 3 real products per 40 x 40 outputs and channel pair at k = 9 against
 // 81 in the direct form (37x fewer; tiles that fit the map badly give some of it back).  The per-frequency channel contraction is
 // k-independent: eqa_fft48k5_cgemm3m / _wgrad3m / torch.bmm on buffers of eqa_fft48k5_tile_pitch rows, as for k = 5.
