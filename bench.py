@@ -810,17 +810,18 @@ def main():
         dom = max((k for k in line["stages"] if "frac" in line["stages"][k]), key=lambda k: line["stages"][k]["ms"], default=None)
         if dom is not None:
             d = dict(line["stages"][dom])
-            tr = None
+            tr, tsrc = None, None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r03", "traffic_canon_net.json")))
+                tsrc = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
+                tj = json.load(open(os.path.join(ROOT, "profiles", tsrc, "traffic_canon_net.json")))
                 key = {"fft_gemm": "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
                        "lift_conv": "lift_conv_dense_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
-            except (OSError, ValueError):
+            except (OSError, ValueError, StopIteration):
                 pass
             line["roofline_dominant"] = {"stage": dom, "kernel": d.get("what"), "bound": d["bound"], "achieved": d["achieved"], "peak": d["peak"],
                                          "unit": d["unit"], "frac": d["frac"], "avg_launch_ms": d["ms"], "share_of_step": d["ms"] / line["ms_per_step"],
-                                         "traffic": tr, "traffic_unit": "HBM bytes/launch (rocprofv3 PMC, profiles/r03/traffic_canon_net.json)",
+                                         "traffic": tr, "traffic_unit": f"HBM bytes/launch (rocprofv3 PMC, profiles/{tsrc}/traffic_canon_net.json)",
                                          "traffic_source": "committed"}
 
     if args.mode in ("all", "train"):

@@ -40,15 +40,30 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
 // Written select-style (one integer select, one fma-shaped op, one select) so it stays branch-free.
+// Every multiply-add of the coordinate arithmetic is spelled out (contraction off, explicit fma) -- the forms the compiler chose
+// on its own in rounds 1-3 -- so that two evaluations of the same pixel are the same bits wherever they are inlined: the source
+// window of a tile is derived from the sample points of its four corner pixels (group_action_body).
 __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
+#pragma clang fp contract(off)
   const bool lo = idx < (steps >> 1);
   const float k = (float)(lo ? idx : steps - 1 - idx);
-  const float up = -1.0f + step * k, dn = 1.0f - step * k;
+  const float up = __builtin_fmaf(step, k, -1.0f), dn = __builtin_fmaf(-step, k, 1.0f);
   return lo ? up : dn;
+}
+// affine_grid: [xn, yn, 1] . theta^T ; grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1).  Monotone in xn for a fixed yn
+// and in yn for a fixed xn (every step is a correctly rounded monotone function of its varying operand).
+__device__ __forceinline__ void sample_point(float t0, float t1, float t2, float t3, float t4, float t5, float xn, float yn,
+                                             float half_w, float half_h, float& ix, float& iy) {
+#pragma clang fp contract(off)
+  ix = ((__builtin_fmaf(t0, xn, t1 * yn) + t2) + 1.0f) * half_w;
+  iy = ((__builtin_fmaf(t3, xn, t4 * yn) + t5) + 1.0f) * half_h;
 }
 
 
 // ablation switches for tools/ablate.sh (never set in the product build)
+#ifndef EQA_ABL_BOXGUARD
+#define EQA_ABL_BOXGUARD 0.0f   // -DEQA_ABL_BOXGUARD=1e-3f: the guarded window of rounds 1-3
+#endif
 #ifdef EQA_ABL_NOLOAD
 #define EQA_ABL_YB(yb) (a.force_direct == 12345 ? (yb) : 0)
 #else
@@ -133,24 +148,35 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   // frame column of output column j (post-flip: hflip of the rotated frame, then the crop)
   auto frame_x = [&](int j) { return flip_dst ? (a.Wp - 1 - (a.left + j)) : (a.left + j); };
 
-  // ---- source window of the tile.  The map is affine in the normalised coords, so the extremes are sums of
-  // per-axis extremes; a 1e-3 px guard covers the rounding difference to the per-pixel evaluation below.
+  // ---- source window of the tile = the bounding box of the north-west neighbours its pixels have, + 1 for the south-east ones.
+  // The sample point is monotone along a row and along a column of the tile (sample_point), so its extremes over the tile are
+  // those of the four corner pixels -- evaluated here with the per-pixel arithmetic itself, which makes the box EXACT.  Rounds 1-3
+  // bounded it with the corners of the real-valued map and a 1e-3 px guard for the rounding difference.  For elements whose
+  // sample points are whole pixels (every multiple of 90 degrees: all of C4 / D4, half of C8) that guard always added the column
+  // left of the tile, which lies in the PREVIOUS 128-byte line: three line requests per window row instead of two.  The copy model
+  // (tools/micro/pc_tile.hip, window 35 vs 33) prices that at 7 % on 224 x 224 planes and 12 % on 1024 x 1024 ones; the exact box
+  // has the extra column only where rounding really puts a sample point below its pixel (a fifth of the tiles).
   const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
-  const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
-  const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
-  auto fmn = [](float p, float q) { return p < q ? p : q; };
-  auto fmx = [](float p, float q) { return p > q ? p : q; };
-  const float gx_lo = fmn(t0 * xa, t0 * xb) + fmn(t1 * ya, t1 * yb) + t2;
-  const float gx_hi = fmx(t0 * xa, t0 * xb) + fmx(t1 * ya, t1 * yb) + t2;
-  const float gy_lo = fmn(t3 * xa, t3 * xb) + fmn(t4 * ya, t4 * yb) + t5;
-  const float gy_hi = fmx(t3 * xa, t3 * xb) + fmx(t4 * ya, t4 * yb) + t5;
-  const float minx_f = (gx_lo + 1.0f) * a.half_w - 1e-3f, maxx_f = (gx_hi + 1.0f) * a.half_w + 1e-3f;
-  const float miny_f = (gy_lo + 1.0f) * a.half_h - 1e-3f, maxy_f = (gy_hi + 1.0f) * a.half_h + 1e-3f;
-  // keep at most one ring of off-frame (zero) pixels
-  const int x_lo = (int)floorf(fmx(minx_f, -1.0f)), y_lo = (int)floorf(fmx(miny_f, -1.0f));
-  // at least 2x2 so the clamped neighbour reads of fully off-frame pixels stay inside staged data
-  const int x_hi = max((int)floorf(fmn(maxx_f, (float)(a.Wp - 1))) + 1, x_lo + 1);
-  const int y_hi = max((int)floorf(fmn(maxy_f, (float)(a.Hp - 1))) + 1, y_lo + 1);
+  int x_lo, y_lo, x_hi, y_hi;
+  {
+    const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
+    const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
+    float cx[4], cy[4];
+    sample_point(t0, t1, t2, t3, t4, t5, xa, ya, a.half_w, a.half_h, cx[0], cy[0]);
+    sample_point(t0, t1, t2, t3, t4, t5, xb, ya, a.half_w, a.half_h, cx[1], cy[1]);
+    sample_point(t0, t1, t2, t3, t4, t5, xa, yb, a.half_w, a.half_h, cx[2], cy[2]);
+    sample_point(t0, t1, t2, t3, t4, t5, xb, yb, a.half_w, a.half_h, cx[3], cy[3]);
+    const float minx_f = floorf(fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3])) - EQA_ABL_BOXGUARD);
+    const float maxx_f = floorf(fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])) + EQA_ABL_BOXGUARD);
+    const float miny_f = floorf(fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3])) - EQA_ABL_BOXGUARD);
+    const float maxy_f = floorf(fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])) + EQA_ABL_BOXGUARD);
+    // keep at most one ring of off-frame (zero) pixels; a tile entirely off the frame keeps a 2 x 2 window at the frame's edge
+    x_lo = (int)fminf(fmaxf(minx_f, -1.0f), (float)(a.Wp - 1));
+    y_lo = (int)fminf(fmaxf(miny_f, -1.0f), (float)(a.Hp - 1));
+    // at least 2x2 so the clamped neighbour reads of fully off-frame pixels stay inside staged data
+    x_hi = max((int)fminf(fmaxf(maxx_f, -1.0f), (float)(a.Wp - 1)) + 1, x_lo + 1);
+    y_hi = max((int)fminf(fmaxf(maxy_f, -1.0f), (float)(a.Hp - 1)) + 1, y_lo + 1);
+  }
   const int bw = x_hi - x_lo + 1, bh = y_hi - y_lo + 1;
   const bool use_lds = (bw <= kBox) && (bh <= a.lds_rows) && !a.force_direct;
 
@@ -176,8 +202,8 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
     for (int k = 0; k < 4; ++k) {
       // affine_grid: [xn, yn, 1] . theta^T ; grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1)
       const float xn = lin_m1_p1(frame_x(pj + k), a.Wp, a.step_x);
-      const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
-      const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+      float ix, iy;
+      sample_point(t0, t1, t2, t3, t4, t5, xn, yn, a.half_w, a.half_h, ix, iy);
       const float xf = floorf(ix), yf = floorf(iy);
       const float wx1 = ix - xf, wy1 = iy - yf;
       const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
@@ -190,6 +216,9 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
       gy0[k] = yi;
       // (pixels of a partial tile beyond OW/OH are computed but never stored: keep their reads in the window)
       const int lx = min(max(xi - x_lo, 0), bw - 2), ly = min(max(yi - y_lo, 0), bh - 2);
+#ifdef EQA_CHECK_WINDOW   // validation build (tools/fuzz_r03.py --lib): a stored pixel whose neighbours are not in the corner-derived window
+      if (live[k] && pi < a.OH && pj + k < a.OW && (xi < x_lo || xi + 1 > x_hi || yi < y_lo || yi + 1 > y_hi)) __builtin_trap();
+#endif
       lidx[k] = ly * (CH * kLdsStride) + lx;
       if (MODE == 0) {
         w00[k] = wy0 * wx0;  // nw
@@ -367,7 +396,8 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
 #pragma unroll 1
           for (int k = 0; k < 4; ++k) {
             const float yn = lin_m1_p1(a.top + i, a.Hp, a.step_y), xn = lin_m1_p1(frame_x(jb + k), a.Wp, a.step_x);
-            const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w, iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+            float ix, iy;
+            sample_point(t0, t1, t2, t3, t4, t5, xn, yn, a.half_w, a.half_h, ix, iy);
             const float xf = floorf(ix), yf = floorf(iy);
             const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1)), yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
             const bool lv = xin && yin && row_ok && (jb + k < a.OW);
@@ -581,8 +611,8 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
   for (int k = 0; k < 4; ++k) {
     const int fj = a.left + jb + k;
     const float xn = lin_m1_p1(flip_dst ? (a.Wp - 1 - fj) : fj, a.Wp, a.step_x);
-    const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
-    const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+    float ix, iy;
+    sample_point(t0, t1, t2, t3, t4, t5, xn, yn, a.half_w, a.half_h, ix, iy);
     const float xf = floorf(ix), yf = floorf(iy);
     wx1[k] = ix - xf;
     wy1[k] = iy - yf;
@@ -737,8 +767,8 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_gather_kernel(const
       const int i = ii - a.top, j = (flip_dst ? (a.Wp - 1 - jf) : jf) - a.left;
       if (ii <= i_hi && jf <= j_hi && i >= 0 && i < a.OH && j >= 0 && j < a.OW) {
         const float xn = lin_m1_p1(jf, a.Wp, a.step_x), yn = lin_m1_p1(ii, a.Hp, a.step_y);
-        const float ix = ((t0 * xn + t1 * yn + t2) + 1.0f) * a.half_w;
-        const float iy = ((t3 * xn + t4 * yn + t5) + 1.0f) * a.half_h;
+        float ix, iy;
+        sample_point(t0, t1, t2, t3, t4, t5, xn, yn, a.half_w, a.half_h, ix, iy);
         const float xf = floorf(ix), yf = floorf(iy);
         const float wx1 = ix - xf, wy1 = iy - yf;
         const float ffx = (float)fx, ffy = (float)fy;

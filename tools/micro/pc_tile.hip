@@ -11,14 +11,17 @@
 #include <stdio.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr_t;
-constexpr int S = 224, C = 3, T = 32, LS = 47, TPI = 49;  // image edge, planes, tile edge, LDS row stride, tiles per image
+#ifndef S_EDGE
+#define S_EDGE 224          // -DS_EDGE=1024: config 5's planes (run with B = 32)
+#endif
+constexpr int S = S_EDGE, C = 3, T = 32, LS = 47, TR = S / T, TPI = TR * TR;  // image edge, planes, tile edge, LDS row stride, tiles per row / image
 constexpr int kPlaneLds = LS * LS;
 
 struct Win { int n, ty, tx, x_lo, y_lo; };
 __device__ __forceinline__ Win decode(int w, int xcd, int WB) {
   Win o;
   const int z = w / TPI, t = w - z * TPI;
-  o.ty = t / 7; o.tx = t - o.ty * 7; o.n = z * 8 + xcd;
+  o.ty = t / TR; o.tx = t - o.ty * TR; o.n = z * 8 + xcd;
   o.x_lo = min(max(o.tx * T - (WB - 33) / 2, 0), S - WB);
   o.y_lo = min(max(o.ty * T - (WB - 33) / 2, 0), S - WB);
   return o;
@@ -347,9 +350,9 @@ int main(int argc, char** argv) {
     // dirty L2 lines, ramp, tail)
     float *rs[4], *rd[4];
     for (int i = 0; i < 4; ++i) { (void)hipMalloc(&rs[i], bytes); (void)hipMalloc(&rd[i], bytes); (void)hipMemcpy(rs[i], s, bytes, hipMemcpyDeviceToDevice); }
-    const dim3 grid(8 * 7, 7, g_B / 8);
+    const dim3 grid(8 * TR, TR, g_B / 8);
     const size_t lds3 = (size_t)3 * kPlaneLds * 4;
-    for (int WB : {33, 47}) {
+    for (int WB : {33, 35, 47}) {     // (35: the window starts one pixel left of the tile, i.e. in the previous 128-byte line)
       int it = 0;
 #define RING(NTV, what) { const float us = time_us([&] { it = (it + 1) & 3; base_tile<NTV><<<grid, 256, lds3>>>(rs[it], rd[it], g_B, WB); }, 40); if (check(what)) report(what, WB, us); }
       RING(0, "ring: base, plain stores");
@@ -380,7 +383,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   for (int WB : {33, 47}) {
-    const dim3 grid(8 * 7, 7, g_B / 8);
+    const dim3 grid(8 * TR, TR, g_B / 8);
     const size_t lds3 = (size_t)3 * kPlaneLds * 4;
     float us = time_us([&] { base_tile<0><<<grid, 256, lds3>>>(s, d, g_B, WB); });
     if (check("base")) report("base: block per tile, 3 planes, stage-barrier-gather-store", WB, us);
