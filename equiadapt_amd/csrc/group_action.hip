@@ -40,9 +40,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 // torch.linspace(-1, 1, steps) as the CPU kernel evaluates it (symmetric halves), fp32.
 // Written select-style (one integer select, one fma-shaped op, one select) so it stays branch-free.
-// Every multiply-add of the coordinate arithmetic is spelled out (contraction off, explicit fma) -- the forms the compiler chose
-// on its own in rounds 1-3 -- so that two evaluations of the same pixel are the same bits wherever they are inlined: the source
-// window of a tile is derived from the sample points of its four corner pixels (group_action_body).
+// Every multiply-add of the coordinate arithmetic is spelled out (contraction off, explicit fma) so that two evaluations of the same
+// pixel are the same bits wherever they are inlined: the source window of a tile is derived from the sample points of its four
+// corner pixels (group_action_body).
 __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
 #pragma clang fp contract(off)
   const bool lo = idx < (steps >> 1);
@@ -52,15 +52,31 @@ __device__ __forceinline__ float lin_m1_p1(int idx, int steps, float step) {
 }
 // affine_grid: [xn, yn, 1] . theta^T ; grid_sample(align_corners=True): ((g + 1) / 2) * (size - 1).  Monotone in xn for a fixed yn
 // and in yn for a fixed xn (every step is a correctly rounded monotone function of its varying operand).
+// Which fp32 spelling of the three-term dot product is "the reference's" depends on the host: torch's CPU affine_grid is a batched
+// matrix product, and the same torch build evaluates it as x * t0, fma(y, t1, .), + t2 on an 8-thread container and as
+// (x * t0 + y * t1) + t2 with every operation rounded on the 128-thread host of the GPU box (tests/cpu_arith_probe.py, both outputs
+// in profiles/r04/cpu_arith_probe.txt); a GPU run of the reference goes through yet another BLAS.  The kernel pins the second,
+// plain IEEE form: together with the weights and the blend below (blend4, the same on both hosts) it reproduces the oracle of the
+// GPU box bit for bit on most pixels of every element, and EVERY host's oracle bit for bit for the elements that are multiples
+// of 90 degrees (tests/parity_scan.py, profiles/r04/parity_scan.txt).  Rounds 1-3 left the contraction to the compiler, which
+// rounded t1 * y first and fused the final multiply into the fractional part: 1.5e-4 from the oracle on white noise.
 __device__ __forceinline__ void sample_point(float t0, float t1, float t2, float t3, float t4, float t5, float xn, float yn,
                                              float half_w, float half_h, float& ix, float& iy) {
 #pragma clang fp contract(off)
-  ix = ((__builtin_fmaf(t0, xn, t1 * yn) + t2) + 1.0f) * half_w;
-  iy = ((__builtin_fmaf(t3, xn, t4 * yn) + t5) + 1.0f) * half_h;
+  ix = (((t0 * xn + t1 * yn) + t2) + 1.0f) * half_w;
+  iy = (((t3 * xn + t4 * yn) + t5) + 1.0f) * half_h;
+}
+// F.grid_sample's CPU kernel blends the four neighbours as one multiply and three fused multiply-adds in the order nw, ne, sw, se
+__device__ __forceinline__ float blend4(float nw, float ne, float sw, float se, float w_nw, float w_ne, float w_sw, float w_se) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(se, w_se, __builtin_fmaf(sw, w_sw, __builtin_fmaf(ne, w_ne, nw * w_nw)));
 }
 
 
 // ablation switches for tools/ablate.sh (never set in the product build)
+#ifndef EQA_ABL_MASKGUARD
+#define EQA_ABL_MASKGUARD 0     // -DEQA_ABL_MASKGUARD=1: the guard ring of mask_action_u8_kernel's staged box (rounds 1-3)
+#endif
 #ifndef EQA_ABL_BOXGUARD
 #define EQA_ABL_BOXGUARD 0.0f   // -DEQA_ABL_BOXGUARD=1e-3f: the guarded window of rounds 1-3
 #endif
@@ -129,7 +145,6 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably uniform: row math stays on the SALU
   int n, tile_x, tile_y;
   if (!block_tile(a.n_out, bz, n, tile_x, tile_y)) return;
-  const int j0 = tile_x * kTile, i0 = tile_y * kTile;
 
   int e, b;
   if (a.gidx) {
@@ -144,6 +159,20 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
   const float* th = a.theta + e * 6;
   const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
   const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+#ifndef EQA_ABL_ROWWALK
+  // Quarter turns read source ROWS along output COLUMNS: the blocks of an image then walk its tiles column by column, so that the
+  // blocks in flight together read whole source rows (DRAM pages) -- rows of output tiles read 128-byte pieces of 32 rows 4 KB
+  // apart on config 5's planes.  tools/micro/tile_shape.hip: 0.592 -> 0.629 of the HBM peak on 1024 x 1024 planes, no difference on
+  // 224 x 224 ones; the kernel (profiles/r04/kbench_exact_window.txt): a batch of quarter turns 171 -> 157 us per 32 frames of
+  // config 5, mixed batches and the metric's 224 x 224 frames unchanged.  (Any bijection of the image's tiles serves here.)
+  if (fabsf(t1) > fabsf(t0) && gridDim.y > 1) {
+    const int tiles_x = (int)(gridDim.x >> 3), tiles_y = (int)gridDim.y;
+    const int lin = tile_y * tiles_x + tile_x;
+    tile_x = lin / tiles_y;
+    tile_y = lin - tile_x * tiles_y;
+  }
+#endif
+  const int j0 = tile_x * kTile, i0 = tile_y * kTile;
 
   // frame column of output column j (post-flip: hflip of the rotated frame, then the crop)
   auto frame_x = [&](int j) { return flip_dst ? (a.Wp - 1 - (a.left + j)) : (a.left + j); };
@@ -461,7 +490,7 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
         for (int k = 0; k < 4; ++k) {
           const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
           const float sw = s[lidx[k] + CH * kLdsStride], se = s[lidx[k] + CH * kLdsStride + 1];
-          const float v = nw * w00[k] + ne * w01[k] + sw * w10[k] + se * w11[k];
+          const float v = blend4(nw, ne, sw, se, w00[k], w01[k], w10[k], w11[k]);
           acc[cc][k] = live[k] ? v : 0.0f;
         }
       }
@@ -490,7 +519,7 @@ __device__ __forceinline__ void group_action_body(const ActionArgs& a, const int
         const int o00 = src_offset(gy, gx, in00), o01 = src_offset(gy, gx + 1, in01);
         const int o10 = src_offset(gy + 1, gx, in10), o11 = src_offset(gy + 1, gx + 1, in11);
         const float v00 = pl[o00], v01 = pl[o01], v10 = pl[o10], v11 = pl[o11];
-        float v = (in00 ? v00 : 0.0f) * a00 + (in01 ? v01 : 0.0f) * a01 + (in10 ? v10 : 0.0f) * a10 + (in11 ? v11 : 0.0f) * a11;
+        float v = blend4(in00 ? v00 : 0.0f, in01 ? v01 : 0.0f, in10 ? v10 : 0.0f, in11 ? v11 : 0.0f, a00, a01, a10, a11);
         v = lv ? v : 0.0f;
 #pragma unroll
         for (int c2 = 0; c2 < CH; ++c2) {
@@ -1360,8 +1389,9 @@ __global__ __launch_bounds__(kThreads) void nearest_action_tile_kernel(const T* 
   const int i1 = min(i0 + kNearTile, OH) - 1, j1 = min(j0 + kNearTile, OW) - 1;
   float xa, ya, xb_, yb_, xc, yc, xd, yd;
   frame_xy(i0, j0, xa, ya); frame_xy(i0, j1, xb_, yb_); frame_xy(i1, j0, xc, yc); frame_xy(i1, j1, xd, yd);
-  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - 1, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + 1;
-  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - 1, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + 1;
+  // (no guard ring: the rounded coordinate is monotone along rows and columns, and a pixel outside the box is read from global memory)
+  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - EQA_ABL_MASKGUARD, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + EQA_ABL_MASKGUARD;
+  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - EQA_ABL_MASKGUARD, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + EQA_ABL_MASKGUARD;
   fx0 = max(fx0, 0); fx1 = min(fx1, Wp - 1); fy0 = max(fy0, 0); fy1 = min(fy1, Hp - 1);
   if (flip) { const int a = Wp - 1 - fx1, b = Wp - 1 - fx0; fx0 = a; fx1 = b; }
   const int sx0 = min(max(fx0 - pad, 0), W - 1), sx1 = min(max(fx1 - pad, 0), W - 1);
@@ -1438,8 +1468,12 @@ __global__ __launch_bounds__(kThreads) void mask_action_u8_kernel(const uint8_t*
   const int i1 = min(i0 + kNearTile, H) - 1, j1 = min(j0 + kNearTile, W) - 1;
   float xa, ya, xb_, yb_, xc, yc, xd, yd;
   frame_xy(i0, j0, xa, ya); frame_xy(i0, j1, xb_, yb_); frame_xy(i1, j0, xc, yc); frame_xy(i1, j1, xd, yd);
-  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - 1, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + 1;
-  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - 1, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + 1;
+  // The rounded coordinate is monotone along rows and columns of the tile, so the four corners bound it exactly; a pixel that
+  // landed outside the box all the same is read from global memory below, so the box needs no guard ring for correctness.  With
+  // one (rounds 1-3) the staged rows of an axis-aligned element were 66 bytes starting one byte in front of the tile's 64:
+  // two 128-byte lines per row instead of one.
+  int fx0 = (int)fminf(fminf(xa, xb_), fminf(xc, xd)) - EQA_ABL_MASKGUARD, fx1 = (int)fmaxf(fmaxf(xa, xb_), fmaxf(xc, xd)) + EQA_ABL_MASKGUARD;
+  int fy0 = (int)fminf(fminf(ya, yb_), fminf(yc, yd)) - EQA_ABL_MASKGUARD, fy1 = (int)fmaxf(fmaxf(ya, yb_), fmaxf(yc, yd)) + EQA_ABL_MASKGUARD;
   fx0 = max(fx0, 0); fx1 = min(fx1, W - 1); fy0 = max(fy0, 0); fy1 = min(fy1, H - 1);
   if (flip) { const int a = W - 1 - fx1, b = W - 1 - fx0; fx0 = a; fx1 = b; }
   const int sx0 = fx0 & ~3, sx1 = fx1;               // dword-aligned left edge

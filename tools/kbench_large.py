@@ -48,6 +48,7 @@ def main():
         cases = [("rand", torch.randint(0, 8, (B,), device=dev, dtype=torch.int32))]
         if B in (32,):
             cases += [(f"e{e}", torch.full((B,), e, device=dev, dtype=torch.int32)) for e in range(8)]
+            cases += [("rand again", cases[0][1]), ("rand, other draw", torch.randint(0, 8, (B,), device=dev, dtype=torch.int32))]
         for name, g in cases:
             def run():
                 i = it[0] = (it[0] + 1) % ring
