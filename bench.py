@@ -838,6 +838,15 @@ def main():
         import bench_tutorial
 
         line["tutorial"] = {leg: bench_tutorial.run_leg(leg, dev, 512, 20, 5, barrier=comm.barrier) for leg in ("prior", "optimized")}
+        if rank == 0:
+            # the step's dominant contraction on the bf16 matrix cores with fp32 semantics (every operand split exactly into three bf16
+            # pieces; 9 = every piece product, 6 = without the three of relative size <= 2^-24): opt-in (EQA_FFT_GEMM_PIECES),
+            # measured here beside the fp32 matrix instruction the timed step uses, with each result's distance to fp64
+            import kbench_gemm_pieces
+
+            line["gemm_pieces"] = kbench_gemm_pieces.measure(1024, 256, 256, 10, dev)
+            line["gemm_pieces"]["note"] = ("eqa_fft48k5_cgemm3m (f32: what the timed step runs) vs eqa_fft48k5_cgemm3m_bf16x3 with 9 / 6 piece "
+                                           "products on the headline layer's shape; not part of `value`")
         line["tutorial"]["note"] = ("understanding_discrete_canonicalization.ipynb cells 17+21 (ESCNN k=9, 16 ch, 3 layers, prior loss) and "
                                     "26+30 (Optimized + ConvNetwork k=5, artifact_err_wt=1000): canonicalize -> loss -> backward -> Adam step "
                                     "-> identity metric, synthetic CIFAR-shaped batches; images_s per rank")

@@ -1,0 +1,370 @@
+// libeqa_hip.so, part 11 -- the channel contraction of the overlap-save FFT convolution (cgemm3m.hip) on the bf16 matrix cores,
+// EXACT in the sense the fp32 matrix instruction is: every fp32 operand is split without error into three bf16 pieces
+//     x = p1 + p2 + p3,     p1 = the top 16 bits of x, p2 = the top 16 bits of x - p1, p3 = x - p1 - p2   (8 significant bits each:
+//     3 x 8 = the 24 of an fp32 significand; truncation keeps the remainders' signs equal, so no bit is spent twice)
+// and the product of two operands is the sum of the nine products of their pieces, each of which the matrix core forms exactly
+// (8 x 8 significant bits) and accumulates in fp32 -- the same "exact products, fp32 accumulation" contract as
+// v_mfma_f32_32x32x2_f32, in a different summation order.  v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles where the fp32
+// form retires 2 per 64: nine piece products cost 288 cycles per 16 k against 512.  C ABI: include/eqa_hip.h; DESIGN.md 3.8.
+//
+// TERMS = 9: all piece products (the default when this path is selected).  TERMS = 6: the three products of relative size
+// <= 2^-24 (p2.p3, p3.p2, p3.p3) are left out -- an error of at most 2^-23 |a||b| per product, the size of the rounding a single
+// fp32 multiply-add commits; opt-in (the caller passes terms = 6), reported beside the exact form, never silently.
+//
+// Same work decomposition, operand flow and epilogue as fft_cgemm3m_kernel: a wave-tile is (frequency, 64 rows, 64 complex
+// columns), three accumulator sets (T1 = Ar.Br, T2 = Ai.Bi, T3 = (Ar + Ai).(Br + Bi)), one wave per SIMD, no LDS for operands,
+// operands one K-stage (16 complex k) ahead, the finished tile parked in LDS and flushed under the next tile's MFMA stream.
+// A (the spectra of the activations, fp32 in HBM) is split in registers: 48 values per lane and stage, ~6 VALU instructions each,
+// in the shadow of the matrix instructions (tools/micro/bf16x3_rate.hip: 3925 cycles per stage with the split, 3465 without,
+// 6144 in the fp32 form).  B (the filter spectra) is split once per weight version (eqa_fft48k5_spectra3m_split) into the
+// fragment order of the bf16 instruction: (F, S, Cout / 32, 3 parts, 3 pieces, 64 lanes, 8 bf16).
+// The instruction sums over k in any order, so a lane keeps the 16 + 16 bytes it loads today: slot e = 4 b + t of lane (i, h) is
+// channel 16 s + 8 b + 4 h + t on both sides.
+#include "eqa_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kTileM = 64, kTileN = 64;
+constexpr int kStageK = 16;
+constexpr unsigned kHi = 0xffff0000u;
+
+// 8 fp32 values (two 16-byte loads) -> three packed operands of the bf16 instruction
+struct Pieces {
+  u32x4 p[3];
+};
+__device__ __forceinline__ Pieces split8(const f32x4 lo, const f32x4 hi) {
+  Pieces o;
+#ifdef EQA_CGEMM_NOSPLIT      // experiment: no split arithmetic (wrong values): what the kernel costs without its vector work
+  o.p[0] = __builtin_bit_cast(u32x4, lo); o.p[1] = __builtin_bit_cast(u32x4, hi); o.p[2] = __builtin_bit_cast(u32x4, lo);
+  return o;
+#endif
+  unsigned x0[8], x1[8], x2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float a = e < 4 ? lo[e & 3] : hi[e & 3];
+    const float p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & kHi);
+    const float r1 = a - p1;                                       // exact: the low 16 bits of the significand
+    const float p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & kHi);
+    const float r2 = r1 - p2;                                      // exact: at most 8 significant bits -> a bf16 as it stands
+    x0[e] = __builtin_bit_cast(unsigned, a);
+    x1[e] = __builtin_bit_cast(unsigned, r1);
+    x2[e] = __builtin_bit_cast(unsigned, r2);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                                    // the high halves of two floats -> one dword (v_perm_b32)
+    o.p[0][j] = __builtin_amdgcn_perm(x0[2 * j + 1], x0[2 * j], 0x07060302u);
+    o.p[1][j] = __builtin_amdgcn_perm(x1[2 * j + 1], x1[2 * j], 0x07060302u);
+    o.p[2][j] = __builtin_amdgcn_perm(x2[2 * j + 1], x2[2 * j], 0x07060302u);
+  }
+  return o;
+}
+
+// Registers: 192 accumulators (AGPRs) leave 256 + 64 for everything else, and the register allocator shuttles operands between
+// the two files once the architectural half overflows (first version: 576 v_accvgpr copies per 216 matrix instructions, no faster
+// than the fp32 kernel).  So B is held by HALF stages -- the 36 registers of one 32-column half in use, the other half in flight --
+// and a stage runs column half by column half: [n = 0: m = 0, m = 1] [n = 1: m = 0, m = 1] with the pieces of both row halves of A
+// (72 registers) split once per stage.
+struct ARaw {                    // the rows of one 32-row half of a K-stage of A as loaded: fp32, [b]
+  f32x4 ar[2], ai[2];
+};
+struct BHalf {                   // one 32-column half of a K-stage of B: [part r/i/s][piece]
+  u32x4 b[3][3];
+};
+struct APieces {
+  Pieces a[2][3];                // [m][part]
+};
+
+struct StageAddr {
+  __amdgpu_buffer_rsrc_t a, b;
+  unsigned sa, sb;
+};
+
+__device__ __forceinline__ u32x4 buf_ld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+
+constexpr unsigned kBFrag = 64 * 16;    // bytes of one (part, piece) fragment of a 32-column tile
+
+__device__ __forceinline__ void load_a(ARaw& o, const StageAddr& at, unsigned aoff) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    o.ar[b] = __builtin_bit_cast(f32x4, buf_ld(at.a, aoff + 32 * b, at.sa));
+    o.ai[b] = __builtin_bit_cast(f32x4, buf_ld(at.a, aoff + 32 * b + 64, at.sa));
+  }
+}
+__device__ __forceinline__ void load_b(BHalf& o, const StageAddr& at, unsigned boff, int n) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) o.b[p][q] = buf_ld(at.b, boff + ((n * 3 + p) * 3 + q) * kBFrag, at.sb);
+}
+
+__device__ __forceinline__ void split_a(APieces& P, const ARaw& r, int m) {
+  P.a[m][0] = split8(r.ar[0], r.ar[1]);
+  P.a[m][1] = split8(r.ai[0], r.ai[1]);
+  P.a[m][2] = split8(r.ar[0] + r.ai[0], r.ar[1] + r.ai[1]);
+}
+
+__device__ __forceinline__ f32x16 mma(const u32x4 a, const u32x4 b, const f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// the matrix instructions of one (column half n, row half m): consecutive ones go to different accumulators, large products first
+template <int TERMS>
+__device__ __forceinline__ void mma_quarter(const APieces& P, const BHalf& B, f32x16 (&acc)[3][2][2], int m, int n) {
+#pragma unroll
+  for (int w = 0; w < 5; ++w)         // w = pa + pb
+#pragma unroll
+    for (int pa = 0; pa < 3; ++pa) {
+      const int pb = w - pa;
+      if (pb < 0 || pb > 2 || (TERMS == 6 && w > 2)) continue;
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc[p][m][n] = mma(P.a[m][p].p[pa], B.b[p][pb], acc[p][m][n]);
+    }
+}
+
+constexpr int kLdsRowFloats = 2 * kTileN;
+constexpr int kLdsWaveFloats = kTileM * kLdsRowFloats;
+
+struct ParkedDst {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int voff, pair_bytes;
+  unsigned soff;
+};
+
+__device__ __forceinline__ void store_pair(const ParkedDst& d, int p, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), d.rsrc, d.voff + p * d.pair_bytes, d.soff, 0);
+}
+__device__ __forceinline__ void flush_rows(const float* lds_lane, const ParkedDst& d, int p0, int p1) {
+  for (int p = p0; p < p1; ++p) store_pair(d, p, *reinterpret_cast<const f32x4*>(lds_lane + p * (2 * kLdsRowFloats)));
+}
+
+// One K-stage = four quarters (column half n, row half m), 3 x TERMS matrix instructions each, every quarter one scheduling region
+// in which the instruction order is pinned: the wave issues in order, so whatever is to run in the shadow of the matrix pipe has
+// to sit BETWEEN two matrix instructions.
+//   quarter (0,0): + split of THIS stage's row half 1 (its pieces are dead since the previous stage's last quarter)
+//                  + requests: this stage's column half 1 of B, the next stage's row half 0 of A
+//   quarter (1,0): + request: the next stage's row half 1 of A (its registers were read by the split just done)
+//   quarter (0,1): + request: the next stage's column half 0 of B (half 0 was last read in the previous quarter); parked rows leave
+//   quarter (1,1): + split of the NEXT stage's row half 0 (requested three quarters ago)
+// so a B half is requested half a stage before its use, A a whole stage, and the 280 VALU instructions of a stage's splits are
+// spread over two quarters.  On entry: P.a[0] = pieces of this stage's row half 0, raw1 = this stage's row half 1 as loaded,
+// B0 = this stage's column half 0.
+template <int NMMA, int NVALU, int NLOAD, int NSTORE, int NDS>
+__device__ __forceinline__ void pin_quarter() {
+#ifndef EQA_CGEMM_BF16_NOPIN
+  if (NDS) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+  constexpr int kMem = NLOAD + NSTORE;
+  constexpr int kValuPer = (NVALU + NMMA - 1) / NMMA;
+#pragma unroll
+  for (int k = 0; k < NMMA; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                       // one matrix instruction
+    if (k < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // one load behind each of the first ones
+    else if (k < kMem) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);    // ... then the stores
+    if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);     // its share of the vector arithmetic
+  }
+#endif
+}
+
+template <int NPAIR, int TERMS>
+__device__ __forceinline__ void run_stage(APieces& P, ARaw& raw0, ARaw& raw1, BHalf& B0, BHalf& B1, f32x16 (&acc)[3][2][2],
+                                          const StageAddr& cur, const StageAddr& nxt, unsigned naoff0, unsigned naoff1, unsigned boff,
+                                          const float* lds_lane, const ParkedDst& dst, int p0) {
+  constexpr int kQ = 3 * TERMS;          // matrix instructions per quarter
+  constexpr int kSplit = 150;            // vector instructions of one row half's split (an upper bound for the pinning)
+  f32x4 park[NPAIR > 0 ? NPAIR : 1];
+  __builtin_amdgcn_sched_barrier(0);
+  load_b(B1, cur, boff, 1);
+  load_a(raw0, nxt, naoff0);
+  split_a(P, raw1, 1);
+  mma_quarter<TERMS>(P, B0, acc, 0, 0);
+  pin_quarter<kQ, kSplit, 13, 0, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+  load_a(raw1, nxt, naoff1);
+  mma_quarter<TERMS>(P, B0, acc, 1, 0);
+  pin_quarter<kQ, 0, 4, 0, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) park[k] = *reinterpret_cast<const f32x4*>(lds_lane + (p0 + k) * (2 * kLdsRowFloats));
+  load_b(B0, nxt, boff, 0);
+  mma_quarter<TERMS>(P, B1, acc, 0, 1);
+#pragma unroll
+  for (int k = 0; k < NPAIR; ++k) store_pair(dst, p0 + k, park[k]);
+  pin_quarter<kQ, 0, 9, NPAIR, NPAIR>();
+  __builtin_amdgcn_sched_barrier(0);
+  split_a(P, raw0, 0);
+  mma_quarter<TERMS>(P, B1, acc, 1, 1);
+  pin_quarter<kQ, kSplit, 0, 0, 0>();
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NPAIR, int TERMS>
+__global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* __restrict__ V, const uint16_t* __restrict__ Bp,
+                                                                  float* __restrict__ Mo, int M, int pitch, int Cin, int Cout, int F,
+                                                                  int n_rt, int n_ct, int waves_per_xcd) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & (kXcd - 1);
+  const int q = (blockIdx.x >> 3) * 4 + wave;
+  const int S = Cin / kStageK;
+  const int wpf = n_rt * n_ct;
+  const int nf_x = (F - xcd + kXcd - 1) / kXcd;
+  const int total = nf_x * wpf;
+  if (q >= total) return;
+  const int i = lane & 31, h = lane >> 5;
+  __shared__ __attribute__((aligned(16))) float lds_all[4 * kLdsWaveFloats];
+  float* lds_w = lds_all + wave * kLdsWaveFloats;
+  const float* lds_lane = lds_w + h * kLdsRowFloats + i * 4;
+  const size_t rowf = (size_t)2 * Cin, mo_row = (size_t)2 * Cout;
+  const unsigned b_stage_bytes = (unsigned)(Cout / 32) * 9 * kBFrag;        // bytes per (f, stage) of Bp
+  const unsigned a_stage = 32u * 4u;
+  const unsigned boff = lane * 16;
+
+  auto locate = [&](int u, StageAddr& at, unsigned& aoff0, unsigned& aoff1, int& f, int& row0, int& ct) {
+#ifdef EQA_CGEMM_SAMETILE     // experiment: every wave-tile reads tile 0 -- operands always cached
+    u = 0;
+#endif
+    const int fi = u / wpf, r = u - fi * wpf;
+    f = xcd + kXcd * fi;
+    const int rt = r / n_ct;
+    ct = r - rt * n_ct;
+    row0 = rt * kTileM;
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, (unsigned)((size_t)pitch * rowf * 4), 0x00020000);
+    at.sa = 0;
+    aoff0 = (unsigned)((size_t)(row0 + i) * rowf + 4 * h) * 4u;
+    aoff1 = aoff0 + 32 * (unsigned)rowf * 4u;
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp) + (size_t)f * S * (b_stage_bytes / 2), 0, (unsigned)S * b_stage_bytes, 0x00020000);
+    at.sb = (unsigned)(2 * ct) * (9 * kBFrag);
+  };
+  auto at_stage = [&](const StageAddr& t, int s) { return StageAddr{t.a, t.b, t.sa + s * a_stage, t.sb + s * b_stage_bytes}; };
+  auto parked = [&](int f, int row0, int ct) {
+    const int rows = min(kTileM, M - row0);
+    ParkedDst d;
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo + ((size_t)f * pitch + row0) * mo_row, 0, (unsigned)(rows * mo_row * 4), 0x00020000);
+    d.voff = (h * (int)mo_row + ct * kLdsRowFloats + i * 4) * 4;
+    d.pair_bytes = 2 * (int)mo_row * 4;
+    d.soff = 0;
+    return d;
+  };
+
+  StageAddr at;
+  unsigned aoff0, aoff1;
+  int f, row0, ct;
+  locate(q, at, aoff0, aoff1, f, row0, ct);
+  ParkedDst dst = parked(f, row0, ct);
+  dst.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo, 0, 0, 0x00020000);       // nothing parked yet: an empty buffer drops the stores
+  ARaw raw0, raw1;
+  APieces P;
+  BHalf B0, B1;
+  load_a(raw0, at, aoff0);
+  load_a(raw1, at, aoff1);
+  load_b(B0, at, boff, 0);
+  split_a(P, raw0, 0);
+  for (int u = q; u < total; u += waves_per_xcd) {
+    f32x16 acc[3][2][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[p][m][n][e] = 0.f;
+    const int un = u + waves_per_xcd < total ? u + waves_per_xcd : u;
+    StageAddr nat;
+    unsigned naoff0, naoff1;
+    int nf, nrow0, nct;
+    locate(un, nat, naoff0, naoff1, nf, nrow0, nct);
+    for (int s = 0; s < S; ++s) {
+      const bool more = s + 1 < S;
+      if (NPAIR == 0) flush_rows(lds_lane, dst, (32 * s) / S, (32 * (s + 1)) / S);
+      run_stage<NPAIR, TERMS>(P, raw0, raw1, B0, B1, acc, at_stage(at, s), more ? at_stage(at, s + 1) : nat, more ? aoff0 : naoff0,
+                              more ? aoff1 : naoff1, boff, lds_lane, dst, s * NPAIR);
+    }
+    // epilogue: Cr = T1 - T2, Ci = T3 - T1 - T2 into the wave's LDS tile (accumulator layout = that of the fp32 instruction)
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = 32 * m + (e & 3) + 8 * (e >> 2) + 4 * h;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const float t1 = acc[0][m][n][e], t2 = acc[1][m][n][e], t3 = acc[2][m][n][e];
+          f32x2v c;
+          c[0] = t1 - t2;
+          c[1] = t3 - t1 - t2;
+          *reinterpret_cast<f32x2v*>(lds_w + r * kLdsRowFloats + (32 * n + i) * 2) = c;
+        }
+      }
+    dst = parked(f, row0, ct);
+    at = nat; aoff0 = naoff0; aoff1 = naoff1; f = nf; row0 = nrow0; ct = nct;
+  }
+  flush_rows(lds_lane, dst, 0, 32);
+}
+
+// B3 (F, S, Cout/32, 3, 2, 64, 4) fp32 -> Bp (F, S, Cout/32, 3, 3, 64, 8) bf16: one thread per (f, s, column tile, part, lane)
+__global__ __launch_bounds__(256) void spectra3m_split_kernel(const float* __restrict__ B3, uint16_t* __restrict__ Bp, size_t groups) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= groups * 64) return;
+  const size_t g = t >> 6;            // (f, s, nt, part)
+  const int lane = (int)(t & 63);
+  const float* src = B3 + g * (2 * 64 * 4) + lane * 4;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(src), hi = *reinterpret_cast<const f32x4*>(src + 64 * 4);
+  const Pieces p = split8(lo, hi);
+  u32x4* dst = reinterpret_cast<u32x4*>(Bp + g * (3 * 64 * 8)) + lane;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) dst[q * 64] = p.p[q];
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout) {
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout)) return 0;
+  return (int64_t)eqa_fft48k5_frequencies() * Cin * Cout * 3 * 3 * 2;
+}
+
+int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream) {
+  if (!B3 || !Bp) return EQA_ERR_INVALID_ARG;
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || (((uintptr_t)B3 | (uintptr_t)Bp) & 15)) return EQA_ERR_UNSUPPORTED;
+  const size_t groups = (size_t)eqa_fft48k5_frequencies() * (Cin / kStageK) * (Cout / 32) * 3;
+  const size_t threads = groups * 64;
+  hipLaunchKernelGGL(spectra3m_split_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B3,
+                     static_cast<uint16_t*>(Bp), groups);
+  return launch_status();
+}
+
+int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_t M, int Cin, int Cout, int terms, void* stream) {
+  if (!V || !Bp || !Mo || M < 0 || Cin <= 0 || Cout <= 0 || (terms != 9 && terms != 6)) return EQA_ERR_INVALID_ARG;
+  if (M == 0) return EQA_OK;
+  const int F = eqa_fft48k5_frequencies();
+  const int64_t fm_bytes = ((M | 1) + 64) * 2 * (int64_t)std::max(Cin, Cout) * 4;
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || M > 0x3fffff || fm_bytes > 0x7fffffffLL || (int64_t)Cin * Cout * 9 * 2 > 0x7fffffffLL ||
+      (((uintptr_t)V | (uintptr_t)Bp | (uintptr_t)Mo) & 15))
+    return EQA_ERR_UNSUPPORTED;
+  const int n_rt = (int)((M + kTileM - 1) / kTileM), n_ct = Cout / kTileN;
+  const int blocks = 256;
+  const int S = Cin / kStageK;
+#define EQA_CG_LAUNCH(NP, T)                                                                                                       \
+  hipLaunchKernelGGL((fft_cgemm3m_bf16_kernel<NP, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, static_cast<const uint16_t*>(Bp), \
+                     Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rt, n_ct, (blocks / kXcd) * 4)
+#define EQA_CG_TERMS(NP) do { if (terms == 9) EQA_CG_LAUNCH(NP, 9); else EQA_CG_LAUNCH(NP, 6); } while (0)
+  switch (32 % S == 0 ? 32 / S : 0) {
+    case 4: EQA_CG_TERMS(4); break;
+    case 2: EQA_CG_TERMS(2); break;
+    case 1: EQA_CG_TERMS(1); break;
+    default: EQA_CG_TERMS(0); break;
+  }
+#undef EQA_CG_TERMS
+#undef EQA_CG_LAUNCH
+  return launch_status();
+}
+
+}  // extern "C"

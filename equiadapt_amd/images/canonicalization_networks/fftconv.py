@@ -25,16 +25,31 @@ TRAIN_FORWARD = os.environ.get("EQA_FFT_TRAIN", "1") != "0"     # forward pass o
 # The per-frequency channel contraction: "3m" = the hand-written complex GEMM on the fp32 MFMA in the 3-multiplication form
 # (eqa_fft48k5_cgemm3m; channel counts it takes: Cin % 32 == 0, Cout % 64 == 0), "lib" = the library's real batched GEMM.
 GEMM = os.environ.get("EQA_FFT_GEMM", "3m")
+# How the hand-written GEMM multiplies: "f32" = the fp32 matrix instruction; "9" / "6" = every fp32 operand split exactly into three
+# bf16 pieces and that many piece products on the bf16 matrix cores (eqa_fft48k5_cgemm3m_bf16x3: 9 = every product, the same
+# exact-products / fp32-accumulation contract as the fp32 instruction; 6 = without the three products of relative size <= 2^-24).
+GEMM_PIECES = os.environ.get("EQA_FFT_GEMM_PIECES", "f32")
 
 
 class Spectra3M:
     """Filter spectra in the operand order of eqa_fft48k5_cgemm3m: ``data`` is the flat (F * Cin * Cout * 3) fp32 buffer
-    [Br | Bi | Br + Bi] per (frequency, K-stage, 32 output channels)."""
+    [Br | Bi | Br + Bi] per (frequency, K-stage, 32 output channels); ``pieces()``: the same split into three bf16 pieces per value
+    in the fragment order of the bf16 matrix instruction (built on first use)."""
 
-    __slots__ = ("data", "cin", "cout")
+    __slots__ = ("data", "cin", "cout", "_pieces")
 
     def __init__(self, data: torch.Tensor, cin: int, cout: int):
-        self.data, self.cin, self.cout = data, cin, cout
+        self.data, self.cin, self.cout, self._pieces = data, cin, cout, None
+
+    def pieces(self) -> torch.Tensor:
+        if self._pieces is None:
+            lib = _lib.load()
+            bp = torch.empty(lib.eqa_fft48k5_spectra3m_bf16_bytes(self.cin, self.cout) // 2, dtype=torch.int16, device=self.data.device)
+            with torch.cuda.device(self.data.device):
+                _lib.check(lib.eqa_fft48k5_spectra3m_split(self.data.data_ptr(), bp.data_ptr(), self.cin, self.cout,
+                                                           torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_spectra3m_split")
+            self._pieces = bp
+        return self._pieces
 
 
 def gemm3m_supported(cin: int, cout: int) -> bool:
@@ -70,6 +85,10 @@ def contract(V: torch.Tensor, B, M: int) -> torch.Tensor:
         lib = _lib.load()
         assert V.shape[2] == 2 * B.cin and V.stride(1) == 2 * B.cin and V.stride(0) == lib.eqa_fft48k5_tile_pitch(M) * 2 * B.cin
         Mo = spectra_buffer(M, 2 * B.cout, dev)
+        if GEMM_PIECES in ("9", "6"):
+            _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, int(GEMM_PIECES),
+                                                      torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_cgemm3m_bf16x3")
+            return Mo
         _lib.check(lib.eqa_fft48k5_cgemm3m(V.data_ptr(), B.data.data_ptr(), Mo.data_ptr(), M, B.cin, B.cout,
                                            torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_cgemm3m")
         return Mo

@@ -448,6 +448,17 @@ int eqa_fft48k5_cgemm3m_supported(int Cin, int Cout);
 int64_t eqa_fft48k5_spectra3m_floats(int Cin, int Cout);
 int eqa_fft48k5_filter_spectra3m(const float* bank, float* B3, int Cout, int Cin, int correlate, void* stream);
 int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, int Cin, int Cout, void* stream);
+/* The same contraction on the bf16 matrix cores with fp32 semantics (csrc/cgemm3m_bf16.hip): every fp32 operand is split without
+ * error into three bf16 pieces (8 significant bits each), the product of two operands is the sum of the products of their pieces
+ * -- each exact in the matrix core -- accumulated in fp32.  terms = 9: every piece product (exact products, fp32 accumulation: the
+ * contract of the fp32 matrix instruction, in another summation order); terms = 6: without the three products of relative size
+ * <= 2^-24 (error <= 2^-23 |a||b| per product).  Same reference arithmetic as eqa_fft48k5_cgemm3m (escnn_networks.py:67-91).
+ *   eqa_fft48k5_spectra3m_bf16_bytes  bytes of Bp = F * Cin * Cout * 3 parts * 3 pieces * 2.
+ *   eqa_fft48k5_spectra3m_split       B3 (the operand of eqa_fft48k5_cgemm3m) -> Bp:(F, Cin/16, Cout/32, 3, 3 pieces, 64, 8) bf16.
+ *   eqa_fft48k5_cgemm3m_bf16x3        V, Bp -> Mo; shapes and layouts of V / Mo as for eqa_fft48k5_cgemm3m. */
+int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout);
+int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream);
+int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_t M, int Cin, int Cout, int terms, void* stream);
 /* The filter gradient's contraction (training), replacing the library's real [2Cin x M].[M x 2Cout] product (autograd through the
  * same R2Conv): D[f] = V[f]^T . conj(G[f]) over the M tiles in the 3-multiplication form on the fp32 MFMA.  V:(F, M|1, 2Cin),
  * G:(F, M|1, 2Cout) as eqa_fft48k5_input / _grad_transform write them; D3:(F, Cin, 2, Cout) = Dr | Di per input channel, plain
