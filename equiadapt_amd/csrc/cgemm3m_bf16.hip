@@ -175,16 +175,28 @@ __device__ __forceinline__ void pin_quarter() {
 template <int NPAIR, int TERMS>
 __device__ __forceinline__ void run_stage(APieces& P, ARaw& raw0, ARaw& raw1, BHalf& B0, BHalf& B1, f32x16 (&acc)[3][2][2],
                                           const StageAddr& cur, const StageAddr& nxt, unsigned naoff0, unsigned naoff1, unsigned boff,
-                                          const float* lds_lane, const ParkedDst& dst, int p0) {
+                                          const float* lds_lane, const ParkedDst& dst, int p0, const StageAddr& far, unsigned far_off,
+                                          unsigned& touch) {
   constexpr int kQ = 3 * TERMS;          // matrix instructions per quarter
   constexpr int kSplit = 150;            // vector instructions of one row half's split (an upper bound for the pinning)
   f32x4 park[NPAIR > 0 ? NPAIR : 1];
   __builtin_amdgcn_sched_barrier(0);
+#ifdef EQA_CGEMM_TOUCH     // experiment, measured SLOWER (3.46 vs 3.32 ms): not the missing look-ahead
+  // A stage is 1.8 us of matrix instructions and A is requested three quarters of a stage ahead: less than an HBM round trip
+  // under load.  One dword per lane (= per row of the tile: a row's stage is one 128-byte line) of the stage kPrefetch ahead pulls
+  // those lines into L2 early; the value is never used (the previous stage's is retired here, a stage after its request).
+  asm volatile("" ::"v"(touch));
+  touch = __builtin_amdgcn_raw_buffer_load_b32(far.a, far_off, far.sa, 0);
+#endif
   load_b(B1, cur, boff, 1);
   load_a(raw0, nxt, naoff0);
   split_a(P, raw1, 1);
   mma_quarter<TERMS>(P, B0, acc, 0, 0);
+#ifdef EQA_CGEMM_TOUCH
+  pin_quarter<kQ, kSplit, 14, 0, 0>();
+#else
   pin_quarter<kQ, kSplit, 13, 0, 0>();
+#endif
   __builtin_amdgcn_sched_barrier(0);
   load_a(raw1, nxt, naoff1);
   mma_quarter<TERMS>(P, B0, acc, 1, 0);
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
   const unsigned a_stage = 32u * 4u;
   const unsigned boff = lane * 16;
 
-  auto locate = [&](int u, StageAddr& at, unsigned& aoff0, unsigned& aoff1, int& f, int& row0, int& ct) {
+  auto locate = [&](int u, StageAddr& at, unsigned& aoff0, unsigned& aoff1, int& f, int& row0, int& ct, unsigned& toff) {
 #ifdef EQA_CGEMM_SAMETILE     // experiment: every wave-tile reads tile 0 -- operands always cached
     u = 0;
 #endif
@@ -235,18 +247,34 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
     const int rt = r / n_ct;
     ct = r - rt * n_ct;
     row0 = rt * kTileM;
+#ifdef EQA_CGEMM_SAME_A      // experiment: A always from (frequency 0, row tile 0)
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, (unsigned)((size_t)pitch * rowf * 4), 0x00020000);
+    at.sa = 0;
+    aoff0 = (unsigned)((size_t)i * rowf + 4 * h) * 4u;
+#else
     at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, (unsigned)((size_t)pitch * rowf * 4), 0x00020000);
     at.sa = 0;
     aoff0 = (unsigned)((size_t)(row0 + i) * rowf + 4 * h) * 4u;
+#endif
     aoff1 = aoff0 + 32 * (unsigned)rowf * 4u;
+    toff = (unsigned)((size_t)(row0 + lane) * rowf) * 4u;                  // row `lane` of the tile: the prefetch touch
+#ifdef EQA_CGEMM_SAME_B      // experiment: B always from (frequency 0, column tile 0)
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp), 0, (unsigned)S * b_stage_bytes, 0x00020000);
+    at.sb = 0;
+#else
     at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp) + (size_t)f * S * (b_stage_bytes / 2), 0, (unsigned)S * b_stage_bytes, 0x00020000);
     at.sb = (unsigned)(2 * ct) * (9 * kBFrag);
+#endif
   };
   auto at_stage = [&](const StageAddr& t, int s) { return StageAddr{t.a, t.b, t.sa + s * a_stage, t.sb + s * b_stage_bytes}; };
   auto parked = [&](int f, int row0, int ct) {
     const int rows = min(kTileM, M - row0);
     ParkedDst d;
+#ifdef EQA_CGEMM_NOSTORE     // experiment: an empty buffer drops the stores
+    d.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo, 0, 0, 0x00020000);
+#else
     d.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo + ((size_t)f * pitch + row0) * mo_row, 0, (unsigned)(rows * mo_row * 4), 0x00020000);
+#endif
     d.voff = (h * (int)mo_row + ct * kLdsRowFloats + i * 4) * 4;
     d.pair_bytes = 2 * (int)mo_row * 4;
     d.soff = 0;
@@ -256,8 +284,11 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
   StageAddr at;
   unsigned aoff0, aoff1;
   int f, row0, ct;
-  locate(q, at, aoff0, aoff1, f, row0, ct);
+  unsigned toff;
+  locate(q, at, aoff0, aoff1, f, row0, ct, toff);
   ParkedDst dst = parked(f, row0, ct);
+  unsigned touch = 0;
+  constexpr int kPrefetch = 3;             // stages between the touch of a row's line and the request of its operands
   dst.rsrc = __builtin_amdgcn_make_buffer_rsrc(Mo, 0, 0, 0x00020000);       // nothing parked yet: an empty buffer drops the stores
   ARaw raw0, raw1;
   APieces P;
@@ -278,14 +309,16 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
           for (int e = 0; e < 16; ++e) acc[p][m][n][e] = 0.f;
     const int un = u + waves_per_xcd < total ? u + waves_per_xcd : u;
     StageAddr nat;
-    unsigned naoff0, naoff1;
+    unsigned naoff0, naoff1, ntoff;
     int nf, nrow0, nct;
-    locate(un, nat, naoff0, naoff1, nf, nrow0, nct);
+    locate(un, nat, naoff0, naoff1, nf, nrow0, nct, ntoff);
     for (int s = 0; s < S; ++s) {
       const bool more = s + 1 < S;
       if (NPAIR == 0) flush_rows(lds_lane, dst, (32 * s) / S, (32 * (s + 1)) / S);
+      const bool far_here = s + kPrefetch < S;   // (S < kPrefetch: the touches run into the next tile's later stages -- harmless)
       run_stage<NPAIR, TERMS>(P, raw0, raw1, B0, B1, acc, at_stage(at, s), more ? at_stage(at, s + 1) : nat, more ? aoff0 : naoff0,
-                              more ? aoff1 : naoff1, boff, lds_lane, dst, s * NPAIR);
+                              more ? aoff1 : naoff1, boff, lds_lane, dst, s * NPAIR,
+                              far_here ? at_stage(at, s + kPrefetch) : at_stage(nat, s + kPrefetch - S), far_here ? toff : ntoff, touch);
     }
     // epilogue: Cr = T1 - T2, Ci = T3 - T1 - T2 into the wave's LDS tile (accumulator layout = that of the fp32 instruction)
 #pragma unroll
@@ -303,8 +336,9 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
         }
       }
     dst = parked(f, row0, ct);
-    at = nat; aoff0 = naoff0; aoff1 = naoff1; f = nf; row0 = nrow0; ct = nct;
+    at = nat; aoff0 = naoff0; aoff1 = naoff1; f = nf; row0 = nrow0; ct = nct; toff = ntoff;
   }
+  asm volatile("" ::"v"(touch));
   flush_rows(lds_lane, dst, 0, 32);
 }
 
