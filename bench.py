@@ -668,6 +668,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=32)
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-only", action="store_true",
+                    help="forward mode without the group-action leg and the oracle check: every launch of a profiled run belongs to the timed "
+                         "step (profiles/*/rocprofv3_kernel_stats_step.md)")
     ap.add_argument("--dry-run", action="store_true", help="launcher logic only, CPU + gloo, empty step")
     args = ap.parse_args()
 
@@ -728,6 +731,14 @@ def main():
             elapsed, per_rank = comm.timed(step, args.steps, args.warmup, kt)
             ktimes = kt.summary()
 
+            if args.step_only:
+                ct, iv = ktimes.get("canon_transform", (0, float("nan"))), ktimes.get("invert_action", (0, float("nan")))
+                if rank == 0:
+                    print(json.dumps({"metric": "step only (profiling run)", "ms_per_step": elapsed / args.steps * 1e3, "steps": args.steps,
+                                      "warmup": args.warmup, "canon_transform_ms": ct[1], "invert_action_ms": iv[1],
+                                      "group_action_kernel_mean_ms": (ct[1] + iv[1]) / 2,
+                                      "note": "both launches run group_action_kernel<3,true>: a kernel trace of this command averages them"}))
+                return
             # group-action-only leg: the two resampling kernels back to back with a seeded random index
             x, f = xs[0], fs[0]
             gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)

@@ -21,6 +21,8 @@ for w in $what; do
       ;;
     stats)
       stats bench 16 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline
+      stats step 10 python bench.py --mode forward --steps 20 --warmup 10 --step-only
+      python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only.json" 2>/dev/null
       stats tutorial_prior 28 python tools/bench_tutorial.py --leg prior --steps 5 --warmup 3
       stats tutorial_optimized 20 python tools/bench_tutorial.py --leg optimized --steps 5 --warmup 3
       stats train_images_leg 20 python bench.py --mode train --train-steps 5 --train-warmup 2 --no-cpu-baseline
