@@ -466,7 +466,8 @@ int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, i
 #define EQA_CG_LAUNCH(NP)                                                                                                        \
   hipLaunchKernelGGL(fft_cgemm3m_kernel<NP>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, B3, Mo, (int)M,                 \
                      (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rt, n_ct, (blocks / kXcd) * 4)
-  switch (32 % S == 0 ? 32 / S : 0) {     // (8 or 16 pairs per stage would need 32 / 64 registers to park them: dynamic form)
+  switch (32 % S == 0 ? 32 / S : 0) {     // (16 pairs per stage -- 32 channels -- would need 64 registers to park them: dynamic form)
+    case 8: EQA_CG_LAUNCH(8); break;      // 64 channels (the reference tutorial's 16 x C4): 4 stages, 8 row pairs leave per stage
     case 4: EQA_CG_LAUNCH(4); break;
     case 2: EQA_CG_LAUNCH(2); break;
     case 1: EQA_CG_LAUNCH(1); break;
