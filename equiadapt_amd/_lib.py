@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_conv_wide.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -100,6 +100,9 @@ SIGNATURES = {
     "eqa_fft48k5_spectra3m_floats": (ctypes.c_int64, [_int, _int]),
     "eqa_fft48k5_filter_spectra3m": (_int, [_vp, _vp, _int, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
+    "eqa_lift_conv_wide_supported": (_int, [_int, _int, _int, _int]),
+    "eqa_lift_conv_wide_weight_floats": (ctypes.c_int64, [_int, _int, _int, _int]),
+    "eqa_lift_conv_wide": (_int, [_vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "eqa_fft48k5_spectra3m_bf16_bytes": (ctypes.c_int64, [_int, _int]),
     "eqa_fft48k5_spectra3m_split": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m_bf16x3": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _int, _vp]),

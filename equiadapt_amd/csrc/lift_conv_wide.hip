@@ -1,0 +1,217 @@
+// libeqa_hip.so, part 12 -- the lifting convolution for the filters lift_conv.hip does not take: wide filter rows (7 x 7 and
+// 9 x 9 over RGB: the reference tutorial's ESCNN canonicalizer is k = 9) and single-channel input (any of 3 / 5 / 7 / 9).
+// Until round 4 these went to the framework's convolution (MIOpen igemm, 0.61 ms per step of the tutorial's first loop).
+// C ABI: include/eqa_hip.h (eqa_lift_conv_wide).  Reference arithmetic: escnn_networks.py:60-66 (first R2Conv),
+// custom_group_equivariant_layers.py lifting layer.
+//
+//   y[n,oy,ox,co] = [relu]( sum_{ky,kx,ci} x[n,oy+ky,ox+kx,ci] * w[co,ci,ky,kx] + bias[co] )      channels-last, stride 1, no padding
+//
+// Implicit GEMM on v_mfma_f32_32x32x2_f32 with the weights as the A operand (rows = channels) and the pixels as B, like
+// lift_conv.hip, but the whole filter is ONE run of R = KH*KW*Cin taps, two per matrix instruction: tap r = 2 step + (lane >> 5)
+// is input element (r / RW) rows down and r % RW floats along the row (RW = KW*Cin), so no filter-row padding is spent.
+//  * A wave owns a 64-channel slice and keeps its (R + 1) / 2 x 2 weight registers for the whole kernel (122 x 2 at 9 x 9 x 3);
+//    it walks tiles of 32 consecutive pixels of one output row.
+//  * The KH input-row segments a tile reads ((31 + KW) * Cin floats each) go HBM -> registers -> the wave's private LDS double
+//    buffer one tile ahead; the B operand of a step is one ds_read_b32 (lane stride Cin dwords: conflict-free for odd Cin).
+//  * No barrier anywhere: a wave is its own pipeline (one wave per SIMD: the weights take most of the register file).
+#include "eqa_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWideWaves = 1024;            // persistent waves: 256 CUs x 4 SIMDs
+constexpr int kWideSegMax = 128;            // floats of one staged row segment at most: (31 + KW) * Cin <= 120
+constexpr int kWideRowsMax = 9;
+
+template <int KS, int CIN>
+struct WideShape {
+  static constexpr int R = KS * KS * CIN, RW = KS * CIN, STEPS = (R + 1) / 2;
+  static constexpr int SEG = (31 + KS) * CIN;                 // floats of a tile's row segment
+  static constexpr int NLD = (KS * SEG + 63) / 64;            // staging loads per lane and tile
+  static constexpr int BUF = NLD * 64;                        // floats of one LDS buffer (every lane owns NLD slots)
+};
+
+// tap r -> offset inside the staged block (rows of SEG floats); taps past R carry weight 0 and read element 0
+template <int KS, int CIN>
+__host__ __device__ constexpr int wide_off(int r) {
+  return r < WideShape<KS, CIN>::R ? (r / WideShape<KS, CIN>::RW) * WideShape<KS, CIN>::SEG + r % WideShape<KS, CIN>::RW : 0;
+}
+
+template <int KS, int CIN, bool MASKED>
+__global__ __launch_bounds__(256, 1) void lift_conv_wide_kernel(const float* __restrict__ x, const float* __restrict__ wpk,
+                                                                const float* __restrict__ bias, int relu, float* __restrict__ y,
+                                                                int nimg, int H, int W, int Cout, int slices, int tiles_per_row) {
+  using S = WideShape<KS, CIN>;
+  __shared__ float lds_all[4 * 2 * S::BUF];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * 4 + wave;                       // global wave
+  const int slice = gw % slices;                              // its 64-channel slice, for the whole kernel
+  const int stream = gw / slices, nstreams = (int)(gridDim.x * 4) / slices;
+  const int OH = H - KS + 1, OW = W - KS + 1;
+  const long long ntiles = (long long)nimg * OH * tiles_per_row;
+  float* lds = lds_all + wave * 2 * S::BUF;
+  const int pix = lane & 31, kh = lane >> 5;
+
+  // weights: wpk (slices, STEPS, 2, 64)
+  float wreg[S::STEPS][2];
+  {
+    const float* wp = wpk + (size_t)slice * S::STEPS * 128 + lane;
+#pragma unroll
+    for (int s = 0; s < S::STEPS; ++s) {
+      wreg[s][0] = wp[s * 128];
+      wreg[s][1] = wp[s * 128 + 64];
+    }
+  }
+  // the lane's bias values: accumulator e of lane (pix, kh) is channel 32 nt + 8 (e >> 2) + 4 kh + (e & 3)
+  float bv[2][16];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bv[nt][e] = bias ? bias[slice * 64 + 32 * nt + 8 * (e >> 2) + 4 * kh + (e & 3)] : 0.0f;
+
+  // staging slots of this lane: element id = lane + 64 j of the KS x SEG block -> (row, column)
+  int srow[S::NLD], scol[S::NLD];
+#pragma unroll
+  for (int j = 0; j < S::NLD; ++j) {
+    const int id = min(lane + 64 * j, KS * S::SEG - 1);
+    srow[j] = id / S::SEG;
+    scol[j] = id - srow[j] * S::SEG;
+  }
+  auto tile_pos = [&](long long t, int& n, int& oy, int& ox0) {
+    const long long r = t / tiles_per_row;
+    const int tx = (int)(t - r * tiles_per_row);
+    n = (int)(r / OH);
+    oy = (int)(r - (long long)n * OH);
+    ox0 = MASKED ? tx * 32 : min(tx * 32, OW - 32);           // (the last tile of a row overlaps its neighbour: same values twice)
+  };
+  float stage[S::NLD];
+  auto request = [&](long long t) {
+    int n, oy, ox0;
+    tile_pos(t, n, oy, ox0);
+    const float* base = x + ((size_t)n * H + oy) * (size_t)W * CIN + (size_t)ox0 * CIN;
+    const int lim = (W - ox0) * CIN - 1;                      // last float of the row segment that exists
+#pragma unroll
+    for (int j = 0; j < S::NLD; ++j) stage[j] = base[(size_t)srow[j] * W * CIN + min(scol[j], lim)];
+  };
+  auto deposit = [&](float* buf) {
+#pragma unroll
+    for (int j = 0; j < S::NLD; ++j) buf[lane + 64 * j] = stage[j];
+  };
+
+  long long t = stream;
+  if (t >= ntiles) return;
+  request(t);
+  deposit(lds);
+  int cur = 0;
+  for (; t < ntiles; t += nstreams) {
+    const long long tn = t + nstreams < ntiles ? t + nstreams : t;
+    request(tn);                                              // next tile's rows: in flight during this tile's matrix instructions
+    const float* buf = lds + cur * S::BUF + pix * CIN;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[nt][e] = bv[nt][e];
+    // The B operand of a step is one ds_read_b32.  Left to itself the compiler reads it right in front of the two matrix instructions
+    // that use it and waits (~100 cycles per 128 of matrix work: 0.72 ms at the tutorial's shape); here the reads run one chunk of
+    // kChunk steps ahead, one read behind every second matrix instruction.
+    constexpr int kChunk = 8, kNch = (S::STEPS + kChunk - 1) / kChunk;
+    float bq[2][kChunk];
+#pragma unroll
+    for (int j = 0; j < kChunk; ++j)
+      if (j < S::STEPS) bq[0][j] = buf[kh ? wide_off<KS, CIN>(2 * j + 1) : wide_off<KS, CIN>(2 * j)];
+#pragma unroll
+    for (int c = 0; c < kNch; ++c) {
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const int sn = (c + 1) * kChunk + j;
+        if (sn < S::STEPS) bq[(c + 1) & 1][j] = buf[kh ? wide_off<KS, CIN>(2 * sn + 1) : wide_off<KS, CIN>(2 * sn)];
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        const int sc = c * kChunk + j;
+        if (sc < S::STEPS) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[sc][0], bq[c & 1][j], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[sc][1], bq[c & 1][j], acc[1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kChunk; ++j) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    deposit(lds + (cur ^ 1) * S::BUF);
+    cur ^= 1;
+    // epilogue: [relu], 16-byte stores of 4 consecutive channels of the lane's pixel
+    int n, oy, ox0;
+    tile_pos(t, n, oy, ox0);
+    const int ox = ox0 + pix;
+    if (!MASKED || ox < OW) {
+      float* o = y + (((size_t)n * OH + oy) * OW + ox) * (size_t)Cout + slice * 64 + 4 * kh;
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]};
+          if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.0f);
+          }
+          *reinterpret_cast<f32x4*>(o + 32 * nt + 8 * g) = v;
+        }
+    }
+  }
+}
+
+template <int KS, int CIN>
+int wide_launch(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cout, hipStream_t st) {
+  const int OW = W - KS + 1, slices = Cout / 64;
+  const bool masked = OW < 32;
+  const int tiles_per_row = (OW + 31) / 32;
+  const int blocks = kWideWaves / 4;
+  if (masked)
+    hipLaunchKernelGGL((lift_conv_wide_kernel<KS, CIN, true>), dim3(blocks), dim3(256), 0, st, x, wpk, bias, relu, y, nimg, H, W, Cout, slices,
+                       tiles_per_row);
+  else
+    hipLaunchKernelGGL((lift_conv_wide_kernel<KS, CIN, false>), dim3(blocks), dim3(256), 0, st, x, wpk, bias, relu, y, nimg, H, W, Cout, slices,
+                       tiles_per_row);
+  return launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_lift_conv_wide_supported(int Cin, int KH, int KW, int Cout) {
+  if (KH != KW || Cout <= 0 || Cout % 64 || kWideWaves % (Cout / 64)) return 0;
+  if (Cin == 3) return KH == 7 || KH == 9;
+  if (Cin == 1) return KH == 3 || KH == 5 || KH == 7 || KH == 9;
+  return 0;
+}
+
+int64_t eqa_lift_conv_wide_weight_floats(int Cin, int KH, int KW, int Cout) {
+  if (!eqa_lift_conv_wide_supported(Cin, KH, KW, Cout)) return 0;
+  return (int64_t)(Cout / 64) * ((KH * KW * Cin + 1) / 2) * 128;
+}
+
+int eqa_lift_conv_wide(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin, int KH,
+                       int KW, int Cout, void* stream) {
+  if (nimg < 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (!eqa_lift_conv_wide_supported(Cin, KH, KW, Cout) || H < KH || W < KW) return EQA_ERR_UNSUPPORTED;
+  if (nimg == 0) return EQA_OK;                     // (an empty batch has no storage: nothing to check, nothing launched)
+  if (!x || !wpk || !y) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)y) & 15) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+#define EQA_WIDE(K, C) if (KH == K && Cin == C) return wide_launch<K, C>(x, wpk, bias, relu, y, nimg, H, W, Cout, st)
+  EQA_WIDE(9, 3); EQA_WIDE(7, 3); EQA_WIDE(9, 1); EQA_WIDE(7, 1); EQA_WIDE(5, 1); EQA_WIDE(3, 1);
+#undef EQA_WIDE
+  return EQA_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

@@ -142,7 +142,8 @@ class _GroupConvBase(nn.Module):
         k in {3, 5}, O * |G| a multiple of 16)."""
         return (self.lifting and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self.stride == 1
                 and self.padding == 0 and x.dim() == 4 and x.shape[-2] >= self.kernel_size and x.shape[-1] >= self.kernel_size
-                and ops.lift_conv_supported(self.in_channels, self.kernel_size, self.kernel_size, self.out_channels * self.num_group_elements))
+                and (ops.lift_conv_supported(self.in_channels, self.kernel_size, self.kernel_size, self.out_channels * self.num_group_elements)
+                     or ops.lift_conv_wide_supported(self.in_channels, self.kernel_size, self.kernel_size, self.out_channels * self.num_group_elements)))
 
     def lift_nhwc(self, x: torch.Tensor, relu: bool = False) -> torch.Tensor:
         """[relu](lifting convolution + bias) as a channels-last (B, O*|G|, H', W') tensor (channel = field * |G| + element): the
@@ -151,11 +152,13 @@ class _GroupConvBase(nn.Module):
         key = (w._version, -1 if b is None else b._version, str(w.device))
         hit = getattr(self, "_cached_lift", None)
         if hit is None or hit[0] != key:
-            wpk = ops.pack_lift_weights(self.expanded_weights().detach())
+            narrow = ops.lift_conv_supported(self.in_channels, self.kernel_size, self.kernel_size, self.out_channels * self.num_group_elements)
+            wpk = (ops.pack_lift_weights if narrow else ops.pack_lift_weights_wide)(self.expanded_weights().detach())
             be = None if b is None else b.detach().repeat_interleave(self.num_group_elements).contiguous()
-            hit = (key, wpk, be)
+            hit = (key, wpk, be, narrow)
             self._cached_lift = hit
-        return ops.lift_conv_nhwc(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2], relu, self.kernel_size, self.kernel_size)
+        fn = ops.lift_conv_nhwc if hit[3] else ops.lift_conv_wide
+        return fn(x.contiguous(memory_format=torch.channels_last), hit[1], hit[2], relu, self.kernel_size, self.kernel_size)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]

@@ -52,6 +52,8 @@ class LiftConvFunction(torch.autograd.Function):
         kernel's epilogue (eqa_lift_conv_nhwc_stats) -- the batch-norm behind the layer then skips its own pass over the map."""
         ctx.save_for_backward(x, bank)
         k = bank.shape[-1]
+        if not ops.lift_conv_supported(bank.shape[1], bank.shape[-2], k, bank.shape[0]):      # wide / single-channel filters
+            return ops.lift_conv_wide(x, ops.pack_lift_weights_wide(bank.detach()), None, False, bank.shape[-2], k)
         wpk = ops.pack_lift_weights(bank.detach())
         if with_stats:
             y, part = ops.lift_conv_nhwc_stats(x, wpk, bank.shape[-2], k)
@@ -471,7 +473,8 @@ class ESCNNEquivariantNetwork(nn.Module):
         hit = self._fold_cache.get(("lift", id(conv)))
         key = self._fold_cache[id(conv)][0]
         if hit is None or hit[0] != key:
-            hit = (key, ops.pack_lift_weights(bank))
+            narrow = ops.lift_conv_supported(bank.shape[1], bank.shape[-2], bank.shape[-1], bank.shape[0])
+            hit = (key, ops.pack_lift_weights(bank) if narrow else ops.pack_lift_weights_wide(bank))
             self._fold_cache[("lift", id(conv))] = hit
         return hit[1]
 
@@ -555,6 +558,13 @@ class ESCNNEquivariantNetwork(nn.Module):
                 if last_before_tail:
                     return conv_then_group_pool(h, convs[-1])
                 continue
+            if (nhwc and conv.lifting and conv.stride == 1 and conv.padding == 0 and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
+                    and h.shape[-2] >= k and h.shape[-1] >= k and ops.lift_conv_wide_supported(bank.shape[1], k, k, bank.shape[0])):
+                # the lifting filters the kernel above does not take (7 x 7 / 9 x 9 over RGB: the reference tutorial's k = 9; grayscale)
+                h = ops.lift_conv_wide(h, self._lift_weights(conv, bank), bias, True, k, k)
+                if last_before_tail:
+                    return conv_then_group_pool(h, convs[-1])
+                continue
             if last_before_tail:
                 # bias + ReLU of this layer are applied inside the window-sum pass of the next (last) layer
                 c = F.conv2d(h, bank)
@@ -626,6 +636,10 @@ class ESCNNEquivariantNetwork(nn.Module):
                     h, part = LiftConvFunction.apply(h, bank, True)
                 else:
                     h = LiftConvFunction.apply(h, bank)
+            elif (conv.lifting and conv.stride == 1 and conv.padding == 0 and os.environ.get("EQA_LIFT_MFMA", "1") != "0"
+                  and h.is_contiguous(memory_format=torch.channels_last) and h.shape[-2] >= conv.kernel_size and h.shape[-1] >= conv.kernel_size
+                  and ops.lift_conv_wide_supported(bank.shape[1], conv.kernel_size, conv.kernel_size, bank.shape[0])):
+                h = LiftConvFunction.apply(h, bank)          # forward: eqa_lift_conv_wide; filter gradient: the framework's
             else:
                 h = F.conv2d(h, bank.contiguous(memory_format=torch.channels_last))
             fused = os.environ.get("EQA_TRAIN_FUSED_BN", "1") != "0" and h.is_contiguous(memory_format=torch.channels_last)

@@ -619,6 +619,41 @@ def lift_conv_nhwc(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def lift_conv_wide_supported(cin: int, kh: int, kw: int, cout: int) -> bool:
+    """Shapes eqa_lift_conv_wide takes: the lifting filters eqa_lift_conv_nhwc does not (7 x 7 / 9 x 9 over RGB, 3 ... 9 over one channel)."""
+    return bool(_lib.load().eqa_lift_conv_wide_supported(cin, kh, kw, cout))
+
+
+def pack_lift_weights_wide(bank: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, KH, KW) filters -> (Cout/64, (R+1)/2, 2, 64) operand of eqa_lift_conv_wide (layout: include/eqa_hip.h): tap
+    r = (ky*KW + kx)*Cin + ci, two taps per matrix instruction, a zero tap where R is odd."""
+    Cout, Cin, KH, KW = bank.shape
+    R = KH * KW * Cin
+    steps = (R + 1) // 2
+    taps = bank.permute(0, 2, 3, 1).reshape(Cout, R).float()            # [co][r]
+    if 2 * steps > R:
+        taps = torch.cat([taps, taps.new_zeros(Cout, 2 * steps - R)], dim=1)
+    # [slice][nt][c32][step][khalf] -> [slice][step][nt][khalf][c32]
+    t = taps.view(Cout // 64, 2, 32, steps, 2).permute(0, 3, 1, 4, 2)
+    return t.reshape(Cout // 64, steps, 2, 64).contiguous()
+
+
+def lift_conv_wide(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, kh: int, kw: int) -> torch.Tensor:
+    """`lift_conv_nhwc` for the wide / single-channel lifting filters (eqa_lift_conv_wide); wpk = pack_lift_weights_wide(w)."""
+    lib = _lib.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("lift_conv_wide expects a channels-last fp32 tensor on the device")
+    wpk = _need(wpk, "wpk")
+    bias, p_bias = _opt(bias, "bias", torch.float32)
+    B, Cin, H, W = x.shape
+    Cout = wpk.shape[0] * 64
+    y = torch.empty((B, Cout, H - kh + 1, W - kw + 1), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device), _timed("lift_conv"):
+        st = lib.eqa_lift_conv_wide(x.data_ptr(), wpk.data_ptr(), p_bias, int(relu), y.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
+    _lib.check(st, "eqa_lift_conv_wide")
+    return y
+
+
 def lift_conv_stats_supported(x_shape, kh: int, kw: int, cout: int) -> bool:
     """Shapes eqa_lift_conv_nhwc_stats takes (x_shape: (B, Cin, H, W))."""
     B, Cin, H, W = x_shape

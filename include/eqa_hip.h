@@ -336,6 +336,16 @@ int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int 
  * block; grouped, a tile row of a channel group is one contiguous run.  Same arguments and return codes. */
 int eqa_lift_conv_grouped(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin,
                           int KH, int KW, int Cout, void* stream);
+/* The lifting convolution for the filters eqa_lift_conv_nhwc does not take (csrc/lift_conv_wide.hip): 7 x 7 and 9 x 9 over 3 input
+ * channels (the reference tutorial's ESCNN canonicalizer: kernel_size = 9) and 3 x 3 ... 9 x 9 over one (grayscale); same
+ * arithmetic and layouts (escnn_networks.py:60-66; custom_group_equivariant_layers.py lifting layer), Cout % 64 == 0 and
+ * Cout / 64 a divisor of 1024.  wpk: (Cout/64, (R+1)/2, 2, 64) with R = KH*KW*Cin:
+ *   wpk[slice][step][nt][lane] = w[co = 64 slice + 32 nt + (lane & 31)][ci][ky][kx],  r = 2 step + (lane >> 5) = (ky*KW + kx)*Cin + ci,
+ *   0 for r >= R.  eqa_lift_conv_wide_weight_floats: its size. */
+int eqa_lift_conv_wide_supported(int Cin, int KH, int KW, int Cout);
+int64_t eqa_lift_conv_wide_weight_floats(int Cin, int KH, int KW, int Cout);
+int eqa_lift_conv_wide(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin,
+                       int KH, int KW, int Cout, void* stream);
 /* Training: the lifting convolution of escnn_networks.py:60-66 feeds an InnerBatchNorm (escnn_networks.py:67-70) whose batch
  * statistics are per-channel sums over this very map.  This form (no bias, no activation) also leaves
  *   sum over rows r of partial[(r * Cout + c) * 2 + {0, 1}]  =  sum, sum of squares of y[.., c] over all pixels      (fp64)
