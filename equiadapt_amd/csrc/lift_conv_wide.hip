@@ -80,21 +80,32 @@ __global__ __launch_bounds__(256, 1) void lift_conv_wide_kernel(const float* __r
     srow[j] = id / S::SEG;
     scol[j] = id - srow[j] * S::SEG;
   }
-  auto tile_pos = [&](long long t, int& n, int& oy, int& ox0) {
-    const long long r = t / tiles_per_row;
-    const int tx = (int)(t - r * tiles_per_row);
-    n = (int)(r / OH);
-    oy = (int)(r - (long long)n * OH);
-    ox0 = MASKED ? tx * 32 : min(tx * 32, OW - 32);           // (the last tile of a row overlaps its neighbour: same values twice)
+  // a tile's position (tile column, output row, image), advanced by the stream's stride without divisions; all wave-uniform
+  struct Pos { unsigned tx, oy, n; };
+  const unsigned tpr = (unsigned)tiles_per_row, uOH = (unsigned)OH;
+  auto pos_of = [&](unsigned t) { const unsigned r = t / tpr; return Pos{t % tpr, r % uOH, r / uOH}; };
+  const Pos dpos = pos_of((unsigned)nstreams);
+  auto pos_next = [&](const Pos& p) {
+    Pos q;
+    q.tx = p.tx + dpos.tx;
+    unsigned c = q.tx >= tpr ? 1u : 0u;
+    q.tx -= c ? tpr : 0u;
+    q.oy = p.oy + dpos.oy + c;
+    c = q.oy >= uOH ? 1u : 0u;
+    q.oy -= c ? uOH : 0u;
+    const unsigned c2 = q.oy >= uOH ? 1u : 0u;      // d.oy + carry can reach OH
+    q.oy -= c2 ? uOH : 0u;
+    q.n = p.n + dpos.n + c + c2;
+    return q;
   };
+  auto ox0_of = [&](const Pos& p) { return MASKED ? (int)p.tx * 32 : min((int)p.tx * 32, OW - 32); };  // (the last tile of a row overlaps its neighbour)
   float stage[S::NLD];
-  auto request = [&](long long t) {
-    int n, oy, ox0;
-    tile_pos(t, n, oy, ox0);
-    const float* base = x + ((size_t)n * H + oy) * (size_t)W * CIN + (size_t)ox0 * CIN;
+  auto request = [&](const Pos& p) {
+    const int ox0 = ox0_of(p);
+    const float* base = x + ((size_t)p.n * H + p.oy) * (size_t)W * CIN + (size_t)ox0 * CIN;
     const int lim = (W - ox0) * CIN - 1;                      // last float of the row segment that exists
 #pragma unroll
-    for (int j = 0; j < S::NLD; ++j) stage[j] = base[(size_t)srow[j] * W * CIN + min(scol[j], lim)];
+    for (int j = 0; j < S::NLD; ++j) stage[j] = base[srow[j] * W * CIN + min(scol[j], lim)];
   };
   auto deposit = [&](float* buf) {
 #pragma unroll
@@ -103,12 +114,15 @@ __global__ __launch_bounds__(256, 1) void lift_conv_wide_kernel(const float* __r
 
   long long t = stream;
   if (t >= ntiles) return;
-  request(t);
+  Pos pos = pos_of((unsigned)stream);
+  request(pos);
   deposit(lds);
   int cur = 0;
   for (; t < ntiles; t += nstreams) {
-    const long long tn = t + nstreams < ntiles ? t + nstreams : t;
-    request(tn);                                              // next tile's rows: in flight during this tile's matrix instructions
+    const Pos pn = t + nstreams < ntiles ? pos_next(pos) : pos;
+#ifndef EQA_WIDE_NOSTAGE      // (experiment switch: no staging of the next tile)
+    request(pn);                                              // next tile's rows: in flight during this tile's matrix instructions
+#endif
     const float* buf = lds + cur * S::BUF + pix * CIN;
     f32x16 acc[2];
 #pragma unroll
@@ -146,14 +160,18 @@ __global__ __launch_bounds__(256, 1) void lift_conv_wide_kernel(const float* __r
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifndef EQA_WIDE_NOSTAGE
     deposit(lds + (cur ^ 1) * S::BUF);
     cur ^= 1;
+#endif
     // epilogue: [relu], 16-byte stores of 4 consecutive channels of the lane's pixel
-    int n, oy, ox0;
-    tile_pos(t, n, oy, ox0);
-    const int ox = ox0 + pix;
+    const int ox = ox0_of(pos) + pix;
+#ifdef EQA_WIDE_NOSTORE        // (experiment switch: one lane stores)
+    if (ox == 0x7fffffff) {
+#else
     if (!MASKED || ox < OW) {
-      float* o = y + (((size_t)n * OH + oy) * OW + ox) * (size_t)Cout + slice * 64 + 4 * kh;
+#endif
+      float* o = y + (((size_t)pos.n * OH + pos.oy) * OW + ox) * (size_t)Cout + slice * 64 + 4 * kh;
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -166,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void lift_conv_wide_kernel(const float* __r
           *reinterpret_cast<f32x4*>(o + 32 * nt + 8 * g) = v;
         }
     }
+    pos = pn;
   }
 }
 
@@ -204,6 +223,7 @@ int eqa_lift_conv_wide(const float* x, const float* wpk, const float* bias, int 
                        int KW, int Cout, void* stream) {
   if (nimg < 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
   if (!eqa_lift_conv_wide_supported(Cin, KH, KW, Cout) || H < KH || W < KW) return EQA_ERR_UNSUPPORTED;
+  if ((int64_t)nimg * (H - KH + 1) * ((W - KW + 32) / 32) > 0x7fffffffLL) return EQA_ERR_UNSUPPORTED;   // tiles are counted in 32 bits
   if (nimg == 0) return EQA_OK;                     // (an empty batch has no storage: nothing to check, nothing launched)
   if (!x || !wpk || !y) return EQA_ERR_INVALID_ARG;
   if (((uintptr_t)y) & 15) return EQA_ERR_UNSUPPORTED;
