@@ -103,6 +103,8 @@ SIGNATURES = {
     "eqa_lift_conv_wide_supported": (_int, [_int, _int, _int, _int]),
     "eqa_lift_conv_wide_weight_floats": (ctypes.c_int64, [_int, _int, _int, _int]),
     "eqa_lift_conv_wide": (_int, [_vp, _vp, _vp, _int, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
+    "eqa_lift_conv_wide_wgrad_workspace_bytes": (ctypes.c_int64, [_int, _int, _int, _int]),
+    "eqa_lift_conv_wide_wgrad": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, _int, _int, _int, _int, _vp]),
     "eqa_fft48k5_spectra3m_bf16_bytes": (ctypes.c_int64, [_int, _int]),
     "eqa_fft48k5_spectra3m_split": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m_bf16x3": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _int, _vp]),

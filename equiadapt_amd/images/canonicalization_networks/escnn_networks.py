@@ -71,6 +71,8 @@ class LiftConvFunction(torch.autograd.Function):
             kh, kw = bank.shape[-2], bank.shape[-1]
             if ops.lift_conv_wgrad_supported(x, bank.shape[0], kh, kw):
                 dbank = ops.lift_conv_wgrad_nhwc(x, dy, kh, kw)            # fp32 MFMA, 0.8 ms where MIOpen's solvers take 3.1
+            elif ops.lift_conv_wide_supported(bank.shape[1], kh, kw, bank.shape[0]) and x.shape[0] > 0:
+                dbank = ops.lift_conv_wide_wgrad(x, dy, kh, kw)            # the wide / single-channel filters (tutorial k = 9)
             else:
                 dbank = torch.nn.grad.conv2d_weight(x, bank.shape, dy)
         return dx, dbank, None

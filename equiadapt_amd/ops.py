@@ -654,6 +654,24 @@ def lift_conv_wide(x: torch.Tensor, wpk: torch.Tensor, bias: Optional[torch.Tens
     return y
 
 
+def lift_conv_wide_wgrad(x: torch.Tensor, dy: torch.Tensor, kh: int, kw: int) -> torch.Tensor:
+    """d loss / d filters (Cout, Cin, kh, kw) of `lift_conv_wide` from channels-last x and dy, deterministic (eqa_lift_conv_wide_wgrad)."""
+    lib = _lib.load()
+    for t, name in ((x, "x"), (dy, "dy")):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(memory_format=torch.channels_last)):
+            raise RuntimeError(f"lift_conv_wide_wgrad expects a channels-last fp32 tensor on the device for {name}")
+    B, Cin, H, W = x.shape
+    Cout = dy.shape[1]
+    if tuple(dy.shape) != (B, Cout, H - kh + 1, W - kw + 1):
+        raise RuntimeError("lift_conv_wide_wgrad: dy does not match x and the kernel size")
+    ws = torch.empty(max(lib.eqa_lift_conv_wide_wgrad_workspace_bytes(Cin, kh, kw, Cout), 16) // 4, dtype=torch.float32, device=x.device)
+    dbank = torch.empty((Cout, Cin, kh, kw), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        st = lib.eqa_lift_conv_wide_wgrad(x.data_ptr(), dy.data_ptr(), ws.data_ptr(), dbank.data_ptr(), B, H, W, Cin, kh, kw, Cout, _stream())
+    _lib.check(st, "eqa_lift_conv_wide_wgrad")
+    return dbank
+
+
 def lift_conv_stats_supported(x_shape, kh: int, kw: int, cout: int) -> bool:
     """Shapes eqa_lift_conv_nhwc_stats takes (x_shape: (B, Cin, H, W))."""
     B, Cin, H, W = x_shape

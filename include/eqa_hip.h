@@ -346,6 +346,12 @@ int eqa_lift_conv_wide_supported(int Cin, int KH, int KW, int Cout);
 int64_t eqa_lift_conv_wide_weight_floats(int Cin, int KH, int KW, int Cout);
 int eqa_lift_conv_wide(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W, int Cin,
                        int KH, int KW, int Cout, void* stream);
+/* Its filter gradient (training; autograd's convolution-weight-gradient of the same layer, escnn_networks.py:60-66):
+ * dbank[co][ci][ky][kx] = sum_{n,oy,ox} dy[n,oy,ox,co] * x[n,oy+ky,ox+kx,ci], deterministic (per-block partials reduced in a fixed
+ * order).  workspace: eqa_lift_conv_wide_wgrad_workspace_bytes(...) bytes; x, dy channels-last. */
+int64_t eqa_lift_conv_wide_wgrad_workspace_bytes(int Cin, int KH, int KW, int Cout);
+int eqa_lift_conv_wide_wgrad(const float* x, const float* dy, void* workspace, float* dbank, int nimg, int H, int W, int Cin, int KH,
+                             int KW, int Cout, void* stream);
 /* Training: the lifting convolution of escnn_networks.py:60-66 feeds an InnerBatchNorm (escnn_networks.py:67-70) whose batch
  * statistics are per-channel sums over this very map.  This form (no bias, no activation) also leaves
  *   sum over rows r of partial[(r * Cout + c) * 2 + {0, 1}]  =  sum, sum of squares of y[.., c] over all pixels      (fp64)
