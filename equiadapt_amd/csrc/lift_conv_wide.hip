@@ -14,6 +14,10 @@
 //  * The KH input-row segments a tile reads ((31 + KW) * Cin floats each) go HBM -> registers -> the wave's private LDS double
 //    buffer one tile ahead; the B operand of a step is one ds_read_b32 (lane stride Cin dwords: conflict-free for odd Cin).
 //  * No barrier anywhere: a wave is its own pipeline (one wave per SIMD: the weights take most of the register file).
+//  * Known cost: at 9 x 9 x 3 the 244 weight registers live in the accumulator half and the compiler copies each into ONE reused
+//    vector register in front of its matrix instruction (82 instead of 64 cycles per instruction: 0.62 ms at the tutorial's shape).
+//    Inline-asm matrix instructions reading the accumulator half directly ran at 0.57 ms but produced wrong values for 9 x 9 x 3
+//    (wait states the compiler does not pad inside asm): dropped.
 #include "eqa_common.hpp"
 
 namespace {
