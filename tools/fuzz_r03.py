@@ -36,7 +36,7 @@ def main():
     dev = torch.device("cuda:0")
     rng = random.Random(args.seed)
     torch.manual_seed(args.seed)
-    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "pair": 0, "aa": 0, "action": 0, "fftk": 0}
+    counts = {"knn": 0, "vnsmall": 0, "plane_gemm": 0, "lift": 0, "liftwide": 0, "pair": 0, "aa": 0, "action": 0, "fftk": 0}
     worst = {}
     t_end = time.time() + args.seconds
     guard = None
@@ -44,7 +44,7 @@ def main():
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
         import conftest as guard    # installs the guarded torch.empty / zeros / ... at import
     while time.time() < t_end:
-        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "pair", "aa", "action", "fftk"])
+        what = rng.choice(["knn", "vnsmall", "plane_gemm", "lift", "liftwide", "pair", "aa", "action", "fftk"])
         if what in ("knn", "vnsmall"):
             k = rng.randint(1, 32)
             N = rng.choice([k, k + 1, rng.randint(k, 200), rng.randint(k, 1500), 1024])
@@ -167,6 +167,20 @@ def main():
             got = ops.lift_conv_nhwc(x, ops.pack_lift_weights(w), b, True, K, K)
             want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
             assert (got.double() - want).abs().max().item() <= 2e-6 * max(want.abs().max().item(), 1e-3), ("lift", B, Cin, K, Cout, H, W)
+        elif what == "liftwide":   # round 4: the wide / single-channel lifting filters, forward and filter gradient
+            K, Cin = rng.choice([(9, 3), (7, 3), (9, 1), (7, 1), (5, 1), (3, 1)])
+            Cout = rng.choice([64, 128, 256])
+            H, W, B = rng.randint(K, 72), rng.randint(K, 100), rng.randint(1, 5)
+            x = torch.randn(B, Cin, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+            w = torch.randn(Cout, Cin, K, K, device=dev) / (K * Cin ** 0.5)
+            b = torch.randn(Cout, device=dev)
+            got = ops.lift_conv_wide(x, ops.pack_lift_weights_wide(w), b, True, K, K)
+            want = torch.relu(F.conv2d(x.double(), w.double(), b.double()))
+            assert (got.double() - want).abs().max().item() <= 3e-6 * max(want.abs().max().item(), 1e-3), ("liftwide", B, Cin, K, Cout, H, W)
+            dy = torch.randn_like(got)
+            gw = ops.lift_conv_wide_wgrad(x, dy, K, K)
+            gwant = torch.nn.grad.conv2d_weight(x.double().cpu(), (Cout, Cin, K, K), dy.double().cpu())
+            assert (gw.double().cpu() - gwant).abs().max().item() <= 2e-5 * max(gwant.abs().max().item(), 1e-3), ("liftwide wgrad", B, Cin, K, Cout, H, W)
         elif what == "action":
             N, refl = rng.choice([(4, False), (8, False), (4, True), (8, True), (2, False)])
             G = 2 * N if refl else N
