@@ -14,10 +14,11 @@
 //  * The KH input-row segments a tile reads ((31 + KW) * Cin floats each) go HBM -> registers -> the wave's private LDS double
 //    buffer one tile ahead; the B operand of a step is one ds_read_b32 (lane stride Cin dwords: conflict-free for odd Cin).
 //  * No barrier anywhere: a wave is its own pipeline (one wave per SIMD: the weights take most of the register file).
-//  * Known cost: at 9 x 9 x 3 the 244 weight registers live in the accumulator half and the compiler copies each into ONE reused
-//    vector register in front of its matrix instruction (82 instead of 64 cycles per instruction: 0.62 ms at the tutorial's shape).
-//    Inline-asm matrix instructions reading the accumulator half directly ran at 0.57 ms but produced wrong values for 9 x 9 x 3
-//    (wait states the compiler does not pad inside asm): dropped.
+//  * Known cost: 0.62 ms at the tutorial's shape is 82 cycles per matrix instruction where the instruction takes 64.  At 9 x 9 x 3
+//    the 244 weight registers live in the accumulator half and the compiler copies each into a vector register in front of its
+//    instruction; copying them a step early into their own registers changed nothing (0.63 ms), inline-asm instructions reading the
+//    accumulator half directly ran at 0.57 ms but produced wrong values for 9 x 9 x 3 (wait states the compiler does not pad inside
+//    asm) and were dropped.  Staging costs 0.06 ms of it (-DEQA_WIDE_NOSTAGE); the rest is not accounted for yet.
 #include "eqa_common.hpp"
 
 namespace {
