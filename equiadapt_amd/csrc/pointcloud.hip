@@ -55,22 +55,27 @@ __global__ __launch_bounds__(kThreads) void gram_schmidt_kernel(const float* __r
 }
 
 __device__ __forceinline__ void gram_schmidt_rows(const float* p, float* o) {
-  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
-  // e1 = a / |a|   (torch.norm: sqrt of the sum of squares; division, not rsqrt, to stay on the reference's rounding)
-  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  // The three steps of common/utils.py:22-51 (no epsilon, no handedness fix) evaluated in fp64 and rounded once: 9 numbers per
+  // cloud, so the cost is nil, and the step has no epsilon -- it amplifies rounding by the conditioning of the three vectors
+  // (cond 540 on one of the bench's eight clouds, 1,659 among 64: an fp32 evaluation, this one or the reference's, then sits
+  // 4e-5 .. 6e-5 from the exact frame; tools/cfg4_budget.py).  In fp64 the frame is the exact Gram-Schmidt of the vectors the
+  // network kernel produced, to the last fp32 bit, so the only error left in R is the network's own, amplified.
+  double a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  double n = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
   a0 /= n; a1 /= n; a2 /= n;
-  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  const double d = b0 * a0 + b1 * a1 + b2 * a2;
   b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
-  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  n = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
   b0 /= n; b1 /= n; b2 /= n;
-  const float d1 = c0 * a0 + c1 * a1 + c2 * a2;
-  const float d2 = c0 * b0 + c1 * b1 + c2 * b2;  // classical GS: both projections use the ORIGINAL c
+  const double d1 = c0 * a0 + c1 * a1 + c2 * a2;
+  const double d2 = c0 * b0 + c1 * b1 + c2 * b2;  // classical GS: both projections use the ORIGINAL c
   c0 = c0 - d1 * a0 - d2 * b0;
   c1 = c1 - d1 * a1 - d2 * b1;
   c2 = c2 - d1 * a2 - d2 * b2;
-  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  n = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
   c0 /= n; c1 /= n; c2 /= n;
-  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+  o[0] = (float)a0; o[1] = (float)a1; o[2] = (float)a2; o[3] = (float)b0; o[4] = (float)b1; o[5] = (float)b2;
+  o[6] = (float)c0; o[7] = (float)c1; o[8] = (float)c2;
 }
 
 // Backward of the classical Gram-Schmidt above: g:(B,3,3) = dL/d(e1,e2,e3) -> gv:(B,3,3) = dL/d(v1,v2,v3).  With e = u / |u|,
@@ -574,21 +579,23 @@ __global__ __launch_bounds__(kThreads) void modified_gram_schmidt_kernel(const f
   const int b = blockIdx.x * kThreads + threadIdx.x;
   if (b >= B) return;
   const float* p = v + (size_t)b * 9;
-  float a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
-  float n = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+  // fp64 inside, rounded once (see gram_schmidt_rows)
+  double a0 = p[0], a1 = p[1], a2 = p[2], b0 = p[3], b1 = p[4], b2 = p[5], c0 = p[6], c1 = p[7], c2 = p[8];
+  double n = sqrt(a0 * a0 + a1 * a1 + a2 * a2);
   a0 /= n; a1 /= n; a2 /= n;
-  float d = b0 * a0 + b1 * a1 + b2 * a2;
+  double d = b0 * a0 + b1 * a1 + b2 * a2;
   b0 -= d * a0; b1 -= d * a1; b2 -= d * a2;
-  n = sqrtf(b0 * b0 + b1 * b1 + b2 * b2);
+  n = sqrt(b0 * b0 + b1 * b1 + b2 * b2);
   b0 /= n; b1 /= n; b2 /= n;
   d = c0 * a0 + c1 * a1 + c2 * a2;
   c0 -= d * a0; c1 -= d * a1; c2 -= d * a2;
   d = c0 * b0 + c1 * b1 + c2 * b2;  // modified GS: second projection uses the UPDATED third vector
   c0 -= d * b0; c1 -= d * b1; c2 -= d * b2;
-  n = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+  n = sqrt(c0 * c0 + c1 * c1 + c2 * c2);
   c0 /= n; c1 /= n; c2 /= n;
   float* o = out + (size_t)b * 9;
-  o[0] = a0; o[1] = a1; o[2] = a2; o[3] = b0; o[4] = b1; o[5] = b2; o[6] = c0; o[7] = c1; o[8] = c2;
+  o[0] = (float)a0; o[1] = (float)a1; o[2] = (float)a2; o[3] = (float)b0; o[4] = (float)b1; o[5] = (float)b2;
+  o[6] = (float)c0; o[7] = (float)c1; o[8] = (float)c2;
 }
 
 // mode 0: out = x R + t            (invert_canonicalization :126-137; t may be NULL)

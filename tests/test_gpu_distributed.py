@@ -160,3 +160,136 @@ def test_nccl_world1_ddp_wrapped_step_equals_the_bare_step(kind):
     assert res["self_deterministic"], res
     # ... and so must the run whose gradients went through DDP's buckets and the RCCL all-reduce
     assert res["loss_equal"] and res["grads_equal"] and res["state_equal"], res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# world size 2 on the ONE GPU of the test box: two processes, both on cuda:0, gloo as the collective backend (RCCL refuses two
+# ranks per device; gloo all-reduces CUDA tensors through the host).  Everything else is the N-rank job: wrap_ddp (bucket views),
+# the ctypes-launched kernels writing gradients on torch's current stream, DDP's hooks averaging them over DIFFERENT shards.
+# ----------------------------------------------------------------------------------------------------------------------
+def _shards(kind, xs, ys, split):
+    """Step i's batch cut into the two ranks' shards; `split` = size of rank 0's."""
+    return [[(x[:split], y[:split]), (x[split:], y[split:])] for x, y in zip(xs, ys)]
+
+
+def _seed_for(step, rank):
+    return 1000 * (step + 1) + rank    # the fused blocks draw their dropout seeds from torch's CPU generator at forward time
+
+
+def _worker2(kind, split, rank, port, q):
+    import copy
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    res = {"ok": False, "rank": rank}
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=2)
+        from equiadapt_amd import _lib
+        from equiadapt_amd import training as tr
+
+        _lib.load()
+        torch.backends.cudnn.deterministic = True
+        model, opt_fn, xs, ys = _build(kind, dev)          # same seeds on both ranks: identical initial replicas, identical full batches
+        initial = copy.deepcopy(model)
+        shards = _shards(kind, xs, ys, split)
+        ddp = tr.wrap_ddp(model, dev)
+        res["wrapped"] = type(ddp).__name__
+        opt = opt_fn(model)
+        losses, grads, metrics = [], [], []
+        for i, per_rank in enumerate(shards):
+            x, y = per_rank[rank]
+            torch.manual_seed(_seed_for(i, rank))
+            out = tr.train_step(ddp, opt, x.contiguous(), y.contiguous())
+            losses.append(float(out["loss"].detach()))
+            grads.append([p.grad.detach().cpu().clone() for p in model.parameters()])
+            metrics.append(tr.reduce_metrics({k: v for k, v in out.items() if v.dim() == 0}))
+        torch.cuda.synchronize()
+        res.update(losses=losses, grads=grads, metrics=metrics, params=[p.detach().cpu().clone() for p in model.parameters()],
+                   n_local=[int(s[rank][0].shape[0]) for s in shards])
+        if rank == 0:
+            # the single-process equivalent of the two-rank step.  DDP averages the per-rank gradients of per-rank MEAN losses, and
+            # batch-norm statistics stay per replica (the reference uses plain DDP, no SyncBN: train_utils.py:89-91), so the
+            # equivalent is "each shard forwarded on its own, loss = (L_0 + L_1) / 2" -- for unequal shards that is NOT the mean
+            # over the concatenated batch, and neither is it in the reference.
+            emul = initial
+            eopt = opt_fn(emul)
+            e_grads, e_losses = [], []
+            for i, per_rank in enumerate(shards):
+                eopt.zero_grad(set_to_none=True)
+                ls = []
+                for r, (x, y) in enumerate(per_rank):
+                    torch.manual_seed(_seed_for(i, r))
+                    o = emul(x.contiguous(), y.contiguous())
+                    (o["loss"] / 2).backward()
+                    ls.append(float(o["loss"].detach()))
+                e_grads.append([p.grad.detach().cpu().clone() for p in emul.parameters()])
+                e_losses.append(ls)
+                eopt.step()
+            torch.cuda.synchronize()
+            res.update(e_grads=e_grads, e_losses=e_losses, e_params=[p.detach().cpu().clone() for p in emul.parameters()])
+        dist.barrier()
+        res["ok"] = True
+    except Exception as exc:  # noqa: BLE001
+        import traceback
+
+        res["error"] = f"{exc!r}\n{traceback.format_exc()}"
+    finally:
+        try:
+            import torch.distributed as dist
+
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+        q.put(res)
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,split", [("images", 5), ("images", 4), ("pointcloud", 10), ("pointcloud", 8)])
+def test_gloo_world2_on_one_gpu_real_canonicalizers_average_different_shards(kind, split):
+    """Reference: examples/images/classification/train_utils.py:89-91 (strategy="ddp"), model.py:59-127; point clouds
+    examples/pointcloud/classification/train_utils.py:50-51.  Two ranks, different (and unequal: 5 + 3, 10 + 6) shards, two
+    optimisation steps of the headline canonicalizer / the VNSmall canonicalizer around a small predictor."""
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker2, args=(kind, split, r, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(), q.get()]
+    for p in procs:
+        p.join(120)
+    res = {r["rank"]: r for r in got}
+    for r in (0, 1):
+        assert res[r]["ok"], res[r].get("error")
+        assert res[r]["wrapped"] == "DistributedDataParallel"
+    assert all(p.exitcode == 0 for p in procs)
+    total = 8 if kind == "images" else 16
+    assert res[0]["n_local"] == [split, split] and res[1]["n_local"] == [total - split, total - split]
+    # (i) the replicas stay identical: same averaged gradients after every step, same parameters at the end -- bit for bit
+    for g0, g1 in zip(res[0]["grads"], res[1]["grads"]):
+        assert all(torch.equal(a, b) for a, b in zip(g0, g1))
+    assert all(torch.equal(a, b) for a, b in zip(res[0]["params"], res[1]["params"]))
+    assert any(a.abs().sum() > 0 for a in res[0]["grads"][-1])
+    # ... although the ranks saw different data (their local losses differ)
+    assert res[0]["losses"] != res[1]["losses"]
+    # (ii) equal to the single-process evaluation of the same two shards within fp32 reduction noise (the only differences: gloo
+    # sums g_0 + g_1 then scales, autograd accumulates g_0 / 2 + g_1 / 2)
+    for step, (g, e) in enumerate(zip(res[0]["grads"], res[0]["e_grads"])):
+        for a, b in zip(g, e):
+            scale = max(b.abs().max().item(), 1e-12)
+            assert (a - b).abs().max().item() <= 2e-5 * scale + 1e-9, (kind, step, (a - b).abs().max().item(), scale)
+    for a, b in zip(res[0]["params"], res[0]["e_params"]):
+        assert (a - b).abs().max().item() <= 2e-6 * max(b.abs().max().item(), 1.0), (a - b).abs().max().item()
+    for step in range(2):
+        assert res[0]["e_losses"][step] == pytest.approx([res[0]["losses"][step], res[1]["losses"][step]], rel=1e-5)
+    # (iii) reduce_metrics = the mean over ranks (the reference's sync_dist=True), the same on both ranks
+    for step in range(2):
+        m0, m1 = res[0]["metrics"][step], res[1]["metrics"][step]
+        assert m0 == m1
+        assert m0["loss"] == pytest.approx((res[0]["losses"][step] + res[1]["losses"][step]) / 2, rel=1e-6)
