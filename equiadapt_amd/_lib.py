@@ -209,6 +209,16 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     if res.returncode != 0:
         raise EqaLibraryError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     os.replace(tmp, out)
+    if not extra_flags:
+        # a product build leaves only the product's objects behind: the flag-hash variants of A/B experiments (tools/ablate.sh)
+        # accumulate otherwise (round 4 ended with 23 stale sets, 104 MB)
+        keep = {os.path.basename(o) for o, _ in results}
+        for name in os.listdir(objdir):
+            if name not in keep and (name.endswith(".o") or ".o.tmp" in name):
+                try:
+                    os.remove(os.path.join(objdir, name))
+                except OSError:
+                    pass
     return out
 
 

@@ -23,10 +23,12 @@ def device_tables(kind: str, num_rotations: int, reflections: bool, frame_hw: Tu
         build = {"canonicalize": geometry.canonicalize_tables, "invert": geometry.invert_tables,
                  "orbit": geometry.orbit_tables}[kind]
         hit = tuple(t.to(device) for t in build(num_rotations, reflections, tuple(frame_hw)))
-        if num_rotations in (1, 2, 4):
-            # every element is a multiple of 90 degrees: a 32 x 32 output tile samples a window of at most 35 x 35 source pixels
-            # (ops passes the bound on: eqa_group_action_fwd_hint reserves less LDS per block, more blocks per CU)
-            hit[0].eqa_max_window = 35
+        if num_rotations in (1, 2, 4) and frame_hw[0] == frame_hw[1]:
+            # every element is a multiple of 90 degrees and the frame is square: a 32 x 32 output tile samples a window of at most
+            # 35 x 35 source pixels (eqa_group_action_fwd_hint then reserves less LDS per block: more blocks per CU).  On a
+            # non-square frame torch's normalised grid stretches a quarter turn by the aspect ratio -- a tile's window grows to
+            # 36-47 rows, every such tile would fall to the direct gather path -- so no hint there.
+            ops.register_window_hint(hit[0], 35)
         _device_tables[key] = hit
     return hit
 

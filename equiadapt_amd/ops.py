@@ -177,8 +177,26 @@ def group_action_bwd(
     return g_src, g_angle
 
 
-def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int) -> torch.Tensor:
-    """I5: fused pad(edge) -> [hflip] -> rotate -> center-crop (eqa_canon_transform_fwd)."""
+# Window-bound hints: device address of an element table -> the most source rows a 32 x 32 output tile can sample under ANY of its
+# elements (images.utils.device_tables registers 35 for right-angle groups on square frames).  A registry keyed by the table's
+# storage, not an attribute on the tensor: .to() / .clone() / tracing drop attributes silently, and a copy at another address
+# simply has no hint.  The hint only sizes the LDS reservation (eqa_group_action_fwd_hint); a tile whose window exceeds it takes
+# the direct gather path, so a stale or wrong hint costs time, never correctness.
+_window_hints: dict = {}
+
+
+def register_window_hint(theta: torch.Tensor, max_window_rows: int) -> None:
+    _window_hints[theta.data_ptr()] = int(max_window_rows)
+
+
+def _window_hint(theta: torch.Tensor, explicit: Optional[int]) -> int:
+    return int(explicit) if explicit is not None else _window_hints.get(theta.data_ptr(), 0)
+
+
+def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int,
+                    max_window: Optional[int] = None) -> torch.Tensor:
+    """I5: fused pad(edge) -> [hflip] -> rotate -> center-crop (eqa_canon_transform_fwd).  ``max_window``: bound on a tile's source
+    window rows (0 = none; default: what was registered for this table)."""
     lib = _lib.load()
     x = _need(x, "x")
     gidx = _need(gidx, "gidx", torch.int32)
@@ -186,7 +204,7 @@ def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, fl
     flags, p_flags = _opt(flags, "flags", torch.int32)
     B, C, H, W = x.shape
     y = torch.empty_like(x)
-    hint = int(getattr(theta, "eqa_max_window", 0))     # set by images.utils.device_tables for right-angle groups
+    hint = _window_hint(theta, max_window)
     with torch.cuda.device(x.device), _timed("canon_transform"):
         if hint > 0 and B > 0:
             st = lib.eqa_group_action_fwd_hint(x.data_ptr(), y.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, None,
@@ -199,7 +217,7 @@ def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, fl
 
 
 def invert_action(f: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor],
-                  chan_map: Optional[torch.Tensor]) -> torch.Tensor:
+                  chan_map: Optional[torch.Tensor], max_window: Optional[int] = None) -> torch.Tensor:
     """I7: rotate(+theta) zero-corner -> flip -> regular-representation roll (eqa_invert_action_fwd)."""
     lib = _lib.load()
     f = _need(f, "feature_map")
@@ -210,7 +228,7 @@ def invert_action(f: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flag
     G = chan_map.shape[1] if chan_map is not None else 1
     B, C, H, W = f.shape
     out = torch.empty_like(f)
-    hint = int(getattr(theta, "eqa_max_window", 0))
+    hint = _window_hint(theta, max_window)
     with torch.cuda.device(f.device), _timed("invert_action"):
         if hint > 0 and B > 0:
             st = lib.eqa_group_action_fwd_hint(f.data_ptr(), out.data_ptr(), gidx.data_ptr(), theta.data_ptr(), p_flags, p_map,

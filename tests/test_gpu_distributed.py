@@ -172,6 +172,30 @@ def _shards(kind, xs, ys, split):
     return [[(x[:split], y[:split]), (x[split:], y[split:])] for x, y in zip(xs, ys)]
 
 
+def _by_value(o):
+    """Tensors -> numpy arrays (pickled by value): torch's queue reduction shares CPU tensors through file descriptors the parent
+    can no longer open once the worker has exited."""
+    if torch.is_tensor(o):
+        return o.detach().cpu().numpy()
+    if isinstance(o, dict):
+        return {k: _by_value(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_by_value(v) for v in o]
+    return o
+
+
+def _tensors(o):
+    import numpy as np
+
+    if isinstance(o, np.ndarray):
+        return torch.from_numpy(o)
+    if isinstance(o, dict):
+        return {k: _tensors(v) for k, v in o.items()}
+    if isinstance(o, list):
+        return [_tensors(v) for v in o]
+    return o
+
+
 def _seed_for(step, rank):
     return 1000 * (step + 1) + rank    # the fused blocks draw their dropout seeds from torch's CPU generator at forward time
 
@@ -245,7 +269,7 @@ def _worker2(kind, split, rank, port, q):
                 dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
-        q.put(res)
+        q.put(_by_value(res))
 
 
 @pytest.mark.timeout(900)
@@ -261,7 +285,7 @@ def test_gloo_world2_on_one_gpu_real_canonicalizers_average_different_shards(kin
     procs = [ctx.Process(target=_worker2, args=(kind, split, r, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(), q.get()]
+    got = [_tensors(q.get()), _tensors(q.get())]
     for p in procs:
         p.join(120)
     res = {r["rank"]: r for r in got}

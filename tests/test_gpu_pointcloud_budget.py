@@ -17,6 +17,15 @@ import torch
 from oracle import pointcloud_ops as po
 
 
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with -m gpu on the MI355X box"
+    from equiadapt_amd import _lib
+
+    _lib.load()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
 def _vnsmall_state(seed=2):
     import equiadapt_amd as ea
 
