@@ -146,14 +146,18 @@ def cpu_baseline(sample: int, reps: int):
         best = (float("inf"), cores)
         xs, fs = x, f
         x, f = x[:4], f[:4]
+        calib = {}
         for nt in sorted({cores, 64, 32, 16, 8} & set(range(1, cores + 1)), reverse=True):
             torch.set_num_threads(nt)
             step()
-            t0 = time.perf_counter()
-            step()
-            dt = time.perf_counter() - t0
-            if dt < best[0]:
-                best = (dt, nt)
+            ts3 = []
+            for _ in range(3):                      # three timed runs per thread count, the best of them: one run is noise on a shared host
+                t0 = time.perf_counter()
+                step()
+                ts3.append(time.perf_counter() - t0)
+            calib[nt] = min(ts3)
+            if calib[nt] < best[0]:
+                best = (calib[nt], nt)
         x, f = xs, fs
         torch.set_num_threads(best[1])
         step()
@@ -174,7 +178,8 @@ def cpu_baseline(sample: int, reps: int):
     return {"value": sample / med, "unit": "images/s", "cores": torch.get_num_threads(), "host_cores": cores, "kind": "port",
             "sample": f"{sample} images x {reps} reps of the same step (oracle/: pre-transform, conv stack, "
                       f"argmax, pad+rotate+crop, invert) on torch-CPU, {torch.get_num_threads()} threads",
-            "group_action_only_images_s": sample / ga}
+            "group_action_only_images_s": sample / ga,
+            "thread_calibration_ms_per_4_images": {str(k): v * 1e3 for k, v in sorted(calib.items())}}
 
 
 def cpu_baseline_config(name: str, state: dict):
@@ -204,14 +209,29 @@ def cpu_baseline_config(name: str, state: dict):
         dt = timed(f1, 5)
         return {"value": 128 / dt, "unit": "images/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port", "sample": "B=128 x 5 reps"}
     if name == "cfg4":
-        pcs, sd = torch.randn(4, 3, 1024), state["sd"]
-        dt = timed(lambda: po.canonicalize_pointcloud(pcs, po.gram_schmidt(po.vnsmall_forward(pcs, sd))), 2)
-        return {"value": 4 / dt, "unit": "clouds/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port", "sample": "B=4 x 2 reps"}
-    if name == "cfg5":  # transform + invert only (the orbit / network part is a few ms either way)
-        x1, ang, refl = torch.randn(1, 3, 1024, 1024), torch.tensor([90.0]), torch.tensor([1.0])
-        dt = timed(lambda: (io.canonicalize_images(x1, ang, refl, (3, 1024, 1024)), io.invert_action(x1[:, :1], ang, refl, 4, 8, "scalar")), 2)
+        pcs, sd = torch.randn(8, 3, 1024), state["sd"]
+        dt = timed(lambda: po.canonicalize_pointcloud(pcs, po.gram_schmidt(po.vnsmall_forward(pcs, sd))), 3)
+        return {"value": 8 / dt, "unit": "clouds/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port", "sample": "B=8 x 3 reps"}
+    if name == "cfg5":  # the WHOLE step of the GPU leg on one image: resize -> orbit -> ConvNetwork -> activations -> argmax -> transform of the
+        # image, its 3 masks and 3 boxes -> invert of a mask-shaped output
+        g = torch.Generator().manual_seed(13)
+        x1, pred1 = torch.randn(1, 3, 1024, 1024, generator=g), torch.randn(1, 1, 1024, 1024, generator=g)
+        m1 = (torch.rand(3, 1024, 1024, generator=g) > 0.5).to(torch.uint8)
+        b1 = torch.tensor([[10.0, 20.0, 200.0, 300.0]] * 3)
+        sd, ref = state["sd"], state["ref_vec"]
+
+        def f5():
+            xin = io.pre_canonicalization_transform(x1, (3, 1024, 1024), 1.0, 128)
+            vec = onets.conv_network(io.orbit_expand(xin, 4, "roto-reflection", 128), sd, 3, training=False)
+            acts = io.optimized_group_activations(vec, ref, 8)
+            el = io.group_element_from_activations(acts, 4, "roto-reflection", 1.0, training=False)
+            y = io.canonicalize_images(x1, el["rotation"], el["reflection"], (3, 1024, 1024))
+            mk = io.rotate_masks(io.flip_masks(m1), -el["rotation"][0].item())
+            bx = io.rotate_boxes(io.flip_boxes(b1.clone(), 1024), el["rotation"][0], 1024)
+            return y, mk, bx, io.invert_action(pred1, el["rotation"], el["reflection"], 4, 8, "scalar")
+        dt = timed(f5, 3)
         return {"value": 1 / dt, "unit": "images/s", "ms": dt * 1e3, "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "B=1 x 2 reps, transform + invert only"}
+                "sample": "B=1 x 3 reps of the whole step (resize, orbit, ConvNetwork on 8 views, activations, image + 3 masks + 3 boxes, invert)"}
     raise ValueError(name)
 
 
@@ -648,7 +668,7 @@ def leg_configs(comm: Comm, with_cpu: bool):
         ach_m = B * 3 * 2 * 1024 * 1024 / (ms_mk * 1e-3) / 1e9
         # The per-launch HIP-event bracket carries a fixed cost (an EMPTY bracket measures ~4.8 us on this runtime, a 256 MB fill
         # 2 us more than back to back: tools/event_overhead.py) that is negligible for the headline's 58 us kernel and a fifth of
-        # these launches at B = 4.  The same two kernels launched 30 times between one pair of events, same tensors:
+        # these launches at B = 4.  The same two kernels launched 30 times between one pair of events, over a cache-cold ring of buffers:
         from equiadapt_amd.images import geometry
         from equiadapt_amd.images.utils import device_tables
         g5 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
@@ -658,24 +678,36 @@ def leg_configs(comm: Comm, with_cpu: bool):
         rth5 = geometry.mask_rotation_table((-geometry.group_angles(4)).tolist(), (1024, 1024)).to(dev)
         mfl5 = torch.full((4,), geometry.FLIP_SRC, dtype=torch.int32, device=dev)
 
-        def b2b(fn, reps=30):
-            for _ in range(3):
-                fn()
+        def b2b(fn, inputs, reps=30):
+            """`reps` launches between ONE pair of events, each on the next buffer of a ring whose inputs + kept outputs exceed the
+            256 MB Infinity Cache several times over: no launch finds its operands (or the lines it is about to write) cached by the
+            launch before -- at B = 4 the whole working set of one launch (100 MB image, 25 MB masks) would otherwise stay resident
+            and the figure would be a cache bandwidth, not HBM's."""
+            n = len(inputs)
+            outs = [None] * n
+            for i in range(n):
+                outs[i] = fn(inputs[i])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
-                fn()
+            for r in range(reps):
+                outs[r % n] = fn(inputs[r % n])
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
+
+        def ring(t, at_least_bytes=640 << 20):      # distinct copies of t: inputs + outputs >= 2.5 x the cache
+            n = max(2, -(-at_least_bytes // (2 * t.numel() * t.element_size())))
+            return [t] + [t.clone() for _ in range(n - 1)]
         with torch.no_grad():
-            ms_ct_b2b = b2b(lambda: ops.canon_transform(x, g5, th5, fl5, 512))
-            ms_mk_b2b = b2b(lambda: ops.mask_action_nearest(mcat, e5, rth5, mfl5))
+            xs5, ms5 = ring(x), ring(mcat)
+            ms_ct_b2b = b2b(lambda a: ops.canon_transform(a, g5, th5, fl5, 512), xs5)
+            ms_mk_b2b = b2b(lambda a: ops.mask_action_nearest(a, e5, rth5, mfl5), ms5)
+            ring_note = f"ring of {len(xs5)} image batches / {len(ms5)} mask stacks (inputs + outputs >= 640 MB per ring: cache-cold)"
+            del xs5, ms5
         del mcat
         ach_b, ach_mb = B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct_b2b * 1e-3) / 1e9, B * 3 * 2 * 1024 * 1024 / (ms_mk_b2b * 1e-3) / 1e9
-        how = ("avg_launch_ms / achieved / frac: the kernel launched 30 times between ONE pair of HIP events on the same tensors -- the duration "
-               "rocprofv3's kernel trace reports (profiles/r04/rocprofv3_kernel_stats_cfg5_b4.md: mask kernel 12.5 us); "
-               "per_launch_event_*: one event bracket per launch inside the timed step, which adds the bracket's own ~2-5 us "
+        how = ("avg_launch_ms / achieved / frac: the kernel launched 30 times between ONE pair of HIP events over a " + ring_note +
+               "; per_launch_event_*: one event bracket per launch inside the timed step, which adds the bracket's own ~2-5 us "
                "(tools/event_overhead.py) to these 12-27 us launches")
         c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
             "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach_b,
@@ -694,7 +726,7 @@ def leg_configs(comm: Comm, with_cpu: bool):
             del gstep
     c5["value"] = c5["batches"]["32"]["value"]
     if with_cpu:
-        c5["cpu_baseline"] = cpu_baseline_config("cfg5", {})
+        c5["cpu_baseline"] = cpu_baseline_config("cfg5", {"sd": sd5, "ref_vec": ref5})
         c5["parity"] = parity_config("cfg5", {"sd": sd5, "ref_vec": ref5, "can": can5, "dev": dev})
     out["cfg5"] = c5
     return out
@@ -753,9 +785,10 @@ def main():
     line = {"metric": "canonicalize+invert images/sec (224x224 C8)", "value": None, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 224x224x3 synthetic, C8, GroupEquivariantImageCanonicalization + "
-                                   "ESCNNEquivariantNetwork(32ch,k5,3 layers, crop 0.8, resize 96) forward, "
-                                   "then invert_canonicalization(scalar, 3ch); prediction network excluded",
+            "config": {"workload": "configs[1]: 224x224x3 synthetic, C8, GroupEquivariantImageCanonicalization + ESCNNEquivariantNetwork in e2cnn's "
+                                   "LAYER SHAPES (32 fields x 8 = 256 ch, k5, 3 layers, crop 0.8, resize 96) with this repository's own filter-bank "
+                                   "parameterisation (bilinear-rotated banks; e2cnn's steerable basis is not restated -- e2cnn-trained weights enter "
+                                   "via load_exported_dense), forward, then invert_canonicalization(scalar, 3ch); prediction network excluded",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world} (no collective in the forward path)"},
             "rccl_ranks": world if comm.backend == "nccl" else 0, "backend": comm.backend, "ranks_share_gpu": comm.ranks_share_gpu}
 
@@ -843,11 +876,18 @@ def main():
         # HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch
         # correction; tools/collect_traffic.sh).  Counters cannot be collected inside this process, so the committed
         # measurement of the same kernel / shape is reported; null when it does not match this run's shape.
-        traffic, tsrc = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        from equiadapt_amd import _lib as _eqalib
+
+        traffic, tsrc, tstate = None, None, None
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             tpath = os.path.join(ROOT, "profiles", rnd, "traffic_group_action.json")
             if os.path.exists(tpath) and B == 256:
-                traffic, tsrc = json.load(open(tpath)).get("traffic_bytes_per_launch"), f"profiles/{rnd}/traffic_group_action.json"
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj.get("traffic_bytes_per_launch"), f"profiles/{rnd}/traffic_group_action.json"
+                stamp = tj.get("kernel_source_sha1")
+                tstate = ("committed, no source stamp (collected before round 5)" if stamp is None else
+                          "committed, kernel source unchanged since collection" if stamp == _eqalib.source_hash("group_action.hip") else
+                          "committed, STALE: csrc/group_action.hip changed since collection")
                 break
         ga_bytes = 2 * B * BYTES_TRANSFORM
         line.update({
@@ -855,7 +895,7 @@ def main():
             "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
             "roofline": {"bound": "hbm", "kernel": "group_action_kernel<3,true> via eqa_canon_transform_fwd",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC, {tsrc})", "traffic_source": "committed",
+                         "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC, {tsrc})", "traffic_source": tstate,
                          "launches_timed": n_ct, "avg_launch_ms": ms_ct, "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
             "group_action": {"images_s_per_gpu": B / (ga2_ms * 1e-3), "ms": ga2_ms,
@@ -877,7 +917,7 @@ def main():
             d = dict(line["stages"][dom])
             tr, tsrc = None, None
             try:
-                tsrc = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
+                tsrc = next(r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
                 tj = json.load(open(os.path.join(ROOT, "profiles", tsrc, "traffic_canon_net.json")))
                 key = {"fft_gemm": "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
                        "lift_conv": "lift_conv_dense_kernel"}.get(dom)

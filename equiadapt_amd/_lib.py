@@ -152,6 +152,18 @@ _lock = threading.Lock()
 _lib = None
 
 
+def source_hash(*names: str) -> str:
+    """sha1 over the named csrc files (+ the shared headers): what a committed counter measurement of a kernel is stamped with
+    (tools/collect_traffic*.sh) and what bench.py compares against before it reports that measurement beside a live timing."""
+    import hashlib
+
+    h = hashlib.sha1()
+    for path in [os.path.join(CSRC, n) for n in names] + HEADERS:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 class EqaLibraryError(RuntimeError):
     pass
 

@@ -1703,7 +1703,10 @@ extern "C" {
 
 int eqa_abi_version(void) { return EQA_ABI_VERSION; }
 
-int eqa_get_option(int key) { return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : EQA_ERR_INVALID_ARG; }
+int eqa_get_option(int key) {
+  if (key == 100) return kMaxWinK;   // read-only: the largest window the window-sum kernels take (ops.MAX_WINDOW_K must equal it)
+  return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : EQA_ERR_INVALID_ARG;
+}
 
 int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad) {
   if (planes <= 0 || H <= 0 || W <= 0 || pad < 0) return 0;

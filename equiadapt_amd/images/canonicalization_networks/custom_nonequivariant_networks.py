@@ -149,8 +149,17 @@ class ConvNetwork(nn.Module):
             h = x.contiguous(memory_format=torch.channels_last) if mode.startswith("cl") else x
             for m in self.enc_network:
                 if isinstance(m, nn.BatchNorm2d) and mode.endswith("native"):
-                    with torch.backends.cudnn.flags(enabled=False):      # (the convolutions stay with MIOpen)
-                        h = m(h)
+                    # ATen's own channels-last batch-norm for THIS call (cudnn_enabled=False is an argument of the op): no
+                    # process-global backend flag is touched, so threaded replicas and torch.compile see nothing change
+                    # (the convolutions stay with MIOpen).  Same bookkeeping as nn.BatchNorm2d.forward.
+                    if m.training and m.track_running_stats and m.num_batches_tracked is not None:
+                        m.num_batches_tracked.add_(1)
+                    mom = 0.0 if m.momentum is None else m.momentum
+                    if m.training and m.track_running_stats and m.momentum is None:
+                        mom = 1.0 / float(m.num_batches_tracked)
+                    use_batch = m.training or (m.running_mean is None and m.running_var is None)
+                    h = torch.batch_norm(h, m.weight, m.bias, m.running_mean if (not m.training or m.track_running_stats) else None,
+                                         m.running_var if (not m.training or m.track_running_stats) else None, use_batch, mom, m.eps, False)
                 else:
                     h = m(h)
             return self.final_fc(h.reshape(x.shape[0], -1))

@@ -42,9 +42,9 @@ class _InnerBatchNorm(nn.BatchNorm3d):
 
 class LiftConvFunction(torch.autograd.Function):
     """Training counterpart of the lifting convolution in `_forward_inference`: forward on the fp32-MFMA kernel
-    (`eqa_lift_conv_nhwc`, 0.71 ms at the headline shape; the framework's convolution: 1.5 ms), filter gradient on the
-    matrix cores too (`eqa_lift_conv_wgrad_nhwc`; other shapes: the framework's convolution-weight-gradient).  The input image
-    needs no gradient in the canonicalizer; if asked for, it is the framework's."""
+    (`eqa_lift_conv_nhwc`, 0.71 ms at the headline shape; wide / single-channel filters: `eqa_lift_conv_wide`), filter gradient on
+    the matrix cores too (`eqa_lift_conv_wgrad_nhwc` / `eqa_lift_conv_wide_wgrad`; shapes neither takes: the framework's
+    convolution-weight-gradient).  The input image needs no gradient in the canonicalizer; if asked for, it is the framework's."""
 
     @staticmethod
     def forward(ctx, x, bank, with_stats=False):
@@ -53,6 +53,8 @@ class LiftConvFunction(torch.autograd.Function):
         ctx.save_for_backward(x, bank)
         k = bank.shape[-1]
         if not ops.lift_conv_supported(bank.shape[1], bank.shape[-2], k, bank.shape[0]):      # wide / single-channel filters
+            if with_stats:
+                raise ValueError("LiftConvFunction: with_stats needs a shape eqa_lift_conv_nhwc_stats takes (gate on ops.lift_conv_supported)")
             return ops.lift_conv_wide(x, ops.pack_lift_weights_wide(bank.detach()), None, False, bank.shape[-2], k)
         wpk = ops.pack_lift_weights(bank.detach())
         if with_stats:

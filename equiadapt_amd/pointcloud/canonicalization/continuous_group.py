@@ -57,7 +57,11 @@ class EquivariantPointcloudCanonicalization(ContinuousGroupPointcloudCanonicaliz
     def canonicalize(self, x: torch.Tensor, targets: Optional[List] = None, **kwargs: Any
                      ) -> Union[torch.Tensor, Tuple[torch.Tensor, List]]:
         net = self.canonicalization_network
-        if getattr(net, "fused_inference_applies", None) is not None and net.fused_inference_applies(x) and x.shape[0] > 0:
+        # the fused route replaces get_groupelement() and the network's __call__: only when neither has been customised (a subclass
+        # overriding get_groupelement, forward hooks on the network) -- otherwise eval would silently differ from training
+        plain = (type(self).get_groupelement is EquivariantPointcloudCanonicalization.get_groupelement
+                 and not net._forward_hooks and not net._forward_pre_hooks)
+        if plain and getattr(net, "fused_inference_applies", None) is not None and net.fused_inference_applies(x) and x.shape[0] > 0:
             # inference: network, Gram-Schmidt and rotation in two launches (eqa_vnsmall_canonicalize) instead of four; the same
             # info dict as the general path below
             self.device = x.device

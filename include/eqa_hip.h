@@ -52,7 +52,8 @@ int eqa_abi_version(void);
 
 /* Debug/benchmark knobs (process-global, not part of the data path):
  *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels.
- *   key 1: VNSmall forward kernel: 0 = chosen by size (default), 1 = one thread per point (k = 20 only), 2 = four lanes per point. */
+ *   key 1: VNSmall forward kernel: 0 = chosen by size (default), 1 = one thread per point (k = 20 only), 2 = four lanes per point.
+ *   key 100 (get only): the largest window size k the window-sum kernels take (eqa_window_sums*, the linearised last layer). */
 int eqa_set_option(int key, int value);
 int eqa_get_option(int key);
 

@@ -28,6 +28,10 @@ def test_library_exports_every_declared_symbol():
     # the version the library reports == the header's macro == the binding's constant (bumped whenever entry points are added)
     macro = int(re.search(r"#define\s+EQA_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "eqa_hip.h")).read()).group(1))
     assert _lib.load().eqa_abi_version() == macro == _lib.ABI_VERSION == 3
+    # host-side constants that mirror compiled ones are read back from the library (no compute: a getter)
+    from equiadapt_amd import ops
+
+    assert _lib.load().eqa_get_option(100) == ops.MAX_WINDOW_K
     # argument validation happens before any device work, so it is checkable without a GPU
     assert _lib.load().eqa_set_option(99, 0) == -1
     assert _lib.load().eqa_group_pool_workspace_bytes(4, 32, 8, 7056) > 0
