@@ -826,6 +826,22 @@ def main():
                                       "group_action_kernel_mean_ms": (ct[1] + iv[1]) / 2,
                                       "note": "both launches run group_action_kernel<3,true>: a kernel trace of this command averages them"}))
                 return
+            # the same step with the dominant contraction on the bf16 matrix cores (every fp32 operand split exactly into three bf16
+            # pieces, all nine piece products, fp32 accumulation: eqa_fft48k5_cgemm3m_bf16x3) -- opt-in (EQA_FFT_GEMM_PIECES=9), never
+            # `value`; printed beside the fp32-instruction step so the two forms are compared on the same box in the same run
+            from equiadapt_amd.images.canonicalization_networks import fftconv as _fc
+
+            step_forms = {"f32": elapsed / args.steps * 1e3}
+            if _fc.GEMM_PIECES == "f32":
+                for mode in ("9", "6"):
+                    _fc.GEMM_PIECES = mode
+                    try:
+                        step()                      # builds the pre-split filter spectra once
+                        it[0] = 0
+                        e_alt, _ = comm.timed(step, args.steps, 3)
+                        step_forms[mode] = e_alt / args.steps * 1e3
+                    finally:
+                        _fc.GEMM_PIECES = "f32"
             # group-action-only leg: the two resampling kernels back to back with a seeded random index
             x, f = xs[0], fs[0]
             gidx = torch.randint(0, 8, (B,), generator=torch.Generator().manual_seed(1)).to(dev, torch.int32)
@@ -898,6 +914,8 @@ def main():
                          "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC, {tsrc})", "traffic_source": tstate,
                          "launches_timed": n_ct, "avg_launch_ms": ms_ct, "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
+            "step_ms_by_gemm_form": {**step_forms, "note": "the whole timed step with the complex GEMM as: f32 = v_mfma_f32_32x32x2_f32 (default, `value`); "
+                                     "9 / 6 = bf16 matrix cores on exact three-piece splits with nine / six piece products (opt-in)"},
             "group_action": {"images_s_per_gpu": B / (ga2_ms * 1e-3), "ms": ga2_ms,
                              "achieved_GBs": ga_bytes / (ga2_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

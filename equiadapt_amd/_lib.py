@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_conv_wide.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_conv_wide.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip", "convnet_train.hip")]
 HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
@@ -131,6 +131,15 @@ SIGNATURES = {
     "eqa_fft48_filter_grad": (_int, [_vp, _vp, _int, _int, _int, _int, _vp]),
     "eqa_conv_s2_supported": (_int, [_int] * 5),
     "eqa_conv_s2": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 8 + [_vp]),
+    "eqa_conv_s2_wgrad_supported": (_int, [_int] * 5),
+    "eqa_conv_s2_wgrad_workspace_bytes": (ctypes.c_int64, [_int] * 8),
+    "eqa_conv_s2_wgrad": (_int, [_vp] * 4 + [_int] * 8 + [_vp]),
+    "eqa_conv_s2_dgrad_supported": (_int, [_int] * 4),
+    "eqa_conv_s2_dgrad": (_int, [_vp] * 3 + [_int] * 7 + [_vp]),
+    "eqa_bn_act_fwd": (_int, [_vp] * 5 + [ctypes.c_int64, _int, _int, _vp]),
+    "eqa_bn_act_partial_blocks": (ctypes.c_int64, [ctypes.c_int64]),
+    "eqa_bn_act_bwd_reduce": (_int, [_vp] * 8 + [ctypes.c_int64, _int, _int, _vp]),
+    "eqa_bn_act_bwd_apply": (_int, [_vp] * 11 + [ctypes.c_int64, _int, _int, _vp]),
     "eqa_affine_relu_rows": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, _vp]),
     "eqa_cosine_group_activations": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_float, _vp]),
     "eqa_bias_relu_nhwc": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),

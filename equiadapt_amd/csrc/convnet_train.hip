@@ -1,0 +1,563 @@
+// libeqa_hip.so, part 16 -- ConvNetwork (row I10) in TRAINING: the stride-2 convolutions' filter and data gradients on the fp32
+// matrix cores, and the batch-norm (batch statistics) + activation blocks of the encoder and the head, forward and backward.
+// C ABI: include/eqa_hip.h.
+//
+// Reference: equiadapt/images/canonicalization_networks/custom_nonequivariant_networks.py:44-80 -- per layer
+// Conv2d(k, stride 2, padding 0 / 1) -> BatchNorm2d -> GELU; head BatchNorm1d -> Dropout1d(0.5) -> ReLU -> Linear.  The optimised
+// canonicalizer trains it on G group views per image (tutorial cell 26/30: 2048 views of 64 x 64 per step, twice).  Through the
+// framework that was MIOpen's implicit-GEMM forward / backward-data / backward-weights kernels (34 % of the loop) and ATen's
+// batch-norm kernels (28 %).  Here (forward convolution: eqa_conv_s2 of smallconv.hip, with gelu = 0):
+//   conv_s2_wgrad_*   dW[co][ci][u][v] = sum over output pixels of dz[p][co] * x[window(p) + (u, v)][ci].  The reduction index of
+//                     the 16x16x4 matrix instruction is the PIXEL: A[i = co][k = pixel] = dz, B[k = pixel][j = ci] = x at one tap.
+//                     A wave owns one filter row u and a run of output pixels; its K * (Cout / 16) * (Cin / 16) accumulator tiles go
+//                     to a workspace, summed over the runs in a fixed order by conv_s2_wgrad_reduce_kernel (deterministic, no atomics).
+//   conv_s2_dgrad_*   dx[pixel][ci] = sum over (tap, co) of dz[.][co] * W[co][ci][tap] -- only taps of the pixel's own parity reach
+//                     a stride-2 output, so the input pixels are walked one parity class (row parity, column parity) at a time: inside a
+//                     class the gradient is a dense stride-1 correlation of dz with the sub-sampled filter, the forward kernel's loop
+//                     with the roles of Cin and Cout exchanged.
+//   bn_act_*          y = rowscale[p] * act(scale[c] z + shift[c]) and its backward in two passes (per-channel sums of g and g * zhat
+//                     as fp64 partials per block, then dz); act = exact GELU (encoder) or ReLU (head, rowscale = Dropout1d's per-row
+//                     factor).  The batch statistics themselves: eqa_bn_stats_nhwc (batchnorm.hip).
+#include "eqa_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr unsigned kOob = 0x7ffffff0u;   // a buffer offset outside every buffer: the load returns zero
+
+__device__ __forceinline__ float act_fwd(int act, float h) {
+  return act == 0 ? 0.5f * h * (1.0f + erff(h * 0.70710678118654752440f)) : fmaxf(h, 0.0f);
+}
+__device__ __forceinline__ float act_grad(int act, float h) {
+  if (act != 0) return h > 0.0f ? 1.0f : 0.0f;
+  // d/dh [h Phi(h)] = Phi(h) + h phi(h)
+  return 0.5f * (1.0f + erff(h * 0.70710678118654752440f)) + h * 0.39894228040143267794f * __expf(-0.5f * h * h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// batch-norm (given per-channel scale / shift) + activation (+ per-row factor), channels-last (npix, C), C % 4 == 0
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const float* __restrict__ rowscale,
+                                                             float* __restrict__ y, size_t nquad, int Q) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
+    const int q = (int)(i % Q);
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float r = rowscale ? rowscale[i / Q] : 1.0f;
+    reinterpret_cast<float4*>(y)[i] = make_float4(r * act_fwd(ACT, v.x * sc.x + sh.x), r * act_fwd(ACT, v.y * sc.y + sh.y),
+                                                  r * act_fwd(ACT, v.z * sc.z + sh.z), r * act_fwd(ACT, v.w * sc.w + sh.w));
+  }
+}
+
+// g = gy * rowscale * act'(scale z + shift);  partial[(blk * C + c) * 2 + {0, 1}] = sum of g, sum of g * zhat over the block's pixels
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void bn_act_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ z,
+                                                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const float* __restrict__ rowscale, double* __restrict__ partial,
+                                                                    size_t npix, int C, int pix_per_block) {
+  __shared__ float4 s_red[2][kThreads];
+  const int Q = C >> 2;
+  const int lanes = min(Q, kThreads);
+  const int rows = kThreads / lanes;
+  const int q0 = threadIdx.x % lanes, r0 = threadIdx.x / lanes;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = min(npix, p0 + pix_per_block);
+  for (int qb = 0; qb < Q; qb += lanes) {      // uniform trip count: every thread reaches both barriers of every trip
+    const int q = qb + q0;
+    const bool has_q = q < Q;
+    const int qc = has_q ? q : 0;
+    const float4 sc = reinterpret_cast<const float4*>(scale)[qc], sh = reinterpret_cast<const float4*>(shift)[qc];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[qc], rs = reinterpret_cast<const float4*>(rstd)[qc];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), sx = s;
+    if (r0 < rows && has_q) {
+      for (size_t p = p0 + r0; p < p1; p += rows) {
+        const size_t i = p * Q + q;
+        const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+        const float4 v = reinterpret_cast<const float4*>(z)[i];
+        const float r = rowscale ? rowscale[p] : 1.0f;
+        const float g0 = g4.x * r * act_grad(ACT, v.x * sc.x + sh.x), g1 = g4.y * r * act_grad(ACT, v.y * sc.y + sh.y);
+        const float g2 = g4.z * r * act_grad(ACT, v.z * sc.z + sh.z), g3 = g4.w * r * act_grad(ACT, v.w * sc.w + sh.w);
+        s.x += g0; s.y += g1; s.z += g2; s.w += g3;
+        sx.x += g0 * (v.x - mu.x) * rs.x; sx.y += g1 * (v.y - mu.y) * rs.y;
+        sx.z += g2 * (v.z - mu.z) * rs.z; sx.w += g3 * (v.w - mu.w) * rs.w;
+      }
+    }
+    __syncthreads();
+    s_red[0][threadIdx.x] = s;
+    s_red[1][threadIdx.x] = sx;
+    __syncthreads();
+    if (r0 == 0 && has_q) {
+      for (int r = 1; r < rows; ++r) {
+        const float4 a = s_red[0][r * lanes + q0], b = s_red[1][r * lanes + q0];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        sx.x += b.x; sx.y += b.y; sx.z += b.z; sx.w += b.w;
+      }
+      double* o = partial + ((size_t)blockIdx.x * C + 4 * q) * 2;
+      o[0] = s.x; o[1] = sx.x; o[2] = s.y; o[3] = sx.y; o[4] = s.z; o[5] = sx.z; o[6] = s.w; o[7] = sx.w;
+    }
+  }
+}
+
+// dz = gscale[c] * (g - m1[c] - zhat * m2[c]),  gscale = gamma * rstd, m1 = sum(g) / n, m2 = sum(g zhat) / n
+template <int ACT>
+__global__ __launch_bounds__(kThreads) void bn_act_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ z,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                   const float* __restrict__ rowscale, const float* __restrict__ gscale,
+                                                                   const float* __restrict__ m1, const float* __restrict__ m2,
+                                                                   float* __restrict__ dz, size_t nquad, int Q) {
+  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
+    const int q = (int)(i % Q);
+    const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
+    const float4 v = reinterpret_cast<const float4*>(z)[i];
+    const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
+    const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
+    const float4 gs = reinterpret_cast<const float4*>(gscale)[q], a1 = reinterpret_cast<const float4*>(m1)[q],
+                 a2 = reinterpret_cast<const float4*>(m2)[q];
+    const float r = rowscale ? rowscale[i / Q] : 1.0f;
+    float4 o;
+    o.x = gs.x * (g4.x * r * act_grad(ACT, v.x * sc.x + sh.x) - a1.x - (v.x - mu.x) * rs.x * a2.x);
+    o.y = gs.y * (g4.y * r * act_grad(ACT, v.y * sc.y + sh.y) - a1.y - (v.y - mu.y) * rs.y * a2.y);
+    o.z = gs.z * (g4.z * r * act_grad(ACT, v.z * sc.z + sh.z) - a1.z - (v.z - mu.z) * rs.z * a2.z);
+    o.w = gs.w * (g4.w * r * act_grad(ACT, v.w * sc.w + sh.w) - a1.w - (v.w - mu.w) * rs.w * a2.w);
+    reinterpret_cast<float4*>(dz)[i] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// filter gradient of the stride-2 convolution
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kWgIter = 16;       // output pixels per loop trip of a wave (four k-slots x four matrix instructions)
+
+// the output pixel's (image, row, column) kept by increments: one division per wave start, carries afterwards
+struct PixPos {
+  int b, oy, ox;
+};
+__device__ __forceinline__ PixPos pix_pos(long p, int OH, int OW) {
+  PixPos r;
+  r.ox = (int)(p % OW);
+  r.oy = (int)((p / OW) % OH);
+  r.b = (int)(p / ((long)OW * OH));
+  return r;
+}
+__device__ __forceinline__ void pix_advance(PixPos& r, int step, int OH, int OW) {
+  r.ox += step;
+  while (r.ox >= OW) {
+    r.ox -= OW;
+    if (++r.oy == OH) {
+      r.oy = 0;
+      ++r.b;
+    }
+  }
+}
+
+// NHWC input, Cin = 16 CH.  x:(B,H,W,Cin), dz:(B,OH,OW,Cout).  grid (pixel runs, K filter rows, Cout / 16 channel chunks).
+// ws:(runs, K, K, Cout, Cin) partial filter gradients.
+template <int K, int CH, int PAD>
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                     float* __restrict__ ws, int Cout, int H, int W, int OH, int OW, long P,
+                                                                     int pix_per_wave, unsigned x_bytes, unsigned dz_bytes) {
+  constexpr int Cin = 16 * CH;
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int u = blockIdx.y, n = blockIdx.z;
+  const long p_begin = run * pix_per_wave;
+  if (p_begin >= P) return;
+  const long p_end = min(P, p_begin + pix_per_wave);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
+  f32x4 acc[K][CH];
+#pragma unroll
+  for (int v = 0; v < K; ++v)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // slot s of this lane = pixel p + 4 s + kq of the trip starting at p
+  PixPos pos[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
+#pragma unroll 1
+  for (long p = p_begin; p < p_end; p += kWgIter) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long ps = p + 4 * s + kq;
+      const bool live = ps < p_end;
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
+      const int iy = 2 * pos[s].oy - PAD + u, ix0 = 2 * pos[s].ox - PAD;
+      const bool row_ok = live && (PAD == 0 || (iy >= 0 && iy < H));
+      const unsigned base = (unsigned)((((long)pos[s].b * H + iy) * W + ix0) * Cin + j) * 4u;
+      float b[K][CH];
+#pragma unroll
+      for (int v = 0; v < K; ++v) {
+        const bool ok = row_ok && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+          b[v][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? base + (unsigned)(v * Cin + 16 * c) * 4u : kOob, 0, 0));
+      }
+      pix_advance(pos[s], kWgIter, OH, OW);
+#pragma unroll
+      for (int v = 0; v < K; ++v)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[v][c], acc[v][c], 0, 0, 0);
+    }
+  }
+  // D[i = 4 kq + r][j]: co = 16 n + 4 kq + r, ci = 16 c + j
+  float* o = ws + (((size_t)run * K + u) * K) * (size_t)(Cout * Cin);
+#pragma unroll
+  for (int v = 0; v < K; ++v)
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)v * (Cout * Cin) + (16 * n + 4 * kq + r) * Cin + 16 * c + j] = acc[v][c][r];
+}
+
+// planar input with Cin <= 4 (the first layer: NCHW views).  The 16 columns of a B tile are the (channel, filter column) pairs
+// jj = ci * K + v of filter row u (Cin * K <= 16 NJ); x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [u], Cout, 16 NJ [jj]).
+template <int K, int NJ, int PAD>
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                       float* __restrict__ ws, int Cin, int Cout, int H, int W, int OH,
+                                                                       int OW, long P, int pix_per_wave, unsigned x_bytes,
+                                                                       unsigned dz_bytes) {
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int u = blockIdx.y, n = blockIdx.z;
+  const long p_begin = run * pix_per_wave;
+  if (p_begin >= P) return;
+  const long p_end = min(P, p_begin + pix_per_wave);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
+  // this lane's columns: jj = 16 t + j -> (ci, v)
+  int lci[NJ], lv[NJ];
+  bool lhas[NJ];
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) {
+    const int jj = 16 * t + j;
+    lhas[t] = jj < Cin * K;
+    lci[t] = lhas[t] ? jj / K : 0;
+    lv[t] = lhas[t] ? jj - lci[t] * K : 0;
+  }
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int t = 0; t < NJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  PixPos pos[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
+#pragma unroll 1
+  for (long p = p_begin; p < p_end; p += kWgIter) {
+    float a[4], b[4][NJ];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const long ps = p + 4 * s + kq;
+      const bool live = ps < p_end;
+      a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
+      const int iy = 2 * pos[s].oy - PAD + u, ix0 = 2 * pos[s].ox - PAD;
+      const bool row_ok = live && (PAD == 0 || (iy >= 0 && iy < H));
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) {
+        const int ix = ix0 + lv[t];
+        const bool ok = row_ok && lhas[t] && (PAD == 0 || (ix >= 0 && ix < W));
+        const unsigned off = (unsigned)((((long)pos[s].b * Cin + lci[t]) * H + iy) * W + ix) * 4u;
+        b[s][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off : kOob, 0, 0));
+      }
+      pix_advance(pos[s], kWgIter, OH, OW);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s][t], acc[t], 0, 0, 0);
+  }
+  float* o = ws + ((size_t)run * K + u) * (size_t)(Cout * 16 * NJ);
+#pragma unroll
+  for (int t = 0; t < NJ; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[(16 * n + 4 * kq + r) * (16 * NJ) + 16 * t + j] = acc[t][r];
+}
+
+// dw[co][ci][u][v] = sum over the runs of the partials, in run order (fp32 partials of <= pix_per_wave pixels each, fp64 across).
+// nhwc:   ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int runs,
+                                                                       int K, int Cout, int Cin, int JJ) {
+  const int n_out = Cout * Cin * K * K;
+  const int e = blockIdx.x * kThreads + threadIdx.x;   // element of ws's per-run block (coalesced reads)
+  const size_t per_run = JJ ? (size_t)K * Cout * JJ : (size_t)n_out;
+  if ((size_t)e >= per_run) return;
+  int co, ci, u, v;
+  if (JJ) {
+    const int jj = e % JJ;
+    co = (e / JJ) % Cout;
+    u = e / (JJ * Cout);
+    if (jj >= Cin * K) return;
+    ci = jj / K;
+    v = jj - ci * K;
+  } else {
+    ci = e % Cin;
+    co = (e / Cin) % Cout;
+    v = (e / (Cin * Cout)) % K;
+    u = e / (Cin * Cout * K);
+  }
+  double acc = 0.0;
+  for (int r = 0; r < runs; ++r) acc += (double)ws[(size_t)r * per_run + e];
+  dw[((co * Cin + ci) * K + u) * K + v] = (float)acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// data gradient of the stride-2 convolution, NHWC: dz:(B,OH,OW,Cout = 16 CC) -> dx:(B,H,W,Cin = 16 NCI)
+// One parity class (PY, PX) of input pixels: iy = PY + 2 yh, ix = PX + 2 xh.  Taps of the class: u = U0 + 2 a, v = V0 + 2 c with
+// U0 = (PY + PAD) & 1; the output pixel is oy = yh + (PY + PAD - U0) / 2 - a.  wd:(K*K taps, CC, NCI, 4 [kq], 16 [j = ci], 4 [s])
+// holds W[co = 16 cc + 4 kq + s][ci = 16 n + j][u][v] (ops.pack_conv_s2_dgrad_weights).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int kDgTiles = 4;
+
+template <int K, int CC, int NCI, int PAD, int PY, int PX>
+__device__ __forceinline__ void conv_s2_dgrad_class(const float* __restrict__ dz, const float* __restrict__ wd, float* __restrict__ dx, int B,
+                                                    int H, int W, int OH, int OW, unsigned dz_bytes, long wave) {
+  constexpr int Cout = 16 * CC, Cin = 16 * NCI;
+  constexpr int U0 = (PY + PAD) & 1, V0 = (PX + PAD) & 1;
+  constexpr int TA = (K - U0 + 1) / 2, TC = (K - V0 + 1) / 2;       // taps per axis in this class
+  constexpr int OY0 = (PY + PAD - U0) / 2, OX0 = (PX + PAD - V0) / 2;
+  const int Hc = (H - PY + 1) / 2, Wc = (W - PX + 1) / 2;            // class pixels per column / row
+  const long Q = (long)B * Hc * Wc;
+  const long q0 = wave * (16 * kDgTiles);
+  if (q0 >= Q || Hc <= 0 || Wc <= 0) return;
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, kq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
+  int yh[kDgTiles], xh[kDgTiles], bb[kDgTiles];
+#pragma unroll
+  for (int t = 0; t < kDgTiles; ++t) {
+    const long q = min(q0 + 16 * t + i, Q - 1);
+    xh[t] = (int)(q % Wc);
+    yh[t] = (int)((q / Wc) % Hc);
+    bb[t] = (int)(q / ((long)Wc * Hc));
+  }
+  f32x4 acc[kDgTiles][NCI];
+#pragma unroll
+  for (int t = 0; t < kDgTiles; ++t)
+#pragma unroll
+    for (int n = 0; n < NCI; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const f32x4* wl = reinterpret_cast<const f32x4*>(wd) + lane;
+#pragma unroll 1
+  for (int a = 0; a < TA; ++a) {
+#pragma unroll
+    for (int c = 0; c < TC; ++c) {
+      const int tap = (U0 + 2 * a) * K + V0 + 2 * c;
+#pragma unroll
+      for (int cc = 0; cc < CC; ++cc) {
+        f32x4 av[kDgTiles], bv[NCI];
+#pragma unroll
+        for (int t = 0; t < kDgTiles; ++t) {
+          const int oy = yh[t] + OY0 - a, ox = xh[t] + OX0 - c;
+          const bool ok = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
+          const unsigned off = (unsigned)((((long)bb[t] * OH + oy) * OW + ox) * Cout + 16 * cc + 4 * kq) * 4u;
+          av[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, ok ? off : kOob, 0, 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NCI; ++n) bv[n] = wl[((tap * CC + cc) * NCI + n) * 64];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < kDgTiles; ++t)
+#pragma unroll
+            for (int n = 0; n < NCI; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[t][s], bv[n][s], acc[t][n], 0, 0, 0);
+      }
+    }
+  }
+  // D[i = 4 rq + r][j]: pixel q0 + 16 t + 4 rq + r, channel 16 n + j
+  const int jj = lane & 15, rq = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < kDgTiles; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long q = q0 + 16 * t + 4 * rq + r;
+      if (q >= Q) continue;
+      const int x2 = (int)(q % Wc), y2 = (int)((q / Wc) % Hc);
+      const long b2 = q / ((long)Wc * Hc);
+      float* o = dx + (((b2 * H + PY + 2 * y2) * W + PX + 2 * x2) * (long)Cin);
+#pragma unroll
+      for (int n = 0; n < NCI; ++n) o[16 * n + jj] = acc[t][n][r];
+    }
+}
+
+template <int K, int CC, int NCI, int PAD>
+__global__ __launch_bounds__(kThreads) void conv_s2_dgrad_nhwc_kernel(const float* __restrict__ dz, const float* __restrict__ wd,
+                                                                     float* __restrict__ dx, int B, int H, int W, int OH, int OW,
+                                                                     unsigned dz_bytes) {
+  const long wave = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  switch (blockIdx.y) {   // block-uniform
+    case 0: conv_s2_dgrad_class<K, CC, NCI, PAD, 0, 0>(dz, wd, dx, B, H, W, OH, OW, dz_bytes, wave); break;
+    case 1: conv_s2_dgrad_class<K, CC, NCI, PAD, 0, 1>(dz, wd, dx, B, H, W, OH, OW, dz_bytes, wave); break;
+    case 2: conv_s2_dgrad_class<K, CC, NCI, PAD, 1, 0>(dz, wd, dx, B, H, W, OH, OW, dz_bytes, wave); break;
+    default: conv_s2_dgrad_class<K, CC, NCI, PAD, 1, 1>(dz, wd, dx, B, H, W, OH, OW, dz_bytes, wave); break;
+  }
+}
+
+int wgrad_pix_per_wave(long P) {
+  // enough runs to fill the chip (1024 SIMDs x K rows of blocks), runs of >= 256 pixels, a multiple of the trip
+  long per = (P + 2047) / 2048;
+  per = std::max(256L, std::min(4096L, per));
+  return (int)((per + kWgIter - 1) / kWgIter * kWgIter);
+}
+
+}  // namespace
+
+extern "C" {
+
+int eqa_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* rowscale, float* y, int64_t npix, int C, int act,
+                   void* stream) {
+  if (npix < 0 || C <= 0 || (act != 0 && act != 1)) return EQA_ERR_INVALID_ARG;
+  if (npix == 0) return EQA_OK;
+  if (!z || !scale || !shift || !y) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || (((uintptr_t)z | (uintptr_t)y | (uintptr_t)scale | (uintptr_t)shift) & 15)) return EQA_ERR_UNSUPPORTED;
+  const size_t nquad = (size_t)npix * (C >> 2);
+  const unsigned blocks = (unsigned)std::min<size_t>((nquad + kThreads - 1) / kThreads, 256 * 16);
+  if (act == 0)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, z, scale, shift, rowscale, y, nquad, C >> 2);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, z, scale, shift, rowscale, y, nquad, C >> 2);
+  return launch_status();
+}
+
+int64_t eqa_bn_act_partial_blocks(int64_t npix) { return npix <= 0 ? 0 : (npix + 255) / 256; }
+
+int eqa_bn_act_bwd_reduce(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          const float* rowscale, double* partial, int64_t npix, int C, int act, void* stream) {
+  if (npix < 0 || C <= 0 || (act != 0 && act != 1)) return EQA_ERR_INVALID_ARG;
+  if (npix == 0) return EQA_OK;
+  if (!gy || !z || !scale || !shift || !mean || !rstd || !partial) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || (((uintptr_t)gy | (uintptr_t)z | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd) & 15))
+    return EQA_ERR_UNSUPPORTED;
+  const unsigned blocks = (unsigned)eqa_bn_act_partial_blocks(npix);
+  if (act == 0)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
+                       rowscale, partial, (size_t)npix, C, 256);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
+                       rowscale, partial, (size_t)npix, C, 256);
+  return launch_status();
+}
+
+int eqa_bn_act_bwd_apply(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* rowscale, const float* gscale, const float* m1, const float* m2, float* dz, int64_t npix, int C,
+                         int act, void* stream) {
+  if (npix < 0 || C <= 0 || (act != 0 && act != 1)) return EQA_ERR_INVALID_ARG;
+  if (npix == 0) return EQA_OK;
+  if (!gy || !z || !scale || !shift || !mean || !rstd || !gscale || !m1 || !m2 || !dz) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || (((uintptr_t)gy | (uintptr_t)z | (uintptr_t)dz | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)mean | (uintptr_t)rstd |
+                   (uintptr_t)gscale | (uintptr_t)m1 | (uintptr_t)m2) & 15))
+    return EQA_ERR_UNSUPPORTED;
+  const size_t nquad = (size_t)npix * (C >> 2);
+  const unsigned blocks = (unsigned)std::min<size_t>((nquad + kThreads - 1) / kThreads, 256 * 16);
+  if (act == 0)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
+                       rowscale, gscale, m1, m2, dz, nquad, C >> 2);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
+                       rowscale, gscale, m1, m2, dz, nquad, C >> 2);
+  return launch_status();
+}
+
+int eqa_conv_s2_wgrad_supported(int Cin, int Cout, int K, int pad, int planar) {
+  if (!eqa_conv_s2_supported(Cin, Cout, K, pad, planar)) return 0;
+  if (planar) return Cin * K <= 32;
+  return 1;
+}
+
+int64_t eqa_conv_s2_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int K, int pad, int planar) {
+  if (!eqa_conv_s2_wgrad_supported(Cin, Cout, K, pad, planar) || B <= 0 || H + 2 * pad < K || W + 2 * pad < K) return 0;
+  const long OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1, P = (long)B * OH * OW;
+  const long per = wgrad_pix_per_wave(P), runs = (P + per - 1) / per;
+  const long per_run = planar ? (long)K * Cout * (Cin * K <= 16 ? 16 : 32) : (long)K * K * Cout * Cin;
+  return runs * per_run * 4;
+}
+
+int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout, int K, int pad,
+                      int planar, void* stream) {
+  if (!x || !dz || !dw || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (!eqa_conv_s2_wgrad_supported(Cin, Cout, K, pad, planar)) return EQA_ERR_UNSUPPORTED;
+  if (H + 2 * pad < K || W + 2 * pad < K) return EQA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) return hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * K * 4, st) == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+  if (!workspace) return EQA_ERR_INVALID_ARG;
+  const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
+  const long P = (long)B * OH * OW;
+  const size_t xbytes = (size_t)B * Cin * H * W * 4, gbytes = (size_t)P * Cout * 4;
+  if (xbytes > 0x7fffffe0ULL || gbytes > 0x7fffffe0ULL || (((uintptr_t)x | (uintptr_t)dz | (uintptr_t)dw | (uintptr_t)workspace) & 15))
+    return EQA_ERR_UNSUPPORTED;
+  const int per = wgrad_pix_per_wave(P);
+  const long runs = (P + per - 1) / per;
+  const dim3 grid((unsigned)((runs + kThreads / 64 - 1) / (kThreads / 64)), K, Cout / 16);
+  float* ws = static_cast<float*>(workspace);
+  const unsigned xb = (unsigned)xbytes, gb = (unsigned)gbytes;
+  int jj = 0;
+  if (planar) {
+    const int nj = Cin * K <= 16 ? 1 : 2;
+    jj = 16 * nj;
+#define EQA_WGP(KK, NJ, PD)                                                                                                        \
+  hipLaunchKernelGGL((conv_s2_wgrad_planar_kernel<KK, NJ, PD>), grid, dim3(kThreads), 0, st, x, dz, ws, Cin, Cout, H, W, OH, OW, P, per, xb, gb)
+#define EQA_WGP_K(KK)                                                                                                              \
+  do {                                                                                                                             \
+    if (nj == 1) { if (pad) EQA_WGP(KK, 1, 1); else EQA_WGP(KK, 1, 0); }                                                          \
+    else { if (pad) EQA_WGP(KK, 2, 1); else EQA_WGP(KK, 2, 0); }                                                                  \
+  } while (0)
+    if (K == 7) EQA_WGP_K(7); else if (K == 5) EQA_WGP_K(5); else EQA_WGP_K(3);
+#undef EQA_WGP_K
+#undef EQA_WGP
+  } else {
+    const int ch = Cin / 16;
+#define EQA_WGN(KK, CH, PD)                                                                                                        \
+  hipLaunchKernelGGL((conv_s2_wgrad_nhwc_kernel<KK, CH, PD>), grid, dim3(kThreads), 0, st, x, dz, ws, Cout, H, W, OH, OW, P, per, xb, gb)
+#define EQA_WGN_K(KK)                                                                                                              \
+  do {                                                                                                                             \
+    if (ch == 1) { if (pad) EQA_WGN(KK, 1, 1); else EQA_WGN(KK, 1, 0); }                                                          \
+    else if (ch == 2) { if (pad) EQA_WGN(KK, 2, 1); else EQA_WGN(KK, 2, 0); }                                                     \
+    else { if (pad) EQA_WGN(KK, 4, 1); else EQA_WGN(KK, 4, 0); }                                                                  \
+  } while (0)
+    if (K == 7) EQA_WGN_K(7); else if (K == 5) EQA_WGN_K(5); else EQA_WGN_K(3);
+#undef EQA_WGN_K
+#undef EQA_WGN
+  }
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  const size_t per_run = planar ? (size_t)K * Cout * jj : (size_t)K * K * Cout * Cin;
+  hipLaunchKernelGGL(conv_s2_wgrad_reduce_kernel, dim3((unsigned)((per_run + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ws, dw,
+                     (int)runs, K, Cout, Cin, jj);
+  return launch_status();
+}
+
+int eqa_conv_s2_dgrad_supported(int Cin, int Cout, int K, int pad) { return eqa_conv_s2_supported(Cin, Cout, K, pad, 0); }
+
+int eqa_conv_s2_dgrad(const float* dz, const float* wd, float* dx, int B, int Cin, int H, int W, int Cout, int K, int pad, void* stream) {
+  if (!dz || !wd || !dx || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (!eqa_conv_s2_dgrad_supported(Cin, Cout, K, pad)) return EQA_ERR_UNSUPPORTED;
+  if (H + 2 * pad < K || W + 2 * pad < K) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
+  const size_t gbytes = (size_t)B * OH * OW * Cout * 4, xbytes = (size_t)B * H * W * Cin * 4;
+  if (gbytes > 0x7fffffe0ULL || xbytes > 0x7fffffffffULL || (((uintptr_t)dz | (uintptr_t)wd | (uintptr_t)dx) & 15)) return EQA_ERR_UNSUPPORTED;
+  const long Qmax = (long)B * ((H + 1) / 2) * ((W + 1) / 2);        // the largest parity class
+  const long waves = (Qmax + 16 * kDgTiles - 1) / (16 * kDgTiles);
+  const dim3 grid((unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64)), 4);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned gb = (unsigned)gbytes;
+  const int cc = Cout / 16, nci = Cin / 16;
+#define EQA_DG(KK, CC_, NCI_, PD) \
+  hipLaunchKernelGGL((conv_s2_dgrad_nhwc_kernel<KK, CC_, NCI_, PD>), grid, dim3(kThreads), 0, st, dz, wd, dx, B, H, W, OH, OW, gb)
+#define EQA_DG_K(KK)                                                                                                               \
+  do {                                                                                                                             \
+    if (nci == 1 && cc == 1) { if (pad) EQA_DG(KK, 1, 1, 1); else EQA_DG(KK, 1, 1, 0); }                                          \
+    else if (nci == 1 && cc == 2) { if (pad) EQA_DG(KK, 2, 1, 1); else EQA_DG(KK, 2, 1, 0); }                                     \
+    else if (nci == 2 && cc == 2) { if (pad) EQA_DG(KK, 2, 2, 1); else EQA_DG(KK, 2, 2, 0); }                                     \
+    else if (nci == 2 && cc == 4) { if (pad) EQA_DG(KK, 4, 2, 1); else EQA_DG(KK, 4, 2, 0); }                                     \
+    else { if (pad) EQA_DG(KK, 4, 4, 1); else EQA_DG(KK, 4, 4, 0); }                                                              \
+  } while (0)
+  if (K == 7) EQA_DG_K(7); else if (K == 5) EQA_DG_K(5); else EQA_DG_K(3);
+#undef EQA_DG_K
+#undef EQA_DG
+  return launch_status();
+}
+
+}  // extern "C"

@@ -5,10 +5,95 @@ Small MIOpen convolutions (PyTorch-ROCm); module / parameter names match the ref
 The pretrained torchvision wrappers (ResNet18Network, WideResNet*) are out of scope.
 """
 import os
+import threading
 from typing import List
 
 import torch
 from torch import nn
+
+
+_BN_FLAG_LOCK = threading.Lock()
+
+
+def _fold_batch_stats(z2d: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm):
+    """Batch statistics of a channels-last (npix, C) view folded with the module's affine parameters, and the module's running
+    statistics updated as nn.BatchNorm*d does in a training-mode forward -> (scale, shift, mean, rstd) fp32."""
+    from equiadapt_amd import ops
+    from equiadapt_amd.common.utils import update_running_stats
+
+    n = z2d.shape[0]
+    mean64, var64 = ops.bn_batch_stats(z2d)
+    rstd64 = torch.rsqrt(var64 + bn.eps)
+    scale64 = bn.weight.detach().double() * rstd64
+    shift64 = bn.bias.detach().double() - mean64 * scale64
+    update_running_stats(bn, mean64, var64 * (n / max(n - 1, 1)))
+    return scale64.float().contiguous(), shift64.float().contiguous(), mean64.float().contiguous(), rstd64.float().contiguous()
+
+
+class _ConvBnGeluFn(torch.autograd.Function):
+    """One encoder layer in training, y = GELU(BatchNorm2d(conv_s2(x) + b)) with batch statistics, on the library's own kernels
+    (reference: custom_nonequivariant_networks.py:44-57).  Forward: eqa_conv_s2 -> eqa_bn_stats_nhwc -> eqa_bn_act_fwd; backward:
+    eqa_bn_act_bwd_reduce / _apply -> eqa_conv_s2_wgrad (+ eqa_conv_s2_dgrad for the layers behind the first).  x: the NCHW image
+    batch for the first layer (planar), a (B,H,W,C) channels-last activation afterwards; y: (B,OH,OW,Cout) channels-last.  The
+    convolution's bias gets an exactly zero gradient: behind a batch-norm with batch statistics the loss does not depend on it
+    (autograd's own figure is the rounding noise of sum(dz))."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gamma, beta, bn, k, pad, planar):
+        from equiadapt_amd import ops
+
+        cout = w.shape[0]
+        z = ops.conv_s2(x, ops.pack_conv_s2_weights(w.detach(), planar), None if b is None else b.detach(), False, cout, k, pad, planar)
+        z2 = z.view(-1, cout)
+        scale, shift, mean, rstd = _fold_batch_stats(z2, bn)
+        y = ops.bn_act_fwd(z2, scale, shift, None, 0).view(z.shape)
+        ctx.save_for_backward(x, w, z, scale, shift, mean, rstd, gamma)
+        ctx.geom = (k, pad, planar, b is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from equiadapt_amd import ops
+
+        x, w, z, scale, shift, mean, rstd, gamma = ctx.saved_tensors
+        k, pad, planar, has_bias = ctx.geom
+        cout = w.shape[0]
+        dz2, dgamma, dbeta = ops.bn_act_bwd(gy.contiguous().view(-1, cout), z.view(-1, cout), scale, shift, mean, rstd, gamma, None, 0)
+        dz = dz2.view(z.shape)
+        dw = ops.conv_s2_wgrad(x, dz, k, pad, planar) if ctx.needs_input_grad[1] else None
+        db = torch.zeros(cout, dtype=w.dtype, device=w.device) if (has_bias and ctx.needs_input_grad[2]) else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if planar:
+                raise RuntimeError("ConvNetwork: the image itself needs no gradient on the fused training path (EQA_CONVNET_TRAIN_MODE=cl_native)")
+            dx = ops.conv_s2_dgrad(dz, ops.pack_conv_s2_dgrad_weights(w.detach()), (x.shape[1], x.shape[2]), x.shape[3], k, pad)
+        return dx, dw, db, dgamma if ctx.needs_input_grad[3] else None, dbeta if ctx.needs_input_grad[4] else None, None, None, None, None
+
+
+class _BnReluRowsFn(torch.autograd.Function):
+    """The head's BatchNorm1d (batch statistics) -> Dropout1d -> ReLU on (rows, D) (custom_nonequivariant_networks.py:62-67):
+    rowscale is Dropout1d's factor per ROW -- on a 2-D input the reference's Dropout1d drops whole samples (torch treats (N, D) as an
+    unbatched (C, L) signal) -- or None; relu(r h) = r relu(h) for r >= 0, so the factor is applied behind the ReLU."""
+
+    @staticmethod
+    def forward(ctx, h, gamma, beta, bn, rowscale):
+        from equiadapt_amd import ops
+
+        scale, shift, mean, rstd = _fold_batch_stats(h, bn)
+        y = ops.bn_act_fwd(h, scale, shift, rowscale, 1)
+        ctx.save_for_backward(h, scale, shift, mean, rstd, gamma, rowscale if rowscale is not None else torch.empty(0))
+        ctx.has_rs = rowscale is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        from equiadapt_amd import ops
+
+        h, scale, shift, mean, rstd, gamma, rowscale = ctx.saved_tensors
+        dh, dgamma, dbeta = ops.bn_act_bwd(gy.contiguous(), h, scale, shift, mean, rstd, gamma, rowscale if ctx.has_rs else None, 1)
+        return dh if ctx.needs_input_grad[0] else None, dgamma, dbeta, None, None
 
 
 class ConvNetwork(nn.Module):
@@ -92,6 +177,50 @@ class ConvNetwork(nn.Module):
         self._fold_cache["mfma"] = (key, plan)
         return plan
 
+    def _train_hip_applies(self, x: torch.Tensor) -> bool:
+        """Training / autograd forward on the library's own kernels: every layer Conv2d(stride 2, k in 3/5/7, padding 0/1) over
+        channel counts eqa_conv_s2 takes + affine BatchNorm2d + exact GELU, the module in training mode (batch statistics), fp32 on
+        the device, the image needing no gradient, every activation below the kernels' 2 GiB addressing."""
+        from equiadapt_amd import ops
+
+        if not (x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.shape[0] > 1 and not x.requires_grad and self.training):
+            return False
+        mods = list(self.enc_network)
+        convs, bns, acts = mods[0::3], mods[1::3], mods[2::3]
+        bn1 = self.final_fc[0]
+        if any(not isinstance(a, nn.GELU) or a.approximate != "none" for a in acts) or not isinstance(bn1, nn.BatchNorm1d):
+            return False
+        if any(not bn.training or not bn.affine for bn in list(bns) + [bn1]) or bn1.num_features % 4:
+            return False
+        hw = tuple(x.shape[-2:])
+        worst = x.shape[0] * x.shape[1] * hw[0] * hw[1] * 4
+        for i, conv in enumerate(convs):
+            k, pad = conv.kernel_size[0], conv.padding[0]
+            if (conv.kernel_size[0] != conv.kernel_size[1] or conv.stride != (2, 2) or conv.padding[0] != conv.padding[1] or conv.groups != 1
+                    or conv.dilation != (1, 1) or conv.padding_mode != "zeros" or hw[0] + 2 * pad < k or hw[1] + 2 * pad < k
+                    or not ops.conv_s2_supported(conv.in_channels, conv.out_channels, k, pad, i == 0)
+                    or not ops.conv_s2_train_supported(conv.in_channels, conv.out_channels, k, pad, i == 0)):
+                return False
+            hw = ((hw[0] + 2 * pad - k) // 2 + 1, (hw[1] + 2 * pad - k) // 2 + 1)
+            worst = max(worst, x.shape[0] * conv.out_channels * hw[0] * hw[1] * 4)
+        return worst < 2 ** 31 - 64 and min(hw) > 0
+
+    def _forward_train_hip(self, x: torch.Tensor) -> torch.Tensor:
+        mods = list(self.enc_network)
+        h = x.contiguous()
+        for i, (conv, bn) in enumerate(zip(mods[0::3], mods[1::3])):
+            h = _ConvBnGeluFn.apply(h, conv.weight, conv.bias, bn.weight, bn.bias, bn, conv.kernel_size[0], conv.padding[0], i == 0)
+        # the reference flattens (C, H, W); the kernels' activations are (H, W, C): one small copy (B x out_dim floats)
+        h = h.permute(0, 3, 1, 2).reshape(h.shape[0], -1)
+        bn1, drop, lin = self.final_fc[0], self.final_fc[1], self.final_fc[3]
+        rowscale = None
+        if drop.training and drop.p > 0:
+            # Dropout1d on a 2-D input: torch reads (N, D) as an unbatched (C = N, L = D) signal and drops whole ROWS; the same
+            # bernoulli_ / div_ sequence as at::feature_dropout on a (1, N, 1) noise tensor
+            rowscale = torch.empty(1, h.shape[0], 1, dtype=h.dtype, device=h.device).bernoulli_(1 - drop.p).div_(1 - drop.p).view(-1)
+        z = _BnReluRowsFn.apply(h, bn1.weight, bn1.bias, bn1, rowscale)
+        return torch.nn.functional.linear(z, lin.weight, lin.bias)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.training and not torch.is_grad_enabled() and x.is_cuda:
             if x.dtype == torch.float32 and os.environ.get("EQA_CONVNET_MFMA", "1") != "0":
@@ -138,7 +267,11 @@ class ConvNetwork(nn.Module):
                     self._fold_cache["head"] = hit
                 return torch.nn.functional.linear(ops.affine_relu_rows(h.contiguous(), hit[1], hit[2]), lin.weight, lin.bias)
             return self.final_fc(h)
-        mode = os.environ.get("EQA_CONVNET_TRAIN_MODE", "cl_native")
+        mode = os.environ.get("EQA_CONVNET_TRAIN_MODE", "hip")
+        if mode == "hip" and self._train_hip_applies(x):
+            return self._forward_train_hip(x)
+        if mode == "hip":
+            mode = "cl_native"
         if x.is_cuda and x.dim() == 4 and mode != "plain":
             # training (or autograd on): the reference's modules, run channels-last (MIOpen's fp32 convolutions are NHWC kernels)
             # with the batch-norms taken by ATen's channels-last kernels instead of MIOpen's.  Measured on the reference tutorial's
@@ -149,17 +282,12 @@ class ConvNetwork(nn.Module):
             h = x.contiguous(memory_format=torch.channels_last) if mode.startswith("cl") else x
             for m in self.enc_network:
                 if isinstance(m, nn.BatchNorm2d) and mode.endswith("native"):
-                    # ATen's own channels-last batch-norm for THIS call (cudnn_enabled=False is an argument of the op): no
-                    # process-global backend flag is touched, so threaded replicas and torch.compile see nothing change
-                    # (the convolutions stay with MIOpen).  Same bookkeeping as nn.BatchNorm2d.forward.
-                    if m.training and m.track_running_stats and m.num_batches_tracked is not None:
-                        m.num_batches_tracked.add_(1)
-                    mom = 0.0 if m.momentum is None else m.momentum
-                    if m.training and m.track_running_stats and m.momentum is None:
-                        mom = 1.0 / float(m.num_batches_tracked)
-                    use_batch = m.training or (m.running_mean is None and m.running_var is None)
-                    h = torch.batch_norm(h, m.weight, m.bias, m.running_mean if (not m.training or m.track_running_stats) else None,
-                                         m.running_var if (not m.training or m.track_running_stats) else None, use_batch, mom, m.eps, False)
+                    # ATen's channels-last batch-norm instead of MIOpen's: on ROCm only the process-global backend flag selects it (the
+                    # op's own cudnn_enabled argument still lands in MIOpenBatchNorm*: measured, 41 k instead of 98 k img/s), so the
+                    # toggle is taken under a lock -- interleaved save / restore from threaded replicas cannot leave the backend
+                    # disabled for the process.  (Shapes eqa_conv_s2 takes do not come here: _forward_train_hip.)
+                    with _BN_FLAG_LOCK, torch.backends.cudnn.flags(enabled=False):      # (the convolutions stay with MIOpen)
+                        h = m(h)
                 else:
                     h = m(h)
             return self.final_fc(h.reshape(x.shape[0], -1))

@@ -519,6 +519,103 @@ def conv_s2(x: torch.Tensor, wp: torch.Tensor, bias: Optional[torch.Tensor], gel
     return y
 
 
+def pack_conv_s2_dgrad_weights(w: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, K, K) filters -> the operand order of eqa_conv_s2_dgrad: (K*K, Cout/16, Cin/16, 4 [kq], 16 [j], 4 [s]) holding
+    w[16 cc + 4 kq + s][16 n + j][u][v]."""
+    Cout, Cin, K, _ = w.shape
+    t = w.permute(2, 3, 0, 1).reshape(K * K, Cout // 16, 4, 4, Cin // 16, 16)      # tap, cc, kq, s, n, j
+    return t.permute(0, 1, 4, 2, 5, 3).contiguous()                                  # tap, cc, n, kq, j, s
+
+
+def conv_s2_train_supported(cin: int, cout: int, k: int, pad: int, planar: bool) -> bool:
+    lib = _lib.load()
+    return bool(lib.eqa_conv_s2_wgrad_supported(cin, cout, k, pad, int(planar))) and (planar or bool(lib.eqa_conv_s2_dgrad_supported(cin, cout, k, pad)))
+
+
+def conv_s2_wgrad(x: torch.Tensor, dz: torch.Tensor, k: int, pad: int, planar: bool) -> torch.Tensor:
+    """Filter gradient of eqa_conv_s2 (eqa_conv_s2_wgrad): x the layer's input (planar: (B,Cin,H,W); else (B,H,W,Cin)),
+    dz (B,OH,OW,Cout) -> (Cout,Cin,K,K)."""
+    lib = _lib.load()
+    x, dz = _need(x, "x"), _need(dz, "dz")
+    if planar:
+        B, cin, H, W = x.shape
+    else:
+        B, H, W, cin = x.shape
+    cout = dz.shape[-1]
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    ws = torch.empty((max(lib.eqa_conv_s2_wgrad_workspace_bytes(B, cin, H, W, cout, k, pad, int(planar)), 16) // 4,), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device), _timed("conv_s2_wgrad"):
+        st = lib.eqa_conv_s2_wgrad(x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, cin, H, W, cout, k, pad, int(planar), _stream())
+    _lib.check(st, "eqa_conv_s2_wgrad")
+    return dw
+
+
+def conv_s2_dgrad(dz: torch.Tensor, wd: torch.Tensor, in_hw: Tuple[int, int], cin: int, k: int, pad: int) -> torch.Tensor:
+    """Data gradient of eqa_conv_s2 for a channels-last layer (eqa_conv_s2_dgrad): dz (B,OH,OW,Cout), wd from
+    ``pack_conv_s2_dgrad_weights`` -> (B,H,W,Cin)."""
+    lib = _lib.load()
+    dz, wd = _need(dz, "dz"), _need(wd, "wd")
+    B, cout = dz.shape[0], dz.shape[-1]
+    dx = torch.empty((B, in_hw[0], in_hw[1], cin), dtype=torch.float32, device=dz.device)
+    with torch.cuda.device(dz.device), _timed("conv_s2_dgrad"):
+        st = lib.eqa_conv_s2_dgrad(dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, cin, in_hw[0], in_hw[1], cout, k, pad, _stream())
+    _lib.check(st, "eqa_conv_s2_dgrad")
+    return dx
+
+
+def bn_batch_stats(z: torch.Tensor):
+    """Per-channel batch mean and BIASED variance (fp64) of a channels-last (npix, C) view (eqa_bn_stats_nhwc: fp32 sums inside
+    blocks of 256 pixels, fp64 across them)."""
+    lib = _lib.load()
+    z = _need(z, "z")
+    npix, C = z.shape
+    part = torch.empty((max(lib.eqa_bn_partial_blocks(npix), 1), C, 2), dtype=torch.float64, device=z.device)
+    with torch.cuda.device(z.device), _timed("bn_stats"):
+        st = lib.eqa_bn_stats_nhwc(z.data_ptr(), part.data_ptr(), npix, C, _stream())
+    _lib.check(st, "eqa_bn_stats_nhwc")
+    sums = part.sum(0)
+    mean = sums[:, 0] / npix
+    var = (sums[:, 1] / npix - mean * mean).clamp_min(0.0)
+    return mean, var
+
+
+def bn_act_fwd(z: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rowscale: Optional[torch.Tensor], act: int) -> torch.Tensor:
+    """y = rowscale[p] * act(scale[c] z + shift[c]) on a channels-last (npix, C) view (eqa_bn_act_fwd); act 0 = GELU (erf), 1 = ReLU."""
+    lib = _lib.load()
+    z, scale, shift = _need(z, "z"), _need(scale, "scale"), _need(shift, "shift")
+    rowscale, p_rs = _opt(rowscale, "rowscale", torch.float32)
+    npix, C = z.shape
+    y = torch.empty_like(z)
+    with torch.cuda.device(z.device), _timed("bn_act_fwd"):
+        st = lib.eqa_bn_act_fwd(z.data_ptr(), scale.data_ptr(), shift.data_ptr(), p_rs, y.data_ptr(), npix, C, act, _stream())
+    _lib.check(st, "eqa_bn_act_fwd")
+    return y
+
+
+def bn_act_bwd(gy: torch.Tensor, z: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor,
+               gamma: torch.Tensor, rowscale: Optional[torch.Tensor], act: int):
+    """Backward of batch-norm (batch statistics) + activation on (npix, C): -> (dz, dgamma, dbeta) (eqa_bn_act_bwd_reduce / _apply)."""
+    lib = _lib.load()
+    gy, z = _need(gy, "gy"), _need(z, "z")
+    rowscale, p_rs = _opt(rowscale, "rowscale", torch.float32)
+    npix, C = z.shape
+    part = torch.empty((max(lib.eqa_bn_act_partial_blocks(npix), 1), C, 2), dtype=torch.float64, device=z.device)
+    with torch.cuda.device(z.device), _timed("bn_act_bwd_reduce"):
+        st = lib.eqa_bn_act_bwd_reduce(gy.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_rs,
+                                       part.data_ptr(), npix, C, act, _stream())
+    _lib.check(st, "eqa_bn_act_bwd_reduce")
+    sums = part.sum(0)                                          # (C, 2) fp64
+    dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
+    m = (sums / npix).float()
+    m1, m2, gscale = m[:, 0].contiguous(), m[:, 1].contiguous(), (gamma.detach() * rstd).contiguous()
+    dz = torch.empty_like(z)
+    with torch.cuda.device(z.device), _timed("bn_act_bwd_apply"):
+        st = lib.eqa_bn_act_bwd_apply(gy.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_rs,
+                                      gscale.data_ptr(), m1.data_ptr(), m2.data_ptr(), dz.data_ptr(), npix, C, act, _stream())
+    _lib.check(st, "eqa_bn_act_bwd_apply")
+    return dz, dgamma, dbeta
+
+
 def affine_relu_rows(h: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
     """relu(h * scale[d] + shift[d]) on (rows, D) (eqa_affine_relu_rows): eval-mode BatchNorm1d + ReLU in one pass."""
     lib = _lib.load()

@@ -243,6 +243,35 @@ int eqa_window_sums(const float* x, const float* scale, const float* shift, int 
 int eqa_conv_s2_supported(int Cin, int Cout, int K, int pad, int planar);
 int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, float* y, int B, int Cin, int H, int W, int Cout, int K,
                 int pad, int planar, void* stream);
+/* I10 in TRAINING (csrc/convnet_train.hip) -- what the framework's autograd ran through MIOpen / ATen for
+ * custom_nonequivariant_networks.py:44-80 (Conv2d stride 2 -> BatchNorm2d -> GELU per layer; head BatchNorm1d -> Dropout1d -> ReLU):
+ *   eqa_conv_s2_wgrad   dw:(Cout,Cin,K,K) = d/dW of eqa_conv_s2 given dz:(B,OH,OW,Cout) channels-last and the layer's input x (planar = 1:
+ *                       (B,Cin<=4,H,W); else (B,H,W,Cin) channels-last) -- torch.nn.grad.conv2d_weight.  Reduction over the output pixels on
+ *                       the matrix cores, partial sums per pixel run in `workspace` (eqa_conv_s2_wgrad_workspace_bytes), summed in run
+ *                       order: deterministic, no atomics.
+ *   eqa_conv_s2_dgrad   dx:(B,H,W,Cin) = d/dx (channels-last layers only: the image needs no gradient) given dz and
+ *                       wd:(K*K, Cout/16, Cin/16, 4, 16, 4) = w[16 cc + 4 kq + s][16 n + j][u][v] -- torch.nn.grad.conv2d_input.  Every
+ *                       element of dx is written (pixels no tap reaches get 0).
+ *   eqa_bn_act_fwd      y[p][c] = rowscale[p] * act(scale[c] z[p][c] + shift[c]) on (npix, C) channels-last, C % 4 == 0; act 0 = exact GELU
+ *                       (erf), 1 = ReLU; rowscale may be NULL (= 1).  scale / shift = the batch-norm folded with the batch statistics
+ *                       (eqa_bn_stats_nhwc).  For the head, rowscale = Dropout1d's per-row factor (0 or 1 / (1 - p)).
+ *   eqa_bn_act_bwd_reduce  partial:(eqa_bn_act_partial_blocks(npix), C, 2) fp64 = per-block sums of g and g * zhat, g = gy * rowscale *
+ *                       act'(scale z + shift), zhat = (z - mean) * rstd  (the two reductions of batch-norm's backward).
+ *   eqa_bn_act_bwd_apply   dz = gscale[c] * (g - m1[c] - zhat * m2[c]) with gscale = gamma * rstd, m1 = sum(g) / n, m2 = sum(g zhat) / n. */
+int eqa_conv_s2_wgrad_supported(int Cin, int Cout, int K, int pad, int planar);
+int64_t eqa_conv_s2_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int K, int pad, int planar);
+int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout, int K, int pad,
+                      int planar, void* stream);
+int eqa_conv_s2_dgrad_supported(int Cin, int Cout, int K, int pad);
+int eqa_conv_s2_dgrad(const float* dz, const float* wd, float* dx, int B, int Cin, int H, int W, int Cout, int K, int pad, void* stream);
+int eqa_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* rowscale, float* y, int64_t npix, int C, int act,
+                   void* stream);
+int64_t eqa_bn_act_partial_blocks(int64_t npix);
+int eqa_bn_act_bwd_reduce(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                          const float* rowscale, double* partial, int64_t npix, int C, int act, void* stream);
+int eqa_bn_act_bwd_apply(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
+                         const float* rowscale, const float* gscale, const float* m1, const float* m2, float* dz, int64_t npix, int C,
+                         int act, void* stream);
 /* Optimized canonicalizer, inference tail:
  *   eqa_affine_relu_rows           z:(rows,D) = relu(h * scale[d] + shift[d]): the eval-mode BatchNorm1d (folded to scale / shift) +
  *                                  ReLU in front of ConvNetwork's Linear head (custom_nonequivariant_networks.py:62-67); D % 4 == 0.
