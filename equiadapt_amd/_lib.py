@@ -138,6 +138,9 @@ SIGNATURES = {
     "eqa_conv_s2_dgrad": (_int, [_vp] * 3 + [_int] * 7 + [_vp]),
     "eqa_bn_act_fwd": (_int, [_vp] * 5 + [ctypes.c_int64, _int, _int, _vp]),
     "eqa_bn_act_partial_blocks": (ctypes.c_int64, [ctypes.c_int64]),
+    "eqa_bn_act_stats": (_int, [_vp, _vp, ctypes.c_int64, _int, _vp]),
+    "eqa_bn_act_finalize": (_int, [_vp, ctypes.c_int64, _int, _vp, _vp, ctypes.c_double, ctypes.c_double] + [_vp] * 6 + [_vp]),
+    "eqa_bn_act_bwd_finalize": (_int, [_vp, ctypes.c_int64, _int] + [_vp] * 7 + [_vp]),
     "eqa_bn_act_bwd_reduce": (_int, [_vp] * 8 + [ctypes.c_int64, _int, _int, _vp]),
     "eqa_bn_act_bwd_apply": (_int, [_vp] * 11 + [ctypes.c_int64, _int, _int, _vp]),
     "eqa_affine_relu_rows": (_int, [_vp, _vp, _vp, _vp, ctypes.c_int64, _int, _vp]),

@@ -52,6 +52,115 @@ __global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(const float* __res
   }
 }
 
+// partial[(blk * C + c) * 2 + {0, 1}] = sum, sum of squares of z over the block's pixels (bn_stats_nhwc_kernel of batchnorm.hip with the
+// block's pixel count a launch parameter: the head's (2048, 1152) matrix needs 8-pixel blocks to fill the chip, the encoder's maps 256)
+__global__ __launch_bounds__(kThreads) void bn_act_stats_kernel(const float* __restrict__ x, double* __restrict__ partial, size_t npix, int C,
+                                                               int pix_per_block) {
+  __shared__ float4 s_red[2][kThreads];
+  const int Q = C >> 2;
+  const int lanes = min(Q, kThreads);
+  const int rows = kThreads / lanes;
+  const int q0 = threadIdx.x % lanes, r0 = threadIdx.x / lanes;
+  const size_t p0 = (size_t)blockIdx.x * pix_per_block;
+  const size_t p1 = min(npix, p0 + pix_per_block);
+  for (int qb = 0; qb < Q; qb += lanes) {
+    const int q = qb + q0;
+    const bool has_q = q < Q;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
+    if (r0 < rows && has_q) {
+      for (size_t p = p0 + r0; p < p1; p += rows) {
+        const float4 v = reinterpret_cast<const float4*>(x)[p * Q + q];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+      }
+    }
+    __syncthreads();
+    s_red[0][threadIdx.x] = s;
+    s_red[1][threadIdx.x] = ss;
+    __syncthreads();
+    if (r0 == 0 && has_q) {
+      for (int r = 1; r < rows; ++r) {
+        const float4 a = s_red[0][r * lanes + q0], b = s_red[1][r * lanes + q0];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        ss.x += b.x; ss.y += b.y; ss.z += b.z; ss.w += b.w;
+      }
+      double* o = partial + ((size_t)blockIdx.x * C + 4 * q) * 2;
+      o[0] = s.x; o[1] = ss.x; o[2] = s.y; o[3] = ss.y; o[4] = s.z; o[5] = ss.z; o[6] = s.w; o[7] = ss.w;
+    }
+  }
+}
+
+// Sum of the per-block partials of 4 channels (block = 4 channels x 64 slices of the block index; slices combined in order: the
+// result does not depend on the launch) -> out[0..1] on the threads of slice 0.
+constexpr int kBnFinCh = 4, kBnFinSlices = kThreads / kBnFinCh;
+__device__ __forceinline__ void sum_partials(const double* __restrict__ partial, int nblk, int C, int c0, double (&out)[2],
+                                             double (*s_acc)[kBnFinCh][2]) {
+  const int cl = threadIdx.x & (kBnFinCh - 1), slice = threadIdx.x / kBnFinCh;
+  const int c = c0 + cl;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C)
+    for (int b = slice; b < nblk; b += kBnFinSlices) {
+      const double* p = partial + ((size_t)b * C + c) * 2;
+      a0 += p[0];
+      a1 += p[1];
+    }
+  s_acc[slice][cl][0] = a0;
+  s_acc[slice][cl][1] = a1;
+  __syncthreads();
+  out[0] = out[1] = 0.0;
+  if (slice == 0)
+    for (int s = 0; s < kBnFinSlices; ++s) {
+      out[0] += s_acc[s][cl][0];
+      out[1] += s_acc[s][cl][1];
+    }
+}
+
+// Forward finalize: batch mean / biased variance from the partial sums, folded with the affine parameters, and the module's running
+// statistics updated as nn.BatchNorm*d does (momentum < 0: cumulative average with the already incremented batch counter).
+__global__ __launch_bounds__(kThreads) void bn_act_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double npix,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta, double eps,
+                                                                  double momentum, float* __restrict__ running_mean,
+                                                                  float* __restrict__ running_var, float* __restrict__ scale,
+                                                                  float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ double s_acc[kBnFinSlices][kBnFinCh][2];
+  double s[2];
+  const int c0 = blockIdx.x * kBnFinCh;
+  sum_partials(partial, nblk, C, c0, s, s_acc);
+  const int c = c0 + (threadIdx.x & (kBnFinCh - 1));
+  if (threadIdx.x >= kBnFinCh || c >= C) return;
+  const double m = s[0] / npix;
+  const double var = fmax(s[1] / npix - m * m, 0.0);
+  const double r = 1.0 / sqrt(var + eps);
+  const double sc = (double)gamma[c] * r;
+  scale[c] = (float)sc;
+  shift[c] = (float)((double)beta[c] - m * sc);
+  mean[c] = (float)m;
+  rstd[c] = (float)r;
+  if (running_mean) {
+    const double unbiased = var * (npix / fmax(npix - 1.0, 1.0));
+    running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * m);
+    running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+  }
+}
+
+// Backward finalize: dgamma = sum(g zhat), dbeta = sum(g), and the three per-channel coefficients of eqa_bn_act_bwd_apply
+__global__ __launch_bounds__(kThreads) void bn_act_bwd_finalize_kernel(const double* __restrict__ partial, int nblk, int C, double npix,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                      float* __restrict__ gscale, float* __restrict__ m1, float* __restrict__ m2) {
+  __shared__ double s_acc[kBnFinSlices][kBnFinCh][2];
+  double s[2];
+  const int c0 = blockIdx.x * kBnFinCh;
+  sum_partials(partial, nblk, C, c0, s, s_acc);
+  const int c = c0 + (threadIdx.x & (kBnFinCh - 1));
+  if (threadIdx.x >= kBnFinCh || c >= C) return;
+  dbeta[c] = (float)s[0];
+  dgamma[c] = (float)s[1];
+  m1[c] = (float)(s[0] / npix);
+  m2[c] = (float)(s[1] / npix);
+  gscale[c] = gamma[c] * rstd[c];
+}
+
 // g = gy * rowscale * act'(scale z + shift);  partial[(blk * C + c) * 2 + {0, 1}] = sum of g, sum of g * zhat over the block's pixels
 template <int ACT>
 __global__ __launch_bounds__(kThreads) void bn_act_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ z,
@@ -155,9 +264,10 @@ __device__ __forceinline__ void pix_advance(PixPos& r, int step, int OH, int OW)
   }
 }
 
-// NHWC input, Cin = 16 CH.  x:(B,H,W,Cin), dz:(B,OH,OW,Cout).  grid (pixel runs, K filter rows, Cout / 16 channel chunks).
+// NHWC input, Cin = 16 CH.  x:(B,H,W,Cin), dz:(B,OH,OW,Cout).  grid (pixel runs, K / ROWS filter-row groups, Cout / 16 channel
+// chunks): a wave owns ROWS filter rows (all K where the K * K * CH accumulator tiles fit the register file: dz is then read once).
 // ws:(runs, K, K, Cout, Cin) partial filter gradients.
-template <int K, int CH, int PAD>
+template <int K, int CH, int PAD, int ROWS>
 __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                      float* __restrict__ ws, int Cout, int H, int W, int OH, int OW, long P,
                                                                      int pix_per_wave, unsigned x_bytes, unsigned dz_bytes) {
@@ -165,17 +275,19 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
   const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  const int u = blockIdx.y, n = blockIdx.z;
+  const int u0 = blockIdx.y * ROWS, n = blockIdx.z;
   const long p_begin = run * pix_per_wave;
   if (p_begin >= P) return;
   const long p_end = min(P, p_begin + pix_per_wave);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
-  f32x4 acc[K][CH];
+  f32x4 acc[ROWS][K][CH];
 #pragma unroll
-  for (int v = 0; v < K; ++v)
+  for (int ur = 0; ur < ROWS; ++ur)
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < K; ++v)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) acc[ur][v][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   // slot s of this lane = pixel p + 4 s + kq of the trip starting at p
   PixPos pos[4];
 #pragma unroll
@@ -187,36 +299,43 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
       const long ps = p + 4 * s + kq;
       const bool live = ps < p_end;
       const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
-      const int iy = 2 * pos[s].oy - PAD + u, ix0 = 2 * pos[s].ox - PAD;
-      const bool row_ok = live && (PAD == 0 || (iy >= 0 && iy < H));
-      const unsigned base = (unsigned)((((long)pos[s].b * H + iy) * W + ix0) * Cin + j) * 4u;
-      float b[K][CH];
+      const int iy0 = 2 * pos[s].oy - PAD + u0, ix0 = 2 * pos[s].ox - PAD;
+      const unsigned base0 = (unsigned)((((long)pos[s].b * H + iy0) * W + ix0) * Cin + j) * 4u;
 #pragma unroll
-      for (int v = 0; v < K; ++v) {
-        const bool ok = row_ok && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
+      for (int ur = 0; ur < ROWS; ++ur) {
+        const bool row_ok = live && (PAD == 0 || (iy0 + ur >= 0 && iy0 + ur < H));
+        float b[K][CH];
 #pragma unroll
-        for (int c = 0; c < CH; ++c)
-          b[v][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? base + (unsigned)(v * Cin + 16 * c) * 4u : kOob, 0, 0));
+        for (int v = 0; v < K; ++v) {
+          const bool ok = row_ok && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
+#pragma unroll
+          for (int c = 0; c < CH; ++c)
+            b[v][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? base0 + (unsigned)((ur * W + v) * Cin + 16 * c) * 4u : kOob, 0, 0));
+        }
+#pragma unroll
+        for (int v = 0; v < K; ++v)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) acc[ur][v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[v][c], acc[ur][v][c], 0, 0, 0);
       }
       pix_advance(pos[s], kWgIter, OH, OW);
-#pragma unroll
-      for (int v = 0; v < K; ++v)
-#pragma unroll
-        for (int c = 0; c < CH; ++c) acc[v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[v][c], acc[v][c], 0, 0, 0);
     }
   }
   // D[i = 4 kq + r][j]: co = 16 n + 4 kq + r, ci = 16 c + j
-  float* o = ws + (((size_t)run * K + u) * K) * (size_t)(Cout * Cin);
 #pragma unroll
-  for (int v = 0; v < K; ++v)
+  for (int ur = 0; ur < ROWS; ++ur) {
+    float* o = ws + (((size_t)run * K + u0 + ur) * K) * (size_t)(Cout * Cin);
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int v = 0; v < K; ++v)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[(size_t)v * (Cout * Cin) + (16 * n + 4 * kq + r) * Cin + 16 * c + j] = acc[v][c][r];
+      for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[(size_t)v * (Cout * Cin) + (16 * n + 4 * kq + r) * Cin + 16 * c + j] = acc[ur][v][c][r];
+  }
 }
 
 // planar input with Cin <= 4 (the first layer: NCHW views).  The 16 columns of a B tile are the (channel, filter column) pairs
-// jj = ci * K + v of filter row u (Cin * K <= 16 NJ); x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [u], Cout, 16 NJ [jj]).
+// jj = ci * K + v of one filter row (Cin * K <= 16 NJ); a wave owns all K filter rows, so dz -- the large operand of this layer -- is
+// read once.  x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [u], Cout, 16 NJ [jj]).  grid (pixel runs, 1, Cout / 16).
 template <int K, int NJ, int PAD>
 __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                        float* __restrict__ ws, int Cin, int Cout, int H, int W, int OH,
@@ -225,7 +344,7 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
   const int lane = threadIdx.x & 63;
   const int j = lane & 15, kq = lane >> 4;
   const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-  const int u = blockIdx.y, n = blockIdx.z;
+  const int n = blockIdx.z;
   const long p_begin = run * pix_per_wave;
   if (p_begin >= P) return;
   const long p_end = min(P, p_begin + pix_per_wave);
@@ -241,67 +360,92 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
     lci[t] = lhas[t] ? jj / K : 0;
     lv[t] = lhas[t] ? jj - lci[t] * K : 0;
   }
-  f32x4 acc[NJ];
+  f32x4 acc[K][NJ];
 #pragma unroll
-  for (int t = 0; t < NJ; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < K; ++u)
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   PixPos pos[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
 #pragma unroll 1
   for (long p = p_begin; p < p_end; p += kWgIter) {
-    float a[4], b[4][NJ];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const long ps = p + 4 * s + kq;
       const bool live = ps < p_end;
-      a[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
-      const int iy = 2 * pos[s].oy - PAD + u, ix0 = 2 * pos[s].ox - PAD;
-      const bool row_ok = live && (PAD == 0 || (iy >= 0 && iy < H));
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
+      const int iy0 = 2 * pos[s].oy - PAD, ix0 = 2 * pos[s].ox - PAD;
+      float b[K][NJ];
 #pragma unroll
       for (int t = 0; t < NJ; ++t) {
         const int ix = ix0 + lv[t];
-        const bool ok = row_ok && lhas[t] && (PAD == 0 || (ix >= 0 && ix < W));
-        const unsigned off = (unsigned)((((long)pos[s].b * Cin + lci[t]) * H + iy) * W + ix) * 4u;
-        b[s][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off : kOob, 0, 0));
+        const bool col_ok = live && lhas[t] && (PAD == 0 || (ix >= 0 && ix < W));
+        const unsigned off0 = (unsigned)((((long)pos[s].b * Cin + lci[t]) * H + iy0) * W + ix) * 4u;
+#pragma unroll
+        for (int u = 0; u < K; ++u) {
+          const bool ok = col_ok && (PAD == 0 || (iy0 + u >= 0 && iy0 + u < H));
+          b[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off0 + (unsigned)(u * W) * 4u : kOob, 0, 0));
+        }
       }
       pix_advance(pos[s], kWgIter, OH, OW);
+#pragma unroll
+      for (int u = 0; u < K; ++u)
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[u][t], acc[u][t], 0, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int t = 0; t < NJ; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s][t], acc[t], 0, 0, 0);
   }
-  float* o = ws + ((size_t)run * K + u) * (size_t)(Cout * 16 * NJ);
 #pragma unroll
-  for (int t = 0; t < NJ; ++t)
+  for (int u = 0; u < K; ++u) {
+    float* o = ws + ((size_t)run * K + u) * (size_t)(Cout * 16 * NJ);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[(16 * n + 4 * kq + r) * (16 * NJ) + 16 * t + j] = acc[t][r];
+    for (int t = 0; t < NJ; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(16 * n + 4 * kq + r) * (16 * NJ) + 16 * t + j] = acc[u][t][r];
+  }
 }
 
-// dw[co][ci][u][v] = sum over the runs of the partials, in run order (fp32 partials of <= pix_per_wave pixels each, fp64 across).
-// nhwc:   ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
+// dw[co][ci][u][v] = sum over the runs of the partials (fp32 partials of <= pix_per_wave pixels each, fp64 across): a block owns 64
+// consecutive elements of the per-run block, its four waves every fourth run; the four slices are combined in order -- the result
+// does not depend on the launch.   nhwc: ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
 __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int runs,
                                                                        int K, int Cout, int Cin, int JJ) {
+  __shared__ double s_acc[4][64];
   const int n_out = Cout * Cin * K * K;
-  const int e = blockIdx.x * kThreads + threadIdx.x;   // element of ws's per-run block (coalesced reads)
+  const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const size_t e = (size_t)blockIdx.x * 64 + el;   // element of ws's per-run block (coalesced reads)
   const size_t per_run = JJ ? (size_t)K * Cout * JJ : (size_t)n_out;
-  if ((size_t)e >= per_run) return;
+  double acc = 0.0;
+  if (e < per_run) {
+    int r = slice;
+    for (; r + 12 < runs; r += 16) {     // four independent loads in flight
+      const float a0 = ws[(size_t)r * per_run + e], a1 = ws[(size_t)(r + 4) * per_run + e], a2 = ws[(size_t)(r + 8) * per_run + e],
+                  a3 = ws[(size_t)(r + 12) * per_run + e];
+      acc += (double)a0;
+      acc += (double)a1;
+      acc += (double)a2;
+      acc += (double)a3;
+    }
+    for (; r < runs; r += 4) acc += (double)ws[(size_t)r * per_run + e];
+  }
+  s_acc[slice][el] = acc;
+  __syncthreads();
+  if (slice != 0 || e >= per_run) return;
+  acc = ((s_acc[0][el] + s_acc[1][el]) + s_acc[2][el]) + s_acc[3][el];
   int co, ci, u, v;
   if (JJ) {
-    const int jj = e % JJ;
-    co = (e / JJ) % Cout;
-    u = e / (JJ * Cout);
+    const int jj = (int)(e % JJ);
+    co = (int)((e / JJ) % Cout);
+    u = (int)(e / ((size_t)JJ * Cout));
     if (jj >= Cin * K) return;
     ci = jj / K;
     v = jj - ci * K;
   } else {
-    ci = e % Cin;
-    co = (e / Cin) % Cout;
-    v = (e / (Cin * Cout)) % K;
-    u = e / (Cin * Cout * K);
+    ci = (int)(e % Cin);
+    co = (int)((e / Cin) % Cout);
+    v = (int)((e / ((size_t)Cin * Cout)) % K);
+    u = (int)(e / ((size_t)Cin * Cout * K));
   }
-  double acc = 0.0;
-  for (int r = 0; r < runs; ++r) acc += (double)ws[(size_t)r * per_run + e];
   dw[((co * Cin + ci) * K + u) * K + v] = (float)acc;
 }
 
@@ -397,9 +541,10 @@ __global__ __launch_bounds__(kThreads) void conv_s2_dgrad_nhwc_kernel(const floa
 }
 
 int wgrad_pix_per_wave(long P) {
-  // enough runs to fill the chip (1024 SIMDs x K rows of blocks), runs of >= 256 pixels, a multiple of the trip
-  long per = (P + 2047) / 2048;
-  per = std::max(256L, std::min(4096L, per));
+  // ~4096 runs: a wave is a chain of dependent round trips (dword operand loads), so the chip wants several waves per SIMD; every run
+  // costs one partial filter in the workspace and one term of the (parallel) reduction.  Runs of >= 128 pixels, a multiple of the trip
+  long per = (P + 4095) / 4096;
+  per = std::max(128L, std::min(16384L, per));
   return (int)((per + kWgIter - 1) / kWgIter * kWgIter);
 }
 
@@ -422,7 +567,47 @@ int eqa_bn_act_fwd(const float* z, const float* scale, const float* shift, const
   return launch_status();
 }
 
-int64_t eqa_bn_act_partial_blocks(int64_t npix) { return npix <= 0 ? 0 : (npix + 255) / 256; }
+// pixels per block of the reductions: ~2048 blocks on the chip -- 8 pixels per block for the head's (2048, 1152) matrix, 1024 for the
+// first layer's 1.8 M pixels (fewer partials for the finalize kernels to sum)
+static int bn_act_pix_per_block(int64_t npix) {
+  int64_t per = (npix + 2047) / 2048;
+  per = std::max<int64_t>(8, std::min<int64_t>(1024, per));
+  return (int)((per + 7) / 8 * 8);
+}
+
+int64_t eqa_bn_act_partial_blocks(int64_t npix) {
+  if (npix <= 0) return 0;
+  const int per = bn_act_pix_per_block(npix);
+  return (npix + per - 1) / per;
+}
+
+int eqa_bn_act_stats(const float* z, double* partial, int64_t npix, int C, void* stream) {
+  if (npix < 0 || C <= 0) return EQA_ERR_INVALID_ARG;
+  if (npix == 0) return EQA_OK;
+  if (!z || !partial) return EQA_ERR_INVALID_ARG;
+  if ((C & 3) || ((uintptr_t)z & 15)) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(bn_act_stats_kernel, dim3((unsigned)eqa_bn_act_partial_blocks(npix)), dim3(kThreads), 0, (hipStream_t)stream, z, partial,
+                     (size_t)npix, C, bn_act_pix_per_block(npix));
+  return launch_status();
+}
+
+int eqa_bn_act_finalize(const double* partial, int64_t npix, int C, const float* gamma, const float* beta, double eps, double momentum,
+                        float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, void* stream) {
+  if (npix <= 0 || C <= 0 || !partial || !gamma || !beta || !scale || !shift || !mean || !rstd || (!running_mean) != (!running_var))
+    return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_act_finalize_kernel, dim3((C + kBnFinCh - 1) / kBnFinCh), dim3(kThreads), 0, (hipStream_t)stream, partial,
+                     (int)eqa_bn_act_partial_blocks(npix), C, (double)npix, gamma, beta, eps, momentum, running_mean, running_var, scale, shift,
+                     mean, rstd);
+  return launch_status();
+}
+
+int eqa_bn_act_bwd_finalize(const double* partial, int64_t npix, int C, const float* gamma, const float* rstd, float* dgamma, float* dbeta,
+                            float* gscale, float* m1, float* m2, void* stream) {
+  if (npix <= 0 || C <= 0 || !partial || !gamma || !rstd || !dgamma || !dbeta || !gscale || !m1 || !m2) return EQA_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(bn_act_bwd_finalize_kernel, dim3((C + kBnFinCh - 1) / kBnFinCh), dim3(kThreads), 0, (hipStream_t)stream, partial,
+                     (int)eqa_bn_act_partial_blocks(npix), C, (double)npix, gamma, rstd, dgamma, dbeta, gscale, m1, m2);
+  return launch_status();
+}
 
 int eqa_bn_act_bwd_reduce(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
                           const float* rowscale, double* partial, int64_t npix, int C, int act, void* stream) {
@@ -434,10 +619,10 @@ int eqa_bn_act_bwd_reduce(const float* gy, const float* z, const float* scale, c
   const unsigned blocks = (unsigned)eqa_bn_act_partial_blocks(npix);
   if (act == 0)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<0>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
-                       rowscale, partial, (size_t)npix, C, 256);
+                       rowscale, partial, (size_t)npix, C, bn_act_pix_per_block(npix));
   else
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<1>, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, gy, z, scale, shift, mean, rstd,
-                       rowscale, partial, (size_t)npix, C, 256);
+                       rowscale, partial, (size_t)npix, C, bn_act_pix_per_block(npix));
   return launch_status();
 }
 
@@ -490,13 +675,14 @@ int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspac
     return EQA_ERR_UNSUPPORTED;
   const int per = wgrad_pix_per_wave(P);
   const long runs = (P + per - 1) / per;
-  const dim3 grid((unsigned)((runs + kThreads / 64 - 1) / (kThreads / 64)), K, Cout / 16);
+  const unsigned gx = (unsigned)((runs + kThreads / 64 - 1) / (kThreads / 64));
   float* ws = static_cast<float*>(workspace);
   const unsigned xb = (unsigned)xbytes, gb = (unsigned)gbytes;
   int jj = 0;
   if (planar) {
     const int nj = Cin * K <= 16 ? 1 : 2;
     jj = 16 * nj;
+    const dim3 grid(gx, 1, Cout / 16);
 #define EQA_WGP(KK, NJ, PD)                                                                                                        \
   hipLaunchKernelGGL((conv_s2_wgrad_planar_kernel<KK, NJ, PD>), grid, dim3(kThreads), 0, st, x, dz, ws, Cin, Cout, H, W, OH, OW, P, per, xb, gb)
 #define EQA_WGP_K(KK)                                                                                                              \
@@ -509,22 +695,24 @@ int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspac
 #undef EQA_WGP
   } else {
     const int ch = Cin / 16;
-#define EQA_WGN(KK, CH, PD)                                                                                                        \
-  hipLaunchKernelGGL((conv_s2_wgrad_nhwc_kernel<KK, CH, PD>), grid, dim3(kThreads), 0, st, x, dz, ws, Cout, H, W, OH, OW, P, per, xb, gb)
-#define EQA_WGN_K(KK)                                                                                                              \
+    // all K filter rows in one wave where K * K * CH accumulator tiles (4 registers each) leave room: K = 3 always, K = 5 at 16 channels
+#define EQA_WGN(KK, CH, PD, RW)                                                                                                    \
+  hipLaunchKernelGGL((conv_s2_wgrad_nhwc_kernel<KK, CH, PD, RW>), dim3(gx, KK / RW, Cout / 16), dim3(kThreads), 0, st, x, dz, ws, Cout, H, W, \
+                     OH, OW, P, per, xb, gb)
+#define EQA_WGN_K(KK, R1, R2, R4)                                                                                                  \
   do {                                                                                                                             \
-    if (ch == 1) { if (pad) EQA_WGN(KK, 1, 1); else EQA_WGN(KK, 1, 0); }                                                          \
-    else if (ch == 2) { if (pad) EQA_WGN(KK, 2, 1); else EQA_WGN(KK, 2, 0); }                                                     \
-    else { if (pad) EQA_WGN(KK, 4, 1); else EQA_WGN(KK, 4, 0); }                                                                  \
+    if (ch == 1) { if (pad) EQA_WGN(KK, 1, 1, R1); else EQA_WGN(KK, 1, 0, R1); }                                                  \
+    else if (ch == 2) { if (pad) EQA_WGN(KK, 2, 1, R2); else EQA_WGN(KK, 2, 0, R2); }                                             \
+    else { if (pad) EQA_WGN(KK, 4, 1, R4); else EQA_WGN(KK, 4, 0, R4); }                                                          \
   } while (0)
-    if (K == 7) EQA_WGN_K(7); else if (K == 5) EQA_WGN_K(5); else EQA_WGN_K(3);
+    if (K == 7) EQA_WGN_K(7, 1, 1, 1); else if (K == 5) EQA_WGN_K(5, 5, 1, 1); else EQA_WGN_K(3, 3, 3, 3);
 #undef EQA_WGN_K
 #undef EQA_WGN
   }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   const size_t per_run = planar ? (size_t)K * Cout * jj : (size_t)K * K * Cout * Cin;
-  hipLaunchKernelGGL(conv_s2_wgrad_reduce_kernel, dim3((unsigned)((per_run + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, ws, dw,
-                     (int)runs, K, Cout, Cin, jj);
+  hipLaunchKernelGGL(conv_s2_wgrad_reduce_kernel, dim3((unsigned)((per_run + 63) / 64)), dim3(kThreads), 0, st, ws, dw, (int)runs, K, Cout,
+                     Cin, jj);
   return launch_status();
 }
 

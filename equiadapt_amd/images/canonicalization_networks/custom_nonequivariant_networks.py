@@ -15,21 +15,6 @@ from torch import nn
 _BN_FLAG_LOCK = threading.Lock()
 
 
-def _fold_batch_stats(z2d: torch.Tensor, bn: nn.modules.batchnorm._BatchNorm):
-    """Batch statistics of a channels-last (npix, C) view folded with the module's affine parameters, and the module's running
-    statistics updated as nn.BatchNorm*d does in a training-mode forward -> (scale, shift, mean, rstd) fp32."""
-    from equiadapt_amd import ops
-    from equiadapt_amd.common.utils import update_running_stats
-
-    n = z2d.shape[0]
-    mean64, var64 = ops.bn_batch_stats(z2d)
-    rstd64 = torch.rsqrt(var64 + bn.eps)
-    scale64 = bn.weight.detach().double() * rstd64
-    shift64 = bn.bias.detach().double() - mean64 * scale64
-    update_running_stats(bn, mean64, var64 * (n / max(n - 1, 1)))
-    return scale64.float().contiguous(), shift64.float().contiguous(), mean64.float().contiguous(), rstd64.float().contiguous()
-
-
 class _ConvBnGeluFn(torch.autograd.Function):
     """One encoder layer in training, y = GELU(BatchNorm2d(conv_s2(x) + b)) with batch statistics, on the library's own kernels
     (reference: custom_nonequivariant_networks.py:44-57).  Forward: eqa_conv_s2 -> eqa_bn_stats_nhwc -> eqa_bn_act_fwd; backward:
@@ -45,7 +30,7 @@ class _ConvBnGeluFn(torch.autograd.Function):
         cout = w.shape[0]
         z = ops.conv_s2(x, ops.pack_conv_s2_weights(w.detach(), planar), None if b is None else b.detach(), False, cout, k, pad, planar)
         z2 = z.view(-1, cout)
-        scale, shift, mean, rstd = _fold_batch_stats(z2, bn)
+        scale, shift, mean, rstd = ops.bn_fold_batch_stats(z2, bn)
         y = ops.bn_act_fwd(z2, scale, shift, None, 0).view(z.shape)
         ctx.save_for_backward(x, w, z, scale, shift, mean, rstd, gamma)
         ctx.geom = (k, pad, planar, b is not None)
@@ -80,7 +65,7 @@ class _BnReluRowsFn(torch.autograd.Function):
     def forward(ctx, h, gamma, beta, bn, rowscale):
         from equiadapt_amd import ops
 
-        scale, shift, mean, rstd = _fold_batch_stats(h, bn)
+        scale, shift, mean, rstd = ops.bn_fold_batch_stats(h, bn)
         y = ops.bn_act_fwd(h, scale, shift, rowscale, 1)
         ctx.save_for_backward(h, scale, shift, mean, rstd, gamma, rowscale if rowscale is not None else torch.empty(0))
         ctx.has_rs = rowscale is not None

@@ -563,20 +563,51 @@ def conv_s2_dgrad(dz: torch.Tensor, wd: torch.Tensor, in_hw: Tuple[int, int], ci
     return dx
 
 
+def _bn_act_partials(z: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    npix, C = z.shape
+    part = torch.empty((max(lib.eqa_bn_act_partial_blocks(npix), 1), C, 2), dtype=torch.float64, device=z.device)
+    with torch.cuda.device(z.device), _timed("bn_act_stats"):
+        st = lib.eqa_bn_act_stats(z.data_ptr(), part.data_ptr(), npix, C, _stream())
+    _lib.check(st, "eqa_bn_act_stats")
+    return part
+
+
 def bn_batch_stats(z: torch.Tensor):
-    """Per-channel batch mean and BIASED variance (fp64) of a channels-last (npix, C) view (eqa_bn_stats_nhwc: fp32 sums inside
-    blocks of 256 pixels, fp64 across them)."""
+    """Per-channel batch mean and BIASED variance (fp64) of a channels-last (npix, C) view (eqa_bn_act_stats: fp32 sums inside
+    blocks of <= 256 pixels, fp64 across them)."""
+    z = _need(z, "z")
+    sums = _bn_act_partials(z).sum(0)
+    mean = sums[:, 0] / z.shape[0]
+    var = (sums[:, 1] / z.shape[0] - mean * mean).clamp_min(0.0)
+    return mean, var
+
+
+def bn_fold_batch_stats(z: torch.Tensor, bn: torch.nn.modules.batchnorm._BatchNorm):
+    """Batch statistics of a channels-last (npix, C) view folded with the module's affine parameters, the module's running
+    statistics updated as a training-mode forward of nn.BatchNorm*d does -- eqa_bn_act_stats + ONE eqa_bn_act_finalize launch
+    (the same through torch: ~25 element-wise launches on C-sized tensors) -> (scale, shift, mean, rstd) fp32."""
+    from equiadapt_amd.common.utils import mark_written
+
     lib = _lib.load()
     z = _need(z, "z")
     npix, C = z.shape
-    part = torch.empty((max(lib.eqa_bn_partial_blocks(npix), 1), C, 2), dtype=torch.float64, device=z.device)
-    with torch.cuda.device(z.device), _timed("bn_stats"):
-        st = lib.eqa_bn_stats_nhwc(z.data_ptr(), part.data_ptr(), npix, C, _stream())
-    _lib.check(st, "eqa_bn_stats_nhwc")
-    sums = part.sum(0)
-    mean = sums[:, 0] / npix
-    var = (sums[:, 1] / npix - mean * mean).clamp_min(0.0)
-    return mean, var
+    part = _bn_act_partials(z)
+    out = torch.empty((4, C), dtype=torch.float32, device=z.device)
+    track = bn.track_running_stats and bn.running_mean is not None
+    momentum = 0.0
+    if track:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+    with torch.cuda.device(z.device):
+        st = lib.eqa_bn_act_finalize(part.data_ptr(), npix, C, bn.weight.data_ptr(), bn.bias.data_ptr(), float(bn.eps), float(momentum),
+                                     bn.running_mean.data_ptr() if track else None, bn.running_var.data_ptr() if track else None,
+                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), _stream())
+    _lib.check(st, "eqa_bn_act_finalize")
+    if track:
+        mark_written(bn.running_mean, bn.running_var)
+    return out[0], out[1], out[2], out[3]
 
 
 def bn_act_fwd(z: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, rowscale: Optional[torch.Tensor], act: int) -> torch.Tensor:
@@ -604,10 +635,12 @@ def bn_act_bwd(gy: torch.Tensor, z: torch.Tensor, scale: torch.Tensor, shift: to
         st = lib.eqa_bn_act_bwd_reduce(gy.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_rs,
                                        part.data_ptr(), npix, C, act, _stream())
     _lib.check(st, "eqa_bn_act_bwd_reduce")
-    sums = part.sum(0)                                          # (C, 2) fp64
-    dbeta, dgamma = sums[:, 0].float(), sums[:, 1].float()
-    m = (sums / npix).float()
-    m1, m2, gscale = m[:, 0].contiguous(), m[:, 1].contiguous(), (gamma.detach() * rstd).contiguous()
+    coef = torch.empty((5, C), dtype=torch.float32, device=z.device)          # dgamma, dbeta, gscale, m1, m2
+    with torch.cuda.device(z.device):
+        st = lib.eqa_bn_act_bwd_finalize(part.data_ptr(), npix, C, gamma.data_ptr(), rstd.data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                                         coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), _stream())
+    _lib.check(st, "eqa_bn_act_bwd_finalize")
+    dgamma, dbeta, gscale, m1, m2 = coef[0], coef[1], coef[2], coef[3], coef[4]
     dz = torch.empty_like(z)
     with torch.cuda.device(z.device), _timed("bn_act_bwd_apply"):
         st = lib.eqa_bn_act_bwd_apply(gy.data_ptr(), z.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_rs,

@@ -255,9 +255,16 @@ int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, fl
  *   eqa_bn_act_fwd      y[p][c] = rowscale[p] * act(scale[c] z[p][c] + shift[c]) on (npix, C) channels-last, C % 4 == 0; act 0 = exact GELU
  *                       (erf), 1 = ReLU; rowscale may be NULL (= 1).  scale / shift = the batch-norm folded with the batch statistics
  *                       (eqa_bn_stats_nhwc).  For the head, rowscale = Dropout1d's per-row factor (0 or 1 / (1 - p)).
+ *   eqa_bn_act_stats    partial:(eqa_bn_act_partial_blocks(npix), C, 2) fp64 = per-block sum and sum of squares of z (eqa_bn_stats_nhwc with
+ *                       the block's pixel count chosen per launch: the head's (rows, D) matrix has few "pixels" and many channels).
+ *   eqa_bn_act_finalize one launch behind it: batch mean / biased variance (fp64) -> mean, rstd = 1 / sqrt(var + eps), scale = gamma * rstd,
+ *                       shift = beta - mean * scale (fp32), and running_mean / running_var updated in place as nn.BatchNorm*d does
+ *                       (momentum; unbiased variance; both NULL: no running statistics).
  *   eqa_bn_act_bwd_reduce  partial:(eqa_bn_act_partial_blocks(npix), C, 2) fp64 = per-block sums of g and g * zhat, g = gy * rowscale *
  *                       act'(scale z + shift), zhat = (z - mean) * rstd  (the two reductions of batch-norm's backward).
- *   eqa_bn_act_bwd_apply   dz = gscale[c] * (g - m1[c] - zhat * m2[c]) with gscale = gamma * rstd, m1 = sum(g) / n, m2 = sum(g zhat) / n. */
+ *   eqa_bn_act_bwd_finalize  the partials summed in block order -> dgamma = sum(g zhat), dbeta = sum(g), gscale = gamma * rstd,
+ *                       m1 = sum(g) / n, m2 = sum(g zhat) / n.
+ *   eqa_bn_act_bwd_apply   dz = gscale[c] * (g - m1[c] - zhat * m2[c]). */
 int eqa_conv_s2_wgrad_supported(int Cin, int Cout, int K, int pad, int planar);
 int64_t eqa_conv_s2_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout, int K, int pad, int planar);
 int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout, int K, int pad,
@@ -267,6 +274,11 @@ int eqa_conv_s2_dgrad(const float* dz, const float* wd, float* dx, int B, int Ci
 int eqa_bn_act_fwd(const float* z, const float* scale, const float* shift, const float* rowscale, float* y, int64_t npix, int C, int act,
                    void* stream);
 int64_t eqa_bn_act_partial_blocks(int64_t npix);
+int eqa_bn_act_stats(const float* z, double* partial, int64_t npix, int C, void* stream);
+int eqa_bn_act_finalize(const double* partial, int64_t npix, int C, const float* gamma, const float* beta, double eps, double momentum,
+                        float* running_mean, float* running_var, float* scale, float* shift, float* mean, float* rstd, void* stream);
+int eqa_bn_act_bwd_finalize(const double* partial, int64_t npix, int C, const float* gamma, const float* rstd, float* dgamma, float* dbeta,
+                            float* gscale, float* m1, float* m2, void* stream);
 int eqa_bn_act_bwd_reduce(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,
                           const float* rowscale, double* partial, int64_t npix, int C, int act, void* stream);
 int eqa_bn_act_bwd_apply(const float* gy, const float* z, const float* scale, const float* shift, const float* mean, const float* rstd,

@@ -25,6 +25,8 @@ CASES = [  # (B, Cin, H, W, Cout, K, pad, planar)
     (5, 3, 64, 64, 16, 5, 0, True), (3, 3, 33, 41, 32, 7, 1, True), (4, 1, 20, 20, 16, 3, 0, True), (2, 4, 31, 29, 32, 7, 0, True),
     (5, 16, 30, 30, 16, 5, 0, False), (3, 16, 13, 13, 32, 5, 1, False), (2, 32, 28, 27, 32, 7, 1, False), (3, 32, 17, 19, 64, 3, 0, False),
     (2, 64, 12, 12, 64, 5, 1, False), (7, 16, 61, 61, 16, 7, 0, False),
+    (32, 1, 60, 60, 16, 3, 0, True), (32, 16, 29, 29, 16, 3, 0, False), (16, 16, 99, 99, 16, 3, 0, False), (16, 16, 49, 49, 32, 3, 1, False),
+    (16, 32, 5, 5, 64, 3, 1, False), (16, 32, 12, 12, 32, 3, 0, False),
 ]
 
 
@@ -92,49 +94,81 @@ def test_bn_act_forward_and_backward_match_autograd(dev, act, npix, C, rows):
 
 
 @pytest.mark.parametrize("in_shape,oc,k,L,B", [((3, 64, 64), 16, 5, 3, 48), ((3, 128, 128), 16, 7, 3, 12), ((1, 60, 60), 16, 3, 2, 32), ((3, 200, 200), 16, 3, 6, 16)])
-def test_convnetwork_training_step_on_own_kernels_matches_the_framework_path(dev, in_shape, oc, k, L, B, monkeypatch):
-    """The same ConvNetwork, the same batch, one training step two ways: the library's kernels (EQA_CONVNET_TRAIN_MODE=hip, default)
-    and the framework's modules as constructed (=plain, MIOpen + ATen autograd).  Output, running statistics after the step and
-    every parameter gradient agree to fp32 convolution rounding; Dropout1d is active and draws the same per-row mask."""
+def test_convnetwork_training_step_on_own_kernels_against_fp64(dev, in_shape, oc, k, L, B, monkeypatch):
+    """One training step of the same ConvNetwork on the same batch three ways: the library's kernels (EQA_CONVNET_TRAIN_MODE=hip, the
+    default), the framework's modules on the device (=plain: MIOpen + ATen autograd, fp32) and the framework's modules in fp64 on
+    the CPU (the truth).  Output, running statistics and every parameter gradient of the library path are within fp32 rounding of the
+    truth and no further from it than 1.5 x the framework's own fp32 path (+ 2e-4 of the gradient's scale).  Dropout1d off here (its
+    mask is the device generator's); the next test covers it."""
     import copy
 
     import equiadapt_amd as ea
     from equiadapt_amd import ops
 
     torch.manual_seed(5)
-    net = ea.ConvNetwork(in_shape, oc, k, L, 32).to(dev).train()
+    net = ea.ConvNetwork(in_shape, oc, k, L, 32)
     for m in net.modules():
         if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
             m.weight.data.uniform_(0.5, 1.5)
             m.bias.data.normal_(0, 0.2)
+    net.final_fc[1].p = 0.0
+    truth = copy.deepcopy(net).double().train()
+    net = net.to(dev).train()
     ref = copy.deepcopy(net)
-    x = torch.randn(B, *in_shape, generator=torch.Generator().manual_seed(6)).to(dev)
-    up = torch.randn(B, 32, generator=torch.Generator().manual_seed(7)).to(dev)
-    assert net._train_hip_applies(x)
+    x = torch.randn(B, *in_shape, generator=torch.Generator().manual_seed(6))
+    up = torch.randn(B, 32, generator=torch.Generator().manual_seed(7))
+    t_out = truth(x.double())
+    (t_out * up.double()).sum().backward()
+    xd, upd = x.to(dev), up.to(dev)
+    assert net._train_hip_applies(xd)
     timer = ops.KernelTimer()
-    torch.manual_seed(11)
-    torch.cuda.manual_seed(11)
     with timer:
-        out = net(x)
-        (out * up).sum().backward()
+        out = net(xd)
+        (out * upd).sum().backward()
     names = timer.summary()
-    assert {"conv_s2", "conv_s2_wgrad", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"} <= set(names), names
+    assert {"conv_s2", "conv_s2_wgrad", "bn_act_stats", "bn_act_fwd", "bn_act_bwd_reduce", "bn_act_bwd_apply"} <= set(names), names
     assert ("conv_s2_dgrad" in names) == (L > 1)
     monkeypatch.setenv("EQA_CONVNET_TRAIN_MODE", "plain")
-    torch.manual_seed(11)
+    want = ref(xd)
+    (want * upd).sum().backward()
+    scale = t_out.abs().max().item()
+    e_hip, e_fw = (out.cpu().double() - t_out).abs().max().item() / scale, (want.cpu().double() - t_out).abs().max().item() / scale
+    assert e_hip <= max(1.5 * e_fw, 2e-5), (e_hip, e_fw)
+    report = {}
+    for (n, p), (_, q), (_, t) in zip(net.named_parameters(), ref.named_parameters(), truth.named_parameters()):
+        if n.startswith("enc_network.") and n.endswith(".bias") and int(n.split(".")[1]) % 3 == 0:
+            # a conv bias behind batch statistics: the loss does not depend on it.  Exactly zero here; the fp64 evaluation holds 1e-16-size
+            # noise, the framework's fp32 path up to a few % of the layer's weight-gradient scale (the rounding of a sum that cancels)
+            assert p.grad.abs().max().item() == 0.0
+            assert t.grad.abs().max().item() <= 1e-9 * max(dict(truth.named_parameters())[n[:-4] + "weight"].grad.abs().max().item(), 1.0)
+            continue
+        gs = t.grad.abs().max().item() + 1e-12
+        report[n] = ((p.grad.cpu().double() - t.grad).abs().max().item() / gs, (q.grad.cpu().double() - t.grad).abs().max().item() / gs)
+    bad = {n: (f"{a:.1e}", f"{b:.1e}") for n, (a, b) in report.items() if a > 1.5 * b + 2e-4}
+    assert not bad, bad
+    for (n, a), (_, t) in zip(net.named_buffers(), truth.named_buffers()):
+        assert torch.allclose(a.cpu().double(), t.double(), atol=1e-5, rtol=1e-4), n
+
+
+def test_convnetwork_training_head_dropout_drops_the_rows_the_framework_drops(dev, monkeypatch):
+    """Dropout1d(0.5) on the head's 2-D input drops whole ROWS (torch reads (N, D) as an unbatched (C, L) signal); the library path
+    draws the same mask from the device generator as the framework's module (same bernoulli_ / div_ on a (1, N, 1) tensor)."""
+    import copy
+
+    import equiadapt_amd as ea
+
+    torch.manual_seed(5)
+    net = ea.ConvNetwork((3, 64, 64), 16, 5, 3, 32).to(dev).train()
+    ref = copy.deepcopy(net)
+    x = torch.randn(64, 3, 64, 64, generator=torch.Generator().manual_seed(6)).to(dev)
+    torch.cuda.manual_seed(11)
+    out = net(x)
+    monkeypatch.setenv("EQA_CONVNET_TRAIN_MODE", "plain")
     torch.cuda.manual_seed(11)
     want = ref(x)
-    (want * up).sum().backward()
-    scale = want.abs().max().item()
-    assert (out - want).abs().max().item() <= 2e-4 * scale, (out - want).abs().max().item()
-    assert (out == 0).all(dim=1).sum().item() == (want == 0).all(dim=1).sum().item()      # the same rows dropped
-    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
-        if n.startswith("enc_network.") and n.endswith(".bias") and int(n.split(".")[1]) % 3 == 0:
-            assert p.grad.abs().max().item() == 0.0                      # a conv bias behind batch statistics: exactly zero here
-            wn = dict(ref.named_parameters())[n[:-4] + "weight"].grad.abs().max().item()
-            assert q.grad.abs().max().item() <= 1e-3 * wn + 1e-5         # ... rounding noise of a sum that is zero there
-            continue
-        gs = q.grad.abs().max().item()
-        assert (p.grad - q.grad).abs().max().item() <= 2e-3 * gs + 1e-6, (n, (p.grad - q.grad).abs().max().item(), gs)
-    for (n, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
-        assert torch.allclose(a.float(), b.float(), atol=1e-5, rtol=1e-4), n
+    dropped = (want == ref.final_fc[3].bias).all(dim=1)            # a dropped row leaves the Linear layer's bias
+    assert 8 <= int(dropped.sum()) <= 56
+    assert torch.equal((out == net.final_fc[3].bias).all(dim=1), dropped)
+    assert (out - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+    (out.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
