@@ -1,5 +1,5 @@
 // libeqa_hip.so, part 10 -- the channel contraction of the overlap-save FFT convolution (I2a) as a hand-written batched
-// COMPLEX GEMM on the fp32 matrix cores, 3-multiplication form.  C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+// COMPLEX GEMM on the fp32 matrix cores, 3-multiplication form.  C ABI: include/eqa_hip.h.  Design notes: HISTORY.md section 3.4.
 //
 // Per stored frequency f:  Mo[f] (M x Cout, complex) = V[f] (M x Cin, complex) . B[f] (Cin x Cout, complex).  Through the GEMM
 // library this ran as a real [M x 2Cin].[2Cin x 2Cout] product -- 4 real multiplies per complex one -- at 135-138 TFLOP/s, i.e.

@@ -5,7 +5,7 @@
 // and the product of two operands is the sum of the nine products of their pieces, each of which the matrix core forms exactly
 // (8 x 8 significant bits) and accumulates in fp32 -- the same "exact products, fp32 accumulation" contract as
 // v_mfma_f32_32x32x2_f32, in a different summation order.  v_mfma_f32_32x32x16_bf16 retires 16 k per 32 cycles where the fp32
-// form retires 2 per 64: nine piece products cost 288 cycles per 16 k against 512.  C ABI: include/eqa_hip.h; DESIGN.md 3.8.
+// form retires 2 per 64: nine piece products cost 288 cycles per 16 k against 512.  C ABI: include/eqa_hip.h; HISTORY.md 3.8.
 //
 // TERMS = 9: all piece products (the default when this path is selected).  TERMS = 6: the three products of relative size
 // <= 2^-24 (p2.p3, p3.p2, p3.p3) are left out -- an error of at most 2^-23 |a||b| per product, the size of the rounding a single

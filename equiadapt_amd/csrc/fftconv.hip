@@ -1,5 +1,5 @@
 // libeqa_hip.so, part 8 -- 5x5 stride-1 group convolutions in inference as an overlap-save FFT convolution (I2a).
-// C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+// C ABI: include/eqa_hip.h.  Design notes: HISTORY.md section 3.4.
 //
 // Winograd F(4x4,5x5) needs 4 multiplies per output and a 4x expansion of the activations (V, M: 8.1 GB each at the
 // headline shape); its library GEMM runs at the clock-limited fp32 roofline, so only fewer multiplies help.  A 48x48

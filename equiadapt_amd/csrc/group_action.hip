@@ -1,7 +1,7 @@
 // libeqa_hip.so, part 1 of 5 -- the group action on images: fused pad / rotate / flip / crop resampling (I5, I7, I8), its
 // backward, the nearest-neighbour action on masks and images (I6, GroupInference) and the crop + antialiased resize (I1).
 // HBM-bound gathers: coalesced global access, LDS-staged source tiles fed by global->LDS DMA, XCD-aware block->image
-// mapping (each XCD's private L2 sees whole images).  C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.1.
+// mapping (each XCD's private L2 sees whole images).  C ABI: include/eqa_hip.h.  Design notes: HISTORY.md section 3.1.
 #include "eqa_common.hpp"
 
 namespace {
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(kThreads) void group_action_bwd_kernel(const Action
 // A source pixel s receives g[o] * w(o, s) from the output pixels o whose sample point p(o) lies within one pixel of s;
 // p is affine in o, so the candidates are the integer points of A^-1(s + (-1,1)^2): at most 3 x 3 for a rotation, 4 x 4
 // slots here.  Each candidate's weight is recomputed exactly as the forward computes it (floor, fractional parts).
-// Measured against the atomic scatter: 3.4 ms -> see DESIGN.md for 256 x 3 x 224 x 224.
+// Measured against the atomic scatter: 3.4 ms -> see HISTORY.md for 256 x 3 x 224 x 224.
 template <bool MAPPED>
 __global__ __launch_bounds__(kThreads) void group_action_bwd_gather_kernel(const ActionArgs a) {
   __shared__ int s_inv[kMaxMapG];

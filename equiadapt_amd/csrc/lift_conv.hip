@@ -1,5 +1,5 @@
 // libeqa_hip.so, part 4 of 5 -- the lifting convolution (RGB -> regular fields) as an implicit GEMM on the fp32 MFMA (I2a).
-// C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+// C ABI: include/eqa_hip.h.  Design notes: HISTORY.md section 3.4.
 #include "eqa_common.hpp"
 
 namespace {

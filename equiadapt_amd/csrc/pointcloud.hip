@@ -1,5 +1,5 @@
 // libeqa_hip.so, part 5 of 5 -- point clouds and n-body: fused kNN + VNSmall forward (P1, P2), Gram-Schmidt (P3), SO(3) action
-// (P4), modified Gram-Schmidt and the rigid action on rows (n-body E(3)).  C ABI: include/eqa_hip.h.  DESIGN.md section 3.3, 3.5.
+// (P4), modified Gram-Schmidt and the rigid action on rows (n-body E(3)).  C ABI: include/eqa_hip.h.  HISTORY.md section 3.3, 3.5.
 #include "eqa_common.hpp"
 #include "vn_common.hpp"
 

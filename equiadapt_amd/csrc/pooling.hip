@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kThreads) void window_sums_nhwc_segment_kernel(cons
 // part: (B, nseg, C, nval) -> out (B, C, k, k) fp64.  Block = one image x 32 channels.  For a fixed (image, segment) the
 // block's 32 channels x nval values are ONE contiguous run of part, so thread t owns element t of that run (channel t / nval,
 // value t % nval) and walks the segment axis: every load instruction is a contiguous row (the first version gave each
-// thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see DESIGN.md).  Fixed order, deterministic.
+// thread a whole channel, 36-byte lane stride: 0.26 ms for 207 MB; this one: see HISTORY.md).  Fixed order, deterministic.
 // Then one thread per channel assembles the k*k window sums from the totals and the 2(k-1) border-row segments.
 constexpr int kFinThreads = 320;   // k = 5: a block's run is 32 channels x 9 values = 288 elements -- one trip of 320 threads, not two of 256
 

@@ -1,5 +1,5 @@
 // libeqa_hip.so, part 3 of 5 -- Winograd F(2x2,5x5) / F(4x4,5x5) input and output transforms for the 5x5 group
-// convolutions (I2a).  C ABI: include/eqa_hip.h.  Design notes: DESIGN.md section 3.4.
+// convolutions (I2a).  C ABI: include/eqa_hip.h.  Design notes: HISTORY.md section 3.4.
 #include "eqa_common.hpp"
 
 namespace {

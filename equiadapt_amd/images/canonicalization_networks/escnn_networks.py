@@ -609,7 +609,7 @@ class ESCNNEquivariantNetwork(nn.Module):
         """Same layers as ``self.eqv_network`` + group pooling, with autograd, channels-last: 5x5 regular->regular
         convolutions through Winograd (``winograd.Conv5x5Function``: forward, d/dx and d/dfilters on the Winograd kernels),
         the last convolution + group mean as window sums + GEMV (``WindowSumsFunction``), batch-norm / ReLU / dropout as
-        element-wise passes.  Measured on the headline net, B = 256: 353 ms per step through MIOpen -> see DESIGN.md."""
+        element-wise passes.  Measured on the headline net, B = 256: 353 ms per step through MIOpen -> see HISTORY.md."""
         mods = list(self.eqv_network)
         convs = [m for m in mods if hasattr(m, "expanded_weights")]
         norms = [m for m in mods if isinstance(m, _InnerBatchNorm)]

@@ -368,7 +368,7 @@ int eqa_window_sums_gemv(const double* S, const double* Wm, float* act, int B, i
  * first of those zero slots to add the bias on the matrix core).
  * 5 x 5 filters over 3 channels with whole 64-channel slices and output rows of >= 32 pixels run a denser form of the kernel
  * (38 k-steps instead of 40, tiles over the flattened output map): same packed layout, same results to the rounding of the
- * summation order.
+ * summation order (HISTORY.md 3.7).
  */
 int eqa_lift_conv_nhwc(const float* x, const float* wpk, const float* bias, int relu, float* y, int nimg, int H, int W,
                        int Cin, int KH, int KW, int Cout, void* stream);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Ablation builds behind the numbers in DESIGN.md.  Builds variants of libeqa_hip.so into build_variants/ (hipcc
+# Ablation builds behind the numbers in HISTORY.md.  Builds variants of libeqa_hip.so into build_variants/ (hipcc
 # cross-compiles without a GPU; build_variants/ is git-ignored but travels to the GPU box).  Then, on the GPU box:
 #   group-action kernel:
 #     for v in base noload nostore neither; do EQA_LIB=$PWD/build_variants/libeqa_$v.so python tools/kbench.py | grep canon; done

@@ -255,7 +255,7 @@ def render():
     o += [f"  ore[{k}] = {r}; oim[{k}] = {'T(0.0f)' if i == '0.0f' else i};" for k, (r, i) in enumerate(out_r2c)]
     o += ["}"]
     # the half-length inverse transforms were used by an experiment (a tile's rows split by parity over two co-resident blocks:
-    # slower); `--half` emits them again
+    # slower, HISTORY.md section 6); `--half` emits them again
     halves = (("ifft48_even", lines_even, out_even, "even rows y = 2 r"), ("ifft48_odd", lines_odd, out_odd, "odd rows y = 2 r + 1"))
     for name, ls, outs, what in (halves if "--half" in sys.argv else ()):
         o += ["",

@@ -6,7 +6,7 @@
 Thread 0 of the middle block of the grid stamps the phases of the fused inverse (loads issued and returned, column
 transform with its LDS writes, wait at the barrier, row transform with the epilogue, window-sum pieces) and of the fused
 forward transform (loads, row transform + LDS writes, barrier, LDS reads + column transform, stores issued).
-Numbers: DESIGN.md section 3.4 (the inverse kernel) and section 6.
+Numbers: HISTORY.md section 3.4 (the inverse kernel) and section 6.
 """
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

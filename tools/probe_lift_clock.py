@@ -4,7 +4,7 @@
   EQA_LIB=$PWD/build_variants/libeqa_clock.so python tools/probe_lift_clock.py
 
 Prints shader cycles per tile (5120 = the tile's MFMAs alone), the clock each wave saw (s_memtime / s_memrealtime), the
-spread of start / end times and the host-measured launch period.  Numbers: DESIGN.md section 3.4.
+spread of start / end times and the host-measured launch period.  Numbers: HISTORY.md section 3.4.
 """
 import ctypes, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
