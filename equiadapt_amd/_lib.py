@@ -67,6 +67,9 @@ SIGNATURES = {
     "eqa_vn_tail_pass": (_int, [_int] + [_vp] * 8 + [_int, _int, _vp]),
     "eqa_vn_bn_finalize": (_int, [_vp, _int, _int, _int, ctypes.c_int64] + [_vp] * 5 + [ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "eqa_vn_bn_bwd_finalize": (_int, [_vp, _int, _int, _int, ctypes.c_int64, _vp, _vp, _vp]),
+    "eqa_window_grad_table": (_int, [_vp, _vp] + [_int] * 5 + [_vp]),
+    "eqa_window_sums_gemv_bwd_workspace_bytes": (ctypes.c_int64, [_int, _int]),
+    "eqa_window_sums_gemv_bwd": (_int, [_vp] * 6 + [_int, _int, _int, ctypes.c_double, _vp]),
     "eqa_window_sums_gemv": (_int, [_vp, _vp, _vp, _int, _int, _int, ctypes.c_double, ctypes.c_double, _vp]),
     "eqa_lift_conv_nhwc": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),
     "eqa_lift_conv_grouped": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 7 + [_vp]),

@@ -584,6 +584,102 @@ int eqa::launch_window_sums_nhwc_finalize(const float* part, double* S, int B, i
   return launch_status();
 }
 
+namespace {
+
+// Backward of the k * k shifted-window sums as a CLASS TABLE (escnn_networks._window_grad_table): a pixel's gradient depends only on
+// the class of its row and of its column -- the k - 1 top / left border indices, the interior (representative: index k - 1), the
+// k - 1 bottom / right ones -- and equals the sum of dS over the windows that contain it, a RECTANGLE of the (k, k) array:
+//     table[b][t][s][c] = sum_{u in U(t)} sum_{v in V(s)} dS[b][c][u][v],   U(t) = [max(0, rep_t - (H - k)), min(k - 1, rep_t)].
+// As an einsum over fp64 masks this was two batched fp64 GEMMs of (B C) tiny matrices through the library (295 + 103 us per step of
+// the reference tutorial's first loop).  Here: a block = one image x 64 channels, dS[b][c0..c0+63] staged in LDS (coalesced),
+// thread = channel: 2-D inclusive prefix sums in place, then every table entry from four corners; stores are 256-byte runs.
+constexpr int kWgtCh = 64;
+__global__ __launch_bounds__(kWgtCh) void window_grad_table_kernel(const double* __restrict__ dS, float* __restrict__ table, int C, int H,
+                                                                  int W, int k) {
+  extern __shared__ double s_p[];                  // [kWgtCh][k * k + 1]
+  const int kk = k * k, stride = kk + 1;
+  const int b = blockIdx.y, c0 = blockIdx.x * kWgtCh, nch = min(kWgtCh, C - c0);
+  const double* src = dS + ((size_t)b * C + c0) * kk;
+  for (int i = threadIdx.x; i < nch * kk; i += kWgtCh) s_p[(i / kk) * stride + i % kk] = src[i];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c >= nch) return;
+  double* p = s_p + c * stride;
+  for (int u = 0; u < k; ++u)
+    for (int v = 1; v < k; ++v) p[u * k + v] += p[u * k + v - 1];
+  for (int u = 1; u < k; ++u)
+    for (int v = 0; v < k; ++v) p[u * k + v] += p[(u - 1) * k + v];
+  const int nb = k - 1, T = 2 * nb + 1;
+  auto range = [&](int t, int n, int& lo, int& hi) {      // windows u with u <= rep <= u + (n - k)
+    const int rep = t <= nb ? t : n - nb + (t - nb - 1);
+    lo = max(0, rep - (n - k));
+    hi = min(k - 1, rep);
+  };
+  auto rect = [&](int u0, int u1, int v0, int v1) -> double {
+    if (u0 > u1 || v0 > v1) return 0.0;
+    double r = p[u1 * k + v1];
+    if (u0 > 0) r -= p[(u0 - 1) * k + v1];
+    if (v0 > 0) r -= p[u1 * k + v0 - 1];
+    if (u0 > 0 && v0 > 0) r += p[(u0 - 1) * k + v0 - 1];
+    return r;
+  };
+  float* out = table + (size_t)b * T * T * C + c0 + c;
+  for (int t = 0; t < T; ++t) {
+    int u0, u1;
+    range(t, H, u0, u1);
+    for (int s = 0; s < T; ++s) {
+      int v0, v1;
+      range(s, W, v0, v1);
+      out[((size_t)t * T + s) * C] = (float)rect(u0, u1, v0, v1);
+    }
+  }
+}
+
+// Backward of act = scale * S . Wm^T (sums_gemv_kernel): dS[b][j] = scale * sum_e dact[b][e] Wm[e][j]  (fp64, E <= 16)
+__global__ __launch_bounds__(kThreads) void sums_gemv_bwd_ds_kernel(const float* __restrict__ dact, const double* __restrict__ Wm,
+                                                                   double* __restrict__ dS, int K, int E, double scale) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  if (j >= K) return;
+  double acc = 0.0;
+  for (int e = 0; e < E; ++e) acc += (double)dact[(size_t)b * E + e] * Wm[(size_t)e * K + j];
+  dS[(size_t)b * K + j] = scale * acc;
+}
+
+// ... and dWm[e][j] = scale * sum_b dact[b][e] S[b][j]: thread = column j, blockIdx.y = a slice of the batch; the slices' partials
+// (nslice, E, K) are summed in order by the second kernel (deterministic)
+template <int MAXE>
+__global__ __launch_bounds__(kThreads) void sums_gemv_bwd_dw_kernel(const float* __restrict__ dact, const double* __restrict__ S,
+                                                                   double* __restrict__ partial, int B, int K, int E, int per_slice) {
+  const int j = blockIdx.x * kThreads + threadIdx.x;
+  const int b0 = blockIdx.y * per_slice, b1 = min(B, b0 + per_slice);
+  if (j >= K) return;
+  double acc[MAXE];
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e) acc[e] = 0.0;
+  for (int b = b0; b < b1; ++b) {
+    const double sv = S[(size_t)b * K + j];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e)
+      if (e < E) acc[e] += (double)dact[(size_t)b * E + e] * sv;
+  }
+#pragma unroll
+  for (int e = 0; e < MAXE; ++e)
+    if (e < E) partial[((size_t)blockIdx.y * E + e) * K + j] = acc[e];
+}
+__global__ __launch_bounds__(kThreads) void sums_gemv_bwd_dw_reduce_kernel(const double* __restrict__ partial, double* __restrict__ dW,
+                                                                          size_t n, int nslice, double scale) {
+  const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int s = 0; s < nslice; ++s) acc += partial[(size_t)s * n + i];
+  dW[i] = scale * acc;
+}
+
+constexpr int kGemvBwdSlices = 16;
+
+}  // namespace
+
 extern "C" {
 
 int64_t eqa_group_pool_workspace_bytes(int B, int Cf, int G, int HW) {
@@ -754,6 +850,51 @@ static int window_sums_nhwc_impl(const float* x, const float* scale, const float
 #undef EQA_WS_SEG
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   return eqa::launch_window_sums_nhwc_finalize((const float*)workspace, out, B, C, k, nseg, st, 1);
+}
+
+int eqa_window_grad_table(const double* dS, float* table, int B, int C, int H, int W, int k, void* stream) {
+  if (B < 0 || C <= 0 || k < 1 || H < k || W < k) return EQA_ERR_INVALID_ARG;
+  if (B == 0) return EQA_OK;
+  if (!dS || !table) return EQA_ERR_INVALID_ARG;
+  if (k > kMaxWinK || B > 65535 || H < 2 * (k - 1) + 1 || W < 2 * (k - 1) + 1) return EQA_ERR_UNSUPPORTED;
+  const size_t lds = (size_t)kWgtCh * (k * k + 1) * sizeof(double);
+  hipLaunchKernelGGL(window_grad_table_kernel, dim3((C + kWgtCh - 1) / kWgtCh, B), dim3(kWgtCh), lds, (hipStream_t)stream, dS, table, C, H, W,
+                     k);
+  return launch_status();
+}
+
+int64_t eqa_window_sums_gemv_bwd_workspace_bytes(int K, int E) { return K <= 0 || E <= 0 ? 0 : (int64_t)kGemvBwdSlices * E * K * 8; }
+
+int eqa_window_sums_gemv_bwd(const float* dact, const double* Wm, const double* S, double* dS, double* dWm, void* workspace, int B, int K,
+                             int E, double scale, void* stream) {
+  if (B < 0 || K <= 0 || E <= 0) return EQA_ERR_INVALID_ARG;
+  if (E > kGemvMaxE) return EQA_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (B == 0) {
+    if (dWm && hipMemsetAsync(dWm, 0, (size_t)E * K * 8, st) != hipSuccess) return EQA_ERR_LAUNCH;
+    return EQA_OK;
+  }
+  if (!dact || (dS && !Wm) || (dWm && (!S || !workspace))) return EQA_ERR_INVALID_ARG;
+  const unsigned gx = (unsigned)((K + kThreads - 1) / kThreads);
+  if (dS) {
+    if (B > 65535) return EQA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(sums_gemv_bwd_ds_kernel, dim3(gx, B), dim3(kThreads), 0, st, dact, Wm, dS, K, E, scale);
+    if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  }
+  if (dWm) {
+    const int per = (B + kGemvBwdSlices - 1) / kGemvBwdSlices;
+    const int nslice = (B + per - 1) / per;
+    if (E <= 8)
+      hipLaunchKernelGGL((sums_gemv_bwd_dw_kernel<8>), dim3(gx, nslice), dim3(kThreads), 0, st, dact, S, (double*)workspace, B, K, E, per);
+    else
+      hipLaunchKernelGGL((sums_gemv_bwd_dw_kernel<kGemvMaxE>), dim3(gx, nslice), dim3(kThreads), 0, st, dact, S, (double*)workspace, B, K, E,
+                         per);
+    if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+    const size_t n = (size_t)E * K;
+    hipLaunchKernelGGL(sums_gemv_bwd_dw_reduce_kernel, dim3((unsigned)((n + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       (const double*)workspace, dWm, n, nslice, scale);
+  }
+  return launch_status();
 }
 
 }  // extern "C"

@@ -58,6 +58,30 @@ def window_sums_to_activations(S: torch.Tensor, layer, H: int, W: int) -> torch.
     return act.float()
 
 
+class WindowSumsLinearFn(torch.autograd.Function):
+    """act = scale * S . weff^T, the GEMV of the linearised last layer, with its backward (dS = scale * dact . weff,
+    dweff = scale * dact^T . S) on the library's kernels: eqa_window_sums_gemv / eqa_window_sums_gemv_bwd.  S:(B,K) fp64,
+    weff:(E <= 16, K) fp64 -> (B,E) fp32.  (Through torch these are three fp64 library GEMMs with an inner or outer dimension of 4-8.)"""
+
+    @staticmethod
+    def forward(ctx, S, weff, scale):
+        from equiadapt_amd import ops
+
+        S, weff = S.contiguous(), weff.contiguous()
+        ctx.save_for_backward(S, weff)
+        ctx.scale = scale
+        return ops.window_sums_gemv(S, weff, scale, 0.0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dact):
+        from equiadapt_amd import ops
+
+        S, weff = ctx.saved_tensors
+        dS, dW = ops.window_sums_gemv_bwd(dact.float().contiguous(), weff, S, ctx.scale, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dS, dW, None
+
+
 class WindowSumsFunction(torch.autograd.Function):
     """S[b,c,u,v] = sum over the (H-k+1, W-k+1) window at (u, v) of x[b,c] (fp64), with its backward: a pixel (y, x) receives
     the sum of dS over the windows that contain it.  Rows fall into 2(k-1)+1 classes (the k-1 top rows, the interior, the k-1
@@ -89,7 +113,12 @@ class WindowSumsFunction(torch.autograd.Function):
 
         rm, ty = classes(H)
         cm, tx = classes(W)
-        table = torch.einsum("tu,bcuv,sv->btsc", rm, dS, cm).float().contiguous()  # (B, 2nb+1, 2nb+1, C), channels last
+        if dS.is_cuda and dS.dtype == torch.float64 and B <= 65535 and H >= 2 * nb + 1 and W >= 2 * nb + 1:
+            from equiadapt_amd import ops
+
+            table = ops.window_grad_table(dS.contiguous(), H, W)                     # (B, 2nb+1, 2nb+1, C), channels last
+        else:
+            table = torch.einsum("tu,bcuv,sv->btsc", rm, dS, cm).float().contiguous()
         if table.is_cuda and C % 4 == 0:
             from equiadapt_amd import _lib, ops
 

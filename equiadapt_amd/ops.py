@@ -708,6 +708,36 @@ def window_sums_gemv(S: torch.Tensor, weff: torch.Tensor, scale: float, shift) -
     return act
 
 
+def window_sums_gemv_bwd(dact: torch.Tensor, weff: torch.Tensor, S: torch.Tensor, scale: float, need_dS: bool, need_dW: bool):
+    """Backward of `window_sums_gemv`: (dS (B,K) fp64 or None, dweff (E,K) fp64 or None) (eqa_window_sums_gemv_bwd)."""
+    lib = _lib.load()
+    dact = _need(dact, "dact")
+    weff, S = _need(weff, "weff", torch.float64), _need(S, "S", torch.float64)
+    B, K = S.shape
+    E = weff.shape[0]
+    dS = torch.empty_like(S) if need_dS else None
+    dW = torch.empty_like(weff) if need_dW else None
+    ws = torch.empty((max(lib.eqa_window_sums_gemv_bwd_workspace_bytes(K, E), 8) // 8,), dtype=torch.float64, device=S.device) if need_dW else None
+    with torch.cuda.device(S.device), _timed("sums_gemv_bwd"):
+        st = lib.eqa_window_sums_gemv_bwd(dact.data_ptr(), weff.data_ptr(), S.data_ptr(), dS.data_ptr() if need_dS else None,
+                                          dW.data_ptr() if need_dW else None, ws.data_ptr() if need_dW else None, B, K, E, float(scale), _stream())
+    _lib.check(st, "eqa_window_sums_gemv_bwd")
+    return dS, dW
+
+
+def window_grad_table(dS: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Backward of the window sums as a class table: dS (B,C,k,k) fp64 -> (B, 2k-1, 2k-1, C) fp32 (eqa_window_grad_table)."""
+    lib = _lib.load()
+    dS = _need(dS, "dS", torch.float64)
+    B, C, k, _ = dS.shape
+    T = 2 * (k - 1) + 1
+    table = torch.empty((B, T, T, C), dtype=torch.float32, device=dS.device)
+    with torch.cuda.device(dS.device), _timed("window_grad_table"):
+        st = lib.eqa_window_grad_table(dS.data_ptr(), table.data_ptr(), B, C, H, W, k, _stream())
+    _lib.check(st, "eqa_window_grad_table")
+    return table
+
+
 def plane_gemm_supported(cin: int, cout: int) -> bool:
     return bool(_lib.load().eqa_plane_gemm_supported(cin, cout))
 

@@ -292,6 +292,17 @@ int eqa_bn_act_bwd_apply(const float* gy, const float* z, const float* scale, co
  *                                  discrete_group.py:475-481 (cosine_similarity + reshape(G,-1).T) in one launch. */
 int eqa_affine_relu_rows(const float* h, const float* scale, const float* shift, float* z, int64_t rows, int D, void* stream);
 int eqa_cosine_group_activations(const float* v, const float* ref, float* act, int B, int G, int V, float eps, void* stream);
+/* Training counterparts of the linearised last layer (escnn_networks.py:106-115 pooled, in training: pooling.py / escnn_networks.py):
+ *   eqa_window_grad_table       dS:(B,C,k,k) fp64 -> table:(B,2k-1,2k-1,C) fp32, the backward of eqa_window_sums* as a class table (a pixel's
+ *                               gradient depends on the class of its row / column only: k-1 border indices each side + the interior) --
+ *                               rectangle sums of dS from 2-D prefix sums; replaces an fp64 mask einsum (two library batched GEMMs).
+ *   eqa_window_sums_gemv_bwd    backward of eqa_window_sums_gemv (act = scale * S . Wm^T): dS:(B,K) = scale * dact . Wm and
+ *                               dWm:(E,K) = scale * dact^T . S, both fp64; either may be NULL; workspace (for dWm):
+ *                               eqa_window_sums_gemv_bwd_workspace_bytes(K, E); batch slices summed in order (deterministic). */
+int eqa_window_grad_table(const double* dS, float* table, int B, int C, int H, int W, int k, void* stream);
+int64_t eqa_window_sums_gemv_bwd_workspace_bytes(int K, int E);
+int eqa_window_sums_gemv_bwd(const float* dact, const double* Wm, const double* S, double* dS, double* dWm, void* workspace, int B, int K,
+                             int E, double scale, void* stream);
 int eqa_bias_relu_nhwc(float* x, const float* bias, int64_t n_pixels, int C, void* stream);
 int64_t eqa_window_sums_nhwc_workspace_bytes(int B, int C, int H, int k);
 int eqa_window_sums_nhwc(const float* x, const float* scale, const float* shift, int relu, double* out, void* workspace,
