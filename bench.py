@@ -703,6 +703,10 @@ def leg_configs(comm: Comm, with_cpu: bool):
             ms_ct_b2b = b2b(lambda a: ops.canon_transform(a, g5, th5, fl5, 512), xs5)
             ms_mk_b2b = b2b(lambda a: ops.mask_action_nearest(a, e5, rth5, mfl5), ms5)
             ring_note = f"ring of {len(xs5)} image batches / {len(ms5)} mask stacks (inputs + outputs >= 640 MB per ring: cache-cold)"
+            # the floor of a launch of this size on this chip: the framework's plain copy of the same bytes over the same rings (a
+            # 25 MB launch is over before the memory pipe is full: what a kernel can reach here is what a copy reaches, not 8 TB/s)
+            ms_ct_copy = b2b(lambda a: a.clone(), xs5)
+            ms_mk_copy = b2b(lambda a: a.clone(), ms5)
             del xs5, ms5
         del mcat
         ach_b, ach_mb = B * 2 * 3 * 1024 * 1024 * 4 / (ms_ct_b2b * 1e-3) / 1e9, B * 3 * 2 * 1024 * 1024 / (ms_mk_b2b * 1e-3) / 1e9
@@ -712,10 +716,14 @@ def leg_configs(comm: Comm, with_cpu: bool):
         c5["batches"][str(B)] = {"value": v, "ms_per_step": ms, "roofline": {
             "bound": "hbm", "kernel": "group_action_kernel via eqa_canon_transform_fwd (25,165,824 B / image)", "achieved": ach_b,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_b / HBM_PEAK_GBS, "avg_launch_ms": ms_ct_b2b,
-            "per_launch_event_ms": ms_ct, "per_launch_event_frac": ach / HBM_PEAK_GBS, "how": how},
+            "per_launch_event_ms": ms_ct, "per_launch_event_frac": ach / HBM_PEAK_GBS, "how": how,
+            "copy_same_bytes_ms": ms_ct_copy, "frac_of_copy": ms_ct_copy / ms_ct_b2b},
             "mask_kernel": {"kernel": "mask_action_u8_kernel via eqa_mask_action_nearest (2 B / mask pixel)", "achieved": ach_mb,
                             "unit": "GB/s", "frac": ach_mb / HBM_PEAK_GBS, "avg_launch_ms": ms_mk_b2b,
-                            "per_launch_event_ms": ms_mk, "per_launch_event_frac": ach_m / HBM_PEAK_GBS}}
+                            "per_launch_event_ms": ms_mk, "per_launch_event_frac": ach_m / HBM_PEAK_GBS,
+                            "copy_same_bytes_ms": ms_mk_copy, "frac_of_copy": ms_mk_copy / ms_mk_b2b,
+                            "note": "frac_of_copy = time of torch's clone() of the same tensor over the same ring / this kernel's time: "
+                                    "the rate a launch of this size can reach at all"}}
         if B == 4:   # BASELINE's own batch: the whole step (image, masks, boxes, invert) captured once and replayed as a hipGraph
             from equiadapt_amd.graphs import GraphedCanonicalizer
 
