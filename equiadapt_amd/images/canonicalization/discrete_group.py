@@ -179,14 +179,16 @@ class DiscreteGroupImageCanonicalization(DiscreteGroupCanonicalization):
                 # crop ratio 1 and a resize to the size the image already has (the CIFAR-shaped configuration): CenterCrop returns
                 # the image and torchvision's resize returns its input when the size matches -- no kernel at all
                 return x
-            if out_hw[0] <= crop.size[0] and out_hw[1] <= crop.size[1]:  # down-sampling (the reference's use)
-                key = (tuple(x.shape[-2:]), crop.size, out_hw, str(x.device))
-                tabs = self._consts.get(key)
-                if tabs is None:
-                    t = geometry.aa_resize_tables(tuple(x.shape[-2:]), crop.size, out_hw)
-                    tabs = tuple(v.to(x.device) if isinstance(v, torch.Tensor) else v for v in t)
-                    self._consts[key] = tabs
-                return ops.crop_resize_aa(x, tabs, out_hw)
+            # down-sampling (the reference's configurations) and up-sampling alike (the reference tutorial crops 64 -> 58 and
+            # resizes back to 64: torch's antialiased filter has support 1 there, three taps): the tables follow torch's formula
+            # for either direction (tests/test_abi_and_host.py, tests/test_gpu_parity.py::test_crop_resize_aa_matches_torch_interpolate)
+            key = (tuple(x.shape[-2:]), crop.size, out_hw, str(x.device))
+            tabs = self._consts.get(key)
+            if tabs is None:
+                t = geometry.aa_resize_tables(tuple(x.shape[-2:]), crop.size, out_hw)
+                tabs = tuple(v.to(x.device) if isinstance(v, torch.Tensor) else v for v in t)
+                self._consts[key] = tabs
+            return ops.crop_resize_aa(x, tabs, out_hw)
         return resize(crop(x))
 
     # -- the hot path ------------------------------------------------------------------------------

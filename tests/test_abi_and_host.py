@@ -115,7 +115,8 @@ def test_aa_resize_tables_reproduce_torch_interpolate():
     from oracle import image_ops as io
 
     torch.manual_seed(0)
-    for (H, W, ratio, size) in [(224, 224, 0.8, 96), (64, 64, 0.9, 32), (50, 70, 0.8, (24, 40)), (33, 33, 1.0, 17)]:
+    for (H, W, ratio, size) in [(224, 224, 0.8, 96), (64, 64, 0.9, 32), (50, 70, 0.8, (24, 40)), (33, 33, 1.0, 17),
+                                (64, 64, 0.9, 64), (40, 52, 0.7, (61, 80))]:   # up-sampling: the tutorial's 58 -> 64, and both axes by 2.2
         x = torch.randn(2, 3, H, W)
         crop = (math.ceil(H * ratio), math.ceil(W * ratio))
         out_hw = io.tv_resize_output_size(crop, size)
