@@ -172,3 +172,36 @@ def test_convnetwork_training_head_dropout_drops_the_rows_the_framework_drops(de
     assert (out - want).abs().max().item() <= 2e-4 * want.abs().max().item()
     (out.sum()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_training_kernels_take_empty_batches_and_refuse_bad_arguments(dev):
+    """Edge cases of the C ABI (include/eqa_hip.h): an empty batch is a no-op (the filter gradient of nothing is zero), unsupported
+    channel counts / kernel sizes are refused with EQA_ERR_UNSUPPORTED, malformed calls with EQA_ERR_INVALID_ARG -- never a launch."""
+    from equiadapt_amd import _lib, ops
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x0 = torch.empty(0, 16, 9, 9, device=dev).permute(0, 2, 3, 1).contiguous()
+    dz0 = torch.empty(0, 3, 3, 16, device=dev)
+    dw = ops.conv_s2_wgrad(x0, dz0, 5, 0, False)
+    assert dw.shape == (16, 16, 5, 5) and (dw == 0).all()
+    assert ops.conv_s2_dgrad(dz0, ops.pack_conv_s2_dgrad_weights(torch.randn(16, 16, 5, 5, device=dev)), (9, 9), 16, 5, 0).shape == (0, 9, 9, 16)
+    z0 = torch.empty(0, 16, device=dev)
+    sc = torch.ones(16, device=dev)
+    assert ops.bn_act_fwd(z0, sc, sc, None, 0).shape == (0, 16)
+    assert not ops.conv_s2_train_supported(24, 16, 5, 0, False) and not ops.conv_s2_train_supported(16, 16, 4, 0, False)
+    assert not ops.conv_s2_train_supported(5, 16, 5, 0, True) and not ops.conv_s2_train_supported(16, 16, 5, 2, False)
+    assert ops.conv_s2_train_supported(3, 32, 7, 1, True) and ops.conv_s2_train_supported(64, 64, 3, 1, False)
+    x = torch.randn(2, 9, 9, 16, device=dev)
+    dz = torch.randn(2, 3, 3, 16, device=dev)
+    out = torch.empty(16, 16, 5, 5, device=dev)
+    ws = torch.empty(1 << 16, device=dev)
+    assert lib.eqa_conv_s2_wgrad(x.data_ptr(), dz.data_ptr(), out.data_ptr(), ws.data_ptr(), 2, 24, 9, 9, 16, 5, 0, 0, st) == -3      # Cin % 16
+    assert lib.eqa_conv_s2_wgrad(x.data_ptr(), dz.data_ptr(), out.data_ptr(), ws.data_ptr(), 2, 16, 3, 3, 16, 5, 0, 0, st) == -1      # frame < filter
+    assert lib.eqa_conv_s2_wgrad(None, dz.data_ptr(), out.data_ptr(), ws.data_ptr(), 2, 16, 9, 9, 16, 5, 0, 0, st) == -1
+    assert lib.eqa_conv_s2_wgrad(x.data_ptr(), dz.data_ptr(), out.data_ptr(), None, 2, 16, 9, 9, 16, 5, 0, 0, st) == -1               # no workspace
+    assert lib.eqa_conv_s2_dgrad(dz.data_ptr(), ws.data_ptr(), x.data_ptr(), 2, 16, 9, 9, 16, 6, 0, st) == -3                           # K = 6
+    assert lib.eqa_bn_act_fwd(x.data_ptr(), sc.data_ptr(), sc.data_ptr(), None, x.data_ptr(), 10, 6, 0, st) == -3                      # C % 4
+    assert lib.eqa_bn_act_fwd(x.data_ptr(), sc.data_ptr(), sc.data_ptr(), None, x.data_ptr(), 10, 16, 2, st) == -1                     # act
+    assert lib.eqa_bn_act_partial_blocks(0) == 0 and lib.eqa_bn_act_partial_blocks(2048) == 256 and lib.eqa_bn_act_partial_blocks(2048 * 900) == 2039
+    assert lib.eqa_conv_s2_wgrad_workspace_bytes(0, 16, 9, 9, 16, 5, 0, 0) == 0

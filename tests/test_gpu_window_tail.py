@@ -60,3 +60,22 @@ def test_window_sums_linear_function_matches_fp64_autograd(dev, B, K, E):
     assert (W.grad - W2.grad).abs().max().item() <= 1e-12 * W2.grad.abs().max().item()
     again = WindowSumsLinearFn.apply(S.detach().requires_grad_(True), W.detach().requires_grad_(True), scale)
     assert torch.equal(again, act)
+
+
+def test_window_tail_kernels_edge_cases(dev):
+    from equiadapt_amd import _lib, ops
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    assert ops.window_grad_table(torch.empty(0, 8, 5, 5, dtype=torch.float64, device=dev), 20, 20).shape == (0, 9, 9, 8)
+    dS = torch.zeros(2, 8, 5, 5, dtype=torch.float64, device=dev)
+    tab = torch.empty(2, 9, 9, 8, device=dev)
+    assert lib.eqa_window_grad_table(dS.data_ptr(), tab.data_ptr(), 2, 8, 8, 20, 5, st) == -3       # H < 2 (k - 1) + 1: classes overlap
+    assert lib.eqa_window_grad_table(dS.data_ptr(), tab.data_ptr(), 2, 8, 4, 20, 5, st) == -1       # H < k
+    assert lib.eqa_window_grad_table(dS.data_ptr(), tab.data_ptr(), 2, 8, 40, 40, 11, st) == -3     # k beyond the window-sum kernels
+    S = torch.empty(0, 100, dtype=torch.float64, device=dev)
+    W = torch.randn(4, 100, dtype=torch.float64, device=dev)
+    dS0, dW0 = ops.window_sums_gemv_bwd(torch.empty(0, 4, device=dev), W, S, 0.5, True, True)
+    assert dS0.shape == (0, 100) and (dW0 == 0).all()
+    assert lib.eqa_window_sums_gemv_bwd(None, W.data_ptr(), S.data_ptr(), None, None, None, 3, 100, 17, 1.0, st) == -3     # E > 16
+    assert lib.eqa_window_sums_gemv_bwd_workspace_bytes(100, 4) == 16 * 4 * 100 * 8
