@@ -662,12 +662,13 @@ int64_t eqa_conv_s2_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout
 
 int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout, int K, int pad,
                       int planar, void* stream) {
-  if (!x || !dz || !dw || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (!dw || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
   if (!eqa_conv_s2_wgrad_supported(Cin, Cout, K, pad, planar)) return EQA_ERR_UNSUPPORTED;
   if (H + 2 * pad < K || W + 2 * pad < K) return EQA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // an empty batch (its tensors may be null pointers): the filter gradient of nothing is zero
   if (B == 0) return hipMemsetAsync(dw, 0, (size_t)Cout * Cin * K * K * 4, st) == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
-  if (!workspace) return EQA_ERR_INVALID_ARG;
+  if (!x || !dz || !workspace) return EQA_ERR_INVALID_ARG;
   const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
   const long P = (long)B * OH * OW;
   const size_t xbytes = (size_t)B * Cin * H * W * 4, gbytes = (size_t)P * Cout * 4;
@@ -719,10 +720,11 @@ int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspac
 int eqa_conv_s2_dgrad_supported(int Cin, int Cout, int K, int pad) { return eqa_conv_s2_supported(Cin, Cout, K, pad, 0); }
 
 int eqa_conv_s2_dgrad(const float* dz, const float* wd, float* dx, int B, int Cin, int H, int W, int Cout, int K, int pad, void* stream) {
-  if (!dz || !wd || !dx || B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
+  if (B < 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return EQA_ERR_INVALID_ARG;
   if (!eqa_conv_s2_dgrad_supported(Cin, Cout, K, pad)) return EQA_ERR_UNSUPPORTED;
   if (H + 2 * pad < K || W + 2 * pad < K) return EQA_ERR_INVALID_ARG;
   if (B == 0) return EQA_OK;
+  if (!dz || !wd || !dx) return EQA_ERR_INVALID_ARG;
   const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
   const size_t gbytes = (size_t)B * OH * OW * Cout * 4, xbytes = (size_t)B * H * W * Cin * 4;
   if (gbytes > 0x7fffffe0ULL || xbytes > 0x7fffffffffULL || (((uintptr_t)dz | (uintptr_t)wd | (uintptr_t)dx) & 15)) return EQA_ERR_UNSUPPORTED;

@@ -205,3 +205,46 @@ def test_training_kernels_take_empty_batches_and_refuse_bad_arguments(dev):
     assert lib.eqa_bn_act_fwd(x.data_ptr(), sc.data_ptr(), sc.data_ptr(), None, x.data_ptr(), 10, 16, 2, st) == -1                     # act
     assert lib.eqa_bn_act_partial_blocks(0) == 0 and lib.eqa_bn_act_partial_blocks(2048) == 256 and lib.eqa_bn_act_partial_blocks(2048 * 900) == 2039
     assert lib.eqa_conv_s2_wgrad_workspace_bytes(0, 16, 9, 9, 16, 5, 0, 0) == 0
+
+
+def test_conv_s2_gradients_fuzz(dev):
+    """Sixty random shapes over every supported (Cin, Cout, K, pad, planar) family -- odd frames, frames barely larger than the
+    filter, one image, runs that end inside a row -- against fp64 torch.nn.grad on the CPU."""
+    import random
+
+    from equiadapt_amd import ops
+
+    rnd = random.Random(2025)
+    fam_planar = [(c, o) for c in (1, 2, 3, 4) for o in (16, 32)]
+    fam_nhwc = [(16, 16), (16, 32), (32, 32), (32, 64), (64, 64)]
+    seen = set()
+    for it in range(60):
+        planar = rnd.random() < 0.4
+        Cin, Cout = rnd.choice(fam_planar if planar else fam_nhwc)
+        K, pad = rnd.choice((3, 5, 7)), rnd.choice((0, 1))
+        if planar and Cin * K > 32:
+            continue
+        H, W = rnd.randint(K, 40), rnd.randint(K, 40)
+        B = rnd.choice((1, 2, 3, 7))
+        assert ops.conv_s2_train_supported(Cin, Cout, K, pad, planar)
+        seen.add((planar, K, pad))
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, K, K, generator=g) * 0.1
+        OH, OW = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+        dz = torch.randn(B, Cout, OH, OW, generator=g)
+        want_w = torch.nn.grad.conv2d_weight(x.double(), w.shape, dz.double(), stride=2, padding=pad)
+        xd = x.to(dev) if planar else x.permute(0, 2, 3, 1).contiguous().to(dev)
+        dzd = dz.permute(0, 2, 3, 1).contiguous().to(dev)
+        got_w = ops.conv_s2_wgrad(xd, dzd, K, pad, planar).cpu().double()
+        tol = 2e-5 * want_w.abs().max().item() + 1e-6
+        assert (got_w - want_w).abs().max().item() <= tol, ("wgrad", it, planar, Cin, Cout, K, pad, H, W, B)
+        if not planar:
+            want_x = torch.nn.grad.conv2d_input(x.shape, w.double(), dz.double(), stride=2, padding=pad)
+            got_x = ops.conv_s2_dgrad(dzd, ops.pack_conv_s2_dgrad_weights(w.to(dev)), (H, W), Cin, K, pad).permute(0, 3, 1, 2).cpu().double()
+            assert (got_x - want_x).abs().max().item() <= 2e-5 * want_x.abs().max().item() + 1e-6, ("dgrad", it, Cin, Cout, K, pad, H, W, B)
+            # and the forward kernel the two are the gradients of, as a vector-Jacobian identity: <conv(x), dz> == <x, dgrad(dz)>
+            y = ops.conv_s2(xd, ops.pack_conv_s2_weights(w.to(dev), False), None, False, Cout, K, pad, False)
+            lhs, rhs = (y.double() * dzd.double()).sum().item(), (x.double() * want_x).sum().item()
+            assert abs(lhs - rhs) <= 1e-4 * (abs(rhs) + 1.0)
+    assert len(seen) >= 10
