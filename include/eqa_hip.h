@@ -692,6 +692,9 @@ int eqa_vn_bn_bwd_finalize(const float* partial, int nblk, int stride, int C, lo
 /*
  * P3 -- batched 3x3 classical Gram-Schmidt on rows (no epsilon, no handedness fix).
  * Replaces equiadapt/common/utils.py:22-51.   v,out:(B,3,3).
+ * fp32 in, fp32 out; the three steps are evaluated in fp64 and rounded once (the step has no epsilon and amplifies rounding by the
+ * conditioning of the three vectors: an fp32 evaluation -- the reference's included -- sits 4e-5..6e-5 from the exact frame at
+ * cond(V) = 540; this one is the exact Gram-Schmidt of its input to the last fp32 bit).  Same for eqa_modified_gram_schmidt.
  */
 int eqa_gram_schmidt(const float* v, float* out, int B, void* stream);
 /* its backward (training): grad_out:(B,3,3) = dL/d out -> grad_v:(B,3,3) = dL/d v, the analytic derivative of the three steps */
