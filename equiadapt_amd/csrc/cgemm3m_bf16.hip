@@ -342,6 +342,342 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
   flush_rows(lds_lane, dst, 0, 32);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The BLOCK form (Cout a multiple of 128).  What bounds the wave form is not the matrix pipe but the vector L1: a 1-KB wave load
+// returns every ~22 cycles per CU, and a wave-tile of 64 x 64 asks for 18 fragments of B and 8 loads of A per K-stage -- 104 loads
+// per CU and stage = 2.3 k cycles against 2.3 k (six products) / 3.5 k (nine) of matrix instructions.  Here a block works on
+// 128 rows x 128 columns of one frequency, wave w on columns 32 w .. 32 w + 31 of all 128 rows:
+//   * A's K-stage is the same for the four waves: loaded and split ONCE per block (two rows per thread) and shared through LDS in
+//     the fragment order of the instruction -- a half of the wave form's split arithmetic per matrix instruction, no A load per wave;
+//   * B's K-stage is 9 fragments per wave instead of 18: 36 + 16 loads per CU and stage (1.1 k cycles of the L1).
+//   LDS: three K-stages of A's pieces, 36 fragments [row quarter m][part r/i/s][piece] of 64 lanes x 16 bytes = 36 KB a stage.
+//        Stage g + 2 is written while stage g is multiplied and stage g + 1 stands published: ONE barrier per stage, at the stage
+//        boundary, and nothing is read right behind it (a stage's first fragments are read before the barrier that ends the
+//        stage before: they were published a stage earlier).
+//   splitter: thread (wave w, lane l) owns rows 16 w + (l >> 1 & 15) and + 64, k = 8 (l & 1) + 4 (l >> 5) + 0..3 of the stage:
+//        four 16-byte loads (re, im of two rows), 24 values split, eighteen 8-byte LDS writes (lanes 0..31 of a write cover 512
+//        contiguous bytes: no conflict).  The raw values of stage g + 4 are requested when those of g + 2 have been split.
+//   B: a K-stage (9 fragments, 36 registers) a stage ahead in a second register set, requested in the stage's first quarter.
+//   matrix instructions of a stage: four regions (row quarter m), each the three A pieces against every B piece: 27 (TERMS = 6:
+//        18) instructions; a region reads the nine fragments it needs next from LDS behind its first nine matrix instructions.
+//   the finished tile leaves straight from the accumulators: lane (column i, h) holds (Cr, Ci) of 16 rows per m -- 8-byte stores,
+//        256 contiguous bytes per row.
+constexpr int kBlkM = 128, kBlkN = 128;
+constexpr int kFragBytes = 64 * 16;
+constexpr int kAStageBytes = 36 * kFragBytes;
+constexpr int kABufs = 3;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct BSet {
+  u32x4 b[3][3];                  // [part][piece] of the wave's 32 columns
+};
+struct AFrags {
+  u32x4 a[3];                     // [part] of one (row quarter, piece)
+};
+struct RawA {
+  f32x4 re[2], im[2];             // rows r and r + 64
+};
+struct TileAt {                   // uniform: where a block tile's operands are
+  __amdgpu_buffer_rsrc_t a, b;
+  unsigned sb;
+};
+
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[3]) {
+  unsigned x[3][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float a = v[t];
+    const float p1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & kHi);
+    const float r1 = a - p1;
+    const float p2 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r1) & kHi);
+    const float r2 = r1 - p2;
+    x[0][t] = __builtin_bit_cast(unsigned, a);
+    x[1][t] = __builtin_bit_cast(unsigned, r1);
+    x[2][t] = __builtin_bit_cast(unsigned, r2);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    o[q][0] = __builtin_amdgcn_perm(x[q][1], x[q][0], 0x07060302u);
+    o[q][1] = __builtin_amdgcn_perm(x[q][3], x[q][2], 0x07060302u);
+  }
+}
+// one part (0 re, 1 im, 2 re + im) of row ROW's 4 k: split, three 8-byte writes into the stage being built (row r + 64 is row
+// quarter m + 2: 18 fragments further)
+template <int ROW, int PART>
+__device__ __forceinline__ void split_part(const RawA& r, unsigned char* wr) {
+  u32x2 o[3];
+  split4(PART == 0 ? r.re[ROW] : PART == 1 ? r.im[ROW] : r.re[ROW] + r.im[ROW], o);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(wr + (ROW * 18 + PART * 3 + q) * kFragBytes) = o[q];
+}
+template <int ROW>
+__device__ __forceinline__ void load_raw(RawA& o, const TileAt& t, unsigned voff, unsigned row64, unsigned soff) {
+  o.re[ROW] = __builtin_bit_cast(f32x4, buf_ld(t.a, voff + ROW * row64, soff));
+  o.im[ROW] = __builtin_bit_cast(f32x4, buf_ld(t.a, voff + ROW * row64 + 64, soff));
+}
+__device__ __forceinline__ void load_bset(BSet& o, const TileAt& t, unsigned voff, unsigned soff) {
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o.b[k / 3][k % 3] = buf_ld(t.b, voff + k * kBFrag, t.sb + soff);
+}
+template <int M, int PA>
+__device__ __forceinline__ void read_frags(AFrags& o, const unsigned char* rd) {
+#pragma unroll
+  for (int p = 0; p < 3; ++p) o.a[p] = *reinterpret_cast<const u32x4*>(rd + ((M * 3 + p) * 3 + PA) * kFragBytes);
+}
+// FIRST: the tile's first K-stage -- the first product into an accumulator starts from zero (no accumulator is ever cleared)
+template <int TERMS, int M, int PA, bool FIRST>
+__device__ __forceinline__ void mma_rows(const AFrags& A, const BSet& B, f32x16 (&acc)[3][4]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pb = 0; pb < 3; ++pb) {
+    if (TERMS == 6 && PA + pb > 2) continue;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc[p][M] = mma(A.a[p], B.b[p][pb], FIRST && PA == 0 && pb == 0 ? zero : acc[p][M]);
+  }
+}
+// the order of a region's instructions: behind each matrix instruction its share of the LDS reads, loads, vector arithmetic, writes
+template <int NMMA, int NDSR, int NLOAD, int NVALU, int NDSW>
+__device__ __forceinline__ void pin_region() {
+#ifndef EQA_CGEMM_BF16_NOPIN
+  constexpr int kValuPer = (NVALU + NMMA - 1) / NMMA;
+#pragma unroll
+  for (int k = 0; k < NMMA; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if (k < NDSR) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if (k < NLOAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+    if (k >= NMMA - NDSW) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+  }
+#endif
+}
+
+#if defined(EQA_BLK_CLOCK) && EQA_BLK_CLOCK >= 2
+#define EQA_TICK(i) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0" : "=s"(tk[i])); } while (0)
+#else
+#define EQA_TICK(i)
+#endif
+
+// One K-stage.  On entry: Bc = this stage's B, F0 = the fragments (row quarter 0, piece 0), raw = the raw values of stage g + 2
+// (arrived); rd / rd_next = this lane's read address in this stage's / the next stage's LDS buffer, wr = its write address in
+// stage g + 2's.  On exit: Bn = the next stage's B (requested), F0 = the next stage's (0, 0), raw = stage g + 4 (requested).
+template <int TERMS, bool FIRST>
+__device__ __forceinline__ void run_stage_block(const BSet& Bc, BSet& Bn, RawA& raw, AFrags& F0, AFrags& F1, AFrags& F2, AFrags& F3,
+                                                f32x16 (&acc)[3][4], const unsigned char* rd, const unsigned char* rd_next,
+                                                unsigned char* wr, const TileAt& tb, unsigned sb_off, unsigned b_voff, const TileAt& ta,
+                                                unsigned sa_off, unsigned a_voff, unsigned row64
+#ifdef EQA_BLK_CLOCK
+                                                , unsigned long long (&tot)[8]
+#endif
+                                                ) {
+#ifdef EQA_BLK_CLOCK
+  unsigned long long tk[8];
+#endif
+  constexpr int kN = TERMS == 9 ? 27 : 18;        // matrix instructions of a region
+  constexpr int kSplit = 32;                      // vector instructions of one split_part (an upper bound for the pinning)
+  EQA_TICK(0);
+  // region m = 0: B of the next stage; row r: re
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<0, 1>(F1, rd); read_frags<0, 2>(F2, rd); read_frags<1, 0>(F3, rd);
+  load_bset(Bn, tb, b_voff, sb_off);
+  split_part<0, 0>(raw, wr);
+  mma_rows<TERMS, 0, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 0, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 0, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, 9, 9, kSplit, 3>();
+  EQA_TICK(1);
+  // region m = 1: row r: im, re + im
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<1, 1>(F1, rd); read_frags<1, 2>(F2, rd); read_frags<2, 0>(F0, rd);
+  split_part<0, 1>(raw, wr); split_part<0, 2>(raw, wr);
+  mma_rows<TERMS, 1, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 1, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 1, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, 9, 0, 2 * kSplit + 4, 6>();
+  EQA_TICK(2);
+  // region m = 2: row r + 64: re, im
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<2, 1>(F1, rd); read_frags<2, 2>(F2, rd); read_frags<3, 0>(F3, rd);
+  split_part<1, 0>(raw, wr); split_part<1, 1>(raw, wr);
+  mma_rows<TERMS, 2, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 2, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 2, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, 9, 0, 2 * kSplit, 6>();
+  EQA_TICK(3);
+  // region m = 3: row r + 64: re + im; the raw values of stage g + 4
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags<3, 1>(F1, rd); read_frags<3, 2>(F2, rd); read_frags<0, 0>(F0, rd_next);
+  split_part<1, 2>(raw, wr);
+  load_raw<0>(raw, ta, a_voff, row64, sa_off);
+  mma_rows<TERMS, 3, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 3, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 3, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, 9, 2, kSplit + 4, 3>();
+  __builtin_amdgcn_sched_barrier(0);
+  load_raw<1>(raw, ta, a_voff, row64, sa_off);
+  EQA_TICK(4);
+  __builtin_amdgcn_sched_barrier(0);
+  // the stage's pieces are written (mine: lgkmcnt), every wave is done with the buffer that stage g + 3 will be built in
+#ifdef EQA_BLK_NOBARRIER
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+#if defined(EQA_BLK_CLOCK) && EQA_BLK_CLOCK >= 2
+  EQA_TICK(5);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < 5; ++i) tot[i] += tk[i + 1] - tk[i];
+#endif
+}
+
+#ifdef EQA_BLK_CLOCK
+__device__ long long g_blk_clock[16];
+#endif
+template <int TERMS>
+__global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const float* __restrict__ V, const uint16_t* __restrict__ Bp,
+                                                                        float* __restrict__ Mo, int M, int pitch, int Cin, int Cout, int F,
+                                                                        int n_rt, int n_cg, int blocks_per_xcd) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int xcd = blockIdx.x & (kXcd - 1);
+  const int q = blockIdx.x >> 3;
+  const int S = Cin / kStageK;
+  const int tpf = n_rt * n_cg;                                    // block tiles per frequency
+  const int nf_x = (F - xcd + kXcd - 1) / kXcd;
+  const int total = nf_x * tpf;
+  if (q >= total) return;
+#ifdef EQA_BLK_CLOCK
+  const long long c0 = clock64(), w0 = wall_clock64();
+  unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_epi = 0;
+#define EQA_TOT , tot
+#else
+#define EQA_TOT
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // kABufs * kAStageBytes
+  const size_t rowf = (size_t)2 * Cin, mo_row = (size_t)2 * Cout;
+  const unsigned b_stage_bytes = (unsigned)(Cout / 32) * 9 * kBFrag;
+  const unsigned a_stage = 32u * 4u;
+  const unsigned b_voff = lane * 16;
+  const unsigned row64 = (unsigned)(64 * rowf * 4);
+  // splitter: rows 16 w + (l >> 1 & 15) and + 64, k = 8 (l & 1) + 4 (l >> 5) + t
+  const int sp_b = lane & 1, sp_r = (lane >> 1) & 15, sp_h = lane >> 5;
+  const int sp_row = 16 * wave + sp_r;
+  const unsigned sp_lds = (unsigned)((sp_row >> 5) * 9 * kFragBytes + ((sp_row & 31) + 32 * sp_h) * 16 + 8 * sp_b);
+  const unsigned sp_k = (unsigned)(8 * sp_b + 4 * sp_h) * 4u;
+
+  auto locate = [&](int u, TileAt& at, unsigned& aoff, int& f, int& row0, int& ct) {
+    const bool live = u < total;
+    const int uu = live ? u : 0;
+    const int fi = uu / tpf, r = uu - fi * tpf;
+    f = xcd + kXcd * fi;
+    const int rt = r / n_cg, cg = r - rt * n_cg;
+    row0 = rt * kBlkM;
+    ct = 4 * cg + wave;                                            // in units of 32 columns
+    // past the block's last tile: empty descriptors (the look-ahead reads zeros, no traffic); rows past the pitch likewise
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V) + (size_t)f * pitch * rowf, 0, live ? (unsigned)((size_t)pitch * rowf * 4) : 0u, 0x00020000);
+    aoff = (unsigned)((size_t)(row0 + sp_row) * rowf * 4) + sp_k;
+#ifdef EQA_BLK_SAME_B
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp), 0, live ? (unsigned)S * b_stage_bytes : 0u, 0x00020000);
+    at.sb = 0;
+#else
+    at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp) + (size_t)f * S * (b_stage_bytes / 2), 0, live ? (unsigned)S * b_stage_bytes : 0u, 0x00020000);
+    at.sb = (unsigned)ct * (9 * kBFrag);
+#endif
+#ifdef EQA_BLK_SAME_A
+    at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, live ? (unsigned)((size_t)pitch * rowf * 4) : 0u, 0x00020000);
+    aoff = (unsigned)((size_t)(sp_row) * rowf * 4) + sp_k;
+#endif
+  };
+
+  // three positions in the block's sequence of K-stages: A's loads (4 stages ahead), B's loads (1 ahead), the matrix instructions
+  TileAt ta, tb;
+  unsigned a_voff, b_unused;
+  int ua = q, sa = 0, ub = q, sb = 0;
+  int fa, rowa, cta, f, row0, ct;
+  locate(q, ta, a_voff, f, row0, ct);
+  tb = ta;
+  auto next_a = [&]() {
+    if (++sa == S) { sa = 0; ua += blocks_per_xcd; locate(ua, ta, a_voff, fa, rowa, cta); }
+  };
+  auto next_b = [&]() {
+    if (++sb == S) { sb = 0; ub += blocks_per_xcd; locate(ub, tb, b_unused, fa, rowa, cta); }
+  };
+
+  RawA raw0, raw1;
+  BSet B0, B1;
+  AFrags F0, F1, F2, F3;
+  // prologue: stages 0 and 1 of A built in buffers 0 and 1, stages 2 and 3 requested, stage 0 of B requested
+  load_raw<0>(raw0, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw0, ta, a_voff, row64, sa * a_stage); next_a();
+  load_raw<0>(raw1, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw1, ta, a_voff, row64, sa * a_stage); next_a();
+  load_bset(B0, tb, b_voff, sb * b_stage_bytes); next_b();
+  {
+    unsigned char* w0p = lds + sp_lds;
+    unsigned char* w1p = lds + kAStageBytes + sp_lds;
+    split_part<0, 0>(raw0, w0p); split_part<0, 1>(raw0, w0p); split_part<0, 2>(raw0, w0p);
+    split_part<1, 0>(raw0, w0p); split_part<1, 1>(raw0, w0p); split_part<1, 2>(raw0, w0p);
+    split_part<0, 0>(raw1, w1p); split_part<0, 1>(raw1, w1p); split_part<0, 2>(raw1, w1p);
+    split_part<1, 0>(raw1, w1p); split_part<1, 1>(raw1, w1p); split_part<1, 2>(raw1, w1p);
+  }
+  load_raw<0>(raw0, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw0, ta, a_voff, row64, sa * a_stage); next_a();
+  load_raw<0>(raw1, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw1, ta, a_voff, row64, sa * a_stage); next_a();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned rbuf = 0;                                               // byte offset of the LDS buffer of the stage being multiplied
+  read_frags<0, 0>(F0, lds + lane * 16);
+  auto step = [&](unsigned o) { return o + kAStageBytes >= kABufs * kAStageBytes ? o + kAStageBytes - kABufs * kAStageBytes : o + kAStageBytes; };
+
+  for (int u = q; u < total; u += blocks_per_xcd) {
+    f32x16 acc[3][4];
+#define EQA_STAGE(FIRST, BC, BN, RAW)                                                                                                 \
+  {                                                                                                                                  \
+    const unsigned r1 = step(rbuf), r2 = step(r1);                                                                                   \
+    run_stage_block<TERMS, FIRST>(BC, BN, RAW, F0, F1, F2, F3, acc, lds + rbuf + lane * 16, lds + r1 + lane * 16, lds + r2 + sp_lds, \
+                                  tb, sb * b_stage_bytes, b_voff, ta, sa * a_stage, a_voff, row64 EQA_TOT);                          \
+    next_a(); next_b();                                                                                                              \
+    rbuf = r1;                                                                                                                       \
+  }
+    EQA_STAGE(true, B0, B1, raw0)
+    EQA_STAGE(false, B1, B0, raw1)
+    for (int s = 2; s < S; s += 2) {
+      EQA_STAGE(false, B0, B1, raw0)
+      EQA_STAGE(false, B1, B0, raw1)
+    }
+#undef EQA_STAGE
+    // Cr = T1 - T2, Ci = T3 - T1 - T2, straight from the accumulators: lane (i, h), slot e = row (e & 3) + 8 (e >> 2) + 4 h, column i
+#ifdef EQA_BLK_CLOCK
+    const long long e0 = clock64();
+#endif
+    {
+      const int rows = __builtin_amdgcn_readfirstlane(min(kBlkM, M - row0));
+#ifdef EQA_BLK_NOSTORE
+      const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(Mo, 0, (unsigned)(rows * 0), 0x00020000);
+#else
+      const __amdgpu_buffer_rsrc_t dr =
+          __builtin_amdgcn_make_buffer_rsrc(Mo + ((size_t)f * pitch + row0) * mo_row, 0, (unsigned)(rows * mo_row * 4), 0x00020000);
+#endif
+      const int i = lane & 31, h = lane >> 5;
+      const unsigned voff = (unsigned)((4 * h * mo_row + (size_t)(32 * ct + i) * 2) * 4);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const unsigned roff = voff + (unsigned)((32 * m + (e & 3) + 8 * (e >> 2)) * mo_row * 4);     // in the range-checked offset
+          const float t1 = acc[0][m][e], t2 = acc[1][m][e], t3 = acc[2][m][e];
+          u32x2 c;
+          c[0] = __builtin_bit_cast(unsigned, t1 - t2);
+          c[1] = __builtin_bit_cast(unsigned, t3 - t1 - t2);
+          __builtin_amdgcn_raw_buffer_store_b64(c, dr, roff, 0, 0);
+        }
+    }
+    int nf, nrow0, nct;
+    TileAt unused_t;
+    unsigned unused_o;
+    locate(u + blocks_per_xcd, unused_t, unused_o, nf, nrow0, nct);
+    f = nf; row0 = nrow0; ct = nct;
+#ifdef EQA_BLK_CLOCK
+    t_epi += clock64() - e0;
+#endif
+  }
+#ifdef EQA_BLK_CLOCK
+  if (blockIdx.x == 100 && threadIdx.x == 0) {
+    g_blk_clock[0] = clock64() - c0; g_blk_clock[1] = wall_clock64() - w0; g_blk_clock[2] = t_epi;
+    for (int i = 0; i < 7; ++i) g_blk_clock[3 + i] = (long long)tot[i];
+  }
+#endif
+}
+
 // B3 (F, S, Cout/32, 3, 2, 64, 4) fp32 -> Bp (F, S, Cout/32, 3, 3, 64, 8) bf16: one thread per (f, s, column tile, part, lane)
 __global__ __launch_bounds__(256) void spectra3m_split_kernel(const float* __restrict__ B3, uint16_t* __restrict__ Bp, size_t groups) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -358,12 +694,20 @@ __global__ __launch_bounds__(256) void spectra3m_split_kernel(const float* __res
 
 }  // namespace
 
+namespace eqa {
+int g_cgemm_bf16_form = 0;     // eqa_set_option key 2: 0 = the block form where it applies (Cout % 128 == 0), 1 = always the wave form
+}
+
 extern "C" {
 
 int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout) {
   if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout)) return 0;
   return (int64_t)eqa_fft48k5_frequencies() * Cin * Cout * 3 * 3 * 2;
 }
+
+#ifdef EQA_BLK_CLOCK
+int eqa_debug_blk_clock(long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_clock), 80); }
+#endif
 
 int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream) {
   if (!B3 || !Bp) return EQA_ERR_INVALID_ARG;
@@ -386,6 +730,19 @@ int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_
   const int n_rt = (int)((M + kTileM - 1) / kTileM), n_ct = Cout / kTileN;
   const int blocks = 256;
   const int S = Cin / kStageK;
+  if (Cout % kBlkN == 0 && eqa::g_cgemm_bf16_form != 1) {      // the block form: A split once per block, shared through LDS
+    const int n_rb = (int)((M + kBlkM - 1) / kBlkM), n_cg = Cout / kBlkN;
+    constexpr int kLds = kABufs * kAStageBytes;
+    const void* kern = terms == 9 ? (const void*)fft_cgemm3m_bf16_block_kernel<9> : (const void*)fft_cgemm3m_bf16_block_kernel<6>;
+    if (!allow_dynamic_lds(kern, kLds)) return EQA_ERR_LAUNCH;
+    if (terms == 9)
+      hipLaunchKernelGGL((fft_cgemm3m_bf16_block_kernel<9>), dim3(blocks), dim3(256), kLds, (hipStream_t)stream, V,
+                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd);
+    else
+      hipLaunchKernelGGL((fft_cgemm3m_bf16_block_kernel<6>), dim3(blocks), dim3(256), kLds, (hipStream_t)stream, V,
+                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd);
+    return launch_status();
+  }
 #define EQA_CG_LAUNCH(NP, T)                                                                                                       \
   hipLaunchKernelGGL((fft_cgemm3m_bf16_kernel<NP, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, V, static_cast<const uint16_t*>(Bp), \
                      Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rt, n_ct, (blocks / kXcd) * 4)

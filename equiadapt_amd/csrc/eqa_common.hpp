@@ -44,6 +44,7 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 #undef EQA_DPP_ADD
 
 extern int g_vn_kernel_choice;  // pointcloud.hip; eqa_set_option key 1
+extern int g_cgemm_bf16_form;   // cgemm3m_bf16.hip; eqa_set_option key 2
 
 // Counter-based hash for the dropout mask of the canonicalization network's hidden blocks (one draw per element, reproducible from
 // (seed, element index)): shared by batchnorm.hip (which writes / recomputes the mask) and pooling.hip (the window sums that

@@ -1718,7 +1718,7 @@ int eqa_abi_version(void) { return EQA_ABI_VERSION; }
 
 int eqa_get_option(int key) {
   if (key == 100) return kMaxWinK;   // read-only: the largest window the window-sum kernels take (ops.MAX_WINDOW_K must equal it)
-  return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : EQA_ERR_INVALID_ARG;
+  return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : key == 2 ? eqa::g_cgemm_bf16_form : EQA_ERR_INVALID_ARG;
 }
 
 int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad) {
@@ -1747,6 +1747,10 @@ int eqa_set_option(int key, int value) {
   }
   if (key == 1 && value >= 0 && value <= 2) {
     eqa::g_vn_kernel_choice = value;
+    return EQA_OK;
+  }
+  if (key == 2 && value >= 0 && value <= 1) {
+    eqa::g_cgemm_bf16_form = value;
     return EQA_OK;
   }
   return EQA_ERR_INVALID_ARG;

@@ -53,6 +53,7 @@ int eqa_abi_version(void);
 /* Debug/benchmark knobs (process-global, not part of the data path):
  *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels.
  *   key 1: VNSmall forward kernel: 0 = chosen by size (default), 1 = one thread per point (k = 20 only), 2 = four lanes per point.
+ *   key 2: eqa_fft48k5_cgemm3m_bf16x3: 0 = the block form where it applies (Cout % 128 == 0; default), 1 = always the wave form.
  *   key 100 (get only): the largest window size k the window-sum kernels take (eqa_window_sums*, the linearised last layer). */
 int eqa_set_option(int key, int value);
 int eqa_get_option(int key);
@@ -524,7 +525,10 @@ int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, i
  * <= 2^-24 (error <= 2^-23 |a||b| per product).  Same reference arithmetic as eqa_fft48k5_cgemm3m (escnn_networks.py:67-91).
  *   eqa_fft48k5_spectra3m_bf16_bytes  bytes of Bp = F * Cin * Cout * 3 parts * 3 pieces * 2.
  *   eqa_fft48k5_spectra3m_split       B3 (the operand of eqa_fft48k5_cgemm3m) -> Bp:(F, Cin/16, Cout/32, 3, 3 pieces, 64, 8) bf16.
- *   eqa_fft48k5_cgemm3m_bf16x3        V, Bp -> Mo; shapes and layouts of V / Mo as for eqa_fft48k5_cgemm3m. */
+ *   eqa_fft48k5_cgemm3m_bf16x3        V, Bp -> Mo; shapes and layouts of V / Mo as for eqa_fft48k5_cgemm3m.  Two kernels: a wave
+ *                                     per 64 x 64 tile (any supported shape), and -- Cout % 128 == 0 -- a block per 128 x 128 tile
+ *                                     with A split once per block and shared through LDS (a third of the vector-L1 loads per
+ *                                     matrix instruction; eqa_set_option key 2 = 1 forces the wave form). */
 int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout);
 int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream);
 int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_t M, int Cin, int Cout, int terms, void* stream);
