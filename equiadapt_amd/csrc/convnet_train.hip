@@ -405,20 +405,23 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
   }
 }
 
-// dw[co][ci][u][v] = sum over the runs of the partials (fp32 partials of <= pix_per_wave pixels each, fp64 across): a block owns 64
-// consecutive elements of the per-run block, its four waves every fourth run; the four slices are combined in order -- the result
-// does not depend on the launch.   nhwc: ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
-__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int runs,
-                                                                       int K, int Cout, int Cin, int JJ) {
+// dw[co][ci][u][v] = sum over the runs of the partials (fp32 partials of <= pix_per_wave pixels each, fp64 across), in two launches so
+// that the whole chip reads the workspace (one launch over per_run / 64 blocks is 20 blocks at the first layer: 53 us of latency):
+//   partial: block (64 consecutive elements of the per-run block, chunk of kRedChunk runs); its four waves take every fourth run of
+//            the chunk, the four slices are combined in order -> part2 (chunks, per_run) fp64
+//   final:   a thread per element adds the chunks in order and writes dw in the framework's order.
+// The result does not depend on the launch.   nhwc: ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
+constexpr int kRedChunk = 128;
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_partial_kernel(const float* __restrict__ ws, double* __restrict__ part2, int runs,
+                                                                        size_t per_run) {
   __shared__ double s_acc[4][64];
-  const int n_out = Cout * Cin * K * K;
   const int el = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const size_t e = (size_t)blockIdx.x * 64 + el;   // element of ws's per-run block (coalesced reads)
-  const size_t per_run = JJ ? (size_t)K * Cout * JJ : (size_t)n_out;
+  const int r0 = (int)blockIdx.y * kRedChunk, r1 = min(runs, r0 + kRedChunk);
   double acc = 0.0;
   if (e < per_run) {
-    int r = slice;
-    for (; r + 12 < runs; r += 16) {     // four independent loads in flight
+    int r = r0 + slice;
+    for (; r + 12 < r1; r += 16) {     // four independent loads in flight
       const float a0 = ws[(size_t)r * per_run + e], a1 = ws[(size_t)(r + 4) * per_run + e], a2 = ws[(size_t)(r + 8) * per_run + e],
                   a3 = ws[(size_t)(r + 12) * per_run + e];
       acc += (double)a0;
@@ -426,12 +429,22 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const fl
       acc += (double)a2;
       acc += (double)a3;
     }
-    for (; r < runs; r += 4) acc += (double)ws[(size_t)r * per_run + e];
+    for (; r < r1; r += 4) acc += (double)ws[(size_t)r * per_run + e];
   }
   s_acc[slice][el] = acc;
   __syncthreads();
   if (slice != 0 || e >= per_run) return;
-  acc = ((s_acc[0][el] + s_acc[1][el]) + s_acc[2][el]) + s_acc[3][el];
+  part2[(size_t)blockIdx.y * per_run + e] = ((s_acc[0][el] + s_acc[1][el]) + s_acc[2][el]) + s_acc[3][el];
+}
+
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const double* __restrict__ part2, float* __restrict__ dw, int chunks,
+                                                                       int K, int Cout, int Cin, int JJ) {
+  const int n_out = Cout * Cin * K * K;
+  const size_t e = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  const size_t per_run = JJ ? (size_t)K * Cout * JJ : (size_t)n_out;
+  if (e >= per_run) return;
+  double acc = 0.0;
+  for (int c = 0; c < chunks; ++c) acc += part2[(size_t)c * per_run + e];
   int co, ci, u, v;
   if (JJ) {
     const int jj = (int)(e % JJ);
@@ -657,7 +670,8 @@ int64_t eqa_conv_s2_wgrad_workspace_bytes(int B, int Cin, int H, int W, int Cout
   const long OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1, P = (long)B * OH * OW;
   const long per = wgrad_pix_per_wave(P), runs = (P + per - 1) / per;
   const long per_run = planar ? (long)K * Cout * (Cin * K <= 16 ? 16 : 32) : (long)K * K * Cout * Cin;
-  return runs * per_run * 4;
+  const long chunks = (runs + kRedChunk - 1) / kRedChunk;
+  return ((runs * per_run * 4 + 15) & ~15L) + chunks * per_run * 8;      // the runs' fp32 partials, then the chunks' fp64 ones
 }
 
 int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspace, int B, int Cin, int H, int W, int Cout, int K, int pad,
@@ -712,8 +726,13 @@ int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspac
   }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
   const size_t per_run = planar ? (size_t)K * Cout * jj : (size_t)K * K * Cout * Cin;
-  hipLaunchKernelGGL(conv_s2_wgrad_reduce_kernel, dim3((unsigned)((per_run + 63) / 64)), dim3(kThreads), 0, st, ws, dw, (int)runs, K, Cout,
-                     Cin, jj);
+  const int chunks = (int)((runs + kRedChunk - 1) / kRedChunk);
+  double* part2 = reinterpret_cast<double*>(static_cast<char*>(workspace) + (((size_t)runs * per_run * 4 + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(conv_s2_wgrad_partial_kernel, dim3((unsigned)((per_run + 63) / 64), (unsigned)chunks), dim3(kThreads), 0, st, ws, part2,
+                     (int)runs, per_run);
+  if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL(conv_s2_wgrad_reduce_kernel, dim3((unsigned)((per_run + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, part2, dw,
+                     chunks, K, Cout, Cin, jj);
   return launch_status();
 }
 

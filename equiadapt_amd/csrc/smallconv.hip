@@ -136,28 +136,65 @@ __global__ __launch_bounds__(kThreads) void conv_s2_planar_kernel(const float* _
 #pragma unroll
     for (int n = 0; n < NCO; ++n) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* wl = wp + lane;
+  if (PAD == 0) {
+    // Without padding the K taps of a filter row are K consecutive floats of the plane: one 16-byte load + one 4-byte load (K = 5),
+    // two 16-byte loads (K = 7) per tile and filter row instead of K dword gathers -- the kernel was bound by the number of wave loads the vector L1
+    // takes (25 x 4 dword gathers per wave at K = 5: 58 of its 117 us), not by bytes.
 #pragma unroll 1
-  for (int u = 0; u < K; ++u) {
-#pragma unroll
-    for (int v = 0; v < K; ++v) {
-      float a[kTiles], b[NCO];
-      const unsigned tap_off = (unsigned)((u * W + v) * 4);
+    for (int u = 0; u < K; ++u) {
+      float a[kTiles][K];
 #pragma unroll
       for (int t = 0; t < kTiles; ++t) {
-        unsigned off = base[t] + tap_off;
-        if (PAD > 0) {
-          const int iy = oy2[t] + u, ix = ox2[t] + v;
-          off = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? off : 0x7ffffff0u;
+        const unsigned off = has_ch ? base[t] + (unsigned)(u * W * 4) : 0x7ffffff0u;
+        if (K >= 4) {
+          const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+#pragma unroll
+          for (int v = 0; v < 4; ++v) a[t][v] = q[v];
         }
-        off = has_ch ? off : 0x7ffffff0u;
-        a[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+        if (K == 7) {                                  // taps 3 .. 6: a second 16-byte load ending exactly at the row's last tap
+          const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off + 12, 0, 0));
+#pragma unroll
+          for (int v = 4; v < 7; ++v) a[t][v] = q[v - 3];
+        } else if (K == 5) {
+          a[t][4] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off + 16, 0, 0));
+        } else {
+#pragma unroll
+          for (int v = 0; v < K; ++v) a[t][v] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off + 4 * v, 0, 0));
+        }
       }
 #pragma unroll
-      for (int n = 0; n < NCO; ++n) b[n] = wl[((u * K + v) * NCO + n) * 64];
+      for (int v = 0; v < K; ++v) {
+        float b[NCO];
 #pragma unroll
-      for (int t = 0; t < kTiles; ++t)
+        for (int n = 0; n < NCO; ++n) b[n] = wl[((u * K + v) * NCO + n) * 64];
 #pragma unroll
-        for (int n = 0; n < NCO; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n], acc[t][n], 0, 0, 0);
+        for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+          for (int n = 0; n < NCO; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t][v], b[n], acc[t][n], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll 1
+    for (int u = 0; u < K; ++u) {
+#pragma unroll
+      for (int v = 0; v < K; ++v) {
+        float a[kTiles], b[NCO];
+        const unsigned tap_off = (unsigned)((u * W + v) * 4);
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t) {
+          unsigned off = base[t] + tap_off;
+          const int iy = oy2[t] + u, ix = ox2[t] + v;
+          off = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? off : 0x7ffffff0u;
+          off = has_ch ? off : 0x7ffffff0u;
+          a[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+        }
+#pragma unroll
+        for (int n = 0; n < NCO; ++n) b[n] = wl[((u * K + v) * NCO + n) * 64];
+#pragma unroll
+        for (int t = 0; t < kTiles; ++t)
+#pragma unroll
+          for (int n = 0; n < NCO; ++n) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[n], acc[t][n], 0, 0, 0);
+      }
     }
   }
   conv_epilogue<NCO>(acc, bias, gelu, y, p0, P, 16 * NCO, lane);

@@ -248,8 +248,8 @@ int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, fl
  * custom_nonequivariant_networks.py:44-80 (Conv2d stride 2 -> BatchNorm2d -> GELU per layer; head BatchNorm1d -> Dropout1d -> ReLU):
  *   eqa_conv_s2_wgrad   dw:(Cout,Cin,K,K) = d/dW of eqa_conv_s2 given dz:(B,OH,OW,Cout) channels-last and the layer's input x (planar = 1:
  *                       (B,Cin<=4,H,W); else (B,H,W,Cin) channels-last) -- torch.nn.grad.conv2d_weight.  Reduction over the output pixels on
- *                       the matrix cores, partial sums per pixel run in `workspace` (eqa_conv_s2_wgrad_workspace_bytes), summed in run
- *                       order: deterministic, no atomics.
+ *                       the matrix cores, partial sums per pixel run in `workspace` (eqa_conv_s2_wgrad_workspace_bytes), summed in a
+ *                       fixed order (fp64: chunks of 128 runs, then the chunks): deterministic, no atomics.
  *   eqa_conv_s2_dgrad   dx:(B,H,W,Cin) = d/dx (channels-last layers only: the image needs no gradient) given dz and
  *                       wd:(K*K, Cout/16, Cin/16, 4, 16, 4) = w[16 cc + 4 kq + s][16 n + j][u][v] -- torch.nn.grad.conv2d_input.  Every
  *                       element of dx is written (pixels no tap reaches get 0).
