@@ -247,10 +247,11 @@ struct PixPos {
   int b, oy, ox;
 };
 __device__ __forceinline__ PixPos pix_pos(long p, int OH, int OW) {
-  PixPos r;
-  r.ox = (int)(p % OW);
-  r.oy = (int)((p / OW) % OH);
-  r.b = (int)(p / ((long)OW * OH));
+  PixPos r;                           // 32-bit divisions: p < 2^29 (dz is at most 2^31 bytes)
+  const unsigned q = (unsigned)p, row = q / (unsigned)OW;
+  r.ox = (int)(q - row * (unsigned)OW);
+  r.b = (int)(row / (unsigned)OH);
+  r.oy = (int)(row - (unsigned)r.b * (unsigned)OH);
   return r;
 }
 __device__ __forceinline__ void pix_advance(PixPos& r, int step, int OH, int OW) {
@@ -478,19 +479,25 @@ __device__ __forceinline__ void conv_s2_dgrad_class(const float* __restrict__ dz
   constexpr int TA = (K - U0 + 1) / 2, TC = (K - V0 + 1) / 2;       // taps per axis in this class
   constexpr int OY0 = (PY + PAD - U0) / 2, OX0 = (PX + PAD - V0) / 2;
   const int Hc = (H - PY + 1) / 2, Wc = (W - PX + 1) / 2;            // class pixels per column / row
-  const long Q = (long)B * Hc * Wc;
-  const long q0 = wave * (16 * kDgTiles);
-  if (q0 >= Q || Hc <= 0 || Wc <= 0) return;
+  if (Hc <= 0 || Wc <= 0) return;
+  // 32-bit index arithmetic (the host checks B * H * W < 2^31): a 64-bit division is ~100 instructions, and the first version spent
+  // 60 of them per wave (three per tile up front, three per stored row) next to 64-144 matrix instructions
+  const unsigned Q = (unsigned)B * (unsigned)Hc * (unsigned)Wc;
+  const unsigned q0 = (unsigned)wave * (16 * kDgTiles);
+  if (q0 >= Q) return;
   const int lane = threadIdx.x & 63;
   const int i = lane & 15, kq = lane >> 4;
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
   int yh[kDgTiles], xh[kDgTiles], bb[kDgTiles];
+  int opix[kDgTiles];                                                 // this lane's pixel of the tile: its index in dx (pixels)
 #pragma unroll
   for (int t = 0; t < kDgTiles; ++t) {
-    const long q = min(q0 + 16 * t + i, Q - 1);
-    xh[t] = (int)(q % Wc);
-    yh[t] = (int)((q / Wc) % Hc);
-    bb[t] = (int)(q / ((long)Wc * Hc));
+    const unsigned q = min(q0 + 16 * t + i, Q - 1);
+    const unsigned row = q / (unsigned)Wc;
+    xh[t] = (int)(q - row * (unsigned)Wc);
+    bb[t] = (int)(row / (unsigned)Hc);
+    yh[t] = (int)(row - (unsigned)bb[t] * (unsigned)Hc);
+    opix[t] = (bb[t] * H + PY + 2 * yh[t]) * W + PX + 2 * xh[t];
   }
   f32x4 acc[kDgTiles][NCI];
 #pragma unroll
@@ -510,7 +517,7 @@ __device__ __forceinline__ void conv_s2_dgrad_class(const float* __restrict__ dz
         for (int t = 0; t < kDgTiles; ++t) {
           const int oy = yh[t] + OY0 - a, ox = xh[t] + OX0 - c;
           const bool ok = oy >= 0 && oy < OH && ox >= 0 && ox < OW;
-          const unsigned off = (unsigned)((((long)bb[t] * OH + oy) * OW + ox) * Cout + 16 * cc + 4 * kq) * 4u;
+          const unsigned off = (unsigned)(((bb[t] * OH + oy) * OW + ox) * Cout + 16 * cc + 4 * kq) * 4u;
           av[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gr, ok ? off : kOob, 0, 0));
         }
 #pragma unroll
@@ -524,17 +531,15 @@ __device__ __forceinline__ void conv_s2_dgrad_class(const float* __restrict__ dz
       }
     }
   }
-  // D[i = 4 rq + r][j]: pixel q0 + 16 t + 4 rq + r, channel 16 n + j
+  // D[i = 4 rq + r][j]: pixel q0 + 16 t + 4 rq + r, channel 16 n + j; that pixel's place in dx is held by lane 4 rq + r
   const int jj = lane & 15, rq = lane >> 4;
 #pragma unroll
   for (int t = 0; t < kDgTiles; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const long q = q0 + 16 * t + 4 * rq + r;
-      if (q >= Q) continue;
-      const int x2 = (int)(q % Wc), y2 = (int)((q / Wc) % Hc);
-      const long b2 = q / ((long)Wc * Hc);
-      float* o = dx + (((b2 * H + PY + 2 * y2) * W + PX + 2 * x2) * (long)Cin);
+      const int pix = __builtin_amdgcn_ds_bpermute((4 * rq + r) * 4, opix[t]);
+      if (q0 + 16 * t + 4 * rq + r >= Q) continue;
+      float* o = dx + (size_t)pix * Cin;
 #pragma unroll
       for (int n = 0; n < NCI; ++n) o[16 * n + jj] = acc[t][n][r];
     }
@@ -746,7 +751,9 @@ int eqa_conv_s2_dgrad(const float* dz, const float* wd, float* dx, int B, int Ci
   if (!dz || !wd || !dx) return EQA_ERR_INVALID_ARG;
   const int OH = (H + 2 * pad - K) / 2 + 1, OW = (W + 2 * pad - K) / 2 + 1;
   const size_t gbytes = (size_t)B * OH * OW * Cout * 4, xbytes = (size_t)B * H * W * Cin * 4;
-  if (gbytes > 0x7fffffe0ULL || xbytes > 0x7fffffffffULL || (((uintptr_t)dz | (uintptr_t)wd | (uintptr_t)dx) & 15)) return EQA_ERR_UNSUPPORTED;
+  if (gbytes > 0x7fffffe0ULL || xbytes > 0x7fffffffffULL || (size_t)B * H * W > 0x7fffffffULL ||
+      (((uintptr_t)dz | (uintptr_t)wd | (uintptr_t)dx) & 15))
+    return EQA_ERR_UNSUPPORTED;
   const long Qmax = (long)B * ((H + 1) / 2) * ((W + 1) / 2);        // the largest parity class
   const long waves = (Qmax + 16 * kDgTiles - 1) / (16 * kDgTiles);
   const dim3 grid((unsigned)((waves + kThreads / 64 - 1) / (kThreads / 64)), 4);

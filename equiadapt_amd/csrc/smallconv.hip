@@ -64,9 +64,11 @@ __global__ __launch_bounds__(kThreads) void conv_s2_nhwc_kernel(const float* __r
   int oy2[kTiles], ox2[kTiles];
 #pragma unroll
   for (int t = 0; t < kTiles; ++t) {
-    const long p = min(p0 + 16 * t + i, P - 1);
-    const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
-    const long b = p / ((long)OW * OH);
+    const unsigned p = (unsigned)min(p0 + 16 * t + i, P - 1);        // 32-bit divisions (P < 2^31: checked by the host)
+    const unsigned row = p / (unsigned)OW;
+    const int ox = (int)(p - row * (unsigned)OW);
+    const long b = row / (unsigned)OH;
+    const int oy = (int)(row - (unsigned)b * (unsigned)OH);
     oy2[t] = 2 * oy - PAD;
     ox2[t] = 2 * ox - PAD;
     base[t] = (unsigned)((((b * H + oy2[t]) * W + ox2[t]) * Cin + 4 * kq) * 4);
@@ -123,9 +125,11 @@ __global__ __launch_bounds__(kThreads) void conv_s2_planar_kernel(const float* _
   int oy2[kTiles], ox2[kTiles];
 #pragma unroll
   for (int t = 0; t < kTiles; ++t) {
-    const long p = min(p0 + 16 * t + i, P - 1);
-    const int ox = (int)(p % OW), oy = (int)((p / OW) % OH);
-    const long b = p / ((long)OW * OH);
+    const unsigned p = (unsigned)min(p0 + 16 * t + i, P - 1);
+    const unsigned row = p / (unsigned)OW;
+    const int ox = (int)(p - row * (unsigned)OW);
+    const long b = row / (unsigned)OH;
+    const int oy = (int)(row - (unsigned)b * (unsigned)OH);
     oy2[t] = 2 * oy - PAD;
     ox2[t] = 2 * ox - PAD;
     base[t] = has_ch ? (unsigned)((((b * Cin + kq) * H + oy2[t]) * W + ox2[t]) * 4) : 0x7ffffff0u;   // missing channel: zero
@@ -253,6 +257,7 @@ int eqa_conv_s2(const float* x, const float* wp, const float* bias, int gelu, fl
   const size_t xbytes = (size_t)B * Cin * H * W * 4;
   if (xbytes > 0x7fffffe0ULL || (((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15)) return EQA_ERR_UNSUPPORTED;
   const long P = (long)B * OH * OW;
+  if (P > 0x7fffffffL) return EQA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const unsigned xb = (unsigned)xbytes;
 #define EQA_SC_K(KK)                                                                                                                  \
