@@ -56,8 +56,10 @@ __global__ __launch_bounds__(kThreads) void bn_relu_dropout_nhwc_kernel(const fl
                                                                        const float* __restrict__ shift, float* __restrict__ y,
                                                                        size_t nquad, int Q, uint32_t drop_threshold,
                                                                        float inv_keep, uint32_t seed) {
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
-    const int q = (int)(i % Q);
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x, stride = (size_t)gridDim.x * kThreads;
+  QuadWalk w(i0, stride, Q);
+  for (size_t i = i0; i < nquad; i += stride, w.next()) {
+    const int q = (int)w.q;
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     float o[4] = {fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f), fmaxf(v.z * sc.z + sh.z, 0.f),
@@ -92,8 +94,8 @@ struct WsGradGeom {
 };
 __device__ __forceinline__ int ws_cls(int i, int n, int nb) { return i < nb ? i : (i >= n - nb ? i - (n - nb) + nb + 1 : nb); }
 __device__ __forceinline__ size_t ws_table_quad(size_t p, int q, int Q, const WsGradGeom& g) {   // pixel index -> quad index in the table
-  const unsigned hw = (unsigned)g.H * (unsigned)g.W;
-  const unsigned b = (unsigned)(p / hw), r = (unsigned)(p - (size_t)b * hw);
+  const unsigned hw = (unsigned)g.H * (unsigned)g.W, pp = (unsigned)p;      // B * H * W < 2^31: checked by the host; 32-bit divisions
+  const unsigned b = pp / hw, r = pp - b * hw;
   const unsigned y = r / (unsigned)g.W, x = r - y * (unsigned)g.W;
   const unsigned T = 2 * g.nb + 1;
   return ((size_t)(b * T + ws_cls((int)y, g.H, g.nb)) * T + ws_cls((int)x, g.W, g.nb)) * Q + q;
@@ -167,9 +169,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_nhwc_kernel(const float
                                                                     float inv_keep, float* __restrict__ dx, size_t nquad, int Q,
                                                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     uint32_t drop_threshold, uint32_t seed, WsGradGeom geom) {
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
-    const int q = (int)(i % Q);
-    const float4 g4 = reinterpret_cast<const float4*>(gy)[TABLE ? ws_table_quad(i / Q, q, Q, geom) : i];
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x, stride = (size_t)gridDim.x * kThreads;
+  QuadWalk w(i0, stride, Q);
+  for (size_t i = i0; i < nquad; i += stride, w.next()) {
+    const int q = (int)w.q;
+    const float4 g4 = reinterpret_cast<const float4*>(gy)[TABLE ? ws_table_quad(w.row, q, Q, geom) : i];
     const float4 x4 = reinterpret_cast<const float4*>(x)[i];
     bool live[4];
     if (RECOMPUTE) {

@@ -42,11 +42,13 @@ template <int ACT>
 __global__ __launch_bounds__(kThreads) void bn_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const float* __restrict__ rowscale,
                                                              float* __restrict__ y, size_t nquad, int Q) {
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
-    const int q = (int)(i % Q);
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x, stride = (size_t)gridDim.x * kThreads;
+  QuadWalk w(i0, stride, Q);
+  for (size_t i = i0; i < nquad; i += stride, w.next()) {
+    const int q = (int)w.q;
     const float4 v = reinterpret_cast<const float4*>(z)[i];
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
-    const float r = rowscale ? rowscale[i / Q] : 1.0f;
+    const float r = rowscale ? rowscale[w.row] : 1.0f;
     reinterpret_cast<float4*>(y)[i] = make_float4(r * act_fwd(ACT, v.x * sc.x + sh.x), r * act_fwd(ACT, v.y * sc.y + sh.y),
                                                   r * act_fwd(ACT, v.z * sc.z + sh.z), r * act_fwd(ACT, v.w * sc.w + sh.w));
   }
@@ -219,15 +221,17 @@ __global__ __launch_bounds__(kThreads) void bn_act_bwd_apply_kernel(const float*
                                                                    const float* __restrict__ rowscale, const float* __restrict__ gscale,
                                                                    const float* __restrict__ m1, const float* __restrict__ m2,
                                                                    float* __restrict__ dz, size_t nquad, int Q) {
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nquad; i += (size_t)gridDim.x * kThreads) {
-    const int q = (int)(i % Q);
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x, stride = (size_t)gridDim.x * kThreads;
+  QuadWalk w(i0, stride, Q);
+  for (size_t i = i0; i < nquad; i += stride, w.next()) {
+    const int q = (int)w.q;
     const float4 g4 = reinterpret_cast<const float4*>(gy)[i];
     const float4 v = reinterpret_cast<const float4*>(z)[i];
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     const float4 mu = reinterpret_cast<const float4*>(mean)[q], rs = reinterpret_cast<const float4*>(rstd)[q];
     const float4 gs = reinterpret_cast<const float4*>(gscale)[q], a1 = reinterpret_cast<const float4*>(m1)[q],
                  a2 = reinterpret_cast<const float4*>(m2)[q];
-    const float r = rowscale ? rowscale[i / Q] : 1.0f;
+    const float r = rowscale ? rowscale[w.row] : 1.0f;
     float4 o;
     o.x = gs.x * (g4.x * r * act_grad(ACT, v.x * sc.x + sh.x) - a1.x - (v.x - mu.x) * rs.x * a2.x);
     o.y = gs.y * (g4.y * r * act_grad(ACT, v.y * sc.y + sh.y) - a1.y - (v.y - mu.y) * rs.y * a2.y);

@@ -43,6 +43,31 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 }
 #undef EQA_DPP_ADD
 
+
+// (i % Q, i / Q) along a grid-stride loop without a division per trip.  The loops used `i % Q` on a size_t index: a 64-bit division
+// is ~100 vector instructions -- more than the 16 bytes of data a trip moves are worth.  One 32-bit division pair at the start (the
+// first index and the stride are below 2^32 for every launch in this library: <= 2^20 threads), additions with a carry afterwards.
+struct QuadWalk {
+  unsigned q, dq, Q;
+  size_t row, drow;
+  __device__ __forceinline__ QuadWalk(size_t i0, size_t stride, int Q_) {
+    Q = (unsigned)Q_;
+    const unsigned i = (unsigned)i0, st = (unsigned)stride;
+    row = i / Q;
+    q = i - (unsigned)row * Q;
+    drow = st / Q;
+    dq = st - (unsigned)drow * Q;
+  }
+  __device__ __forceinline__ void next() {
+    q += dq;
+    row += drow;
+    if (q >= Q) {
+      q -= Q;
+      ++row;
+    }
+  }
+};
+
 extern int g_vn_kernel_choice;  // pointcloud.hip; eqa_set_option key 1
 extern int g_cgemm_bf16_form;   // cgemm3m_bf16.hip; eqa_set_option key 2
 

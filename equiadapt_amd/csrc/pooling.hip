@@ -178,8 +178,10 @@ __global__ __launch_bounds__(kThreads) void window_sums_kernel(const float* __re
 __global__ __launch_bounds__(kThreads) void bias_relu_nhwc_kernel(float* __restrict__ x, const float* __restrict__ bias,
                                                                  size_t n_vec, int C4) {
   const size_t stride = (size_t)gridDim.x * kThreads;
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n_vec; i += stride) {
-    const int c4 = (int)(i % (size_t)C4);
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x;
+  QuadWalk w(i0, stride, C4);
+  for (size_t i = i0; i < n_vec; i += stride, w.next()) {
+    const int c4 = (int)w.q;
     float4 v = reinterpret_cast<float4*>(x)[i];
     const float4 b = reinterpret_cast<const float4*>(bias)[c4];
     v.x = fmaxf(v.x + b.x, 0.f); v.y = fmaxf(v.y + b.y, 0.f); v.z = fmaxf(v.z + b.z, 0.f); v.w = fmaxf(v.w + b.w, 0.f);
@@ -533,8 +535,10 @@ __global__ __launch_bounds__(THREADS) void sums_gemv_kernel(const double* __rest
 __global__ __launch_bounds__(kThreads) void affine_relu_rows_kernel(const float* __restrict__ h, const float* __restrict__ scale,
                                                                    const float* __restrict__ shift, float* __restrict__ z, size_t n_vec,
                                                                    int Dq) {
-  for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * kThreads) {
-    const int q = (int)(i % Dq);
+  const size_t i0 = (size_t)blockIdx.x * kThreads + threadIdx.x, stride = (size_t)gridDim.x * kThreads;
+  QuadWalk w(i0, stride, Dq);
+  for (size_t i = i0; i < n_vec; i += stride, w.next()) {
+    const int q = (int)w.q;
     const float4 v = reinterpret_cast<const float4*>(h)[i];
     const float4 sc = reinterpret_cast<const float4*>(scale)[q], sh = reinterpret_cast<const float4*>(shift)[q];
     reinterpret_cast<float4*>(z)[i] = make_float4(fmaxf(v.x * sc.x + sh.x, 0.f), fmaxf(v.y * sc.y + sh.y, 0.f),
