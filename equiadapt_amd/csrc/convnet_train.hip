@@ -25,6 +25,12 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr unsigned kOob = 0x7ffffff0u;   // a buffer offset outside every buffer: the load returns zero
+// ok ? off : kOob without a branch: the compiler turns the ternary into an exec-mask region when `off` is a few instructions of
+// arithmetic, and a region boundary between matrix instructions makes it copy their accumulators between the register files
+__device__ __forceinline__ unsigned off_or_oob(bool ok, unsigned off) {
+  const unsigned m = 0u - (unsigned)ok;
+  return (off & m) | (kOob & ~m);
+}
 
 __device__ __forceinline__ float act_fwd(int act, float h) {
   return act == 0 ? 0.5f * h * (1.0f + erff(h * 0.70710678118654752440f)) : fmaxf(h, 0.0f);
@@ -258,15 +264,24 @@ __device__ __forceinline__ PixPos pix_pos(long p, int OH, int OW) {
   r.oy = (int)(row - (unsigned)r.b * (unsigned)OH);
   return r;
 }
-__device__ __forceinline__ void pix_advance(PixPos& r, int step, int OH, int OW) {
-  r.ox += step;
-  while (r.ox >= OW) {
-    r.ox -= OW;
-    if (++r.oy == OH) {
-      r.oy = 0;
-      ++r.b;
-    }
-  }
+// branch-free (a loop with a data-dependent trip count between two groups of matrix instructions splits the block they live in, and
+// the accumulators carried across the split get copied between the register files): quotients by OW / OH through their 32-bit
+// reciprocals m = floor(2^32 / d) + 1, exact for operands below 2^16
+struct PixStep {
+  unsigned m_ow, m_oh, one_ow, one_oh;     // one_*: all ones when the divisor is 1 (its reciprocal does not fit 32 bits: quotient = operand)
+  int OH, OW;
+};
+__device__ __forceinline__ PixStep pix_step(int OH, int OW) {
+  return PixStep{0xffffffffu / (unsigned)OW + 1u, 0xffffffffu / (unsigned)OH + 1u, 0u - (unsigned)(OW == 1), 0u - (unsigned)(OH == 1), OH, OW};
+}
+__device__ __forceinline__ void pix_advance(PixPos& r, int step, const PixStep& g) {
+  const unsigned x = (unsigned)(r.ox + step);
+  const unsigned cx = (__umulhi(x, g.m_ow) & ~g.one_ow) | (x & g.one_ow);
+  r.ox = (int)(x - cx * (unsigned)g.OW);
+  const unsigned y = (unsigned)r.oy + cx;
+  const unsigned cy = (__umulhi(y, g.m_oh) & ~g.one_oh) | (y & g.one_oh);
+  r.oy = (int)(y - cy * (unsigned)g.OH);
+  r.b += (int)cy;
 }
 
 // NHWC input, Cin = 16 CH.  x:(B,H,W,Cin), dz:(B,OH,OW,Cout).  grid (pixel runs, K / ROWS filter-row groups, Cout / 16 channel
@@ -281,9 +296,12 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
   const int j = lane & 15, kq = lane >> 4;
   const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   const int u0 = blockIdx.y * ROWS, n = blockIdx.z;
-  const long p_begin = run * pix_per_wave;
-  if (p_begin >= P) return;
-  const long p_end = min(P, p_begin + pix_per_wave);
+  if (run * pix_per_wave >= P) return;
+  // 32-bit pixel indices (P < 2^29: dz is at most 2^31 bytes): with 64-bit ones the compiler put the address arithmetic of a dead
+  // slot under a branch, and accumulators carried across that branch were copied between the register files around every matrix
+  // instruction (148 + 148 v_accvgpr copies per 100 matrix instructions)
+  const int p_begin = (int)(run * pix_per_wave);
+  const int p_end = (int)min(P, (long)p_begin + pix_per_wave);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
   f32x4 acc[ROWS][K][CH];
@@ -297,15 +315,16 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
   PixPos pos[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
+  const PixStep pstep = pix_step(OH, OW);
 #pragma unroll 1
-  for (long p = p_begin; p < p_end; p += kWgIter) {
+  for (int p = p_begin; p < p_end; p += kWgIter) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const long ps = p + 4 * s + kq;
+      const int ps = p + 4 * s + kq;
       const bool live = ps < p_end;
-      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off_or_oob(live, (unsigned)(ps * Cout + 16 * n + j) * 4u), 0, 0));
       const int iy0 = 2 * pos[s].oy - PAD + u0, ix0 = 2 * pos[s].ox - PAD;
-      const unsigned base0 = (unsigned)((((long)pos[s].b * H + iy0) * W + ix0) * Cin + j) * 4u;
+      const unsigned base0 = (unsigned)(((pos[s].b * H + iy0) * W + ix0) * Cin + j) * 4u;
 #pragma unroll
       for (int ur = 0; ur < ROWS; ++ur) {
         const bool row_ok = live && (PAD == 0 || (iy0 + ur >= 0 && iy0 + ur < H));
@@ -315,14 +334,14 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
           const bool ok = row_ok && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
 #pragma unroll
           for (int c = 0; c < CH; ++c)
-            b[v][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? base0 + (unsigned)((ur * W + v) * Cin + 16 * c) * 4u : kOob, 0, 0));
+            b[v][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off_or_oob(ok, base0 + (unsigned)((ur * W + v) * Cin + 16 * c) * 4u), 0, 0));
         }
 #pragma unroll
         for (int v = 0; v < K; ++v)
 #pragma unroll
           for (int c = 0; c < CH; ++c) acc[ur][v][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[v][c], acc[ur][v][c], 0, 0, 0);
       }
-      pix_advance(pos[s], kWgIter, OH, OW);
+      pix_advance(pos[s], kWgIter, pstep);
     }
   }
   // D[i = 4 kq + r][j]: co = 16 n + 4 kq + r, ci = 16 c + j
@@ -350,9 +369,9 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
   const int j = lane & 15, kq = lane >> 4;
   const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
   const int n = blockIdx.z;
-  const long p_begin = run * pix_per_wave;
-  if (p_begin >= P) return;
-  const long p_end = min(P, p_begin + pix_per_wave);
+  if (run * pix_per_wave >= P) return;
+  const int p_begin = (int)(run * pix_per_wave);          // 32-bit indices: see conv_s2_wgrad_nhwc_kernel
+  const int p_end = (int)min(P, (long)p_begin + pix_per_wave);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
   // this lane's columns: jj = 16 t + j -> (ci, v)
@@ -373,27 +392,28 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
   PixPos pos[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
+  const PixStep pstep = pix_step(OH, OW);
 #pragma unroll 1
-  for (long p = p_begin; p < p_end; p += kWgIter) {
+  for (int p = p_begin; p < p_end; p += kWgIter) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const long ps = p + 4 * s + kq;
+      const int ps = p + 4 * s + kq;
       const bool live = ps < p_end;
-      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, live ? (unsigned)(ps * Cout + 16 * n + j) * 4u : kOob, 0, 0));
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off_or_oob(live, (unsigned)(ps * Cout + 16 * n + j) * 4u), 0, 0));
       const int iy0 = 2 * pos[s].oy - PAD, ix0 = 2 * pos[s].ox - PAD;
       float b[K][NJ];
 #pragma unroll
       for (int t = 0; t < NJ; ++t) {
         const int ix = ix0 + lv[t];
         const bool col_ok = live && lhas[t] && (PAD == 0 || (ix >= 0 && ix < W));
-        const unsigned off0 = (unsigned)((((long)pos[s].b * Cin + lci[t]) * H + iy0) * W + ix) * 4u;
+        const unsigned off0 = (unsigned)(((pos[s].b * Cin + lci[t]) * H + iy0) * W + ix) * 4u;
 #pragma unroll
         for (int u = 0; u < K; ++u) {
           const bool ok = col_ok && (PAD == 0 || (iy0 + u >= 0 && iy0 + u < H));
-          b[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, ok ? off0 + (unsigned)(u * W) * 4u : kOob, 0, 0));
+          b[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off_or_oob(ok, off0 + (unsigned)(u * W) * 4u), 0, 0));
         }
       }
-      pix_advance(pos[s], kWgIter, OH, OW);
+      pix_advance(pos[s], kWgIter, pstep);
 #pragma unroll
       for (int u = 0; u < K; ++u)
 #pragma unroll
@@ -565,8 +585,14 @@ __global__ __launch_bounds__(kThreads) void conv_s2_dgrad_nhwc_kernel(const floa
 int wgrad_pix_per_wave(long P) {
   // ~4096 runs: a wave is a chain of dependent round trips (dword operand loads), so the chip wants several waves per SIMD; every run
   // costs one partial filter in the workspace and one term of the (parallel) reduction.  Runs of >= 128 pixels, a multiple of the trip
-  long per = (P + 4095) / 4096;
-  per = std::max(128L, std::min(16384L, per));
+#ifndef EQA_WG_RUNS
+#define EQA_WG_RUNS 4096
+#endif
+#ifndef EQA_WG_MINPIX
+#define EQA_WG_MINPIX 128
+#endif
+  long per = (P + EQA_WG_RUNS - 1) / EQA_WG_RUNS;
+  per = std::max((long)EQA_WG_MINPIX, std::min(16384L, per));
   return (int)((per + kWgIter - 1) / kWgIter * kWgIter);
 }
 
