@@ -30,6 +30,8 @@
 // Work: wave-tile = (frequency, 64 rows, 64 complex columns); the 4 waves of a block take the column tiles of one (f, row tile)
 // (they share the rows of V through L1 / L2); the frequencies are dealt to the XCDs (f mod 8, block b runs on XCD b mod 8) so that a
 // frequency's B panel (0.79 MB at 256 channels) is read from HBM once and then served by that XCD's L2 to its 16 row tiles.
+#include <type_traits>
+
 #include "eqa_common.hpp"
 
 namespace {
@@ -83,7 +85,11 @@ __device__ __forceinline__ void load_stage(OperandSet& o, const StageAddr& at, u
   }
 }
 
+// FIRST: the tile's first K-stage -- the first product into each accumulator starts from zero, so no accumulator is ever cleared
+// (clearing them was 2 x 192 v_accvgpr_write per tile in front of the matrix stream: the compiler emitted the loop twice)
+template <bool FIRST = false>
 __device__ __forceinline__ void mma_stage(const OperandSet& o, f32x16 (&acc)[3][2][2]) {
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const f32x4 as0 = o.ar[0][b] + o.ai[0][b], as1 = o.ar[1][b] + o.ai[1][b];
@@ -94,9 +100,10 @@ __device__ __forceinline__ void mma_stage(const OperandSet& o, f32x16 (&acc)[3][
         const float ar = o.ar[m][b][t], ai = o.ai[m][b][t], as = (m ? as1 : as0)[t];
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
-          acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, o.b[0][n][b][t], acc[0][m][n], 0, 0, 0);
-          acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, o.b[1][n][b][t], acc[1][m][n], 0, 0, 0);
-          acc[2][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, o.b[2][n][b][t], acc[2][m][n], 0, 0, 0);
+          const bool fresh = FIRST && b == 0 && t == 0;
+          acc[0][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar, o.b[0][n][b][t], fresh ? zero : acc[0][m][n], 0, 0, 0);
+          acc[1][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, o.b[1][n][b][t], fresh ? zero : acc[1][m][n], 0, 0, 0);
+          acc[2][m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, o.b[2][n][b][t], fresh ? zero : acc[2][m][n], 0, 0, 0);
         }
       }
     }
@@ -130,7 +137,7 @@ __device__ __forceinline__ void flush_rows(const float* lds_lane, const ParkedDs
 // One K-stage: request the next stage's operands, send NPAIR row pairs of the parked tile on their way, 96 MFMAs -- as ONE
 // scheduling region whose instruction order is then pinned: the LDS reads first, one global load behind every third MFMA (a run of
 // 20 loads would stall the in-order wave for ~300 cycles with the matrix pipe drained), the stores further down.
-template <int NPAIR>
+template <int NPAIR, bool FIRST = false>
 __device__ __forceinline__ void run_stage(OperandSet& nxt, const OperandSet& cur, f32x16 (&acc)[3][2][2], const StageAddr& at,
                                           unsigned aoff0, unsigned aoff1, unsigned boff, const float* lds_lane, const ParkedDst& dst,
                                           int p0) {
@@ -138,7 +145,7 @@ __device__ __forceinline__ void run_stage(OperandSet& nxt, const OperandSet& cur
 #pragma unroll
   for (int k = 0; k < NPAIR; ++k) park[k] = *reinterpret_cast<const f32x4*>(lds_lane + (p0 + k) * (2 * kLdsRowFloats));
   load_stage(nxt, at, aoff0, aoff1, boff);
-  mma_stage(cur, acc);
+  mma_stage<FIRST>(cur, acc);
 #pragma unroll
   for (int k = 0; k < NPAIR; ++k) store_pair(dst, p0 + k, park[k]);
 #ifndef EQA_CGEMM_NOPIN
@@ -225,28 +232,21 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
   load_stage(s0, at, aoff0, aoff1, boff);
   for (int u = q; u < total; u += waves_per_xcd) {
     CG_STAMP(c0);
-    f32x16 acc[3][2][2];
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[p][m][n][e] = 0.f;
+    f32x16 acc[3][2][2];      // never cleared: the first stage's products start from zero (mma_stage<true>)
     // the tile after this one (or this one again when it is the last: a harmless reload instead of a conditional load)
     const int un = u + waves_per_xcd < total ? u + waves_per_xcd : u;
     StageAddr nat;
     unsigned naoff0, naoff1;
     int nf, nrow0, nct;
     locate(un, nat, naoff0, naoff1, nf, nrow0, nct);
-    for (int s = 0; s < S; s += 2) {
-      // the scheduling barriers keep the next stage's loads INSIDE this stage's MFMA stream: left alone, the compiler sinks them
-      // to their first use (the next stage) to save registers and every stage starts with an exposed HBM round trip
+    // two K-stages; the scheduling barriers keep the next stage's loads INSIDE this stage's MFMA stream: left alone, the compiler
+    // sinks them to their first use (the next stage) to save registers and every stage starts with an exposed HBM round trip
+    auto stage_pair = [&](int s, auto first_tag) {
+      constexpr bool kFirst = decltype(first_tag)::value;
       const bool more = s + 2 < S;
       if (NPAIR > 0) {
         __builtin_amdgcn_sched_barrier(0);
-        run_stage<NPAIR>(s1, s0, acc, at_stage(at, s + 1), aoff0, aoff1, boff, lds_lane, dst, s * NPAIR);
+        run_stage<NPAIR, kFirst>(s1, s0, acc, at_stage(at, s + 1), aoff0, aoff1, boff, lds_lane, dst, s * NPAIR);
         __builtin_amdgcn_sched_barrier(0);
         run_stage<NPAIR>(s0, s1, acc, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff, lds_lane, dst,
                          (s + 1) * NPAIR);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
         load_stage(s1, at_stage(at, s + 1), aoff0, aoff1, boff);
         flush_rows(lds_lane, dst, (32 * s) / S, (32 * (s + 1)) / S);
         __builtin_amdgcn_sched_barrier(0);
-        mma_stage(s0, acc);
+        mma_stage<kFirst>(s0, acc);
         __builtin_amdgcn_sched_barrier(0);
         load_stage(s0, more ? at_stage(at, s + 2) : nat, more ? aoff0 : naoff0, more ? aoff1 : naoff1, boff);
         flush_rows(lds_lane, dst, (32 * (s + 1)) / S, (32 * (s + 2)) / S);
@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_kernel(const float* __rest
         mma_stage(s1, acc);
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+    };
+    stage_pair(0, std::true_type{});
+    for (int s = 2; s < S; s += 2) stage_pair(s, std::false_type{});
     CG_STAMP(c1);
     // epilogue: Cr = T1 - T2, Ci = T3 - T1 - T2 into the wave's LDS tile [row][complex column]; accumulator register e of lane
     // (h, j) is row (e & 3) + 8 (e >> 2) + 4 h, column j of its 32 x 32 block.  (All of the previous tile's rows have left the
