@@ -870,6 +870,18 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ga2_ms = e0.elapsed_time(e1) / reps
+            # the same bytes through the framework's plain copy, same loop on the same two tensors: what a launch that reads and
+            # writes 2 x 154 MB reaches on this chip at all (8 TB/s is the memory's rating, not a kernel's)
+            for _ in range(10):
+                x.clone(), f.clone()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                x.clone()
+                f.clone()
+            e1.record()
+            torch.cuda.synchronize()
+            ga_copy_ms = e0.elapsed_time(e1) / reps
             # the same two jobs in ONE launch (eqa_group_action_pair: job 1's first blocks fill the CUs job 0's tail leaves idle)
             for _ in range(10):
                 ops.group_action_pair(x, f, gidx, th_c, fl_c, H // 2, th_i, fl_i, None)
@@ -920,7 +932,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "group_action_kernel<3,true> via eqa_canon_transform_fwd",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_unit": f"bytes/launch (rocprofv3 PMC, {tsrc})", "traffic_source": tstate,
-                         "launches_timed": n_ct, "avg_launch_ms": ms_ct, "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM},
+                         "launches_timed": n_ct, "avg_launch_ms": ms_ct, "algorithmic_bytes_per_launch": B * BYTES_TRANSFORM,
+                         "frac_of_copy": ga_copy_ms / ga2_ms,
+                         "frac_of_copy_note": "torch's clone() of the same bytes / this kernel, both back to back on the same tensors (the "
+                                              "`group_action` leg: canonicalize + invert vs clone(x) + clone(f)): the share of a plain copy's "
+                                              "rate the kernel reaches -- 8 TB/s is the memory's rating, a copy is what a launch can get"},
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
             "step_ms_by_gemm_form": {**step_forms, "note": "the whole timed step with the complex GEMM as: f32 = v_mfma_f32_32x32x2_f32 (default, `value`); "
                                      "9 / 6 = bf16 matrix cores on exact three-piece splits with nine / six piece products (opt-in)"},
@@ -928,6 +944,7 @@ def main():
                              "achieved_GBs": ga_bytes / (ga2_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                              "pair_launch_ms": ga_ms, "pair_launch_frac_hbm_peak": ga_bytes / (ga_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "copy_same_bytes_ms": ga_copy_ms, "frac_of_copy": ga_copy_ms / ga2_ms,
                              "note": "canonicalize x + invert f only, seeded random C8 index (all eight elements), back to back: "
                                      "ms / frac_hbm_peak = eqa_canon_transform_fwd then eqa_invert_action_fwd, the two launches the "
                                      "library's canonicalize / invert_canonicalization make (comparable with rounds 1-2); pair_launch_* = "
