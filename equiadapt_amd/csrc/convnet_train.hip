@@ -357,9 +357,9 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
   }
 }
 
-// planar input with Cin <= 4 (the first layer: NCHW views).  The 16 columns of a B tile are the (channel, filter column) pairs
-// jj = ci * K + v of one filter row (Cin * K <= 16 NJ); a wave owns all K filter rows, so dz -- the large operand of this layer -- is
-// read once.  x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [u], Cout, 16 NJ [jj]).  grid (pixel runs, 1, Cout / 16).
+// planar input with Cin <= 4 (the first layer: NCHW views).  The 16 columns of a B tile are the (channel, filter row) pairs
+// jj = ci * K + u of one filter COLUMN v (Cin * K <= 16 NJ); a wave owns all K filter columns, so dz -- the large operand of this layer
+// -- is read once.  x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [v], Cout, 16 NJ [jj]).  grid (pixel runs, 1, Cout / 16).
 template <int K, int NJ, int PAD>
 __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const float* __restrict__ x, const float* __restrict__ dz,
                                                                        float* __restrict__ ws, int Cin, int Cout, int H, int W, int OH,
@@ -374,21 +374,23 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
   const int p_end = (int)min(P, (long)p_begin + pix_per_wave);
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
-  // this lane's columns: jj = 16 t + j -> (ci, v)
-  int lci[NJ], lv[NJ];
+  // this lane's columns: jj = 16 t + j -> (ci, u): a lane owns one filter ROW of one channel, so the K taps it needs for a pixel are
+  // K consecutive floats of the plane -- one 16-byte load (+ one 4-byte / a second 16-byte load) instead of K dword gathers per
+  // pixel group (the kernel is bound by the number of wave loads: 6 per 5 matrix instructions before, 3 now)
+  int lci[NJ], lu[NJ];
   bool lhas[NJ];
 #pragma unroll
   for (int t = 0; t < NJ; ++t) {
     const int jj = 16 * t + j;
     lhas[t] = jj < Cin * K;
     lci[t] = lhas[t] ? jj / K : 0;
-    lv[t] = lhas[t] ? jj - lci[t] * K : 0;
+    lu[t] = lhas[t] ? jj - lci[t] * K : 0;
   }
-  f32x4 acc[K][NJ];
+  f32x4 acc[K][NJ];       // [v][t]
 #pragma unroll
-  for (int u = 0; u < K; ++u)
+  for (int v = 0; v < K; ++v)
 #pragma unroll
-    for (int t = 0; t < NJ; ++t) acc[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NJ; ++t) acc[v][t] = f32x4{0.f, 0.f, 0.f, 0.f};
   PixPos pos[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
@@ -404,29 +406,43 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
       float b[K][NJ];
 #pragma unroll
       for (int t = 0; t < NJ; ++t) {
-        const int ix = ix0 + lv[t];
-        const bool col_ok = live && lhas[t] && (PAD == 0 || (ix >= 0 && ix < W));
-        const unsigned off0 = (unsigned)(((pos[s].b * Cin + lci[t]) * H + iy0) * W + ix) * 4u;
+        const int iy = iy0 + lu[t];
+        const bool row_ok = live && lhas[t] && (PAD == 0 || (iy >= 0 && iy < H));
+        const unsigned off0 = (unsigned)(((pos[s].b * Cin + lci[t]) * H + iy) * W + ix0) * 4u;
+        if (PAD == 0 && K >= 4) {
+          const unsigned o = off_or_oob(row_ok, off0);
+          const f32x4 q = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o, 0, 0));
 #pragma unroll
-        for (int u = 0; u < K; ++u) {
-          const bool ok = col_ok && (PAD == 0 || (iy0 + u >= 0 && iy0 + u < H));
-          b[u][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off_or_oob(ok, off0 + (unsigned)(u * W) * 4u), 0, 0));
+          for (int v = 0; v < 4; ++v) b[v][t] = q[v];
+          if (K == 5) {
+            b[4][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o + 16, 0, 0));
+          } else if (K == 7) {       // taps 3 .. 6: a second 16-byte load ending exactly at the row's last tap
+            const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o + 12, 0, 0));
+#pragma unroll
+            for (int v = 4; v < 7; ++v) b[v][t] = q2[v - 3];
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < K; ++v) {
+            const bool ok = row_ok && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
+            b[v][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off_or_oob(ok, off0 + (unsigned)v * 4u), 0, 0));
+          }
         }
       }
       pix_advance(pos[s], kWgIter, pstep);
 #pragma unroll
-      for (int u = 0; u < K; ++u)
+      for (int v = 0; v < K; ++v)
 #pragma unroll
-        for (int t = 0; t < NJ; ++t) acc[u][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[u][t], acc[u][t], 0, 0, 0);
+        for (int t = 0; t < NJ; ++t) acc[v][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[v][t], acc[v][t], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int u = 0; u < K; ++u) {
-    float* o = ws + ((size_t)run * K + u) * (size_t)(Cout * 16 * NJ);
+  for (int v = 0; v < K; ++v) {
+    float* o = ws + ((size_t)run * K + v) * (size_t)(Cout * 16 * NJ);
 #pragma unroll
     for (int t = 0; t < NJ; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[(16 * n + 4 * kq + r) * (16 * NJ) + 16 * t + j] = acc[u][t][r];
+      for (int r = 0; r < 4; ++r) o[(16 * n + 4 * kq + r) * (16 * NJ) + 16 * t + j] = acc[v][t][r];
   }
 }
 
@@ -435,7 +451,7 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
 //   partial: block (64 consecutive elements of the per-run block, chunk of kRedChunk runs); its four waves take every fourth run of
 //            the chunk, the four slices are combined in order -> part2 (chunks, per_run) fp64
 //   final:   a thread per element adds the chunks in order and writes dw in the framework's order.
-// The result does not depend on the launch.   nhwc: ws (runs, K, K, Cout, Cin);   planar: ws (runs, K, Cout, JJ) with jj = ci * K + v
+// The result does not depend on the launch.   nhwc: ws (runs, K, K, Cout, Cin);   planar: ws (runs, K [v], Cout, JJ) with jj = ci * K + u
 constexpr int kRedChunk = 128;
 __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_partial_kernel(const float* __restrict__ ws, double* __restrict__ part2, int runs,
                                                                         size_t per_run) {
@@ -474,10 +490,10 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_reduce_kernel(const do
   if (JJ) {
     const int jj = (int)(e % JJ);
     co = (int)((e / JJ) % Cout);
-    u = (int)(e / ((size_t)JJ * Cout));
+    v = (int)(e / ((size_t)JJ * Cout));
     if (jj >= Cin * K) return;
     ci = jj / K;
-    v = jj - ci * K;
+    u = jj - ci * K;
   } else {
     ci = (int)(e % Cin);
     co = (int)((e / Cin) % Cout);
