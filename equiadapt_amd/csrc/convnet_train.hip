@@ -357,6 +357,100 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc_kernel(const floa
   }
 }
 
+// The same for Cin = 16 with the taps fetched four at a time: lane (j, kq) asks for the 16 bytes x[pixel kq][row][tap j / 4]
+// [channels 4 (j % 4) .. + 3] -- the 16 lanes of a pixel cover four consecutive taps (256 contiguous bytes) -- and matrix instruction e
+// of the group uses element e of every lane: D_e[co][j] = dW[co][ci = 4 (j % 4) + e][v = v0 + j / 4].  Four taps cost ONE wave load
+// instead of four (the kernel is bound by the number of wave loads the vector L1 takes, 26 per 25 matrix instructions before);
+// the accumulators just hold the filter in a permuted order, undone by the store.  K = 5: taps 0..3 by one such load, tap 4 by a
+// dword load (j = channel, as before); K = 7: taps 0..3 and 3..6 by two loads, the second with its first tap masked (lanes j < 4).
+// Launched with ROWS = 1 (a wave per filter row): with all five rows in one wave the register allocator rotates the 25 accumulator
+// tiles through the register files every trip (391 v_accvgpr copies) and the kernel is slower than the dword form (132 vs 92 us);
+// a row per wave runs the second layer as fast as that form and the third in 46 us instead of 66.
+template <int K, int PAD, int ROWS>
+__global__ __launch_bounds__(kThreads) void conv_s2_wgrad_nhwc16_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                                       float* __restrict__ ws, int Cout, int H, int W, int OH, int OW,
+                                                                       long P, int pix_per_wave, unsigned x_bytes, unsigned dz_bytes) {
+  static_assert(K == 5 || K == 7, "taps four at a time: 5 = 4 + 1, 7 = 4 + (1 masked +) 3");
+  constexpr int Cin = 16;
+  constexpr int NQ = K == 5 ? 1 : 2;           // 16-byte tap groups per filter row
+  const int lane = threadIdx.x & 63;
+  const int j = lane & 15, kq = lane >> 4;
+  const int jt = j >> 2, jc = j & 3;           // this lane's tap inside a group, its channel quad
+  const long run = (long)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  const int u0 = blockIdx.y * ROWS, n = blockIdx.z;
+  if (run * pix_per_wave >= P) return;
+  const int p_begin = (int)(run * pix_per_wave);
+  const int p_end = (int)min(P, (long)p_begin + pix_per_wave);
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, dz_bytes, 0x00020000);
+  f32x4 accq[ROWS][NQ][4];       // [row][tap group][e]
+  f32x4 acc1[ROWS];              // K = 5: tap 4
+#pragma unroll
+  for (int ur = 0; ur < ROWS; ++ur) {
+    acc1[ur] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NQ; ++g)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accq[ur][g][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  PixPos pos[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pos[s] = pix_pos(p_begin + 4 * s + kq, OH, OW);
+  const PixStep pstep = pix_step(OH, OW);
+#pragma unroll 1
+  for (int p = p_begin; p < p_end; p += kWgIter) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ps = p + 4 * s + kq;
+      const bool live = ps < p_end;
+      const float a = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, off_or_oob(live, (unsigned)(ps * Cout + 16 * n + j) * 4u), 0, 0));
+      const int iy0 = 2 * pos[s].oy - PAD + u0, ix0 = 2 * pos[s].ox - PAD;
+      const unsigned pix0 = (unsigned)((pos[s].b * H + iy0) * W + ix0);       // pixel index of tap (row u0, column 0)
+#pragma unroll
+      for (int ur = 0; ur < ROWS; ++ur) {
+        const bool row_ok = live && (PAD == 0 || (iy0 + ur >= 0 && iy0 + ur < H));
+        f32x4 q[NQ];
+#pragma unroll
+        for (int g = 0; g < NQ; ++g) {
+          const int v = 3 * g + jt;                                            // group 0: taps 0..3; group 1 (K = 7): taps 3..6
+          const bool ok = row_ok && (g == 0 || jt != 0) && (PAD == 0 || (ix0 + v >= 0 && ix0 + v < W));
+          q[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                               xr, off_or_oob(ok, ((pix0 + (unsigned)(ur * W + v)) * Cin + 4 * jc) * 4u), 0, 0));
+        }
+        float b4 = 0.f;
+        if (K == 5) {
+          const bool ok = row_ok && (PAD == 0 || (ix0 + 4 >= 0 && ix0 + 4 < W));
+          b4 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off_or_oob(ok, ((pix0 + (unsigned)(ur * W + 4)) * Cin + j) * 4u), 0, 0));
+        }
+#pragma unroll
+        for (int g = 0; g < NQ; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accq[ur][g][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, q[g][e], accq[ur][g][e], 0, 0, 0);
+        if (K == 5) acc1[ur] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b4, acc1[ur], 0, 0, 0);
+      }
+      pix_advance(pos[s], kWgIter, pstep);
+    }
+  }
+  // D_e[i = 4 kq + r][j]: co = 16 n + 4 kq + r, ci = 4 jc + e, v = 3 g + jt (group 1's jt = 0 column is zero: tap 3 belongs to group 0)
+#pragma unroll
+  for (int ur = 0; ur < ROWS; ++ur) {
+    float* o = ws + (((size_t)run * K + u0 + ur) * K) * (size_t)(Cout * Cin);
+#pragma unroll
+    for (int g = 0; g < NQ; ++g) {
+      const int v = 3 * g + jt;
+      if (g == 1 && jt == 0) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)     // the lane's four channels of (tap v, output channel 16 n + 4 kq + r): one 16-byte store
+        *reinterpret_cast<f32x4*>(o + (size_t)v * (Cout * Cin) + (16 * n + 4 * kq + r) * Cin + 4 * jc) =
+            f32x4{accq[ur][g][0][r], accq[ur][g][1][r], accq[ur][g][2][r], accq[ur][g][3][r]};
+    }
+    if (K == 5) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)4 * (Cout * Cin) + (16 * n + 4 * kq + r) * Cin + j] = acc1[ur][r];
+    }
+  }
+}
+
 // planar input with Cin <= 4 (the first layer: NCHW views).  The 16 columns of a B tile are the (channel, filter row) pairs
 // jj = ci * K + u of one filter COLUMN v (Cin * K <= 16 NJ); a wave owns all K filter columns, so dz -- the large operand of this layer
 // -- is read once.  x:(B,Cin,H,W), dz:(B,OH,OW,Cout).  ws:(runs, K [v], Cout, 16 NJ [jj]).  grid (pixel runs, 1, Cout / 16).
@@ -765,14 +859,20 @@ int eqa_conv_s2_wgrad(const float* x, const float* dz, float* dw, void* workspac
 #define EQA_WGN(KK, CH, PD, RW)                                                                                                    \
   hipLaunchKernelGGL((conv_s2_wgrad_nhwc_kernel<KK, CH, PD, RW>), dim3(gx, KK / RW, Cout / 16), dim3(kThreads), 0, st, x, dz, ws, Cout, H, W, \
                      OH, OW, P, per, xb, gb)
+#define EQA_WGN16(KK, PD, RW)                                                                                                      \
+  hipLaunchKernelGGL((conv_s2_wgrad_nhwc16_kernel<KK, PD, RW>), dim3(gx, KK / RW, Cout / 16), dim3(kThreads), 0, st, x, dz, ws, Cout, H, W, OH, \
+                     OW, P, per, xb, gb)
 #define EQA_WGN_K(KK, R1, R2, R4)                                                                                                  \
   do {                                                                                                                             \
-    if (ch == 1) { if (pad) EQA_WGN(KK, 1, 1, R1); else EQA_WGN(KK, 1, 0, R1); }                                                  \
+    if (ch == 1 && KK == 5) { if (pad) EQA_WGN16(5, 1, 1); else EQA_WGN16(5, 0, 1); }                                             \
+    else if (ch == 1 && KK == 7) { if (pad) EQA_WGN16(7, 1, 1); else EQA_WGN16(7, 0, 1); }                                        \
+    else if (ch == 1) { if (pad) EQA_WGN(KK, 1, 1, R1); else EQA_WGN(KK, 1, 0, R1); }                                             \
     else if (ch == 2) { if (pad) EQA_WGN(KK, 2, 1, R2); else EQA_WGN(KK, 2, 0, R2); }                                             \
     else { if (pad) EQA_WGN(KK, 4, 1, R4); else EQA_WGN(KK, 4, 0, R4); }                                                          \
   } while (0)
     if (K == 7) EQA_WGN_K(7, 1, 1, 1); else if (K == 5) EQA_WGN_K(5, 5, 1, 1); else EQA_WGN_K(3, 3, 3, 3);
 #undef EQA_WGN_K
+#undef EQA_WGN16
 #undef EQA_WGN
   }
   if (hipGetLastError() != hipSuccess) return EQA_ERR_LAUNCH;
