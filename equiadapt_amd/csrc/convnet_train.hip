@@ -693,13 +693,14 @@ __global__ __launch_bounds__(kThreads) void conv_s2_dgrad_nhwc_kernel(const floa
 }
 
 int wgrad_pix_per_wave(long P) {
-  // ~4096 runs: a wave is a chain of dependent round trips (dword operand loads), so the chip wants several waves per SIMD; every run
-  // costs one partial filter in the workspace and one term of the (parallel) reduction.  Runs of >= 128 pixels, a multiple of the trip
+  // ~2048 runs of >= 256 pixels (a multiple of the trip): the chip wants several waves per SIMD, but every run costs one partial
+  // filter in the workspace and one term of the reduction (swept with the round-5 kernels, tools/kbench_convnet.py: 1024 / 2048 /
+  // 4096 / 8192 runs = 168 / 122 / 126 / 138 us at the first layer, 93 / 83 / 92 / 115 at the second)
 #ifndef EQA_WG_RUNS
-#define EQA_WG_RUNS 4096
+#define EQA_WG_RUNS 2048
 #endif
 #ifndef EQA_WG_MINPIX
-#define EQA_WG_MINPIX 128
+#define EQA_WG_MINPIX 256
 #endif
   long per = (P + EQA_WG_RUNS - 1) / EQA_WG_RUNS;
   per = std::max((long)EQA_WG_MINPIX, std::min(16384L, per));
