@@ -1284,6 +1284,97 @@ __global__ __launch_bounds__(kThreads) void crop_resize_aa_wide_kernel(const flo
   }
 }
 
+// The same for rows no wider than one float4 per thread (x_span <= 1024: config 5), VERTICAL pass first and without staging the
+// input: the row-staged kernel above keeps one block per CU (74 KB intermediate band + 37 KB of staged rows) and 32 KB of loads in
+// flight between two barriers per eight input rows -- 155 us for 32 x 3 x 1024^2 (2.6 TB/s).  Here a thread owns four columns:
+// every input row of the band's span is loaded ONCE, 16 bytes per lane, eight rows ahead, and added to the band's eight output
+// rows with its (uniform) vertical weight -- zero outside a row's K taps, so any overlap of the windows is handled -- and only the
+// eight finished 1024-wide rows go through LDS (four at a time, 18 KB) for the horizontal taps.  Four blocks per CU, 128 KB of loads
+// in flight per CU, four barriers per block.  (Summation order: vertical taps first; the staged kernels sum the horizontal taps first.)
+constexpr int kAaStreamRows = 8;
+__global__ __launch_bounds__(kThreads) void crop_resize_aa_stream_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                        const float* __restrict__ wx, const int32_t* __restrict__ x0,
+                                                                        const float* __restrict__ wy, const int32_t* __restrict__ y0,
+                                                                        int H, int W, int OH, int OW, int K, int xbeg, int xlen,
+                                                                        int pad_shift, int row_stride) {
+  extern __shared__ __attribute__((aligned(16))) float aa_rows[];   // [kAaBand / 2][row_stride]
+  const int plane = blockIdx.y;
+  const int r0 = blockIdx.x * kAaBand, nr_out = min(kAaBand, OH - r0);
+  int ys[kAaBand];                                                   // first input row of each output row (uniform)
+#pragma unroll
+  for (int r = 0; r < kAaBand; ++r) ys[r] = y0[r0 + min(r, nr_out - 1)];
+  const int ybeg = ys[0];
+  const int span = ys[kAaBand - 1] + K - ybeg;                       // input rows the band touches (ys is non-decreasing)
+  const float* src = x + (size_t)plane * H * W + xbeg;
+  const int e = 4 * (int)threadIdx.x;
+  const int e_ld = min(e, xlen - 4);
+  auto pos = [&](int i) { return pad_shift ? i + (i >> pad_shift) : i; };
+  float4 acc[kAaBand];
+#pragma unroll
+  for (int r = 0; r < kAaBand; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load8 = [&](float4 (&v)[kAaStreamRows], int yc) {           // rows ybeg + yc .. + 7 (clamped to the image: their weights are 0)
+#pragma unroll
+    for (int q = 0; q < kAaStreamRows; ++q)
+      v[q] = *reinterpret_cast<const float4*>(src + (size_t)min(ybeg + yc + q, H - 1) * W + e_ld);
+  };
+  // the 8 x 8 vertical weights of a trip (input row q of the trip, output row r): lane 8 q + r loads its one weight, the others
+  // get it by v_readlane (64 scalar loads in a chain, one per weight, cost 13 k cycles a trip: every one waited out its latency)
+  const int lane = threadIdx.x & 63;
+  const int wq = lane >> 3, wr = lane & 7;
+  const int ys_w = y0[r0 + min(wr, nr_out - 1)];
+  auto wload = [&](int yc) {
+    const int t = ybeg + yc + wq - ys_w;
+    const bool ok = wr < nr_out && t >= 0 && t < K && yc + wq < span;
+    return ok ? wy[(size_t)(r0 + wr) * K + min(max(t, 0), K - 1)] : 0.0f;
+  };
+  auto add8 = [&](const float4 (&v)[kAaStreamRows], float wv) {
+#pragma unroll
+    for (int q = 0; q < kAaStreamRows; ++q) {
+#pragma unroll
+      for (int r = 0; r < kAaBand; ++r) {
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wv), 8 * q + r));
+        acc[r].x += w * v[q].x; acc[r].y += w * v[q].y; acc[r].z += w * v[q].z; acc[r].w += w * v[q].w;
+      }
+    }
+  };
+  static_assert(kAaStreamRows == 8 && kAaBand == 8, "one weight per lane: 8 rows of a trip x 8 output rows = 64 lanes");
+  float4 va[kAaStreamRows], vb[kAaStreamRows];
+  float wa, wb = 0.0f;
+  load8(va, 0);
+  wa = wload(0);
+  for (int yc = 0; yc < span; yc += 2 * kAaStreamRows) {
+    if (yc + kAaStreamRows < span) { load8(vb, yc + kAaStreamRows); wb = wload(yc + kAaStreamRows); }
+    add8(va, wa);
+    if (yc + 2 * kAaStreamRows < span) { load8(va, yc + 2 * kAaStreamRows); wa = wload(yc + 2 * kAaStreamRows); }
+    if (yc + kAaStreamRows < span) add8(vb, wb);
+  }
+  float* dst = y + (size_t)plane * OH * OW;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (e < xlen) {
+#pragma unroll
+      for (int rr = 0; rr < kAaBand / 2; ++rr) {
+        float* lrow = aa_rows + rr * row_stride;
+        const float4 v = acc[half * (kAaBand / 2) + rr];
+        lrow[pos(e)] = v.x; lrow[pos(e + 1)] = v.y; lrow[pos(e + 2)] = v.z; lrow[pos(e + 3)] = v.w;
+      }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (kAaBand / 2) * OW; idx += kThreads) {
+      const int rr = idx / OW, ox = idx - rr * OW;
+      const int r = half * (kAaBand / 2) + rr;
+      if (r < nr_out) {
+        const float* row = aa_rows + rr * row_stride;
+        const int xs = x0[ox] - xbeg;
+        float a = 0.0f;
+        for (int j = 0; j < K; ++j) a += wx[ox * K + j] * row[pos(min(xs + j, xlen - 1))];
+        dst[(size_t)(r0 + r) * OW + ox] = a;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // I6: nearest-neighbour action on uint8 masks (torchvision.transforms.functional.rotate defaults on a uint8 tensor:
 // half-pixel base grid, theta rescaled by (0.5 W, 0.5 H), grid_sample(nearest, zeros, align_corners=False), round;
@@ -1840,6 +1931,13 @@ int eqa_crop_resize_aa(const float* x, float* y, const float* wx, const int32_t*
     const size_t row_bytes = (size_t)row_stride * sizeof(float);
     const int rpi = (int)std::min<size_t>(8, lds + row_bytes <= 96 * 1024 ? (96 * 1024 - lds) / row_bytes : 0);
     const size_t lds2 = lds + (size_t)rpi * row_bytes;
+    static const bool stream_off = [] { const char* e = getenv("EQA_AA_STREAM"); return e && e[0] == '0'; }();
+    if (!stream_off && x_span <= 4 * kThreads && (x_span & 3) == 0 && (x_begin & 3) == 0 && (W & 3) == 0 && (((uintptr_t)x) & 15) == 0 &&
+        (size_t)(kAaBand / 2) * row_bytes <= 64 * 1024) {
+      hipLaunchKernelGGL(crop_resize_aa_stream_kernel, grid, dim3(kThreads), (kAaBand / 2) * row_bytes, (hipStream_t)stream, x, y, wx, x0, wy,
+                         y0, H, W, OH, OW, K, x_begin, x_span, pad_shift, row_stride);
+      return launch_status();
+    }
     if (rpi >= 1) {
       hipLaunchKernelGGL(crop_resize_aa_wide_kernel, grid, dim3(kThreads), lds2, (hipStream_t)stream, x, y, wx, x0, wy, y0, H, W, OH,
                          OW, K, max_rows, x_begin, x_span, pad_shift, row_stride, rpi);
