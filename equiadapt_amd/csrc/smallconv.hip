@@ -24,6 +24,7 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTiles = 2;  // pixel tiles per wave (swept 2 / 4 / 8 at the tutorial's shapes: 77 / 81 / 95 us at the second layer, 29 / 37 / 37 at the third)
 
@@ -59,19 +60,26 @@ __global__ __launch_bounds__(kThreads) void conv_s2_nhwc_kernel(const float* __r
   if (p0 >= P) return;
   const int i = lane & 15, kq = lane >> 4;
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, x_bytes, 0x00020000);
-  // per tile: byte offset of tap (0, 0) of this lane's pixel (+ its 4 channels), and for PAD > 0 which taps exist
+  // The matrix instruction wants lane 16 kq + i to hold pixel i's channels 4 kq .. 4 kq + 3 -- neighbouring lanes on neighbouring
+  // PIXELS, 16 bytes each from a different 64-byte request: loaded that way the kernel ran at a quarter of the vector L1's rate
+  // (66 us of loads against 34 us of matrix instructions at the tutorial's second layer).  So the LOAD uses the other order --
+  // lane 4 p + q fetches pixel p's channel quad q: four neighbouring lanes = one pixel's 64 contiguous bytes -- and four
+  // ds_bpermute per loaded vector bring lane 16 kq + i the data of lane 4 i + kq.
+  const int lp = lane >> 2, lq = lane & 3;
+  const int perm = 4 * (4 * i + kq);                                   // byte address of the source lane
+  // per tile: byte offset of tap (0, 0) of the LOAD lane's pixel (+ its 4 channels), and for PAD > 0 which taps exist
   unsigned base[kTiles];
   int oy2[kTiles], ox2[kTiles];
 #pragma unroll
   for (int t = 0; t < kTiles; ++t) {
-    const unsigned p = (unsigned)min(p0 + 16 * t + i, P - 1);        // 32-bit divisions (P < 2^31: checked by the host)
+    const unsigned p = (unsigned)min(p0 + 16 * t + lp, P - 1);        // 32-bit divisions (P < 2^31: checked by the host)
     const unsigned row = p / (unsigned)OW;
     const int ox = (int)(p - row * (unsigned)OW);
     const long b = row / (unsigned)OH;
     const int oy = (int)(row - (unsigned)b * (unsigned)OH);
     oy2[t] = 2 * oy - PAD;
     ox2[t] = 2 * ox - PAD;
-    base[t] = (unsigned)((((b * H + oy2[t]) * W + ox2[t]) * Cin + 4 * kq) * 4);
+    base[t] = (unsigned)((((b * H + oy2[t]) * W + ox2[t]) * Cin + 4 * lq) * 4);
   }
   f32x4 acc[kTiles][NCO];
 #pragma unroll
@@ -94,7 +102,9 @@ __global__ __launch_bounds__(kThreads) void conv_s2_nhwc_kernel(const float* __r
             const int iy = oy2[t] + u, ix = ox2[t] + v;
             off = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? off : 0x7ffffff0u;     // outside the buffer: reads as zero
           }
-          a[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+          const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a[t][s] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(perm, (int)raw[s]));
         }
 #pragma unroll
         for (int n = 0; n < NCO; ++n) b[n] = wl[(((u * K + v) * CHUNKS + c) * NCO + n) * 64];
