@@ -509,7 +509,7 @@ __global__ __launch_bounds__(kThreads) void conv_s2_wgrad_planar_kernel(const fl
 #pragma unroll
           for (int v = 0; v < 4; ++v) b[v][t] = q[v];
           if (K == 5) {
-            b[4][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o + 16, 0, 0));
+            b[K == 5 ? 4 : 0][t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, o + 16, 0, 0));   // (index: no out-of-range subscript in the K = 3 instantiation's dead branch)
           } else if (K == 7) {       // taps 3 .. 6: a second 16-byte load ending exactly at the row's last tap
             const f32x4 q2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o + 12, 0, 0));
 #pragma unroll
