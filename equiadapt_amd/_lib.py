@@ -206,6 +206,38 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
+    # One builder at a time per tree (round 6): torchrun ranks and pytest-xdist workers that meet a stale tree queue on this
+    # lock; the first compiles and links, the others find the library fresh when their turn comes and return.  The post-link cleanup
+    # below therefore never meets another process's in-flight temporaries (it still only removes what it can prove dead).
+    import fcntl
+
+    lock_file = open(os.path.join(objdir, ".lock"), "w")
+    fcntl.flock(lock_file, fcntl.LOCK_EX)
+    try:
+        if not force and not extra_flags and os.path.exists(out) and os.path.getmtime(out) >= newest_src:
+            return out
+        return _build_locked(hipcc, flags, tag, objdir, out, hdr_time, force, verbose, bool(extra_flags))
+    finally:
+        fcntl.flock(lock_file, fcntl.LOCK_UN)
+        lock_file.close()
+
+
+def _pid_alive(pid: int) -> bool:
+    try:
+        os.kill(pid, 0)
+    except ProcessLookupError:
+        return False
+    except PermissionError:
+        return True
+    return True
+
+
+def _build_locked(hipcc, flags, tag, objdir, out, hdr_time, force, verbose, variant):
+    from concurrent.futures import ThreadPoolExecutor
+    import re
+    import time
+
+    started = time.time()
 
     def compile_one(src):
         obj = os.path.join(objdir, f"{os.path.splitext(os.path.basename(src))[0]}.{tag}.o")
@@ -236,16 +268,22 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     if res.returncode != 0:
         raise EqaLibraryError(f"link failed ({res.returncode}):\n{res.stdout}\n{res.stderr}")
     os.replace(tmp, out)
-    if not extra_flags:
+    if not variant:
         # a product build leaves only the product's objects behind: the flag-hash variants of A/B experiments (tools/ablate.sh)
-        # accumulate otherwise (round 4 ended with 23 stale sets, 104 MB)
+        # accumulate otherwise (round 4 ended with 23 stale sets, 104 MB).  Removed: finished objects of OTHER flag sets that are
+        # older than this build's start, and compile temporaries whose owning process is gone -- never a live process's files.
         keep = {os.path.basename(o) for o, _ in results}
         for name in os.listdir(objdir):
-            if name not in keep and (name.endswith(".o") or ".o.tmp" in name):
-                try:
-                    os.remove(os.path.join(objdir, name))
-                except OSError:
-                    pass
+            path = os.path.join(objdir, name)
+            try:
+                m = re.search(r"\.o\.tmp(\d+)$", name)
+                if m:
+                    if not _pid_alive(int(m.group(1))):
+                        os.remove(path)
+                elif name.endswith(".o") and name not in keep and os.path.getmtime(path) < started:
+                    os.remove(path)
+            except OSError:
+                pass
     return out
 
 

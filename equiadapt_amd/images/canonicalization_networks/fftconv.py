@@ -28,7 +28,20 @@ GEMM = os.environ.get("EQA_FFT_GEMM", "3m")
 # How the hand-written GEMM multiplies: "f32" = the fp32 matrix instruction; "9" / "6" = every fp32 operand split exactly into three
 # bf16 pieces and that many piece products on the bf16 matrix cores (eqa_fft48k5_cgemm3m_bf16x3: 9 = every product, the same
 # exact-products / fp32-accumulation contract as the fp32 instruction; 6 = without the three products of relative size <= 2^-24).
-GEMM_PIECES = os.environ.get("EQA_FFT_GEMM_PIECES", "f32")
+# "auto" (default since round 6): six piece products on the shapes where they are BOTH faster and no further from an fp64
+# evaluation than the fp32 instruction -- Cin >= AUTO_MIN_CIN (the piece form accumulates 8 / 16 products per rounding, the fp32
+# instruction 2: its advantage grows with the contraction length; at Cin = 32 it is 7-11 % further away, profiles/r05/
+# kbench_gemm_error.txt) and Cout % 128 == 0 (the block form: A split once per block, 1.5 x the fp32 form's speed) -- the fp32
+# instruction everywhere else.  The rule is gated by tests/test_gpu_parity.py::test_auto_gemm_form_is_no_further_from_fp64.
+GEMM_PIECES = os.environ.get("EQA_FFT_GEMM_PIECES", "auto")
+AUTO_MIN_CIN = int(os.environ.get("EQA_FFT_GEMM_AUTO_MIN_CIN", "128"))
+
+
+def gemm_form(cin: int, cout: int) -> str:
+    """"f32" / "9" / "6": how `contract` multiplies a (.., 2 cin) . (2 cin, 2 cout) complex product (see GEMM_PIECES)."""
+    if GEMM_PIECES in ("f32", "9", "6"):
+        return GEMM_PIECES
+    return "6" if cin >= AUTO_MIN_CIN and cout % 128 == 0 else "f32"
 
 
 class Spectra3M:
@@ -85,8 +98,9 @@ def contract(V: torch.Tensor, B, M: int) -> torch.Tensor:
         lib = _lib.load()
         assert V.shape[2] == 2 * B.cin and V.stride(1) == 2 * B.cin and V.stride(0) == lib.eqa_fft48k5_tile_pitch(M) * 2 * B.cin
         Mo = spectra_buffer(M, 2 * B.cout, dev)
-        if GEMM_PIECES in ("9", "6"):
-            _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, int(GEMM_PIECES),
+        form = gemm_form(B.cin, B.cout)
+        if form in ("9", "6"):
+            _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, int(form),
                                                       torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_cgemm3m_bf16x3")
             return Mo
         _lib.check(lib.eqa_fft48k5_cgemm3m(V.data_ptr(), B.data.data_ptr(), Mo.data_ptr(), M, B.cin, B.cout,

@@ -375,3 +375,69 @@ def test_variant_build_needs_its_own_output_path():
 
     with pytest.raises(ValueError):
         _lib.build(extra_flags=["-DEQA_ABL_NOMASK"])
+
+
+def test_eight_concurrent_builders_on_a_stale_tree_leave_one_intact_library(tmp_path):
+    """The first run of `bench.py --gpus 8` (or of pytest-xdist) on a stale tree: eight processes call _lib.build() at the same time.
+    With a stand-in compiler (a script that takes 0.2 s per object and concatenates at link time) on a scratch copy of the build
+    inputs: every process returns the library path, the library holds every translation unit exactly once and was linked ONCE (the
+    others queue on csrc/_obj/.lock and find it fresh), no compile temporaries and no foreign objects are left -- and an unrelated
+    live process's temporary survives the cleanup while a dead one's is removed (the cleanup used to delete both)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    csrc = tmp_path / "csrc"
+    (csrc / "_obj").mkdir(parents=True)
+    names = [f"unit{i}.hip" for i in range(6)]
+    for n in names:
+        (csrc / n).write_text(f"// {n}\n")
+    (csrc / "common.hpp").write_text("// header\n")
+    fake = tmp_path / "fakecc"
+    fake.write_text(textwrap.dedent("""\
+        #!/usr/bin/env python3
+        import sys, time, os
+        a = sys.argv[1:]
+        out = a[a.index("-o") + 1]
+        if "-c" in a:
+            time.sleep(0.2)
+            src = a[a.index("-c") + 1]
+            open(out, "w").write("OBJ " + os.path.basename(src) + "\\n")
+        else:
+            objs = [x for x in a if x.endswith(".o")]
+            time.sleep(0.2)
+            with open(os.path.join(os.path.dirname(out), "link_count"), "a") as f:
+                f.write("1\\n")
+            open(out, "w").write("".join(open(o).read() for o in objs))
+        """))
+    fake.chmod(0o755)
+    live = csrc / "_obj" / f"unit0.deadbeef00.o.tmp{os.getpid()}"              # this (live) process's in-flight temporary
+    live.write_text("in flight")
+    dead = csrc / "_obj" / "unit0.deadbeef00.o.tmp999999999"                   # no such pid
+    dead.write_text("orphan")
+    stale = csrc / "_obj" / "unit0.0123456789.o"                                # another flag set's finished object, old
+    stale.write_text("old variant")
+    os.utime(stale, (1, 1))
+    child = textwrap.dedent(f"""\
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        from equiadapt_amd import _lib
+        _lib.CSRC = {str(csrc)!r}
+        _lib.SOURCES = [os.path.join(_lib.CSRC, n) for n in {names!r}]
+        _lib.HEADERS = [os.path.join(_lib.CSRC, "common.hpp")]
+        _lib.SO_PATH = os.path.join(_lib.CSRC, "libfake.so")
+        print(_lib.build())
+        """)
+    env = dict(os.environ, HIPCC=str(fake))
+    procs = [subprocess.Popen([sys.executable, "-c", child], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(8)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se
+        assert so.strip().endswith("libfake.so")
+    lib = (csrc / "libfake.so").read_text().splitlines()
+    assert sorted(lib) == sorted(f"OBJ {n}" for n in names)
+    assert (csrc / "link_count").read_text().count("1") == 1
+    left = sorted(os.listdir(csrc / "_obj"))
+    assert live.name in left and dead.name not in left and stale.name not in left
+    assert [n for n in left if ".o.tmp" in n] == [live.name]
+    assert len([n for n in left if n.endswith(".o")]) == len(names)
