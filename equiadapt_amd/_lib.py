@@ -13,8 +13,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("EQA_LIB") or os.path.join(CSRC, "libeqa_hip.so")  # EQA_LIB: A/B a variant build
-SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_conv_wide.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip", "convnet_train.hip")]
-HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc")]
+SOURCES = [os.path.join(CSRC, f) for f in ("group_action.hip", "pooling.hip", "batchnorm.hip", "winograd.hip", "lift_conv.hip", "lift_conv_wide.hip", "lift_wgrad.hip", "pointcloud.hip", "vnsmall_train.hip", "vnsmall_tail.hip", "fftconv.hip", "lift_fft.hip", "cgemm3m.hip", "cgemm3m_bf16.hip", "smallconv.hip", "planegemm.hip", "convnet_train.hip")]
+HEADERS = [os.path.join(CSRC, "eqa_common.hpp"), os.path.join(CSRC, "vn_common.hpp"), os.path.join(CSRC, "fft48.inc"), os.path.join(CSRC, "fft_common.inc")]
 INCLUDE = os.path.join(ROOT, "include")
 
 ABI_VERSION = 3   # == EQA_ABI_VERSION of include/eqa_hip.h (tests/test_abi_and_host.py compares the two)
@@ -118,6 +118,8 @@ SIGNATURES = {
     "eqa_fft48k5_input": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_input_grouped": (_int, [_vp, _vp, _vp, _vp] + [_int] * 5 + [_vp]),
     "eqa_fft48k5_input_grouped_supported": (_int, [_int]),
+    "eqa_lift5_fft48k5_input_supported": (_int, [_int] * 4),
+    "eqa_lift5_fft48k5_input": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output_stats_rows": (ctypes.c_int64, [_int] * 4),
     "eqa_fft48k5_output_stats": (_int, [_vp, _vp, _vp, _vp] + [_int] * 4 + [_vp]),

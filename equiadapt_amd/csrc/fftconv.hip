@@ -27,24 +27,7 @@
 
 namespace {
 
-constexpr int kFftN = 48, kFftH = 25, kFftO = 44;
-#include "fft48.inc"
-
-// Stored frequencies.  A real tile's spectrum is Hermitian: X[-ky][-kx] = conj(X[ky][kx]).  Keeping kx = 0..24 uses that for
-// 0 < kx < 24; in the columns kx = 0 and kx = 24 (their own mirror images) the rows ky = 25..47 are the conjugates of rows
-// 23..1 and are not stored either: 48 x 23 + 2 x 25 = 1154 frequencies instead of 1200 (the GEMM runs per frequency).
-// Index: f = ky * 23 + (kx - 1) for 0 < kx < 24, then 1104 + 2 ky + (kx == 24) for the two edge columns, ky <= 24.
-constexpr int kFftInner = kFftH - 2;
-constexpr int kFftF = kFftN * kFftInner + 2 * kFftH;
-__device__ __forceinline__ bool fft_edge(int kx) { return kx == 0 || kx == kFftH - 1; }
-__device__ __forceinline__ int fft_f0(int kx) { return kx == 0 ? kFftN * kFftInner : (kx == kFftH - 1 ? kFftN * kFftInner + 1 : kx - 1); }
-__device__ __forceinline__ int fft_fstep(int kx) { return fft_edge(kx) ? 2 : kFftInner; }
-__device__ __forceinline__ int fft_nky(int kx) { return fft_edge(kx) ? kFftH : kFftN; }
-
-// Rows per stored frequency of V, Mo, G and the gradient products: the tile count made odd.  With M = 1024 tiles of 256
-// channels a frequency is exactly 2 MB apart from the next, and the 1154 128-byte pieces a block gathers all fall into the
-// same HBM channel / bank group: one row of padding takes the fused inverse from 1.23 to 1.01 ms.
-__host__ __device__ inline size_t fft_pitch(size_t M) { return M | 1; }
+#include "fft_common.inc"
 
 // Mo in HBM: complex numbers, re and im interleaved, read once with 8-byte non-temporal loads
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -514,6 +514,8 @@ class ESCNNEquivariantNetwork(nn.Module):
                 continue
             if isinstance(h, fftconv.GroupedMap):   # written for an FFT layer that did not take it after all
                 h = h.to_channels_last()
+            elif isinstance(h, fftconv.LiftedInput):
+                h = h.materialize()
             if (nhwc and not conv.lifting and conv.kernel_size != 5 and conv.stride == 1 and conv.padding == 0
                     and h.is_contiguous(memory_format=torch.channels_last)
                     and fftconv.applicable_k(h.shape, bank.shape[1], bank.shape[0], conv.kernel_size, h.device)):
@@ -557,6 +559,12 @@ class ESCNNEquivariantNetwork(nn.Module):
                 # layer's input transform reads in whole cache lines (it is consumed by nothing else).
                 nxt = convs[i + 1] if i + 1 < len(convs) - 1 else None
                 out_shape = (h.shape[0], bank.shape[0], h.shape[2] - k + 1, h.shape[3] - k + 1)
+                if (nxt is not None and not nxt.lifting and nxt.kernel_size == 5 and nxt.stride == 1 and nxt.padding == 0
+                        and fftconv.lift_fused_applicable(h.shape, bank.shape, nxt.out_channels * nxt.num_group_elements, h.device)):
+                    # round 6: the layer does not run here at all -- the FFT layer behind it computes each tile of this map from
+                    # its input patch inside its own forward transform (eqa_lift5_fft48k5_input)
+                    h = fftconv.LiftedInput(h, bank, bias, True)
+                    continue
                 if (nxt is not None and not nxt.lifting and nxt.kernel_size == 5 and nxt.stride == 1 and nxt.padding == 0
                         and fftconv.grouped_applicable(out_shape, bank.shape[0], bank.shape[0], h.device)):
                     h = fftconv.GroupedMap(ops.lift_conv_grouped(h, self._lift_weights(conv, bank), bias, True, k, k))

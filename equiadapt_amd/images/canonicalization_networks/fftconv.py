@@ -142,6 +142,40 @@ class GroupedMap:
         return self.data.permute(0, 1, 4, 2, 3).reshape(n, g * 16, h, w).contiguous(memory_format=torch.channels_last)
 
 
+class LiftedInput:
+    """A lifting layer that has NOT run: (x channels-last (nimg, 3, H0, W0), folded 5 x 5 bank (C, 3, 5, 5) channels-last, bias (C),
+    relu) standing for the map [relu](conv2d(x, bank) + bias) of logical `.shape` (nimg, C, H0 - 4, W0 - 4).  `conv5x5` takes it in
+    place of that map and produces the map's tile spectra straight from x (eqa_lift5_fft48k5_input: the lifting convolution fused
+    into the forward FFT-48 transform -- the 2.2 GB map of the headline shape is neither written nor read)."""
+
+    def __init__(self, x: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor], relu: bool):
+        assert x.dim() == 4 and x.shape[1] == 3 and bank.shape[1:] == (3, 5, 5)
+        self.x = x.contiguous(memory_format=torch.channels_last)
+        self.bank = bank.contiguous(memory_format=torch.channels_last)           # memory order (C, 5, 5, 3)
+        self.bias, self.relu = (bias.contiguous() if bias is not None else None), bool(relu)
+        self.shape = torch.Size((x.shape[0], bank.shape[0], x.shape[2] - 4, x.shape[3] - 4))
+        self.device, self.dtype, self.is_cuda = x.device, x.dtype, x.is_cuda
+
+    def materialize(self) -> torch.Tensor:
+        """The map itself, channels-last (the unfused lifting kernel) -- for a consumer that turned out not to be `conv5x5`."""
+        y = ops.lift_conv_nhwc(self.x, ops.pack_lift_weights(self.bank), self.bias, self.relu, 5, 5)
+        return y
+
+
+LIFT_FFT_FUSED_DEFAULT = "0"     # work in progress: on once the fused kernel beats the two kernels inside the step
+
+
+def lift_fused_applicable(x_shape, bank_shape, cout_next: int, device) -> bool:
+    """Can the lifting layer (x_shape channels-last input, bank_shape (C, Cin, k, k)) be fused into the FFT convolution behind it?"""
+    if os.environ.get("EQA_LIFT_FFT_FUSED", LIFT_FFT_FUSED_DEFAULT) == "0" or len(x_shape) != 4:
+        return False
+    C, Cin, kh, kw = bank_shape
+    if not _lib.load().eqa_lift5_fft48k5_input_supported(Cin, kh, kw, C):
+        return False
+    out_shape = (x_shape[0], C, x_shape[2] - 4, x_shape[3] - 4)
+    return x_shape[2] >= 5 and x_shape[3] >= 5 and grouped_applicable(out_shape, C, cout_next, device)
+
+
 def grouped_applicable(shape, cin: int, cout: int, device, max_waste: float = 1.12) -> bool:
     """Would `conv5x5` take a (nimg, cin, H, W) fp32 map of this shape on `device` through the FFT path AND read it in the
     grouped layout?  (Decided before the producing layer runs, so that it can write that layout.)"""
@@ -161,7 +195,7 @@ def applicable(x: torch.Tensor, cin: int, cout: int, max_waste: float = 1.12) ->
     """Channels-last fp32 device tensor, 5x5 kernel, enough tiles to amortise the filter spectra (``MIN_TILES``), and tiles
     that fit the output to within ``max_waste`` (the FFT work is per tile: 88 outputs per axis = 2 tiles exactly, 84 would
     waste 5 %, 50 would waste 43 % -> Winograd)."""
-    if isinstance(x, GroupedMap):
+    if isinstance(x, (GroupedMap, LiftedInput)):
         return grouped_applicable(x.shape, cin, cout, x.device, max_waste)
     if not (ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         return False
@@ -252,15 +286,21 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     M = nimg * TY * TX
     dev = x.device
     st = torch.cuda.current_stream().cuda_stream
-    T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
     V = spectra_buffer(M, 2 * Cin, dev)
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     p_bias = bias.data_ptr() if bias is not None else None
     with torch.cuda.device(dev):
-        with _timed("fft_input"):
-            fn = lib.eqa_fft48k5_input_grouped if isinstance(x, GroupedMap) else lib.eqa_fft48k5_input
-            _lib.check(fn(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st), "eqa_fft48k5_input")
-        del T
+        if isinstance(x, LiftedInput):
+            assert in_bias is None and not in_relu
+            with _timed("lift_fft_input"):
+                _lib.check(lib.eqa_lift5_fft48k5_input(x.x.data_ptr(), x.bank.data_ptr(), x.bias.data_ptr() if x.bias is not None else None,
+                                                       int(x.relu), V.data_ptr(), nimg, H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input")
+        else:
+            T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
+            with _timed("fft_input"):
+                fn = lib.eqa_fft48k5_input_grouped if isinstance(x, GroupedMap) else lib.eqa_fft48k5_input
+                _lib.check(fn(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st), "eqa_fft48k5_input")
+            del T
         with _timed("fft_gemm"):
             Mo = contract(V, B, M)
         if keep_V is not None:

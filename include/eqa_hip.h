@@ -548,6 +548,18 @@ int eqa_fft48k5_input(const float* x, float* T, float* V, const float* in_bias, 
 int eqa_fft48k5_input_grouped_supported(int C);
 int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* in_bias, int in_relu, int nimg, int H, int W, int C,
                               void* stream);
+/* The lifting layer FUSED into the input transform of the layer behind it (round 6, csrc/lift_fft.hip; inference):
+ *   V = eqa_fft48k5_input( [relu]( conv2d(x, bank) + bias ) )
+ * without the lifted map ever existing in memory -- a persistent block owns (48 x 48 tile, 16-channel group) items, computes the
+ * tile from its 52 x 52 x 3 input patch on the fp32 matrix cores (v_mfma_f32_16x16x4_f32; the 76 products of a pixel in the order
+ * of eqa_lift_conv_nhwc's dense form), and transforms it in place.  Reference layers: escnn_networks.py:60-85 (R2Conv trivial ->
+ * regular, InnerBatchNorm folded into bank / bias, ReLU) + the input side of the first regular -> regular R2Conv.
+ * x:(nimg,H0,W0,3) channels-last; bank:(Cout,5,5,3) = the MEMORY ORDER of a channels-last (Cout,3,5,5) tensor; bias:(Cout) or NULL;
+ * V:(F, M|1, 2 Cout), M = nimg * tiles(H0-4) * tiles(W0-4), as eqa_fft48k5_input writes it.  Cout % 16 == 0 (else
+ * EQA_ERR_UNSUPPORTED); sizes beyond 32-bit byte offsets: EQA_ERR_UNSUPPORTED (use the two calls). */
+int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout);
+int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
+                            void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
 /* Training: eqa_fft48k5_output without bias / activation that also leaves the fp64 partial sums of the InnerBatchNorm behind the

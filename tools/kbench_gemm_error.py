@@ -7,7 +7,7 @@ import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from equiadapt_amd import _lib
 from equiadapt_amd.images.canonicalization_networks import fftconv
-lib = _lib.load(); dev = torch.device("cuda:0")
+lib = _lib.load(); dev = torch.device("cuda:0"); fftconv.GEMM_PIECES = "f32"   # `contract` below = the fp32 matrix instruction
 for (M, Cin, Cout) in [(36, 64, 64), (130, 32, 128), (64, 256, 256), (257, 96, 192), (1024, 128, 64), (1, 32, 128), (129, 64, 256), (300, 160, 384), (512, 256, 256)]:
     for seed in (0, 1):
         g = torch.Generator().manual_seed(M + Cin + 1 + seed)
