@@ -1005,7 +1005,7 @@ def main():
                 tsrc = next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
                 tj = json.load(open(os.path.join(ROOT, "profiles", tsrc, "traffic_canon_net.json")))
                 key = {"fft_gemm": "fft_cgemm3m_bf16_block_kernel" if default_form in ("6", "9") else "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
-                       "lift_conv": "lift_conv_dense_kernel"}.get(dom)
+                       "lift_conv": "lift_conv_dense_kernel", "lift_fft_input": "lift5_fft48_fused_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
             except (OSError, ValueError, StopIteration):
                 pass
@@ -1096,6 +1096,11 @@ def stage_table(ktimes, B):
         gemm_spec = ("mfma", 4.0 / 3.0 * real_products, "1154 x [tiles x 512].[512 x 512] batched GEMM, complex as real (library)")
     spec.update({
         "fft_input": ("hbm", px_l * 256 * 4 + spectra, "eqa_fft48k5_input: row + column FFT-48 passes (hand-written)"),
+        # round 6: the lifting convolution fused into the forward transform (one launch instead of lift_conv + fft_input; the lifted
+        # map is never written): bounded by the fp32 matrix pipe (2 x 75 flops per lifted pixel, 1.19 x recomputed on the tile overlap
+        # -- the algorithmic count below is WITHOUT the overlap) with the spectrum stores (2.4 GB) hidden behind it
+        "lift_fft_input": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift5_fft48k5_input: lifting conv (fp32 MFMA 16x16x4) + ReLU + row / column FFT-48 in "
+                           "one persistent kernel, spectra out as whole 128-byte lines (hand-written)"),
         "fft_gemm": gemm_spec,
         "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
     })

@@ -162,7 +162,7 @@ class LiftedInput:
         return y
 
 
-LIFT_FFT_FUSED_DEFAULT = "0"     # work in progress: on once the fused kernel beats the two kernels inside the step
+LIFT_FFT_FUSED_DEFAULT = "1"     # EQA_LIFT_FFT_FUSED=0: the two kernels (eqa_lift_conv_grouped, eqa_fft48k5_input_grouped)
 
 
 def lift_fused_applicable(x_shape, bank_shape, cout_next: int, device) -> bool:

@@ -91,7 +91,7 @@ def test_conv5x5_takes_a_lifted_input(dev, monkeypatch):
 
     torch.manual_seed(61)
     monkeypatch.setenv("EQA_LIFT_FFT_FUSED", "1")
-    for (nimg, H0, W0, C1, C2) in [(9, 96, 96, 64, 64), (4, 96, 140, 32, 128)]:
+    for (nimg, H0, W0, C1, C2) in [(9, 96, 96, 64, 64), (6, 96, 140, 32, 128)]:
         x = torch.randn(nimg, 3, H0, W0, device=dev).contiguous(memory_format=torch.channels_last)
         w1 = (torch.randn(C1, 3, 5, 5, device=dev) / 75 ** 0.5).contiguous(memory_format=torch.channels_last)
         b1 = torch.randn(C1, device=dev)

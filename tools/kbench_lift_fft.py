@@ -66,7 +66,7 @@ def main():
         assert raw.eqa_debug_lf_clock(out) == 0
         names = ["stage + barrier 1", "prefetch issue", "role work", "barrier 2", "tail row passes", "barrier 3", "column read", "barrier 4"]
         items = max(1, (M * (C // 16) + 255) // 256) if M * (C // 16) >= 256 else 1
-        for base, who in ((0, "convolution wave 1"), (8, "row wave 4"), (16, "column wave 6")):
+        for base, who in ((0, "convolution wave 8"), (8, "column wave 1"), (16, "column wave 0 (packed)")):
             tot = sum(out[base:base + 8])
             print(f"{who}: cycles per item (block 0, {items} items): " + " | ".join(f"{n}: {out[base + i] // items}" for i, n in enumerate(names)) + f" | total {tot // items}")
 
