@@ -22,7 +22,11 @@ PARITY PINNING STATUS
   primitives they delegate to (``F.affine_grid``, ``F.grid_sample``, ``F.pad``, ``F.interpolate``).
   No reference-generated vector exists for them and the reference's own image tests assert no values
   (tests/images/canonicalization/test_discrete_group.py ends without an assert).
-  -> **PARITY UNPINNED** at the kornia/torchvision boundary; guarded by property tests
+  THE ONE COMMAND THAT PINS THEM: ``python tests/golden/regen_with_reference.py --reference <unmodified equiadapt checkout>``
+  on a machine with kornia 0.7.0 + torchvision 0.17.0 (+ e2cnn): it regenerates every image case through the reference's own
+  classes, diffs them against this oracle, and writes ``tests/golden/images_reference.pt``, which
+  ``tests/test_oracle_golden.py::test_oracle_matches_reference_generated_image_vectors`` then checks in every CPU run.
+  -> **PARITY UNPINNED** at the kornia/torchvision boundary until that file exists; guarded by property tests
   (C4 == torch.rot90, group composition, round trips, pad+rotate+crop == clamp-gather) and by
   restatement-generated fixtures that are labelled as such.
 """
