@@ -324,3 +324,32 @@ def test_gloo_world2_on_one_gpu_real_canonicalizers_average_different_shards(kin
         m0, m1 = res[0]["metrics"][step], res[1]["metrics"][step]
         assert m0 == m1
         assert m0["loss"] == pytest.approx((res[0]["losses"][step] + res[1]["losses"][step]) / 2, rel=1e-6)
+
+
+@pytest.mark.timeout(900)
+def test_bench_gpus_4_forward_over_gloo_on_one_gpu_prints_one_line():
+    """The driver's scaling run is `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` on an 8-GPU node; what a
+    one-GPU test box can exercise of it is everything except RCCL's transport: `bench.py --gpus 4 --mode forward` self-spawns four
+    ranks (LOCAL_RANK 0..3 folded onto cuda:0, gloo: RCCL refuses two ranks per device), every rank loads the library, builds its
+    own canonicalizer and batches (per-rank seeds), passes the barriers on both sides of the timed region, and rank 0 prints ONE
+    JSON line with n_gpus = 4, one per-rank time for each of the four ranks, the global batch, and a green parity record for its
+    own batch (reference: examples/images/classification/train_utils.py:89-91: one process per GPU)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EQA_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--mode", "forward", "--steps", "3", "--warmup", "1",
+                          "--batch", "64", "--check-images", "16"], capture_output=True, text=True, env=env, timeout=850)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 4 and line["backend"] == "gloo" and line["ranks_share_gpu"] is True and line["rccl_ranks"] == 0
+    assert len(line["per_rank_ms_per_step"]) == 4 and all(t > 0 for t in line["per_rank_ms_per_step"])
+    assert line["config"]["global_batch"] == 256 and line["config"]["batch_per_gpu"] == 64
+    assert line["parity_ok"] is True and line["self_check"]["ok"] is True
+    assert line["value"] > 0 and abs(line["value"] - 256 * 1e3 / line["ms_per_step"]) <= 1e-6 * line["value"]
