@@ -190,6 +190,23 @@ class ConvNetwork(nn.Module):
             return False
         if any(not bn.training or not bn.affine for bn in list(bns) + [bn1]) or bn1.num_features % 4:
             return False
+        #  what the raw-pointer kernels assume and the module sequence does not: a dropout rate below 1 (rate 1 is 0 / 0
+        # in the row mask; torch returns zeros), fp32 contiguous parameters and running statistics on x's device, no forward hooks on
+        # the submodules the fused path would bypass.  Anything else takes the module sequence (cl_native).  Double backward
+        # (gradient penalties, Hessian-vector products) also needs EQA_CONVNET_TRAIN_MODE=cl_native: the fused Functions are
+        # once_differentiable.
+        drop = self.final_fc[1]
+        if not isinstance(drop, nn.Dropout1d) or not (0.0 <= drop.p < 1.0):
+            return False
+        lin = self.final_fc[3]
+        for m in list(convs) + list(bns) + [bn1, lin]:
+            for t in list(m._parameters.values()) + list(m._buffers.values()):
+                if t is None or t.dtype == torch.int64:          # (num_batches_tracked)
+                    continue
+                if t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous():
+                    return False
+        if any(m._forward_hooks or m._forward_pre_hooks for m in list(self.enc_network.modules()) + list(self.final_fc.modules())):
+            return False
         hw = tuple(x.shape[-2:])
         worst = x.shape[0] * x.shape[1] * hw[0] * hw[1] * 4
         for i, conv in enumerate(convs):

@@ -184,15 +184,26 @@ def group_action_bwd(
 # storage, not an attribute on the tensor: .to() / .clone() / tracing drop attributes silently, and a copy at another address
 # simply has no hint.  The hint only sizes the LDS reservation (eqa_group_action_fwd_hint); a tile whose window exceeds it takes
 # the direct gather path, so a stale or wrong hint costs time, never correctness.
+#  keyed by (device, address, element count) and dropped when the registered tensor dies: the caching allocator hands a
+# freed table's address to the next allocation, and another table at that address must not inherit the hint (it would push every
+# oversized tile onto the slow path without anyone noticing).
 _window_hints: dict = {}
 
 
+def _hint_key(theta: torch.Tensor):
+    return (theta.device.index, theta.data_ptr(), theta.numel())
+
+
 def register_window_hint(theta: torch.Tensor, max_window_rows: int) -> None:
-    _window_hints[theta.data_ptr()] = int(max_window_rows)
+    import weakref
+
+    key = _hint_key(theta)
+    _window_hints[key] = int(max_window_rows)
+    weakref.finalize(theta, _window_hints.pop, key, None)
 
 
 def _window_hint(theta: torch.Tensor, explicit: Optional[int]) -> int:
-    return int(explicit) if explicit is not None else _window_hints.get(theta.data_ptr(), 0)
+    return int(explicit) if explicit is not None else _window_hints.get(_hint_key(theta), 0)
 
 
 def canon_transform(x: torch.Tensor, gidx: torch.Tensor, theta: torch.Tensor, flags: Optional[torch.Tensor], pad: int,

@@ -211,6 +211,7 @@ def knn_sets_agree(idx_a: torch.Tensor, idx_b: torch.Tensor, x: torch.Tensor, k:
 
 # what an fp32 evaluation of the network output may differ from fp64 by, beyond the fp32 oracle's own figure (relative, max norm)
 VEC_REL_SLACK = 1e-6
+FLAT_GATE_COND, FLAT_ROT_TOL, FLAT_COORD_TOL = 50.0, 1e-4, 5e-4   # the flat tolerances, enforced on well-conditioned clouds
 
 
 def pointcloud_parity_record(point_cloud: torch.Tensor, p: Dict[str, torch.Tensor], got_idx: torch.Tensor, got_vec: torch.Tensor,
@@ -244,10 +245,22 @@ def pointcloud_parity_record(point_cloud: torch.Tensor, p: Dict[str, torch.Tenso
     y_tol = 1.5 * own["oracle_coords_err"] + x1 * (own["amplification"] * v_tol + 3e-7) + 3e-6
     clean = ~tie_clouds
     worst = int(own["cond"].argmax())
+    # BASELINE.md's flat tolerance stays a HARD gate where it can hold: on clouds whose Gram-Schmidt step has
+    # condition number < 50 (and whose neighbour sets agree) the product must be within 1e-4 (rotation) / 5e-4 (coordinates) of
+    # the fp32 oracle itself; the derived budget above adds to that check for the ill-conditioned rest, it does not replace it
+    well = clean & (own["cond"] < FLAT_GATE_COND)
+    flat_R, flat_y = amax(got_R - orc["R32"].double()), amax(got_y - orc["y32"].double())
+    flat_ok = bool((flat_R[well] <= FLAT_ROT_TOL).all() and (flat_y[well] <= FLAT_COORD_TOL).all())
+    outside = ((flat_R > FLAT_ROT_TOL) | (flat_y > FLAT_COORD_TOL)) & clean
     ok = bool(knn_ok and (v_err <= v_tol).all() and (gs_err <= 3e-7).all() and (act_err <= 3e-6).all() and (R_err <= R_tol).all()
-              and (y_err <= y_tol).all())
+              and (y_err <= y_tol).all() and flat_ok)
     f = lambda t: float(t.max()) if t.numel() else 0.0  # noqa: E731
     return {"clouds": B, "ok": ok,
+            "flat_baseline_gate": {"ok": flat_ok, "rule": f"clouds with Gram-Schmidt cond < {FLAT_GATE_COND:g} and agreeing neighbour sets: |product - "
+                                   f"fp32 oracle| <= {FLAT_ROT_TOL:g} (rotation) / {FLAT_COORD_TOL:g} (coordinates), BASELINE.md's flat figures",
+                                   "clouds_gated": int(well.sum()), "rotation_max_err_gated": f(flat_R[well]), "coords_max_err_gated": f(flat_y[well]),
+                                   "clouds_outside_flat_tolerance": int(outside.sum()), "fraction_outside_flat_tolerance": float(outside.float().mean()),
+                                   "cond_of_clouds_outside": [float(c) for c in own["cond"][outside][:8]]},
             "knn": {"ok": knn_ok, "points_differing": n_bad, "clouds_differing": int(tie_clouds.sum()),
                     "rule": "sets equal except where the fp64 gap of the k-th / (k+1)-th squared distance is < 1e-5 relative"},
             "vector_rel_err_vs_fp64": f(v_err), "vector_rel_err_oracle_vs_fp64": f(orc["oracle_vector_rel_err"]), "vector_rel_tol": float(v_tol),
