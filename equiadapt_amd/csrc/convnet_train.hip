@@ -75,9 +75,15 @@ __global__ __launch_bounds__(kThreads) void bn_act_stats_kernel(const float* __r
     const int q = qb + q0;
     const bool has_q = q < Q;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = s;
+    // SHIFTED sums: the fp32 accumulators hold sum (x - K) and sum (x - K)^2 with K = the block's first pixel of the
+    // channel, and the block's sum / sum of squares of x are put together from them in fp64 below.  Plain fp32 sums of x^2 lose
+    // ~1e-7 mean^2 / var of the variance to cancellation for a channel whose mean is large against its spread (the head's
+    // BatchNorm1d sits behind a GELU: means well away from 0); shifted, the loss is ~1e-7 of the variance itself.
+    const float4 K = (has_q && p0 < p1) ? reinterpret_cast<const float4*>(x)[p0 * Q + q] : make_float4(0.f, 0.f, 0.f, 0.f);
     if (r0 < rows && has_q) {
       for (size_t p = p0 + r0; p < p1; p += rows) {
-        const float4 v = reinterpret_cast<const float4*>(x)[p * Q + q];
+        float4 v = reinterpret_cast<const float4*>(x)[p * Q + q];
+        v.x -= K.x; v.y -= K.y; v.z -= K.z; v.w -= K.w;
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
       }
@@ -93,7 +99,15 @@ __global__ __launch_bounds__(kThreads) void bn_act_stats_kernel(const float* __r
         ss.x += b.x; ss.y += b.y; ss.z += b.z; ss.w += b.w;
       }
       double* o = partial + ((size_t)blockIdx.x * C + 4 * q) * 2;
-      o[0] = s.x; o[1] = ss.x; o[2] = s.y; o[3] = ss.y; o[4] = s.z; o[5] = ss.z; o[6] = s.w; o[7] = ss.w;
+      const double n = (double)(p1 - p0);
+      auto put = [&](int k, float sd, float sdd, float kk) {      // sum x = sum d + n K;  sum x^2 = sum d^2 + 2 K sum d + n K^2
+        o[2 * k] = (double)sd + n * (double)kk;
+        o[2 * k + 1] = (double)sdd + 2.0 * (double)kk * (double)sd + n * (double)kk * (double)kk;
+      };
+      put(0, s.x, ss.x, K.x);
+      put(1, s.y, ss.y, K.y);
+      put(2, s.z, ss.z, K.z);
+      put(3, s.w, ss.w, K.w);
     }
   }
 }

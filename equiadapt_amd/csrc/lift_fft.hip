@@ -44,7 +44,7 @@ __device__ unsigned long long g_lf_clock[32];
 #define LF_CLOCK_BEGIN() const bool lfc_on = blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (wave == 0 || wave == 1 || wave == 8); \
   unsigned long long lfc_t = __builtin_readcyclecounter(); unsigned long long lfc_s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define LF_CLOCK(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); lfc_s[i] += n_ - lfc_t; lfc_t = n_; } while (0)
-#define LF_CLOCK_END() do { if (lfc_on) for (int i_ = 0; i_ < 8; ++i_) g_lf_clock[8 * (ROLE == kConv ? 0 : (ROLE == kCols ? 1 : 2)) + i_] = lfc_s[i_]; } while (0)
+#define LF_CLOCK_END() do { if (lfc_on) for (int i_ = 0; i_ < 8; ++i_) g_lf_clock[8 * (ROLE == kConv ? 0 : (wave == 1 ? 1 : 2)) + i_] = lfc_s[i_]; } while (0)
 #else
 #define LF_CLOCK_BEGIN() do { } while (0)
 #define LF_CLOCK(i) do { } while (0)
@@ -99,13 +99,13 @@ __device__ __forceinline__ LfItem lf_item(unsigned work, int ngrp, int TY, int T
 //
 // ROLE (a block's 12 waves; one instantiation each, so that a role's registers are live in its own code only; all pass the same
 // eight barriers per item in the same order):
-//   kCols / kColsP  waves 0..5: in the three sub-phases the column transform of the PREVIOUS item and its stores, a third per
+//   kCols  waves 0..5: in the three sub-phases the column transform of the PREVIOUS item and its stores, a third per
 //          sub-phase (the store path of a CU moves ~10 bytes per clock: an item's 147 KB take ~15 k cycles, hidden behind the
-//          convolution of this item), and the staging of the input patches; wave 0 (kColsP) carries the packed edge columns
+//          convolution of this item), and the staging of the input patches; wave 0 also carries the packed edge columns
 //   kConv  waves 6..11: the convolution, 16 tile rows per sub-phase.  Waves w and w + 4 share a SIMD: 6 | 10 and 7 | 11 take 3 + 2 rows,
 //          8 and 9 (alone on their SIMDs) three each
 //   tail   all twelve waves: the row transforms (four consecutive rows x 16 channels per wave), then the column read (waves 0..5)
-enum { kConv = 0, kCols = 1, kColsP = 2 };
+enum { kConv = 0, kCols = 1 };
 
 template <int ROLE>
 __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, const float* __restrict__ bank, const float* __restrict__ bias,
@@ -179,39 +179,56 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[it.grp * kLfCh + 4 * q + r] : 0.0f;
   };
-  // One tile row (3 tiles of 16 pixels): patch rows r0 + drow .. + 4 -> tile row y.  All 57 operands are requested first (immediate
-  // offsets off the per-lane addresses of `setup`: no address arithmetic in the stream), then the 57 matrix instructions STEP by step:
-  // the three tiles' instructions of a step are independent, a dependent instruction follows two others (the scheduler barriers keep
-  // that order).  (Left to the compiler the stream was read -> wait -> multiply per step, 100-160 cycles per matrix instruction and
-  // wave.  Built and measured slower, 45 k against 40 k cycles per item: a hand-pipelined form that requests the next row's first
-  // operands under this row's last instructions and moves the epilogue under the next row's first -- its 143 live registers beside
-  // the row pass of the tail spill into the stream.)
-  auto conv_row = [&](const LfItem& it, int drow, int y) {
-    const bool row_ok = it.gy0 + y < H1;
-    float b[3][kLfSteps];
+  // The wave's tile rows of a sub-phase (a row = 3 tiles of 16 pixels: patch rows r0 + r .. + 4 -> tile row y0 + r).  The 57 matrix
+  // instructions of a row run STEP by step (the three tiles' instructions of a step are independent; the scheduler barriers keep
+  // that order) and the operand reads are interleaved with them by hand, five steps ahead: a wave can have 15 LDS reads in flight
+  // (lgkmcnt), so all 57 requested up front stood in front of the first matrix instruction for ~500 cycles per row.  The first five
+  // steps of the NEXT row are requested under the last five steps of this one.  All reads use immediate offsets off the per-lane
+  // addresses of `setup`.
+  constexpr int kAhead = 5;
+  auto conv_rows = [&](const LfItem& it, int y0) {
+    float b[3][kLfSteps], bq[2][3][kAhead];
+    auto lds_at = [&](int t, int drow, int tx3) {
+      return reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + a_off[t])[drow * kLfPatchPitch + tx3 * 48];
+    };
 #pragma unroll
-    for (int t = 0; t < kLfSteps; ++t)
+    for (int t = 0; t < kAhead; ++t)
 #pragma unroll
-      for (int tx3 = 0; tx3 < 3; ++tx3)
-        b[tx3][t] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + a_off[t])[drow * kLfPatchPitch + tx3 * 48];
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[3] = {bias4, bias4, bias4};
+      for (int tx3 = 0; tx3 < 3; ++tx3) bq[0][tx3][t] = lds_at(t, 0, tx3);
 #pragma unroll
-    for (int t = 0; t < kLfSteps; ++t) {
+    for (int r = 0; r < 3; ++r) {
+      if (r < nr) {       // wave-uniform
+        const int par = r & 1;
+        const bool row_ok = it.gy0 + y0 + r < H1;
+        f32x4 acc[3] = {bias4, bias4, bias4};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int tx3 = 0; tx3 < 3; ++tx3) acc[tx3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t], b[tx3][t], acc[tx3], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int t = 0; t < kLfSteps; ++t) {
 #pragma unroll
-    for (int tx3 = 0; tx3 < 3; ++tx3) {
-      const bool ok = row_ok && it.gx0 + tx3 * 16 + j < W1;
-      f32x4 v = acc[tx3];
+          for (int tx3 = 0; tx3 < 3; ++tx3)
+            acc[tx3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t], t < kAhead ? bq[par][tx3][t] : b[tx3][t], acc[tx3], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (t + kAhead < kLfSteps) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float u = relu ? fmaxf(v[r], 0.0f) : v[r];
-        v[r] = ok ? u : 0.0f;
+            for (int tx3 = 0; tx3 < 3; ++tx3) b[tx3][t + kAhead] = lds_at(t + kAhead, r, tx3);
+          } else if (r + 1 < nr) {
+#pragma unroll
+            for (int tx3 = 0; tx3 < 3; ++tx3) bq[par ^ 1][tx3][t + kAhead - kLfSteps] = lds_at(t + kAhead - kLfSteps, r + 1, tx3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int tx3 = 0; tx3 < 3; ++tx3) {
+          const bool ok = row_ok && it.gx0 + tx3 * 16 + j < W1;
+          f32x4 v = acc[tx3];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float u = relu ? fmaxf(v[k], 0.0f) : v[k];
+            v[k] = ok ? u : 0.0f;
+          }
+          *reinterpret_cast<f32x4*>(tile + (y0 + r) * kLfRowPitch + q * kLfQuadPitch + (tx3 * 16 + j) * 4) = v;
+        }
       }
-      *reinterpret_cast<f32x4*>(tile + y * kLfRowPitch + q * kLfQuadPitch + (tx3 * 16 + j) * 4) = v;
     }
   };
 
@@ -243,12 +260,12 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   const int kc_of0 = 8 * (cw >> 1) + 2 * (cw & 1) + (col_kxi >> 1);       // the pair's even task (kxi & ~1)
   const int kc = kc_of0 + ((col_kxi & 1) ? 4 : 0);
   const bool odd = (col_kxi & 1) != 0;
-  const bool pair_packed = ROLE == kColsP && kc_of0 == 0;                   // the pair whose even task is the packed one
-  const bool packed = ROLE == kColsP && kc == 0;
+  const bool has_packed = COLS && __builtin_amdgcn_readfirstlane((int)(cw == 0)) != 0;   // wave 0 (wave-uniform)
+  const bool pair_packed = COLS && kc_of0 == 0;                             // the pair whose even task is the packed one (wave 0, kxi 0 / 1)
+  const bool packed = COLS && kc == 0;
   const float* const colp = tile + col_cq * kLfQuadPitch + col_ci + kc * 4;   // Re: slot kc; Im: slot 24 + kc (+ 96 floats)
   const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(V, 0, v_bytes, 0x00020000);
   float cre[kFftN], cim[kFftN];      // column data read from LDS, then (in place) the spectrum waiting to be stored
-  float p24re[ROLE == kColsP ? 28 : 1], p24im[ROLE == kColsP ? 28 : 1];     // wave 0: the kx = 24 column of the packed task
   unsigned pend_m = 0, pend_grp = 0;
   bool pending = false;
   // 4 x 4 transpose of (register k, lane row i) across the wave's four 16-lane rows: afterwards register k of row i holds what
@@ -284,6 +301,8 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   auto col_work = [&](auto SUB) {
     constexpr int sub = decltype(SUB)::value;
     if (!pending) return;
+    const size_t rowb = Mp * 2 * (size_t)C * 4;                         // bytes per stored frequency
+    const unsigned col = (unsigned)(((size_t)pend_m * 2 * C + pend_grp * 2 * kLfCh) * 4) + (unsigned)((odd ? 64 : 0) + 16 * col_cq);
     if (sub == 0) {
       float ore[kFftN], oim[kFftN];
       fft48(cre, cim, ore, oim);
@@ -292,9 +311,11 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         cre[ky] = ore[ky];
         cim[ky] = oim[ky];
       }
-      if constexpr (ROLE == kColsP) {
-        // the packed lanes separate their two real columns: C0 = (Z[k] + conj Z[-k]) / 2 replaces Z[k] in place (k = 0..24),
-        // C24 = (Z[k] - conj Z[-k]) / 2i goes to a second pair of streams
+      if (has_packed) {
+        // Wave 0.  The packed lanes separate their two real columns: C0 = (Z[k] + conj Z[-k]) / 2 replaces Z[k] in place (k = 0..24);
+        // C24 = (Z[k] - conj Z[-k]) / 2i leaves at once (seven line stores: even lanes the real quad, odd lanes the imaginary quad,
+        // received) -- kept until its turn in a later sub-phase it would cost every column wave 56 registers.
+        float p24re[28], p24im[28];
 #pragma unroll
         for (int ky = 0; ky < kFftH; ++ky) {
           const int kn = (kFftN - ky) % kFftN;
@@ -306,11 +327,17 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         }
 #pragma unroll
         for (int ky = kFftH; ky < 28; ++ky) p24re[ky] = p24im[ky] = 0.0f;
+#ifndef EQA_LF_NOSTORE
+        const unsigned vb24 = (unsigned)((size_t)(kFftN * kFftInner + 1 + 2 * col_ci) * rowb) + col;
+#pragma unroll
+        for (int g = 0; g < 7; ++g) {
+          const bool live = pair_packed && 4 * g + col_ci < kFftH;
+          store_pair(&p24re[4 * g], &p24im[4 * g], live ? vb24 + (unsigned)g * (unsigned)(8 * rowb) : 0xfffffff0u, 0xfffffff0u, false);
+        }
+#endif
       }
     }
 #ifndef EQA_LF_NOSTORE
-    const size_t rowb = Mp * 2 * (size_t)C * 4;                         // bytes per stored frequency
-    const unsigned col = (unsigned)(((size_t)pend_m * 2 * C + pend_grp * 2 * kLfCh) * 4) + (unsigned)((odd ? 64 : 0) + 16 * col_cq);
     const unsigned f1 = pair_packed ? (unsigned)(kFftN * kFftInner + 2 * col_ci) : (unsigned)(kFftInner * col_ci + kc_of0 - 1);
     const unsigned vb1 = (unsigned)((size_t)f1 * rowb) + col, vs1 = (unsigned)((pair_packed ? 8 : 4 * kFftInner) * rowb);
     const unsigned vb2 = (unsigned)((size_t)(kFftInner * col_ci + kc_of0 + 3) * rowb) + col, vs2 = (unsigned)(4 * kFftInner * rowb);
@@ -319,77 +346,77 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
       const bool live1 = !pair_packed || 4 * g + col_ci < kFftH;
       store_pair(&cre[4 * g], &cim[4 * g], live1 ? vb1 + (unsigned)g * vs1 : 0xfffffff0u, vb2 + (unsigned)g * vs2, true);
     }
-    if constexpr (ROLE == kColsP) {
-      // the kx = 24 line of the packed pair: even lanes the real quad, odd lanes the imaginary quad (received); groups 0..6
-      const unsigned vb24 = (unsigned)((size_t)(kFftN * kFftInner + 1 + 2 * col_ci) * rowb) + col;
-#pragma unroll
-      for (int g = (sub == 0 ? 0 : (sub == 1 ? 3 : 5)); g < (sub == 0 ? 3 : (sub == 1 ? 5 : 7)); ++g) {
-        const bool live = pair_packed && 4 * g + col_ci < kFftH;
-        // (store_pair's first line with the roles of "odd" as above: the odd lane receives the even lane's imaginary quad)
-        store_pair(&p24re[4 * g], &p24im[4 * g], live ? vb24 + (unsigned)g * (unsigned)(8 * rowb) : 0xfffffff0u, 0xfffffff0u, false);
-      }
-    }
 #endif
   };
 
+  // The item loop runs ONE iteration past the block's last item: in it only the column waves work (the last item's transform and
+  // stores) and everybody passes the barriers -- a second copy of that code behind the loop, and a copy of the sub-phase per
+  // sub-phase in the convolution role, made the kernel 70 KB: more than the 64 KB instruction cache two CUs share, and the matrix
+  // instruction streams waited for their own code.
   unsigned cur_grp = 0xffffffffu;
   unsigned v = blockIdx.x;
   if (v < nwork) prefetch(lf_item(v, ngrp, TY, TX), 0, true);
-  for (; v < nwork; v += nblk) {
-    const LfItem it = lf_item(v, ngrp, TY, TX);
+  for (;; v += nblk) {
+    const bool live = v < nwork;          // block-uniform
+    if (!live && !pending) break;
+    const LfItem it = lf_item(live ? v : 0, ngrp, TY, TX);
     const unsigned vn = v + nblk;
-    const LfItem nx = lf_item(vn < nwork ? vn : v, ngrp, TY, TX);
-    auto subphase = [&](auto SUB) {
-      constexpr int sub = decltype(SUB)::value;
-      stage();
-      __syncthreads();
-      LF_CLOCK(0);
-      if (sub < 2) prefetch(it, sub + 1, true);
-      else prefetch(nx, 0, vn < nwork);
-      LF_CLOCK(1);
-      if constexpr (ROLE == kConv) {
-        if (sub == 0 && it.grp != cur_grp) {     // (one block per CU and a group count that divides the grid: a block stays on its group)
-          setup(it);
-          cur_grp = it.grp;
+    const bool next_live = live && vn < nwork;
+    const LfItem nx = lf_item(next_live ? vn : 0, ngrp, TY, TX);
+    if constexpr (ROLE == kConv) {
+#pragma unroll 1
+      for (int sub = 0; sub < 3; ++sub) {
+        __syncthreads();
+        LF_CLOCK(0);
+        if (live) {
+          if (sub == 0 && it.grp != cur_grp) {     // (one block per CU and a group count that divides the grid: a block stays on its group)
+            setup(it);
+            cur_grp = it.grp;
+          }
+          conv_rows(it, kLfSubRows * sub + r0);
         }
-        conv_row(it, 0, kLfSubRows * sub + r0);
-        conv_row(it, 1, kLfSubRows * sub + r0 + 1);
-        if (nr == 3) conv_row(it, 2, kLfSubRows * sub + r0 + 2);
-      } else {
-        col_work(SUB);
+        LF_CLOCK(2);
+        __syncthreads();
+        LF_CLOCK(3);
       }
-      LF_CLOCK(2);
-      __syncthreads();
-      LF_CLOCK(3);
-    };
-    subphase(std::integral_constant<int, 0>());
-    subphase(std::integral_constant<int, 1>());
-    subphase(std::integral_constant<int, 2>());
+    } else {
+      auto subphase = [&](auto SUB) {
+        constexpr int sub = decltype(SUB)::value;
+        stage();
+        __syncthreads();
+        LF_CLOCK(0);
+        if (sub < 2) prefetch(it, sub + 1, live);
+        else prefetch(nx, 0, next_live);
+        LF_CLOCK(1);
+        col_work(SUB);
+        LF_CLOCK(2);
+        __syncthreads();
+        LF_CLOCK(3);
+      };
+      subphase(std::integral_constant<int, 0>());
+      subphase(std::integral_constant<int, 1>());
+      subphase(std::integral_constant<int, 2>());
+    }
     // ---- the tail: every wave transforms four rows, then the column waves read their columns
-    row_pass(4 * wave);
+    if (live) row_pass(4 * wave);
     LF_CLOCK(4);
     __syncthreads();
     LF_CLOCK(5);
     if constexpr (COLS) {
+      if (live) {
 #pragma unroll
-      for (int y = 0; y < kFftN; ++y) {
-        cre[y] = colp[y * kLfRowPitch];
-        cim[y] = colp[y * kLfRowPitch + 24 * 4];
+        for (int y = 0; y < kFftN; ++y) {
+          cre[y] = colp[y * kLfRowPitch];
+          cim[y] = colp[y * kLfRowPitch + 24 * 4];
+        }
       }
     }
     pend_m = it.m;
     pend_grp = it.grp;
-    pending = true;
+    pending = live;
     LF_CLOCK(6);
     __syncthreads();
     LF_CLOCK(7);
-  }
-  if constexpr (COLS) {
-    if (pending) {
-      col_work(std::integral_constant<int, 0>());
-      col_work(std::integral_constant<int, 1>());
-      col_work(std::integral_constant<int, 2>());
-    }
   }
   LF_CLOCK_END();
 }
@@ -398,8 +425,7 @@ __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_kernel(const flo
                                                                         const float* __restrict__ bias, int relu, float* __restrict__ V,
                                                                         int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
                                                                         unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
-  if (threadIdx.x < 64) lift5_fft48_body<kColsP>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
-  else if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
   else lift5_fft48_body<kConv>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
 }
 

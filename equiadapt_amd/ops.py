@@ -588,7 +588,7 @@ def _bn_act_partials(z: torch.Tensor) -> torch.Tensor:
 
 def bn_batch_stats(z: torch.Tensor):
     """Per-channel batch mean and BIASED variance (fp64) of a channels-last (npix, C) view (eqa_bn_act_stats: fp32 sums inside
-    blocks of <= 256 pixels, fp64 across them)."""
+    blocks of up to 1024 pixels -- shifted by the block's first pixel, so that a large mean does not cancel the variance --, fp64 across them)."""
     z = _need(z, "z")
     sums = _bn_act_partials(z).sum(0)
     mean = sums[:, 0] / z.shape[0]
