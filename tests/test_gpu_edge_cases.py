@@ -436,8 +436,8 @@ def test_window_hint_changes_the_lds_reservation_not_the_result(dev):
             th, fl = device_tables("canonicalize", 4, refl, (H + 2 * pad, W + 2 * pad), dev)
             # the hint is registered for square frames only (a quarter turn on a non-square frame stretches the window), explicitly,
             # not as a tensor attribute; the launch without it must give the same bits
-            assert ops._window_hints.get(th.data_ptr(), 0) == (35 if H == W else 0)
-            assert ops._window_hints.get(th.clone().data_ptr(), 0) == 0          # a copy has no hint: the safe default
+            assert ops._window_hint(th, None) == (35 if H == W else 0)
+            assert ops._window_hint(th.clone(), None) == 0                         # a copy has no hint: the safe default
             y = ops.canon_transform(x, gidx, th, fl, pad)                       # takes the hint where there is one
             assert torch.equal(y, ops.canon_transform(x, gidx, th, fl, pad, max_window=0))
             assert (y - ops.canon_transform(x, gidx, th, fl, pad, max_window=35)).abs().max().item() <= (0.0 if H == W else 2e-6)
@@ -457,7 +457,7 @@ def test_window_hint_changes_the_lds_reservation_not_the_result(dev):
     x = torch.randn(8, 3, 96, 96, device=dev)
     gidx = torch.arange(8, device=dev, dtype=torch.int32)
     th8, fl8 = device_tables("canonicalize", 8, False, (192, 192), dev)
-    assert th8.data_ptr() not in ops._window_hints
+    assert ops._window_hint(th8, None) == 0
     want = ops.canon_transform(x, gidx, th8, fl8, 48)
     got = torch.empty_like(x)
     assert lib.eqa_group_action_fwd_hint(x.data_ptr(), got.data_ptr(), gidx.data_ptr(), th8.data_ptr(), fl8.data_ptr(), None, 8, 1, 8, 8, 3,

@@ -43,16 +43,22 @@ for w in $what; do
       ;;
     rccl1)
       # the same forward bench bare and as a 1-rank RCCL job under the launcher the driver uses: `value` must agree within 2 %
-      python bench.py --mode forward --no-cpu-baseline > "$out/bench_forward_bare.json" 2>/dev/null
-      python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 1 --mode forward --no-cpu-baseline > "$out/bench_forward_rccl_world1.json" 2> "$out/bench_forward_rccl_world1.err"
+      # (two rounds, alternating: the chip's clocks differ by 2-3 % from run to run)
+      for i in 1 2; do
+        python bench.py --mode forward --no-cpu-baseline > "$out/bench_forward_bare_$i.json" 2>/dev/null
+        python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 2957$i bench.py --gpus 1 --mode forward --no-cpu-baseline > "$out/bench_forward_rccl_world1_$i.json" 2> "$out/bench_forward_rccl_world1_$i.err"
+      done
       EQA_BENCH_BACKEND=gloo python bench.py --gpus 4 --mode forward --steps 5 --warmup 2 --batch 64 --check-images 16 > "$out/bench_gloo_world4_one_gpu.json" 2>/dev/null
       python - "$out" <<'PY'
 import json, sys
 o = sys.argv[1]
-a = json.loads(open(o + "/bench_forward_bare.json").read().strip().splitlines()[-1])
-b = json.loads(open(o + "/bench_forward_rccl_world1.json").read().strip().splitlines()[-1])
-print(f"bare: {a['value']:.0f} img/s (rccl_ranks {a['rccl_ranks']}); torch.distributed.run --nproc-per-node 1: {b['value']:.0f} img/s "
-      f"(rccl_ranks {b['rccl_ranks']}, backend {b['backend']}); ratio {b['value'] / a['value']:.4f}", file=open(o + "/rccl_world1_vs_bare.txt", "w"))
+rows = []
+for i in (1, 2):
+    a = json.loads(open(o + f"/bench_forward_bare_{i}.json").read().strip().splitlines()[-1])
+    b = json.loads(open(o + f"/bench_forward_rccl_world1_{i}.json").read().strip().splitlines()[-1])
+    rows.append(f"round {i}: bare {a['value']:.0f} img/s (rccl_ranks {a['rccl_ranks']}); torch.distributed.run --nproc-per-node 1: {b['value']:.0f} img/s "
+                f"(rccl_ranks {b['rccl_ranks']}, backend {b['backend']}); ratio {b['value'] / a['value']:.4f}")
+open(o + "/rccl_world1_vs_bare.txt", "w").write("\n".join(rows) + "\n")
 PY
       cat "$out/rccl_world1_vs_bare.txt"
       ;;
