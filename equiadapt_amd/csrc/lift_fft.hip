@@ -178,6 +178,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[it.grp * kLfCh + 4 * q + r] : 0.0f;
+    asm volatile("" : "+v"(bias4));      // opaque: otherwise re-loaded from memory in front of every sub-phase's first matrix instruction
   };
   // The wave's tile rows of a sub-phase (a row = 3 tiles of 16 pixels: patch rows r0 + r .. + 4 -> tile row y0 + r).  The 57 matrix
   // instructions of a row run STEP by step (the three tiles' instructions of a step are independent; the scheduler barriers keep
@@ -185,11 +186,18 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   // (lgkmcnt), so all 57 requested up front stood in front of the first matrix instruction for ~500 cycles per row.  The first five
   // steps of the NEXT row are requested under the last five steps of this one.  All reads use immediate offsets off the per-lane
   // addresses of `setup`.
-  constexpr int kAhead = 5;
+#ifndef EQA_LF_AHEAD
+#define EQA_LF_AHEAD 5
+#endif
+  constexpr int kAhead = EQA_LF_AHEAD;
   auto conv_rows = [&](const LfItem& it, int y0) {
     float b[3][kLfSteps], bq[2][3][kAhead];
     auto lds_at = [&](int t, int drow, int tx3) {
+#ifdef EQA_LF_NOLDSREAD   // ablation: the matrix stream without its operand reads
+      return __builtin_bit_cast(float, a_off[t] + (unsigned)(drow + tx3));
+#else
       return reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + a_off[t])[drow * kLfPatchPitch + tx3 * 48];
+#endif
     };
 #pragma unroll
     for (int t = 0; t < kAhead; ++t)
@@ -206,7 +214,11 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         for (int t = 0; t < kLfSteps; ++t) {
 #pragma unroll
           for (int tx3 = 0; tx3 < 3; ++tx3)
+#ifdef EQA_LF_NOMFMA      // ablation: the operand reads and the epilogue without the matrix instructions
+            acc[tx3][t & 3] += wreg[t] * (t < kAhead ? bq[par][tx3][t] : b[tx3][t]);
+#else
             acc[tx3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[t], t < kAhead ? bq[par][tx3][t] : b[tx3][t], acc[tx3], 0, 0, 0);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           if (t + kAhead < kLfSteps) {
 #pragma unroll
