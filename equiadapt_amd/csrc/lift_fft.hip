@@ -107,11 +107,42 @@ __device__ __forceinline__ LfItem lf_item(unsigned work, int ngrp, int TY, int T
 //   tail   all twelve waves: the row transforms (four consecutive rows x 16 channels per wave), then the column read (waves 0..5)
 enum { kConv = 0, kCols = 1 };
 
-template <int ROLE>
+template <class F, int... Is>
+__device__ __forceinline__ void lf_for_const(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>()), ...);
+}
+
+// PIECES (round 6, second form): the convolution on the bf16 matrix cores.  The fp32 matrix instruction runs on the vector ALU's
+// datapath (profiles/r06/mfma_valu_overlap.txt): the transforms' vector work queues behind it at a third of its rate.  Here every
+// fp32 pixel and weight is split EXACTLY into three bf16 pieces (8 + 8 + 8 mantissa bits) and a product is six piece products on
+// v_mfma_f32_16x16x32_bf16, fp32 accumulation (the three of relative size <= 2^-24 left out: the contract of eqa_fft48k5_cgemm3m_bf16x3).
+//   K layout: a pixel = 4 bf16 (3 channels + 0), a chunk = 8 K-elements = 2 pixels (kx = 2 p, 2 p + 1; kx = 5: weight 0), a filter row
+//   = 3 chunks, 15 chunks + 1 spare = 16 = 4 matrix instructions of K = 32 per piece product: 24 instructions per 16-pixel tile
+//   (the fp32 form: 19 of twice the duration).
+//   LDS: the patch as three piece planes of 8 rows x 53 pixels x 8 bytes (a ring over the input rows: rows 4 s .. 4 s + 7 serve the
+//   sub-phase of tile rows 4 s .. 4 s + 3; twelve sub-phases per item), 10 KB like the fp32 patch of 20 rows.
+constexpr int kLpRowB = 53 * 8;                  // bytes per patch row and plane (52 pixels + 1 finite pad pixel: the kx = 5 slot of the last tile)
+constexpr int kLpPlaneB = 8 * kLpRowB;           // 3,392 bytes
+constexpr int kLpPatchB = 3 * kLpPlaneB;         // 10,176 bytes
+constexpr int kLpLdsBytes = kLfTileFloats * 4 + kLpPatchB;   // 160,704 bytes
+typedef __bf16 lf_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 lf_bf16x4 __attribute__((ext_vector_type(4)));
+// x = p1 + p2 + p3 exactly (round to nearest each time: the remainder of an 8-bit piece fits the next)
+__device__ __forceinline__ void lf_split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - (float)p1;
+  p2 = (__bf16)r1;
+  p3 = (__bf16)(r1 - (float)p2);
+}
+
+template <int ROLE, bool PIECES>
 __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, const float* __restrict__ bank, const float* __restrict__ bias,
                                                  int relu, float* __restrict__ V, int H0, int W0, int C, int TY, int TX, size_t Mp,
                                                  unsigned nwork, unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
   constexpr bool COLS = ROLE != kConv;
+  constexpr int NSUB = PIECES ? 12 : 3;              // sub-phases per item
+  constexpr int SUBROWS = kFftN / NSUB;              // tile rows per sub-phase (4 | 16)
+  constexpr int NGRP = 12 / NSUB;                    // frequency groups a column wave stores per sub-phase (1 | 4)
   extern __shared__ float lds[];
   float* const tile = lds;
   float* const patch = lds + kLfTileFloats;
@@ -150,6 +181,39 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
       for (int i = 0; i < kLfPre; ++i) {
         const int idx = tid + kLfStagers * i;
         if (idx < kLfPatchFloats) patch[idx] = pre[i];
+      }
+    }
+  };
+
+  // PIECES: input rows in groups of four (group g = patch rows 4 g .. 4 g + 3, 13 groups per item, ring slot g % 2): thread t < 208 of
+  // the column waves owns pixel (row t / 52, x t % 52) of a group -- three dword loads one sub-phase ahead, three 8-byte LDS stores
+  // (one per piece plane: c0 c1 c2 0).  `which`: the register set (the last sub-phase of an item fetches two groups of the next).
+  float preg[COLS && PIECES ? 2 : 1][3];
+  auto prefetch_grp = [&](const LfItem& it, int g, int which, bool live) {
+    if constexpr (COLS && PIECES) {
+      int tq = tid;
+      asm volatile("" : "+v"(tq));
+      const int pr = tq / 52, px = tq - pr * 52;
+      const int gy = it.gy0 + 4 * g + pr, gx = it.gx0 + px;
+      const bool ok = live && tq < 208 && gy < H0 && gx < W0;
+      const unsigned off = ok ? (unsigned)((((it.img * H0 + gy) * (size_t)W0 + gx) * 3) * 4) : 0xfffffff0u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) preg[which][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, c * 4, 0));
+    }
+  };
+  auto stage_grp = [&](int g, int which) {
+    if constexpr (COLS && PIECES) {
+      if (tid < 208) {
+        const int pr = tid / 52, px = tid - pr * 52;
+        __bf16 pc[3][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lf_split3(preg[which][c], pc[0][c], pc[1][c], pc[2][c]);
+        char* dst = reinterpret_cast<char*>(lds) + patch_b + ((4 * g + pr) & 7) * kLpRowB + px * 8;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const lf_bf16x4 v = {pc[pl][0], pc[pl][1], pc[pl][2], (__bf16)0.0f};
+          *reinterpret_cast<lf_bf16x4*>(dst + pl * kLpPlaneB) = v;
+        }
       }
     }
   };
@@ -239,6 +303,96 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
             v[k] = ok ? u : 0.0f;
           }
           *reinterpret_cast<f32x4*>(tile + (y0 + r) * kLfRowPitch + q * kLfQuadPitch + (tx3 * 16 + j) * 4) = v;
+        }
+      }
+    }
+  };
+
+  // ---- PIECES convolution.  Lane (i = lane % 16, q = lane / 16): chunk c = 4 s + q of K-step s = (filter row ky = c / 3, pixel pair
+  // c % 3); A = weights of channel i (three pieces x four K-steps x 16 bytes, resident), B = the pixel pair (j + 2 pair, + 1) of pixel j.
+  lf_bf16x8 wq[PIECES ? 4 : 1][PIECES ? 3 : 1];
+  unsigned c_off[PIECES ? 4 : 1];      // per K-step: byte offset of the lane's chunk in patch row 0, tile column 0, plane 0
+  int c_ky[PIECES ? 4 : 1];
+  auto setup_p = [&](const LfItem& it) {
+    if constexpr (PIECES) {
+      const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bank), 0, bank_bytes, 0x00020000);
+#pragma unroll
+      for (int sstep = 0; sstep < 4; ++sstep) {
+        const int c = 4 * sstep + q;
+        c_ky[sstep] = min(c / 3, 4);
+        c_off[sstep] = (unsigned)((j + 2 * (c % 3)) * 8);
+#pragma unroll
+        for (int wp = 0; wp < 3; ++wp) {
+          // wpieces: (Cout, 3 pieces, 16 chunks, 8) bf16
+          const unsigned off = (unsigned)((((it.grp * kLfCh + j) * 3 + wp) * 16 + c) * 16);
+          wq[sstep][wp] = __builtin_bit_cast(lf_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(br, off, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[it.grp * kLfCh + 4 * q + r] : 0.0f;
+      asm volatile("" : "+v"(bias4));
+    }
+  };
+  // nt (1..3, wave-uniform) tiles tx0 .. tx0 + nt - 1 of tile row y (row of the ITEM: patch rows y .. y + 4 sit in ring slots (y + ky) % 8)
+  auto conv_tiles_p = [&](const LfItem& it, int y, int tx0, auto NT) {
+    constexpr int nt = decltype(NT)::value;     // compile-time: a wave-uniform `t < nt` in front of every matrix instruction became a branch each
+    if constexpr (PIECES) {
+      const bool row_ok = it.gy0 + y < H1;
+      unsigned addr[4];
+#pragma unroll
+      for (int sstep = 0; sstep < 4; ++sstep) addr[sstep] = patch_b + (unsigned)(((y + c_ky[sstep]) & 7) * kLpRowB) + c_off[sstep] + (unsigned)(tx0 * 16 * 8);
+      f32x4 acc[3] = {bias4, bias4, bias4};
+      lf_bf16x8 bp[2][3][3];
+      auto read_step = [&](int sstep, int buf) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+          if (t < nt)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#ifdef EQA_LF_NOLDSREAD
+            {
+              const f32x4 cv = {1.0f + (float)(addr[sstep] & 7), 0.5f + t, 0.25f + pl, 2.0f};
+              bp[buf][t][pl] = __builtin_bit_cast(lf_bf16x8, cv);
+            }
+#else
+            {
+              // two 8-byte reads (ds_read2_b64): the pixel pair sits at an 8-byte boundary, and a 16-byte LDS read off a 16-byte
+              // boundary takes ~200 cycles on this chip (the first build: 122 k instead of 33 k cycles per item)
+              typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+              const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(lds) + addr[sstep] + t * 128 + pl * kLpPlaneB);
+              const u64x2_t two = {pp[0], pp[1]};
+              bp[buf][t][pl] = __builtin_bit_cast(lf_bf16x8, two);
+            }
+#endif
+      };
+      read_step(0, 0);
+#pragma unroll
+      for (int sstep = 0; sstep < 4; ++sstep) {
+        const int buf = sstep & 1;
+        if (sstep + 1 < 4) read_step(sstep + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // six piece products, small terms first: (w3, p1) (w1, p3) (w2, p2) (w2, p1) (w1, p2) (w1, p1)
+        constexpr int kW[6] = {2, 0, 1, 1, 0, 0}, kP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            if (t < nt) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[sstep][kW[pr]], bp[buf][t][kP[pr]], acc[t], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t < nt) {
+          const int tx3 = tx0 + t;
+          const bool ok = row_ok && it.gx0 + tx3 * 16 + j < W1;
+          f32x4 v = acc[t];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float u = relu ? fmaxf(v[k], 0.0f) : v[k];
+            v[k] = ok ? u : 0.0f;
+          }
+          *reinterpret_cast<f32x4*>(tile + y * kLfRowPitch + q * kLfQuadPitch + (tx3 * 16 + j) * 4) = v;
         }
       }
     }
@@ -354,7 +508,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     const unsigned vb1 = (unsigned)((size_t)f1 * rowb) + col, vs1 = (unsigned)((pair_packed ? 8 : 4 * kFftInner) * rowb);
     const unsigned vb2 = (unsigned)((size_t)(kFftInner * col_ci + kc_of0 + 3) * rowb) + col, vs2 = (unsigned)(4 * kFftInner * rowb);
 #pragma unroll
-    for (int g = 4 * sub; g < 4 * sub + 4; ++g) {
+    for (int g = NGRP * sub; g < NGRP * sub + NGRP; ++g) {
       const bool live1 = !pair_packed || 4 * g + col_ci < kFftH;
       store_pair(&cre[4 * g], &cim[4 * g], live1 ? vb1 + (unsigned)g * vs1 : 0xfffffff0u, vb2 + (unsigned)g * vs2, true);
     }
@@ -367,7 +521,17 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   // instruction streams waited for their own code.
   unsigned cur_grp = 0xffffffffu;
   unsigned v = blockIdx.x;
-  if (v < nwork) prefetch(lf_item(v, ngrp, TY, TX), 0, true);
+  if constexpr (PIECES) {
+    // the pad pixel of every patch row and plane: finite (its weight is 0), written once
+    if (COLS && tid < 24) *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds) + patch_b + tid * kLpRowB + 52 * 8) = 0ull;
+    const LfItem f = lf_item(v < nwork ? v : 0, ngrp, TY, TX);
+    prefetch_grp(f, 0, 0, v < nwork);
+    prefetch_grp(f, 1, 1, v < nwork);
+    stage_grp(0, 0);
+    stage_grp(1, 1);
+  } else {
+    if (v < nwork) prefetch(lf_item(v, ngrp, TY, TX), 0, true);
+  }
   for (;; v += nblk) {
     const bool live = v < nwork;          // block-uniform
     if (!live && !pending) break;
@@ -377,15 +541,25 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     const LfItem nx = lf_item(next_live ? vn : 0, ngrp, TY, TX);
     if constexpr (ROLE == kConv) {
 #pragma unroll 1
-      for (int sub = 0; sub < 3; ++sub) {
+      for (int sub = 0; sub < NSUB; ++sub) {
         __syncthreads();
         LF_CLOCK(0);
         if (live) {
           if (sub == 0 && it.grp != cur_grp) {     // (one block per CU and a group count that divides the grid: a block stays on its group)
-            setup(it);
+            if constexpr (PIECES) setup_p(it);
+            else setup(it);
             cur_grp = it.grp;
           }
-          conv_rows(it, kLfSubRows * sub + r0);
+          if constexpr (PIECES) {
+            // the sub-phase's 12 tiles, three per SIMD: waves 8, 9 (alone on theirs) a row each, 6 | 10 and 7 | 11 share a row 2 + 1
+            const int y = SUBROWS * sub + (wave == 8 ? 0 : (wave == 9 ? 1 : ((wave == 6 || wave == 10) ? 2 : 3)));
+            const int tx0 = (wave == 10 || wave == 11) ? 2 : 0;
+            if (wave == 8 || wave == 9) conv_tiles_p(it, y, tx0, std::integral_constant<int, 3>());
+            else if (wave == 10 || wave == 11) conv_tiles_p(it, y, tx0, std::integral_constant<int, 1>());
+            else conv_tiles_p(it, y, tx0, std::integral_constant<int, 2>());
+          } else {
+            conv_rows(it, kLfSubRows * sub + r0);
+          }
         }
         LF_CLOCK(2);
         __syncthreads();
@@ -394,20 +568,36 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     } else {
       auto subphase = [&](auto SUB) {
         constexpr int sub = decltype(SUB)::value;
-        stage();
+        if constexpr (!PIECES) stage();
         __syncthreads();
         LF_CLOCK(0);
-        if (sub < 2) prefetch(it, sub + 1, live);
-        else prefetch(nx, 0, next_live);
+        if constexpr (PIECES) {
+          // what is staged behind this sub-phase's second barrier: group sub + 2 of this item, or the first two groups of the next
+          if (sub < NSUB - 1) {
+            prefetch_grp(it, sub + 2, 0, live);
+          } else {
+            prefetch_grp(nx, 0, 0, next_live);
+            prefetch_grp(nx, 1, 1, next_live);
+          }
+        } else {
+          if (sub < NSUB - 1) prefetch(it, sub + 1, live);
+          else prefetch(nx, 0, next_live);
+        }
         LF_CLOCK(1);
         col_work(SUB);
         LF_CLOCK(2);
         __syncthreads();
         LF_CLOCK(3);
+        if constexpr (PIECES) {
+          if (sub < NSUB - 1) {
+            stage_grp(sub + 2, 0);
+          } else {
+            stage_grp(0, 0);
+            stage_grp(1, 1);
+          }
+        }
       };
-      subphase(std::integral_constant<int, 0>());
-      subphase(std::integral_constant<int, 1>());
-      subphase(std::integral_constant<int, 2>());
+      lf_for_const(subphase, std::make_integer_sequence<int, NSUB>());
     }
     // ---- the tail: every wave transforms four rows, then the column waves read their columns
     if (live) row_pass(4 * wave);
@@ -437,8 +627,17 @@ __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_kernel(const flo
                                                                         const float* __restrict__ bias, int relu, float* __restrict__ V,
                                                                         int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
                                                                         unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
-  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
-  else lift5_fft48_body<kConv>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+  else lift5_fft48_body<kConv, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+}
+
+// the same with the convolution on the bf16 matrix cores; `bank` = the weights' pieces (Cout, 3, 16, 8) bf16
+__global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_pieces_kernel(const float* __restrict__ x, const float* __restrict__ bank,
+                                                                               const float* __restrict__ bias, int relu, float* __restrict__ V,
+                                                                               int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
+                                                                               unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+  else lift5_fft48_body<kConv, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
 }
 
 }  // namespace
@@ -453,8 +652,8 @@ int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout) {
   return (Cin == 3 && KH == 5 && KW == 5 && Cout > 0 && Cout % kLfCh == 0) ? 1 : 0;
 }
 
-int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
-                            void* stream) {
+static int lift_fft_launch(const float* x, const void* bank, size_t bank_bytes, const float* bias, int relu, float* V, int nimg, int H0, int W0,
+                           int Cout, void* stream, bool pieces) {
   if (!x || !bank || !V || nimg < 0 || H0 < 5 || W0 < 5 || Cout <= 0) return EQA_ERR_INVALID_ARG;
   if (Cout % kLfCh != 0) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
@@ -464,17 +663,35 @@ int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias
   const size_t M = (size_t)nimg * TY * TX;
   const size_t nwork = M * (Cout / kLfCh);
   const size_t vb = (size_t)kFftF * fft_pitch(M) * 2 * Cout * 4;
-  const size_t xb = (size_t)nimg * H0 * W0 * 3 * 4, bb = (size_t)Cout * 75 * 4;
-  if (nwork > 0x7fffffffULL || vb > 0xffffff00ULL || xb > 0xffffff00ULL || bb > 0xffffff00ULL) return EQA_ERR_UNSUPPORTED;
-  if (!allow_dynamic_lds((const void*)lift5_fft48_fused_kernel, kLfLdsFloats * 4)) return EQA_ERR_UNSUPPORTED;
-  // persistent: one block per CU; a multiple of the group count keeps a block on ONE channel group (its weights stay put in L1)
+  const size_t xb = (size_t)nimg * H0 * W0 * 3 * 4;
+  if (nwork > 0x7fffffffULL || vb > 0xffffff00ULL || xb > 0xffffff00ULL || bank_bytes > 0xffffff00ULL) return EQA_ERR_UNSUPPORTED;
+  const void* kern = pieces ? (const void*)lift5_fft48_fused_pieces_kernel : (const void*)lift5_fft48_fused_kernel;
+  const int lds_bytes = pieces ? kLpLdsBytes : kLfLdsFloats * 4;
+  if (!allow_dynamic_lds(kern, lds_bytes)) return EQA_ERR_UNSUPPORTED;
+  // persistent: one block per CU; a multiple of the group count keeps a block on ONE channel group (its weights stay in registers)
   const unsigned ngrp = (unsigned)(Cout / kLfCh);
   unsigned nblk = 256;
   if (ngrp <= 256) nblk = (256 / ngrp) * ngrp;
   if ((size_t)nblk > nwork) nblk = (unsigned)nwork;
-  hipLaunchKernelGGL(lift5_fft48_fused_kernel, dim3(nblk), dim3(kLfThreads), kLfLdsFloats * sizeof(float), (hipStream_t)stream, x, bank, bias,
-                     relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bb);
+  if (pieces)
+    hipLaunchKernelGGL(lift5_fft48_fused_pieces_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
+                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes);
+  else
+    hipLaunchKernelGGL(lift5_fft48_fused_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
+                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes);
   return launch_status();
+}
+
+int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
+                            void* stream) {
+  return lift_fft_launch(x, bank, (size_t)(Cout > 0 ? Cout : 0) * 75 * 4, bias, relu, V, nimg, H0, W0, Cout, stream, false);
+}
+
+int64_t eqa_lift5_pieces_bytes(int Cout) { return Cout > 0 ? (int64_t)Cout * 3 * 16 * 8 * 2 : 0; }
+
+int eqa_lift5_fft48k5_input_bf16x3(const float* x, const void* wpieces, const float* bias, int relu, float* V, int nimg, int H0, int W0,
+                                   int Cout, void* stream) {
+  return lift_fft_launch(x, wpieces, (size_t)eqa_lift5_pieces_bytes(Cout), bias, relu, V, nimg, H0, W0, Cout, stream, true);
 }
 
 }  // extern "C"

@@ -148,13 +148,33 @@ class LiftedInput:
     place of that map and produces the map's tile spectra straight from x (eqa_lift5_fft48k5_input: the lifting convolution fused
     into the forward FFT-48 transform -- the 2.2 GB map of the headline shape is neither written nor read)."""
 
-    def __init__(self, x: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor], relu: bool):
+    def __init__(self, x: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, pieces: Optional[torch.Tensor] = None):
         assert x.dim() == 4 and x.shape[1] == 3 and bank.shape[1:] == (3, 5, 5)
         self.x = x.contiguous(memory_format=torch.channels_last)
         self.bank = bank.contiguous(memory_format=torch.channels_last)           # memory order (C, 5, 5, 3)
         self.bias, self.relu = (bias.contiguous() if bias is not None else None), bool(relu)
         self.shape = torch.Size((x.shape[0], bank.shape[0], x.shape[2] - 4, x.shape[3] - 4))
         self.device, self.dtype, self.is_cuda = x.device, x.dtype, x.is_cuda
+        self._pieces = pieces
+
+    def pieces(self) -> torch.Tensor:
+        """The folded bank as the operand of eqa_lift5_fft48k5_input_bf16x3: (C, 3 pieces, 16 chunks, 8) bf16 -- chunk c < 15 = (filter
+        row c // 3, pixel pair c % 3): [w(ci 0..2, kx = 2 p), 0, w(ci 0..2, kx = 2 p + 1), 0] (kx = 5: 0), chunk 15 = 0; every value
+        split exactly into three bf16 pieces (built once per LiftedInput; the network caches it per weight version)."""
+        if self._pieces is None:
+            w = self.bank.float()                                   # (C, 3, 5, 5) logical
+            C = w.shape[0]
+            wp = torch.zeros(C, 5, 6, 4, dtype=torch.float32, device=w.device)       # (co, ky, kx padded to 6, ci padded to 4)
+            wp[:, :, :5, :3] = w.permute(0, 2, 3, 1)
+            chunks = torch.zeros(C, 16, 8, dtype=torch.float32, device=w.device)
+            chunks[:, :15] = wp.reshape(C, 5, 3, 8).reshape(C, 15, 8)
+            p0 = chunks.bfloat16()
+            r1 = chunks - p0.float()
+            p1 = r1.bfloat16()
+            p2 = (r1 - p1.float()).bfloat16()
+            assert torch.equal((p0.float() + p1.float()) + p2.float(), chunks), "the three bf16 pieces of a weight must add up exactly"
+            self._pieces = torch.stack([p0, p1, p2], dim=1).contiguous()
+        return self._pieces
 
     def materialize(self) -> torch.Tensor:
         """The map itself, channels-last (the unfused lifting kernel) -- for a consumer that turned out not to be `conv5x5`."""
@@ -162,6 +182,8 @@ class LiftedInput:
         return y
 
 
+# how the fused kernel multiplies: "f32" = v_mfma_f32_16x16x4_f32, "bf16x3" = exact three-piece splits, six products on the bf16 matrix cores
+LIFT_FFT_FORM = os.environ.get("EQA_LIFT_FFT_FORM", "f32")
 LIFT_FFT_FUSED_DEFAULT = "1"     # EQA_LIFT_FFT_FUSED=0: the two kernels (eqa_lift_conv_grouped, eqa_fft48k5_input_grouped)
 
 
@@ -293,8 +315,13 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
         if isinstance(x, LiftedInput):
             assert in_bias is None and not in_relu
             with _timed("lift_fft_input"):
-                _lib.check(lib.eqa_lift5_fft48k5_input(x.x.data_ptr(), x.bank.data_ptr(), x.bias.data_ptr() if x.bias is not None else None,
-                                                       int(x.relu), V.data_ptr(), nimg, H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input")
+                p_b = x.bias.data_ptr() if x.bias is not None else None
+                if LIFT_FFT_FORM == "bf16x3":
+                    _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.x.data_ptr(), x.pieces().data_ptr(), p_b, int(x.relu), V.data_ptr(), nimg,
+                                                                  H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input_bf16x3")
+                else:
+                    _lib.check(lib.eqa_lift5_fft48k5_input(x.x.data_ptr(), x.bank.data_ptr(), p_b, int(x.relu), V.data_ptr(), nimg, H + 4, W + 4,
+                                                           Cin, st), "eqa_lift5_fft48k5_input")
         else:
             T = torch.empty(max(lib.eqa_fft48k5_workspace_bytes(nimg, H, OW, Cin), 4) // 4, dtype=torch.float32, device=dev)
             with _timed("fft_input"):

@@ -560,6 +560,14 @@ int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* i
 int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout);
 int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
                             void* stream);
+/* The same with the convolution on the bf16 matrix cores: every fp32 pixel and weight split exactly into three bf16 pieces, six piece
+ * products per product, fp32 accumulation (the contract of eqa_fft48k5_cgemm3m_bf16x3; the fp32 matrix instruction of the form above
+ * runs on the vector ALU's datapath and holds the transforms' vector work back).  wpieces: the weights' pieces, (Cout, 3 pieces, 16
+ * chunks, 8) bf16 = eqa_lift5_pieces_bytes(Cout) bytes; chunk c < 15 = (filter row c / 3, pixel pair p = c % 3): [w(ci 0..2, kx = 2 p), 0,
+ * w(ci 0..2, kx = 2 p + 1), 0] with kx = 5 -> 0; chunk 15 = 0; piece 0 = bf16(w), piece 1 = bf16(w - p0), piece 2 = bf16(w - p0 - p1). */
+int64_t eqa_lift5_pieces_bytes(int Cout);
+int eqa_lift5_fft48k5_input_bf16x3(const float* x, const void* wpieces, const float* bias, int relu, float* V, int nimg, int H0, int W0,
+                                   int Cout, void* stream);
 int eqa_fft48k5_output(const float* Mo, float* T2, const float* bias, int relu, float* y, int nimg, int OH, int OW, int C,
                        void* stream);
 /* Training: eqa_fft48k5_output without bias / activation that also leaves the fp64 partial sums of the InnerBatchNorm behind the

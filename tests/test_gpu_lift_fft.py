@@ -70,6 +70,16 @@ def test_fused_lift_fft_input_matches_the_two_kernels_and_fp64(dev, nimg, H0, W0
     scale = want.abs().max().item()
     err = (_unpack_V(got, C) - want).abs().max().item()
     assert err <= 3e-6 * scale, (err, scale)
+    # (3) the same on the bf16 matrix cores (exact three-piece splits, six products): as close to fp64 as the fp32 matrix instruction
+    wp = fftconv.LiftedInput(x, bank, bias, relu).pieces()
+    assert wp.shape == (C, 3, 16, 8) and wp.dtype == torch.bfloat16 and wp.numel() * 2 == lib.eqa_lift5_pieces_bytes(C)
+    full_p = torch.full((fftconv.F, pitch, 2 * C), 7.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr() if with_bias else None, int(relu), full_p.data_ptr(),
+                                                  nimg, H0, W0, C, st), "eqa_lift5_fft48k5_input_bf16x3")
+    assert (full_p[:, M:] == 7.0).all()
+    err_p = (_unpack_V(full_p[:, :M], C) - want).abs().max().item()
+    print(f"fused lift+fft {(nimg, H0, W0, C)} relu={relu}: |bf16x3 - fp64| {err_p:.3e}, |f32 - fp64| {err:.3e}, scale {scale:.3e}")
+    assert err_p <= 3e-6 * scale and err_p <= 1.5 * err + 1e-7 * scale, (err_p, err, scale)
     # (1) the two kernels it replaces (where the unfused lifting kernel takes the channel count)
     if C % 64 == 0 and ops.lift_conv_supported(3, 5, 5, C):
         ymap = ops.lift_conv_grouped(x, ops.pack_lift_weights(bank), bias, relu, 5, 5)

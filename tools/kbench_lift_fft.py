@@ -40,6 +40,12 @@ def main():
     def fused():
         _lib.check(lib.eqa_lift5_fft48k5_input(x.data_ptr(), bank.data_ptr(), bias.data_ptr(), 1, V.data_ptr(), B, S, S, C, st), "fused")
 
+    from equiadapt_amd.images.canonicalization_networks.fftconv import LiftedInput
+    wp = LiftedInput(x, bank, bias, True).pieces()
+
+    def fused_p():
+        _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), 1, V.data_ptr(), B, S, S, C, st), "fused bf16x3")
+
     def two():
         y = ops.lift_conv_grouped(x, wpk, bias, True, 5, 5)
         _lib.check(lib.eqa_fft48k5_input_grouped(y.data_ptr(), T.data_ptr(), V.data_ptr(), None, 0, B, H1, H1, C, st), "grouped")
@@ -47,7 +53,7 @@ def main():
     def lift_only():
         ops.lift_conv_grouped(x, wpk, bias, True, 5, 5)
 
-    for name, fn in (("fused eqa_lift5_fft48k5_input", fused), ("lift_conv_grouped + fft48k5_input_grouped", two), ("lift_conv_grouped alone", lift_only)):
+    for name, fn in (("fused eqa_lift5_fft48k5_input", fused), ("fused eqa_lift5_fft48k5_input_bf16x3", fused_p), ("lift_conv_grouped + fft48k5_input_grouped", two), ("lift_conv_grouped alone", lift_only)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -61,7 +67,7 @@ def main():
     raw = ctypes.CDLL(_lib.SO_PATH)
     if hasattr(raw, "eqa_debug_lf_clock"):
         out = (ctypes.c_ulonglong * 32)()
-        fused()
+        (fused_p if os.environ.get("EQA_LIFT_FFT_FORM") == "bf16x3" else fused)()
         torch.cuda.synchronize()
         assert raw.eqa_debug_lf_clock(out) == 0
         names = ["stage + barrier 1", "prefetch issue", "role work", "barrier 2", "tail row passes", "barrier 3", "column read", "barrier 4"]
