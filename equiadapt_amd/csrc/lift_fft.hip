@@ -559,6 +559,10 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
             else conv_tiles_p(it, y, tx0, std::integral_constant<int, 2>());
           } else {
             conv_rows(it, kLfSubRows * sub + r0);
+            // The waves that are alone on their SIMD finish their three rows ~2.6 k cycles before the shared SIMDs finish their
+            // five: in sub-phases 1 and 2 they spend that wait on a row pass of the PREVIOUS sub-phase's rows (four passes, rows
+            // 0..15, leave the tail, which then has two passes per SIMD instead of three).
+            if (sub > 0 && (wave == 8 || wave == 9)) row_pass(8 * (sub - 1) + 4 * (wave - 8));
           }
         }
         LF_CLOCK(2);
@@ -600,7 +604,11 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
       lf_for_const(subphase, std::make_integer_sequence<int, NSUB>());
     }
     // ---- the tail: every wave transforms four rows, then the column waves read their columns
-    if (live) row_pass(4 * wave);
+    if constexpr (PIECES) {
+      if (live) row_pass(4 * wave);
+    } else {
+      if (live && wave < 8) row_pass(16 + 4 * wave);      // rows 16..47 (rows 0..15: waves 8, 9 during sub-phases 1, 2)
+    }
     LF_CLOCK(4);
     __syncthreads();
     LF_CLOCK(5);
