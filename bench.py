@@ -974,6 +974,10 @@ def main():
                                         "how": "the same kernel on a seeded uniform C8 index (all eight elements, 5/8 of them non-right-angle), "
                                                "one HIP-event bracket per launch, 30 launches over a ring of 3 distinct 154 MB batches; the "
                                                "in-step `frac` above runs on the index the random-weight network chooses (mostly right angles)"},
+                         "in_step_note": "`frac` is measured INSIDE the timed step, right behind the network's bf16 piece GEMM: the chip leaves that "
+                                         "kernel at a reduced clock and this (unchanged) kernel runs ~9 us slower for it -- 0.73 inside the step "
+                                         "with EQA_FFT_GEMM_PIECES=f32 on the same box (profiles/r06/bench_step_only_round5_forms.json); "
+                                         "`uniform_c8` and `frac_of_copy` are the kernel back to back",
                          "frac_of_copy": ga_copy_ms / ga2_ms,
                          "frac_of_copy_note": "torch's clone() of the same bytes / this kernel, both back to back on the same tensors (the "
                                               "`group_action` leg: canonicalize + invert vs clone(x) + clone(f)): the share of a plain copy's "
