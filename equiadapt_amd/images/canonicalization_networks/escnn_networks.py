@@ -563,7 +563,15 @@ class ESCNNEquivariantNetwork(nn.Module):
                         and fftconv.lift_fused_applicable(h.shape, bank.shape, nxt.out_channels * nxt.num_group_elements, h.device)):
                     # round 6: the layer does not run here at all -- the FFT layer behind it computes each tile of this map from
                     # its input patch inside its own forward transform (eqa_lift5_fft48k5_input)
-                    h = fftconv.LiftedInput(h, bank, bias, True)
+                    pieces = None
+                    if fftconv.LIFT_FFT_FORM == "bf16x3":     # the opt-in form's operand, cached per weight version like the folded bank
+                        hit = self._fold_cache.get(("liftp", id(conv)))
+                        key = self._fold_cache[id(conv)][0]
+                        if hit is None or hit[0] != key:
+                            hit = (key, fftconv.LiftedInput(h, bank, bias, True).pieces())
+                            self._fold_cache[("liftp", id(conv))] = hit
+                        pieces = hit[1]
+                    h = fftconv.LiftedInput(h, bank, bias, True, pieces)
                     continue
                 if (nxt is not None and not nxt.lifting and nxt.kernel_size == 5 and nxt.stride == 1 and nxt.padding == 0
                         and fftconv.grouped_applicable(out_shape, bank.shape[0], bank.shape[0], h.device)):

@@ -16,7 +16,17 @@ MAX_WINDOW_K = 10   # == kMaxWinK (csrc/eqa_common.hpp): the largest window the 
 def _stream() -> int:
     """The raw handle of torch's current HIP stream on the current device.  (torch.cuda.current_stream() builds a Stream object
     through four Python frames: 4-9 us per call, twelve calls in a configs[4] step -- a fifth of its host time at B = 4.)"""
-    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+    return _raw_stream(_current_device())
+
+
+try:                                   # private but stable since torch 1.x (inductor's own launcher uses the first)
+    _raw_stream, _current_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+except AttributeError:                 # a torch without them: the public, slower spelling
+    def _raw_stream(_dev):
+        return torch.cuda.current_stream().cuda_stream
+
+    def _current_device():
+        return 0
 
 
 class KernelTimer:

@@ -153,3 +153,12 @@ def test_network_inference_takes_the_fused_route(dev, monkeypatch):
     assert len(calls) == 1
     assert (fused - unfused).abs().max().item() <= 2e-6 * unfused.abs().max().item()
     assert torch.equal(fused.argmax(1), unfused.argmax(1))
+    # the opt-in form with the convolution on the bf16 matrix cores (exact three-piece splits): same activations, pieces cached per weights
+    monkeypatch.setenv("EQA_LIFT_FFT_FUSED", "1")
+    monkeypatch.setattr(fftconv, "LIFT_FFT_FORM", "bf16x3")
+    with torch.no_grad():
+        pieces_form = net(x)
+        again = net(x)
+    assert ("liftp", id(net.eqv_network[0])) in net._fold_cache and torch.equal(pieces_form, again)
+    assert (pieces_form - unfused).abs().max().item() <= 2e-6 * unfused.abs().max().item()
+    assert torch.equal(pieces_form.argmax(1), unfused.argmax(1))
