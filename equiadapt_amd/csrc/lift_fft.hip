@@ -530,7 +530,11 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     stage_grp(0, 0);
     stage_grp(1, 1);
   } else {
+    // the first item's first patch: staged here; afterwards an item's first patch is staged in the TAIL of the item before it, so
+    // that the convolution of sub-phase 0 starts as soon as the column waves have read tile rows 0..15 (see the tail)
     if (v < nwork) prefetch(lf_item(v, ngrp, TY, TX), 0, true);
+    stage();
+    __syncthreads();
   }
   for (;; v += nblk) {
     const bool live = v < nwork;          // block-uniform
@@ -542,7 +546,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     if constexpr (ROLE == kConv) {
 #pragma unroll 1
       for (int sub = 0; sub < NSUB; ++sub) {
-        __syncthreads();
+        if (PIECES || sub > 0) __syncthreads();
         LF_CLOCK(0);
         if (live) {
           if (sub == 0 && it.grp != cur_grp) {     // (one block per CU and a group count that divides the grid: a block stays on its group)
@@ -572,8 +576,10 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     } else {
       auto subphase = [&](auto SUB) {
         constexpr int sub = decltype(SUB)::value;
-        if constexpr (!PIECES) stage();
-        __syncthreads();
+        if constexpr (!PIECES) {
+          if (sub > 0) stage();
+        }
+        if (PIECES || sub > 0) __syncthreads();
         LF_CLOCK(0);
         if constexpr (PIECES) {
           // what is staged behind this sub-phase's second barrier: group sub + 2 of this item, or the first two groups of the next
@@ -602,6 +608,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         }
       };
       lf_for_const(subphase, std::make_integer_sequence<int, NSUB>());
+      if constexpr (!PIECES) stage();      // the NEXT item's first patch (fetched during the last sub-phase); the patch buffer is free
     }
     // ---- the tail: every wave transforms four rows, then the column waves read their columns
     if constexpr (PIECES) {
@@ -612,10 +619,25 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     LF_CLOCK(4);
     __syncthreads();
     LF_CLOCK(5);
+    // fp32 form: the barrier that releases the tile buffer sits behind the column waves' read of tile rows 0..15 -- all the next
+    // item's first sub-phase overwrites --, and they read rows 16..47 while its convolution has already started
+    constexpr int kEarly = PIECES ? kFftN : kLfSubRows;
     if constexpr (COLS) {
       if (live) {
 #pragma unroll
-        for (int y = 0; y < kFftN; ++y) {
+        for (int y = 0; y < kEarly; ++y) {
+          cre[y] = colp[y * kLfRowPitch];
+          cim[y] = colp[y * kLfRowPitch + 24 * 4];
+        }
+      }
+    }
+    LF_CLOCK(6);
+    __syncthreads();
+    LF_CLOCK(7);
+    if constexpr (COLS && !PIECES) {
+      if (live) {
+#pragma unroll
+        for (int y = kEarly; y < kFftN; ++y) {
           cre[y] = colp[y * kLfRowPitch];
           cim[y] = colp[y * kLfRowPitch + 24 * 4];
         }
@@ -624,9 +646,6 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     pend_m = it.m;
     pend_grp = it.grp;
     pending = live;
-    LF_CLOCK(6);
-    __syncthreads();
-    LF_CLOCK(7);
   }
   LF_CLOCK_END();
 }
