@@ -397,6 +397,10 @@ class Comm:
             self.backend = "gloo" if dry_run else want   # "nccl" IS RCCL on ROCm
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world)
         self.dev = torch.device("cpu") if dry_run else torch.device("cuda", self.device_index)
+        # RCCL builds its communicator inside the FIRST collective (hundreds of ms).  Left to the barrier in front of the timed
+        # region that gap idles the GPU right before the clock starts and the first steps run at the idle clock: the one-rank RCCL job
+        # measured 2-3 % below the bare process (profiles/r06/rccl_world1_vs_bare.txt, first collection).  Pay it here.
+        self.barrier()
 
     def barrier(self):
         if self.backend is not None:

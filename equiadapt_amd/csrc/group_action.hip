@@ -593,6 +593,243 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_pair_
 }
 
 // ------------------------------------------------------------------------------------------------
+// One-channel maps (configs[4]'s inverse on a (B, 1, 1024, 1024) output; discrete_group.py:204-238): NT tiles per block.  With one
+// channel a block of the kernel above moves 4.6 KB in and 4 KB out over a life of three dependent memory round trips (element ->
+// matrix -> window -> stores), and the eight blocks a CU holds keep 2.5 TB/s in flight (105 us per 32 maps of 1024 x 1024).  Here
+// a block requests the windows of NT consecutive tiles of the walk TOGETHER (NT windows in LDS), then gathers and stores them one
+// after the other.  The per-pixel arithmetic is that of group_action_body (the same functions in the same order): the output is
+// bit-identical.  grid = (8 * ceil(tiles / NT), 1, ceil(n_out / 8)): block_tile deals (image, slot) as it deals (image, tile).
+#ifndef EQA_ACTION_C1_TILES
+#define EQA_ACTION_C1_TILES 4
+#endif
+int g_c1_tiles = EQA_ACTION_C1_TILES;   // eqa_set_option(3, 0 | 2 | 4): 0 = one-channel maps through group_action_kernel<1>
+
+template <int NT, bool VEC>
+__global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionArgs a, const int tiles_x, const int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int n, slot, ty_unused;
+  if (!block_tile(a.n_out, (int)blockIdx.z, n, slot, ty_unused)) return;
+  int e, b;
+  if (a.gidx) {
+    e = a.gidx[n];
+    b = n;
+  } else {
+    e = n / a.B;
+    b = n - e * a.B;
+  }
+  e = min(max(e, 0), a.E - 1);
+  const int fl = a.flags ? a.flags[e] : 0;
+  const float* th = a.theta + e * 6;
+  const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+  const bool flip_dst = (fl & EQA_FLIP_DST) != 0, flip_src = (fl & EQA_FLIP_SRC) != 0;
+  const bool col_walk = fabsf(t1) > fabsf(t0) && tiles_y > 1;   // quarter turns walk the tiles column by column (group_action_body)
+  const int tiles = tiles_x * tiles_y;
+  const int win_floats = a.lds_rows * kLdsStride;
+  auto frame_x = [&](int j) { return flip_dst ? (a.Wp - 1 - (a.left + j)) : (a.left + j); };
+  auto src_offset = [&](int fy, int fx, bool& inside) -> int {
+    inside = ((unsigned)fx < (unsigned)a.Wp) && ((unsigned)fy < (unsigned)a.Hp);
+    int sx = flip_src ? (a.Wp - 1 - fx) : fx;
+    sx = min(max(sx - a.pad, 0), a.W - 1);
+    const int sy = min(max(fy - a.pad, 0), a.H - 1);
+    return sy * a.W + sx;
+  };
+  const unsigned src_plane = (unsigned)(a.H * a.W), dst_plane = (unsigned)(a.OH * a.OW);
+  const float* const plane = a.src + (size_t)b * src_plane;
+  float* const dst_img = a.dst + (size_t)n * dst_plane;
+
+  // the inverse of the sampling map, for the lanes of a window row that lie outside the tile's pre-image (group_action_body)
+  float m00 = 0.0f, m01 = 0.0f, m10 = 0.0f, m11 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+  bool have_mask = false;
+  {
+    const float a00 = a.half_w * t0 * a.step_x, a01 = a.half_w * t1 * a.step_y;
+    const float a10 = a.half_h * t3 * a.step_x, a11 = a.half_h * t4 * a.step_y;
+    b0 = a.half_w * ((t2 - t0 - t1) + 1.0f);
+    b1 = a.half_h * ((t5 - t3 - t4) + 1.0f);
+    const float det = a00 * a11 - a01 * a10;
+    if (fabsf(det) > 1e-12f) {
+      const float rdet = 1.0f / det;
+      m00 = a11 * rdet; m01 = -a01 * rdet; m10 = -a10 * rdet; m11 = a00 * rdet;
+      have_mask = true;
+    }
+  }
+
+  int wi0[NT], wj0[NT], x_lo[NT], y_lo[NT], bw[NT], bh[NT];
+  bool use_lds[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int lin = slot * NT + t;
+    bw[t] = 0;                      // bw == 0: no such tile
+    use_lds[t] = false;
+    if (lin < tiles) {              // block-uniform
+      int tile_x, tile_y;
+      if (col_walk) { tile_x = lin / tiles_y; tile_y = lin - tile_x * tiles_y; }
+      else { tile_y = lin / tiles_x; tile_x = lin - tile_y * tiles_x; }
+      const int j0 = tile_x * kTile, i0 = tile_y * kTile;
+      const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
+      wi0[t] = i0; wj0[t] = j0;
+      int xl, yl, xh, yh;
+      {
+        const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
+        const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
+        float cx[4], cy[4];
+        sample_point(t0, t1, t2, t3, t4, t5, xa, ya, a.half_w, a.half_h, cx[0], cy[0]);
+        sample_point(t0, t1, t2, t3, t4, t5, xb, ya, a.half_w, a.half_h, cx[1], cy[1]);
+        sample_point(t0, t1, t2, t3, t4, t5, xa, yb, a.half_w, a.half_h, cx[2], cy[2]);
+        sample_point(t0, t1, t2, t3, t4, t5, xb, yb, a.half_w, a.half_h, cx[3], cy[3]);
+        const float minx_f = floorf(fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3])));
+        const float maxx_f = floorf(fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])));
+        const float miny_f = floorf(fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3])));
+        const float maxy_f = floorf(fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])));
+        xl = (int)fminf(fmaxf(minx_f, -1.0f), (float)(a.Wp - 1));
+        yl = (int)fminf(fmaxf(miny_f, -1.0f), (float)(a.Hp - 1));
+        xh = max((int)fminf(fmaxf(maxx_f, -1.0f), (float)(a.Wp - 1)) + 1, xl + 1);
+        yh = max((int)fminf(fmaxf(maxy_f, -1.0f), (float)(a.Hp - 1)) + 1, yl + 1);
+      }
+      x_lo[t] = xl; y_lo[t] = yl;
+      bw[t] = xh - xl + 1; bh[t] = yh - yl + 1;
+      use_lds[t] = (bw[t] <= kBox) && (bh[t] <= a.lds_rows) && !a.force_direct;
+      if (use_lds[t]) {
+        // ---- request the window: lane = window column, the four waves interleave the window rows (global -> LDS DMA)
+        float* const win = smem + t * win_floats;
+        const bool col_ok = lane < bw[t];
+        const int col_fx = xl + lane;
+        const bool col_inside = (unsigned)col_fx < (unsigned)a.Wp;
+        const unsigned col_off = (unsigned)min(max((flip_src ? (a.Wp - 1 - col_fx) : col_fx) - a.pad, 0), a.W - 1) * 4u;
+        float mask_uj = 0.0f, mask_ui = 0.0f, mask_hj = __builtin_inff(), mask_hi = __builtin_inff();
+        if (have_mask) {
+          const float jfa = (float)frame_x(j0), jfb = (float)frame_x(j1);
+          const float px = (float)col_fx - b0, py = (float)yl - b1;
+          mask_uj = (m00 * px + m01 * py) - 0.5f * (jfa + jfb);
+          mask_ui = (m10 * px + m11 * py) - ((float)a.top + 0.5f * (float)(i0 + i1));
+          mask_hj = 0.5f * fabsf(jfb - jfa) + fabsf(m00) + fabsf(m01) + 0.25f;
+          mask_hi = 0.5f * (float)(i1 - i0) + fabsf(m10) + fabsf(m11) + 0.25f;
+        }
+        if (col_ok && col_inside) {
+          const int ya = max(-yl, 0), yb = min(bh[t], a.Hp - yl);
+          const char* p0 = reinterpret_cast<const char*>(plane);
+          unsigned keep;
+          asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
+          const int y_first = ya + ((wave - ya) & 3);
+          float vj = mask_uj + m01 * (float)y_first, vi = mask_ui + m11 * (float)y_first;
+          const float sj = 4.0f * m01, si = 4.0f * m11;
+#pragma unroll 1
+          for (int y = y_first; y < EQA_ABL_YB(yb); y += 4, vj += sj, vi += si) {
+            const int fy = yl + y;
+            const unsigned voff = (unsigned)(min(max(fy - a.pad, 0), a.H - 1) * a.W) * 4u + col_off;
+            const unsigned lrow = (unsigned)(uintptr_t)(lptr_t)(win + y * kLdsStride);
+            if (!(fabsf(vj) <= mask_hj && fabsf(vi) <= mask_hi)) continue;
+            asm volatile("s_mov_b32 m0, %[l]\n\ts_nop 0\n\tglobal_load_lds_dword %[v], %[p0]"
+                         :: [v] "v"(voff), [l] "s"(lrow), [p0] "s"(p0) : "memory");
+          }
+          asm volatile("s_mov_b32 m0, %0" :: "s"(keep));
+        }
+        const bool any_zero = (xl < 0) || (yl < 0) || (xh > a.Wp - 1) || (yh > a.Hp - 1);
+        if (any_zero && col_ok) {
+#pragma unroll 1
+          for (int y = wave; y < bh[t]; y += 4)
+            if (!(col_inside && ((unsigned)(yl + y) < (unsigned)a.Hp))) win[y * kLdsStride + lane] = 0.0f;
+        }
+      }
+    }
+  }
+
+  const int r = tid >> 3, q = tid & 7;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (bw[t] == 0) break;          // block-uniform: the tiles of a slot are consecutive
+    const int i = wi0[t] + r, jb = wj0[t] + 4 * q;
+    int pi = i, pj = jb;
+    if (t == 0) asm volatile("" : "+v"(pi), "+v"(pj));   // the first tile's setup runs under the DMA
+    int lidx[4], gx0[4], gy0[4];
+    bool live[4];
+    float w00[4], w01[4], w10[4], w11[4];
+    const float yn = lin_m1_p1(a.top + pi, a.Hp, a.step_y);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#ifdef EQA_ABL_CHEAPSETUP  // ablation: the kernel without the per-pixel coordinate arithmetic (wrong pixels)
+      lidx[k] = min(pi - wi0[t], bh[t] - 2) * kLdsStride + min(pj - wj0[t] + k, bw[t] - 2);
+      gx0[k] = 0; gy0[k] = 0; live[k] = true;
+      w00[k] = 0.25f; w01[k] = 0.25f; w10[k] = 0.25f; w11[k] = yn;
+      continue;
+#endif
+      const float xn = lin_m1_p1(frame_x(pj + k), a.Wp, a.step_x);
+      float ix, iy;
+      sample_point(t0, t1, t2, t3, t4, t5, xn, yn, a.half_w, a.half_h, ix, iy);
+      const float xf = floorf(ix), yf = floorf(iy);
+      const float wx1 = ix - xf, wy1 = iy - yf;
+      const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+      const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+      const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+      live[k] = xin && yin;
+      const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
+      gx0[k] = xi;
+      gy0[k] = yi;
+      const int lx = min(max(xi - x_lo[t], 0), bw[t] - 2), ly = min(max(yi - y_lo[t], 0), bh[t] - 2);
+#ifdef EQA_CHECK_WINDOW
+      if (live[k] && pi < a.OH && pj + k < a.OW &&
+          (xi < x_lo[t] || xi + 1 > x_lo[t] + bw[t] - 1 || yi < y_lo[t] || yi + 1 > y_lo[t] + bh[t] - 1)) __builtin_trap();
+#endif
+      lidx[k] = ly * kLdsStride + lx;
+      w00[k] = wy0 * wx0;
+      w01[k] = wy0 * wx1;
+      w10[k] = wy1 * wx0;
+      w11[k] = wy1 * wx1;
+    }
+    if (t == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA (every tile's) has landed in LDS
+      __syncthreads();                                    // ... and so has every other wave's
+    }
+    float acc[4];
+    if (use_lds[t]) {
+      const float* s = smem + t * win_floats;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
+        const float sw = s[lidx[k] + kLdsStride], se = s[lidx[k] + kLdsStride + 1];
+        const float v = blend4(nw, ne, sw, se, w00[k], w01[k], w10[k], w11[k]);
+        acc[k] = live[k] ? v : 0.0f;
+      }
+    } else {
+      // window too large for LDS, or forced: rare, the same arithmetic from global memory
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = 0.0f;
+#pragma unroll 1
+      for (int k = 0; k < 4; ++k) {
+        const int gx = k == 0 ? gx0[0] : k == 1 ? gx0[1] : k == 2 ? gx0[2] : gx0[3];
+        const int gy = k == 0 ? gy0[0] : k == 1 ? gy0[1] : k == 2 ? gy0[2] : gy0[3];
+        const float a00 = k == 0 ? w00[0] : k == 1 ? w00[1] : k == 2 ? w00[2] : w00[3];
+        const float a01 = k == 0 ? w01[0] : k == 1 ? w01[1] : k == 2 ? w01[2] : w01[3];
+        const float a10 = k == 0 ? w10[0] : k == 1 ? w10[1] : k == 2 ? w10[2] : w10[3];
+        const float a11 = k == 0 ? w11[0] : k == 1 ? w11[1] : k == 2 ? w11[2] : w11[3];
+        const bool lv = k == 0 ? live[0] : k == 1 ? live[1] : k == 2 ? live[2] : live[3];
+        bool in00, in01, in10, in11;
+        const int o00 = src_offset(gy, gx, in00), o01 = src_offset(gy, gx + 1, in01);
+        const int o10 = src_offset(gy + 1, gx, in10), o11 = src_offset(gy + 1, gx + 1, in11);
+        const float v00 = plane[o00], v01 = plane[o01], v10 = plane[o10], v11 = plane[o11];
+        float v = blend4(in00 ? v00 : 0.0f, in01 ? v01 : 0.0f, in10 ? v10 : 0.0f, in11 ? v11 : 0.0f, a00, a01, a10, a11);
+        v = lv ? v : 0.0f;
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2)
+          if (k2 == k) acc[k2] = v;
+      }
+    }
+    if (i < a.OH) {
+      float* o = dst_img + (unsigned)(i * a.OW + jb);
+      if (VEC) {
+        if (jb < a.OW && EQA_ABL_STORE_OK(acc[0])) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (jb + k < a.OW) o[k] = acc[k];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of the group action.  y[n,c,i,j] = sum_k w_k(phi) * frame[c, nbr_k(i,j; phi)]  (bilinear, 4 neighbours)
 //   ANGLE: dL/dphi = sum gy * (dy/dix * dix/dphi + dy/diy * diy/dphi), with the source point rotating about the frame
 //          centre c:  s = c + R(phi)^-1 (dst - c)  =>  ds/dphi = (-(s_y - c_y), s_x - c_x)  [per radian],
@@ -881,6 +1118,29 @@ int launch_action_ch(const ActionArgs& a, bool vec, hipStream_t st) {
   return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
 }
 
+template <int NT>
+int launch_action_c1_nt(const ActionArgs& a, bool vec, hipStream_t st) {
+  const int tiles_x = (a.OW + kTile - 1) / kTile, tiles_y = (a.OH + kTile - 1) / kTile;
+  const long long slots = ((long long)tiles_x * tiles_y + NT - 1) / NT;
+  const int groups = (a.n_out + kXcd - 1) / kXcd;
+  if (slots * kXcd > 0x7fffffffLL || groups > 65535) return EQA_ERR_UNSUPPORTED;
+  const dim3 grid((unsigned)(kXcd * slots), 1u, (unsigned)groups);
+  const size_t lds = (size_t)NT * a.lds_rows * kLdsStride * sizeof(float);
+  if (vec)
+    hipLaunchKernelGGL((group_action_c1_kernel<NT, true>), grid, dim3(kThreads), lds, st, a, tiles_x, tiles_y);
+  else
+    hipLaunchKernelGGL((group_action_c1_kernel<NT, false>), grid, dim3(kThreads), lds, st, a, tiles_x, tiles_y);
+  return hipGetLastError() == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+}
+
+// one-channel maps: NT tiles per block where the map has enough tiles to fill the chip that way
+int launch_action_c1(const ActionArgs& a, bool vec, hipStream_t st) {
+  const long long tiles = (long long)((a.OW + kTile - 1) / kTile) * ((a.OH + kTile - 1) / kTile);
+  if (tiles * a.n_out < 4096) return EQA_ERR_UNSUPPORTED;      // small jobs: a tile per block fills the CUs better
+  if (g_c1_tiles >= 4) return launch_action_c1_nt<4>(a, vec, st);
+  return launch_action_c1_nt<2>(a, vec, st);
+}
+
 int fill_action_args(ActionArgs& a, const float* src, float* dst, const int32_t* gidx, const float* theta,
                      const int32_t* flags, const int32_t* chan_map, int E, int G, int n_out, int B, int C, int H, int W,
                      int pad, int OH, int OW, int top, int left) {
@@ -926,6 +1186,10 @@ int launch_action(const float* src, float* dst, const int32_t* gidx, const float
 #if EQA_FORCE_CH
   return launch_action_ch<EQA_FORCE_CH>(a, vec, st);
 #else
+  if (C == 1 && !chan_map && g_c1_tiles > 0) {
+    const int rc1 = launch_action_c1(a, vec, st);
+    if (rc1 != EQA_ERR_UNSUPPORTED) return rc1;
+  }
   if (C % 3 == 0) return launch_action_ch<3>(a, vec, st);
   if (C % 2 == 0) return launch_action_ch<2>(a, vec, st);
   return launch_action_ch<1>(a, vec, st);
@@ -1809,7 +2073,7 @@ int eqa_abi_version(void) { return EQA_ABI_VERSION; }
 
 int eqa_get_option(int key) {
   if (key == 100) return kMaxWinK;   // read-only: the largest window the window-sum kernels take (ops.MAX_WINDOW_K must equal it)
-  return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : key == 2 ? eqa::g_cgemm_bf16_form : EQA_ERR_INVALID_ARG;
+  return key == 0 ? g_force_direct : key == 1 ? eqa::g_vn_kernel_choice : key == 2 ? eqa::g_cgemm_bf16_form : key == 3 ? g_c1_tiles : EQA_ERR_INVALID_ARG;
 }
 
 int64_t eqa_fold_edge_pad_workspace_bytes(int planes, int H, int W, int pad) {
@@ -1842,6 +2106,10 @@ int eqa_set_option(int key, int value) {
   }
   if (key == 2 && value >= 0 && value <= 1) {
     eqa::g_cgemm_bf16_form = value;
+    return EQA_OK;
+  }
+  if (key == 3 && (value == 0 || value == 2 || value == 4)) {
+    g_c1_tiles = value;
     return EQA_OK;
   }
   return EQA_ERR_INVALID_ARG;

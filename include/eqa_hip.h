@@ -54,6 +54,8 @@ int eqa_abi_version(void);
  *   key 0: 1 = force the direct-from-global gather path (no LDS staging) in the resampling kernels.
  *   key 1: VNSmall forward kernel: 0 = chosen by size (default), 1 = one thread per point (k = 20 only), 2 = four lanes per point.
  *   key 2: eqa_fft48k5_cgemm3m_bf16x3: 0 = the block form where it applies (Cout % 128 == 0; default), 1 = always the wave form.
+ *   key 3: one-channel maps in eqa_group_action_fwd / _hint / eqa_invert_action_fwd: tiles per block of group_action_c1_kernel
+ *          (4 = default, 2, or 0 = the general kernel with one tile per block); the output is bit-identical either way.
  *   key 100 (get only): the largest window size k the window-sum kernels take (eqa_window_sums*, the linearised last layer). */
 int eqa_set_option(int key, int value);
 int eqa_get_option(int key);
