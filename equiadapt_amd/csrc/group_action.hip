@@ -599,6 +599,9 @@ __global__ __launch_bounds__(kThreads, EQA_ACTION_WAVES) void group_action_pair_
 // a block requests the windows of NT consecutive tiles of the walk TOGETHER (NT windows in LDS), then gathers and stores them one
 // after the other.  The per-pixel arithmetic is that of group_action_body (the same functions in the same order): the output is
 // bit-identical.  grid = (8 * ceil(tiles / NT), 1, ceil(n_out / 8)): block_tile deals (image, slot) as it deals (image, tile).
+// 32 maps of 1024 x 1024, random D4 (profiles/r06/kbench_invert_c1.txt): 97 us in the general kernel, 70 / 66 us with 2 / 4 tiles
+// per block (8: 95 us -- the per-tile scalars no longer fit the SGPR file), torch's copy of the same bytes 51 us.  What is left
+// is vector arithmetic: the per-pixel coordinates of a tile cost the same for one channel as for three.
 #ifndef EQA_ACTION_C1_TILES
 #define EQA_ACTION_C1_TILES 4
 #endif
@@ -620,7 +623,10 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
     e = n / a.B;
     b = n - e * a.B;
   }
-  e = min(max(e, 0), a.E - 1);
+  e = __builtin_amdgcn_readfirstlane(min(max(e, 0), a.E - 1));   // (block-uniform; the DMA below wants its plane pointer in SGPRs)
+  b = __builtin_amdgcn_readfirstlane(b);
+  n = __builtin_amdgcn_readfirstlane(n);
+  slot = __builtin_amdgcn_readfirstlane(slot);
   const int fl = a.flags ? a.flags[e] : 0;
   const float* th = a.theta + e * 6;
   const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
@@ -656,41 +662,56 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
     }
   }
 
+  // ---- the windows of the slot's NT tiles: lane t of every wave evaluates tile t (one pass of the corner arithmetic per wave
+  // instead of NT), v_readlane hands the results to the wave as scalars.  (With every lane evaluating every tile this part was
+  // a third of the kernel's vector instructions: profiles/r06/kbench_invert_c1_v1_ablations.txt.)
+  int v_i0, v_j0, v_xl, v_yl, v_bw, v_bh, v_in;
+  {
+    const int lin = slot * NT + min(lane, NT - 1);
+    const int lc = min(lin, tiles - 1);
+    int tile_x, tile_y;
+    if (col_walk) { tile_x = lc / tiles_y; tile_y = lc - tile_x * tiles_y; }
+    else { tile_y = lc / tiles_x; tile_x = lc - tile_y * tiles_x; }
+    const int j0 = tile_x * kTile, i0 = tile_y * kTile;
+    const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
+    const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
+    const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
+    float cx[4], cy[4];
+    sample_point(t0, t1, t2, t3, t4, t5, xa, ya, a.half_w, a.half_h, cx[0], cy[0]);
+    sample_point(t0, t1, t2, t3, t4, t5, xb, ya, a.half_w, a.half_h, cx[1], cy[1]);
+    sample_point(t0, t1, t2, t3, t4, t5, xa, yb, a.half_w, a.half_h, cx[2], cy[2]);
+    sample_point(t0, t1, t2, t3, t4, t5, xb, yb, a.half_w, a.half_h, cx[3], cy[3]);
+    const float minx_f = floorf(fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3])));
+    const float maxx_f = floorf(fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])));
+    const float miny_f = floorf(fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3])));
+    const float maxy_f = floorf(fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])));
+    const int xl = (int)fminf(fmaxf(minx_f, -1.0f), (float)(a.Wp - 1));
+    const int yl = (int)fminf(fmaxf(miny_f, -1.0f), (float)(a.Hp - 1));
+    const int xh = max((int)fminf(fmaxf(maxx_f, -1.0f), (float)(a.Wp - 1)) + 1, xl + 1);
+    const int yh = max((int)fminf(fmaxf(maxy_f, -1.0f), (float)(a.Hp - 1)) + 1, yl + 1);
+    v_i0 = i0; v_j0 = j0; v_xl = xl; v_yl = yl;
+    v_bw = lin < tiles ? xh - xl + 1 : 0;                     // 0: no such tile
+    v_bh = yh - yl + 1;
+    // a whole tile whose window lies inside the frame: no pixel of it needs a range check or a clamp
+    v_in = (xl >= 0 && yl >= 0 && xh <= a.Wp - 1 && yh <= a.Hp - 1 && i0 + kTile <= a.OH && j0 + kTile <= a.OW) ? 1 : 0;
+  }
   int wi0[NT], wj0[NT], x_lo[NT], y_lo[NT], bw[NT], bh[NT];
-  bool use_lds[NT];
+  bool use_lds[NT], inner[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int lin = slot * NT + t;
-    bw[t] = 0;                      // bw == 0: no such tile
-    use_lds[t] = false;
-    if (lin < tiles) {              // block-uniform
-      int tile_x, tile_y;
-      if (col_walk) { tile_x = lin / tiles_y; tile_y = lin - tile_x * tiles_y; }
-      else { tile_y = lin / tiles_x; tile_x = lin - tile_y * tiles_x; }
-      const int j0 = tile_x * kTile, i0 = tile_y * kTile;
+    wi0[t] = __builtin_amdgcn_readlane(v_i0, t); wj0[t] = __builtin_amdgcn_readlane(v_j0, t);
+    x_lo[t] = __builtin_amdgcn_readlane(v_xl, t); y_lo[t] = __builtin_amdgcn_readlane(v_yl, t);
+    bw[t] = __builtin_amdgcn_readlane(v_bw, t); bh[t] = __builtin_amdgcn_readlane(v_bh, t);
+    inner[t] = __builtin_amdgcn_readlane(v_in, t) != 0;
+    use_lds[t] = (bw[t] != 0) && (bw[t] <= kBox) && (bh[t] <= a.lds_rows) && !a.force_direct;
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (bw[t] != 0) {               // block-uniform
+      const int i0 = wi0[t], j0 = wj0[t];
       const int i1 = min(i0 + kTile - 1, a.OH - 1), j1 = min(j0 + kTile - 1, a.OW - 1);
-      wi0[t] = i0; wj0[t] = j0;
-      int xl, yl, xh, yh;
-      {
-        const float xa = lin_m1_p1(frame_x(j0), a.Wp, a.step_x), xb = lin_m1_p1(frame_x(j1), a.Wp, a.step_x);
-        const float ya = lin_m1_p1(a.top + i0, a.Hp, a.step_y), yb = lin_m1_p1(a.top + i1, a.Hp, a.step_y);
-        float cx[4], cy[4];
-        sample_point(t0, t1, t2, t3, t4, t5, xa, ya, a.half_w, a.half_h, cx[0], cy[0]);
-        sample_point(t0, t1, t2, t3, t4, t5, xb, ya, a.half_w, a.half_h, cx[1], cy[1]);
-        sample_point(t0, t1, t2, t3, t4, t5, xa, yb, a.half_w, a.half_h, cx[2], cy[2]);
-        sample_point(t0, t1, t2, t3, t4, t5, xb, yb, a.half_w, a.half_h, cx[3], cy[3]);
-        const float minx_f = floorf(fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3])));
-        const float maxx_f = floorf(fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])));
-        const float miny_f = floorf(fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3])));
-        const float maxy_f = floorf(fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])));
-        xl = (int)fminf(fmaxf(minx_f, -1.0f), (float)(a.Wp - 1));
-        yl = (int)fminf(fmaxf(miny_f, -1.0f), (float)(a.Hp - 1));
-        xh = max((int)fminf(fmaxf(maxx_f, -1.0f), (float)(a.Wp - 1)) + 1, xl + 1);
-        yh = max((int)fminf(fmaxf(maxy_f, -1.0f), (float)(a.Hp - 1)) + 1, yl + 1);
-      }
-      x_lo[t] = xl; y_lo[t] = yl;
-      bw[t] = xh - xl + 1; bh[t] = yh - yl + 1;
-      use_lds[t] = (bw[t] <= kBox) && (bh[t] <= a.lds_rows) && !a.force_direct;
+      const int xl = x_lo[t], yl = y_lo[t];
+      const int xh = xl + bw[t] - 1, yh = yl + bh[t] - 1;
       if (use_lds[t]) {
         // ---- request the window: lane = window column, the four waves interleave the window rows (global -> LDS DMA)
         float* const win = smem + t * win_floats;
@@ -737,9 +758,11 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
   }
 
   const int r = tid >> 3, q = tid & 7;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (bw[t] == 0) break;          // block-uniform: the tiles of a slot are consecutive
+  // one tile: per-pixel setup (under the DMA for the first tile), gather, store.  INNER (block-uniform per tile): a whole tile
+  // whose window lies inside the frame -- every neighbour is a frame pixel inside the window, the range checks and clamps of the
+  // general form are identities and are not evaluated.
+  auto do_tile = [&](const int t, auto inner_c) {
+    constexpr bool INNER = decltype(inner_c)::value;
     const int i = wi0[t] + r, jb = wj0[t] + 4 * q;
     int pi = i, pj = jb;
     if (t == 0) asm volatile("" : "+v"(pi), "+v"(pj));   // the first tile's setup runs under the DMA
@@ -761,13 +784,20 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
       const float xf = floorf(ix), yf = floorf(iy);
       const float wx1 = ix - xf, wy1 = iy - yf;
       const float wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-      const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
-      const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
-      live[k] = xin && yin;
-      const int xi = xin ? (int)xf : -1, yi = yin ? (int)yf : -1;
+      int xi, yi, lx, ly;
+      if (INNER) {
+        live[k] = true;
+        xi = (int)xf; yi = (int)yf;
+        lx = xi - x_lo[t]; ly = yi - y_lo[t];
+      } else {
+        const bool xin = (xf >= -1.0f) && (xf <= (float)(a.Wp - 1));
+        const bool yin = (yf >= -1.0f) && (yf <= (float)(a.Hp - 1));
+        live[k] = xin && yin;
+        xi = xin ? (int)xf : -1; yi = yin ? (int)yf : -1;
+        lx = min(max(xi - x_lo[t], 0), bw[t] - 2); ly = min(max(yi - y_lo[t], 0), bh[t] - 2);
+      }
       gx0[k] = xi;
       gy0[k] = yi;
-      const int lx = min(max(xi - x_lo[t], 0), bw[t] - 2), ly = min(max(yi - y_lo[t], 0), bh[t] - 2);
 #ifdef EQA_CHECK_WINDOW
       if (live[k] && pi < a.OH && pj + k < a.OW &&
           (xi < x_lo[t] || xi + 1 > x_lo[t] + bw[t] - 1 || yi < y_lo[t] || yi + 1 > y_lo[t] + bh[t] - 1)) __builtin_trap();
@@ -790,7 +820,7 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
         const float nw = s[lidx[k]], ne = s[lidx[k] + 1];
         const float sw = s[lidx[k] + kLdsStride], se = s[lidx[k] + kLdsStride + 1];
         const float v = blend4(nw, ne, sw, se, w00[k], w01[k], w10[k], w11[k]);
-        acc[k] = live[k] ? v : 0.0f;
+        acc[k] = (INNER || live[k]) ? v : 0.0f;
       }
     } else {
       // window too large for LDS, or forced: rare, the same arithmetic from global memory
@@ -826,6 +856,12 @@ __global__ __launch_bounds__(kThreads) void group_action_c1_kernel(const ActionA
           if (jb + k < a.OW) o[k] = acc[k];
       }
     }
+  };
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    if (bw[t] == 0) break;          // block-uniform: the tiles of a slot are consecutive
+    if (inner[t]) do_tile(t, std::true_type());
+    else do_tile(t, std::false_type());
   }
 }
 
