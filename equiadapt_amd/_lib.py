@@ -111,6 +111,9 @@ SIGNATURES = {
     "eqa_fft48k5_spectra3m_bf16_bytes": (ctypes.c_int64, [_int, _int]),
     "eqa_fft48k5_spectra3m_split": (_int, [_vp, _vp, _int, _int, _vp]),
     "eqa_fft48k5_cgemm3m_bf16x3": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _int, _vp]),
+    "eqa_fft48k5_spectra3m_f16_bytes": (ctypes.c_int64, [_int, _int]),
+    "eqa_fft48k5_spectra3m_split_f16": (_int, [_vp, _vp, _int, _int, ctypes.c_float, _vp]),
+    "eqa_fft48k5_cgemm3m_f16x2": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp, _int, ctypes.c_float, _vp]),
     "eqa_fft48k5_wgrad3m_supported": (_int, [_int, _int]),
     "eqa_fft48k5_wgrad3m": (_int, [_vp, _vp, _vp, ctypes.c_int64, _int, _int, _vp]),
     "eqa_fft48k5_group": (_int, [_int, _int]),

@@ -364,12 +364,24 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_kernel(const float* _
 //        256 contiguous bytes per row.
 constexpr int kBlkM = 128, kBlkN = 128;
 constexpr int kFragBytes = 64 * 16;
-constexpr int kAStageBytes = 36 * kFragBytes;
 constexpr int kABufs = 3;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// TERMS = 3: the fp16 form.  An fp32 operand x, scaled by a power of two into the top of the fp16 range, is split into TWO fp16
+// pieces h1 = rn(x), h2 = rn(x - h1): 11 + 11 significant bits and a sign -> |x - h1 - h2| <= 2^-24 |x|, half an fp32 ulp; the
+// product x y is taken as h1 k1 + h1 k2 + h2 k1 (each exact in v_mfma_f32_32x32x16_f16, fp32 accumulate; h2 k2 <= 2^-22 |x y| is
+// left out).  Three matrix instructions per product instead of six, and -- fewer accumulator roundings -- CLOSER to an fp64
+// product than the six bf16 pieces or the fp32 instruction (tools/micro/f16x2_gemm_check.hip, profiles/r06/f16x2_gemm_check.txt:
+// rms 3.9e-8 / 5.1e-8 / 5.7e-8 on the parity test's magnitudes).  The price is the range: the caller hands over an upper bound of
+// |V| (the DC bins of non-negative activations bound every other bin) and the filter spectra are scaled when they are split;
+// values 2^16 below the bound keep full precision, smaller ones lose it gradually (fp16 subnormals: honoured by the instruction).
+constexpr int pieces_of(int terms) { return terms == 3 ? 2 : 3; }
+constexpr int a_stage_bytes(int terms) { return 12 * pieces_of(terms) * kFragBytes; }
+
+template <int NP>
 struct BSet {
-  u32x4 b[3][3];                  // [part][piece] of the wave's 32 columns
+  u32x4 b[3][NP];                 // [part][piece] of the wave's 32 columns
 };
 struct AFrags {
   u32x4 a[3];                     // [part] of one (row quarter, piece)
@@ -401,38 +413,58 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[3]) {
     o[q][1] = __builtin_amdgcn_perm(x[q][3], x[q][2], 0x07060302u);
   }
 }
-// one part (0 re, 1 im, 2 re + im) of row ROW's 4 k: split, three 8-byte writes into the stage being built (row r + 64 is row
-// quarter m + 2: 18 fragments further)
-template <int ROW, int PART>
-__device__ __forceinline__ void split_part(const RawA& r, unsigned char* wr) {
-  u32x2 o[3];
-  split4(PART == 0 ? r.re[ROW] : PART == 1 ? r.im[ROW] : r.re[ROW] + r.im[ROW], o);
+// two fp16 pieces of four (already scaled) values: v_cvt_pk_f16_f32 (round to nearest even), the remainder, again
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split4h(const f32x4 v, u32x2 (&o)[2]) {
 #pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(wr + (ROW * 18 + PART * 3 + q) * kFragBytes) = o[q];
+  for (int j = 0; j < 2; ++j) {
+    const float a = v[2 * j], b = v[2 * j + 1];
+    const f16x2v h = {(_Float16)a, (_Float16)b};
+    const f16x2v l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    o[0][j] = __builtin_bit_cast(unsigned, h);
+    o[1][j] = __builtin_bit_cast(unsigned, l);
+  }
+}
+// one part (0 re, 1 im, 2 re + im) of row ROW's 4 k: split, NP 8-byte writes into the stage being built (row r + 64 is row
+// quarter m + 2: 6 NP fragments further).  NP = 2: the values are scaled first (`scale`: a power of two).
+template <int NP, int ROW, int PART>
+__device__ __forceinline__ void split_part(const RawA& r, unsigned char* wr, const float scale) {
+  const f32x4 v = PART == 0 ? r.re[ROW] : PART == 1 ? r.im[ROW] : r.re[ROW] + r.im[ROW];
+  u32x2 o[NP];
+  if constexpr (NP == 3) split4(v, o);
+  else split4h(v * scale, o);
+#pragma unroll
+  for (int q = 0; q < NP; ++q) *reinterpret_cast<u32x2*>(wr + (ROW * 6 * NP + PART * NP + q) * kFragBytes) = o[q];
 }
 template <int ROW>
 __device__ __forceinline__ void load_raw(RawA& o, const TileAt& t, unsigned voff, unsigned row64, unsigned soff) {
   o.re[ROW] = __builtin_bit_cast(f32x4, buf_ld(t.a, voff + ROW * row64, soff));
   o.im[ROW] = __builtin_bit_cast(f32x4, buf_ld(t.a, voff + ROW * row64 + 64, soff));
 }
-__device__ __forceinline__ void load_bset(BSet& o, const TileAt& t, unsigned voff, unsigned soff) {
+template <int NP>
+__device__ __forceinline__ void load_bset(BSet<NP>& o, const TileAt& t, unsigned voff, unsigned soff) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) o.b[k / 3][k % 3] = buf_ld(t.b, voff + k * kBFrag, t.sb + soff);
+  for (int k = 0; k < 3 * NP; ++k) o.b[k / NP][k % NP] = buf_ld(t.b, voff + k * kBFrag, t.sb + soff);
 }
-template <int M, int PA>
+template <int NP, int M, int PA>
 __device__ __forceinline__ void read_frags(AFrags& o, const unsigned char* rd) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) o.a[p] = *reinterpret_cast<const u32x4*>(rd + ((M * 3 + p) * 3 + PA) * kFragBytes);
+  for (int p = 0; p < 3; ++p) o.a[p] = *reinterpret_cast<const u32x4*>(rd + ((M * 3 + p) * NP + PA) * kFragBytes);
+}
+template <int TERMS>
+__device__ __forceinline__ f32x16 mma_t(const u32x4 a, const u32x4 b, const f32x16 c) {
+  if constexpr (TERMS == 3) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return mma(a, b, c);
 }
 // FIRST: the tile's first K-stage -- the first product into an accumulator starts from zero (no accumulator is ever cleared)
 template <int TERMS, int M, int PA, bool FIRST>
-__device__ __forceinline__ void mma_rows(const AFrags& A, const BSet& B, f32x16 (&acc)[3][4]) {
+__device__ __forceinline__ void mma_rows(const AFrags& A, const BSet<pieces_of(TERMS)>& B, f32x16 (&acc)[3][4]) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int pb = 0; pb < 3; ++pb) {
-    if (TERMS == 6 && PA + pb > 2) continue;
+  for (int pb = 0; pb < pieces_of(TERMS); ++pb) {
+    if ((TERMS == 6 && PA + pb > 2) || (TERMS == 3 && PA + pb > 1)) continue;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) acc[p][M] = mma(A.a[p], B.b[p][pb], FIRST && PA == 0 && pb == 0 ? zero : acc[p][M]);
+    for (int p = 0; p < 3; ++p) acc[p][M] = mma_t<TERMS>(A.a[p], B.b[p][pb], FIRST && PA == 0 && pb == 0 ? zero : acc[p][M]);
   }
 }
 // the order of a region's instructions: behind each matrix instruction its share of the LDS reads, loads, vector arithmetic, writes
@@ -461,10 +493,11 @@ __device__ __forceinline__ void pin_region() {
 // (arrived); rd / rd_next = this lane's read address in this stage's / the next stage's LDS buffer, wr = its write address in
 // stage g + 2's.  On exit: Bn = the next stage's B (requested), F0 = the next stage's (0, 0), raw = stage g + 4 (requested).
 template <int TERMS, bool FIRST>
-__device__ __forceinline__ void run_stage_block(const BSet& Bc, BSet& Bn, RawA& raw, AFrags& F0, AFrags& F1, AFrags& F2, AFrags& F3,
+__device__ __forceinline__ void run_stage_block(const BSet<pieces_of(TERMS)>& Bc, BSet<pieces_of(TERMS)>& Bn, RawA& raw, AFrags& F0,
+                                                AFrags& F1, AFrags& F2, AFrags& F3,
                                                 f32x16 (&acc)[3][4], const unsigned char* rd, const unsigned char* rd_next,
                                                 unsigned char* wr, const TileAt& tb, unsigned sb_off, unsigned b_voff, const TileAt& ta,
-                                                unsigned sa_off, unsigned a_voff, unsigned row64
+                                                unsigned sa_off, unsigned a_voff, unsigned row64, const float scale
 #ifdef EQA_BLK_CLOCK
                                                 , unsigned long long (&tot)[8]
 #endif
@@ -472,38 +505,52 @@ __device__ __forceinline__ void run_stage_block(const BSet& Bc, BSet& Bn, RawA& 
 #ifdef EQA_BLK_CLOCK
   unsigned long long tk[8];
 #endif
-  constexpr int kN = TERMS == 9 ? 27 : 18;        // matrix instructions of a region
-  constexpr int kSplit = 32;                      // vector instructions of one split_part (an upper bound for the pinning)
+  constexpr int NP = pieces_of(TERMS);
+  constexpr int kN = TERMS == 9 ? 27 : TERMS == 6 ? 18 : 9;   // matrix instructions of a region
+  constexpr int kSplit = NP == 3 ? 32 : 20;                   // vector instructions of one split_part (an upper bound for the pinning)
+  constexpr int kRd = 3 * NP;                                 // fragments a region reads: pieces 1.. of its row quarter, piece 0 of the next
   EQA_TICK(0);
   // region m = 0: B of the next stage; row r: re
   __builtin_amdgcn_sched_barrier(0);
-  read_frags<0, 1>(F1, rd); read_frags<0, 2>(F2, rd); read_frags<1, 0>(F3, rd);
-  load_bset(Bn, tb, b_voff, sb_off);
-  split_part<0, 0>(raw, wr);
-  mma_rows<TERMS, 0, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 0, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 0, 2, FIRST>(F2, Bc, acc);
-  pin_region<kN, 9, 9, kSplit, 3>();
+  read_frags<NP, 0, 1>(F1, rd);
+  if constexpr (NP == 3) read_frags<NP, 0, 2>(F2, rd);
+  read_frags<NP, 1, 0>(F3, rd);
+  load_bset<NP>(Bn, tb, b_voff, sb_off);
+  split_part<NP, 0, 0>(raw, wr, scale);
+  mma_rows<TERMS, 0, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 0, 1, FIRST>(F1, Bc, acc);
+  if constexpr (NP == 3) mma_rows<TERMS, 0, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, kRd, kRd, kSplit, NP>();
   EQA_TICK(1);
   // region m = 1: row r: im, re + im
   __builtin_amdgcn_sched_barrier(0);
-  read_frags<1, 1>(F1, rd); read_frags<1, 2>(F2, rd); read_frags<2, 0>(F0, rd);
-  split_part<0, 1>(raw, wr); split_part<0, 2>(raw, wr);
-  mma_rows<TERMS, 1, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 1, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 1, 2, FIRST>(F2, Bc, acc);
-  pin_region<kN, 9, 0, 2 * kSplit + 4, 6>();
+  read_frags<NP, 1, 1>(F1, rd);
+  if constexpr (NP == 3) read_frags<NP, 1, 2>(F2, rd);
+  read_frags<NP, 2, 0>(F0, rd);
+  split_part<NP, 0, 1>(raw, wr, scale); split_part<NP, 0, 2>(raw, wr, scale);
+  mma_rows<TERMS, 1, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 1, 1, FIRST>(F1, Bc, acc);
+  if constexpr (NP == 3) mma_rows<TERMS, 1, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, kRd, 0, 2 * kSplit + 4, 2 * NP>();
   EQA_TICK(2);
   // region m = 2: row r + 64: re, im
   __builtin_amdgcn_sched_barrier(0);
-  read_frags<2, 1>(F1, rd); read_frags<2, 2>(F2, rd); read_frags<3, 0>(F3, rd);
-  split_part<1, 0>(raw, wr); split_part<1, 1>(raw, wr);
-  mma_rows<TERMS, 2, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 2, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 2, 2, FIRST>(F2, Bc, acc);
-  pin_region<kN, 9, 0, 2 * kSplit, 6>();
+  read_frags<NP, 2, 1>(F1, rd);
+  if constexpr (NP == 3) read_frags<NP, 2, 2>(F2, rd);
+  read_frags<NP, 3, 0>(F3, rd);
+  split_part<NP, 1, 0>(raw, wr, scale); split_part<NP, 1, 1>(raw, wr, scale);
+  mma_rows<TERMS, 2, 0, FIRST>(F0, Bc, acc); mma_rows<TERMS, 2, 1, FIRST>(F1, Bc, acc);
+  if constexpr (NP == 3) mma_rows<TERMS, 2, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, kRd, 0, 2 * kSplit, 2 * NP>();
   EQA_TICK(3);
   // region m = 3: row r + 64: re + im; the raw values of stage g + 4
   __builtin_amdgcn_sched_barrier(0);
-  read_frags<3, 1>(F1, rd); read_frags<3, 2>(F2, rd); read_frags<0, 0>(F0, rd_next);
-  split_part<1, 2>(raw, wr);
+  read_frags<NP, 3, 1>(F1, rd);
+  if constexpr (NP == 3) read_frags<NP, 3, 2>(F2, rd);
+  read_frags<NP, 0, 0>(F0, rd_next);
+  split_part<NP, 1, 2>(raw, wr, scale);
   load_raw<0>(raw, ta, a_voff, row64, sa_off);
-  mma_rows<TERMS, 3, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 3, 1, FIRST>(F1, Bc, acc); mma_rows<TERMS, 3, 2, FIRST>(F2, Bc, acc);
-  pin_region<kN, 9, 2, kSplit + 4, 3>();
+  mma_rows<TERMS, 3, 0, FIRST>(F3, Bc, acc); mma_rows<TERMS, 3, 1, FIRST>(F1, Bc, acc);
+  if constexpr (NP == 3) mma_rows<TERMS, 3, 2, FIRST>(F2, Bc, acc);
+  pin_region<kN, kRd, 2, kSplit + 4, NP>();
   __builtin_amdgcn_sched_barrier(0);
   load_raw<1>(raw, ta, a_voff, row64, sa_off);
   EQA_TICK(4);
@@ -528,7 +575,10 @@ __device__ long long g_blk_clock[16];
 template <int TERMS>
 __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const float* __restrict__ V, const uint16_t* __restrict__ Bp,
                                                                         float* __restrict__ Mo, int M, int pitch, int Cin, int Cout, int F,
-                                                                        int n_rt, int n_cg, int blocks_per_xcd) {
+                                                                        int n_rt, int n_cg, int blocks_per_xcd,
+                                                                        const float* __restrict__ vbound, int nbound, float b_scale) {
+  constexpr int NP = pieces_of(TERMS);
+  constexpr int kAStageBytes = a_stage_bytes(TERMS);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int xcd = blockIdx.x & (kXcd - 1);
@@ -548,14 +598,14 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const fl
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // kABufs * kAStageBytes
   const size_t rowf = (size_t)2 * Cin, mo_row = (size_t)2 * Cout;
-  const unsigned b_stage_bytes = (unsigned)(Cout / 32) * 9 * kBFrag;
+  const unsigned b_stage_bytes = (unsigned)(Cout / 32) * 3 * NP * kBFrag;
   const unsigned a_stage = 32u * 4u;
   const unsigned b_voff = lane * 16;
   const unsigned row64 = (unsigned)(64 * rowf * 4);
   // splitter: rows 16 w + (l >> 1 & 15) and + 64, k = 8 (l & 1) + 4 (l >> 5) + t
   const int sp_b = lane & 1, sp_r = (lane >> 1) & 15, sp_h = lane >> 5;
   const int sp_row = 16 * wave + sp_r;
-  const unsigned sp_lds = (unsigned)((sp_row >> 5) * 9 * kFragBytes + ((sp_row & 31) + 32 * sp_h) * 16 + 8 * sp_b);
+  const unsigned sp_lds = (unsigned)((sp_row >> 5) * 3 * NP * kFragBytes + ((sp_row & 31) + 32 * sp_h) * 16 + 8 * sp_b);
   const unsigned sp_k = (unsigned)(8 * sp_b + 4 * sp_h) * 4u;
 
   auto locate = [&](int u, TileAt& at, unsigned& aoff, int& f, int& row0, int& ct) {
@@ -574,7 +624,7 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const fl
     at.sb = 0;
 #else
     at.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(Bp) + (size_t)f * S * (b_stage_bytes / 2), 0, live ? (unsigned)S * b_stage_bytes : 0u, 0x00020000);
-    at.sb = (unsigned)ct * (9 * kBFrag);
+    at.sb = (unsigned)ct * (3 * NP * kBFrag);
 #endif
 #ifdef EQA_BLK_SAME_A
     at.a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(V), 0, live ? (unsigned)((size_t)pitch * rowf * 4) : 0u, 0x00020000);
@@ -596,26 +646,41 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const fl
     if (++sb == S) { sb = 0; ub += blocks_per_xcd; locate(ub, tb, b_unused, fa, rowa, cta); }
   };
 
+  // TERMS = 3: A is scaled by the power of two that takes the caller's bound of |V| (vbound[0 .. nbound): the largest counts) to
+  // 2^14 (re + im then stays below 2^15.5 < 65504); the result is scaled back with B's factor in the epilogue.  Powers of two: exact.
+  float a_scale = 1.0f, out_scale = 1.0f;
+  if constexpr (TERMS == 3) {
+    float mx = 0.0f;
+    for (int t = lane; t < nbound; t += 64) mx = fmaxf(mx, vbound[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int ex = 0;
+    if (mx > 0.0f && mx < 3.0e38f) (void)frexpf(mx, &ex);      // mx <= 2^ex
+    ex = min(max(14 - ex, -100), 100);
+    ex = __builtin_amdgcn_readfirstlane(ex);
+    a_scale = ldexpf(1.0f, ex);
+    out_scale = ldexpf(1.0f, -ex) / b_scale;
+  }
   RawA raw0, raw1;
-  BSet B0, B1;
+  BSet<NP> B0, B1;
   AFrags F0, F1, F2, F3;
   // prologue: stages 0 and 1 of A built in buffers 0 and 1, stages 2 and 3 requested, stage 0 of B requested
   load_raw<0>(raw0, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw0, ta, a_voff, row64, sa * a_stage); next_a();
   load_raw<0>(raw1, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw1, ta, a_voff, row64, sa * a_stage); next_a();
-  load_bset(B0, tb, b_voff, sb * b_stage_bytes); next_b();
+  load_bset<NP>(B0, tb, b_voff, sb * b_stage_bytes); next_b();
   {
     unsigned char* w0p = lds + sp_lds;
     unsigned char* w1p = lds + kAStageBytes + sp_lds;
-    split_part<0, 0>(raw0, w0p); split_part<0, 1>(raw0, w0p); split_part<0, 2>(raw0, w0p);
-    split_part<1, 0>(raw0, w0p); split_part<1, 1>(raw0, w0p); split_part<1, 2>(raw0, w0p);
-    split_part<0, 0>(raw1, w1p); split_part<0, 1>(raw1, w1p); split_part<0, 2>(raw1, w1p);
-    split_part<1, 0>(raw1, w1p); split_part<1, 1>(raw1, w1p); split_part<1, 2>(raw1, w1p);
+    split_part<NP, 0, 0>(raw0, w0p, a_scale); split_part<NP, 0, 1>(raw0, w0p, a_scale); split_part<NP, 0, 2>(raw0, w0p, a_scale);
+    split_part<NP, 1, 0>(raw0, w0p, a_scale); split_part<NP, 1, 1>(raw0, w0p, a_scale); split_part<NP, 1, 2>(raw0, w0p, a_scale);
+    split_part<NP, 0, 0>(raw1, w1p, a_scale); split_part<NP, 0, 1>(raw1, w1p, a_scale); split_part<NP, 0, 2>(raw1, w1p, a_scale);
+    split_part<NP, 1, 0>(raw1, w1p, a_scale); split_part<NP, 1, 1>(raw1, w1p, a_scale); split_part<NP, 1, 2>(raw1, w1p, a_scale);
   }
   load_raw<0>(raw0, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw0, ta, a_voff, row64, sa * a_stage); next_a();
   load_raw<0>(raw1, ta, a_voff, row64, sa * a_stage); load_raw<1>(raw1, ta, a_voff, row64, sa * a_stage); next_a();
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   unsigned rbuf = 0;                                               // byte offset of the LDS buffer of the stage being multiplied
-  read_frags<0, 0>(F0, lds + lane * 16);
+  read_frags<NP, 0, 0>(F0, lds + lane * 16);
   auto step = [&](unsigned o) { return o + kAStageBytes >= kABufs * kAStageBytes ? o + kAStageBytes - kABufs * kAStageBytes : o + kAStageBytes; };
 
   for (int u = q; u < total; u += blocks_per_xcd) {
@@ -624,7 +689,7 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const fl
   {                                                                                                                                  \
     const unsigned r1 = step(rbuf), r2 = step(r1);                                                                                   \
     run_stage_block<TERMS, FIRST>(BC, BN, RAW, F0, F1, F2, F3, acc, lds + rbuf + lane * 16, lds + r1 + lane * 16, lds + r2 + sp_lds, \
-                                  tb, sb * b_stage_bytes, b_voff, ta, sa * a_stage, a_voff, row64 EQA_TOT);                          \
+                                  tb, sb * b_stage_bytes, b_voff, ta, sa * a_stage, a_voff, row64, a_scale EQA_TOT);                          \
     next_a(); next_b();                                                                                                              \
     rbuf = r1;                                                                                                                       \
   }
@@ -656,8 +721,8 @@ __global__ __launch_bounds__(256, 1) void fft_cgemm3m_bf16_block_kernel(const fl
           const unsigned roff = voff + (unsigned)((32 * m + (e & 3) + 8 * (e >> 2)) * mo_row * 4);     // in the range-checked offset
           const float t1 = acc[0][m][e], t2 = acc[1][m][e], t3 = acc[2][m][e];
           u32x2 c;
-          c[0] = __builtin_bit_cast(unsigned, t1 - t2);
-          c[1] = __builtin_bit_cast(unsigned, t3 - t1 - t2);
+          c[0] = __builtin_bit_cast(unsigned, TERMS == 3 ? (t1 - t2) * out_scale : t1 - t2);
+          c[1] = __builtin_bit_cast(unsigned, TERMS == 3 ? (t3 - t1 - t2) * out_scale : t3 - t1 - t2);
           __builtin_amdgcn_raw_buffer_store_b64(c, dr, roff, 0, 0);
         }
     }
@@ -690,6 +755,27 @@ __global__ __launch_bounds__(256) void spectra3m_split_kernel(const float* __res
   u32x4* dst = reinterpret_cast<u32x4*>(Bp + g * (3 * 64 * 8)) + lane;
 #pragma unroll
   for (int q = 0; q < 3; ++q) dst[q * 64] = p.p[q];
+}
+
+
+// ... -> Bh (F, S, Cout/32, 3, 2, 64, 8) fp16: the two pieces of b_scale * B3 (b_scale: a power of two that takes max |B3| to 2^14)
+__global__ __launch_bounds__(256) void spectra3m_split_f16_kernel(const float* __restrict__ B3, uint16_t* __restrict__ Bh, size_t groups,
+                                                                  float b_scale) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= groups * 64) return;
+  const size_t g = t >> 6;            // (f, s, nt, part)
+  const int lane = (int)(t & 63);
+  const float* src = B3 + g * (2 * 64 * 4) + lane * 4;
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(src) * b_scale, hi = *reinterpret_cast<const f32x4*>(src + 64 * 4) * b_scale;
+  u32x2 a[2], b[2];
+  split4h(lo, a);
+  split4h(hi, b);
+  u32x4* dst = reinterpret_cast<u32x4*>(Bh + g * (2 * 64 * 8)) + lane;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const u32x4 v = {a[q][0], a[q][1], b[q][0], b[q][1]};
+    dst[q * 64] = v;
+  }
 }
 
 }  // namespace
@@ -732,15 +818,17 @@ int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_
   const int S = Cin / kStageK;
   if (Cout % kBlkN == 0 && eqa::g_cgemm_bf16_form != 1) {      // the block form: A split once per block, shared through LDS
     const int n_rb = (int)((M + kBlkM - 1) / kBlkM), n_cg = Cout / kBlkN;
-    constexpr int kLds = kABufs * kAStageBytes;
+    constexpr int kLds = kABufs * a_stage_bytes(9);
     const void* kern = terms == 9 ? (const void*)fft_cgemm3m_bf16_block_kernel<9> : (const void*)fft_cgemm3m_bf16_block_kernel<6>;
     if (!allow_dynamic_lds(kern, kLds)) return EQA_ERR_LAUNCH;
     if (terms == 9)
       hipLaunchKernelGGL((fft_cgemm3m_bf16_block_kernel<9>), dim3(blocks), dim3(256), kLds, (hipStream_t)stream, V,
-                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd);
+                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd,
+                         (const float*)nullptr, 0, 1.0f);
     else
       hipLaunchKernelGGL((fft_cgemm3m_bf16_block_kernel<6>), dim3(blocks), dim3(256), kLds, (hipStream_t)stream, V,
-                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd);
+                         static_cast<const uint16_t*>(Bp), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd,
+                         (const float*)nullptr, 0, 1.0f);
     return launch_status();
   }
 #define EQA_CG_LAUNCH(NP, T)                                                                                                       \
@@ -755,6 +843,43 @@ int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_
   }
 #undef EQA_CG_TERMS
 #undef EQA_CG_LAUNCH
+  return launch_status();
+}
+
+
+int64_t eqa_fft48k5_spectra3m_f16_bytes(int Cin, int Cout) {
+  if (!eqa_fft48k5_cgemm3m_supported(Cin, Cout) || Cout % kBlkN != 0) return 0;
+  return (int64_t)eqa_fft48k5_frequencies() * Cin * Cout * 3 * 2 * 2;
+}
+
+int eqa_fft48k5_spectra3m_split_f16(const float* B3, void* Bh, int Cin, int Cout, float b_scale, void* stream) {
+  if (!B3 || !Bh || !(b_scale > 0.0f)) return EQA_ERR_INVALID_ARG;
+  if (eqa_fft48k5_spectra3m_f16_bytes(Cin, Cout) == 0 || (((uintptr_t)B3 | (uintptr_t)Bh) & 15)) return EQA_ERR_UNSUPPORTED;
+  int ex = 0;
+  if (frexpf(b_scale, &ex) != 0.5f) return EQA_ERR_INVALID_ARG;            // a power of two: the scaling must be exact
+  const size_t groups = (size_t)eqa_fft48k5_frequencies() * (Cin / kStageK) * (Cout / 32) * 3;
+  const size_t threads = groups * 64;
+  hipLaunchKernelGGL(spectra3m_split_f16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, B3,
+                     static_cast<uint16_t*>(Bh), groups, b_scale);
+  return launch_status();
+}
+
+int eqa_fft48k5_cgemm3m_f16x2(const float* V, const void* Bh, float* Mo, int64_t M, int Cin, int Cout, const float* vbound, int nbound,
+                              float b_scale, void* stream) {
+  if (!V || !Bh || !Mo || M < 0 || Cin <= 0 || Cout <= 0 || !vbound || nbound <= 0 || !(b_scale > 0.0f)) return EQA_ERR_INVALID_ARG;
+  if (M == 0) return EQA_OK;
+  const int F = eqa_fft48k5_frequencies();
+  const int64_t fm_bytes = ((M | 1) + 64) * 2 * (int64_t)std::max(Cin, Cout) * 4;
+  if (eqa_fft48k5_spectra3m_f16_bytes(Cin, Cout) == 0 || M > 0x3fffff || fm_bytes > 0x7fffffffLL || (int64_t)Cin * Cout * 6 * 2 > 0x7fffffffLL ||
+      (((uintptr_t)V | (uintptr_t)Bh | (uintptr_t)Mo) & 15) || (Cin / kStageK) % 2 != 0)
+    return EQA_ERR_UNSUPPORTED;
+  const int blocks = 256;
+  const int n_rb = (int)((M + kBlkM - 1) / kBlkM), n_cg = Cout / kBlkN;
+  constexpr int kLds = kABufs * a_stage_bytes(3);
+  if (!allow_dynamic_lds((const void*)fft_cgemm3m_bf16_block_kernel<3>, kLds)) return EQA_ERR_LAUNCH;
+  hipLaunchKernelGGL((fft_cgemm3m_bf16_block_kernel<3>), dim3(blocks), dim3(256), kLds, (hipStream_t)stream, V,
+                     static_cast<const uint16_t*>(Bh), Mo, (int)M, (int)eqa_fft48k5_tile_pitch(M), Cin, Cout, F, n_rb, n_cg, blocks / kXcd,
+                     vbound, nbound, b_scale);
   return launch_status();
 }
 

@@ -7,6 +7,7 @@ canonicalization network (reference: equiadapt/images/canonicalization_networks/
 GEMM library runs as a real one (see include/eqa_hip.h, eqa_fft48k5_*).  Where the tiles fit the output (88 = 2 x 44 at the
 headline shape) this needs 2.5 real multiplies per output against 4 for Winograd F(4x4,5x5), and spectra of 1.24x the
 activation size against 4x.  fp32 throughout."""
+import math
 import os
 from typing import Optional
 
@@ -37,10 +38,19 @@ GEMM_PIECES = os.environ.get("EQA_FFT_GEMM_PIECES", "auto")
 AUTO_MIN_CIN = int(os.environ.get("EQA_FFT_GEMM_AUTO_MIN_CIN", "128"))
 
 
-def gemm_form(cin: int, cout: int) -> str:
-    """"f32" / "9" / "6": how `contract` multiplies a (.., 2 cin) . (2 cin, 2 cout) complex product (see GEMM_PIECES)."""
+def f16_form_takes(cin: int, cout: int) -> bool:
+    return cout % 128 == 0 and cin % 32 == 0
+
+
+def gemm_form(cin: int, cout: int, bounded: bool = False) -> str:
+    """"f32" / "9" / "6" / "h3": how `contract` multiplies a (.., 2 cin) . (2 cin, 2 cout) complex product (see GEMM_PIECES).
+    ``bounded``: the caller holds an upper bound of |V| on the device (what the fp16 form "h3" needs)."""
     if GEMM_PIECES in ("f32", "9", "6"):
         return GEMM_PIECES
+    if bounded and f16_form_takes(cin, cout) and (GEMM_PIECES == "h3" or cin >= AUTO_MIN_CIN):
+        return "h3"
+    if GEMM_PIECES == "h3":        # no bound, or a shape the fp16 kernel does not take: as "auto" without it
+        return "6" if cin >= AUTO_MIN_CIN and cout % 128 == 0 else "f32"
     return "6" if cin >= AUTO_MIN_CIN and cout % 128 == 0 else "f32"
 
 
@@ -49,10 +59,25 @@ class Spectra3M:
     [Br | Bi | Br + Bi] per (frequency, K-stage, 32 output channels); ``pieces()``: the same split into three bf16 pieces per value
     in the fragment order of the bf16 matrix instruction (built on first use)."""
 
-    __slots__ = ("data", "cin", "cout", "_pieces")
+    __slots__ = ("data", "cin", "cout", "_pieces", "_pieces_f16")
 
     def __init__(self, data: torch.Tensor, cin: int, cout: int):
-        self.data, self.cin, self.cout, self._pieces = data, cin, cout, None
+        self.data, self.cin, self.cout, self._pieces, self._pieces_f16 = data, cin, cout, None, None
+
+    def pieces_f16(self):
+        """(Bh, b_scale): the spectra times the power of two b_scale (max |.| -> at most 2^14) as two fp16 pieces per value, in the
+        fragment order of the fp16 matrix instruction (built on first use: one host synchronisation for the maximum)."""
+        if self._pieces_f16 is None:
+            lib = _lib.load()
+            mx = float(self.data.abs().max().item())
+            ex = 14 - math.frexp(mx)[1] if 0.0 < mx < float("inf") else 0        # mx <= 2^frexp(mx)[1]
+            scale = math.ldexp(1.0, max(-100, min(100, ex)))
+            bh = torch.empty(lib.eqa_fft48k5_spectra3m_f16_bytes(self.cin, self.cout) // 2, dtype=torch.int16, device=self.data.device)
+            with torch.cuda.device(self.data.device):
+                _lib.check(lib.eqa_fft48k5_spectra3m_split_f16(self.data.data_ptr(), bh.data_ptr(), self.cin, self.cout, scale,
+                                                               torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_spectra3m_split_f16")
+            self._pieces_f16 = (bh, scale)
+        return self._pieces_f16
 
     def pieces(self) -> torch.Tensor:
         if self._pieces is None:
@@ -91,14 +116,21 @@ def spectra_for(bank: torch.Tensor, correlate: bool = True):
     return filter_spectra(bank, correlate=correlate)
 
 
-def contract(V: torch.Tensor, B, M: int) -> torch.Tensor:
-    """Mo[f] = V[f] . B[f] for every stored frequency: V (F, M, 2Cin) view of a pitched buffer -> Mo (F, M, 2Cout) likewise."""
+def contract(V: torch.Tensor, B, M: int, vbound: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Mo[f] = V[f] . B[f] for every stored frequency: V (F, M, 2Cin) view of a pitched buffer -> Mo (F, M, 2Cout) likewise.
+    ``vbound``: a device fp32 tensor whose maximum bounds every |Re|, |Im| of V (the producer's DC bins) -- admits the fp16 form."""
     dev = V.device
     if isinstance(B, Spectra3M):
         lib = _lib.load()
         assert V.shape[2] == 2 * B.cin and V.stride(1) == 2 * B.cin and V.stride(0) == lib.eqa_fft48k5_tile_pitch(M) * 2 * B.cin
         Mo = spectra_buffer(M, 2 * B.cout, dev)
-        form = gemm_form(B.cin, B.cout)
+        form = gemm_form(B.cin, B.cout, vbound is not None)
+        if form == "h3":
+            bh, b_scale = B.pieces_f16()
+            _lib.check(lib.eqa_fft48k5_cgemm3m_f16x2(V.data_ptr(), bh.data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, vbound.data_ptr(),
+                                                     vbound.numel(), b_scale, torch.cuda.current_stream().cuda_stream),
+                       "eqa_fft48k5_cgemm3m_f16x2")
+            return Mo
         if form in ("9", "6"):
             _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, int(form),
                                                       torch.cuda.current_stream().cuda_stream), "eqa_fft48k5_cgemm3m_bf16x3")

@@ -534,6 +534,21 @@ int eqa_fft48k5_cgemm3m(const float* V, const float* B3, float* Mo, int64_t M, i
 int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout);
 int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream);
 int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_t M, int Cin, int Cout, int terms, void* stream);
+/* The same contraction on TWO fp16 pieces per fp32 operand (csrc/cgemm3m_bf16.hip, TERMS = 3): x = h1 + h2 + d with h1 = rn16(s x),
+ * h2 = rn16(s x - h1), |d| <= 2^-24 |x| (s: a power of two that takes the operand's bound to 2^14); a product is h1 k1 + h1 k2 + h2 k1,
+ * each exact in v_mfma_f32_32x32x16_f16, fp32 accumulate -- three matrix instructions per product instead of six, and closer to an
+ * fp64 product than the six-product bf16 form or the fp32 instruction (profiles/r06/f16x2_gemm_check.txt, kbench_gemm_error.txt).
+ * The caller bounds the operands: vbound[0 .. nbound) (device memory, read by the kernel: no host synchronisation) holds numbers
+ * whose maximum is >= every |Re|, |Im| of V -- for the spectra of NON-NEGATIVE activations the DC bins (eqa_lift5_fft48k5_input_dcmax);
+ * values more than 2^16 below the bound lose precision gradually (fp16 subnormals).  b_scale: the power of two the filter spectra
+ * were multiplied by when split (max |B3| b_scale <= 2^14).  Same reference arithmetic as eqa_fft48k5_cgemm3m (escnn_networks.py:67-91).
+ *   eqa_fft48k5_spectra3m_f16_bytes   bytes of Bh = F * Cin * Cout * 3 parts * 2 pieces * 2; 0: shape not taken (Cout % 128 != 0).
+ *   eqa_fft48k5_spectra3m_split_f16   B3 -> Bh:(F, Cin/16, Cout/32, 3, 2 pieces, 64, 8) fp16 of b_scale * B3.
+ *   eqa_fft48k5_cgemm3m_f16x2         V, Bh -> Mo; shapes and layouts of V / Mo as for eqa_fft48k5_cgemm3m. */
+int64_t eqa_fft48k5_spectra3m_f16_bytes(int Cin, int Cout);
+int eqa_fft48k5_spectra3m_split_f16(const float* B3, void* Bh, int Cin, int Cout, float b_scale, void* stream);
+int eqa_fft48k5_cgemm3m_f16x2(const float* V, const void* Bh, float* Mo, int64_t M, int Cin, int Cout, const float* vbound, int nbound,
+                              float b_scale, void* stream);
 /* The filter gradient's contraction (training), replacing the library's real [2Cin x M].[M x 2Cout] product (autograd through the
  * same R2Conv): D[f] = V[f]^T . conj(G[f]) over the M tiles in the 3-multiplication form on the fp32 MFMA.  V:(F, M|1, 2Cin),
  * G:(F, M|1, 2Cout) as eqa_fft48k5_input / _grad_transform write them; D3:(F, Cin, 2, Cout) = Dr | Di per input channel, plain

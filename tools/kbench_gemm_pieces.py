@@ -25,11 +25,15 @@ def measure(M: int = 1024, Cin: int = 256, Cout: int = 256, reps: int = 10, dev=
     V = fc.spectra_buffer(M, 2 * Cin, dev)
     V.normal_(generator=torch.Generator(device=dev).manual_seed(1))
     st = torch.cuda.current_stream().cuda_stream
+    vb = V.abs().max().reshape(1)            # the bound the fp16 form ("h3") asks for
 
     def run(mode):
         Mo = fc.spectra_buffer(M, 2 * Cout, dev)
         if mode == "f32":
             _lib.check(lib.eqa_fft48k5_cgemm3m(V.data_ptr(), B.data.data_ptr(), Mo.data_ptr(), M, Cin, Cout, st), "cgemm3m")
+        elif mode == "h3":
+            bh, b_scale = B.pieces_f16()
+            _lib.check(lib.eqa_fft48k5_cgemm3m_f16x2(V.data_ptr(), bh.data_ptr(), Mo.data_ptr(), M, Cin, Cout, vb.data_ptr(), 1, b_scale, st), "f16x2")
         else:
             _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, Cin, Cout, int(mode[0]), st), "bf16x3")
         return Mo
@@ -38,7 +42,7 @@ def measure(M: int = 1024, Cin: int = 256, Cout: int = 256, reps: int = 10, dev=
     fs = [0, 1, 577, fc.F - 1]
     want = torch.bmm(V[fs, :M].double(), fc.filter_spectra(bank)[fs].double())     # fp64 truth on a sample of frequencies
     out = {"scale": want.abs().max().item(), "shape": f"{fc.F} x [{M} x {Cin}].[{Cin} x {Cout}] complex"}
-    for mode in ("f32", "9", "6", "9w", "6w"):
+    for mode in ("f32", "9", "6", "9w", "6w") + (("h3",) if fc.f16_form_takes(Cin, Cout) else ()):
         # "9" / "6": the form the library chooses (the block form when Cout % 256 == 0); "9w" / "6w": the wave form forced (option 2)
         _lib.check(lib.eqa_set_option(2, 1 if mode.endswith("w") else 0), "set_option")
         for _ in range(3):
@@ -67,9 +71,10 @@ def main():
     args = ap.parse_args()
     r = measure(args.m, args.cin, args.cout, args.reps)
     print(r["shape"], " max |fp64 result| on the sampled frequencies:", f"{r['scale']:.3e}")
-    for mode in ("f32", "9", "6", "9w", "6w"):
+    for mode in ("f32", "9", "6", "9w", "6w") + (("h3",) if "h3" in r else ()):
         m = r[mode]
-        what = "fp32 matrix instruction" if mode == "f32" else f"bf16 pieces, {mode[0]} products" + (" (wave form)" if mode.endswith("w") else "")
+        what = ("fp32 matrix instruction" if mode == "f32" else "two fp16 pieces, 3 products" if mode == "h3"
+                else f"bf16 pieces, {mode[0]} products" + (" (wave form)" if mode.endswith("w") else ""))
         print(f"{what:>38}: {m['ms']:7.3f} ms  {m['tflops_fp32_equivalent']:6.1f} TFLOP/s fp32-equivalent   |result - fp64| max {m['max_err_vs_fp64']:.3e} rms {m['rms_err_vs_fp64']:.3e}")
 
 
