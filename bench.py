@@ -857,10 +857,10 @@ def main():
             # and with all nine piece products is timed beside it, same box, same run.
             from equiadapt_amd.images.canonicalization_networks import fftconv as _fc
 
-            default_form = _fc.gemm_form(256, 256)
+            default_form = _fc.LAST_FORM or _fc.gemm_form(256, 256)      # what the timed steps' contraction ran in
             step_forms = {default_form: elapsed / args.steps * 1e3, "default": default_form}
             if _fc.GEMM_PIECES == "auto":
-                for mode in ("f32", "9", "6"):
+                for mode in ("f32", "9", "6", "h3"):
                     if mode == default_form:
                         continue
                     _fc.GEMM_PIECES = mode
@@ -988,10 +988,13 @@ def main():
                                               "rate the kernel reaches -- 8 TB/s is the memory's rating, a copy is what a launch can get"},
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
             "ms_per_step_with_event_brackets": elapsed_kt / args.steps * 1e3,
-            "step_ms_by_gemm_form": {**step_forms, "note": "the whole timed step with the complex GEMM as: 6 / 9 = bf16 matrix cores on exact "
-                                     "three-piece splits of the fp32 operands with six / nine piece products, fp32 accumulation; f32 = "
-                                     "v_mfma_f32_32x32x2_f32.  `default` is what `value` ran (fftconv.gemm_form: six products where Cin >= 128 "
-                                     "and Cout % 128 == 0, gated by a distance-to-fp64 test; EQA_FFT_GEMM_PIECES=f32 restores the fp32 instruction)"},
+            "step_ms_by_gemm_form": {**step_forms, "note": "the whole timed step with the complex GEMM as: h3 = fp16 matrix cores on TWO fp16 "
+                                     "pieces per fp32 operand (11 + 11 bits and a sign: within half an fp32 ulp), three exact products per "
+                                     "product, fp32 accumulation, operands scaled by powers of two under the bound the fused lifting kernel "
+                                     "hands over; 6 / 9 = bf16 matrix cores on exact three-piece splits with six / nine piece products; f32 = "
+                                     "v_mfma_f32_32x32x2_f32.  `default` is what `value` ran (fftconv.gemm_form: h3 where the producer bounds "
+                                     "|V|, Cin >= 64, Cout % 128 == 0 -- measured CLOSER to fp64 than the fp32 instruction, gated by "
+                                     "tests/test_gpu_parity.py; EQA_FFT_GEMM_PIECES=f32 restores the fp32 instruction)"},
             "group_action": {"images_s_per_gpu": B / (ga2_ms * 1e-3), "ms": ga2_ms,
                              "achieved_GBs": ga_bytes / (ga2_ms * 1e-3) / 1e9,
                              "frac_hbm_peak": ga_bytes / (ga2_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1004,7 +1007,11 @@ def main():
                                      "for callers that hold x and f at the same time, not what the library's two calls use)"},
             "self_check": self_check,
         })
-        if default_form in ("6", "9"):
+        if default_form == "h3":
+            line["dtype"] = ("f32 (resampling / FFT / accumulation in fp32; the network's channel contraction as 2xfp16 split of every fp32 "
+                             "operand (within half an fp32 ulp), 3 exact products, fp32 accumulate -- closer to fp64 than the fp32 matrix "
+                             "instruction, see step_ms_by_gemm_form)")
+        elif default_form in ("6", "9"):
             line["dtype"] = (f"f32 (resampling / FFT / accumulation in fp32; the network's channel contraction as 3xbf16 exact split, "
                              f"{default_form} products, fp32 accumulate -- no further from fp64 than the fp32 matrix instruction, see step_ms_by_gemm_form)")
         line["stages"] = stage_table(ktimes, B)
@@ -1093,9 +1100,15 @@ def stage_table(ktimes, B):
 
     m_tiles, spectra = B * 4, 1154 * B * 4 * 512 * 4
     own_gemm = fftconv.gemm3m_supported(256, 256)
-    form = fftconv.gemm_form(256, 256) if own_gemm else "lib"
+    form = (fftconv.LAST_FORM or fftconv.gemm_form(256, 256)) if own_gemm else "lib"
     real_products = 3.0 * 2.0 * 1154 * m_tiles * 256 * 256           # flops of the 3 real products per complex one
-    if form in ("6", "9"):
+    if form == "h3":
+        # fp16 form: every real product is 3 fp16 piece products -- the matrix-core flops, priced against the dense fp16 peak (= bf16's)
+        gemm_spec = ("mfma_bf16", 3.0 * real_products,
+                     "eqa_fft48k5_cgemm3m_f16x2: 1154 x [tiles x 256].[256 x 256] complex products, 3-multiplication form, every fp32 operand "
+                     "split into two fp16 pieces (within half an fp32 ulp), 3 piece products per real product on v_mfma_f32_32x32x16_f16, fp32 "
+                     "accumulate (hand-written)")
+    elif form in ("6", "9"):
         # piece form: every real product is `form` bf16 piece products -- THOSE are the matrix-core flops, priced against the dense
         # bf16 peak (the fp32-equivalent rate, real_products / time, is reported beside it)
         gemm_spec = ("mfma_bf16", float(form) * real_products,
@@ -1133,8 +1146,12 @@ def stage_table(ktimes, B):
                             "unit": "TFLOP/s", "frac": a / peak, "launches_timed": n_k}
             if bound == "mfma_bf16":
                 stages[name]["fp32_equivalent_TFLOPs"] = real_products / (ms_k * 1e-3) / 1e12
-                stages[name]["note"] = ("achieved / peak count the bf16 piece products the matrix cores execute against the dense bf16 peak; under "
+                stages[name]["note"] = ("achieved / peak count the piece products the matrix cores execute against the dense bf16 / fp16 peak; under "
                                         "this instruction stream the chip holds ~1.6 GHz (power), see DESIGN.md section 6")
+                if name == "fft_gemm":     # the fp16 form is no longer far from its memory time: V in, Mo out, the filter pieces once
+                    gb = (2.0 * spectra + 1154 * 256 * 256 * 3 * (2 if form == "h3" else 3) * 2) / 1e9
+                    stages[name]["hbm_algorithmic_GB"] = gb
+                    stages[name]["hbm_frac_if_memory_bound"] = gb / (ms_k * 1e-3) / HBM_PEAK_GBS
     for name in ("group_pool", "window_sums", "crop_resize_aa", "sums_gemv"):
         if name in ktimes and name not in stages:
             stages[name] = {"ms": ktimes[name][1], "launches_timed": ktimes[name][0]}

@@ -138,7 +138,8 @@ __device__ __forceinline__ void lf_split3(float x, __bf16& p1, __bf16& p2, __bf1
 template <int ROLE, bool PIECES>
 __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, const float* __restrict__ bank, const float* __restrict__ bias,
                                                  int relu, float* __restrict__ V, int H0, int W0, int C, int TY, int TX, size_t Mp,
-                                                 unsigned nwork, unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
+                                                 unsigned nwork, unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
+                                                 float* __restrict__ dcmax) {
   constexpr bool COLS = ROLE != kConv;
   constexpr int NSUB = PIECES ? 12 : 3;              // sub-phases per item
   constexpr int SUBROWS = kFftN / NSUB;              // tile rows per sub-phase (4 | 16)
@@ -434,6 +435,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   float cre[kFftN], cim[kFftN];      // column data read from LDS, then (in place) the spectrum waiting to be stored
   unsigned pend_m = 0, pend_grp = 0;
   bool pending = false;
+  float dc_seen = 0.0f;              // wave 0: the largest DC bin it stored (see the end of the kernel)
   // 4 x 4 transpose of (register k, lane row i) across the wave's four 16-lane rows: afterwards register k of row i holds what
   // register i held in row k.  (Inline asm with the hazard's two wait states inside the string: chained through the builtins'
   // two-element results, hipcc 7.2 folded the second element into the first -- tools/micro/permlane_swap.hip.)
@@ -491,6 +493,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
           cre[ky] = packed ? 0.5f * (a + c2) : a;
           cim[ky] = packed ? 0.5f * (b - d) : b;
         }
+        dc_seen = fmaxf(dc_seen, packed ? cre[0] : 0.0f);     // the DC bin (kx = 0, ky = 0) of this lane's channel
 #pragma unroll
         for (int ky = kFftH; ky < 28; ++ky) p24re[ky] = p24im[ky] = 0.0f;
 #ifndef EQA_LF_NOSTORE
@@ -647,24 +650,40 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     pend_grp = it.grp;
     pending = live;
   }
+  // The block's largest DC bin -> dcmax[block]; block 0 clears the slots no block writes.  With relu the activations are >= 0 and
+  // |X[k]| <= X[0] for every frequency: the maximum over the kEqaLiftDcSlots slots bounds every entry of V -- what the fp16 form of the
+  // channel contraction scales its operands by (eqa_fft48k5_cgemm3m_f16x2).
+  if constexpr (COLS) {
+    if (dcmax != nullptr && has_packed) {
+      float m = dc_seen;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+      if (lane == 0) dcmax[blockIdx.x] = m;
+      if (blockIdx.x == 0) {
+        for (unsigned t = nblk + lane; t < (unsigned)EQA_LIFT5_DCMAX_SLOTS; t += 64) dcmax[t] = 0.0f;
+      }
+    }
+  }
   LF_CLOCK_END();
 }
 
 __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_kernel(const float* __restrict__ x, const float* __restrict__ bank,
                                                                         const float* __restrict__ bias, int relu, float* __restrict__ V,
                                                                         int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
-                                                                        unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
-  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
-  else lift5_fft48_body<kConv, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+                                                                        unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
+                                                                        float* __restrict__ dcmax) {
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
+  else lift5_fft48_body<kConv, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
 }
 
 // the same with the convolution on the bf16 matrix cores; `bank` = the weights' pieces (Cout, 3, 16, 8) bf16
 __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_pieces_kernel(const float* __restrict__ x, const float* __restrict__ bank,
                                                                                const float* __restrict__ bias, int relu, float* __restrict__ V,
                                                                                int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
-                                                                               unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes) {
-  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
-  else lift5_fft48_body<kConv, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes);
+                                                                               unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
+                                                                               float* __restrict__ dcmax) {
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
+  else lift5_fft48_body<kConv, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
 }
 
 }  // namespace
@@ -680,7 +699,7 @@ int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout) {
 }
 
 static int lift_fft_launch(const float* x, const void* bank, size_t bank_bytes, const float* bias, int relu, float* V, int nimg, int H0, int W0,
-                           int Cout, void* stream, bool pieces) {
+                           int Cout, void* stream, bool pieces, float* dcmax = nullptr) {
   if (!x || !bank || !V || nimg < 0 || H0 < 5 || W0 < 5 || Cout <= 0) return EQA_ERR_INVALID_ARG;
   if (Cout % kLfCh != 0) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
@@ -702,16 +721,24 @@ static int lift_fft_launch(const float* x, const void* bank, size_t bank_bytes, 
   if ((size_t)nblk > nwork) nblk = (unsigned)nwork;
   if (pieces)
     hipLaunchKernelGGL(lift5_fft48_fused_pieces_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
-                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes);
+                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes, dcmax);
   else
     hipLaunchKernelGGL(lift5_fft48_fused_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
-                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes);
+                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes, dcmax);
   return launch_status();
 }
 
 int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
                             void* stream) {
   return lift_fft_launch(x, bank, (size_t)(Cout > 0 ? Cout : 0) * 75 * 4, bias, relu, V, nimg, H0, W0, Cout, stream, false);
+}
+
+int eqa_lift5_fft48k5_input_dcmax(const float* x, const float* bank, const float* bias, int relu, float* V, float* dcmax, int nimg, int H0,
+                                  int W0, int Cout, void* stream) {
+  if (!dcmax) return EQA_ERR_INVALID_ARG;
+  if (!relu) return EQA_ERR_UNSUPPORTED;            // the DC bins bound the spectrum of NON-NEGATIVE activations only
+  if (nimg == 0) return hipMemsetAsync(dcmax, 0, EQA_LIFT5_DCMAX_SLOTS * sizeof(float), (hipStream_t)stream) == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+  return lift_fft_launch(x, bank, (size_t)(Cout > 0 ? Cout : 0) * 75 * 4, bias, relu, V, nimg, H0, W0, Cout, stream, false, dcmax);
 }
 
 int64_t eqa_lift5_pieces_bytes(int Cout) { return Cout > 0 ? (int64_t)Cout * 3 * 16 * 8 * 2 : 0; }

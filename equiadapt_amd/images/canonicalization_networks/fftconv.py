@@ -36,6 +36,14 @@ GEMM = os.environ.get("EQA_FFT_GEMM", "3m")
 # instruction everywhere else.  The rule is gated by tests/test_gpu_parity.py::test_auto_gemm_form_is_no_further_from_fp64.
 GEMM_PIECES = os.environ.get("EQA_FFT_GEMM_PIECES", "auto")
 AUTO_MIN_CIN = int(os.environ.get("EQA_FFT_GEMM_AUTO_MIN_CIN", "128"))
+# "h3" (round 6, the default where it applies): TWO fp16 pieces per operand, three exact products per product on the fp16 matrix
+# cores (eqa_fft48k5_cgemm3m_f16x2).  Half the matrix instructions of "6" and closer to fp64 than "6" AND the fp32 instruction for
+# Cin >= AUTO_MIN_CIN_H3 (fewer accumulator roundings; profiles/r06/kbench_gemm_error.txt) -- but fp16's range wants the operands
+# scaled, so it runs only where the producer of V hands over a bound of |V| on the device: the fused lifting kernel on non-negative
+# (relu) activations, whose DC bins bound every other bin (eqa_lift5_fft48k5_input_dcmax).  Everywhere else "auto" stays as above.
+AUTO_MIN_CIN_H3 = int(os.environ.get("EQA_FFT_GEMM_AUTO_MIN_CIN_H3", "64"))
+DCMAX_SLOTS = 256       # EQA_LIFT5_DCMAX_SLOTS (include/eqa_hip.h)
+LAST_FORM = None        # the form the most recent `contract` on the hand-written GEMM ran in (bench.py reports it)
 
 
 def f16_form_takes(cin: int, cout: int) -> bool:
@@ -47,7 +55,7 @@ def gemm_form(cin: int, cout: int, bounded: bool = False) -> str:
     ``bounded``: the caller holds an upper bound of |V| on the device (what the fp16 form "h3" needs)."""
     if GEMM_PIECES in ("f32", "9", "6"):
         return GEMM_PIECES
-    if bounded and f16_form_takes(cin, cout) and (GEMM_PIECES == "h3" or cin >= AUTO_MIN_CIN):
+    if bounded and f16_form_takes(cin, cout) and (GEMM_PIECES == "h3" or cin >= AUTO_MIN_CIN_H3):
         return "h3"
     if GEMM_PIECES == "h3":        # no bound, or a shape the fp16 kernel does not take: as "auto" without it
         return "6" if cin >= AUTO_MIN_CIN and cout % 128 == 0 else "f32"
@@ -124,7 +132,8 @@ def contract(V: torch.Tensor, B, M: int, vbound: Optional[torch.Tensor] = None) 
         lib = _lib.load()
         assert V.shape[2] == 2 * B.cin and V.stride(1) == 2 * B.cin and V.stride(0) == lib.eqa_fft48k5_tile_pitch(M) * 2 * B.cin
         Mo = spectra_buffer(M, 2 * B.cout, dev)
-        form = gemm_form(B.cin, B.cout, vbound is not None)
+        global LAST_FORM
+        form = LAST_FORM = gemm_form(B.cin, B.cout, vbound is not None)
         if form == "h3":
             bh, b_scale = B.pieces_f16()
             _lib.check(lib.eqa_fft48k5_cgemm3m_f16x2(V.data_ptr(), bh.data_ptr(), Mo.data_ptr(), M, B.cin, B.cout, vbound.data_ptr(),
@@ -343,6 +352,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
     V = spectra_buffer(M, 2 * Cin, dev)
     p_in_bias = in_bias.data_ptr() if in_bias is not None else None
     p_bias = bias.data_ptr() if bias is not None else None
+    vbound = None
     with torch.cuda.device(dev):
         if isinstance(x, LiftedInput):
             assert in_bias is None and not in_relu
@@ -351,6 +361,11 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
                 if LIFT_FFT_FORM == "bf16x3":
                     _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.x.data_ptr(), x.pieces().data_ptr(), p_b, int(x.relu), V.data_ptr(), nimg,
                                                                   H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input_bf16x3")
+                elif x.relu and isinstance(B, Spectra3M) and gemm_form(Cin, Cout, True) == "h3":
+                    # non-negative activations: the kernel also hands over its DC bins, the bound the fp16 contraction scales by
+                    vbound = torch.empty(DCMAX_SLOTS, dtype=torch.float32, device=dev)
+                    _lib.check(lib.eqa_lift5_fft48k5_input_dcmax(x.x.data_ptr(), x.bank.data_ptr(), p_b, 1, V.data_ptr(), vbound.data_ptr(),
+                                                                 nimg, H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input_dcmax")
                 else:
                     _lib.check(lib.eqa_lift5_fft48k5_input(x.x.data_ptr(), x.bank.data_ptr(), p_b, int(x.relu), V.data_ptr(), nimg, H + 4, W + 4,
                                                            Cin, st), "eqa_lift5_fft48k5_input")
@@ -361,7 +376,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
                 _lib.check(fn(x.data_ptr(), T.data_ptr(), V.data_ptr(), p_in_bias, int(in_relu), nimg, H, W, Cin, st), "eqa_fft48k5_input")
             del T
         with _timed("fft_gemm"):
-            Mo = contract(V, B, M)
+            Mo = contract(V, B, M, vbound)
         if keep_V is not None:
             keep_V.append(V)
         del V

@@ -577,6 +577,13 @@ int eqa_fft48k5_input_grouped(const float* x, float* T, float* V, const float* i
 int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout);
 int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias, int relu, float* V, int nimg, int H0, int W0, int Cout,
                             void* stream);
+/* The same launch with relu != 0 (EQA_ERR_UNSUPPORTED otherwise), which also writes dcmax[0 .. EQA_LIFT5_DCMAX_SLOTS): per block of
+ * the persistent grid the largest DC bin (kx = 0, ky = 0: the sum of a tile's non-negative activations) it stored, 0 in the unused
+ * slots.  |X[k]| <= X[0] for a non-negative signal, so the maximum of the slots bounds every |Re|, |Im| of V: the `vbound` of
+ * eqa_fft48k5_cgemm3m_f16x2, produced without a pass over V and consumed without a host synchronisation. */
+#define EQA_LIFT5_DCMAX_SLOTS 256
+int eqa_lift5_fft48k5_input_dcmax(const float* x, const float* bank, const float* bias, int relu, float* V, float* dcmax, int nimg, int H0,
+                                  int W0, int Cout, void* stream);
 /* The same with the convolution on the bf16 matrix cores: every fp32 pixel and weight split exactly into three bf16 pieces, six piece
  * products per product, fp32 accumulation (the contract of eqa_fft48k5_cgemm3m_bf16x3; the fp32 matrix instruction of the form above
  * runs on the vector ALU's datapath and holds the transforms' vector work back).  wpieces: the weights' pieces, (Cout, 3 pieces, 16

@@ -162,3 +162,66 @@ def test_network_inference_takes_the_fused_route(dev, monkeypatch):
     assert ("liftp", id(net.eqv_network[0])) in net._fold_cache and torch.equal(pieces_form, again)
     assert (pieces_form - unfused).abs().max().item() <= 2e-6 * unfused.abs().max().item()
     assert torch.equal(pieces_form.argmax(1), unfused.argmax(1))
+
+
+@pytest.mark.parametrize("nimg,H0,W0,C", [(3, 96, 96, 64), (2, 100, 97, 48), (1, 52, 52, 16), (5, 96, 96, 256), (40, 96, 96, 256)])
+def test_fused_kernel_hands_over_a_bound_of_its_spectra(dev, nimg, H0, W0, C):
+    """eqa_lift5_fft48k5_input_dcmax: the same spectra as eqa_lift5_fft48k5_input, bit for bit, plus EQA_LIFT5_DCMAX_SLOTS floats whose
+    maximum is the largest DC bin stored -- which bounds every |Re|, |Im| of V when the activations are non-negative (|X[k]| <= X[0]):
+    the `vbound` of the fp16 contraction.  Slots of blocks that do not exist are 0; relu = 0 is refused."""
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nimg + H0 + C)
+    x = torch.randn(nimg, 3, H0, W0, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    bank = (torch.randn(C, 3, 5, 5, generator=g) / 75 ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(C, generator=g).to(dev)
+    M = nimg * fftconv.tiles(H0 - 4) * fftconv.tiles(W0 - 4)
+    pitch = lib.eqa_fft48k5_tile_pitch(M)
+    st = torch.cuda.current_stream().cuda_stream
+    plain = torch.full((fftconv.F, pitch, 2 * C), 7.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_lift5_fft48k5_input(x.data_ptr(), bank.data_ptr(), bias.data_ptr(), 1, plain.data_ptr(), nimg, H0, W0, C, st), "plain")
+    full = torch.full((fftconv.F, pitch, 2 * C), 7.0, dtype=torch.float32, device=dev)
+    slots = torch.full((fftconv.DCMAX_SLOTS + 8,), -3.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_lift5_fft48k5_input_dcmax(x.data_ptr(), bank.data_ptr(), bias.data_ptr(), 1, full.data_ptr(), slots.data_ptr(), nimg, H0, W0,
+                                                 C, st), "dcmax")
+    assert torch.equal(full, plain)
+    assert (slots[fftconv.DCMAX_SLOTS:] == -3.0).all() and (slots[:fftconv.DCMAX_SLOTS] >= 0).all()
+    V = full[:, :M]
+    dc = V[48 * 23]                                      # frequency (kx = 0, ky = 0): [Re x 16 | Im x 16] per channel group
+    assert slots[:fftconv.DCMAX_SLOTS].max().item() == dc.max().item()
+    assert V.abs().max().item() <= slots[:fftconv.DCMAX_SLOTS].max().item()
+    assert lib.eqa_lift5_fft48k5_input_dcmax(x.data_ptr(), bank.data_ptr(), bias.data_ptr(), 0, full.data_ptr(), slots.data_ptr(), nimg, H0, W0, C,
+                                             st) == -3        # EQA_ERR_UNSUPPORTED
+
+
+def test_two_layer_convolution_takes_the_fp16_contraction_behind_the_fused_kernel(dev):
+    """conv5x5 on a LiftedInput with relu, Cin = 64 / 256, Cout = 128 / 256: the fused kernel hands its DC bins to the fp16 form of
+    the contraction ("h3"); the result against F.conv2d in fp64 at the tolerance of the fp32 path, and no further from it than the
+    same chain with the fp32 matrix instruction."""
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    for (nimg, C1, C2, scale_in) in [(9, 64, 128, 1.0), (9, 256, 256, 1.0), (9, 256, 256, 3000.0), (9, 64, 128, 1e-3)]:
+        g = torch.Generator().manual_seed(C1 + C2)
+        x = (torch.randn(nimg, 3, 96, 96, generator=g) * scale_in).to(dev).contiguous(memory_format=torch.channels_last)
+        bank1 = (torch.randn(C1, 3, 5, 5, generator=g) / 75 ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+        b1 = (torch.randn(C1, generator=g) * scale_in).to(dev)
+        w2 = (torch.randn(C2, C1, 5, 5, generator=g) / (5 * C1 ** 0.5)).to(dev)
+        b2 = torch.randn(C2, generator=g).to(dev)
+        B2 = fftconv.spectra_for(w2)
+        want = F.conv2d(torch.relu(F.conv2d(x.double(), bank1.double(), b1.double())), w2.double(), b2.double())
+        lifted = fftconv.LiftedInput(x, bank1, b1, True)
+        got = fftconv.conv5x5(lifted, B2, b2, False)
+        assert fftconv.LAST_FORM == "h3"
+        keep = fftconv.GEMM_PIECES
+        try:
+            fftconv.GEMM_PIECES = "f32"
+            ref = fftconv.conv5x5(lifted, B2, b2, False)
+            assert fftconv.LAST_FORM == "f32"
+        finally:
+            fftconv.GEMM_PIECES = keep
+        s = want.abs().max().item()
+        e_h3, e_f32 = (got.double() - want).abs().max().item(), (ref.double() - want).abs().max().item()
+        print(f"two-layer chain C {C1} -> {C2}, input scale {scale_in:g}: |h3 - fp64| {e_h3 / s:.3e}, |f32 - fp64| {e_f32 / s:.3e} (of max |y|)")
+        assert e_h3 <= 5e-6 * s and e_h3 <= 1.25 * e_f32 + 1e-7 * s, (C1, C2, scale_in, e_h3 / s, e_f32 / s)
