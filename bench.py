@@ -1024,7 +1024,7 @@ def main():
             try:
                 tsrc = next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
                 tj = json.load(open(os.path.join(ROOT, "profiles", tsrc, "traffic_canon_net.json")))
-                key = {"fft_gemm": "fft_cgemm3m_bf16_block_kernel" if default_form in ("6", "9") else "fft_cgemm3m_kernel", "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
+                key = {"fft_gemm": {"h3": "fft_cgemm3m_bf16_block_kernel<3>", "6": "fft_cgemm3m_bf16_block_kernel<6>", "9": "fft_cgemm3m_bf16_block_kernel<9>"}.get(default_form, "fft_cgemm3m_kernel"), "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
                        "lift_conv": "lift_conv_dense_kernel", "lift_fft_input": "lift5_fft48_fused_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
             except (OSError, ValueError, StopIteration):

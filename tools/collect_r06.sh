@@ -24,6 +24,7 @@ for w in $what; do
       python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only.json" 2>/dev/null
       stats bench 16 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline
       EQA_LIFT_FFT_FUSED=0 EQA_FFT_GEMM_PIECES=f32 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_round5_forms.json" 2>/dev/null
+      EQA_FFT_GEMM_PIECES=6 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_six_bf16_products.json" 2>/dev/null
       ;;
     traffic)
       bash tools/collect_traffic.sh "$out/traffic_ga" > "$out/traffic_group_action.log" 2>&1 && cp "$out/traffic_ga/traffic.json" "$out/traffic_group_action.json"
@@ -38,6 +39,10 @@ for w in $what; do
       [ -x tools/micro/_bin/permlane_swap ] && tools/micro/_bin/permlane_swap > "$out/permlane_swap.txt" 2>&1
       python tools/kbench_gemm_error.py > "$out/kbench_gemm_error.txt" 2>&1
       python tools/kbench_gemm_pieces.py > "$out/kbench_gemm_pieces.txt" 2>&1
+      python tools/kbench_invert_c1.py > "$out/kbench_invert_c1.txt" 2>&1
+      python tools/kbench_invert_c1.py --batch 4 >> "$out/kbench_invert_c1.txt" 2>&1
+      [ -x tools/micro/_bin/f16x2_gemm_check ] && tools/micro/_bin/f16x2_gemm_check > "$out/f16x2_gemm_check.txt" 2>&1
+      for v in 1 2; do [ -f build_variants/libeqa_clock$v.so ] && EQA_LIB=$PWD/build_variants/libeqa_clock$v.so python tools/kbench_gemm_clock.py; done > "$out/kbench_gemm_clock.txt" 2>&1
       python tools/host_time_cfg5.py 2>&1 | head -4 > "$out/host_time_cfg5.txt"
       python tools/bench_small_batches.py > "$out/small_batches.txt" 2>&1
       ;;

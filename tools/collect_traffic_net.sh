@@ -30,7 +30,9 @@ alg = {  # algorithmic bytes per launch, fp32
     "fft_cgemm3m_kernel": 2 * 1154 * (B * 4 | 1) * 512 * 4 + 1154 * 256 * 256 * 3 * 4,
     # round 6: the six-product piece form (default at the headline shape): V in + the pre-split filter spectra (3 bf16 pieces per value
     # = 1.5 x the fp32 bytes) + Mo out
-    "fft_cgemm3m_bf16_block_kernel": 2 * 1154 * (B * 4 | 1) * 512 * 4 + 1154 * 256 * 256 * 3 * 3 * 2,
+    "fft_cgemm3m_bf16_block_kernel<6>": 2 * 1154 * (B * 4 | 1) * 512 * 4 + 1154 * 256 * 256 * 3 * 3 * 2,
+    # the fp16 form (the step's default since the second half of round 6): V in + the filter spectra as two fp16 pieces per value + Mo out
+    "fft_cgemm3m_bf16_block_kernel<3>": 2 * 1154 * (B * 4 | 1) * 512 * 4 + 1154 * 256 * 256 * 3 * 2 * 2,
     # round 6: lifting convolution fused into the forward transform: the 96 x 96 x 3 input in (re-read by the 16 channel groups of a
     # tile out of L2), the spectra out -- the lifted map is never written
     "lift5_fft48_fused_kernel": B * 96 * 96 * 3 * 4 + 1154 * B * 4 * 512 * 4,

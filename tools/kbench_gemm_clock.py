@@ -33,8 +33,13 @@ def main():
     for what in ("random operands", "A = 0"):
         V = fc.spectra_buffer(M, 2 * Cin, dev)
         V.normal_() if what == "random operands" else V.zero_()
-        for terms in (9, 6):
+        vb = torch.ones(1, device=dev) * 8.0
+        for terms in (9, 6, 3):
             def run():
+                if terms == 3:        # the fp16 form: two pieces, three products
+                    bh, b_scale = B.pieces_f16()
+                    _lib.check(lib.eqa_fft48k5_cgemm3m_f16x2(V.data_ptr(), bh.data_ptr(), Mo.data_ptr(), M, Cin, Cout, vb.data_ptr(), 1, b_scale, st), "f16x2")
+                    return
                 _lib.check(lib.eqa_fft48k5_cgemm3m_bf16x3(V.data_ptr(), B.pieces().data_ptr(), Mo.data_ptr(), M, Cin, Cout, terms, st), "bf16x3")
             for _ in range(3):
                 run()
@@ -47,7 +52,7 @@ def main():
             torch.cuda.synchronize()
             raw.eqa_debug_blk_clock(out)
             stages = tiles * S
-            mfma = (27 if terms == 9 else 18) * 4 * 32
+            mfma = {9: 27, 6: 18, 3: 9}[terms] * 4 * 32
             print(f"{what:>16}, {terms} products: {a.elapsed_time(b) / 10:6.3f} ms per launch; block 100: {out[0]} cycles = {out[0] / stages:6.0f} per K-stage "
                   f"(matrix instructions {mfma}: {mfma * stages / out[0]:.2f} of the cycles), {out[0] / (out[1] * 10.0):5.3f} GHz, "
                   f"tile epilogue {out[2] / tiles:5.0f} cycles" + (f", regions per stage {[round(out[3 + i] / stages) for i in range(5)]}" if out[3] else ""))
