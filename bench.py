@@ -1025,7 +1025,8 @@ def main():
                 tsrc = next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "traffic_canon_net.json")))
                 tj = json.load(open(os.path.join(ROOT, "profiles", tsrc, "traffic_canon_net.json")))
                 key = {"fft_gemm": {"h3": "fft_cgemm3m_bf16_block_kernel<3>", "6": "fft_cgemm3m_bf16_block_kernel<6>", "9": "fft_cgemm3m_bf16_block_kernel<9>"}.get(default_form, "fft_cgemm3m_kernel"), "fft_input": "fft48_fwd_fused_kernel", "fft_output_sums": "fft48_inv_pipe_kernel",
-                       "lift_conv": "lift_conv_dense_kernel", "lift_fft_input": "lift5_fft48_fused_kernel"}.get(dom)
+                       "lift_conv": "lift_conv_dense_kernel",
+                       "lift_fft_input": "lift5_fft48_fused_h2_kernel" if _fc.LIFT_FFT_FORM == "h2" else "lift5_fft48_fused_kernel"}.get(dom)
                 tr = tj.get(key, {}).get("traffic_bytes_per_launch") if B == 256 else None
             except (OSError, ValueError, StopIteration):
                 pass
@@ -1125,8 +1126,14 @@ def stage_table(ktimes, B):
         # round 6: the lifting convolution fused into the forward transform (one launch instead of lift_conv + fft_input; the lifted
         # map is never written): bounded by the fp32 matrix pipe (2 x 75 flops per lifted pixel, 1.19 x recomputed on the tile overlap
         # -- the algorithmic count below is WITHOUT the overlap) with the spectrum stores (2.4 GB) hidden behind it
-        "lift_fft_input": ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift5_fft48k5_input: lifting conv (fp32 MFMA 16x16x4) + ReLU + row / column FFT-48 in "
-                           "one persistent kernel, spectra out as whole 128-byte lines (hand-written)"),
+        "lift_fft_input": (("hbm", B * 96 * 96 * 3 * 4 + spectra,
+                            "eqa_absmax_slots + eqa_lift5_fft48k5_input_f16x2: lifting conv on two fp16 pieces per value (three exact products on "
+                            "v_mfma_f32_16x16x32_f16, fp32 accumulate) + ReLU + row / column FFT-48 in one persistent kernel, spectra out as "
+                            "whole 128-byte lines; with the convolution on the matrix cores what is left is the transforms' vector "
+                            "arithmetic over the spectrum stores (hand-written)")
+                           if fftconv.LIFT_FFT_FORM == "h2" else
+                           ("mfma", 2.0 * px_l * 256 * 75, "eqa_lift5_fft48k5_input: lifting conv (fp32 MFMA 16x16x4) + ReLU + row / column FFT-48 in "
+                            "one persistent kernel, spectra out as whole 128-byte lines (hand-written)")),
         "fft_gemm": gemm_spec,
         "fft_output_sums": ("hbm", spectra, "eqa_fft48k5_output_sums: column + row inverse passes + window sums + finalize (hand-written)"),
     })

@@ -124,6 +124,9 @@ SIGNATURES = {
     "eqa_lift5_fft48k5_input_supported": (_int, [_int] * 4),
     "eqa_lift5_fft48k5_input": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_lift5_fft48k5_input_dcmax": (_int, [_vp, _vp, _vp, _int, _vp, _vp] + [_int] * 4 + [_vp]),
+    "eqa_lift5_pieces_f16_bytes": (ctypes.c_int64, [_int]),
+    "eqa_absmax_slots": (_int, [_vp, ctypes.c_int64, _vp, _vp]),
+    "eqa_lift5_fft48k5_input_f16x2": (_int, [_vp, _vp, ctypes.c_float, _vp, _int, _vp, _int, _vp, _vp] + [_int] * 4 + [_vp]),
     "eqa_lift5_pieces_bytes": (ctypes.c_int64, [_int]),
     "eqa_lift5_fft48k5_input_bf16x3": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),
     "eqa_fft48k5_output": (_int, [_vp, _vp, _vp, _int, _vp] + [_int] * 4 + [_vp]),

@@ -105,7 +105,7 @@ __device__ __forceinline__ LfItem lf_item(unsigned work, int ngrp, int TY, int T
 //   kConv  waves 6..11: the convolution, 16 tile rows per sub-phase.  Waves w and w + 4 share a SIMD: 6 | 10 and 7 | 11 take 3 + 2 rows,
 //          8 and 9 (alone on their SIMDs) three each
 //   tail   all twelve waves: the row transforms (four consecutive rows x 16 channels per wave), then the column read (waves 0..5)
-enum { kConv = 0, kCols = 1 };
+enum { kConv = 0, kCols = 1, kRowp = 2 };   // kRowp (FORM 2 only): waves 6, 7, 11 -- staging and row transforms, no convolution
 
 template <class F, int... Is>
 __device__ __forceinline__ void lf_for_const(F&& f, std::integer_sequence<int, Is...>) {
@@ -125,6 +125,26 @@ constexpr int kLpRowB = 53 * 8;                  // bytes per patch row and plan
 constexpr int kLpPlaneB = 8 * kLpRowB;           // 3,392 bytes
 constexpr int kLpPatchB = 3 * kLpPlaneB;         // 10,176 bytes
 constexpr int kLpLdsBytes = kLfTileFloats * 4 + kLpPatchB;   // 160,704 bytes
+// FORM 2 (round 6, third form): the convolution on TWO fp16 pieces per fp32 value, three exact products (h1 k1 + h1 k2 + h2 k1 on
+// v_mfma_f32_16x16x32_f16, fp32 accumulate: the contract of eqa_fft48k5_cgemm3m_f16x2 -- within half an fp32 ulp per operand; pixels
+// scaled by the power of two that takes a caller-supplied bound of |x| to 2^14, weights when they are split, the accumulators scaled
+// back in the epilogue).  Two planes of 8 bytes per pixel are the fp32 patch's bytes + a third, so a sub-phase is TWELVE tile rows (a
+// ring of 16 patch rows; four sub-phases per item, where the three bf16 planes allowed four rows and needed twelve), and twelve
+// matrix instructions of 16 cycles per 16-pixel tile replace 19 of 32 on a datapath the transforms do not share: the convolution
+// waves are done in a third of a sub-phase, so THEY stage the patches (the column waves' loads queued behind their own stores:
+// 8.6 k cycles per item) and transform the previous sub-phase's rows; only twelve rows are left for the tail.
+//   K layout: a chunk = the pixel pair (j - 1 + 2 p, j + 2 p) of output pixel j, i.e. kx = 2 p - 1 (p = 0: weight 0), 2 p; the
+//   pair of p = 0, j = 0 starts 8 bytes in front of the row: the previous ring row's last pixel, and in front of the patch the tile
+//   buffer's last (never written, zeroed once) pad floats -- which is how the patch fits the CU's LDS to the byte.
+constexpr int kLhRowB = 52 * 8;                  // bytes per patch row and plane
+constexpr int kLhRing = 16;                      // ring rows (12 tile rows + 4)
+constexpr int kLhPlaneB = kLhRing * kLhRowB;     // 6,656 bytes
+constexpr int kLhPatchB = 2 * kLhPlaneB;         // 13,312 bytes
+constexpr int kLhLdsBytes = kLfTileFloats * 4 + kLhPatchB;   // 163,840 bytes: all of the CU's LDS
+constexpr int kLhSubRows = 12;
+constexpr int kLhPre = 3;                        // pixels per staging thread and unit (16 rows x 52 pixels over 384 threads)
+typedef _Float16 lf_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 lf_f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 lf_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 lf_bf16x4 __attribute__((ext_vector_type(4)));
 // x = p1 + p2 + p3 exactly (round to nearest each time: the remainder of an 8-bit piece fits the next)
@@ -135,15 +155,17 @@ __device__ __forceinline__ void lf_split3(float x, __bf16& p1, __bf16& p2, __bf1
   p3 = (__bf16)(r1 - (float)p2);
 }
 
-template <int ROLE, bool PIECES>
+template <int ROLE, int FORM>
 __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, const float* __restrict__ bank, const float* __restrict__ bias,
                                                  int relu, float* __restrict__ V, int H0, int W0, int C, int TY, int TX, size_t Mp,
                                                  unsigned nwork, unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
-                                                 float* __restrict__ dcmax) {
-  constexpr bool COLS = ROLE != kConv;
-  constexpr int NSUB = PIECES ? 12 : 3;              // sub-phases per item
-  constexpr int SUBROWS = kFftN / NSUB;              // tile rows per sub-phase (4 | 16)
-  constexpr int NGRP = 12 / NSUB;                    // frequency groups a column wave stores per sub-phase (1 | 4)
+                                                 float* __restrict__ dcmax, const float* __restrict__ xbound, int nxbound, float w_scale) {
+  constexpr bool COLS = ROLE == kCols;
+  constexpr bool PIECES = FORM == 3;                 // three bf16 pieces, six products
+  constexpr bool H2 = FORM == 2;                     // two fp16 pieces, three products
+  constexpr int NSUB = PIECES ? 12 : (H2 ? 4 : 3);   // sub-phases per item
+  constexpr int SUBROWS = kFftN / NSUB;              // tile rows per sub-phase (4 | 12 | 16)
+  constexpr int NGRP = 12 / NSUB;                    // frequency groups a column wave stores per sub-phase (1 | 3 | 4)
   extern __shared__ float lds[];
   float* const tile = lds;
   float* const patch = lds + kLfTileFloats;
@@ -214,6 +236,72 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         for (int pl = 0; pl < 3; ++pl) {
           const lf_bf16x4 v = {pc[pl][0], pc[pl][1], pc[pl][2], (__bf16)0.0f};
           *reinterpret_cast<lf_bf16x4*>(dst + pl * kLpPlaneB) = v;
+        }
+      }
+    }
+  };
+
+  // FORM 2: a staging unit = patch rows [row0, row0 + nrows) of an item (16 rows in front of its first sub-phase, 12 afterwards), by
+  // the 384 threads of the CONVOLUTION waves: thread t owns pixels t, t + 384, t + 768 of the unit -- three dword loads each a
+  // sub-phase ahead; behind the sub-phase's second barrier the scaled values are split and written, 8 bytes per plane.
+  float preh[(!COLS && H2) ? kLhPre : 1][3];
+  float x_scale = 1.0f, out_scale = 1.0f;
+  if constexpr (H2) {
+    float mx = 0.0f;
+    for (int t = lane; t < nxbound; t += 64) mx = fmaxf(mx, xbound[t]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int ex = 0;
+    if (mx > 0.0f && mx < 3.0e38f) (void)frexpf(mx, &ex);      // mx <= 2^ex
+    ex = __builtin_amdgcn_readfirstlane(min(max(14 - ex, -100), 100));
+    x_scale = ldexpf(1.0f, ex);
+    out_scale = ldexpf(1.0f, -ex) / w_scale;
+  }
+  int h_pr[(!COLS && H2) ? kLhPre : 1], h_px[(!COLS && H2) ? kLhPre : 1];     // the staging thread's three pixels of a unit
+  if constexpr (!COLS && H2) {
+#pragma unroll
+    for (int i = 0; i < kLhPre; ++i) {
+      const int idx = tid - 6 * 64 + kLfStagers * i;
+      h_pr[i] = idx / 52;
+      h_px[i] = idx - h_pr[i] * 52;
+    }
+  }
+  auto prefetch_h = [&](const LfItem& it, int row0, int nrows, bool live) {
+    if constexpr (!COLS && H2) {
+#ifdef EQA_LF_H2_NOPREFETCH    // ablation: no patch loads (the ring keeps the first item's rows)
+      if (row0 >= 0) return;
+#endif
+#pragma unroll
+      for (int i = 0; i < kLhPre; ++i) {
+        const int pr = h_pr[i], px = h_px[i];
+        const int gy = it.gy0 + row0 + pr, gx = it.gx0 + px;
+        const bool ok = live && pr < nrows && gy < H0 && gx < W0;
+        const unsigned off = ok ? (unsigned)((((it.img * H0 + gy) * (size_t)W0 + gx) * 3) * 4) : 0xfffffff0u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) preh[i][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, c * 4, 0));
+      }
+    }
+  };
+  auto stage_h = [&](int row0, int nrows) {
+    if constexpr (!COLS && H2) {
+#pragma unroll
+      for (int i = 0; i < kLhPre; ++i) {
+        // (opaque here: the scaling below is plain register arithmetic, and hoisted above the barrier it put the wait for the loads
+        // -- 2-4 us under this kernel's traffic -- in front of the convolution: 32 k cycles per item)
+        asm volatile("" : "+v"(preh[i][0]), "+v"(preh[i][1]), "+v"(preh[i][2]));
+        if (h_pr[i] < nrows) {
+          const int pr = h_pr[i], px = h_px[i];
+          _Float16 hi[3], lo[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const float v = preh[i][c] * x_scale;
+            hi[c] = (_Float16)v;
+            lo[c] = (_Float16)(v - (float)hi[c]);
+          }
+          char* dst = reinterpret_cast<char*>(lds) + patch_b + ((row0 + pr) & (kLhRing - 1)) * kLhRowB + px * 8;
+          const lf_f16x4 vh = {hi[0], hi[1], hi[2], (_Float16)0.0f}, vl = {lo[0], lo[1], lo[2], (_Float16)0.0f};
+          *reinterpret_cast<lf_f16x4*>(dst) = vh;
+          *reinterpret_cast<lf_f16x4*>(dst + kLhPlaneB) = vl;
         }
       }
     }
@@ -399,10 +487,109 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     }
   };
 
+  // ---- FORM 2 convolution.  K-step s = filter row ky = s (five steps of K = 32); lane (i = lane % 16, q = lane / 16) holds chunk q of a
+  // step: the pixel pair p = q (pixels j - 1 + 2 p, j + 2 p: kx = 2 p - 1, 2 p) for q < 3, a chunk of zero weights for q = 3 (its
+  // lanes read pair 2 again: the same addresses as their neighbours, a broadcast).  So the B fragment of (patch row R, tile column t)
+  // does not depend on ky: a wave works DOWN one tile column, holds a window of five patch rows in registers and reads ONE new row
+  // (two 16-byte fragments) per tile row -- 2 KB of LDS reads per tile where the row-major order with its 4 K-steps per tile read 8
+  // (the first build of this form: 33 k cycles per item in the convolution waves, on LDS bandwidth).  15 matrix instructions per
+  // tile, in three independent chains (one per piece product) summed small terms first.
+  lf_f16x8 wh[H2 ? 5 : 1][H2 ? 2 : 1];
+  int h_off = 0;
+  auto setup_h = [&](const LfItem& it) {
+    if constexpr (H2) {
+      const __amdgpu_buffer_rsrc_t br = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bank), 0, bank_bytes, 0x00020000);
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int wp = 0; wp < 2; ++wp) {
+          // wpieces: (Cout, 2 pieces, 5 filter rows, 4 chunks, 8) fp16
+          const unsigned off = (unsigned)(((((it.grp * kLfCh + j) * 2 + wp) * 5 + ky) * 4 + q) * 16);
+          wh[ky][wp] = __builtin_bit_cast(lf_f16x8, __builtin_amdgcn_raw_buffer_load_b128(br, off, 0, 0));
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bias4[r] = bias ? bias[it.grp * kLfCh + 4 * q + r] : 0.0f;
+      asm volatile("" : "+v"(bias4));
+    }
+  };
+  // tile column t (16 pixels), tile rows y0 .. y0 + NROWS - 1 of the item (patch row R sits in ring slot R % 16)
+  auto conv_col_h = [&](const LfItem& it, int y0, int t, auto NR) {
+    if constexpr (H2) {
+      constexpr int NROWS = decltype(NR)::value;
+#ifdef EQA_LF_H2_NOCONV    // ablation: the convolution waves without their convolution (the tile keeps what it held)
+      return;
+#endif
+      const int base = (int)patch_b + (j - 1 + 2 * min(q, 2)) * 8 + t * 128;
+      lf_f16x8 win[7][2];                     // patch rows y0 + k in slot k % 7: five in use, two arriving (an LDS read comes back
+                                              // after 400-600 cycles while the row transforms and column reads queue beside it)
+      auto read_row = [&](int k) {
+        const int a = base + ((y0 + k) & (kLhRing - 1)) * kLhRowB;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          // two 8-byte reads: the pixel pair sits at an 8-byte boundary (a 16-byte LDS read off a 16-byte boundary: ~200 cycles)
+          typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+          const unsigned long long* pp = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const char*>(lds) + a + pl * kLhPlaneB);
+          const u64x2_t two = {pp[0], pp[1]};
+          win[k % 7][pl] = __builtin_bit_cast(lf_f16x8, two);
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < 6; ++k) read_row(k);
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      const bool col_ok = it.gx0 + t * 16 + j < W1;
+      // accumulators of two rows: a row's epilogue (scale, bias, relu, LDS write) sits BEHIND the next row's matrix instructions in
+      // program order, so that it issues under them -- directly behind its own row it waited out the pipe's latency first, and the
+      // wave issues in order: 39 cycles per matrix instruction instead of 16
+      // accumulators of two rows (three chains each: one per piece product): a row's epilogue runs a row later, in pieces between
+      // the next row's matrix instructions
+      f32x4 a_ll[2], a_hl[2], a_hh[2];          // (w lo, p hi), (w hi, p lo), (w hi, p hi)
+      f32x4 ev = zero;
+      // piece m of the epilogue of row rp: sum small terms first, scale, bias, relu, mask, write
+      auto epi = [&](int m, int rp) {
+        const int y = y0 + rp;
+        if (m == 0) ev = a_ll[rp & 1] + a_hl[rp & 1];
+        else if (m == 1) ev = ev + a_hh[rp & 1];
+        else if (m == 2) ev = ev * out_scale + bias4;
+        else if (m == 3) { ev[0] = relu ? fmaxf(ev[0], 0.0f) : ev[0]; ev[1] = relu ? fmaxf(ev[1], 0.0f) : ev[1]; }
+        else if (m == 4) { ev[2] = relu ? fmaxf(ev[2], 0.0f) : ev[2]; ev[3] = relu ? fmaxf(ev[3], 0.0f) : ev[3]; }
+        else if (m == 5) {
+          const bool ok = col_ok && it.gy0 + y < H1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) ev[k] = ok ? ev[k] : 0.0f;
+        } else if (m == 6) {
+          *reinterpret_cast<f32x4*>(tile + y * kLfRowPitch + q * kLfQuadPitch + (t * 16 + j) * 4) = ev;
+        }
+      };
+      // The wave issues in order and the pipe takes a matrix instruction every 16 cycles, 4 of which are the issue: what stands
+      // BETWEEN two matrix instructions is free (three vector instructions' worth), what stands behind a block of them is not.  So
+      // every instruction of a row is followed by one piece of the PREVIOUS row's epilogue (or the reads of the row two ahead),
+      // pinned by scheduling barriers.
+#pragma unroll
+      for (int r = 0; r < NROWS; ++r) {
+#pragma unroll
+        for (int m = 0; m < 15; ++m) {
+          const int ky = m / 3, ch = m % 3;
+          __builtin_amdgcn_sched_barrier(0);
+          if (ch == 0) a_ll[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][1], win[(r + ky) % 7][0], ky == 0 ? zero : a_ll[r & 1], 0, 0, 0);
+          else if (ch == 1) a_hl[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][0], win[(r + ky) % 7][1], ky == 0 ? zero : a_hl[r & 1], 0, 0, 0);
+          else a_hh[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][0], win[(r + ky) % 7][0], ky == 0 ? zero : a_hh[r & 1], 0, 0, 0);
+          if (r > 0 && m >= 3 && m < 10) epi(m - 3, r - 1);       // (behind the first filter row: the previous row's last results have left the pipe)
+          if (m == 11 && r + 2 < NROWS) read_row(r + 6);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 7; ++m) epi(m, NROWS - 1);
+    }
+  };
+
   // ---- row pass of four consecutive tile rows y0 .. y0 + 3: thread (r = lane / 16, c = lane % 16), 48 reals -> 23 complex + 2 real
   // bins IN PLACE (slot kx: Re[kx], kx = 0..23; slot 24: Re[24]; slot 24 + kx: Im[kx]).  Row pitch 784 = 16 (mod 32): the rows of
   // a 32-lane group sit 16 banks apart.
   auto row_pass = [&](int y0) {
+#ifdef EQA_LF_H2_NOROWP     // ablation: no row transforms (wrong spectra)
+    if (H2) return;
+#endif
     float* const rowp = tile + (y0 + (lane >> 4)) * kLfRowPitch + ((lane & 15) >> 2) * kLfQuadPitch + (lane & 3);
     float re[kFftN], ore[kFftH], oim[kFftH];
 #pragma unroll
@@ -469,6 +656,9 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   auto col_work = [&](auto SUB) {
     constexpr int sub = decltype(SUB)::value;
     if (!pending) return;
+#ifdef EQA_LF_H2_NOCOLS     // ablation: no column transforms / stores
+    if (H2) return;
+#endif
     const size_t rowb = Mp * 2 * (size_t)C * 4;                         // bytes per stored frequency
     const unsigned col = (unsigned)(((size_t)pend_m * 2 * C + pend_grp * 2 * kLfCh) * 4) + (unsigned)((odd ? 64 : 0) + 16 * col_cq);
     if (sub == 0) {
@@ -532,6 +722,12 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     prefetch_grp(f, 1, 1, v < nwork);
     stage_grp(0, 0);
     stage_grp(1, 1);
+  } else if constexpr (H2) {
+    // the tile buffer's last pad floats: the 8 bytes in front of the patch that the pair (pixel -1, pixel 0) of ring row 0 reads
+    if (tid == 0) *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(lds) + patch_b - 8) = 0ull;
+    prefetch_h(lf_item(v < nwork ? v : 0, ngrp, TY, TX), 0, kLhRing, v < nwork);
+    stage_h(0, kLhRing);
+    __syncthreads();
   } else {
     // the first item's first patch: staged here; afterwards an item's first patch is staged in the TAIL of the item before it, so
     // that the convolution of sub-phase 0 starts as soon as the column waves have read tile rows 0..15 (see the tail)
@@ -546,18 +742,33 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     const unsigned vn = v + nblk;
     const bool next_live = live && vn < nwork;
     const LfItem nx = lf_item(next_live ? vn : 0, ngrp, TY, TX);
-    if constexpr (ROLE == kConv) {
+    if constexpr (!COLS) {
 #pragma unroll 1
       for (int sub = 0; sub < NSUB; ++sub) {
         if (PIECES || sub > 0) __syncthreads();
         LF_CLOCK(0);
+        if constexpr (H2) {
+          // requested now, staged behind this sub-phase's second barrier: the next sub-phase's twelve new rows, or the next item's first 16
+          if (sub < NSUB - 1) prefetch_h(it, kLhSubRows * sub + kLhRing, kLhSubRows, live);
+          else prefetch_h(nx, 0, kLhRing, next_live);
+          LF_CLOCK(1);
+        }
         if (live) {
           if (sub == 0 && it.grp != cur_grp) {     // (one block per CU and a group count that divides the grid: a block stays on its group)
             if constexpr (PIECES) setup_p(it);
+            else if constexpr (H2) { if constexpr (ROLE == kConv) setup_h(it); }
             else setup(it);
             cur_grp = it.grp;
           }
-          if constexpr (PIECES) {
+          if constexpr (H2) {
+            // waves 8, 9, 10: a tile column each of the sub-phase's twelve rows; waves 6, 7, 11: the row transform of four of the PREVIOUS
+            // sub-phase's rows each (the tail keeps rows 36..47)
+            if constexpr (ROLE == kConv) {
+              conv_col_h(it, kLhSubRows * sub, wave - 8, std::integral_constant<int, kLhSubRows>());
+            } else {
+              if (sub > 0) row_pass(kLhSubRows * (sub - 1) + 4 * (wave == 11 ? 2 : wave - 6));
+            }
+          } else if constexpr (PIECES) {
             // the sub-phase's 12 tiles, three per SIMD: waves 8, 9 (alone on theirs) a row each, 6 | 10 and 7 | 11 share a row 2 + 1
             const int y = SUBROWS * sub + (wave == 8 ? 0 : (wave == 9 ? 1 : ((wave == 6 || wave == 10) ? 2 : 3)));
             const int tx0 = (wave == 10 || wave == 11) ? 2 : 0;
@@ -575,16 +786,22 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         LF_CLOCK(2);
         __syncthreads();
         LF_CLOCK(3);
+        if constexpr (H2) {
+          if (sub < NSUB - 1) stage_h(kLhSubRows * sub + kLhRing, kLhSubRows);
+          else stage_h(0, kLhRing);
+        }
       }
     } else {
       auto subphase = [&](auto SUB) {
         constexpr int sub = decltype(SUB)::value;
-        if constexpr (!PIECES) {
+        if constexpr (FORM == 0) {
           if (sub > 0) stage();
         }
         if (PIECES || sub > 0) __syncthreads();
         LF_CLOCK(0);
-        if constexpr (PIECES) {
+        if constexpr (H2) {
+          // (the convolution / row waves stage: the column waves' loads queue behind their own stores)
+        } else if constexpr (PIECES) {
           // what is staged behind this sub-phase's second barrier: group sub + 2 of this item, or the first two groups of the next
           if (sub < NSUB - 1) {
             prefetch_grp(it, sub + 2, 0, live);
@@ -611,11 +828,15 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
         }
       };
       lf_for_const(subphase, std::make_integer_sequence<int, NSUB>());
-      if constexpr (!PIECES) stage();      // the NEXT item's first patch (fetched during the last sub-phase); the patch buffer is free
+      if constexpr (FORM == 0) stage();    // the NEXT item's first patch (fetched during the last sub-phase); the patch buffer is free
     }
     // ---- the tail: every wave transforms four rows, then the column waves read their columns
     if constexpr (PIECES) {
       if (live) row_pass(4 * wave);
+    } else if constexpr (H2) {
+      if constexpr (ROLE == kRowp) {
+        if (live) row_pass(36 + 4 * (wave == 11 ? 2 : wave - 6));      // rows 36..47
+      }
     } else {
       if (live && wave < 8) row_pass(16 + 4 * wave);      // rows 16..47 (rows 0..15: waves 8, 9 during sub-phases 1, 2)
     }
@@ -624,7 +845,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
     LF_CLOCK(5);
     // fp32 form: the barrier that releases the tile buffer sits behind the column waves' read of tile rows 0..15 -- all the next
     // item's first sub-phase overwrites --, and they read rows 16..47 while its convolution has already started
-    constexpr int kEarly = PIECES ? kFftN : kLfSubRows;
+    constexpr int kEarly = PIECES ? kFftN : (H2 ? kLhSubRows : kLfSubRows);
     if constexpr (COLS) {
       if (live) {
 #pragma unroll
@@ -672,8 +893,8 @@ __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_kernel(const flo
                                                                         int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
                                                                         unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
                                                                         float* __restrict__ dcmax) {
-  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
-  else lift5_fft48_body<kConv, false>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, 0>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, nullptr, 0, 1.0f);
+  else lift5_fft48_body<kConv, 0>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, nullptr, 0, 1.0f);
 }
 
 // the same with the convolution on the bf16 matrix cores; `bank` = the weights' pieces (Cout, 3, 16, 8) bf16
@@ -682,8 +903,38 @@ __global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_pieces_kernel(co
                                                                                int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
                                                                                unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
                                                                                float* __restrict__ dcmax) {
-  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
-  else lift5_fft48_body<kConv, true>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax);
+  if (threadIdx.x < 6 * 64) lift5_fft48_body<kCols, 3>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, nullptr, 0, 1.0f);
+  else lift5_fft48_body<kConv, 3>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, nullptr, 0, 1.0f);
+}
+
+// the same with the convolution on two fp16 pieces (FORM 2); `bank` = the weights' pieces (Cout, 2, 16, 8) fp16 of w_scale * w
+__global__ __launch_bounds__(kLfThreads) void lift5_fft48_fused_h2_kernel(const float* __restrict__ x, const float* __restrict__ bank,
+                                                                           const float* __restrict__ bias, int relu, float* __restrict__ V,
+                                                                           int H0, int W0, int C, int TY, int TX, size_t Mp, unsigned nwork,
+                                                                           unsigned v_bytes, unsigned x_bytes, unsigned bank_bytes,
+                                                                           float* __restrict__ dcmax, const float* __restrict__ xbound,
+                                                                           int nxbound, float w_scale) {
+  const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (w < 6) lift5_fft48_body<kCols, 2>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, xbound, nxbound, w_scale);
+  else if (w >= 8 && w <= 10) lift5_fft48_body<kConv, 2>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, xbound, nxbound, w_scale);
+  else lift5_fft48_body<kRowp, 2>(x, bank, bias, relu, V, H0, W0, C, TY, TX, Mp, nwork, v_bytes, x_bytes, bank_bytes, dcmax, xbound, nxbound, w_scale);
+}
+
+// |x| maxima in EQA_LIFT5_DCMAX_SLOTS slots (one per block; the consumer takes the largest): the bound FORM 2 scales its pixels by
+__global__ __launch_bounds__(256) void absmax_slots_kernel(const float* __restrict__ x, size_t n, float* __restrict__ out) {
+  float m = 0.0f;
+  const size_t n4 = n / 4;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 }  // namespace
@@ -699,7 +950,8 @@ int eqa_lift5_fft48k5_input_supported(int Cin, int KH, int KW, int Cout) {
 }
 
 static int lift_fft_launch(const float* x, const void* bank, size_t bank_bytes, const float* bias, int relu, float* V, int nimg, int H0, int W0,
-                           int Cout, void* stream, bool pieces, float* dcmax = nullptr) {
+                           int Cout, void* stream, bool pieces, float* dcmax = nullptr, const float* xbound = nullptr, int nxbound = 0,
+                           float w_scale = 0.0f) {
   if (!x || !bank || !V || nimg < 0 || H0 < 5 || W0 < 5 || Cout <= 0) return EQA_ERR_INVALID_ARG;
   if (Cout % kLfCh != 0) return EQA_ERR_UNSUPPORTED;
   if (nimg == 0) return EQA_OK;
@@ -711,15 +963,20 @@ static int lift_fft_launch(const float* x, const void* bank, size_t bank_bytes, 
   const size_t vb = (size_t)kFftF * fft_pitch(M) * 2 * Cout * 4;
   const size_t xb = (size_t)nimg * H0 * W0 * 3 * 4;
   if (nwork > 0x7fffffffULL || vb > 0xffffff00ULL || xb > 0xffffff00ULL || bank_bytes > 0xffffff00ULL) return EQA_ERR_UNSUPPORTED;
-  const void* kern = pieces ? (const void*)lift5_fft48_fused_pieces_kernel : (const void*)lift5_fft48_fused_kernel;
-  const int lds_bytes = pieces ? kLpLdsBytes : kLfLdsFloats * 4;
+  const bool h2 = xbound != nullptr;
+  const void* kern = h2 ? (const void*)lift5_fft48_fused_h2_kernel : pieces ? (const void*)lift5_fft48_fused_pieces_kernel : (const void*)lift5_fft48_fused_kernel;
+  const int lds_bytes = h2 ? kLhLdsBytes : pieces ? kLpLdsBytes : kLfLdsFloats * 4;
   if (!allow_dynamic_lds(kern, lds_bytes)) return EQA_ERR_UNSUPPORTED;
   // persistent: one block per CU; a multiple of the group count keeps a block on ONE channel group (its weights stay in registers)
   const unsigned ngrp = (unsigned)(Cout / kLfCh);
   unsigned nblk = 256;
   if (ngrp <= 256) nblk = (256 / ngrp) * ngrp;
   if ((size_t)nblk > nwork) nblk = (unsigned)nwork;
-  if (pieces)
+  if (h2)
+    hipLaunchKernelGGL(lift5_fft48_fused_h2_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
+                       relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes, dcmax,
+                       xbound, nxbound, w_scale);
+  else if (pieces)
     hipLaunchKernelGGL(lift5_fft48_fused_pieces_kernel, dim3(nblk), dim3(kLfThreads), lds_bytes, (hipStream_t)stream, x, (const float*)bank, bias,
                        relu, V, H0, W0, Cout, TY, TX, fft_pitch(M), (unsigned)nwork, (unsigned)vb, (unsigned)xb, (unsigned)bank_bytes, dcmax);
   else
@@ -739,6 +996,26 @@ int eqa_lift5_fft48k5_input_dcmax(const float* x, const float* bank, const float
   if (!relu) return EQA_ERR_UNSUPPORTED;            // the DC bins bound the spectrum of NON-NEGATIVE activations only
   if (nimg == 0) return hipMemsetAsync(dcmax, 0, EQA_LIFT5_DCMAX_SLOTS * sizeof(float), (hipStream_t)stream) == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
   return lift_fft_launch(x, bank, (size_t)(Cout > 0 ? Cout : 0) * 75 * 4, bias, relu, V, nimg, H0, W0, Cout, stream, false, dcmax);
+}
+
+int64_t eqa_lift5_pieces_f16_bytes(int Cout) { return Cout > 0 ? (int64_t)Cout * 2 * 5 * 4 * 8 * 2 : 0; }
+
+int eqa_absmax_slots(const float* x, int64_t n, float* slots, void* stream) {
+  if (n < 0 || !slots || (n > 0 && !x)) return EQA_ERR_INVALID_ARG;
+  if (((uintptr_t)x & 15) != 0) return EQA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(absmax_slots_kernel, dim3(EQA_LIFT5_DCMAX_SLOTS), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, slots);
+  return launch_status();
+}
+
+int eqa_lift5_fft48k5_input_f16x2(const float* x, const void* wpieces, float w_scale, const float* xbound, int nxbound, const float* bias,
+                                  int relu, float* V, float* dcmax, int nimg, int H0, int W0, int Cout, void* stream) {
+  if (!xbound || nxbound <= 0 || !(w_scale > 0.0f)) return EQA_ERR_INVALID_ARG;
+  int ex = 0;
+  if (frexpf(w_scale, &ex) != 0.5f) return EQA_ERR_INVALID_ARG;            // a power of two: the scaling must be exact
+  if (dcmax && !relu) return EQA_ERR_UNSUPPORTED;                           // the DC bins bound the spectrum of NON-NEGATIVE activations only
+  if (nimg == 0 && dcmax) return hipMemsetAsync(dcmax, 0, EQA_LIFT5_DCMAX_SLOTS * sizeof(float), (hipStream_t)stream) == hipSuccess ? EQA_OK : EQA_ERR_LAUNCH;
+  return lift_fft_launch(x, wpieces, (size_t)eqa_lift5_pieces_f16_bytes(Cout), bias, relu, V, nimg, H0, W0, Cout, stream, false, dcmax, xbound,
+                         nxbound, w_scale);
 }
 
 int64_t eqa_lift5_pieces_bytes(int Cout) { return Cout > 0 ? (int64_t)Cout * 3 * 16 * 8 * 2 : 0; }

@@ -571,7 +571,14 @@ class ESCNNEquivariantNetwork(nn.Module):
                             hit = (key, fftconv.LiftedInput(h, bank, bias, True).pieces())
                             self._fold_cache[("liftp", id(conv))] = hit
                         pieces = hit[1]
-                    h = fftconv.LiftedInput(h, bank, bias, True, pieces)
+                    hit = None
+                    if fftconv.LIFT_FFT_FORM == "h2":         # the fp16 form's operand (and its scale: one host synchronisation per weight version)
+                        hit = self._fold_cache.get(("lifth", id(conv)))
+                        if hit is not None and hit[0] != self._fold_cache[id(conv)][0]:
+                            hit = None
+                    h = fftconv.LiftedInput(h, bank, bias, True, pieces, hit[1] if hit is not None else None)
+                    if fftconv.LIFT_FFT_FORM == "h2" and hit is None:
+                        self._fold_cache[("lifth", id(conv))] = (self._fold_cache[id(conv)][0], h.pieces_f16())
                     continue
                 if (nxt is not None and not nxt.lifting and nxt.kernel_size == 5 and nxt.stride == 1 and nxt.padding == 0
                         and fftconv.grouped_applicable(out_shape, bank.shape[0], bank.shape[0], h.device)):

@@ -189,7 +189,8 @@ class LiftedInput:
     place of that map and produces the map's tile spectra straight from x (eqa_lift5_fft48k5_input: the lifting convolution fused
     into the forward FFT-48 transform -- the 2.2 GB map of the headline shape is neither written nor read)."""
 
-    def __init__(self, x: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, pieces: Optional[torch.Tensor] = None):
+    def __init__(self, x: torch.Tensor, bank: torch.Tensor, bias: Optional[torch.Tensor], relu: bool, pieces: Optional[torch.Tensor] = None,
+                 pieces_f16=None):
         assert x.dim() == 4 and x.shape[1] == 3 and bank.shape[1:] == (3, 5, 5)
         self.x = x.contiguous(memory_format=torch.channels_last)
         self.bank = bank.contiguous(memory_format=torch.channels_last)           # memory order (C, 5, 5, 3)
@@ -197,6 +198,26 @@ class LiftedInput:
         self.shape = torch.Size((x.shape[0], bank.shape[0], x.shape[2] - 4, x.shape[3] - 4))
         self.device, self.dtype, self.is_cuda = x.device, x.dtype, x.is_cuda
         self._pieces = pieces
+        self._pieces_f16 = pieces_f16
+
+    def pieces_f16(self):
+        """(wh, w_scale): the folded bank as the operand of eqa_lift5_fft48k5_input_f16x2 -- (C, 2 pieces, 5 filter rows, 4 chunks, 8)
+        fp16 of w_scale * w (w_scale: the power of two that takes max |w| to at most 2^14); chunk p < 3 of filter row ky =
+        [w(ci 0..2, kx = 2 p - 1), 0, w(ci 0..2, kx = 2 p), 0] (kx = -1: 0), chunk 3 = 0; pieces h1 = rn16(v), h2 = rn16(v - h1).
+        Built once per LiftedInput (one host synchronisation); the network caches it per weight version."""
+        if self._pieces_f16 is None:
+            w = self.bank.float()                                   # (C, 3, 5, 5) logical
+            C = w.shape[0]
+            mx = float(w.abs().max().item())
+            ex = 14 - math.frexp(mx)[1] if 0.0 < mx < float("inf") else 0
+            scale = math.ldexp(1.0, max(-100, min(100, ex)))
+            wp = torch.zeros(C, 5, 8, 4, dtype=torch.float32, device=w.device)       # (co, ky, kx + 1 in 0..7, ci padded to 4)
+            wp[:, :, 1:6, :3] = w.permute(0, 2, 3, 1) * scale
+            chunks = wp.reshape(C, 5, 4, 8)
+            h1 = chunks.half()
+            h2 = (chunks - h1.float()).half()
+            self._pieces_f16 = (torch.stack([h1, h2], dim=1).contiguous(), scale)
+        return self._pieces_f16
 
     def pieces(self) -> torch.Tensor:
         """The folded bank as the operand of eqa_lift5_fft48k5_input_bf16x3: (C, 3 pieces, 16 chunks, 8) bf16 -- chunk c < 15 = (filter
@@ -223,8 +244,11 @@ class LiftedInput:
         return y
 
 
-# how the fused kernel multiplies: "f32" = v_mfma_f32_16x16x4_f32, "bf16x3" = exact three-piece splits, six products on the bf16 matrix cores
-LIFT_FFT_FORM = os.environ.get("EQA_LIFT_FFT_FORM", "f32")
+# how the fused kernel multiplies: "h2" (default since the end of round 6) = two fp16 pieces per value, three exact products on the fp16
+# matrix cores (eqa_lift5_fft48k5_input_f16x2; pixels scaled under the bound eqa_absmax_slots takes, one 10 us launch; as close to
+# fp64 as the fp32 form: tests/test_gpu_lift_fft.py), "f32" = v_mfma_f32_16x16x4_f32 (which shares the vector ALU's datapath with the
+# transforms), "bf16x3" = exact three-piece splits, six products on the bf16 matrix cores (opt-in: no faster than f32)
+LIFT_FFT_FORM = os.environ.get("EQA_LIFT_FFT_FORM", "h2")
 LIFT_FFT_FUSED_DEFAULT = "1"     # EQA_LIFT_FFT_FUSED=0: the two kernels (eqa_lift_conv_grouped, eqa_fft48k5_input_grouped)
 
 
@@ -358,7 +382,17 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
             assert in_bias is None and not in_relu
             with _timed("lift_fft_input"):
                 p_b = x.bias.data_ptr() if x.bias is not None else None
-                if LIFT_FFT_FORM == "bf16x3":
+                if LIFT_FFT_FORM == "h2":
+                    wh, w_scale = x.pieces_f16()
+                    xbound = torch.empty(DCMAX_SLOTS, dtype=torch.float32, device=dev)
+                    _lib.check(lib.eqa_absmax_slots(x.x.data_ptr(), x.x.numel(), xbound.data_ptr(), st), "eqa_absmax_slots")
+                    want_dc = x.relu and isinstance(B, Spectra3M) and gemm_form(Cin, Cout, True) == "h3"
+                    if want_dc:
+                        vbound = torch.empty(DCMAX_SLOTS, dtype=torch.float32, device=dev)
+                    _lib.check(lib.eqa_lift5_fft48k5_input_f16x2(x.x.data_ptr(), wh.data_ptr(), w_scale, xbound.data_ptr(), DCMAX_SLOTS, p_b,
+                                                                 int(x.relu), V.data_ptr(), vbound.data_ptr() if want_dc else None, nimg,
+                                                                 H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input_f16x2")
+                elif LIFT_FFT_FORM == "bf16x3":
                     _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.x.data_ptr(), x.pieces().data_ptr(), p_b, int(x.relu), V.data_ptr(), nimg,
                                                                   H + 4, W + 4, Cin, st), "eqa_lift5_fft48k5_input_bf16x3")
                 elif x.relu and isinstance(B, Spectra3M) and gemm_form(Cin, Cout, True) == "h3":

@@ -584,6 +584,19 @@ int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias
 #define EQA_LIFT5_DCMAX_SLOTS 256
 int eqa_lift5_fft48k5_input_dcmax(const float* x, const float* bank, const float* bias, int relu, float* V, float* dcmax, int nimg, int H0,
                                   int W0, int Cout, void* stream);
+/* The same kernel with its convolution on TWO fp16 pieces per fp32 value, three exact products on v_mfma_f32_16x16x32_f16 (the contract of
+ * eqa_fft48k5_cgemm3m_f16x2: every operand within half an fp32 ulp, fp32 accumulation): fifteen matrix instructions of 16 cycles per
+ * 16-pixel tile instead of 19 of 32 on the vector ALU's datapath, and a quarter of the LDS operand reads.
+ *   wpieces  (Cout, 2 pieces, 5 filter rows, 4 chunks, 8) fp16 of w_scale * bank, eqa_lift5_pieces_f16_bytes(Cout) bytes: chunk p < 3 of
+ *            filter row ky = [w(ci 0..2, kx = 2p - 1), 0, w(ci 0..2, kx = 2p), 0] (kx = -1: 0), chunk 3 = 0; w_scale a power of two with
+ *            max |bank| w_scale <= 2^14.
+ *   xbound   nxbound device floats whose maximum bounds |x| (eqa_absmax_slots writes EQA_LIFT5_DCMAX_SLOTS of them; read by the kernel,
+ *            no host synchronisation); the pixels are scaled by the power of two that takes it to 2^14.
+ *   dcmax    null, or as in eqa_lift5_fft48k5_input_dcmax (relu != 0 required then). */
+int64_t eqa_lift5_pieces_f16_bytes(int Cout);
+int eqa_absmax_slots(const float* x, int64_t n, float* slots, void* stream);
+int eqa_lift5_fft48k5_input_f16x2(const float* x, const void* wpieces, float w_scale, const float* xbound, int nxbound, const float* bias,
+                                  int relu, float* V, float* dcmax, int nimg, int H0, int W0, int Cout, void* stream);
 /* The same with the convolution on the bf16 matrix cores: every fp32 pixel and weight split exactly into three bf16 pieces, six piece
  * products per product, fp32 accumulation (the contract of eqa_fft48k5_cgemm3m_bf16x3; the fp32 matrix instruction of the form above
  * runs on the vector ALU's datapath and holds the transforms' vector work back).  wpieces: the weights' pieces, (Cout, 3 pieces, 16

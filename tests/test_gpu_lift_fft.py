@@ -153,6 +153,13 @@ def test_network_inference_takes_the_fused_route(dev, monkeypatch):
     assert len(calls) == 1
     assert (fused - unfused).abs().max().item() <= 2e-6 * unfused.abs().max().item()
     assert torch.equal(fused.argmax(1), unfused.argmax(1))
+    # the default form of the fused kernel is the fp16 one, its operand cached per weight version; the fp32 form gives the same activations
+    assert fftconv.LIFT_FFT_FORM == "h2" and ("lifth", id(net.eqv_network[0])) in net._fold_cache
+    monkeypatch.setenv("EQA_LIFT_FFT_FUSED", "1")
+    monkeypatch.setattr(fftconv, "LIFT_FFT_FORM", "f32")
+    with torch.no_grad():
+        f32_form = net(x)
+    assert (f32_form - unfused).abs().max().item() <= 2e-6 * unfused.abs().max().item() and torch.equal(f32_form.argmax(1), unfused.argmax(1))
     # the opt-in form with the convolution on the bf16 matrix cores (exact three-piece splits): same activations, pieces cached per weights
     monkeypatch.setenv("EQA_LIFT_FFT_FUSED", "1")
     monkeypatch.setattr(fftconv, "LIFT_FFT_FORM", "bf16x3")
@@ -225,3 +232,52 @@ def test_two_layer_convolution_takes_the_fp16_contraction_behind_the_fused_kerne
         e_h3, e_f32 = (got.double() - want).abs().max().item(), (ref.double() - want).abs().max().item()
         print(f"two-layer chain C {C1} -> {C2}, input scale {scale_in:g}: |h3 - fp64| {e_h3 / s:.3e}, |f32 - fp64| {e_f32 / s:.3e} (of max |y|)")
         assert e_h3 <= 5e-6 * s and e_h3 <= 1.25 * e_f32 + 1e-7 * s, (C1, C2, scale_in, e_h3 / s, e_f32 / s)
+
+
+@pytest.mark.parametrize("nimg,H0,W0,C", CASES + [(40, 96, 96, 256)])
+@pytest.mark.parametrize("relu,with_bias,xscale", [(True, True, 1.0), (False, False, 1.0), (True, True, 300.0), (True, False, 1e-3)])
+def test_fused_kernel_on_two_fp16_pieces_matches_fp64_like_the_fp32_form(dev, nimg, H0, W0, C, relu, with_bias, xscale):
+    """eqa_lift5_fft48k5_input_f16x2 (FORM 2 of csrc/lift_fft.hip: pixels and weights as two fp16 pieces, three exact products,
+    scaled by powers of two under eqa_absmax_slots' bound) against an fp64 evaluation at the fp32 form's tolerance, no further from
+    it than the fp32 form (x 1.5: both sit at a few fp32 ulps of the largest bin), the padding rows untouched, the DC slots equal to the
+    stored DC bins, at input scales 1e-3 .. 300."""
+    from equiadapt_amd import _lib
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(nimg * 1000 + H0 + C)
+    x = (torch.randn(nimg, 3, H0, W0, generator=g) * xscale).to(dev).contiguous(memory_format=torch.channels_last)
+    bank = (torch.randn(C, 3, 5, 5, generator=g) / 75 ** 0.5).to(dev).contiguous(memory_format=torch.channels_last)
+    bias = (torch.randn(C, generator=g) * xscale).to(dev) if with_bias else None
+    p_b = bias.data_ptr() if with_bias else None
+    M = nimg * fftconv.tiles(H0 - 4) * fftconv.tiles(W0 - 4)
+    pitch = lib.eqa_fft48k5_tile_pitch(M)
+    st = torch.cuda.current_stream().cuda_stream
+    lifted = fftconv.LiftedInput(x, bank, bias, relu)
+    wh, w_scale = lifted.pieces_f16()
+    assert wh.shape == (C, 2, 5, 4, 8) and wh.dtype == torch.float16 and wh.numel() * 2 == lib.eqa_lift5_pieces_f16_bytes(C)
+    assert (wh[:, :, :, 3] == 0).all() and (wh[..., 3] == 0).all() and (wh[..., 7] == 0).all() and (wh[:, :, :, 0, :4] == 0).all()
+    xb = torch.full((fftconv.DCMAX_SLOTS,), -1.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_absmax_slots(x.data_ptr(), x.numel(), xb.data_ptr(), st), "absmax")
+    assert xb.max().item() == x.abs().max().item() and (xb >= 0).all()
+    full = torch.full((fftconv.F, pitch, 2 * C), 7.0, dtype=torch.float32, device=dev)
+    slots = torch.full((fftconv.DCMAX_SLOTS,), -3.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_lift5_fft48k5_input_f16x2(x.data_ptr(), wh.data_ptr(), w_scale, xb.data_ptr(), fftconv.DCMAX_SLOTS, p_b, int(relu),
+                                                 full.data_ptr(), slots.data_ptr() if relu else None, nimg, H0, W0, C, st), "f16x2")
+    assert (full[:, M:] == 7.0).all()
+    ref = torch.full((fftconv.F, pitch, 2 * C), 7.0, dtype=torch.float32, device=dev)
+    _lib.check(lib.eqa_lift5_fft48k5_input(x.data_ptr(), bank.data_ptr(), p_b, int(relu), ref.data_ptr(), nimg, H0, W0, C, st), "f32")
+    y64 = F.conv2d(x.double(), bank.double(), bias.double() if with_bias else None)
+    y64 = torch.relu(y64) if relu else y64
+    want = _spectra_fp64(y64)
+    scale = want.abs().max().item()
+    e_h = (_unpack_V(full[:, :M], C) - want).abs().max().item()
+    e_f = (_unpack_V(ref[:, :M], C) - want).abs().max().item()
+    print(f"fused lift+fft f16x2 {(nimg, H0, W0, C)} relu={relu} x{xscale:g}: |f16x2 - fp64| {e_h / scale:.3e}, |f32 - fp64| {e_f / scale:.3e} (of max |V|)")
+    assert e_h <= 3e-6 * scale and e_h <= 1.5 * e_f + 1e-7 * scale, (e_h / scale, e_f / scale)
+    if relu:
+        assert slots.max().item() == full[48 * 23, :M].max().item() and full[:, :M].abs().max().item() <= slots.max().item()
+        assert lib.eqa_lift5_fft48k5_input_f16x2(x.data_ptr(), wh.data_ptr(), w_scale, xb.data_ptr(), 256, p_b, 0, full.data_ptr(), slots.data_ptr(),
+                                                 nimg, H0, W0, C, st) == -3
+    assert lib.eqa_lift5_fft48k5_input_f16x2(x.data_ptr(), wh.data_ptr(), 3.0, xb.data_ptr(), 256, p_b, int(relu), full.data_ptr(), None,
+                                             nimg, H0, W0, C, st) == -1        # the weights' scale must be a power of two

@@ -36,6 +36,7 @@ alg = {  # algorithmic bytes per launch, fp32
     # round 6: lifting convolution fused into the forward transform: the 96 x 96 x 3 input in (re-read by the 16 channel groups of a
     # tile out of L2), the spectra out -- the lifted map is never written
     "lift5_fft48_fused_kernel": B * 96 * 96 * 3 * 4 + 1154 * B * 4 * 512 * 4,
+    "lift5_fft48_fused_h2_kernel": B * 96 * 96 * 3 * 4 + 1154 * B * 4 * 512 * 4,      # the same kernel with its convolution on two fp16 pieces
 }
 res = {k: {"algorithmic_bytes_per_launch": v} for k, v in alg.items()}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -46,6 +46,15 @@ def main():
     def fused_p():
         _lib.check(lib.eqa_lift5_fft48k5_input_bf16x3(x.data_ptr(), wp.data_ptr(), bias.data_ptr(), 1, V.data_ptr(), B, S, S, C, st), "fused bf16x3")
 
+    wh, w_scale = LiftedInput(x, bank, bias, True).pieces_f16()
+    xb = torch.empty(256, dtype=torch.float32, device=dev)
+    dcm = torch.empty(256, dtype=torch.float32, device=dev)
+
+    def fused_h():
+        _lib.check(lib.eqa_absmax_slots(x.data_ptr(), x.numel(), xb.data_ptr(), st), "absmax")
+        _lib.check(lib.eqa_lift5_fft48k5_input_f16x2(x.data_ptr(), wh.data_ptr(), w_scale, xb.data_ptr(), 256, bias.data_ptr(), 1, V.data_ptr(),
+                                                     dcm.data_ptr(), B, S, S, C, st), "fused f16x2")
+
     def two():
         y = ops.lift_conv_grouped(x, wpk, bias, True, 5, 5)
         _lib.check(lib.eqa_fft48k5_input_grouped(y.data_ptr(), T.data_ptr(), V.data_ptr(), None, 0, B, H1, H1, C, st), "grouped")
@@ -53,7 +62,8 @@ def main():
     def lift_only():
         ops.lift_conv_grouped(x, wpk, bias, True, 5, 5)
 
-    for name, fn in (("fused eqa_lift5_fft48k5_input", fused), ("fused eqa_lift5_fft48k5_input_bf16x3", fused_p), ("lift_conv_grouped + fft48k5_input_grouped", two), ("lift_conv_grouped alone", lift_only)):
+    for name, fn in (("fused eqa_lift5_fft48k5_input", fused), ("fused eqa_lift5_fft48k5_input_bf16x3", fused_p),
+                     ("eqa_absmax_slots + fused eqa_lift5_fft48k5_input_f16x2", fused_h), ("lift_conv_grouped + fft48k5_input_grouped", two), ("lift_conv_grouped alone", lift_only)):
         for _ in range(3):
             fn()
         torch.cuda.synchronize()
@@ -63,11 +73,12 @@ def main():
             fn()
         e1.record()
         torch.cuda.synchronize()
-        print(f"{name:>44}: {e0.elapsed_time(e1) / a.reps:7.3f} ms per launch  (B = {B}, {C} channels, {S} x {S})")
+        print(f"{name:>56}: {e0.elapsed_time(e1) / a.reps:7.3f} ms per launch  (B = {B}, {C} channels, {S} x {S})")
     raw = ctypes.CDLL(_lib.SO_PATH)
     if hasattr(raw, "eqa_debug_lf_clock"):
         out = (ctypes.c_ulonglong * 32)()
-        (fused_p if os.environ.get("EQA_LIFT_FFT_FORM") == "bf16x3" else fused)()
+        form = os.environ.get("EQA_LIFT_FFT_FORM")
+        (fused_p if form == "bf16x3" else fused_h if form == "h2" else fused)()
         torch.cuda.synchronize()
         assert raw.eqa_debug_lf_clock(out) == 0
         names = ["stage + barrier 1", "prefetch issue", "role work", "barrier 2", "tail row passes", "barrier 3", "column read", "barrier 4"]
