@@ -23,8 +23,9 @@ for w in $what; do
       stats step 10 python bench.py --mode forward --steps 20 --warmup 10 --step-only
       python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only.json" 2>/dev/null
       stats bench 16 python bench.py --mode forward --steps 20 --warmup 3 --no-cpu-baseline
-      EQA_LIFT_FFT_FUSED=0 EQA_FFT_GEMM_PIECES=f32 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_round5_forms.json" 2>/dev/null
-      EQA_FFT_GEMM_PIECES=6 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_six_bf16_products.json" 2>/dev/null
+      EQA_LIFT_FFT_FUSED=0 EQA_LIFT_FFT_FORM=f32 EQA_FFT_GEMM_PIECES=f32 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_round5_forms.json" 2>/dev/null
+      EQA_LIFT_FFT_FORM=f32 EQA_FFT_GEMM_PIECES=6 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_six_bf16_products.json" 2>/dev/null
+      EQA_LIFT_FFT_FORM=f32 python bench.py --mode forward --steps 20 --warmup 10 --step-only > "$out/bench_step_only_fp32_lifting.json" 2>/dev/null
       ;;
     traffic)
       bash tools/collect_traffic.sh "$out/traffic_ga" > "$out/traffic_group_action.log" 2>&1 && cp "$out/traffic_ga/traffic.json" "$out/traffic_group_action.json"
@@ -34,7 +35,9 @@ for w in $what; do
     kbench)
       python tools/kbench.py --reps 60 > "$out/kbench.txt" 2>&1
       python tools/kbench_lift_fft.py > "$out/kbench_lift_fft.txt" 2>&1
-      [ -f build_variants/libeqa_lfclock.so ] && EQA_LIB=$PWD/build_variants/libeqa_lfclock.so python tools/kbench_lift_fft.py >> "$out/kbench_lift_fft.txt" 2>&1
+      [ -f build_variants/libeqa_lfclock.so ] && EQA_LIB=$PWD/build_variants/libeqa_lfclock.so EQA_LIFT_FFT_FORM=f32 python tools/kbench_lift_fft.py >> "$out/kbench_lift_fft.txt" 2>&1
+      [ -f build_variants/libeqa_lfclock.so ] && EQA_LIB=$PWD/build_variants/libeqa_lfclock.so EQA_LIFT_FFT_FORM=h2 python tools/kbench_lift_fft.py 2>&1 | tail -n 3 >> "$out/kbench_lift_fft.txt"
+      [ -x tools/micro/_bin/mfma16_chains ] && tools/micro/_bin/mfma16_chains > "$out/mfma16_chains.txt" 2>&1
       [ -x tools/micro/_bin/store_pattern ] && tools/micro/_bin/store_pattern > "$out/store_pattern.txt" 2>&1
       [ -x tools/micro/_bin/permlane_swap ] && tools/micro/_bin/permlane_swap > "$out/permlane_swap.txt" 2>&1
       python tools/kbench_gemm_error.py > "$out/kbench_gemm_error.txt" 2>&1
