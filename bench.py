@@ -989,7 +989,7 @@ def main():
             "kernels_ms": {"canon_transform": ms_ct, "invert_action": ms_iv},
             "ms_per_step_with_event_brackets": elapsed_kt / args.steps * 1e3,
             "step_ms_by_gemm_form": {**step_forms, "note": "the whole timed step with the complex GEMM as: h3 = fp16 matrix cores on TWO fp16 "
-                                     "pieces per fp32 operand (11 + 11 bits and a sign: within half an fp32 ulp), three exact products per "
+                                     "pieces per fp32 operand (11 + 11 bits and a sign: within one fp32 ulp), three exact products per "
                                      "product, fp32 accumulation, operands scaled by powers of two under the bound the fused lifting kernel "
                                      "hands over; 6 / 9 = bf16 matrix cores on exact three-piece splits with six / nine piece products; f32 = "
                                      "v_mfma_f32_32x32x2_f32.  `default` is what `value` ran (fftconv.gemm_form: h3 where the producer bounds "
@@ -1009,7 +1009,7 @@ def main():
         })
         if default_form == "h3":
             line["dtype"] = ("f32 (resampling / FFT / accumulation in fp32; the network's channel contraction as 2xfp16 split of every fp32 "
-                             "operand (within half an fp32 ulp), 3 exact products, fp32 accumulate -- closer to fp64 than the fp32 matrix "
+                             "operand (within one fp32 ulp), 3 exact products, fp32 accumulate -- closer to fp64 than the fp32 matrix "
                              "instruction, see step_ms_by_gemm_form)")
         elif default_form in ("6", "9"):
             line["dtype"] = (f"f32 (resampling / FFT / accumulation in fp32; the network's channel contraction as 3xbf16 exact split, "
@@ -1107,7 +1107,7 @@ def stage_table(ktimes, B):
         # fp16 form: every real product is 3 fp16 piece products -- the matrix-core flops, priced against the dense fp16 peak (= bf16's)
         gemm_spec = ("mfma_bf16", 3.0 * real_products,
                      "eqa_fft48k5_cgemm3m_f16x2: 1154 x [tiles x 256].[256 x 256] complex products, 3-multiplication form, every fp32 operand "
-                     "split into two fp16 pieces (within half an fp32 ulp), 3 piece products per real product on v_mfma_f32_32x32x16_f16, fp32 "
+                     "split into two fp16 pieces (within one fp32 ulp), 3 piece products per real product on v_mfma_f32_32x32x16_f16, fp32 "
                      "accumulate (hand-written)")
     elif form in ("6", "9"):
         # piece form: every real product is `form` bf16 piece products -- THOSE are the matrix-core flops, priced against the dense

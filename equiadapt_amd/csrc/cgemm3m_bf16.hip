@@ -369,7 +369,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // TERMS = 3: the fp16 form.  An fp32 operand x, scaled by a power of two into the top of the fp16 range, is split into TWO fp16
-// pieces h1 = rn(x), h2 = rn(x - h1): 11 + 11 significant bits and a sign -> |x - h1 - h2| <= 2^-24 |x|, half an fp32 ulp; the
+// pieces h1 = rn(x), h2 = rn(x - h1): 11 + 11 significant bits and a sign -> |x - h1 - h2| <= 2^-23 |x|, one fp32 ulp at worst (a third of one in rms); the
 // product x y is taken as h1 k1 + h1 k2 + h2 k1 (each exact in v_mfma_f32_32x32x16_f16, fp32 accumulate; h2 k2 <= 2^-22 |x y| is
 // left out).  Three matrix instructions per product instead of six, and -- fewer accumulator roundings -- CLOSER to an fp64
 // product than the six bf16 pieces or the fp32 instruction (tools/micro/f16x2_gemm_check.hip, profiles/r06/f16x2_gemm_check.txt:

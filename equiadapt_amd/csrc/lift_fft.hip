@@ -126,7 +126,7 @@ constexpr int kLpPlaneB = 8 * kLpRowB;           // 3,392 bytes
 constexpr int kLpPatchB = 3 * kLpPlaneB;         // 10,176 bytes
 constexpr int kLpLdsBytes = kLfTileFloats * 4 + kLpPatchB;   // 160,704 bytes
 // FORM 2 (round 6, third form): the convolution on TWO fp16 pieces per fp32 value, three exact products (h1 k1 + h1 k2 + h2 k1 on
-// v_mfma_f32_16x16x32_f16, fp32 accumulate: the contract of eqa_fft48k5_cgemm3m_f16x2 -- within half an fp32 ulp per operand; pixels
+// v_mfma_f32_16x16x32_f16, fp32 accumulate: the contract of eqa_fft48k5_cgemm3m_f16x2 -- within one fp32 ulp per operand; pixels
 // scaled by the power of two that takes a caller-supplied bound of |x| to 2^14, weights when they are split, the accumulators scaled
 // back in the epilogue).  Two planes of 8 bytes per pixel are the fp32 patch's bytes + a third, so a sub-phase is TWELVE tile rows (a
 // ring of 16 patch rows; four sub-phases per item, where the three bf16 planes allowed four rows and needed twelve), and twelve

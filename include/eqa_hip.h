@@ -535,7 +535,7 @@ int64_t eqa_fft48k5_spectra3m_bf16_bytes(int Cin, int Cout);
 int eqa_fft48k5_spectra3m_split(const float* B3, void* Bp, int Cin, int Cout, void* stream);
 int eqa_fft48k5_cgemm3m_bf16x3(const float* V, const void* Bp, float* Mo, int64_t M, int Cin, int Cout, int terms, void* stream);
 /* The same contraction on TWO fp16 pieces per fp32 operand (csrc/cgemm3m_bf16.hip, TERMS = 3): x = h1 + h2 + d with h1 = rn16(s x),
- * h2 = rn16(s x - h1), |d| <= 2^-24 |x| (s: a power of two that takes the operand's bound to 2^14); a product is h1 k1 + h1 k2 + h2 k1,
+ * h2 = rn16(s x - h1), |d| <= 2^-23 |x| (s: a power of two that takes the operand's bound to 2^14); a product is h1 k1 + h1 k2 + h2 k1,
  * each exact in v_mfma_f32_32x32x16_f16, fp32 accumulate -- three matrix instructions per product instead of six, and closer to an
  * fp64 product than the six-product bf16 form or the fp32 instruction (profiles/r06/f16x2_gemm_check.txt, kbench_gemm_error.txt).
  * The caller bounds the operands: vbound[0 .. nbound) (device memory, read by the kernel: no host synchronisation) holds numbers
@@ -585,7 +585,7 @@ int eqa_lift5_fft48k5_input(const float* x, const float* bank, const float* bias
 int eqa_lift5_fft48k5_input_dcmax(const float* x, const float* bank, const float* bias, int relu, float* V, float* dcmax, int nimg, int H0,
                                   int W0, int Cout, void* stream);
 /* The same kernel with its convolution on TWO fp16 pieces per fp32 value, three exact products on v_mfma_f32_16x16x32_f16 (the contract of
- * eqa_fft48k5_cgemm3m_f16x2: every operand within half an fp32 ulp, fp32 accumulation): fifteen matrix instructions of 16 cycles per
+ * eqa_fft48k5_cgemm3m_f16x2: every operand within one fp32 ulp, fp32 accumulation): fifteen matrix instructions of 16 cycles per
  * 16-pixel tile instead of 19 of 32 on the vector ALU's datapath, and a quarter of the LDS operand reads.
  *   wpieces  (Cout, 2 pieces, 5 filter rows, 4 chunks, 8) fp16 of w_scale * bank, eqa_lift5_pieces_f16_bytes(Cout) bytes: chunk p < 3 of
  *            filter row ky = [w(ci 0..2, kx = 2p - 1), 0, w(ci 0..2, kx = 2p), 0] (kx = -1: 0), chunk 3 = 0; w_scale a power of two with

@@ -441,3 +441,34 @@ def test_eight_concurrent_builders_on_a_stale_tree_leave_one_intact_library(tmp_
     assert live.name in left and dead.name not in left and stale.name not in left
     assert [n for n in left if ".o.tmp" in n] == [live.name]
     assert len([n for n in left if n.endswith(".o")]) == len(names)
+
+
+def test_gemm_form_rule_and_fp16_weight_pieces_on_the_host():
+    """Host logic of round 6's fp16 forms, no GPU: which contraction `fftconv.gemm_form` picks, and the operand `LiftedInput.pieces_f16`
+    builds for eqa_lift5_fft48k5_input_f16x2 -- layout (C, 2 pieces, 5 filter rows, 4 chunks, 8), zero slots, a power-of-two scale that
+    takes max |w| into [2^13, 2^14], and h1 + h2 within one fp32 ulp of the scaled weight."""
+    import math
+
+    import torch
+
+    from equiadapt_amd.images.canonicalization_networks import fftconv
+
+    if fftconv.GEMM_PIECES == "auto":
+        assert fftconv.gemm_form(256, 256) == "6" and fftconv.gemm_form(256, 256, True) == "h3"
+        assert fftconv.gemm_form(64, 128, True) == "h3" and fftconv.gemm_form(64, 128) == "f32"
+        assert fftconv.gemm_form(32, 128, True) == "f32" and fftconv.gemm_form(256, 64, True) == "f32" and fftconv.gemm_form(80, 128, True) == "f32"
+    torch.manual_seed(0)
+    bank = torch.randn(32, 3, 5, 5) * 0.37
+    x = torch.zeros(1, 3, 16, 16)
+    wh, scale = fftconv.LiftedInput(x, bank, None, True).pieces_f16()
+    assert wh.shape == (32, 2, 5, 4, 8) and wh.dtype == torch.float16
+    assert math.frexp(scale)[0] == 0.5 and 2.0 ** 13 <= bank.abs().max().item() * scale <= 2.0 ** 14
+    assert (wh[:, :, :, 3] == 0).all() and (wh[..., 3] == 0).all() and (wh[..., 7] == 0).all() and (wh[:, :, :, 0, :4] == 0).all()
+    # chunk p of filter row ky = [w(:, kx = 2p - 1), 0, w(:, kx = 2p), 0]
+    got = (wh[:, 0].double() + wh[:, 1].double()).reshape(32, 5, 8, 4)[:, :, 1:6, :3].permute(0, 3, 1, 2)      # (C, ci, ky, kx)
+    want = bank.double() * scale
+    # |x - h1 - h2| <= 2^-23 |x| element by element (one fp32 ulp at worst), a third of that in rms; + the fp16 subnormal step
+    err = (got - want).abs()
+    assert (err <= 2.0 ** -23 * want.abs() + 2.0 ** -24).all()
+    nz = want.abs() > 0
+    assert (err[nz] / want.abs()[nz]).pow(2).mean().sqrt().item() <= 0.5 * 2.0 ** -23

@@ -1,5 +1,5 @@
 // Can the channel contraction run on TWO fp16 pieces per fp32 operand instead of three bf16 ones?
-//   x = h1 + h2 + d,  h1 = rn16(x), h2 = rn16(x - h1): 11 + 11 significant bits and a sign -> |d| <= 2^-24 |x| (half an fp32 ulp)
+//   x = h1 + h2 + d,  h1 = rn16(x), h2 = rn16(x - h1): 11 + 11 significant bits and a sign -> |d| <= 2^-23 |x| (one fp32 ulp at worst, a third of one in rms)
 //   x y ~ h1 k1 + h1 k2 + h2 k1 [+ h2 k2]   (3 or 4 exact products on v_mfma_f32_32x32x16_f16, fp32 accumulate)
 // against the six bf16 piece products of csrc/cgemm3m_bf16.hip and the fp32 instruction, all measured as distance to an fp64 product:
 // one wave per 32 x 32 tile, K = 256, A ~ N(0, 1) * scale, B ~ N(0, 1) / (5 sqrt K) (tools/kbench_gemm_error.py's magnitudes).
