@@ -382,7 +382,7 @@ def conv5x5(x: torch.Tensor, B: torch.Tensor, bias: Optional[torch.Tensor], relu
             assert in_bias is None and not in_relu
             with _timed("lift_fft_input"):
                 p_b = x.bias.data_ptr() if x.bias is not None else None
-                if LIFT_FFT_FORM == "h2":
+                if LIFT_FFT_FORM == "h2" and x.x.data_ptr() % 16 == 0:      # (eqa_absmax_slots reads 16 bytes per lane)
                     wh, w_scale = x.pieces_f16()
                     xbound = torch.empty(DCMAX_SLOTS, dtype=torch.float32, device=dev)
                     _lib.check(lib.eqa_absmax_slots(x.x.data_ptr(), x.x.numel(), xbound.data_ptr(), st), "eqa_absmax_slots")
