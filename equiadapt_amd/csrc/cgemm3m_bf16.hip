@@ -416,6 +416,11 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 (&o)[3]) {
 // two fp16 pieces of four (already scaled) values: v_cvt_pk_f16_f32 (round to nearest even), the remainder, again
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split4h(const f32x4 v, u32x2 (&o)[2]) {
+#ifdef EQA_BLK_NOSPLIT       // ablation: no split arithmetic (wrong values)
+  o[0][0] = __builtin_bit_cast(unsigned, v[0]) & 0x3fff3fffu; o[0][1] = __builtin_bit_cast(unsigned, v[1]) & 0x3fff3fffu;
+  o[1][0] = __builtin_bit_cast(unsigned, v[2]) & 0x3fff3fffu; o[1][1] = __builtin_bit_cast(unsigned, v[3]) & 0x3fff3fffu;
+  return;
+#endif
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const float a = v[2 * j], b = v[2 * j + 1];
@@ -448,6 +453,9 @@ __device__ __forceinline__ void load_bset(BSet<NP>& o, const TileAt& t, unsigned
 }
 template <int NP, int M, int PA>
 __device__ __forceinline__ void read_frags(AFrags& o, const unsigned char* rd) {
+#ifdef EQA_BLK_NOLDSREAD     // ablation: the fragments of (row quarter 0, piece 0) stand for every one (wrong values)
+  if (M != 0 || PA != 0) return;
+#endif
 #pragma unroll
   for (int p = 0; p < 3; ++p) o.a[p] = *reinterpret_cast<const u32x4*>(rd + ((M * 3 + p) * NP + PA) * kFragBytes);
 }
