@@ -540,46 +540,41 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
       // accumulators of two rows: a row's epilogue (scale, bias, relu, LDS write) sits BEHIND the next row's matrix instructions in
       // program order, so that it issues under them -- directly behind its own row it waited out the pipe's latency first, and the
       // wave issues in order: 39 cycles per matrix instruction instead of 16
-      // accumulators of two rows (three chains each: one per piece product): a row's epilogue runs a row later, in pieces between
-      // the next row's matrix instructions
-      f32x4 a_ll[2], a_hl[2], a_hh[2];          // (w lo, p hi), (w hi, p lo), (w hi, p hi)
+      // ONE accumulator chain per row (tools/micro/mfma16_chains.hip: dependent v_mfma_f32_16x16x32_f16 issue every 21.7 counter cycles,
+      // two chains 22.8, THREE 28.7, four or six 22.3 -- the three chains "one per piece product" of the first builds were the worst
+      // choice); two rows' accumulators, so that a row's epilogue runs a row later, in pieces between the next row's instructions.
+      // Per filter row the small products come first: (w lo, p hi), (w hi, p lo), then (w hi, p hi).
+      f32x4 acc[2];
       f32x4 ev = zero;
-      // piece m of the epilogue of row rp: sum small terms first, scale, bias, relu, mask, write
+      // piece m of the epilogue of row rp: scale, bias, relu, mask, write
       auto epi = [&](int m, int rp) {
         const int y = y0 + rp;
-        if (m == 0) ev = a_ll[rp & 1] + a_hl[rp & 1];
-        else if (m == 1) ev = ev + a_hh[rp & 1];
-        else if (m == 2) ev = ev * out_scale + bias4;
-        else if (m == 3) { ev[0] = relu ? fmaxf(ev[0], 0.0f) : ev[0]; ev[1] = relu ? fmaxf(ev[1], 0.0f) : ev[1]; }
-        else if (m == 4) { ev[2] = relu ? fmaxf(ev[2], 0.0f) : ev[2]; ev[3] = relu ? fmaxf(ev[3], 0.0f) : ev[3]; }
-        else if (m == 5) {
+        if (m == 0) ev = acc[rp & 1] * out_scale + bias4;
+        else if (m == 1) { ev[0] = relu ? fmaxf(ev[0], 0.0f) : ev[0]; ev[1] = relu ? fmaxf(ev[1], 0.0f) : ev[1]; }
+        else if (m == 2) { ev[2] = relu ? fmaxf(ev[2], 0.0f) : ev[2]; ev[3] = relu ? fmaxf(ev[3], 0.0f) : ev[3]; }
+        else if (m == 3) {
           const bool ok = col_ok && it.gy0 + y < H1;
 #pragma unroll
           for (int k = 0; k < 4; ++k) ev[k] = ok ? ev[k] : 0.0f;
-        } else if (m == 6) {
+        } else if (m == 4) {
           *reinterpret_cast<f32x4*>(tile + y * kLfRowPitch + q * kLfQuadPitch + (t * 16 + j) * 4) = ev;
         }
       };
-      // The wave issues in order and the pipe takes a matrix instruction every 16 cycles, 4 of which are the issue: what stands
-      // BETWEEN two matrix instructions is free (three vector instructions' worth), what stands behind a block of them is not.  So
-      // every instruction of a row is followed by one piece of the PREVIOUS row's epilogue (or the reads of the row two ahead),
-      // pinned by scheduling barriers.
+      // The wave issues in order: what stands BETWEEN two matrix instructions is free, what stands behind a block of them is not.
 #pragma unroll
       for (int r = 0; r < NROWS; ++r) {
 #pragma unroll
         for (int m = 0; m < 15; ++m) {
           const int ky = m / 3, ch = m % 3;
           __builtin_amdgcn_sched_barrier(0);
-          if (ch == 0) a_ll[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][1], win[(r + ky) % 7][0], ky == 0 ? zero : a_ll[r & 1], 0, 0, 0);
-          else if (ch == 1) a_hl[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][0], win[(r + ky) % 7][1], ky == 0 ? zero : a_hl[r & 1], 0, 0, 0);
-          else a_hh[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][0], win[(r + ky) % 7][0], ky == 0 ? zero : a_hh[r & 1], 0, 0, 0);
-          if (r > 0 && m >= 3 && m < 10) epi(m - 3, r - 1);       // (behind the first filter row: the previous row's last results have left the pipe)
-          if (m == 11 && r + 2 < NROWS) read_row(r + 6);
+          acc[r & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ky][ch == 0 ? 1 : 0], win[(r + ky) % 7][ch == 1 ? 1 : 0], m == 0 ? zero : acc[r & 1], 0, 0, 0);
+          if (r > 0 && m >= 2 && m < 7) epi(m - 2, r - 1);
+          if (m == 9 && r + 2 < NROWS) read_row(r + 6);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int m = 0; m < 7; ++m) epi(m, NROWS - 1);
+      for (int m = 0; m < 5; ++m) epi(m, NROWS - 1);
     }
   };
 
