@@ -493,7 +493,7 @@ __device__ __forceinline__ void lift5_fft48_body(const float* __restrict__ x, co
   // does not depend on ky: a wave works DOWN one tile column, holds a window of five patch rows in registers and reads ONE new row
   // (two 16-byte fragments) per tile row -- 2 KB of LDS reads per tile where the row-major order with its 4 K-steps per tile read 8
   // (the first build of this form: 33 k cycles per item in the convolution waves, on LDS bandwidth).  15 matrix instructions per
-  // tile, in three independent chains (one per piece product) summed small terms first.
+  // tile in ONE accumulator chain (per filter row the small products first).
   lf_f16x8 wh[H2 ? 5 : 1][H2 ? 2 : 1];
   int h_off = 0;
   auto setup_h = [&](const LfItem& it) {
